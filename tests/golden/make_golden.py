@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference); the GPU box never executes
+this script -- it consumes the .npz files this script wrote.  Nothing of the reference's
+source text is stored: only inputs and the outputs the reference computed for them.
+
+What is executed from the reference:
+  * the model:  src/model_training/model/yolo_fastest.py  (class YoloFastest, imported),
+    with the shipped checkpoints models/pytorch/{256x320,512x640}/*.pth;
+  * the post-process: class YOLO_post_process of src/detect.py:14-84, obtained by AST
+    extraction (detect.py itself cannot be imported: `import cv2` at :2 and
+    model_training.train at :10 need packages this image lacks) and exec'd with the
+    module-level global `device` it reads at :44 injected;
+  * the 15 glue lines of Detect_YOLO.batch_detect (src/detect.py:157-169: bucket by class,
+    stable sort by conf descending, NMS per class, concatenate in class order) and
+    __adjust_coord (:131-139) are methods of a class that needs cv2, so they are restated
+    here around calls into the extracted class.
+
+Image decode caveat: cv2 is absent, so the 20 JPEGs of test_data/ (mode L, 640x512) are
+decoded with PIL; for the 256x320 model the 2x downscale uses the 2x2 box mean
+(a+b+c+d+2)>>2 that OpenCV's INTER_LINEAR takes at an exact 2x ratio.  Goldens therefore
+START at the pre-processed u8 tensor, which is stored.
+"""
+import ast
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REF, "src"))
+
+from model_training.model.yolo_fastest import YoloFastest  # noqa: E402  (the reference)
+from model_training._config import config_params  # noqa: E402
+
+
+def extract_post_process():
+    src = open(os.path.join(REF, "src", "detect.py"), encoding="utf-8").read()
+    tree = ast.parse(src)
+    node = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "YOLO_post_process"][0]
+    ns = {"math": math, "np": np, "device": "cpu"}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), "detect.py<YOLO_post_process>", "exec"), ns)
+    return ns["YOLO_post_process"]
+
+
+YOLO_post_process = extract_post_process()
+
+
+def io_params_for(res):
+    io = dict(config_params["io_params"])
+    if res == 512:  # _config.py:9 -- 512x640 uses anchor groups 1..2, no resize
+        io["input_shape"] = [512, 640, 1]
+        io["anchors"] = io["anchors"][1:]
+    return io
+
+
+def load_model(res):
+    path = {256: "models/pytorch/256x320/YOLO-Fastest_epoch_28.pth",
+            512: "models/pytorch/512x640/YOLO-Fastest_epoch_27.pth"}[res]
+    io = io_params_for(res)
+    m = YoloFastest(io).eval()
+    msg = m.load_state_dict(torch.load(os.path.join(REF, path), map_location="cpu"))
+    assert str(msg) == "<All keys matched successfully>"
+    return m, io
+
+
+def preprocess_u8(path, res):
+    from PIL import Image
+    a = np.asarray(Image.open(path))
+    assert a.shape == (512, 640) and a.dtype == np.uint8
+    if res == 256:
+        a = a.astype(np.uint16)
+        a = ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    return np.ascontiguousarray(a)
+
+
+def to_input(u8):
+    x = torch.from_numpy(u8.astype(np.float32))
+    x = (x - 128.0) / 255.0  # detect.py:124
+    while x.dim() < 4:
+        x = x.unsqueeze(0)
+    return x
+
+
+def src_indices(pred, conf_thres):
+    """Flat (head, anchor, i, j) index of every candidate, in the reference's decode order
+    (detect.py:54-58): the same Python-double sigmoid and strict > as the reference."""
+    out, base = [], 0
+    for ph in pred:
+        a = ph.numpy()[0]
+        h, w = a.shape[1], a.shape[2]
+        a = a.reshape(3, 8, h, w)
+        for pp in range(3):
+            for i in range(h):
+                for j in range(w):
+                    if 1. / (1. + math.exp(-a[pp, 4, i, j])) > conf_thres:
+                        out.append(base + (pp * h + i) * w + j)
+        base += 3 * h * w
+    return out
+
+
+def reference_post(pred, io, adjust):
+    """detect.py:157-169 (+ :181-182) around the extracted reference class."""
+    pp = YOLO_post_process(conf_thres=io["conf_thre"], nms_thres=io["nms_thre"], num_anchors=io["num_anchors"],
+                           num_class=io["num_cls"], anchors=io["anchors"], input_shape=io["input_shape"])
+    cands = pp.decode_box(pred)
+    srcs = src_indices(pred, io["conf_thre"])
+    assert len(srcs) == len(cands)
+    for c, s in zip(cands, srcs):
+        c.append(s)  # rides along; the reference only touches [0..6]
+    cand_copy = [list(c) for c in cands]
+    buckets = [[] for _ in range(io["num_cls"])]
+    for b in cands:
+        buckets[b[6]].append(b)
+    final = []
+    for cls in range(io["num_cls"]):
+        if not buckets[cls]:
+            continue
+        buckets[cls].sort(key=lambda it: it[4], reverse=True)
+        final.extend(pp.non_maxium_supression(buckets[cls]))
+    final = [list(f) for f in final]
+    adj = [list(f) for f in final]
+    if adjust:
+        sh = io["origin_img_shape"][0] / io["input_shape"][0]
+        sw = io["origin_img_shape"][1] / io["input_shape"][1]
+        for f in adj:
+            f[0] = round(f[0] * sw); f[2] = round(f[2] * sw)
+            f[1] = round(f[1] * sh); f[3] = round(f[3] * sh)
+    return cand_copy, final, adj
+
+
+def pack_lists(lists, kmax):
+    n = len(lists)
+    box = np.zeros((n, kmax, 4), np.int32)
+    conf = np.zeros((n, kmax), np.float64)
+    score = np.zeros((n, kmax), np.float64)
+    cls = np.full((n, kmax), -1, np.int32)
+    src = np.full((n, kmax), -1, np.int32)
+    cnt = np.zeros((n,), np.int32)
+    for f, L in enumerate(lists):
+        assert len(L) <= kmax, (len(L), kmax)
+        cnt[f] = len(L)
+        for k, e in enumerate(L):
+            box[f, k] = e[0:4]; conf[f, k] = e[4]; score[f, k] = e[5]; cls[f, k] = int(e[6]); src[f, k] = e[7]
+    return dict(box=box, conf=conf, score=score, cls=cls, src=src, count=cnt)
+
+
+def synthetic_heads(seed, hl, wl):
+    """SURVEY.md 8(d) config 5 recipe: dense candidates."""
+    g = np.random.default_rng(seed)
+    outs = []
+    for (h, w) in ((hl, wl), (hl // 2, wl // 2)):
+        t = np.empty((3, 8, h, w), np.float32)
+        t[:, 0:2] = g.normal(0.0, 1.0, (3, 2, h, w))
+        t[:, 2:4] = g.normal(0.0, 0.5, (3, 2, h, w))
+        t[:, 4] = g.normal(-1.0, 1.5, (3, h, w))
+        t[:, 5:8] = g.normal(0.0, 2.0, (3, 3, h, w))
+        outs.append(torch.from_numpy(t.reshape(1, 24, h, w)))
+    return outs
+
+
+PROBES = ["conv0", "conv1_4", "res1_1", "conv1_9", "conv2_1", "res2_2", "conv2_3", "conv3_1", "res3_2", "conv3_4",
+          "res3_3", "res3_6", "conv3_6", "conv4_1", "res4_4", "conv4_2", "conv4_3", "conv5_1", "res5_5", "conv5_2",
+          "conv5_3", "conv5_6", "deconv5_1", "conv4_1_1", "conv4_1_5"]
+
+
+def main():
+    files = sorted(os.listdir(os.path.join(REF, "test_data")))
+    assert len(files) == 20
+    torch.manual_seed(0)
+    for res in (256, 512):
+        model, io = load_model(res)
+        names = files if res == 256 else [files[i] for i in (0, 3, 7, 11, 14, 19)]  # 14 = noCloud_2m_4359 (no targets)
+        u8 = np.stack([preprocess_u8(os.path.join(REF, "test_data", f), res) for f in names])
+        hl_all, hs_all, cands, finals, adjs = [], [], [], [], []
+        with torch.no_grad():
+            for k in range(len(names)):
+                pred = model(to_input(u8[k]))
+                hl_all.append(pred[0].numpy()[0]); hs_all.append(pred[1].numpy()[0])
+                c, f, a = reference_post(pred, io, adjust=(res == 256))
+                cands.append(c); finals.append(f); adjs.append(a)
+        out = dict(names=np.array(names), input_u8=u8, head_large=np.stack(hl_all), head_small=np.stack(hs_all),
+                   anchors=np.array(io["anchors"][:2], np.float64), input_shape=np.array(io["input_shape"][:2]))
+        for tag, L in (("cand", cands), ("final", finals), ("adj", adjs)):
+            for k, v in pack_lists(L, 16).items():
+                out[f"{tag}_{k}"] = v
+        print(res, "has-target flags:", [int(len(f) > 0) for f in finals], "cands", [len(c) for c in cands])
+
+        # random-normal and uniform-u8 synthetic inputs through the real weights (heads only)
+        g = np.random.default_rng(123 + res)
+        n_syn = 4 if res == 256 else 2
+        syn_u8 = g.integers(0, 256, size=(n_syn, res, res * 5 // 4), dtype=np.uint8)
+        with torch.no_grad():
+            p = model(to_input(syn_u8).reshape(n_syn, 1, res, res * 5 // 4))
+        out["syn_input_u8"] = syn_u8
+        out["syn_head_large"] = p[0].numpy(); out["syn_head_small"] = p[1].numpy()
+
+        # per-layer probes on image 1 (NCHW fp32, as the reference module produces them)
+        acts = {}
+        hooks = [getattr(model, nm).register_forward_hook(
+            lambda m, i, o, nm=nm: acts.__setitem__(nm, o.detach().numpy()[0].copy())) for nm in PROBES]
+        with torch.no_grad():
+            model(to_input(u8[1]))
+        for h in hooks:
+            h.remove()
+        if res == 256:
+            for nm in PROBES:
+                out["probe_" + nm] = acts[nm]
+        np.savez_compressed(os.path.join(HERE, f"golden_{res}.npz"), **out)
+
+        # dense synthetic heads -> reference decode + NMS (with source indices)
+        hl, wl = res // 16, res * 5 // 4 // 16
+        d = {}
+        cands, finals, heads_l, heads_s = [], [], [], []
+        for seed in range(4):
+            pred = synthetic_heads(seed, hl, wl)
+            c, f, _ = reference_post(pred, io, adjust=False)
+            cands.append(c); finals.append(f)
+            heads_l.append(pred[0].numpy()[0]); heads_s.append(pred[1].numpy()[0])
+        kmax = max(len(c) for c in cands)
+        d["head_large"] = np.stack(heads_l); d["head_small"] = np.stack(heads_s)
+        d["anchors"] = np.array(io["anchors"][:2], np.float64); d["input_shape"] = np.array(io["input_shape"][:2])
+        for tag, L in (("cand", cands), ("final", finals)):
+            for k, v in pack_lists(L, kmax).items():
+                d[f"{tag}_{k}"] = v
+        print(res, "dense: cands", [len(c) for c in cands], "survivors", [len(f) for f in finals])
+        np.savez_compressed(os.path.join(HERE, f"golden_dense_{res}.npz"), **d)
+
+
+if __name__ == "__main__":
+    main()
