@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path (model forward -> decode -> per-class NMS [-> all-gather of the decoded
+boxes when N > 1]) over one batch of synthetic frames that is already resident in HBM.
+Workload at N = 1: BASELINE.json configs[1], "YOLO-Fastest 320x256 batch=256 fp32, synthetic frames"
+(u8 ~ Uniform{0..255} i.i.d., x = (u8-128)/255, seed = rank).  N > 1: the same per GPU (weak
+scaling, frames are independent units; one RCCL all-gather of the fixed-capacity box records).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_FRAME = {256: 42_575_360, 512: 170_301_440}   # layer-granular algorithmic bytes, fp32
+FLOPS_PER_FRAME = {256: 236_442_880, 512: 945_771_520}
+HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(seconds=12.0):
+    """The oracle (CPU restatement of the reference's detect.py path; kind "port") timed on this host:
+    batch 1 over the 20 bundled frames, model and post-process like detect.py:151-171, repeated for ~`seconds`."""
+    import numpy as np
+    import torch
+    from oracle import backbone_oracle as bo
+    from oracle import post_oracle as po
+    import yolo_fastest_amd as yf
+    io = yf.io_params_for(256)
+    sd = bo.load_state_dict(os.path.join(ROOT, "yolo-fastest-and-embedded-deployment_amd", "assets", "weights",
+                                         "yolo_fastest_256x320_epoch28.pth"))
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_256.npz"))
+    xs = [bo.preprocess(g["input_u8"][i]) for i in range(20)]
+    bo.forward(sd, xs[0])  # warm-up
+    n, t_model, t_post = 0, 0.0, 0.0
+    t_end = time.time() + seconds
+    while time.time() < t_end:
+        for x in xs:
+            t0 = time.time()
+            hl, hs = bo.forward(sd, x)
+            t1 = time.time()
+            po.post_process((hl.numpy()[0], hs.numpy()[0]), io["anchors"], io["input_shape"][:2])
+            t2 = time.time()
+            t_model += t1 - t0; t_post += t2 - t1; n += 1
+    return {"value": round(n / (t_model + t_post), 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} frames = the 20 bundled test_data frames at 320x256, batch 1, repeated ~{seconds:.0f} s; "
+                      f"model {1e3 * t_model / n:.2f} ms + post {1e3 * t_post / n:.2f} ms per frame; "
+                      f"host has {os.cpu_count()} logical CPUs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--res", type=int, default=256, choices=[256, 512])
+    ap.add_argument("--chunk", type=int, default=0, help="frames per pass of the layer chain (0 = whole batch)")
+    ap.add_argument("--kmax", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import yolo_fastest_amd as yf
+    from yolo_fastest_amd import dist as yfd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP extension is the only implementation (no CPU fallback)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+
+    io = yf.io_params_for(args.res)
+    wname = {256: "yolo_fastest_256x320_epoch28.pth", 512: "yolo_fastest_512x640_epoch27.pth"}[args.res]
+    model = yf.YoloFastest(io).to(dev).eval()
+    model.chunk = args.chunk
+    model.load_state_dict(torch.load(os.path.join(ROOT, "yolo-fastest-and-embedded-deployment_amd", "assets",
+                                                  "weights", wname), map_location=dev))
+    post = yf.YOLO_post_process(io["conf_thre"], io["nms_thre"], io["num_anchors"], io["num_cls"], io["anchors"],
+                                io["input_shape"]).bind(model)
+    H, W = io["input_shape"][:2]
+    g = torch.Generator(device="cpu").manual_seed(rank)
+    u8 = torch.randint(0, 256, (args.batch, H, W), generator=g, dtype=torch.uint8)
+    x = ((u8.float() - 128.0) / 255.0)[:, None].contiguous().to(dev)   # resident in HBM before timing
+    n_total = args.batch * world
+
+    def step():
+        with torch.no_grad():
+            pred = model(x)
+        raw = post.detect_raw(pred, kmax=args.kmax)
+        if world > 1:
+            raw = yfd.all_gather_detections(raw, n_total)
+        return raw
+
+    for _ in range(args.warmup):
+        raw = step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    # HIP events on the stream the kernels are launched on (torch's current stream is the one handed to the C ABI)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        with torch.no_grad():
+            pred = model(x)
+        ev[k][1].record()
+        raw = post.detect_raw(pred, kmax=args.kmax)
+        ev[k][2].record()
+        if world > 1:
+            raw = yfd.all_gather_detections(raw, n_total)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
+    post_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+
+    if rank == 0:
+        counts = raw["counts"].cpu().numpy()
+        fps = n_total * args.steps / elapsed
+        achieved = args.batch * BYTES_PER_FRAME[args.res] / (fwd_ms * 1e-3) / 1e9
+        e = model.engine(H, W, args.batch, dev)
+        import ctypes
+        nl = ctypes.c_int()
+        e.lib.yf_num_launches(e.handle, ctypes.byref(nl))
+        out = {
+            "metric": "frames/sec end-to-end (model forward + decode + per-class NMS), 320x256 batch=256 per GPU"
+                      if args.res == 256 else "frames/sec end-to-end, 640x512",
+            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "ms_per_frame": round(1e3 * elapsed / args.steps / n_total, 6),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"YOLO-Fastest {W}x{H} batch={args.batch} fp32 per GPU, synthetic uniform-u8 frames "
+                                   f"(BASELINE.json configs[1])" if args.res == 256 and args.batch == 256 else
+                                   f"YOLO-Fastest {W}x{H} batch={args.batch} fp32 per GPU, synthetic frames",
+                       "global_batch": n_total, "weights": wname, "kmax": args.kmax, "chunk": args.chunk,
+                       "parallelism": f"dp{world} (frames sharded, one RCCL all-gather of box records)" if world > 1 else "single GPU",
+                       "survivors_per_frame_mean": round(float(np.clip(counts, 0, None).mean()), 3)},
+            "roofline": {"bound": "hbm", "kernel": f"yf_forward layer chain ({nl.value} launches/chunk)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_frame": BYTES_PER_FRAME[args.res],
+                         "forward_ms": round(fwd_ms, 4), "post_ms": round(post_ms, 4),
+                         "compute_frac_fp32_vector_peak": round(args.batch * FLOPS_PER_FRAME[args.res] / (fwd_ms * 1e-3) / 157.3e12, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,125 @@
+/* yolo_fastest_hip.h -- C ABI of libyolo_fastest_hip.so (MI355X / gfx950).
+ *
+ * The reference (JunFenngZhi/YOLO-Fastest-and-Embedded-deployment) has no FFI for its inference
+ * path: the boundary is its Python surface.  Each entry point below replaces the body of one
+ * Python-level call of the reference; the Python host code in
+ * yolo-fastest-and-embedded-deployment_amd/ keeps the reference's names and argument meaning and
+ * binds these symbols with ctypes (INTEGRATION.md shows the stub).
+ *
+ *   reference interface (file:line under the reference repo)            entry point
+ *   ------------------------------------------------------------------  -------------------
+ *   YoloFastest(io_params).to(dev).eval() + load_state_dict(torch.load) yf_create
+ *       src/model_training/model/yolo_fastest.py:70-148, src/detect.py:89-91
+ *   model(img) -> (head_large, head_small)                               yf_forward
+ *       src/model_training/model/yolo_fastest.py:150-218, src/detect.py:152
+ *   YOLO_post_process.decode_box + class bucketing + sort + NMS          yf_decode_nms
+ *       src/detect.py:41-84, :157-169   (+ __adjust_coord :131-139 when origin_* given)
+ *   YOLO_post_process.non_maxium_supression(sorted_list)                 yf_nms_sorted
+ *       src/detect.py:69-84
+ *   Detect_YOLO.batch_detect's timed region (model + post-process)       yf_detect
+ *       src/detect.py:151-171
+ *   Detect_YOLO.__pre_process's arithmetic ((u8-128)/255, 2x2 area mean) yf_preprocess_u8
+ *       src/detect.py:107-129
+ *
+ * Conventions: plain pointers and sizes only.  Every pointer named d_* is DEVICE memory owned by the
+ * caller (a torch tensor's data_ptr()); `stream` is a hipStream_t passed as void*.  All launches are
+ * stream-ordered and asynchronous; nothing here synchronises the device except yf_create /
+ * yf_destroy.  Return value: 0 = ok, negative = error (see YF_E_*); yf_last_error_string() gives
+ * the message of the calling thread's last failure.  A handle is bound to one device and is not
+ * thread-safe (one handle per device per thread, as the reference's caller is single-threaded).
+ */
+#ifndef YOLO_FASTEST_HIP_H
+#define YOLO_FASTEST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct yf_engine *yf_handle;
+
+enum {
+    YF_OK = 0,
+    YF_E_INVALID = -1,   /* bad argument (shape not multiple of 32, N > max_batch, null pointer, ...) */
+    YF_E_BLOB = -2,      /* packed-weights blob does not describe YoloFastest (strict layout check)  */
+    YF_E_HIP = -3,       /* a HIP runtime call failed                                                */
+    YF_E_WORKSPACE = -4, /* caller's workspace too small                                             */
+    YF_E_NOPROBE = -5    /* yf_forward_probe: tensor of that name never exists in device memory      */
+};
+
+/* ABI version of this header; yf_abi_version() must return the same number. */
+#define YF_ABI_VERSION 1
+int yf_abi_version(void);
+
+/* Thread-local message of the last failing call ("" if none). */
+const char *yf_last_error_string(void);
+
+/* Build an engine for net-input size H x W (rows x cols, multiples of 32) from a packed-weights blob
+ * (host memory; format: yolo-fastest-and-embedded-deployment_amd/packer.py -- BN-folded fp32, NHWC-friendly
+ * layouts, self-describing layer table that is checked strictly against the YoloFastest graph).
+ * The engine owns a device copy of the weights and nothing else. */
+int yf_create(const void *packed_weights, size_t nbytes, int H, int W, int max_batch, int device, yf_handle *out);
+int yf_destroy(yf_handle h);
+
+/* Bytes of device scratch yf_forward / yf_detect need for a batch of N frames. */
+int yf_workspace_bytes(yf_handle h, int N, size_t *out);
+
+/* model(x): d_x float32 [N,1,H,W] contiguous, values (u8-128)/255.
+ * d_head_large float32 [N,24,H/16,W/16], d_head_small float32 [N,24,H/32,W/32], NCHW like the reference. */
+int yf_forward(yf_handle h, const float *d_x, int N, float *d_head_large, float *d_head_small,
+               void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Test hook: run the forward pass and copy the named intermediate activation (the output of the
+ * reference module attribute `name`, e.g. "conv1_9", "res3_3"), converted to NCHW float32
+ * [N,C,h,w], into d_dst.  Returns YF_E_NOPROBE for tensors that a fused kernel keeps on chip. */
+int yf_forward_probe(yf_handle h, const float *d_x, int N, const char *name, float *d_dst, size_t dst_bytes,
+                     void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Post-process of N frames (the reference handles batch element 0 only, detect.py:46; frame f here is
+ * exactly what the reference computes for pred[f:f+1]).
+ *   anchors: HOST double[2][3][2] = io_params["anchors"][head][anchor][w,h] in net-input pixels.
+ *   conf_thres / nms_thres: strict '>' as in detect.py:58,79.
+ *   origin_h/origin_w: if both > 0 and different from H/W, corners are rescaled and re-rounded as
+ *       __adjust_coord does (detect.py:131-139); pass 0,0 to keep net-input coordinates.
+ * Outputs (device), fixed capacity K_max per frame, survivors in the reference's order
+ * (class-major; within a class conf descending, ties in decode order):
+ *   d_boxes   int32 [N,K_max,4]  x1,y1,x2,y2
+ *   d_scores  float [N,K_max,2]  conf, cls_score  (computed in fp64, stored fp32)
+ *   d_cls     int32 [N,K_max]
+ *   d_src     int32 [N,K_max]    flat index over (head, anchor, row, col) of the surviving cell
+ *   d_counts  int32 [N]          survivors of frame f; if more than K_max survive the first K_max are
+ *                                stored and the count is the TRUE number (caller detects overflow);
+ *                                -2 = the reference would raise ZeroDivisionError (two zero-area boxes
+ *                                compared, detect.py:39)
+ */
+int yf_decode_nms(yf_handle h, const float *d_head_large, const float *d_head_small, int N, double conf_thres,
+                  double nms_thres, const double *anchors, int origin_h, int origin_w, int K_max, int32_t *d_boxes,
+                  float *d_scores, int32_t *d_cls, int32_t *d_src, int32_t *d_counts, void *stream);
+
+/* YOLO_post_process.non_maxium_supression (detect.py:69-84) on its own: d_boxes int32 [n,4] is ONE class's
+ * list already sorted by conf descending.  d_suppressor int32 [n] receives -1 for a kept box, else the index
+ * of the kept box that removed it (-2 in every entry: the reference's ZeroDivisionError). */
+int yf_nms_sorted(yf_handle h, const int32_t *d_boxes, int n, double nms_thres, int32_t *d_suppressor, void *stream);
+
+/* yf_forward + yf_decode_nms back to back on one stream (heads also returned; may be NULL to use
+ * workspace-internal buffers). */
+int yf_detect(yf_handle h, const float *d_x, int N, double conf_thres, double nms_thres, const double *anchors,
+              int origin_h, int origin_w, int K_max, int32_t *d_boxes, float *d_scores, int32_t *d_cls,
+              int32_t *d_src, int32_t *d_counts, float *d_head_large, float *d_head_small, void *d_workspace,
+              size_t workspace_bytes, void *stream);
+
+/* Detect_YOLO.__pre_process arithmetic on device: d_u8 uint8 [N,src_h,src_w] gray frames ->
+ * d_x float32 [N,1,H,W] = (v-128)/255 where v is the pixel itself (src == net size) or the 2x2
+ * box mean (a+b+c+d+2)>>2 (src == 2x net size).  Other ratios: YF_E_INVALID. */
+int yf_preprocess_u8(yf_handle h, const uint8_t *d_u8, int N, int src_h, int src_w, float *d_x, void *stream);
+
+/* Introspection used by tests / bench. */
+int yf_num_launches(yf_handle h, int *out);       /* kernel launches one yf_forward issues            */
+int yf_set_chunk(yf_handle h, int frames);        /* frames per pass of the layer chain (0 = whole batch) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

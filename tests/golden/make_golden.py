@@ -184,7 +184,14 @@ def main():
                 hl_all.append(pred[0].numpy()[0]); hs_all.append(pred[1].numpy()[0])
                 c, f, a = reference_post(pred, io, adjust=(res == 256))
                 cands.append(c); finals.append(f); adjs.append(a)
+        # the reference module evaluated in fp64 (model.double()): "exact arithmetic" yardstick that tells how far
+        # the reference's own fp32 result is from the real-number result of its graph
+        import copy
+        m64 = copy.deepcopy(model).double()
+        with torch.no_grad():
+            p64 = m64(to_input(u8).reshape(len(names), 1, res, res * 5 // 4).double())
         out = dict(names=np.array(names), input_u8=u8, head_large=np.stack(hl_all), head_small=np.stack(hs_all),
+                   head_large_f64=p64[0].numpy(), head_small_f64=p64[1].numpy(),
                    anchors=np.array(io["anchors"][:2], np.float64), input_shape=np.array(io["input_shape"][:2]))
         for tag, L in (("cand", cands), ("final", finals), ("adj", adjs)):
             for k, v in pack_lists(L, 16).items():

@@ -1,0 +1,71 @@
+"""ctypes binding of libyolo_fastest_hip.so (C ABI: include/yolo_fastest_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyolo_fastest_hip.so")
+ABI_VERSION = 1
+
+YF_OK, YF_E_INVALID, YF_E_BLOB, YF_E_HIP, YF_E_WORKSPACE, YF_E_NOPROBE = 0, -1, -2, -3, -4, -5
+
+_c = ctypes
+_SIGS = {
+    "yf_abi_version": (_c.c_int, []),
+    "yf_last_error_string": (_c.c_char_p, []),
+    "yf_create": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_void_p)]),
+    "yf_destroy": (_c.c_int, [_c.c_void_p]),
+    "yf_workspace_bytes": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_size_t)]),
+    "yf_forward": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t,
+                              _c.c_void_p]),
+    "yf_forward_probe": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_char_p, _c.c_void_p, _c.c_size_t,
+                                    _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "yf_decode_nms": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_double, _c.c_double,
+                                 _c.POINTER(_c.c_double), _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p,
+                                 _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "yf_detect": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_double, _c.c_double, _c.POINTER(_c.c_double),
+                             _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                             _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "yf_preprocess_u8": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    "yf_nms_sorted": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_double, _c.c_void_p, _c.c_void_p]),
+    "yf_num_launches": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int)]),
+    "yf_set_chunk": (_c.c_int, [_c.c_void_p, _c.c_int]),
+}
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip for gfx950 into libyolo_fastest_hip.so (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"] + ([] if verbose else ["-s"]))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension is the only implementation of this package "
+                "(no CPU fallback). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C yolo-fastest-and-embedded-deployment_amd/csrc`.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if L.yf_abi_version() != ABI_VERSION:
+            raise ImportError("libyolo_fastest_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+class YFError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().yf_last_error_string().decode(errors="replace")
+        raise YFError(f"yolo_fastest_hip error {rc}: {msg}")

@@ -1,0 +1,476 @@
+// yf_engine.hip -- C-ABI (include/yolo_fastest_hip.h) and the execution plan of the YOLO-Fastest graph.
+//
+// The plan restates the graph of the reference's YoloFastest.forward
+// (src/model_training/model/yolo_fastest.py:150-218) as a list of kernel launches over NHWC tensors with
+// liveness-based reuse of workspace slots; it is built once per engine (yf_create) so that a forward
+// pass is nothing but stream-ordered launches: no allocation, no synchronisation, graph-capturable.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/yolo_fastest_hip.h"
+#include "yf_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_OK(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return fail(YF_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+enum Kind { K_PW = 0, K_DW = 1, K_DENSE = 2, K_DECONV = 3, K_HEAD = 4 };
+
+struct BlobHeader {
+    char magic[8];
+    uint32_t version, n_layers, num_out, input_channel, num_anchors, num_cls;
+    uint64_t data_floats;
+    char pad[24];
+};
+struct BlobLayer {
+    char name[32];
+    uint32_t kind, cin, cout, k, stride, relu, w_off, b_off;
+};
+static_assert(sizeof(BlobHeader) == 64 && sizeof(BlobLayer) == 64, "blob layout");
+
+// The YoloFastest layer table, module-definition order (yolo_fastest.py:78-148). The blob must match it.
+struct LayerSpec {
+    const char* name;
+    int kind, cin, cout, k, stride, relu;
+};
+#define RES(n, c, e) {n ".conv1", K_PW, c, e, 1, 1, 1}, {n ".conv2", K_DW, e, e, 3, 1, 1}, {n ".conv3", K_PW, e, c, 1, 1, 0}
+const LayerSpec kLayers[] = {
+    {"conv0", K_DENSE, 1, 8, 3, 2, 1}, {"conv1_2", K_PW, 8, 8, 1, 1, 1}, {"conv1_3", K_DW, 8, 8, 3, 1, 1},
+    {"conv1_4", K_PW, 8, 4, 1, 1, 0}, RES("res1_1", 4, 8),
+    {"conv1_8", K_PW, 4, 24, 1, 1, 1}, {"conv1_9", K_DENSE, 24, 24, 3, 2, 1}, {"conv2_1", K_PW, 24, 8, 1, 1, 0},
+    RES("res2_1", 8, 32), RES("res2_2", 8, 32),
+    {"conv2_2", K_PW, 8, 32, 1, 1, 1}, {"conv2_3", K_DW, 32, 32, 3, 2, 1}, {"conv3_1", K_PW, 32, 8, 1, 1, 0},
+    RES("res3_1", 8, 48), RES("res3_2", 8, 48),
+    {"conv3_2", K_PW, 8, 48, 1, 1, 1}, {"conv3_3", K_DW, 48, 48, 3, 1, 1}, {"conv3_4", K_PW, 48, 16, 1, 1, 0},
+    RES("res3_3", 16, 96), RES("res3_4", 16, 96), RES("res3_5", 16, 96), RES("res3_6", 16, 96),
+    {"conv3_5", K_PW, 16, 96, 1, 1, 1}, {"conv3_6", K_DW, 96, 96, 3, 2, 1}, {"conv4_1", K_PW, 96, 24, 1, 1, 0},
+    RES("res4_1", 24, 136), RES("res4_2", 24, 136), RES("res4_3", 24, 136), RES("res4_4", 24, 136),
+    {"conv4_2", K_PW, 24, 136, 1, 1, 1}, {"conv4_3", K_DW, 136, 136, 3, 2, 1}, {"conv5_1", K_PW, 136, 48, 1, 1, 1},
+    RES("res5_1", 48, 224), RES("res5_2", 48, 224), RES("res5_3", 48, 224), RES("res5_4", 48, 224),
+    RES("res5_5", 48, 224),
+    {"conv5_2", K_PW, 48, 96, 1, 1, 1}, {"conv5_3", K_DW, 96, 96, 5, 1, 1}, {"conv5_4", K_PW, 96, 128, 1, 1, 0},
+    {"conv5_5", K_DW, 128, 128, 5, 1, 1}, {"conv5_6", K_PW, 128, 128, 1, 1, 0}, {"head_5", K_HEAD, 128, 24, 1, 1, 0},
+    {"deconv5_1", K_DECONV, 96, 96, 2, 2, 1},
+    {"conv4_1_1", K_PW, 232, 96, 1, 1, 1}, {"conv4_1_2", K_DW, 96, 96, 5, 1, 1}, {"conv4_1_3", K_PW, 96, 96, 1, 1, 0},
+    {"conv4_1_4", K_DW, 96, 96, 5, 1, 1}, {"conv4_1_5", K_PW, 96, 96, 1, 1, 0}, {"head_4", K_HEAD, 96, 24, 1, 1, 0},
+};
+constexpr int kNumLayers = sizeof(kLayers) / sizeof(kLayers[0]);
+static_assert(kNumLayers == 86, "84 conv+BN units + 2 heads");
+
+enum { BUF_INPUT = -1, BUF_HEAD_LARGE = -2, BUF_HEAD_SMALL = -3 };
+
+struct Tensor {
+    std::string name;
+    int C, H, W;
+    int slot;      // workspace slot, or BUF_*
+    int last_use;  // index of the last op reading it
+    size_t elems() const { return (size_t)C * H * W; }
+};
+struct Op {
+    int layer;         // index into kLayers
+    int in1, in2, res; // tensor ids (-1 = none)
+    int out;
+    int omode;         // pw: 0 NHWC, 1 NCHW head, 2 deconv
+};
+
+}  // namespace
+
+struct yf_engine {
+    int device = 0, H = 0, W = 0, max_batch = 0, chunk = 0;
+    float* d_weights = nullptr;
+    size_t n_floats = 0;
+    uint32_t w_off[kNumLayers], b_off[kNumLayers];
+    std::vector<Tensor> tensors;
+    std::vector<Op> ops;
+    std::vector<size_t> slot_elems;   // per-frame capacity of each slot
+    std::vector<size_t> slot_offset;  // per-frame offset (floats), prefix sums
+    size_t frame_floats = 0;          // sum of slot capacities
+    size_t head_l_elems = 0, head_s_elems = 0;
+};
+
+namespace {
+
+int find_layer(const char* name)
+{
+    for (int i = 0; i < kNumLayers; ++i)
+        if (!strcmp(kLayers[i].name, name)) return i;
+    return -1;
+}
+
+struct Builder {
+    yf_engine* e;
+    int add_tensor(const std::string& name, int C, int H, int W, int slot = 0)
+    {
+        e->tensors.push_back(Tensor{name, C, H, W, slot, -1});
+        return (int)e->tensors.size() - 1;
+    }
+    int unit(const char* lname, int in, const char* out_name = nullptr, int in2 = -1, int res = -1, int ext = 0)
+    {
+        int li = find_layer(lname);
+        const LayerSpec& L = kLayers[li];
+        const Tensor& ti = e->tensors[in];
+        int Ho = ti.H, Wo = ti.W, omode = 0;
+        if (L.kind == K_DECONV) { Ho *= 2; Wo *= 2; omode = 2; }
+        else if (L.stride == 2) { Ho /= 2; Wo /= 2; }
+        if (L.kind == K_HEAD) omode = 1;
+        int out = add_tensor(out_name ? out_name : lname, L.cout, Ho, Wo, ext);
+        e->ops.push_back(Op{li, in, in2, res, out, omode});
+        return out;
+    }
+    int resblock(const std::string& n, int x)
+    {
+        int a = unit((n + ".conv1").c_str(), x);
+        int b = unit((n + ".conv2").c_str(), a);
+        return unit((n + ".conv3").c_str(), b, n.c_str(), -1, x);
+    }
+};
+
+void build_plan(yf_engine* e)
+{
+    Builder b{e};
+    int x = b.add_tensor("input", 1, e->H, e->W, BUF_INPUT);
+    for (const char* n : {"conv0", "conv1_2", "conv1_3", "conv1_4"}) x = b.unit(n, x);
+    x = b.resblock("res1_1", x);
+    for (const char* n : {"conv1_8", "conv1_9", "conv2_1"}) x = b.unit(n, x);
+    for (const char* n : {"res2_1", "res2_2"}) x = b.resblock(n, x);
+    for (const char* n : {"conv2_2", "conv2_3", "conv3_1"}) x = b.unit(n, x);
+    for (const char* n : {"res3_1", "res3_2"}) x = b.resblock(n, x);
+    for (const char* n : {"conv3_2", "conv3_3", "conv3_4"}) x = b.unit(n, x);
+    for (const char* n : {"res3_3", "res3_4", "res3_5", "res3_6"}) x = b.resblock(n, x);
+    for (const char* n : {"conv3_5", "conv3_6", "conv4_1"}) x = b.unit(n, x);
+    for (const char* n : {"res4_1", "res4_2", "res4_3", "res4_4"}) x = b.resblock(n, x);
+    int conv4_2 = b.unit("conv4_2", x);
+    x = b.unit("conv4_3", conv4_2);
+    x = b.unit("conv5_1", x);
+    for (const char* n : {"res5_1", "res5_2", "res5_3", "res5_4", "res5_5"}) x = b.resblock(n, x);
+    int conv5_2 = b.unit("conv5_2", x);
+    x = conv5_2;
+    for (const char* n : {"conv5_3", "conv5_4", "conv5_5", "conv5_6"}) x = b.unit(n, x);
+    b.unit("head_5", x, "head_small", -1, -1, BUF_HEAD_SMALL);
+    int d = b.unit("deconv5_1", conv5_2);
+    x = b.unit("conv4_1_1", conv4_2, nullptr, d);  // torch.cat((conv4_2, deconv5_1), 1), yolo_fastest.py:209
+    for (const char* n : {"conv4_1_2", "conv4_1_3", "conv4_1_4", "conv4_1_5"}) x = b.unit(n, x);
+    b.unit("head_4", x, "head_large", -1, -1, BUF_HEAD_LARGE);
+
+    // liveness
+    for (size_t i = 0; i < e->ops.size(); ++i) {
+        const Op& o = e->ops[i];
+        for (int t : {o.in1, o.in2, o.res})
+            if (t >= 0) e->tensors[t].last_use = (int)i;
+    }
+    // slot assignment: smallest free slot that fits, else grow the largest free one, else a new slot
+    std::vector<int> free_slots;
+    for (size_t i = 0; i < e->ops.size(); ++i) {
+        Tensor& t = e->tensors[e->ops[i].out];
+        if (t.slot >= 0) {
+            size_t need = t.elems();
+            int best = -1, largest = -1;
+            for (size_t f = 0; f < free_slots.size(); ++f) {
+                int s = free_slots[f];
+                if (e->slot_elems[s] >= need && (best < 0 || e->slot_elems[s] < e->slot_elems[free_slots[best]])) best = (int)f;
+                if (largest < 0 || e->slot_elems[s] > e->slot_elems[free_slots[largest]]) largest = (int)f;
+            }
+            int pick = best >= 0 ? best : largest;
+            if (pick >= 0) {
+                t.slot = free_slots[pick];
+                free_slots.erase(free_slots.begin() + pick);
+                if (e->slot_elems[t.slot] < need) e->slot_elems[t.slot] = need;
+            } else {
+                t.slot = (int)e->slot_elems.size();
+                e->slot_elems.push_back(need);
+            }
+        }
+        const Op& o = e->ops[i];
+        for (int in : {o.in1, o.in2, o.res}) {
+            if (in < 0) continue;
+            Tensor& ti = e->tensors[in];
+            if (ti.slot >= 0 && ti.last_use == (int)i) {
+                bool dup = false;  // the same tensor may appear as in1 and res
+                for (int s : free_slots) dup |= (s == ti.slot);
+                if (!dup) free_slots.push_back(ti.slot);
+            }
+        }
+    }
+    e->slot_offset.resize(e->slot_elems.size());
+    size_t off = 0;
+    for (size_t s = 0; s < e->slot_elems.size(); ++s) {
+        e->slot_offset[s] = off;
+        off += (e->slot_elems[s] + 63) & ~(size_t)63;
+    }
+    e->frame_floats = off;
+    e->head_l_elems = 24u * (e->H / 16) * (e->W / 16);
+    e->head_s_elems = 24u * (e->H / 32) * (e->W / 32);
+}
+
+int chunk_frames(const yf_engine* e, int N)
+{
+    int c = e->chunk > 0 ? e->chunk : N;
+    return c < N ? c : N;
+}
+
+int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs, void* ws, size_t ws_bytes,
+                hipStream_t s, const char* probe, float* probe_dst, size_t probe_bytes)
+{
+    if (!e || !d_x || !d_hl || !d_hs || N <= 0) return fail(YF_E_INVALID, "yf_forward: null pointer or N <= 0");
+    if (N > e->max_batch) return fail(YF_E_INVALID, "yf_forward: N=%d exceeds max_batch=%d", N, e->max_batch);
+    const int cf = chunk_frames(e, N);
+    size_t need = e->frame_floats * (size_t)cf * sizeof(float);
+    if (!ws || ws_bytes < need) return fail(YF_E_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, need);
+    HIP_OK(hipSetDevice(e->device));
+    int probe_t = -1;
+    if (probe) {
+        for (size_t t = 0; t < e->tensors.size(); ++t)
+            if (e->tensors[t].name == probe) probe_t = (int)t;
+        if (probe_t < 0) return fail(YF_E_NOPROBE, "no tensor named '%s' exists in device memory", probe);
+        if (probe_bytes < e->tensors[probe_t].elems() * N * sizeof(float)) return fail(YF_E_INVALID, "probe buffer too small");
+    }
+    float* base = static_cast<float*>(ws);
+    for (int f0 = 0; f0 < N; f0 += cf) {
+        const int n = (N - f0) < cf ? (N - f0) : cf;
+        auto ptr = [&](int t) -> float* {
+            const Tensor& T = e->tensors[t];
+            if (T.slot == BUF_INPUT) return const_cast<float*>(d_x) + (size_t)f0 * T.elems();
+            if (T.slot == BUF_HEAD_LARGE) return d_hl + (size_t)f0 * T.elems();
+            if (T.slot == BUF_HEAD_SMALL) return d_hs + (size_t)f0 * T.elems();
+            return base + e->slot_offset[T.slot] * (size_t)cf;
+        };
+        for (const Op& o : e->ops) {
+            const LayerSpec& L = kLayers[o.layer];
+            const Tensor& ti = e->tensors[o.in1];
+            const Tensor& to = e->tensors[o.out];
+            const float* w = e->d_weights + e->w_off[o.layer];
+            const float* bv = e->d_weights + e->b_off[o.layer];
+            int rc = 0;
+            if (L.kind == K_PW || L.kind == K_HEAD || L.kind == K_DECONV) {
+                yf::PwArgs a{ptr(o.in1), o.in2 >= 0 ? ptr(o.in2) : nullptr, w, bv, o.res >= 0 ? ptr(o.res) : nullptr,
+                             ptr(o.out), (long)n * ti.H * ti.W, (long)ti.H * ti.W, ti.W};
+                int cin2 = o.in2 >= 0 ? e->tensors[o.in2].C : 0;
+                rc = yf::launch_pw(ti.C, cin2, L.cout, L.relu != 0, o.res >= 0, o.omode, a, s);
+            } else if (L.kind == K_DW) {
+                yf::DwArgs a{ptr(o.in1), w, bv, ptr(o.out), (long)n * to.H * to.W * (to.C / 4), ti.C, ti.H, ti.W, to.H, to.W};
+                rc = yf::launch_dw(L.k, L.stride, a, s);
+            } else {
+                yf::DenseArgs a{ptr(o.in1), w, bv, ptr(o.out), (long)n * to.H * to.W, ti.H, ti.W, to.H, to.W};
+                rc = yf::launch_dense3x3s2(L.cin, L.cout, a, s);
+            }
+            if (rc) return fail(YF_E_INVALID, "no kernel for layer %s", L.name);
+            if (o.out == probe_t) {
+                if (to.slot == BUF_HEAD_LARGE || to.slot == BUF_HEAD_SMALL)
+                    HIP_OK(hipMemcpyAsync(probe_dst + (size_t)f0 * to.elems(), ptr(o.out), to.elems() * n * sizeof(float),
+                                          hipMemcpyDeviceToDevice, s));
+                else
+                    yf::launch_nhwc_to_nchw(ptr(o.out), probe_dst + (size_t)f0 * to.elems(), n, to.C, (long)to.H * to.W, s);
+            }
+        }
+    }
+    HIP_OK(hipGetLastError());
+    return YF_OK;
+}
+
+double sigmoid_host(float x) { return 1. / (1. + exp(-(double)x)); }  // detect.py:23-25 in this libm
+
+// smallest fp32 t with 1/(1+exp(-t)) > thres (monotone in t); +inf / -inf sentinels at the extremes
+float logit_threshold(double thres)
+{
+    auto to_ord = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u); };
+    auto from_ord = [](uint32_t o) { uint32_t u = (o & 0x80000000u) ? (o ^ 0x80000000u) : ~o; float f; memcpy(&f, &u, 4); return f; };
+    const float lo_f = -700.f, hi_f = 700.f;  // math.exp overflows beyond; sigmoid saturates long before
+    if (sigmoid_host(lo_f) > thres) return -INFINITY;
+    if (!(sigmoid_host(hi_f) > thres)) return INFINITY;
+    uint32_t lo = to_ord(lo_f), hi = to_ord(hi_f);  // invariant: f(lo) false, f(hi) true
+    while (hi - lo > 1) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        if (sigmoid_host(from_ord(mid)) > thres) hi = mid; else lo = mid;
+    }
+    return from_ord(hi);
+}
+
+}  // namespace
+
+extern "C" {
+
+int yf_abi_version(void) { return YF_ABI_VERSION; }
+const char* yf_last_error_string(void) { return g_err; }
+
+int yf_create(const void* blob, size_t nbytes, int H, int W, int max_batch, int device, yf_handle* out)
+{
+    if (!blob || !out) return fail(YF_E_INVALID, "yf_create: null pointer");
+    if (H <= 0 || W <= 0 || H % 32 || W % 32) return fail(YF_E_INVALID, "input shape %dx%d: rows and cols must be multiples of 32", H, W);
+    if (max_batch <= 0) return fail(YF_E_INVALID, "max_batch must be positive");
+    if (nbytes < sizeof(BlobHeader)) return fail(YF_E_BLOB, "blob too small");
+    BlobHeader hd;
+    memcpy(&hd, blob, sizeof hd);
+    if (memcmp(hd.magic, "YFHIPW01", 8) || hd.version != 1) return fail(YF_E_BLOB, "bad magic/version");
+    if (hd.n_layers != (uint32_t)kNumLayers || hd.num_out != 24 || hd.input_channel != 1)
+        return fail(YF_E_BLOB, "blob describes n_layers=%u num_out=%u input_channel=%u; this build implements 86/24/1",
+                    hd.n_layers, hd.num_out, hd.input_channel);
+    size_t data_off = sizeof(BlobHeader) + sizeof(BlobLayer) * (size_t)kNumLayers;
+    if (nbytes < data_off + hd.data_floats * 4) return fail(YF_E_BLOB, "blob truncated");
+    yf_engine* e = new yf_engine;
+    e->device = device; e->H = H; e->W = W; e->max_batch = max_batch;
+    const BlobLayer* tab = reinterpret_cast<const BlobLayer*>(static_cast<const char*>(blob) + sizeof(BlobHeader));
+    for (int i = 0; i < kNumLayers; ++i) {
+        BlobLayer bl;
+        memcpy(&bl, &tab[i], sizeof bl);
+        const LayerSpec& L = kLayers[i];
+        if (strncmp(bl.name, L.name, 32) || (int)bl.kind != L.kind || (int)bl.cin != L.cin || (int)bl.cout != L.cout ||
+            (int)bl.k != L.k || (int)bl.stride != L.stride || (int)bl.relu != L.relu) {
+            delete e;
+            return fail(YF_E_BLOB, "layer %d: blob has '%.31s', YoloFastest expects '%s' (kind/shape mismatch)", i, bl.name, L.name);
+        }
+        size_t wn = L.kind == K_DW ? (size_t)L.k * L.k * L.cout
+                  : L.kind == K_DENSE ? (size_t)L.k * L.k * L.cin * L.cout
+                  : L.kind == K_DECONV ? (size_t)4 * L.cin * L.cout : (size_t)L.cin * L.cout;
+        if (bl.w_off + wn > hd.data_floats || bl.b_off + (size_t)L.cout > hd.data_floats || (bl.w_off & 3) || (bl.b_off & 3)) {
+            delete e;
+            return fail(YF_E_BLOB, "layer %s: weight offsets out of range or unaligned", L.name);
+        }
+        e->w_off[i] = bl.w_off; e->b_off[i] = bl.b_off;
+    }
+    if (hipSetDevice(device) != hipSuccess) { delete e; return fail(YF_E_HIP, "hipSetDevice(%d) failed", device); }
+    e->n_floats = hd.data_floats;
+    if (hipMalloc(&e->d_weights, e->n_floats * 4) != hipSuccess) { delete e; return fail(YF_E_HIP, "hipMalloc(weights) failed"); }
+    if (hipMemcpy(e->d_weights, static_cast<const char*>(blob) + data_off, e->n_floats * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(e->d_weights); delete e;
+        return fail(YF_E_HIP, "hipMemcpy(weights) failed");
+    }
+    build_plan(e);
+    *out = e;
+    return YF_OK;
+}
+
+int yf_destroy(yf_handle h)
+{
+    if (!h) return YF_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->d_weights);
+    delete h;
+    return YF_OK;
+}
+
+int yf_workspace_bytes(yf_handle h, int N, size_t* out)
+{
+    if (!h || !out || N <= 0) return fail(YF_E_INVALID, "yf_workspace_bytes: bad argument");
+    // layer-chain slots + internal head buffers for yf_detect
+    *out = (h->frame_floats * (size_t)chunk_frames(h, N) + (h->head_l_elems + h->head_s_elems) * (size_t)N) * sizeof(float) + 256;
+    return YF_OK;
+}
+
+int yf_forward(yf_handle h, const float* d_x, int N, float* d_hl, float* d_hs, void* ws, size_t ws_bytes, void* stream)
+{
+    return run_forward(h, d_x, N, d_hl, d_hs, ws, ws_bytes, (hipStream_t)stream, nullptr, nullptr, 0);
+}
+
+int yf_forward_probe(yf_handle h, const float* d_x, int N, const char* name, float* d_dst, size_t dst_bytes, void* ws,
+                     size_t ws_bytes, void* stream)
+{
+    if (!h || !name || !d_dst) return fail(YF_E_INVALID, "yf_forward_probe: null pointer");
+    // heads go to the tail of the workspace
+    size_t chain = h->frame_floats * (size_t)chunk_frames(h, N) * sizeof(float);
+    size_t heads = (h->head_l_elems + h->head_s_elems) * (size_t)N * sizeof(float);
+    if (!ws || ws_bytes < chain + heads) return fail(YF_E_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, chain + heads);
+    float* hl = reinterpret_cast<float*>(static_cast<char*>(ws) + chain);
+    float* hs = hl + h->head_l_elems * (size_t)N;
+    return run_forward(h, d_x, N, hl, hs, ws, chain, (hipStream_t)stream, name, d_dst, dst_bytes);
+}
+
+int yf_decode_nms(yf_handle h, const float* d_hl, const float* d_hs, int N, double conf_thres, double nms_thres,
+                  const double* anchors, int origin_h, int origin_w, int K_max, int32_t* d_boxes, float* d_scores,
+                  int32_t* d_cls, int32_t* d_src, int32_t* d_counts, void* stream)
+{
+    if (!h || !d_hl || !d_hs || !anchors || !d_boxes || !d_scores || !d_cls || !d_src || !d_counts || N <= 0 || K_max <= 0)
+        return fail(YF_E_INVALID, "yf_decode_nms: null pointer or non-positive size");
+    HIP_OK(hipSetDevice(h->device));
+    yf::PostArgs a;
+    a.head_large = d_hl; a.head_small = d_hs;
+    a.hl = h->H / 16; a.wl = h->W / 16; a.hs = h->H / 32; a.ws = h->W / 32;
+    a.in_h = h->H; a.in_w = h->W;
+    a.logit_min = logit_threshold(conf_thres);
+    a.nms_thres = nms_thres;
+    for (int i = 0; i < 12; ++i) a.anchors[i] = anchors[i];
+    bool adj = origin_h > 0 && origin_w > 0 && (origin_h != h->H || origin_w != h->W);
+    a.adj_h = adj ? (double)origin_h / h->H : 0.0;
+    a.adj_w = adj ? (double)origin_w / h->W : 0.0;
+    a.kmax = K_max;
+    a.boxes = d_boxes; a.scores = d_scores; a.cls = d_cls; a.src = d_src; a.counts = d_counts;
+    int rc = yf::launch_post(a, N, (hipStream_t)stream);
+    if (rc == -1) return fail(YF_E_INVALID, "frame of %dx%d has too many cells for the on-chip NMS (limit 8191 cells / 160 KiB LDS)", h->H, h->W);
+    if (rc) return fail(YF_E_HIP, "hipFuncSetAttribute(post_kernel) failed");
+    HIP_OK(hipGetLastError());
+    return YF_OK;
+}
+
+int yf_nms_sorted(yf_handle h, const int32_t* d_boxes, int n, double nms_thres, int32_t* d_sup, void* stream)
+{
+    if (!h || !d_boxes || !d_sup || n < 0) return fail(YF_E_INVALID, "yf_nms_sorted: bad argument");
+    if (n == 0) return YF_OK;
+    HIP_OK(hipSetDevice(h->device));
+    yf::launch_nms_sorted(d_boxes, n, nms_thres, d_sup, (hipStream_t)stream);
+    HIP_OK(hipGetLastError());
+    return YF_OK;
+}
+
+int yf_detect(yf_handle h, const float* d_x, int N, double conf_thres, double nms_thres, const double* anchors, int origin_h,
+              int origin_w, int K_max, int32_t* d_boxes, float* d_scores, int32_t* d_cls, int32_t* d_src, int32_t* d_counts,
+              float* d_hl, float* d_hs, void* ws, size_t ws_bytes, void* stream)
+{
+    if (!h) return fail(YF_E_INVALID, "yf_detect: null handle");
+    size_t chain = h->frame_floats * (size_t)chunk_frames(h, N) * sizeof(float);
+    size_t heads = (h->head_l_elems + h->head_s_elems) * (size_t)N * sizeof(float);
+    if (!ws || ws_bytes < chain + ((d_hl && d_hs) ? 0 : heads)) return fail(YF_E_WORKSPACE, "workspace too small");
+    float* hl = d_hl ? d_hl : reinterpret_cast<float*>(static_cast<char*>(ws) + chain);
+    float* hs = d_hs ? d_hs : reinterpret_cast<float*>(static_cast<char*>(ws) + chain) + h->head_l_elems * (size_t)N;
+    int rc = run_forward(h, d_x, N, hl, hs, ws, chain, (hipStream_t)stream, nullptr, nullptr, 0);
+    if (rc) return rc;
+    return yf_decode_nms(h, hl, hs, N, conf_thres, nms_thres, anchors, origin_h, origin_w, K_max, d_boxes, d_scores, d_cls,
+                         d_src, d_counts, stream);
+}
+
+int yf_preprocess_u8(yf_handle h, const uint8_t* d_u8, int N, int src_h, int src_w, float* d_x, void* stream)
+{
+    if (!h || !d_u8 || !d_x || N <= 0) return fail(YF_E_INVALID, "yf_preprocess_u8: bad argument");
+    int down2;
+    if (src_h == h->H && src_w == h->W) down2 = 0;
+    else if (src_h == 2 * h->H && src_w == 2 * h->W) down2 = 1;
+    else return fail(YF_E_INVALID, "source %dx%d: only 1x or exact 2x of the net input %dx%d is supported", src_h, src_w, h->H, h->W);
+    HIP_OK(hipSetDevice(h->device));
+    yf::launch_preprocess(d_u8, d_x, N, h->H, h->W, down2, (hipStream_t)stream);
+    HIP_OK(hipGetLastError());
+    return YF_OK;
+}
+
+int yf_num_launches(yf_handle h, int* out)
+{
+    if (!h || !out) return fail(YF_E_INVALID, "bad argument");
+    *out = (int)h->ops.size();
+    return YF_OK;
+}
+
+int yf_set_chunk(yf_handle h, int frames)
+{
+    if (!h || frames < 0) return fail(YF_E_INVALID, "bad argument");
+    h->chunk = frames;
+    return YF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// yf_kernels.h -- internal launch interface between the engine (yf_engine.hip) and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace yf {
+
+struct PwArgs {
+    const float* in1;  // NHWC [npix, CIN1]
+    const float* in2;  // NHWC [npix, CIN2] (second half of a channel concat) or null
+    const float* w;    // [cin][cout] (deconv: [4][cin][cout])
+    const float* b;    // [cout]
+    const float* res;  // NHWC [npix, COUT] residual or null
+    float* out;
+    long npix;         // N*H*W input pixels
+    long HW;           // pixels per frame (input resolution of this layer)
+    int W;             // row length (input resolution of this layer)
+};
+
+struct DwArgs {
+    const float* in;  // NHWC [N,H,W,C]
+    const float* w;   // [K*K][C]
+    const float* b;   // [C]
+    float* out;       // NHWC [N,Ho,Wo,C]
+    long total;       // N*Ho*Wo*C/4 threads
+    int C, H, W, Ho, Wo;
+};
+
+struct DenseArgs {
+    const float* in;  // NHWC [N,H,W,CIN]
+    const float* w;   // [3][3][cin][cout]
+    const float* b;
+    float* out;       // NHWC [N,Ho,Wo,COUT]
+    long total;       // N*Ho*Wo
+    int H, W, Ho, Wo;
+};
+
+int launch_pw(int cin1, int cin2, int cout, bool relu, bool res, int omode, const PwArgs& a, hipStream_t s);
+int launch_dw(int k, int stride, const DwArgs& a, hipStream_t s);
+int launch_dense3x3s2(int cin, int cout, const DenseArgs& a, hipStream_t s);
+void launch_nhwc_to_nchw(const float* in, float* out, long N, int C, long HW, hipStream_t s);
+void launch_preprocess(const uint8_t* in, float* out, long N, int H, int W, int down2, hipStream_t s);
+
+struct PostArgs {
+    const float* head_large;  // [N,24,hl,wl]
+    const float* head_small;  // [N,24,hs,ws]
+    int hl, wl, hs, ws;
+    int in_h, in_w;           // net-input rows/cols
+    float logit_min;          // smallest fp32 conf logit the reference's `sigmoid(t) > conf_thres` accepts
+    double nms_thres;
+    double anchors[12];       // [2][3][2]
+    double adj_h, adj_w;      // __adjust_coord scales (0 = no adjustment)
+    int kmax;
+    int32_t* boxes;           // [N,kmax,4]
+    float* scores;            // [N,kmax,2]
+    int32_t* cls;             // [N,kmax]
+    int32_t* src;             // [N,kmax]
+    int32_t* counts;          // [N]
+};
+int launch_post(const PostArgs& a, int N, hipStream_t s);
+size_t post_lds_bytes(int ncell);
+void launch_nms_sorted(const int32_t* boxes, int n, double nms_thres, int32_t* suppressor, hipStream_t s);
+
+}  // namespace yf

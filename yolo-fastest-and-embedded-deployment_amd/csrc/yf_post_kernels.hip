@@ -1,0 +1,268 @@
+// yf_post_kernels.hip -- anchor/grid decode + per-class greedy NMS for gfx950, one workgroup per frame.
+//
+// Replaces the pure-Python post-process of the reference, src/detect.py:
+//   YOLO_post_process.decode_box            :41-67   (triple loop anchors x rows x cols, Python doubles)
+//   class bucketing + stable sort by conf   :158-167
+//   YOLO_post_process.non_maxium_supression :69-84   (+ __cal_iou :27-39, integer corners, no +1)
+//   Detect_YOLO.__adjust_coord              :131-139 (optional epilogue)
+//
+// Exactness plan (SURVEY.md "Hard parts"):
+//   * threshold: the host finds, with this machine's libm, the smallest fp32 logit t for which the
+//     reference's  1/(1+exp(-t)) > conf_thres  holds (sigmoid is monotone), so the device compares raw
+//     fp32 logits -- bit-exact for every conf_thres;
+//   * order: candidates are sorted ONCE on a unique 64-bit key (class asc | conf logit desc | cell asc):
+//     class-major output, conf descending, ties in decode order == the reference's bucket + stable sort
+//     (sigmoid is monotone in the logit; two different logits share one double conf only above
+//     logit ~ 22, conf > 1-3e-10);
+//   * boxes: fp64 arithmetic and rint() (round-half-even == Python round());
+//   * IoU test: int64 areas, fp64 IEEE division, strict '>'.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "yf_kernels.h"
+
+namespace yf {
+
+static constexpr int POST_THREADS = 256;
+
+__device__ inline uint32_t orderable(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ inline double sigmoid_d(double x) { return 1. / (1. + exp(-x)); }
+__device__ inline int32_t clamp_i32(double v)
+{
+    if (v >= 2147483647.0) return 2147483647;
+    if (v <= -2147483648.0) return (int32_t)(-2147483647 - 1);
+    return (int32_t)v;
+}
+
+struct CellRef {
+    const float* p;  // frame's head tensor
+    int h, w, head, pp, i, j;
+};
+__device__ inline CellRef locate(const PostArgs& a, long frame, int cell)
+{
+    CellRef r;
+    int nl = 3 * a.hl * a.wl;
+    if (cell < nl) {
+        r.head = 0; r.h = a.hl; r.w = a.wl; r.p = a.head_large + frame * 24L * a.hl * a.wl;
+    } else {
+        cell -= nl; r.head = 1; r.h = a.hs; r.w = a.ws; r.p = a.head_small + frame * 24L * a.hs * a.ws;
+    }
+    r.j = cell % r.w;
+    int t = cell / r.w;
+    r.i = t % r.h;
+    r.pp = t / r.h;
+    return r;
+}
+__device__ inline float logit_at(const CellRef& r, int k) { return r.p[((r.pp * 8 + k) * r.h + r.i) * r.w + r.j]; }
+
+// LDS carve: keys u64[mpad] | boxes int4[ncell] | alive u8[ncell] | kept i32[ncell] | small scalars
+__global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncell, int mpad_max)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+    int4* boxes = reinterpret_cast<int4*>(smem + (size_t)mpad_max * 8);
+    int32_t* kept = reinterpret_cast<int32_t*>(smem + (size_t)mpad_max * 8 + (size_t)ncell * 16);
+    unsigned char* alive = smem + (size_t)mpad_max * 8 + (size_t)ncell * 20;
+    __shared__ int s_wave_cnt[POST_THREADS / 64];
+    __shared__ int s_total, s_nkept, s_err;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long frame = blockIdx.x;
+    if (tid == 0) { s_total = 0; s_nkept = 0; s_err = 0; }
+    __syncthreads();
+
+    // ---- phase 1: threshold + order-preserving compaction of candidate keys (decode order) ----
+    for (int base = 0; base < ncell; base += POST_THREADS) {
+        int cell = base + tid;
+        bool pass = false;
+        uint64_t key = 0;
+        if (cell < ncell) {
+            CellRef r = locate(a, frame, cell);
+            float t4 = logit_at(r, 4);
+            pass = t4 >= a.logit_min;  // NaN fails, like `nan > thres`
+            if (pass) {
+                if (t4 == 0.f) t4 = 0.f;  // -0.0 and +0.0 have the same conf
+                float best = logit_at(r, 5);
+                int cls = 0;
+#pragma unroll
+                for (int k = 1; k < 3; ++k) {
+                    float v = logit_at(r, 5 + k);
+                    if (v > best) { best = v; cls = k; }  // np.argmax: first maximum wins
+                }
+                key = ((uint64_t)cls << 45) | ((uint64_t)(~orderable(t4)) << 13) | (uint64_t)cell;
+            }
+        }
+        unsigned long long m = __ballot(pass);
+        int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = s_total;
+        for (int wv = 0; wv < wave; ++wv) off += s_wave_cnt[wv];
+        if (pass) keys[off + before] = key;
+        __syncthreads();
+        if (tid == 0) {
+            int t = s_total;
+            for (int wv = 0; wv < POST_THREADS / 64; ++wv) t += s_wave_cnt[wv];
+            s_total = t;
+        }
+        __syncthreads();
+    }
+    const int M = s_total;
+    if (M == 0) {
+        if (tid == 0) a.counts[frame] = 0;
+        return;
+    }
+    int mpad = 64;
+    while (mpad < M) mpad <<= 1;
+    for (int i = M + tid; i < mpad; i += POST_THREADS) keys[i] = ~0ull;
+    __syncthreads();
+
+    // ---- phase 2: bitonic sort of the unique keys (ascending) ----
+    for (int k = 2; k <= mpad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < mpad; i += POST_THREADS) {
+                int l = i ^ j;
+                if (l > i) {
+                    uint64_t x = keys[i], y = keys[l];
+                    bool up = (i & k) == 0;
+                    if ((x > y) == up) { keys[i] = y; keys[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- phase 3: decode the boxes of the sorted candidates (fp64, round-half-even) ----
+    for (int k = tid; k < M; k += POST_THREADS) {
+        int cell = (int)(keys[k] & 0x1fffu);
+        CellRef r = locate(a, frame, cell);
+        double scale_h = (double)a.in_h / r.h, scale_w = (double)a.in_w / r.w;
+        double x = (r.j + sigmoid_d((double)logit_at(r, 0))) * scale_w;
+        double y = (r.i + sigmoid_d((double)logit_at(r, 1))) * scale_h;
+        double bw = exp((double)logit_at(r, 2)) * a.anchors[(r.head * 3 + r.pp) * 2 + 0];
+        double bh = exp((double)logit_at(r, 3)) * a.anchors[(r.head * 3 + r.pp) * 2 + 1];
+        boxes[k] = make_int4(clamp_i32(rint(x - bw / 2)), clamp_i32(rint(y - bh / 2)), clamp_i32(rint(x + bw / 2)),
+                             clamp_i32(rint(y + bh / 2)));
+        alive[k] = 1;
+    }
+    __syncthreads();
+
+    // ---- phase 4: greedy NMS, class segments are contiguous in the sorted list ----
+    for (int i = 0; i < M; ++i) {
+        if (!alive[i]) continue;  // settled by the barrier that ended the sweep which could clear it
+        if (tid == 0) { kept[s_nkept] = i; s_nkept = s_nkept + 1; }
+        const int4 bi = boxes[i];
+        const int ci = (int)(keys[i] >> 45);
+        const long area_i = ((long)bi.z - bi.x) * ((long)bi.w - bi.y);
+        bool any = false;
+        for (int j = i + 1 + tid; j < M; j += POST_THREADS) {
+            if ((int)(keys[j] >> 45) != ci) break;  // past this class
+            any = true;
+            if (!alive[j]) continue;
+            const int4 bj = boxes[j];
+            long iw = (long)min(bj.z, bi.z) - (long)max(bj.x, bi.x);
+            long ih = (long)min(bj.w, bi.w) - (long)max(bj.y, bi.y);
+            long inter = (iw > 0 && ih > 0) ? iw * ih : 0;
+            long uni = ((long)bj.z - bj.x) * ((long)bj.w - bj.y) + area_i - inter;
+            if (uni == 0) { s_err = 1; continue; }  // the reference raises ZeroDivisionError here
+            if ((double)inter / (double)uni > a.nms_thres) alive[j] = 0;
+        }
+        (void)any;
+        __syncthreads();
+    }
+    __syncthreads();
+
+    // ---- phase 5: write survivors ----
+    const int nk = s_nkept;
+    if (tid == 0) a.counts[frame] = s_err ? -2 : nk;
+    const int nw = nk < a.kmax ? nk : a.kmax;
+    for (int k = tid; k < nw; k += POST_THREADS) {
+        int i = kept[k];
+        uint64_t key = keys[i];
+        int cell = (int)(key & 0x1fffu), cls = (int)(key >> 45);
+        CellRef r = locate(a, frame, cell);
+        int4 b = boxes[i];
+        if (a.adj_w != 0.0) {  // __adjust_coord: int * float scale, round-half-even
+            b.x = clamp_i32(rint((double)b.x * a.adj_w)); b.z = clamp_i32(rint((double)b.z * a.adj_w));
+            b.y = clamp_i32(rint((double)b.y * a.adj_h)); b.w = clamp_i32(rint((double)b.w * a.adj_h));
+        }
+        long o = frame * a.kmax + k;
+        reinterpret_cast<int4*>(a.boxes)[o] = b;
+        a.scores[o * 2 + 0] = (float)sigmoid_d((double)logit_at(r, 4));
+        a.scores[o * 2 + 1] = (float)sigmoid_d((double)logit_at(r, 5 + cls));
+        a.cls[o] = cls;
+        a.src[o] = cell;
+    }
+}
+
+// Stand-alone greedy NMS over one class's conf-sorted list (detect.py:69-84); one workgroup.
+__global__ void __launch_bounds__(POST_THREADS) nms_sorted_kernel(const int4* __restrict__ boxes, int n, double thres,
+                                                                  int32_t* sup)
+{
+    __shared__ int s_err;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_err = 0;
+    for (int i = tid; i < n; i += POST_THREADS) sup[i] = -1;
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        if (sup[i] != -1) continue;
+        const int4 bi = boxes[i];
+        const long area_i = ((long)bi.z - bi.x) * ((long)bi.w - bi.y);
+        for (int j = i + 1 + tid; j < n; j += POST_THREADS) {
+            if (sup[j] != -1) continue;
+            const int4 bj = boxes[j];
+            long iw = (long)min(bj.z, bi.z) - (long)max(bj.x, bi.x);
+            long ih = (long)min(bj.w, bi.w) - (long)max(bj.y, bi.y);
+            long inter = (iw > 0 && ih > 0) ? iw * ih : 0;
+            long uni = ((long)bj.z - bj.x) * ((long)bj.w - bj.y) + area_i - inter;
+            if (uni == 0) { s_err = 1; continue; }
+            if ((double)inter / (double)uni > thres) sup[j] = i;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (s_err)
+        for (int i = tid; i < n; i += POST_THREADS) sup[i] = -2;
+}
+
+void launch_nms_sorted(const int32_t* boxes, int n, double nms_thres, int32_t* suppressor, hipStream_t s)
+{
+    hipLaunchKernelGGL(nms_sorted_kernel, dim3(1), dim3(POST_THREADS), 0, s, reinterpret_cast<const int4*>(boxes), n,
+                       nms_thres, suppressor);
+}
+
+static int pow2_at_least(int n)
+{
+    int p = 64;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+size_t post_lds_bytes(int ncell)
+{
+    size_t b = (size_t)pow2_at_least(ncell) * 8 + (size_t)ncell * 16 + (size_t)ncell * 4 + (size_t)ncell;
+    return (b + 15) & ~(size_t)15;
+}
+
+int launch_post(const PostArgs& a, int N, hipStream_t s)
+{
+    int ncell = 3 * (a.hl * a.wl + a.hs * a.ws);
+    if (ncell > 8191) return -1;  // 13-bit cell field of the sort key
+    size_t lds = post_lds_bytes(ncell);
+    if (lds > 160 * 1024 - 256) return -1;
+    static size_t attr_set = 0;
+    if (lds > attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(post_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return -2;
+        attr_set = lds;
+    }
+    hipLaunchKernelGGL(post_kernel, dim3(N), dim3(POST_THREADS), lds, s, a, ncell, pow2_at_least(ncell));
+    return 0;
+}
+
+}  // namespace yf

@@ -1,0 +1,120 @@
+"""`Detect_YOLO` -- the reference's PC inference driver (src/detect.py:87-192), batched and on the GPU.
+
+Same constructor and `batch_detect(data_path, result_path)`; one log line per image in the reference's format
+(:177,190,192).  Differences that follow from the design, not from taste:
+  * frames are processed `batch_size` at a time (the reference loops one image per iteration, :146);
+  * pre-processing arithmetic ((u8-128)/255 and the exact-2x box mean) runs on the device (yf_preprocess_u8);
+    image decode uses PIL (this image has no cv2);
+  * model + post-process are stream-ordered launches (yf_forward, yf_decode_nms); times in the log are
+    per-batch wall times divided by the batch size.
+Drawing (`plot_one_box`, :185-188) is SURVEY.md 8(f).3 "next" and is reduced to rectangle outlines.
+"""
+import ctypes
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from .model import YoloFastest
+from .post_process import YOLO_post_process
+
+
+def preprocess_u8(model, u8, input_shape):
+    """Detect_YOLO.__pre_process arithmetic (detect.py:115-127) on device.
+    u8: uint8 GPU tensor [N,h,w] (h,w == net input or exactly 2x) -> float32 [N,1,H,W]."""
+    if not u8.is_cuda or u8.dtype != torch.uint8 or u8.dim() != 3:
+        raise ValueError("expected a uint8 GPU tensor [N,h,w]")
+    H, W = int(input_shape[0]), int(input_shape[1])
+    N = u8.shape[0]
+    e = model.engine(H, W, N, u8.device)
+    x = torch.empty((N, 1, H, W), dtype=torch.float32, device=u8.device)
+    u8 = u8.contiguous()
+    stream = torch.cuda.current_stream(u8.device).cuda_stream
+    _lib.check(e.lib.yf_preprocess_u8(e.handle, u8.data_ptr(), N, u8.shape[1], u8.shape[2], x.data_ptr(),
+                                      ctypes.c_void_p(stream)))
+    return x
+
+
+class Detect_YOLO():
+    def __init__(self, device, model_path, config_params, logger):
+        self.model = YoloFastest(config_params["io_params"]).to(device).eval()
+        net_param = torch.load(model_path, map_location=device)
+        self.model.load_state_dict(net_param)
+        self.logger = logger
+        self.device = torch.device(device)
+        io = config_params["io_params"]
+        self.class_names = io["class_names"]
+        self.num_cls = io["num_cls"]
+        self.nms_thres = io["nms_thre"]
+        self.conf_thres = io["conf_thre"]
+        self.input_shape = io["input_shape"]
+        self.origin_img_shape = io["origin_img_shape"]
+        self.post_process = YOLO_post_process(conf_thres=self.conf_thres, nms_thres=self.nms_thres,
+                                              num_anchors=io["num_anchors"], anchors=io["anchors"],
+                                              input_shape=self.input_shape, num_class=self.num_cls).bind(self.model)
+        self.colors = [[106, 90, 205], [199, 97, 20], [112, 128, 105]]
+
+    def _read_gray(self, path):
+        from PIL import Image
+        img = Image.open(path)
+        ori = np.asarray(img.convert("RGB"))
+        return np.asarray(img.convert("L")), ori
+
+    def detect_u8(self, u8, kmax=64):
+        """u8: uint8 GPU tensor [N,h,w] in the ORIGINAL image geometry. Returns per-frame lists in original
+        coordinates (after __adjust_coord, detect.py:181-182)."""
+        x = preprocess_u8(self.model, u8, self.input_shape)
+        with torch.no_grad():
+            pred = self.model(x)
+        origin = None
+        if list(self.input_shape[0:2]) != list(self.origin_img_shape[0:2]):
+            origin = self.origin_img_shape
+        return self.post_process.detect(pred, kmax=kmax, origin_shape=origin)
+
+    def batch_detect(self, data_path, result_path, batch_size=256):
+        img_list = sorted(os.listdir(data_path))
+        num = len(img_list)
+        avg_time = 0.0
+        for b0 in range(0, num, batch_size):
+            names = img_list[b0:b0 + batch_size]
+            grays, oris = zip(*[self._read_gray(os.path.join(data_path, n)) for n in names])
+            u8 = torch.from_numpy(np.stack(grays)).to(self.device)
+            x = preprocess_u8(self.model, u8, self.input_shape)
+            torch.cuda.synchronize(self.device)
+            start_time = time.time()
+            with torch.no_grad():
+                pred = self.model(x)
+            torch.cuda.synchronize(self.device)
+            time_mark = time.time()
+            infer_time = (time_mark - start_time) * 1000 / len(names)
+            origin = None
+            if list(self.input_shape[0:2]) != list(self.origin_img_shape[0:2]):
+                origin = self.origin_img_shape
+            results = self.post_process.detect(pred, origin_shape=origin)
+            post_process_time = (time.time() - time_mark) * 1000 / len(names)
+            total_time = infer_time + post_process_time
+            avg_time += total_time * len(names)
+            for filename, ori, boxes in zip(names, oris, results):
+                if len(boxes) == 0:
+                    self._save(os.path.join(result_path, "result_" + filename), ori, [])
+                    self.logger.info("image_name:%s -> no targets, infer time:%.2fms, post_process time:%.2fms, "
+                                     "total time:%.2fms" % (filename, infer_time, post_process_time, total_time))
+                    continue
+                self._save(os.path.join(result_path, "result_" + filename), ori, boxes)
+                self.logger.info("image_name:%s -> detect finished, infer time:%.2fms, post_process time:%.2fms, "
+                                 "total time:%.2fms" % (filename, infer_time, post_process_time, total_time))
+        self.logger.info("detect avg_time: %.2fms" % (avg_time / max(num, 1)))
+
+    def _save(self, path, ori, boxes):
+        if path is None or not os.path.isdir(os.path.dirname(path)):
+            return
+        from PIL import Image, ImageDraw
+        im = Image.fromarray(ori)
+        d = ImageDraw.Draw(im)
+        for *xyxy, conf, cls_score, cls_pred in boxes:
+            d.rectangle([xyxy[0], xyxy[1], xyxy[2], xyxy[3]], outline=tuple(self.colors[int(cls_pred)]), width=3)
+            d.text((xyxy[0], max(0, xyxy[1] - 12)), "%s %.2f" % (self.class_names[int(cls_pred)], conf * cls_score),
+                   fill=tuple(self.colors[int(cls_pred)]))
+        im.save(path)

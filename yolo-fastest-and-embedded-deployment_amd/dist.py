@@ -1,0 +1,55 @@
+"""Data-parallel sharding of a batch of frames over the GPUs of one node (one process per GPU) and the
+single exchange step: an all-gather of fixed-capacity detection records (RCCL over xGMI with backend "nccl";
+gloo on CPU in tests).  The reference has no distributed code; parity is defined as: the concatenation of
+the per-rank results equals the single-GPU result for the same frames, in frame order."""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_frames, rank, world_size):
+    """Contiguous split: rank r owns frames [lo, hi). Sizes differ by at most one."""
+    base, rem = divmod(n_frames, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_records(raw):
+    """dict of tensors (post_process.detect_raw) -> one int32 tensor [n, 1 + 8*kmax]:
+    count | boxes(4k) | scores bit-cast (2k) | cls (k) | src (k).  One buffer -> one collective."""
+    n, kmax = raw["cls"].shape
+    return torch.cat([raw["counts"].view(n, 1), raw["boxes"].reshape(n, 4 * kmax),
+                      raw["scores"].contiguous().view(torch.int32).reshape(n, 2 * kmax), raw["cls"], raw["src"]], dim=1)
+
+
+def unpack_records(buf, kmax):
+    n = buf.shape[0]
+    o = 1
+    boxes = buf[:, o:o + 4 * kmax].reshape(n, kmax, 4); o += 4 * kmax
+    scores = buf[:, o:o + 2 * kmax].contiguous().view(torch.float32).reshape(n, kmax, 2); o += 2 * kmax
+    cls = buf[:, o:o + kmax]; o += kmax
+    src = buf[:, o:o + kmax]
+    return dict(counts=buf[:, 0].contiguous(), boxes=boxes.contiguous(), scores=scores, cls=cls.contiguous(),
+                src=src.contiguous())
+
+
+def all_gather_detections(raw, n_total, group=None):
+    """Every rank contributes its shard's records; every rank gets all n_total frames in frame order.
+    Shards may differ by one frame: each rank pads to the largest shard, the pad is dropped after the gather."""
+    world = dist.get_world_size(group)
+    kmax = raw["cls"].shape[1]
+    rec = pack_records(raw)
+    per = -(-n_total // world)
+    if rec.shape[0] < per:
+        rec = torch.cat([rec, rec.new_zeros((per - rec.shape[0], rec.shape[1]))], dim=0)
+    out = rec.new_empty((world * per, rec.shape[1]))
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(out, rec.contiguous(), group=group)
+    else:
+        parts = [rec.new_empty(rec.shape) for _ in range(world)]
+        dist.all_gather(parts, rec.contiguous(), group=group)
+        out = torch.cat(parts, dim=0)
+    keep = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        keep.append(out[r * per:r * per + (hi - lo)])
+    return unpack_records(torch.cat(keep, dim=0), kmax)

@@ -1,0 +1,191 @@
+"""`YoloFastest(io_params)` -- the reference's module API (src/model_training/model/yolo_fastest.py:69-231)
+with the forward pass executed by the HIP engine (csrc/, C ABI include/yolo_fastest_hip.h).
+
+Drop-in surface kept:
+  * ctor `YoloFastest(io_params)` reading num_cls / input_channel / num_anchors (:70-76);
+  * the 508-key state-dict: `load_state_dict(torch.load(path, map_location=device))` works strictly
+    (src/detect.py:90-91), `.to(device)` / `.eval()` chain (:89);
+  * `model(x)`: x float32 [N,1,H,W] NCHW, H and W multiples of 32 -> `(head_large, head_small)` float32
+    NCHW on the same device (:218).
+The torch.nn modules below are parameter CONTAINERS only (they give the state-dict its names and shapes);
+they are never called.  forward() packs them once (BN fold, packer.py) and runs hand-written HIP kernels.
+There is no CPU path: a non-GPU tensor, train mode, or a missing extension raises.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib, packer
+
+
+def _container(kind, cin, cout, k, stride, relu):
+    if kind == packer.KIND_HEAD:
+        return nn.Conv2d(cin, cout, kernel_size=1, stride=1)
+    if kind == packer.KIND_DECONV:
+        conv = nn.ConvTranspose2d(cin, cout, kernel_size=2, stride=2, padding=0, bias=False)
+    else:
+        conv = nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=(k - 1) // 2, bias=False,
+                         groups=(cin if kind == packer.KIND_DW else 1))
+    mods = [conv, nn.BatchNorm2d(cout)]
+    if relu:
+        mods.append(nn.ReLU())
+    return nn.Sequential(*mods)
+
+
+class _Engine:
+    """One yf_handle (+ its workspace) for a given (H, W, device)."""
+
+    def __init__(self, blob, H, W, max_batch, device_index):
+        self.lib = _lib.lib()
+        self.handle = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(blob, len(blob))
+        _lib.check(self.lib.yf_create(buf, len(blob), H, W, max_batch, device_index, ctypes.byref(self.handle)))
+        self.H, self.W, self.max_batch, self.device_index = H, W, max_batch, device_index
+        self._ws = None
+
+    def workspace(self, N, device):
+        need = ctypes.c_size_t()
+        _lib.check(self.lib.yf_workspace_bytes(self.handle, N, ctypes.byref(need)))
+        if self._ws is None or self._ws.numel() < need.value or self._ws.device != device:
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def set_chunk(self, frames):
+        _lib.check(self.lib.yf_set_chunk(self.handle, int(frames)))
+        self._ws = None
+
+    def close(self):
+        if self.handle:
+            self.lib.yf_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class YoloFastest(nn.Module):
+    def __init__(self, io_params):
+        super().__init__()
+        self.num_cls = io_params["num_cls"]
+        self.input_channel = io_params["input_channel"]
+        num_anchor = io_params["num_anchors"]
+        self.num_anchors = num_anchor
+        self.num_out = num_anchor * (5 + self.num_cls)
+        if self.input_channel != 1 or self.num_out != 24:
+            raise NotImplementedError("the HIP engine implements the shipped configuration: 1 input channel, "
+                                      "3 anchors x (5 + 3 classes) = 24 outputs per cell")
+        # parameter containers, module-definition order of the reference (state-dict order follows it)
+        blocks = {}
+        for name, kind, cin, cout, k, stride, relu in packer.layer_table(self.num_out, self.input_channel):
+            m = _container(kind, cin, cout, k, stride, relu)
+            if "." in name:  # BasicResBlock: resX_Y.conv{1,2,3}
+                blk, sub = name.split(".")
+                if blk not in blocks:
+                    blocks[blk] = nn.Module()
+                    setattr(self, blk, blocks[blk])
+                setattr(blocks[blk], sub, m)
+            else:
+                setattr(self, name, m)
+        self._engines = {}
+        self._blob = None
+        self.chunk = 0  # frames per pass of the layer chain (0 = whole batch); see yf_set_chunk
+
+    # -- weight packing -------------------------------------------------------------------------
+    def _invalidate(self):
+        self._blob = None
+        for e in self._engines.values():
+            e.close()
+        self._engines = {}
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._invalidate()
+        return r
+
+    def _apply(self, fn, *a, **kw):
+        r = super()._apply(fn, *a, **kw)
+        self._invalidate()
+        return r
+
+    def refresh(self):
+        """Re-pack after editing parameters in place (load_state_dict / .to() do it automatically)."""
+        self._invalidate()
+
+    def initialize_weights(self):  # yolo_fastest.py:220-231
+        for m in self.modules():
+            if type(m) is nn.Conv2d:
+                torch.nn.init.kaiming_normal_(m.weight.data, nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif type(m) is nn.BatchNorm2d:
+                m.weight.data.normal_(1.0, 0.02)
+                m.bias.data.fill_(0)
+        self._invalidate()
+
+    def engine(self, H, W, N, device):
+        key = (H, W, device.index if device.index is not None else torch.cuda.current_device())
+        e = self._engines.get(key)
+        if e is None or e.max_batch < N:
+            if e is not None:
+                e.close()
+            if self._blob is None:
+                self._blob = packer.pack_state_dict(self.state_dict(), self.num_out, self.input_channel,
+                                                    self.num_anchors, self.num_cls)
+            e = _Engine(self._blob, H, W, max(N, 256), key[2])
+            if self.chunk:
+                e.set_chunk(self.chunk)
+            self._engines[key] = e
+        return e
+
+    # -- forward --------------------------------------------------------------------------------
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError("YoloFastest (HIP engine) is inference-only: call .eval() first (detect.py:89)")
+        if not x.is_cuda:
+            raise RuntimeError("YoloFastest (HIP engine) has no CPU path: move the model and input to the GPU")
+        if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] % 32 or x.shape[3] % 32:
+            raise ValueError("expected [N,1,H,W] with H and W multiples of 32, got %s" % (tuple(x.shape),))
+        x = x.contiguous().float()
+        N, _, H, W = x.shape
+        e = self.engine(H, W, N, x.device)
+        hl = torch.empty((N, self.num_out, H // 16, W // 16), dtype=torch.float32, device=x.device)
+        hs = torch.empty((N, self.num_out, H // 32, W // 32), dtype=torch.float32, device=x.device)
+        ws = e.workspace(N, x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(e.lib.yf_forward(e.handle, x.data_ptr(), N, hl.data_ptr(), hs.data_ptr(), ws.data_ptr(), ws.numel(),
+                                    ctypes.c_void_p(stream)))
+        return hl, hs
+
+    def probe(self, x, name):
+        """Test hook: the activation the reference module attribute `name` produces, NCHW."""
+        x = x.contiguous().float()
+        N, _, H, W = x.shape
+        e = self.engine(H, W, N, x.device)
+        C, h, w = self.probe_shape(name, H, W)
+        dst = torch.empty((N, C, h, w), dtype=torch.float32, device=x.device)
+        ws = e.workspace(N, x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(e.lib.yf_forward_probe(e.handle, x.data_ptr(), N, name.encode(), dst.data_ptr(),
+                                          dst.numel() * 4, ws.data_ptr(), ws.numel(), ctypes.c_void_p(stream)))
+        return dst
+
+    def probe_shape(self, name, H, W):
+        # spatial size by stage, channels from the layer table
+        tab = {n: (cout, ) for n, _, _, cout, *_ in packer.layer_table(self.num_out, self.input_channel)}
+        lname = name if name in tab else name + ".conv3"
+        C = tab[lname][0]
+        h, w = H, W
+        for n, kind, cin, cout, k, stride, relu in packer.layer_table(self.num_out, self.input_channel):
+            if n == "deconv5_1":
+                h, w = H // 16, W // 16
+            elif n == "conv5_3":
+                h, w = H // 32, W // 32
+            elif stride == 2:
+                h, w = h // 2, w // 2
+            if n == lname:
+                break
+        return C, h, w

@@ -1,0 +1,128 @@
+"""`YOLO_post_process` -- the reference's post-process API (src/detect.py:14-84) executed on the GPU,
+plus the batched entry the reference lacks (it handles batch element 0 only, :46).
+
+Same constructor, same method names, same return conventions:
+  decode_box(pred) -> list of [x1:int, y1:int, x2:int, y2:int, conf:float, cls_score:float, cls_index:int]
+                      for batch element 0, in (head, anchor, row, col) order             (:41-67)
+  non_maxium_supression(sorted_list) -> list; consumes its argument like the reference  (:69-84)
+and `detect(pred)` = decode + class bucketing + stable sort + per-class NMS (+ optional __adjust_coord)
+for EVERY frame of the batch in one kernel launch (yf_decode_nms).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class YOLO_post_process:
+    def __init__(self, conf_thres, nms_thres, num_anchors, num_class, anchors, input_shape):
+        self.conf_thres = conf_thres
+        self.nms_thres = nms_thres
+        self.num_anchors = num_anchors
+        self.bbox_attrs = 5 + num_class
+        self.anchors = anchors
+        self.input_shape = input_shape
+        if num_anchors != 3 or num_class != 3:
+            raise NotImplementedError("the HIP post-process implements 3 anchors x 3 classes")
+        self._anc = (ctypes.c_double * 12)(*[float(v) for head in anchors[:2] for a in head for v in a])
+        self._model = None
+
+    # the kernels need an engine handle (it carries H, W and the device); bind the model that made `pred`
+    def bind(self, model):
+        self._model = model
+        return self
+
+    def _engine(self, pred):
+        hl = pred[0]
+        if not hl.is_cuda:
+            raise RuntimeError("YOLO_post_process (HIP) has no CPU path: pass the GPU tensors the model returned")
+        if self._model is None:
+            raise RuntimeError("call post_process.bind(model) first (the engine handle carries H, W and the device)")
+        H, W = hl.shape[2] * 16, hl.shape[3] * 16
+        if [H, W] != list(self.input_shape[:2]):
+            raise ValueError("pred is for a %dx%d input, input_shape says %s" % (H, W, self.input_shape[:2]))
+        return self._model.engine(H, W, hl.shape[0], hl.device)
+
+    def detect_raw(self, pred, kmax=64, nms_thres=None, origin_shape=None):
+        """Batched. Returns dict of GPU tensors: boxes [N,kmax,4] i32, scores [N,kmax,2] f32, cls, src [N,kmax] i32,
+        counts [N] i32 (see include/yolo_fastest_hip.h for the conventions)."""
+        hl, hs = pred[0].contiguous(), pred[1].contiguous()
+        e = self._engine(pred)
+        N, dev = hl.shape[0], hl.device
+        out = dict(boxes=torch.empty((N, kmax, 4), dtype=torch.int32, device=dev),
+                   scores=torch.empty((N, kmax, 2), dtype=torch.float32, device=dev),
+                   cls=torch.empty((N, kmax), dtype=torch.int32, device=dev),
+                   src=torch.empty((N, kmax), dtype=torch.int32, device=dev),
+                   counts=torch.empty((N,), dtype=torch.int32, device=dev))
+        oh, ow = (origin_shape[0], origin_shape[1]) if origin_shape is not None else (0, 0)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(e.lib.yf_decode_nms(e.handle, hl.data_ptr(), hs.data_ptr(), N, float(self.conf_thres),
+                                       float(self.nms_thres if nms_thres is None else nms_thres), self._anc, int(oh),
+                                       int(ow), kmax, out["boxes"].data_ptr(), out["scores"].data_ptr(),
+                                       out["cls"].data_ptr(), out["src"].data_ptr(), out["counts"].data_ptr(),
+                                       ctypes.c_void_p(stream)))
+        return out
+
+    @staticmethod
+    def to_lists(raw, with_src=False):
+        """GPU result -> per-frame Python lists in the reference's element format."""
+        counts = raw["counts"].cpu().numpy()
+        kmax = raw["boxes"].shape[1]
+        if (counts == -2).any():
+            raise ZeroDivisionError("division by zero")  # detect.py:39, two zero-area boxes compared
+        if (counts > kmax).any():
+            raise OverflowError("more than kmax=%d survivors in a frame (max %d): raise kmax" % (kmax, counts.max()))
+        boxes, scores = raw["boxes"].cpu().numpy(), raw["scores"].cpu().numpy()
+        cls, src = raw["cls"].cpu().numpy(), raw["src"].cpu().numpy()
+        frames = []
+        for f, n in enumerate(counts):
+            L = []
+            for k in range(int(n)):
+                e = [int(boxes[f, k, 0]), int(boxes[f, k, 1]), int(boxes[f, k, 2]), int(boxes[f, k, 3]),
+                     float(scores[f, k, 0]), float(scores[f, k, 1]), int(cls[f, k])]
+                if with_src:
+                    e.append(int(src[f, k]))
+                L.append(e)
+            frames.append(L)
+        return frames
+
+    def detect(self, pred, kmax=64, origin_shape=None, with_src=False):
+        """All frames: [[x1,y1,x2,y2,conf,cls_score,cls], ...] per frame, class-major like detect.py:162-169."""
+        return self.to_lists(self.detect_raw(pred, kmax=kmax, origin_shape=origin_shape), with_src=with_src)
+
+    # -- reference-named methods ------------------------------------------------------------------
+    def decode_box(self, pred):
+        """detect.py:41-67: candidates of batch element 0 in decode order (pre-NMS)."""
+        hl, hs = pred[0][:1], pred[1][:1]
+        ncell = 3 * (hl.shape[2] * hl.shape[3] + hs.shape[2] * hs.shape[3])
+        raw = self.detect_raw((hl, hs), kmax=ncell, nms_thres=float("inf"))  # iou > inf never: nothing suppressed
+        lst = self.to_lists(raw, with_src=True)[0]
+        lst.sort(key=lambda e: e[7])  # back to (head, anchor, row, col) order
+        return [e[:7] for e in lst]
+
+    def non_maxium_supression(self, bbox_list):
+        """detect.py:69-84 on one class's conf-sorted list (mutates it like the reference's pop loop)."""
+        n = len(bbox_list)
+        if n == 0:
+            return []
+        if self._model is None or not self._model._engines:
+            raise RuntimeError("call post_process.bind(model) and run the model once first")
+        e = next(iter(self._model._engines.values()))
+        dev = torch.device("cuda", e.device_index)
+        boxes = torch.tensor([[int(b[0]), int(b[1]), int(b[2]), int(b[3])] for b in bbox_list], dtype=torch.int32,
+                             device=dev)
+        sup = torch.empty((n,), dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(e.lib.yf_nms_sorted(e.handle, boxes.data_ptr(), n, float(self.nms_thres), sup.data_ptr(),
+                                       ctypes.c_void_p(stream)))
+        sup = sup.cpu().numpy()
+        if n and sup[0] == -2:
+            raise ZeroDivisionError("division by zero")
+        results = [bbox_list[i] for i in range(n) if sup[i] == -1]
+        last = max(i for i in range(n) if sup[i] == -1)
+        # the reference leaves [last result] behind iff that result was the only element left when picked
+        tail = [] if np.any(sup == last) else [bbox_list[last]]
+        bbox_list[:] = tail
+        return results
