@@ -59,14 +59,15 @@ __device__ inline CellRef locate(const PostArgs& a, long frame, int cell)
 }
 __device__ inline float logit_at(const CellRef& r, int k) { return r.p[((r.pp * 8 + k) * r.h + r.i) * r.w + r.j]; }
 
-// LDS carve: keys u64[mpad] | boxes int4[ncell] | alive u8[ncell] | kept i32[ncell] | small scalars
+// LDS carve: keys u64[mpad] | boxes int4[ncell] | kept u16[ncell] | alive u8[ncell] | small scalars
+// (worst case 512x640: 8192*8 + 4800*19 = 156.7 KB of the CU's 160 KB)
 __global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncell, int mpad_max)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
     int4* boxes = reinterpret_cast<int4*>(smem + (size_t)mpad_max * 8);
-    int32_t* kept = reinterpret_cast<int32_t*>(smem + (size_t)mpad_max * 8 + (size_t)ncell * 16);
-    unsigned char* alive = smem + (size_t)mpad_max * 8 + (size_t)ncell * 20;
+    uint16_t* kept = reinterpret_cast<uint16_t*>(smem + (size_t)mpad_max * 8 + (size_t)ncell * 16);
+    unsigned char* alive = smem + (size_t)mpad_max * 8 + (size_t)ncell * 18;
     __shared__ int s_wave_cnt[POST_THREADS / 64];
     __shared__ int s_total, s_nkept, s_err;
 
@@ -154,7 +155,7 @@ __global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncel
     // ---- phase 4: greedy NMS, class segments are contiguous in the sorted list ----
     for (int i = 0; i < M; ++i) {
         if (!alive[i]) continue;  // settled by the barrier that ended the sweep which could clear it
-        if (tid == 0) { kept[s_nkept] = i; s_nkept = s_nkept + 1; }
+        if (tid == 0) { kept[s_nkept] = (uint16_t)i; s_nkept = s_nkept + 1; }
         const int4 bi = boxes[i];
         const int ci = (int)(keys[i] >> 45);
         const long area_i = ((long)bi.z - bi.x) * ((long)bi.w - bi.y);
@@ -244,7 +245,7 @@ static int pow2_at_least(int n)
 
 size_t post_lds_bytes(int ncell)
 {
-    size_t b = (size_t)pow2_at_least(ncell) * 8 + (size_t)ncell * 16 + (size_t)ncell * 4 + (size_t)ncell;
+    size_t b = (size_t)pow2_at_least(ncell) * 8 + (size_t)ncell * 16 + (size_t)ncell * 2 + (size_t)ncell;
     return (b + 15) & ~(size_t)15;
 }
 
@@ -253,7 +254,7 @@ int launch_post(const PostArgs& a, int N, hipStream_t s)
     int ncell = 3 * (a.hl * a.wl + a.hs * a.ws);
     if (ncell > 8191) return -1;  // 13-bit cell field of the sort key
     size_t lds = post_lds_bytes(ncell);
-    if (lds > 160 * 1024 - 256) return -1;
+    if (lds > 160 * 1024 - 64) return -1;  // + 28 B of static LDS
     static size_t attr_set = 0;
     if (lds > attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(post_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
