@@ -33,6 +33,7 @@ _SIGS = {
     "yf_nms_sorted": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_double, _c.c_void_p, _c.c_void_p]),
     "yf_num_launches": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int)]),
     "yf_set_chunk": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "yf_set_fusion": (_c.c_int, [_c.c_void_p, _c.c_int]),
 }
 EXPORTS = tuple(_SIGS)
 _lib = None

@@ -86,26 +86,37 @@ struct Tensor {
     int last_use;  // index of the last op reading it
     size_t elems() const { return (size_t)C * H * W; }
 };
+enum OpType { OP_LAYER = 0, OP_FUSED_BLOCK = 1, OP_K19 = 2 };
 struct Op {
-    int layer;         // index into kLayers
+    int layer;         // index into kLayers (fused ops: the first of their layers)
     int in1, in2, res; // tensor ids (-1 = none)
     int out;
     int omode;         // pw: 0 NHWC, 1 NCHW head, 2 deconv
+    int type = OP_LAYER;
+    int l_pre = -1, l_exp = -1, l_dw = -1, l_proj = -1;  // fused block: conv0 (optional), expand, depthwise, project
 };
 
 }  // namespace
+
+struct Plan {
+    int H = 0, W = 0;
+    std::vector<Tensor> tensors;
+    std::vector<Op> ops;
+    std::vector<size_t> slot_elems;   // per-frame capacity of each slot
+    std::vector<size_t> slot_offset;  // per-frame offset (floats), prefix sums
+    size_t frame_floats = 0;          // sum of slot capacities
+};
 
 struct yf_engine {
     int device = 0, H = 0, W = 0, max_batch = 0, chunk = 0;
     float* d_weights = nullptr;
     size_t n_floats = 0;
     uint32_t w_off[kNumLayers], b_off[kNumLayers];
-    std::vector<Tensor> tensors;
-    std::vector<Op> ops;
-    std::vector<size_t> slot_elems;   // per-frame capacity of each slot
-    std::vector<size_t> slot_offset;  // per-frame offset (floats), prefix sums
-    size_t frame_floats = 0;          // sum of slot capacities
+    Plan plans[2];                    // [0] one launch per layer (bring-up / probes), [1] block-fused (default)
+    int fusion = 1;
     size_t head_l_elems = 0, head_s_elems = 0;
+    const Plan& plan() const { return plans[fusion]; }
+    size_t frame_floats_max() const { return plans[0].frame_floats > plans[1].frame_floats ? plans[0].frame_floats : plans[1].frame_floats; }
 };
 
 namespace {
@@ -118,7 +129,7 @@ int find_layer(const char* name)
 }
 
 struct Builder {
-    yf_engine* e;
+    Plan* e;
     int add_tensor(const std::string& name, int C, int H, int W, int slot = 0)
     {
         e->tensors.push_back(Tensor{name, C, H, W, slot, -1});
@@ -139,26 +150,65 @@ struct Builder {
     }
     int resblock(const std::string& n, int x)
     {
+        if (fused) return fused_block(nullptr, (n + ".conv1").c_str(), (n + ".conv2").c_str(), (n + ".conv3").c_str(), x, n.c_str(), true);
         int a = unit((n + ".conv1").c_str(), x);
         int b = unit((n + ".conv2").c_str(), a);
         return unit((n + ".conv3").c_str(), b, n.c_str(), -1, x);
     }
+    // pw-expand -> dw3x3 -> pw-project in one launch (optionally conv0 in front, optionally + residual)
+    int fused_block(const char* pre, const char* ex, const char* dw, const char* pj, int in, const char* out_name, bool res)
+    {
+        Op o{};
+        o.type = OP_FUSED_BLOCK;
+        o.l_pre = pre ? find_layer(pre) : -1;
+        o.l_exp = find_layer(ex); o.l_dw = find_layer(dw); o.l_proj = find_layer(pj);
+        o.layer = pre ? o.l_pre : o.l_exp;
+        const Tensor& ti = e->tensors[in];
+        int H = pre ? ti.H / 2 : ti.H, W = pre ? ti.W / 2 : ti.W;  // expansion resolution
+        int st = kLayers[o.l_dw].stride;
+        o.in1 = in; o.in2 = -1; o.res = res ? in : -1; o.omode = 0;
+        o.out = add_tensor(out_name, kLayers[o.l_proj].cout, H / st, W / st);
+        e->ops.push_back(o);
+        return o.out;
+    }
+    int triple(const char* a, const char* b, const char* c, int x)
+    {
+        if (fused) return fused_block(nullptr, a, b, c, x, c, false);
+        return unit(c, unit(b, unit(a, x)));
+    }
+    bool fused = false;
 };
 
-void build_plan(yf_engine* e)
+void build_plan(Plan* e, bool fused)
 {
     Builder b{e};
+    b.fused = fused;
     int x = b.add_tensor("input", 1, e->H, e->W, BUF_INPUT);
-    for (const char* n : {"conv0", "conv1_2", "conv1_3", "conv1_4"}) x = b.unit(n, x);
+    if (fused) {
+        x = b.fused_block("conv0", "conv1_2", "conv1_3", "conv1_4", x, "conv1_4", false);
+    } else {
+        for (const char* n : {"conv0", "conv1_2", "conv1_3", "conv1_4"}) x = b.unit(n, x);
+    }
     x = b.resblock("res1_1", x);
-    for (const char* n : {"conv1_8", "conv1_9", "conv2_1"}) x = b.unit(n, x);
+    if (fused) {
+        Op o{};
+        o.type = OP_K19;
+        o.layer = find_layer("conv1_8"); o.l_exp = o.layer; o.l_dw = find_layer("conv1_9"); o.l_proj = find_layer("conv2_1");
+        o.in1 = x; o.in2 = -1; o.res = -1; o.omode = 0;
+        o.out = b.add_tensor("conv2_1", 8, e->tensors[x].H / 2, e->tensors[x].W / 2);
+        e->ops.push_back(o);
+        x = o.out;
+    } else {
+        for (const char* n : {"conv1_8", "conv1_9", "conv2_1"}) x = b.unit(n, x);
+    }
     for (const char* n : {"res2_1", "res2_2"}) x = b.resblock(n, x);
-    for (const char* n : {"conv2_2", "conv2_3", "conv3_1"}) x = b.unit(n, x);
+    x = b.triple("conv2_2", "conv2_3", "conv3_1", x);
     for (const char* n : {"res3_1", "res3_2"}) x = b.resblock(n, x);
-    for (const char* n : {"conv3_2", "conv3_3", "conv3_4"}) x = b.unit(n, x);
+    x = b.triple("conv3_2", "conv3_3", "conv3_4", x);
     for (const char* n : {"res3_3", "res3_4", "res3_5", "res3_6"}) x = b.resblock(n, x);
-    for (const char* n : {"conv3_5", "conv3_6", "conv4_1"}) x = b.unit(n, x);
+    x = b.triple("conv3_5", "conv3_6", "conv4_1", x);
     for (const char* n : {"res4_1", "res4_2", "res4_3", "res4_4"}) x = b.resblock(n, x);
+    b.fused = false;  // stride-32 stage and the heads: per-layer kernels (channel-tiled grids) for now
     int conv4_2 = b.unit("conv4_2", x);
     x = b.unit("conv4_3", conv4_2);
     x = b.unit("conv5_1", x);
@@ -218,8 +268,6 @@ void build_plan(yf_engine* e)
         off += (e->slot_elems[s] + 63) & ~(size_t)63;
     }
     e->frame_floats = off;
-    e->head_l_elems = 24u * (e->H / 16) * (e->W / 16);
-    e->head_s_elems = 24u * (e->H / 32) * (e->W / 32);
 }
 
 int chunk_frames(const yf_engine* e, int N)
@@ -233,44 +281,62 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
 {
     if (!e || !d_x || !d_hl || !d_hs || N <= 0) return fail(YF_E_INVALID, "yf_forward: null pointer or N <= 0");
     if (N > e->max_batch) return fail(YF_E_INVALID, "yf_forward: N=%d exceeds max_batch=%d", N, e->max_batch);
+    const Plan& P = e->plan();
     const int cf = chunk_frames(e, N);
-    size_t need = e->frame_floats * (size_t)cf * sizeof(float);
+    size_t need = P.frame_floats * (size_t)cf * sizeof(float);
     if (!ws || ws_bytes < need) return fail(YF_E_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, need);
     HIP_OK(hipSetDevice(e->device));
     int probe_t = -1;
     if (probe) {
-        for (size_t t = 0; t < e->tensors.size(); ++t)
-            if (e->tensors[t].name == probe) probe_t = (int)t;
-        if (probe_t < 0) return fail(YF_E_NOPROBE, "no tensor named '%s' exists in device memory", probe);
-        if (probe_bytes < e->tensors[probe_t].elems() * N * sizeof(float)) return fail(YF_E_INVALID, "probe buffer too small");
+        for (size_t t = 0; t < P.tensors.size(); ++t)
+            if (P.tensors[t].name == probe) probe_t = (int)t;
+        if (probe_t < 0) return fail(YF_E_NOPROBE, "no tensor named '%s' exists in device memory (fusion level %d)", probe, e->fusion);
+        if (probe_bytes < P.tensors[probe_t].elems() * N * sizeof(float)) return fail(YF_E_INVALID, "probe buffer too small");
     }
     float* base = static_cast<float*>(ws);
+    auto W = [&](int layer) { return e->d_weights + e->w_off[layer]; };
+    auto B = [&](int layer) { return e->d_weights + e->b_off[layer]; };
     for (int f0 = 0; f0 < N; f0 += cf) {
         const int n = (N - f0) < cf ? (N - f0) : cf;
         auto ptr = [&](int t) -> float* {
-            const Tensor& T = e->tensors[t];
+            const Tensor& T = P.tensors[t];
             if (T.slot == BUF_INPUT) return const_cast<float*>(d_x) + (size_t)f0 * T.elems();
             if (T.slot == BUF_HEAD_LARGE) return d_hl + (size_t)f0 * T.elems();
             if (T.slot == BUF_HEAD_SMALL) return d_hs + (size_t)f0 * T.elems();
-            return base + e->slot_offset[T.slot] * (size_t)cf;
+            return base + P.slot_offset[T.slot] * (size_t)cf;
         };
-        for (const Op& o : e->ops) {
+        for (const Op& o : P.ops) {
             const LayerSpec& L = kLayers[o.layer];
-            const Tensor& ti = e->tensors[o.in1];
-            const Tensor& to = e->tensors[o.out];
-            const float* w = e->d_weights + e->w_off[o.layer];
-            const float* bv = e->d_weights + e->b_off[o.layer];
+            const Tensor& ti = P.tensors[o.in1];
+            const Tensor& to = P.tensors[o.out];
             int rc = 0;
-            if (L.kind == K_PW || L.kind == K_HEAD || L.kind == K_DECONV) {
-                yf::PwArgs a{ptr(o.in1), o.in2 >= 0 ? ptr(o.in2) : nullptr, w, bv, o.res >= 0 ? ptr(o.res) : nullptr,
+            if (o.type == OP_FUSED_BLOCK) {
+                const bool pre = o.l_pre >= 0;
+                const LayerSpec &LE = kLayers[o.l_exp], &LD = kLayers[o.l_dw], &LP = kLayers[o.l_proj];
+                yf::FbArgs a{};
+                a.in = ptr(o.in1);
+                if (pre) { a.w0 = W(o.l_pre); a.b0 = B(o.l_pre); }
+                a.w1 = W(o.l_exp); a.b1 = B(o.l_exp); a.wd = W(o.l_dw); a.bd = B(o.l_dw); a.w2 = W(o.l_proj); a.b2 = B(o.l_proj);
+                a.out = ptr(o.out);
+                a.H = pre ? ti.H / 2 : ti.H; a.W = pre ? ti.W / 2 : ti.W; a.Ho = to.H; a.Wo = to.W;
+                rc = yf::launch_fused_block(LE.cin, LE.cout, LP.cout, LD.stride, o.res >= 0, LP.relu != 0, pre, a, n, s);
+            } else if (o.type == OP_K19) {
+                yf::K19Args a{};
+                a.in = ptr(o.in1);
+                a.w8 = W(o.l_exp); a.b8 = B(o.l_exp); a.w9 = W(o.l_dw); a.b9 = B(o.l_dw); a.w21 = W(o.l_proj); a.b21 = B(o.l_proj);
+                a.out = ptr(o.out);
+                a.H = ti.H; a.W = ti.W; a.Ho = to.H; a.Wo = to.W;
+                rc = yf::launch_k19(a, n, s);
+            } else if (L.kind == K_PW || L.kind == K_HEAD || L.kind == K_DECONV) {
+                yf::PwArgs a{ptr(o.in1), o.in2 >= 0 ? ptr(o.in2) : nullptr, W(o.layer), B(o.layer), o.res >= 0 ? ptr(o.res) : nullptr,
                              ptr(o.out), (long)n * ti.H * ti.W, (long)ti.H * ti.W, ti.W};
-                int cin2 = o.in2 >= 0 ? e->tensors[o.in2].C : 0;
+                int cin2 = o.in2 >= 0 ? P.tensors[o.in2].C : 0;
                 rc = yf::launch_pw(ti.C, cin2, L.cout, L.relu != 0, o.res >= 0, o.omode, a, s);
             } else if (L.kind == K_DW) {
-                yf::DwArgs a{ptr(o.in1), w, bv, ptr(o.out), (long)n * to.H * to.W * (to.C / 4), ti.C, ti.H, ti.W, to.H, to.W};
+                yf::DwArgs a{ptr(o.in1), W(o.layer), B(o.layer), ptr(o.out), (long)n * to.H * to.W * (to.C / 4), ti.C, ti.H, ti.W, to.H, to.W};
                 rc = yf::launch_dw(L.k, L.stride, a, s);
             } else {
-                yf::DenseArgs a{ptr(o.in1), w, bv, ptr(o.out), (long)n * to.H * to.W, ti.H, ti.W, to.H, to.W};
+                yf::DenseArgs a{ptr(o.in1), W(o.layer), B(o.layer), ptr(o.out), (long)n * to.H * to.W, ti.H, ti.W, to.H, to.W};
                 rc = yf::launch_dense3x3s2(L.cin, L.cout, a, s);
             }
             if (rc) return fail(YF_E_INVALID, "no kernel for layer %s", L.name);
@@ -354,7 +420,12 @@ int yf_create(const void* blob, size_t nbytes, int H, int W, int max_batch, int 
         (void)hipFree(e->d_weights); delete e;
         return fail(YF_E_HIP, "hipMemcpy(weights) failed");
     }
-    build_plan(e);
+    for (int f = 0; f < 2; ++f) {
+        e->plans[f].H = H; e->plans[f].W = W;
+        build_plan(&e->plans[f], f == 1);
+    }
+    e->head_l_elems = 24u * (H / 16) * (W / 16);
+    e->head_s_elems = 24u * (H / 32) * (W / 32);
     *out = e;
     return YF_OK;
 }
@@ -372,7 +443,7 @@ int yf_workspace_bytes(yf_handle h, int N, size_t* out)
 {
     if (!h || !out || N <= 0) return fail(YF_E_INVALID, "yf_workspace_bytes: bad argument");
     // layer-chain slots + internal head buffers for yf_detect
-    *out = (h->frame_floats * (size_t)chunk_frames(h, N) + (h->head_l_elems + h->head_s_elems) * (size_t)N) * sizeof(float) + 256;
+    *out = (h->frame_floats_max() * (size_t)chunk_frames(h, N) + (h->head_l_elems + h->head_s_elems) * (size_t)N) * sizeof(float) + 256;
     return YF_OK;
 }
 
@@ -386,7 +457,7 @@ int yf_forward_probe(yf_handle h, const float* d_x, int N, const char* name, flo
 {
     if (!h || !name || !d_dst) return fail(YF_E_INVALID, "yf_forward_probe: null pointer");
     // heads go to the tail of the workspace
-    size_t chain = h->frame_floats * (size_t)chunk_frames(h, N) * sizeof(float);
+    size_t chain = h->frame_floats_max() * (size_t)chunk_frames(h, N) * sizeof(float);
     size_t heads = (h->head_l_elems + h->head_s_elems) * (size_t)N * sizeof(float);
     if (!ws || ws_bytes < chain + heads) return fail(YF_E_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, chain + heads);
     float* hl = reinterpret_cast<float*>(static_cast<char*>(ws) + chain);
@@ -435,7 +506,7 @@ int yf_detect(yf_handle h, const float* d_x, int N, double conf_thres, double nm
               float* d_hl, float* d_hs, void* ws, size_t ws_bytes, void* stream)
 {
     if (!h) return fail(YF_E_INVALID, "yf_detect: null handle");
-    size_t chain = h->frame_floats * (size_t)chunk_frames(h, N) * sizeof(float);
+    size_t chain = h->frame_floats_max() * (size_t)chunk_frames(h, N) * sizeof(float);
     size_t heads = (h->head_l_elems + h->head_s_elems) * (size_t)N * sizeof(float);
     if (!ws || ws_bytes < chain + ((d_hl && d_hs) ? 0 : heads)) return fail(YF_E_WORKSPACE, "workspace too small");
     float* hl = d_hl ? d_hl : reinterpret_cast<float*>(static_cast<char*>(ws) + chain);
@@ -462,7 +533,14 @@ int yf_preprocess_u8(yf_handle h, const uint8_t* d_u8, int N, int src_h, int src
 int yf_num_launches(yf_handle h, int* out)
 {
     if (!h || !out) return fail(YF_E_INVALID, "bad argument");
-    *out = (int)h->ops.size();
+    *out = (int)h->plan().ops.size();
+    return YF_OK;
+}
+
+int yf_set_fusion(yf_handle h, int level)
+{
+    if (!h || level < 0 || level > 1) return fail(YF_E_INVALID, "fusion level must be 0 or 1");
+    h->fusion = level;
     return YF_OK;
 }
 

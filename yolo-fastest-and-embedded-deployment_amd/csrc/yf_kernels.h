@@ -41,6 +41,30 @@ int launch_dense3x3s2(int cin, int cout, const DenseArgs& a, hipStream_t s);
 void launch_nhwc_to_nchw(const float* in, float* out, long N, int C, long HW, hipStream_t s);
 void launch_preprocess(const uint8_t* in, float* out, long N, int H, int W, int down2, hipStream_t s);
 
+struct FbArgs {
+    const float* in;              // NHWC [N,H,W,CIN]; PRE: the 1-channel net input [N,2H,2W]
+    const float *w0, *b0;         // PRE only: conv0 [9][8], [8]
+    const float *w1, *b1;         // expand  [CIN][CEXP], [CEXP]
+    const float *wd, *bd;         // dw 3x3  [9][CEXP],  [CEXP]
+    const float *w2, *b2;         // project [CEXP][COUT], [COUT]
+    float* out;                   // NHWC [N,Ho,Wo,COUT]
+    int H, W, Ho, Wo;             // expansion-resolution and output-resolution frame sizes
+    int tiles_y, tiles_x;         // filled by the launcher
+};
+int launch_fused_block(int cin, int cexp, int cout, int stride, bool res, bool relu_out, bool pre, const FbArgs& a, int N,
+                       hipStream_t s);
+
+struct K19Args {
+    const float* in;              // NHWC [N,H,W,4] (res1_1 output, stride-2 resolution)
+    const float *w8, *b8;         // conv1_8 [4][24]
+    const float *w9, *b9;         // conv1_9 [3][3][24][24]
+    const float *w21, *b21;       // conv2_1 [24][8]
+    float* out;                   // NHWC [N,Ho,Wo,8]
+    int H, W, Ho, Wo;
+    int tiles_y, tiles_x;
+};
+int launch_k19(K19Args a, int N, hipStream_t s);
+
 struct PostArgs {
     const float* head_large;  // [N,24,hl,wl]
     const float* head_small;  // [N,24,hs,ws]

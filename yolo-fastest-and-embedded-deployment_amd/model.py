@@ -55,6 +55,9 @@ class _Engine:
         _lib.check(self.lib.yf_set_chunk(self.handle, int(frames)))
         self._ws = None
 
+    def set_fusion(self, level):
+        _lib.check(self.lib.yf_set_fusion(self.handle, int(level)))
+
     def close(self):
         if self.handle:
             self.lib.yf_destroy(self.handle)
@@ -93,6 +96,7 @@ class YoloFastest(nn.Module):
         self._engines = {}
         self._blob = None
         self.chunk = 0  # frames per pass of the layer chain (0 = whole batch); see yf_set_chunk
+        self.fusion = 1  # 1 = block-fused kernels (default); 0 = one launch per layer (bring-up, all probes)
 
     # -- weight packing -------------------------------------------------------------------------
     def _invalidate(self):
@@ -139,6 +143,7 @@ class YoloFastest(nn.Module):
             if self.chunk:
                 e.set_chunk(self.chunk)
             self._engines[key] = e
+        e.set_fusion(self.fusion)
         return e
 
     # -- forward --------------------------------------------------------------------------------
