@@ -1,0 +1,143 @@
+"""CPU-only tests: weight packer, blob validation, C-ABI exports, host-side API behaviour (no compute without a GPU)."""
+import ctypes
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import yolo_fastest_amd as yf
+from yolo_fastest_amd import _lib, packer
+from oracle import backbone_oracle as bo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W256 = os.path.join(ROOT, "yolo-fastest-and-embedded-deployment_amd", "assets", "weights", "yolo_fastest_256x320_epoch28.pth")
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return bo.load_state_dict(W256)
+
+
+def test_layer_tables_agree(sd):
+    """packer.layer_table (product) and oracle LAYERS (test infra) describe the same 84 conv+BN units, and the
+    product's expected key list is exactly the reference checkpoint's key list (strict load, detect.py:91)."""
+    t = [l for l in packer.layer_table() if l[1] != packer.KIND_HEAD]
+    assert len(t) == len(bo.LAYERS) == 84
+    kind = {"c": None, "dw": packer.KIND_DW, "dc": packer.KIND_DECONV}
+    for (n, k, ci, co, ks, st, relu), (on, ok, oci, oco, oks, ost, orelu) in zip(t, bo.LAYERS):
+        assert (n, ci, co, ks, st, bool(relu)) == (on, oci, oco, oks, ost, orelu)
+        if kind[ok] is not None:
+            assert k == kind[ok]
+    assert packer.expected_keys() == list(sd.keys())
+
+
+def test_blob_container_and_fold(sd):
+    blob = packer.pack_state_dict(sd)
+    magic, ver, n, num_out, inch, na, nc, nfl = struct.unpack_from("<8s6IQ", blob, 0)
+    assert (magic, ver, n, num_out, inch, na, nc) == (b"YFHIPW01", 1, 86, 24, 1, 3, 3)
+    assert len(blob) == 64 + 64 * 86 + 4 * nfl
+    u = packer.unpack(blob)
+    assert list(u.keys()) == [l[0] for l in packer.layer_table()]
+    # fold identity on one unit of each kind: conv(x, w)*s + b' == BN(conv(x, w))
+    g = torch.Generator().manual_seed(0)
+    for name in ("conv1_2", "conv1_3", "conv1_9", "deconv5_1", "res5_1.conv2"):
+        L = u[name]
+        ci, co, k = L["cin"], L["cout"], L["k"]
+        x = torch.randn(2, ci, 9, 11, generator=g)
+        want = bo._unit(sd, name, x)
+        w, b = torch.from_numpy(L["w"].copy()), torch.from_numpy(L["b"].copy())
+        if L["kind"] == packer.KIND_PW:
+            y = F.conv2d(x, w.view(ci, co).t().reshape(co, ci, 1, 1), b)
+        elif L["kind"] == packer.KIND_DW:
+            y = F.conv2d(x, w.view(k, k, co).permute(2, 0, 1).reshape(co, 1, k, k), b, stride=L["stride"], padding=(k - 1) // 2, groups=co)
+        elif L["kind"] == packer.KIND_DENSE:
+            y = F.conv2d(x, w.view(k, k, ci, co).permute(3, 2, 0, 1), b, stride=L["stride"], padding=1)
+        else:
+            y = F.conv_transpose2d(x, w.view(2, 2, ci, co).permute(2, 3, 0, 1), b, stride=2)
+        y = F.relu(y) if L["relu"] else y
+        assert (y - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item()), name
+    # heads keep their own bias, no BN
+    assert np.allclose(u["head_5"]["b"], sd["head_5.bias"].numpy())
+    assert np.allclose(u["head_4"]["w"].reshape(96, 24), sd["head_4.weight"].numpy()[:, :, 0, 0].T)
+
+
+def test_strict_key_check_like_load_state_dict(sd):
+    bad = dict(sd)
+    bad.pop("conv0.0.weight")
+    with pytest.raises(RuntimeError, match="Missing key"):
+        packer.pack_state_dict(bad)
+    bad = dict(sd)
+    bad["extra.weight"] = torch.zeros(1)
+    with pytest.raises(RuntimeError, match="Unexpected key"):
+        packer.pack_state_dict(bad)
+    m = yf.YoloFastest(yf.config_params["io_params"])
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({k: v for k, v in sd.items() if k != "head_4.bias"})
+    assert str(m.load_state_dict(sd)) == "<All keys matched successfully>"
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    for k, v in m.state_dict().items():
+        assert v.shape == sd[k].shape, k
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "yolo_fastest_hip.h")).read()
+    declared = set(re.findall(r"\b(yf_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 14
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert declared == set(_lib.EXPORTS)
+    assert _lib.lib().yf_abi_version() == 1
+
+
+def test_create_rejects_bad_arguments_before_touching_the_gpu(sd):
+    lib = _lib.lib()
+    h = ctypes.c_void_p()
+    blob = packer.pack_state_dict(sd)
+    buf = ctypes.create_string_buffer(blob, len(blob))
+    assert lib.yf_create(buf, len(blob), 250, 320, 4, 0, ctypes.byref(h)) == _lib.YF_E_INVALID  # rows not % 32
+    assert b"multiples of 32" in lib.yf_last_error_string()
+    assert lib.yf_create(buf, len(blob), 256, 320, 0, 0, ctypes.byref(h)) == _lib.YF_E_INVALID
+    bad = bytearray(blob); bad[0:8] = b"NOTABLOB"
+    b2 = ctypes.create_string_buffer(bytes(bad), len(bad))
+    assert lib.yf_create(b2, len(bad), 256, 320, 4, 0, ctypes.byref(h)) == _lib.YF_E_BLOB
+    bad = bytearray(blob); struct.pack_into("<I", bad, 64 + 64 * 5 + 32 + 8, 999)  # layer 5: wrong cout
+    b3 = ctypes.create_string_buffer(bytes(bad), len(bad))
+    assert lib.yf_create(b3, len(bad), 256, 320, 4, 0, ctypes.byref(h)) == _lib.YF_E_BLOB
+    assert b"res1_1.conv2" in lib.yf_last_error_string()
+    assert lib.yf_create(buf, 100, 256, 320, 4, 0, ctypes.byref(h)) == _lib.YF_E_BLOB  # truncated
+    assert lib.yf_destroy(None) == 0
+
+
+def test_no_cpu_fallback(sd):
+    m = yf.YoloFastest(yf.config_params["io_params"])
+    m.load_state_dict(sd)
+    with pytest.raises(RuntimeError, match="eval"):
+        m(torch.zeros(1, 1, 256, 320))
+    m.eval()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.zeros(1, 1, 256, 320))
+    io = yf.io_params_for(256)
+    post = yf.YOLO_post_process(io["conf_thre"], io["nms_thre"], 3, 3, io["anchors"], io["input_shape"]).bind(m)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        post.detect((torch.zeros(1, 24, 16, 20), torch.zeros(1, 24, 8, 10)))
+    with pytest.raises(NotImplementedError):
+        yf.YoloFastest(dict(io, input_channel=3))
+    # the product package never imports the oracle
+    import sys
+    pkg = os.path.join(ROOT, "yolo-fastest-and-embedded-deployment_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            assert "oracle" not in open(os.path.join(pkg, fn)).read().replace("# oracle", ""), fn
+
+
+def test_config_mirror():
+    io = yf.config_params["io_params"]
+    assert io["anchors"][0] == [[10, 13], [16, 30], [33, 23]] and io["input_shape"] == [256, 320, 1]
+    assert io["conf_thre"] == 0.5 and io["nms_thre"] == 0.2 and io["class_names"] == ["carrier", "defender", "destroyer"]
+    io5 = yf.io_params_for(512)
+    assert io5["input_shape"] == [512, 640, 1] and io5["anchors"][0] == [[150, 75], [100, 100], [75, 150]]

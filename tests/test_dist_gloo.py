@@ -1,0 +1,73 @@
+"""N > 1 path on CPU: world_size-2 gloo.  Frames are sharded contiguously; the single exchange step is an
+all-gather of fixed-capacity detection records; the gathered result must equal the unsharded one, in frame order."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from yolo_fastest_amd import dist as yfd
+
+
+def _fake_raw(n, kmax, seed):
+    g = torch.Generator().manual_seed(seed)
+    counts = torch.randint(0, kmax + 1, (n,), generator=g, dtype=torch.int32)
+    return dict(counts=counts,
+                boxes=torch.randint(-50, 700, (n, kmax, 4), generator=g, dtype=torch.int32),
+                scores=torch.rand((n, kmax, 2), generator=g, dtype=torch.float32),
+                cls=torch.randint(0, 3, (n, kmax), generator=g, dtype=torch.int32),
+                src=torch.randint(0, 1200, (n, kmax), generator=g, dtype=torch.int32))
+
+
+def test_shard_range_covers_everything():
+    for n in (1, 7, 8, 255, 256, 2048):
+        for w in (1, 2, 3, 8):
+            spans = [yfd.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_pack_unpack_roundtrip():
+    raw = _fake_raw(5, 7, 0)
+    back = yfd.unpack_records(yfd.pack_records(raw), 7)
+    for k in raw:
+        assert torch.equal(raw[k], back[k]), k
+
+
+def _worker(rank, world, port, n_total, kmax, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = _fake_raw(n_total, kmax, 123)
+    lo, hi = yfd.shard_range(n_total, rank, world)
+    mine = {k: v[lo:hi].contiguous() for k, v in full.items()}
+    got = yfd.all_gather_detections(mine, n_total)
+    ok = all(torch.equal(got[k], full[k]) for k in full)
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_all_gather_two_ranks_equals_unsharded():
+    ctx = mp.get_context("spawn")
+    for n_total in (8, 7):  # even and ragged split
+        q = ctx.Queue()
+        port = _free_port()
+        ps = [ctx.Process(target=_worker, args=(r, 2, port, n_total, 5, q)) for r in range(2)]
+        for p in ps:
+            p.start()
+        res = sorted(q.get(timeout=120) for _ in ps)
+        for p in ps:
+            p.join(60)
+        assert res == [(0, True), (1, True)]
