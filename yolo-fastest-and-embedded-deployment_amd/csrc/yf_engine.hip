@@ -94,6 +94,7 @@ struct Op {
     int omode;         // pw: 0 NHWC, 1 NCHW head, 2 deconv
     int type = OP_LAYER;
     int l_pre = -1, l_exp = -1, l_dw = -1, l_proj = -1;  // fused block: conv0 (optional), expand, depthwise, project
+    long mfma_off = -1;  // >= 0: pointwise layer runs on the matrix cores; offset of its packed B fragments
 };
 
 }  // namespace
@@ -110,6 +111,7 @@ struct Plan {
 struct yf_engine {
     int device = 0, H = 0, W = 0, max_batch = 0, chunk = 0;
     float* d_weights = nullptr;
+    float* d_wmfma = nullptr;         // MFMA B fragments of the GEMM-worthy pointwise layers (fused plan)
     size_t n_floats = 0;
     uint32_t w_off[kNumLayers], b_off[kNumLayers];
     Plan plans[2];                    // [0] one launch per layer (bring-up / probes), [1] block-fused (default)
@@ -207,8 +209,8 @@ void build_plan(Plan* e, bool fused)
     x = b.triple("conv3_2", "conv3_3", "conv3_4", x);
     for (const char* n : {"res3_3", "res3_4", "res3_5", "res3_6"}) x = b.resblock(n, x);
     x = b.triple("conv3_5", "conv3_6", "conv4_1", x);
+    b.fused = false;  // stride-16 residual blocks, stride-32 stage, heads: matrix-core GEMMs + depthwise kernels
     for (const char* n : {"res4_1", "res4_2", "res4_3", "res4_4"}) x = b.resblock(n, x);
-    b.fused = false;  // stride-32 stage and the heads: per-layer kernels (channel-tiled grids) for now
     int conv4_2 = b.unit("conv4_2", x);
     x = b.unit("conv4_3", conv4_2);
     x = b.unit("conv5_1", x);
@@ -331,7 +333,12 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                 yf::PwArgs a{ptr(o.in1), o.in2 >= 0 ? ptr(o.in2) : nullptr, W(o.layer), B(o.layer), o.res >= 0 ? ptr(o.res) : nullptr,
                              ptr(o.out), (long)n * ti.H * ti.W, (long)ti.H * ti.W, ti.W};
                 int cin2 = o.in2 >= 0 ? P.tensors[o.in2].C : 0;
-                rc = yf::launch_pw(ti.C, cin2, L.cout, L.relu != 0, o.res >= 0, o.omode, a, s);
+                if (o.mfma_off >= 0) {
+                    a.w = e->d_wmfma + o.mfma_off;
+                    rc = yf::launch_pw_mfma(ti.C, cin2, L.cout, L.relu != 0, o.res >= 0, o.omode, a, s);
+                } else {
+                    rc = yf::launch_pw(ti.C, cin2, L.cout, L.relu != 0, o.res >= 0, o.omode, a, s);
+                }
             } else if (L.kind == K_DW) {
                 yf::DwArgs a{ptr(o.in1), W(o.layer), B(o.layer), ptr(o.out), (long)n * to.H * to.W * (to.C / 4), ti.C, ti.H, ti.W, to.H, to.W};
                 rc = yf::launch_dw(L.k, L.stride, a, s);
@@ -426,6 +433,32 @@ int yf_create(const void* blob, size_t nbytes, int H, int W, int max_batch, int 
     }
     e->head_l_elems = 24u * (H / 16) * (W / 16);
     e->head_s_elems = 24u * (H / 32) * (W / 32);
+    {   // matrix-core layers of the fused plan: pre-pack W[K][N] into MFMA B fragments (host) and upload
+        const float* hw = reinterpret_cast<const float*>(static_cast<const char*>(blob) + data_off);
+        std::vector<float> packed;
+        for (Op& o : e->plans[1].ops) {
+            if (o.type != OP_LAYER) continue;
+            const LayerSpec& L = kLayers[o.layer];
+            if (L.kind != K_PW && L.kind != K_HEAD && L.kind != K_DECONV) continue;
+            const Plan& P = e->plans[1];
+            int c1 = P.tensors[o.in1].C, c2 = o.in2 >= 0 ? P.tensors[o.in2].C : 0;
+            if (!yf::mfma_has_kernel(c1, c2, L.cout, L.relu != 0, o.res >= 0, o.omode)) continue;
+            const int nq = L.kind == K_DECONV ? 4 : 1;
+            size_t per = yf::mfma_packed_floats(c1, c2, L.cout);
+            o.mfma_off = (long)packed.size();
+            packed.resize(packed.size() + per * nq);
+            for (int qd = 0; qd < nq; ++qd)
+                yf::mfma_pack_weights(hw + e->w_off[o.layer] + (size_t)qd * L.cin * L.cout, c1, c2, L.cout,
+                                      packed.data() + o.mfma_off + per * qd);
+        }
+        if (!packed.empty()) {
+            if (hipMalloc(&e->d_wmfma, packed.size() * 4) != hipSuccess ||
+                hipMemcpy(e->d_wmfma, packed.data(), packed.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+                (void)hipFree(e->d_weights); (void)hipFree(e->d_wmfma); delete e;
+                return fail(YF_E_HIP, "hipMalloc/hipMemcpy(MFMA weights) failed");
+            }
+        }
+    }
     *out = e;
     return YF_OK;
 }
@@ -435,6 +468,7 @@ int yf_destroy(yf_handle h)
     if (!h) return YF_OK;
     (void)hipSetDevice(h->device);
     (void)hipFree(h->d_weights);
+    (void)hipFree(h->d_wmfma);
     delete h;
     return YF_OK;
 }

@@ -37,6 +37,11 @@ struct DenseArgs {
 
 int launch_pw(int cin1, int cin2, int cout, bool relu, bool res, int omode, const PwArgs& a, hipStream_t s);
 int launch_dw(int k, int stride, const DwArgs& a, hipStream_t s);
+// matrix-core pointwise GEMM (yf_mfma_kernels.hip); a.w points at the layer's PACKED B fragments
+int launch_pw_mfma(int cin1, int cin2, int cout, bool relu, bool res, int omode, const PwArgs& a, hipStream_t s);
+bool mfma_has_kernel(int cin1, int cin2, int cout, bool relu, bool res, int omode);
+size_t mfma_packed_floats(int k1, int k2, int n);
+void mfma_pack_weights(const float* w, int k1, int k2, int n, float* out);
 int launch_dense3x3s2(int cin, int cout, const DenseArgs& a, hipStream_t s);
 void launch_nhwc_to_nchw(const float* in, float* out, long N, int C, long HW, hipStream_t s);
 void launch_preprocess(const uint8_t* in, float* out, long N, int H, int W, int down2, hipStream_t s);

@@ -1,0 +1,199 @@
+// yf_mfma_kernels.hip -- pointwise (1x1) convolutions with GEMM-worthy channel counts on the matrix cores.
+//
+// Replaces torch.nn.Conv2d(k=1)+BN(+ReLU) of the stride-16/32 stages and the two detection heads
+// (src/model_training/model/yolo_fastest.py:108-146, forward :182-216), the 2x2 stride-2 ConvTranspose2d
+// (deconv5_1 = four 96x96 GEMMs writing interleaved pixels, :138) and the 1x1 conv over the channel concat
+// (conv4_1_1 reads its two sources through two pointers, :209-211).
+//
+// Out[M, N] = act(A[M, K] . W[K, N] + b) (+ residual), M = pixels of the whole batch (NHWC rows), fp32 in, fp32
+// accumulate: v_mfma_f32_16x16x4_f32 is exact fp32 (a k-ordered fmaf chain) at the fp32 vector peak rate, but one
+// A value per lane feeds 16 outputs and one B value 16 rows, so there is no per-FMA weight traffic at all.
+//   * one wave = 16*MT rows x all N columns, no LDS, no barriers (waves are independent);
+//   * A fragment: lane (r = l&15, q = l>>4) loads the 16 B  A[row r][k0 + 4q .. 4q+3]  -> four MFMA k-steps whose
+//     k index is permuted (k = k0 + 4q + j); the permutation is folded into B, which the host pre-packs per
+//     (k-step, n-tile) in lane order, so a B fragment is one coalesced 256-B load (L1/L2 resident, ~40 KB/layer);
+//   * C fragment: col = l&15, row = 4q + reg  ->  64-B row segments on store.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "yf_kernels.h"
+
+namespace yf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// number of MFMA k-steps for a source of K channels: 4 per full 16-block, 2 for a trailing 8-block
+__host__ __device__ constexpr int ksteps(int K) { return (K / 16) * 4 + ((K % 16) ? 2 : 0); }
+
+template <int KS, int NT, int MT>
+__device__ __forceinline__ void mfma_source(const float* __restrict__ in, const long (&rows)[MT], int q,
+                                            const float* __restrict__ bp, int lane, f32x4 (&acc)[MT][NT])
+{
+    // full 16-wide k blocks
+    constexpr int NB = KS / 16;
+#pragma unroll 2
+    for (int kb = 0; kb < NB; ++kb) {
+        float4 av[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const float4*>(in + rows[mt] * KS + kb * 16 + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float bv = bp[((kb * 4 + j) * NT + nt) * 64 + lane];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&av[mt])[j], bv, acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+    if constexpr (KS % 16 != 0) {  // trailing 8 channels: 8 B per lane, two k-steps
+        static_assert(KS % 16 == 8, "channel counts are multiples of 8");
+        float2 av[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const float2*>(in + rows[mt] * KS + NB * 16 + 2 * q);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float bv = bp[((NB * 4 + j) * NT + nt) * 64 + lane];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&av[mt])[j], bv, acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int K1, int K2, int N, int MT, bool RELU, bool RES, int OMODE>
+__global__ void __launch_bounds__(256) pw_mfma_kernel(PwArgs a)
+{
+    constexpr int NT = (N + 15) / 16;
+    constexpr int S1 = ksteps(K1), S2 = K2 ? ksteps(K2) : 0;
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long row0 = wave * (16 * MT);
+    if (row0 >= a.npix) return;  // wave-uniform
+    const float* __restrict__ bp = a.w + (OMODE == 2 ? (size_t)blockIdx.z * (S1 + S2) * NT * 64 : 0);
+
+    long rows[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        long rr = row0 + mt * 16 + r;
+        rows[mt] = rr < a.npix ? rr : a.npix - 1;  // clamp loads, guard stores
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    mfma_source<K1, NT, MT>(a.in1, rows, q, bp, lane, acc);
+    if constexpr (K2 > 0) mfma_source<K2, NT, MT>(a.in2, rows, q, bp + (size_t)S1 * NT * 64, lane, acc);
+
+    // epilogue: lane holds column c = nt*16 + r of rows row0 + mt*16 + 4q + reg
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int c = nt * 16 + r;
+        if (c >= N) continue;
+        const float bias = a.b[c];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const long row = row0 + mt * 16 + 4 * q + reg;
+                if (row >= a.npix) continue;
+                float v = acc[mt][nt][reg] + bias;
+                if constexpr (RES) v += a.res[row * N + c];
+                if constexpr (RELU) v = fmaxf(v, 0.f);
+                if constexpr (OMODE == 0) {
+                    a.out[row * N + c] = v;
+                } else if constexpr (OMODE == 1) {  // NCHW (the heads)
+                    const long n = row / a.HW, hw = row - n * a.HW;
+                    a.out[(n * N + c) * a.HW + hw] = v;
+                } else {  // ConvTranspose2d k=2 s=2: quadrant (dy,dx) -> pixel (2y+dy, 2x+dx)
+                    const long n = row / a.HW, hw = row - n * a.HW;
+                    const int y = (int)(hw / a.W), x = (int)(hw - (long)y * a.W);
+                    const int dy = blockIdx.z >> 1, dx = blockIdx.z & 1;
+                    const long opix = (n * (2 * (a.HW / a.W)) + 2 * y + dy) * (2 * a.W) + 2 * x + dx;
+                    a.out[opix * N + c] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int K1, int K2, int N, int MT, bool RELU, bool RES, int OMODE>
+static int launch_t(const PwArgs& a, hipStream_t s)
+{
+    const long waves = (a.npix + 16 * MT - 1) / (16 * MT);
+    dim3 grid((unsigned)((waves + 3) / 4), 1, OMODE == 2 ? 4 : 1);
+    hipLaunchKernelGGL((pw_mfma_kernel<K1, K2, N, MT, RELU, RES, OMODE>), grid, dim3(256), 0, s, a);
+    return 0;
+}
+
+// rows per wave: 16*MT. MT is picked so that even the smallest batch-256 stage (20 480 rows) fills 256 CUs.
+//      (k1, k2, n, MT, relu, residual, omode)
+#define YF_MFMA_SHAPES(MF)                                                          \
+    MF(24, 0, 136, 2, true, false, 0)    /* res4_x.conv1, conv4_2       (stride 16) */ \
+    MF(136, 0, 24, 2, false, true, 0)    /* res4_x.conv3 */                            \
+    MF(136, 0, 48, 1, true, false, 0)    /* conv5_1                     (stride 32) */ \
+    MF(48, 0, 224, 1, true, false, 0)    /* res5_x.conv1 */                            \
+    MF(224, 0, 48, 1, false, true, 0)    /* res5_x.conv3 */                            \
+    MF(48, 0, 96, 1, true, false, 0)     /* conv5_2 */                                 \
+    MF(96, 0, 128, 1, false, false, 0)   /* conv5_4 */                                 \
+    MF(128, 0, 128, 1, false, false, 0)  /* conv5_6 */                                 \
+    MF(128, 0, 24, 1, false, false, 1)   /* head_5  (NCHW) */                          \
+    MF(96, 0, 96, 1, true, false, 2)     /* deconv5_1 (4 quadrants) */                 \
+    MF(136, 96, 96, 2, true, false, 0)   /* conv4_1_1 over cat(conv4_2, deconv5_1) */  \
+    MF(96, 0, 96, 2, false, false, 0)    /* conv4_1_3, conv4_1_5 */                    \
+    MF(96, 0, 24, 2, false, false, 1)    /* head_4  (NCHW) */
+
+int launch_pw_mfma(int cin1, int cin2, int cout, bool relu_, bool res_, int omode, const PwArgs& a, hipStream_t s)
+{
+#define MF(k1, k2, n, mt, relu, res, om)                                                        \
+    if (cin1 == k1 && cin2 == k2 && cout == n && relu_ == relu && res_ == res && omode == om)    \
+        return launch_t<k1, k2, n, mt, relu, res, om>(a, s);
+    YF_MFMA_SHAPES(MF)
+#undef MF
+    return -1;
+}
+
+bool mfma_has_kernel(int cin1, int cin2, int cout, bool relu_, bool res_, int omode)
+{
+#define MF(k1, k2, n, mt, relu, res, om) \
+    if (cin1 == k1 && cin2 == k2 && cout == n && relu_ == relu && res_ == res && omode == om) return true;
+    YF_MFMA_SHAPES(MF)
+#undef MF
+    return false;
+}
+
+// Host-side packing of W[K][N] (row-major, as in the blob) into MFMA B fragments, see the file header.
+//   out[(step*NT + nt)*64 + lane] = W[kidx(step, lane>>4)][nt*16 + (lane&15)]   (0 beyond N)
+// Sources of a concat are packed one after the other (K = K1 + K2 rows of W).
+size_t mfma_packed_floats(int k1, int k2, int n) { return (size_t)(ksteps(k1) + (k2 ? ksteps(k2) : 0)) * ((n + 15) / 16) * 64; }
+
+void mfma_pack_weights(const float* w, int k1, int k2, int n, float* out)
+{
+    const int NT = (n + 15) / 16;
+    size_t step = 0;
+    int kbase = 0;
+    for (int src = 0; src < 2; ++src) {
+        const int K = src == 0 ? k1 : k2;
+        if (K == 0) continue;
+        const int NB = K / 16;
+        for (int kb = 0; kb <= NB; ++kb) {
+            const int per = kb < NB ? 4 : ((K % 16) ? 2 : 0);  // k values per lane-quad in this block
+            for (int j = 0; j < per; ++j, ++step)
+                for (int nt = 0; nt < NT; ++nt)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int q = lane >> 4, c = nt * 16 + (lane & 15);
+                        const int k = kbase + kb * 16 + per * q + j;
+                        out[(step * NT + nt) * 64 + lane] = c < n ? w[(size_t)k * n + c] : 0.f;
+                    }
+        }
+        kbase += K;
+    }
+}
+
+}  // namespace yf
