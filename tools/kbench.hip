@@ -1,0 +1,137 @@
+// kbench.hip -- stand-alone micro-benchmark of kernel template variants (developer tool, not product).
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-fast-math -ffp-contract=off -I yolo-fastest-and-embedded-deployment_amd/csrc \
+//         tools/kbench.hip -o gpurun_out/kbench && gpurun_out/kbench
+// Times each variant with HIP events over `reps` launches on random data (batch 256 of the 320x256 config).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "yf_fused_kernels.hip"
+#include "yf_mfma_kernels.hip"
+#include "yf_conv_kernels.hip"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+static float* dev_rand(size_t n, float scale = 1.f)
+{
+    std::vector<float> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = scale * ((rand() & 0xffff) / 32768.f - 1.f);
+    float* d;
+    CK(hipMalloc(&d, n * 4));
+    CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+    return d;
+}
+
+template <typename F>
+static float time_us(F&& launch, int reps = 20)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) launch();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) launch();
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    CK(hipGetLastError());
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return ms * 1000.f / reps;
+}
+
+using namespace yf;
+
+template <int CIN, int CEXP, int COUT, int S, bool RES, bool PRE, int TYB, int TXB, int BH, int BW, int EC, int CG>
+static void bench_fb(const char* tag, int N, int H, int W)
+{
+    FbArgs a{};
+    const int Ho = H / S, Wo = W / S;
+    a.in = dev_rand(PRE ? (size_t)N * 4 * H * W : (size_t)N * H * W * CIN);
+    a.w0 = dev_rand(72, 0.3f); a.b0 = dev_rand(8, 0.1f);
+    a.w1 = dev_rand((size_t)CIN * CEXP, 0.3f); a.b1 = dev_rand(CEXP, 0.1f);
+    a.wd = dev_rand(9 * CEXP, 0.3f); a.bd = dev_rand(CEXP, 0.1f);
+    a.w2 = dev_rand((size_t)CEXP * COUT, 0.3f); a.b2 = dev_rand(COUT, 0.1f);
+    float* out; CK(hipMalloc(&out, (size_t)N * Ho * Wo * COUT * 4)); a.out = out;
+    a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
+    a.tiles_y = (Ho + TYB * BH - 1) / (TYB * BH); a.tiles_x = (Wo + TXB * BW - 1) / (TXB * BW);
+    dim3 grid(N * a.tiles_y * a.tiles_x);
+    float us = time_us([&] { hipLaunchKernelGGL((fused_block_kernel<CIN, CEXP, COUT, S, RES, false, PRE, TYB, TXB, BH, BW, EC, CG>), grid, dim3(TYB * TXB), 0, 0, a); });
+    double macs = (double)N * (PRE ? H * W * 72.0 : 0) + (double)N * H * W * CIN * CEXP + (double)N * Ho * Wo * CEXP * (9 + COUT);
+    printf("%-44s thr=%4d tile=%2dx%-2d EC=%2d CG=%2d grid=%6u  %8.1f us  %6.2f TMAC/s\n", tag, TYB * TXB, TYB * BH, TXB * BW, EC, CG, grid.x, us, macs / us * 1e-6);
+}
+
+template <int K1, int N, int MT, bool RELU, bool RES>
+static void bench_mfma(const char* tag, long M)
+{
+    PwArgs a{};
+    a.in1 = dev_rand((size_t)M * K1); a.in2 = nullptr;
+    a.w = dev_rand(mfma_packed_floats(K1, 0, N), 0.2f); a.b = dev_rand(N, 0.1f);
+    a.res = RES ? dev_rand((size_t)M * N) : nullptr;
+    float* out; CK(hipMalloc(&out, (size_t)M * N * 4)); a.out = out;
+    a.npix = M; a.HW = 320; a.W = 20;
+    const long waves = (M + 16 * MT - 1) / (16 * MT);
+    dim3 grid((unsigned)((waves + 3) / 4));
+    float us = time_us([&] { hipLaunchKernelGGL((pw_mfma_kernel<K1, 0, N, MT, RELU, RES, 0>), grid, dim3(256), 0, 0, a); });
+    printf("%-44s M=%7ld MT=%d grid=%6u  %8.1f us  %6.2f TMAC/s  out %.1f GB/s\n", tag, M, MT, grid.x, us, (double)M * K1 * N / us * 1e-6, (double)M * N * 4 / us * 1e-3);
+}
+
+int main(int argc, char** argv)
+{
+    const int N = 256;
+    const char* which = argc > 1 ? argv[1] : "all";
+    auto on = [&](const char* k) { return !strcmp(which, "all") || !strcmp(which, k); };
+    if (on("s8")) {
+        printf("--- res3_3..6: 16/96 residual block at 32x40 ---\n");
+        bench_fb<16, 96, 16, 1, true, false, 16, 20, 1, 2, 8, 8>("current 16x40 tile, 1x2", N, 32, 40);
+        bench_fb<16, 96, 16, 1, true, false, 16, 20, 1, 1, 8, 8>("16x20 tile 1x1", N, 32, 40);
+        bench_fb<16, 96, 16, 1, true, false, 16, 20, 1, 1, 16, 8>("16x20 tile 1x1 EC16", N, 32, 40);
+        bench_fb<16, 96, 16, 1, true, false, 16, 20, 1, 1, 16, 16>("16x20 tile 1x1 EC16 CG16", N, 32, 40);
+        bench_fb<16, 96, 16, 1, true, false, 8, 40, 1, 1, 8, 8>("8x40 tile 1x1", N, 32, 40);
+        bench_fb<16, 96, 16, 1, true, false, 16, 20, 1, 2, 16, 8>("16x40 tile 1x2 EC16", N, 32, 40);
+        bench_fb<16, 96, 16, 1, true, false, 16, 20, 2, 2, 8, 8>("32x40 tile 2x2 (whole frame)", N, 32, 40);
+        bench_fb<16, 96, 16, 1, true, false, 8, 16, 1, 1, 8, 8>("8x16 tile 1x1 (128 thr)", N, 32, 40);
+        bench_fb<16, 96, 16, 1, true, false, 8, 8, 1, 1, 8, 8>("8x8 tile 1x1 (64 thr)", N, 32, 40);
+        bench_fb<16, 96, 16, 1, true, false, 8, 8, 2, 2, 8, 8>("16x16 tile 2x2 (64 thr)", N, 32, 40);
+        bench_fb<16, 96, 16, 1, true, false, 8, 16, 2, 2, 8, 8>("16x32 tile 2x2 (128 thr)", N, 32, 40);
+    }
+    if (on("s4")) {
+        printf("--- res2_x: 8/32 residual block at 64x80 ---\n");
+        bench_fb<8, 32, 8, 1, true, false, 32, 8, 2, 2, 8, 8>("current 64x16 tile 2x2", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 16, 16, 2, 2, 8, 8>("32x32 tile 2x2", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 16, 8, 2, 2, 8, 8>("32x16 tile 2x2 (128 thr)", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 16, 16, 1, 1, 8, 8>("16x16 tile 1x1", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 32, 8, 2, 2, 16, 8>("64x16 tile 2x2 EC16", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 16, 20, 1, 2, 8, 8>("16x40 tile 1x2 (320 thr)", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 8, 8, 2, 2, 8, 8>("16x16 tile 2x2 (64 thr)", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 8, 8, 4, 2, 8, 8>("32x16 tile 4x2 (64 thr)", N, 64, 80);
+    }
+    if (on("stem")) {
+        printf("--- stem conv0+conv1_2/1_3/1_4 and res1_1 at 128x160 ---\n");
+        bench_fb<8, 8, 4, 1, false, true, 16, 16, 2, 2, 8, 8>("stem current 32x32 2x2", N, 128, 160);
+        bench_fb<8, 8, 4, 1, false, true, 16, 16, 1, 1, 8, 8>("stem 16x16 1x1", N, 128, 160);
+        bench_fb<8, 8, 4, 1, false, true, 8, 16, 2, 2, 8, 8>("stem 16x32 2x2 (128 thr)", N, 128, 160);
+        bench_fb<8, 8, 4, 1, false, true, 16, 16, 2, 2, 8, 4>("stem 32x32 2x2 CG4", N, 128, 160);
+        bench_fb<4, 8, 4, 1, true, false, 16, 16, 2, 2, 8, 8>("res1_1 current 32x32 2x2", N, 128, 160);
+        bench_fb<4, 8, 4, 1, true, false, 16, 16, 1, 1, 8, 8>("res1_1 16x16 1x1", N, 128, 160);
+        bench_fb<4, 8, 4, 1, true, false, 8, 16, 2, 2, 8, 8>("res1_1 16x32 2x2 (128 thr)", N, 128, 160);
+    }
+    if (on("mfma")) {
+        printf("--- MFMA pointwise GEMMs ---\n");
+        bench_mfma<48, 224, 1, true, false>("48->224 s32", 20480);
+        bench_mfma<48, 224, 2, true, false>("48->224 s32", 20480);
+        bench_mfma<224, 48, 1, false, true>("224->48 s32 +res", 20480);
+        bench_mfma<224, 48, 2, false, true>("224->48 s32 +res", 20480);
+        bench_mfma<24, 136, 1, true, false>("24->136 s16", 81920);
+        bench_mfma<24, 136, 2, true, false>("24->136 s16", 81920);
+        bench_mfma<24, 136, 4, true, false>("24->136 s16", 81920);
+        bench_mfma<136, 24, 1, false, true>("136->24 s16 +res", 81920);
+        bench_mfma<136, 24, 2, false, true>("136->24 s16 +res", 81920);
+        bench_mfma<136, 24, 4, false, true>("136->24 s16 +res", 81920);
+        bench_mfma<96, 96, 1, false, false>("96->96 s16", 81920);
+        bench_mfma<96, 96, 2, false, false>("96->96 s16", 81920);
+        bench_mfma<96, 96, 4, false, false>("96->96 s16", 81920);
+    }
+    return 0;
+}

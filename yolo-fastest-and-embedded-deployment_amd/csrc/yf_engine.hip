@@ -86,7 +86,7 @@ struct Tensor {
     int last_use;  // index of the last op reading it
     size_t elems() const { return (size_t)C * H * W; }
 };
-enum OpType { OP_LAYER = 0, OP_FUSED_BLOCK = 1, OP_K19 = 2 };
+enum OpType { OP_LAYER = 0, OP_FUSED_BLOCK = 1, OP_K19 = 2, OP_MRES = 3 };
 struct Op {
     int layer;         // index into kLayers (fused ops: the first of their layers)
     int in1, in2, res; // tensor ids (-1 = none)
@@ -169,6 +169,8 @@ struct Builder {
         int H = pre ? ti.H / 2 : ti.H, W = pre ? ti.W / 2 : ti.W;  // expansion resolution
         int st = kLayers[o.l_dw].stride;
         o.in1 = in; o.in2 = -1; o.res = res ? in : -1; o.omode = 0;
+        if (!pre && st == 1 && yf::mres_has_kernel(kLayers[o.l_exp].cin, kLayers[o.l_exp].cout, kLayers[o.l_proj].cout, res))
+            o.type = OP_MRES;  // both pointwise convs on the matrix cores
         o.out = add_tensor(out_name, kLayers[o.l_proj].cout, H / st, W / st);
         e->ops.push_back(o);
         return o.out;
@@ -209,12 +211,15 @@ void build_plan(Plan* e, bool fused)
     x = b.triple("conv3_2", "conv3_3", "conv3_4", x);
     for (const char* n : {"res3_3", "res3_4", "res3_5", "res3_6"}) x = b.resblock(n, x);
     x = b.triple("conv3_5", "conv3_6", "conv4_1", x);
-    b.fused = false;  // stride-16 residual blocks, stride-32 stage, heads: matrix-core GEMMs + depthwise kernels
     for (const char* n : {"res4_1", "res4_2", "res4_3", "res4_4"}) x = b.resblock(n, x);
+    const bool fused_deep = fused;
+    b.fused = false;  // conv4_2 (skip tensor), conv4_3, conv5_1 and the heads: matrix-core GEMMs + depthwise kernels
     int conv4_2 = b.unit("conv4_2", x);
     x = b.unit("conv4_3", conv4_2);
     x = b.unit("conv5_1", x);
+    b.fused = fused_deep;
     for (const char* n : {"res5_1", "res5_2", "res5_3", "res5_4", "res5_5"}) x = b.resblock(n, x);
+    b.fused = false;
     int conv5_2 = b.unit("conv5_2", x);
     x = conv5_2;
     for (const char* n : {"conv5_3", "conv5_4", "conv5_5", "conv5_6"}) x = b.unit(n, x);
@@ -312,7 +317,11 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
             const Tensor& ti = P.tensors[o.in1];
             const Tensor& to = P.tensors[o.out];
             int rc = 0;
-            if (o.type == OP_FUSED_BLOCK) {
+            if (o.type == OP_MRES) {
+                const LayerSpec &LE = kLayers[o.l_exp], &LP = kLayers[o.l_proj];
+                yf::MresArgs a{ptr(o.in1), e->d_wmfma + o.mfma_off, ptr(o.out), ti.H, ti.W, 0, 0};
+                rc = yf::launch_mres(LE.cin, LE.cout, LP.cout, o.res >= 0, a, n, s);
+            } else if (o.type == OP_FUSED_BLOCK) {
                 const bool pre = o.l_pre >= 0;
                 const LayerSpec &LE = kLayers[o.l_exp], &LD = kLayers[o.l_dw], &LP = kLayers[o.l_proj];
                 yf::FbArgs a{};
@@ -437,6 +446,15 @@ int yf_create(const void* blob, size_t nbytes, int H, int W, int max_batch, int 
         const float* hw = reinterpret_cast<const float*>(static_cast<const char*>(blob) + data_off);
         std::vector<float> packed;
         for (Op& o : e->plans[1].ops) {
+            if (o.type == OP_MRES) {
+                const LayerSpec &LE = kLayers[o.l_exp], &LP = kLayers[o.l_proj];
+                o.mfma_off = (long)packed.size();
+                packed.resize(packed.size() + ((yf::mres_packed_floats(LE.cin, LE.cout, LP.cout) + 63) & ~(size_t)63));
+                yf::mres_pack_weights(hw + e->w_off[o.l_exp], hw + e->b_off[o.l_exp], hw + e->w_off[o.l_dw], hw + e->b_off[o.l_dw],
+                                      hw + e->w_off[o.l_proj], hw + e->b_off[o.l_proj], LE.cin, LE.cout, LP.cout,
+                                      packed.data() + o.mfma_off);
+                continue;
+            }
             if (o.type != OP_LAYER) continue;
             const LayerSpec& L = kLayers[o.layer];
             if (L.kind != K_PW && L.kind != K_HEAD && L.kind != K_DECONV) continue;

@@ -59,6 +59,19 @@ struct FbArgs {
 int launch_fused_block(int cin, int cexp, int cout, int stride, bool res, bool relu_out, bool pre, const FbArgs& a, int N,
                        hipStream_t s);
 
+struct MresArgs {
+    const float* in;   // NHWC [N,H,W,CIN]
+    const float* wp;   // host-packed weight stream (mres_pack_weights)
+    float* out;        // NHWC [N,H,W,COUT]
+    int H, W;
+    int tiles_y, tiles_x;  // filled by the launcher
+};
+int launch_mres(int cin, int cexp, int cout, bool res, const MresArgs& a, int N, hipStream_t s);
+bool mres_has_kernel(int cin, int cexp, int cout, bool res);
+size_t mres_packed_floats(int cin, int cexp, int cout);
+void mres_pack_weights(const float* w1, const float* b1, const float* wd, const float* bd, const float* w2, const float* b2,
+                       int cin, int cexp, int cout, float* out);
+
 struct K19Args {
     const float* in;              // NHWC [N,H,W,4] (res1_1 output, stride-2 resolution)
     const float *w8, *b8;         // conv1_8 [4][24]
