@@ -11,6 +11,7 @@
 #include "yf_fused_kernels.hip"
 #include "yf_mfma_kernels.hip"
 #include "yf_conv_kernels.hip"
+#include "yf_mres_kernels.hip"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -77,6 +78,26 @@ static void bench_mfma(const char* tag, long M)
     printf("%-44s M=%7ld MT=%d grid=%6u  %8.1f us  %6.2f TMAC/s  out %.1f GB/s\n", tag, M, MT, grid.x, us, (double)M * K1 * N / us * 1e-6, (double)M * N * 4 / us * 1e-3);
 }
 
+template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWAVE>
+static void bench_mres(const char* tag, int N, int H, int W)
+{
+    MresArgs a{};
+    a.in = dev_rand((size_t)N * H * W * CIN);
+    a.wp = dev_rand(mres_packed_floats(CIN, CEXP, COUT) + 4096, 0.2f);
+    float* out; CK(hipMalloc(&out, (size_t)N * H * W * COUT * 4)); a.out = out;
+    a.H = H; a.W = W;
+    a.tiles_y = (H + TH - 1) / TH; a.tiles_x = (W + TW - 1) / TW;
+    constexpr int MTR = ((TH + 2) * (TW + 2) + 15) / 16;
+    constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 16 * (((MTR * 16 + 7) / 8) * 8 + 1) +
+                            ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT) + COUT + 3) & ~3)) * sizeof(float);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mres_kernel<CIN, CEXP, COUT, RES, TH, TW, NWAVE>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid(N * a.tiles_y * a.tiles_x);
+    float us = time_us([&] { hipLaunchKernelGGL((mres_kernel<CIN, CEXP, COUT, RES, TH, TW, NWAVE>), grid, dim3(NWAVE * 64), lds, 0, a); });
+    double macs = (double)N * H * W * CEXP * (CIN + 9 + COUT);
+    printf("%-40s tile=%2dx%-2d waves=%d lds=%6zu grid=%6u  %8.1f us  %6.2f TMAC/s\n", tag, TH, TW, NWAVE, lds, grid.x, us, macs / us * 1e-6);
+}
+
 int main(int argc, char** argv)
 {
     const int N = 256;
@@ -116,6 +137,26 @@ int main(int argc, char** argv)
         bench_fb<4, 8, 4, 1, true, false, 16, 16, 2, 2, 8, 8>("res1_1 current 32x32 2x2", N, 128, 160);
         bench_fb<4, 8, 4, 1, true, false, 16, 16, 1, 1, 8, 8>("res1_1 16x16 1x1", N, 128, 160);
         bench_fb<4, 8, 4, 1, true, false, 8, 16, 2, 2, 8, 8>("res1_1 16x32 2x2 (128 thr)", N, 128, 160);
+    }
+    if (on("mres")) {
+        printf("--- MFMA residual blocks ---\n");
+        bench_mres<16, 96, 16, true, 16, 20, 4>("16/96 s8", N, 32, 40);
+        bench_mres<16, 96, 16, true, 16, 20, 8>("16/96 s8", N, 32, 40);
+        bench_mres<16, 96, 16, true, 32, 20, 8>("16/96 s8", N, 32, 40);
+        bench_mres<16, 96, 16, true, 16, 40, 8>("16/96 s8", N, 32, 40);
+        bench_mres<16, 96, 16, true, 8, 20, 4>("16/96 s8", N, 32, 40);
+        bench_mres<16, 96, 16, true, 8, 40, 4>("16/96 s8", N, 32, 40);
+        bench_mres<24, 136, 24, true, 16, 20, 4>("24/136 s16", N, 16, 20);
+        bench_mres<24, 136, 24, true, 16, 20, 8>("24/136 s16", N, 16, 20);
+        bench_mres<24, 136, 24, true, 8, 20, 4>("24/136 s16", N, 16, 20);
+        bench_mres<24, 136, 24, true, 8, 20, 2>("24/136 s16", N, 16, 20);
+        bench_mres<48, 224, 48, true, 8, 10, 4>("48/224 s32", N, 8, 10);
+        bench_mres<48, 224, 48, true, 8, 10, 8>("48/224 s32", N, 8, 10);
+        bench_mres<48, 224, 48, true, 8, 10, 2>("48/224 s32", N, 8, 10);
+        bench_mres<8, 48, 16, false, 16, 20, 4>("8/48/16 s8", N, 32, 40);
+        bench_mres<8, 48, 16, false, 16, 40, 8>("8/48/16 s8", N, 32, 40);
+        bench_mres<8, 32, 8, true, 16, 20, 4>("8/32 s4", N, 64, 80);
+        bench_mres<8, 32, 8, true, 16, 40, 8>("8/32 s4", N, 64, 80);
     }
     if (on("mfma")) {
         printf("--- MFMA pointwise GEMMs ---\n");

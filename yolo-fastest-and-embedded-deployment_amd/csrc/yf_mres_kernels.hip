@@ -8,8 +8,8 @@
 //
 //   HBM --16-B loads--> LDS X[region px][CIN]      (halo'd input tile, also the residual)
 //   X --A fragments (kept in VGPRs for the whole kernel)--> MFMA expand --C frag: 4 consecutive pixels of one
-//   channel--> bias, ReLU, zero outside the image --ds_write_b128--> LDS E[16 ch][region px] (channel-planar)
-//   E --9 ds_read_b32 per (pixel, channel)--> depthwise FMA chain + ReLU --is directly the A fragment of-->
+//   channel--> bias, ReLU, zero outside the image --4 conflict-free ds_write_b32--> LDS E[4 ch-groups][region px][4 ch]
+//   E --9 ds_read_b128 per pixel (4 channels each)--> depthwise FMA chain + ReLU --is directly the A fragment of-->
 //   MFMA project (accumulators live in VGPRs across all chunks) --> + bias + residual(X) --> HBM
 //
 // Fragment conventions (16x16x4 f32): lane l = (r = l & 15, q = l >> 4).
@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
     constexpr int MTR = (NRP + 15) / 16, MTO = (TH * TW) / 16;
     constexpr int MTRW = (MTR + NWAVE - 1) / NWAVE, MTOW = (MTO + NWAVE - 1) / NWAVE;
     constexpr int XP = CIN + 4;                           // X row pitch: conflict-free b128/b64 fragment reads
-    constexpr int EPL = ((MTR * 16 + 7) / 8) * 8 + 4;     // E plane pitch == 4 (mod 8): conflict-free dw reads
+    constexpr int EPL = ((MTR * 16 + 7) / 8) * 8 + 1;     // pixels per 4-channel plane, == 1 (mod 8): conflict-free writes
     constexpr int KS1 = mres_ksteps(CIN), NB1 = CIN / 16, NT2 = (COUT + 15) / 16, NCH = (CEXP + 15) / 16;
     constexpr int OFF_B1 = KS1 * 64, OFF_WD = OFF_B1 + 16, OFF_BD = OFF_WD + 144, OFF_W2 = OFF_BD + 16;
     constexpr int CHUNK = OFF_W2 + 4 * NT2 * 64;
@@ -49,7 +49,9 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
     static_assert(MTRW * 4 <= 32, "in-image mask bits");
     extern __shared__ __attribute__((aligned(16))) float mres_smem[];
     float* X = mres_smem;                 // [MTR*16][XP]
-    float* E = mres_smem + MTR * 16 * XP; // [16][EPL]
+    float* E = mres_smem + MTR * 16 * XP; // [4][EPL][4]
+    float* WL = E + 16 * EPL;             // the block's whole weight stream (NCH chunks + b2), staged once
+    constexpr int WFLOATS = (NCH * CHUNK + COUT + 3) & ~3;
 
     const int b = blockIdx.x;
     const int tx = b % a.tiles_x, ty = (b / a.tiles_x) % a.tiles_y, n = b / (a.tiles_x * a.tiles_y);
@@ -57,6 +59,9 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
 
+    // ---- stage the weight stream (coalesced 16-B copies; every wave reads its fragments from LDS afterwards) ----
+    for (int i = threadIdx.x * 4; i < WFLOATS; i += NWAVE * 64 * 4)
+        *reinterpret_cast<float4*>(&WL[i]) = *reinterpret_cast<const float4*>(a.wp + i);
     // ---- stage the halo'd input tile (zeros outside the image / beyond the region) ----
     {
         constexpr int C4 = CIN / 4;
@@ -112,8 +117,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
 
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
-        const float* __restrict__ wc = a.wp + (size_t)c * CHUNK;
-        // this chunk's weights: B fragments (one coalesced 256-B load each), dw taps of channels 4q..4q+3
+        const float* wc = WL + c * CHUNK;
         float w1f[KS1];
 #pragma unroll
         for (int s = 0; s < KS1; ++s) w1f[s] = wc[s * 64 + lane];
@@ -136,12 +140,10 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                 f32x4 cf = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < KS1; ++s) cf = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][s], w1f[s], cf, 0, 0, 0);
-                float4 v;
-                v.x = (inmask >> (i * 4 + 0)) & 1 ? fmaxf(cf[0] + b1, 0.f) : 0.f;
-                v.y = (inmask >> (i * 4 + 1)) & 1 ? fmaxf(cf[1] + b1, 0.f) : 0.f;
-                v.z = (inmask >> (i * 4 + 2)) & 1 ? fmaxf(cf[2] + b1, 0.f) : 0.f;
-                v.w = (inmask >> (i * 4 + 3)) & 1 ? fmaxf(cf[3] + b1, 0.f) : 0.f;
-                *reinterpret_cast<float4*>(&E[r * EPL + mt * 16 + 4 * q]) = v;
+                float* dst = E + ((r >> 2) * EPL + mt * 16 + 4 * q) * 4 + (r & 3);  // channel r of pixels 4q..4q+3
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    dst[reg * 4] = (inmask >> (i * 4 + reg)) & 1 ? fmaxf(cf[reg] + b1, 0.f) : 0.f;
             }
         }
         __syncthreads();
@@ -150,18 +152,18 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
         for (int i = 0; i < MTOW; ++i) {
             const int mo = wave + i * NWAVE;
             if (mo < MTO) {
-                const float* e = E + (4 * q) * EPL + rp0[i];
+                const float4* e = reinterpret_cast<const float4*>(E) + q * EPL + rp0[i];
                 float d[4] = {bd.x, bd.y, bd.z, bd.w};
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const int off = (ky - 1) * RW + (kx - 1);
+                        const float4 v = e[(ky - 1) * RW + (kx - 1)];
                         const float4 w = wd[ky * 3 + kx];
-                        d[0] = fmaf(e[0 * EPL + off], w.x, d[0]);
-                        d[1] = fmaf(e[1 * EPL + off], w.y, d[1]);
-                        d[2] = fmaf(e[2 * EPL + off], w.z, d[2]);
-                        d[3] = fmaf(e[3 * EPL + off], w.w, d[3]);
+                        d[0] = fmaf(v.x, w.x, d[0]);
+                        d[1] = fmaf(v.y, w.y, d[1]);
+                        d[2] = fmaf(v.z, w.z, d[2]);
+                        d[3] = fmaf(v.w, w.w, d[3]);
                     }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -176,7 +178,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
     }
 
     // ---- epilogue: + bias (+ residual from X), NHWC store; lane holds cout = nt*16 + r of pixels 4q + reg ----
-    const float* __restrict__ b2 = a.wp + (size_t)NCH * CHUNK;
+    const float* b2 = WL + NCH * CHUNK;
 #pragma unroll
     for (int nt = 0; nt < NT2; ++nt) {
         const int col = nt * 16 + r;
@@ -206,7 +208,8 @@ static int launch_mres_t(MresArgs a, int N, hipStream_t s)
     a.tiles_y = (a.H + TH - 1) / TH;
     a.tiles_x = (a.W + TW - 1) / TW;
     constexpr int MTR = ((TH + 2) * (TW + 2) + 15) / 16;
-    constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 16 * (((MTR * 16 + 7) / 8) * 8 + 4)) * sizeof(float);
+    constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 16 * (((MTR * 16 + 7) / 8) * 8 + 1) +
+                            ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT) + COUT + 3) & ~3)) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done = false;
     if (lds > 64 * 1024 && !attr_done) {
@@ -222,12 +225,10 @@ static int launch_mres_t(MresArgs a, int N, hipStream_t s)
 
 //      (cin, cexp, cout, residual, TH, TW, waves)
 #define YF_MRES_SHAPES(MR)                                                         \
-    MR(8, 32, 8, true, 16, 20, 4)     /* res2_1, res2_2           @ H/4  */         \
-    MR(8, 48, 8, true, 16, 20, 4)     /* res3_1, res3_2           @ H/8  */         \
     MR(8, 48, 16, false, 16, 20, 4)   /* conv3_2/3_3/3_4          @ H/8  */         \
-    MR(16, 96, 16, true, 16, 20, 4)   /* res3_3 .. res3_6         @ H/8  */         \
-    MR(24, 136, 24, true, 16, 20, 4)  /* res4_1 .. res4_4         @ H/16 */         \
-    MR(48, 224, 48, true, 8, 10, 4)   /* res5_1 .. res5_5         @ H/32 */
+    MR(16, 96, 16, true, 16, 20, 8)   /* res3_3 .. res3_6         @ H/8  */         \
+    MR(24, 136, 24, true, 16, 20, 8)  /* res4_1 .. res4_4         @ H/16 */         \
+    MR(48, 224, 48, true, 8, 10, 8)   /* res5_1 .. res5_5         @ H/32 */
 
 int launch_mres(int cin, int cexp, int cout, bool res, const MresArgs& a, int N, hipStream_t s)
 {
@@ -248,7 +249,7 @@ bool mres_has_kernel(int cin, int cexp, int cout, bool res)
 }
 
 // Host-side weight stream of one block: NCH chunks of [W1 frags | b1 | wd 9x16 | bd | W2 frags], then b2.
-size_t mres_packed_floats(int cin, int cexp, int cout) { return (size_t)((cexp + 15) / 16) * mres_chunk_floats(cin, cout) + cout; }
+size_t mres_packed_floats(int cin, int cexp, int cout) { return (((size_t)((cexp + 15) / 16) * mres_chunk_floats(cin, cout) + cout) + 3) & ~(size_t)3; }
 
 void mres_pack_weights(const float* w1 /*[cin][cexp]*/, const float* b1, const float* wd /*[9][cexp]*/, const float* bd,
                        const float* w2 /*[cexp][cout]*/, const float* b2, int cin, int cexp, int cout, float* out)
