@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--res", type=int, default=256, choices=[256, 512])
     ap.add_argument("--chunk", type=int, default=0, help="frames per pass of the layer chain (0 = whole batch)")
+    ap.add_argument("--lanes", type=int, default=1, help="concurrent streams over the chunks (needs --chunk)")
     ap.add_argument("--kmax", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -99,6 +100,7 @@ def main():
     wname = {256: "yolo_fastest_256x320_epoch28.pth", 512: "yolo_fastest_512x640_epoch27.pth"}[args.res]
     model = yf.YoloFastest(io).to(dev).eval()
     model.chunk = args.chunk
+    model.lanes = args.lanes
     model.load_state_dict(torch.load(os.path.join(ROOT, "yolo-fastest-and-embedded-deployment_amd", "assets",
                                                   "weights", wname), map_location=dev))
     post = yf.YOLO_post_process(io["conf_thre"], io["nms_thre"], io["num_anchors"], io["num_cls"], io["anchors"],
@@ -165,7 +167,7 @@ def main():
             "config": {"workload": f"YOLO-Fastest {W}x{H} batch={args.batch} fp32 per GPU, synthetic uniform-u8 frames "
                                    f"(BASELINE.json configs[1])" if args.res == 256 and args.batch == 256 else
                                    f"YOLO-Fastest {W}x{H} batch={args.batch} fp32 per GPU, synthetic frames",
-                       "global_batch": n_total, "weights": wname, "kmax": args.kmax, "chunk": args.chunk,
+                       "global_batch": n_total, "weights": wname, "kmax": args.kmax, "chunk": args.chunk, "lanes": args.lanes,
                        "parallelism": f"dp{world} (frames sharded, one RCCL all-gather of box records)" if world > 1 else "single GPU",
                        "survivors_per_frame_mean": round(float(np.clip(counts, 0, None).mean()), 3)},
             "roofline": {"bound": "hbm", "kernel": f"yf_forward layer chain ({nl.value} launches/chunk)",

@@ -118,6 +118,8 @@ int yf_preprocess_u8(yf_handle h, const uint8_t *d_u8, int N, int src_h, int src
 /* Introspection used by tests / bench. */
 int yf_num_launches(yf_handle h, int *out);       /* kernel launches one yf_forward issues            */
 int yf_set_chunk(yf_handle h, int frames);        /* frames per pass of the layer chain (0 = whole batch) */
+int yf_set_lanes(yf_handle h, int lanes);          /* 1..4: chunks of the batch (yf_set_chunk) run on this many concurrent
+                                                     streams, forked from / joined to the caller's stream by events    */
 int yf_set_fusion(yf_handle h, int level);        /* 1 (default) = block-fused kernels; 0 = one launch per layer, every
                                                      named tensor probe-able (bring-up / layer-wise parity tests)    */
 

@@ -149,7 +149,7 @@ def test_layer_probes_match_reference(yf, models, golden, dev, fusion):
     finally:
         m.fusion = 1
     assert not bad, bad
-    assert seen == (25 if fusion == 0 else 25 - len(fused_away)) and seen >= 19, (seen, fused_away)
+    assert seen == (25 if fusion == 0 else 25 - len(fused_away)) and seen >= 12, (seen, fused_away)
 
 
 def test_fused_and_per_layer_plans_agree(models, golden, dev):

@@ -86,7 +86,7 @@ struct Tensor {
     int last_use;  // index of the last op reading it
     size_t elems() const { return (size_t)C * H * W; }
 };
-enum OpType { OP_LAYER = 0, OP_FUSED_BLOCK = 1, OP_K19 = 2, OP_MRES = 3 };
+enum OpType { OP_LAYER = 0, OP_FUSED_BLOCK = 1, OP_K19 = 2, OP_MRES = 3, OP_MDW = 4 };
 struct Op {
     int layer;         // index into kLayers (fused ops: the first of their layers)
     int in1, in2, res; // tensor ids (-1 = none)
@@ -94,6 +94,7 @@ struct Op {
     int omode;         // pw: 0 NHWC, 1 NCHW head, 2 deconv
     int type = OP_LAYER;
     int l_pre = -1, l_exp = -1, l_dw = -1, l_proj = -1;  // fused block: conv0 (optional), expand, depthwise, project
+    int l_head = -1;     // OP_MDW: fused head conv (or -1)
     long mfma_off = -1;  // >= 0: pointwise layer runs on the matrix cores; offset of its packed B fragments
 };
 
@@ -116,6 +117,11 @@ struct yf_engine {
     uint32_t w_off[kNumLayers], b_off[kNumLayers];
     Plan plans[2];                    // [0] one launch per layer (bring-up / probes), [1] block-fused (default)
     int fusion = 1;
+    // Chunks of the batch can run on `lanes` concurrent streams (fork/join with events around the caller's stream):
+    // at the deep stages one workgroup owns a CU and is latency-bound; a second chunk in flight fills the bubbles.
+    int lanes = 1;
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     size_t head_l_elems = 0, head_s_elems = 0;
     const Plan& plan() const { return plans[fusion]; }
     size_t frame_floats_max() const { return plans[0].frame_floats > plans[1].frame_floats ? plans[0].frame_floats : plans[1].frame_floats; }
@@ -175,6 +181,23 @@ struct Builder {
         e->ops.push_back(o);
         return o.out;
     }
+    // dw5x5(+ReLU) -> 1x1 conv [-> 1x1 head conv] in one launch (yf_mdw_kernels.hip)
+    int dwpw(const char* dw, const char* pw, const char* head, int in, const char* out_name, int ext)
+    {
+        const LayerSpec &LD = kLayers[find_layer(dw)], &LP = kLayers[find_layer(pw)];
+        if (!fused || !yf::mdw_has_kernel(LD.cin, LP.cout, head ? 24 : 0)) {
+            int x = unit(pw, unit(dw, in));
+            return head ? unit(head, x, out_name, -1, -1, ext) : x;
+        }
+        Op o{};
+        o.type = OP_MDW;
+        o.l_dw = find_layer(dw); o.l_proj = find_layer(pw); o.l_head = head ? find_layer(head) : -1;
+        o.layer = o.l_dw; o.in1 = in; o.in2 = -1; o.res = -1; o.omode = head ? 1 : 0;
+        const Tensor& ti = e->tensors[in];
+        o.out = add_tensor(head ? out_name : pw, head ? 24 : LP.cout, ti.H, ti.W, head ? ext : 0);
+        e->ops.push_back(o);
+        return o.out;
+    }
     int triple(const char* a, const char* b, const char* c, int x)
     {
         if (fused) return fused_block(nullptr, a, b, c, x, c, false);
@@ -221,13 +244,16 @@ void build_plan(Plan* e, bool fused)
     for (const char* n : {"res5_1", "res5_2", "res5_3", "res5_4", "res5_5"}) x = b.resblock(n, x);
     b.fused = false;
     int conv5_2 = b.unit("conv5_2", x);
-    x = conv5_2;
-    for (const char* n : {"conv5_3", "conv5_4", "conv5_5", "conv5_6"}) x = b.unit(n, x);
-    b.unit("head_5", x, "head_small", -1, -1, BUF_HEAD_SMALL);
+    b.fused = fused_deep;
+    x = b.dwpw("conv5_3", "conv5_4", nullptr, conv5_2, nullptr, 0);
+    b.dwpw("conv5_5", "conv5_6", "head_5", x, "head_small", BUF_HEAD_SMALL);
+    b.fused = false;
     int d = b.unit("deconv5_1", conv5_2);
     x = b.unit("conv4_1_1", conv4_2, nullptr, d);  // torch.cat((conv4_2, deconv5_1), 1), yolo_fastest.py:209
-    for (const char* n : {"conv4_1_2", "conv4_1_3", "conv4_1_4", "conv4_1_5"}) x = b.unit(n, x);
-    b.unit("head_4", x, "head_large", -1, -1, BUF_HEAD_LARGE);
+    b.fused = fused_deep;
+    x = b.dwpw("conv4_1_2", "conv4_1_3", nullptr, x, nullptr, 0);
+    b.dwpw("conv4_1_4", "conv4_1_5", "head_4", x, "head_large", BUF_HEAD_LARGE);
+    b.fused = false;
 
     // liveness
     for (size_t i = 0; i < e->ops.size(); ++i) {
@@ -290,9 +316,16 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
     if (N > e->max_batch) return fail(YF_E_INVALID, "yf_forward: N=%d exceeds max_batch=%d", N, e->max_batch);
     const Plan& P = e->plan();
     const int cf = chunk_frames(e, N);
-    size_t need = P.frame_floats * (size_t)cf * sizeof(float);
+    const int nchunks = (N + cf - 1) / cf;
+    const int lanes = (probe || nchunks < 2) ? 1 : (e->lanes < nchunks ? e->lanes : nchunks);
+    size_t need = P.frame_floats * (size_t)cf * sizeof(float) * lanes;
     if (!ws || ws_bytes < need) return fail(YF_E_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, need);
     HIP_OK(hipSetDevice(e->device));
+    if (lanes > 1) {  // fork: side streams wait for everything already queued on the caller's stream
+        HIP_OK(hipEventRecord(e->ev_fork, s));
+        for (int l = 1; l < lanes; ++l) HIP_OK(hipStreamWaitEvent(e->side[l - 1], e->ev_fork, 0));
+    }
+    const hipStream_t s_main = s;
     int probe_t = -1;
     if (probe) {
         for (size_t t = 0; t < P.tensors.size(); ++t)
@@ -303,21 +336,28 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
     float* base = static_cast<float*>(ws);
     auto W = [&](int layer) { return e->d_weights + e->w_off[layer]; };
     auto B = [&](int layer) { return e->d_weights + e->b_off[layer]; };
-    for (int f0 = 0; f0 < N; f0 += cf) {
+    int chunk_idx = 0;
+    for (int f0 = 0; f0 < N; f0 += cf, ++chunk_idx) {
         const int n = (N - f0) < cf ? (N - f0) : cf;
+        const int lane_id = chunk_idx % lanes;
+        s = lane_id == 0 ? s_main : e->side[lane_id - 1];
+        float* lane_base = base + P.frame_floats * (size_t)cf * lane_id;
         auto ptr = [&](int t) -> float* {
             const Tensor& T = P.tensors[t];
             if (T.slot == BUF_INPUT) return const_cast<float*>(d_x) + (size_t)f0 * T.elems();
             if (T.slot == BUF_HEAD_LARGE) return d_hl + (size_t)f0 * T.elems();
             if (T.slot == BUF_HEAD_SMALL) return d_hs + (size_t)f0 * T.elems();
-            return base + P.slot_offset[T.slot] * (size_t)cf;
+            return lane_base + P.slot_offset[T.slot] * (size_t)cf;
         };
         for (const Op& o : P.ops) {
             const LayerSpec& L = kLayers[o.layer];
             const Tensor& ti = P.tensors[o.in1];
             const Tensor& to = P.tensors[o.out];
             int rc = 0;
-            if (o.type == OP_MRES) {
+            if (o.type == OP_MDW) {
+                yf::MdwArgs a{ptr(o.in1), e->d_wmfma + o.mfma_off, ptr(o.out), ti.H, ti.W, 0, 0};
+                rc = yf::launch_mdw(ti.C, kLayers[o.l_proj].cout, o.l_head >= 0 ? 24 : 0, a, n, s);
+            } else if (o.type == OP_MRES) {
                 const LayerSpec &LE = kLayers[o.l_exp], &LP = kLayers[o.l_proj];
                 yf::MresArgs a{ptr(o.in1), e->d_wmfma + o.mfma_off, ptr(o.out), ti.H, ti.W, 0, 0};
                 rc = yf::launch_mres(LE.cin, LE.cout, LP.cout, o.res >= 0, a, n, s);
@@ -363,6 +403,12 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                 else
                     yf::launch_nhwc_to_nchw(ptr(o.out), probe_dst + (size_t)f0 * to.elems(), n, to.C, (long)to.H * to.W, s);
             }
+        }
+    }
+    if (lanes > 1) {  // join: the caller's stream continues only after every side stream has drained
+        for (int l = 1; l < lanes; ++l) {
+            HIP_OK(hipEventRecord(e->ev_join[l - 1], e->side[l - 1]));
+            HIP_OK(hipStreamWaitEvent(s_main, e->ev_join[l - 1], 0));
         }
     }
     HIP_OK(hipGetLastError());
@@ -455,6 +501,16 @@ int yf_create(const void* blob, size_t nbytes, int H, int W, int max_batch, int 
                                       packed.data() + o.mfma_off);
                 continue;
             }
+            if (o.type == OP_MDW) {
+                const LayerSpec &LD = kLayers[o.l_dw], &LP = kLayers[o.l_proj];
+                const int headn = o.l_head >= 0 ? 24 : 0;
+                o.mfma_off = (long)packed.size();
+                packed.resize(packed.size() + ((yf::mdw_packed_floats(LD.cin, LP.cout, headn) + 63) & ~(size_t)63));
+                yf::mdw_pack_weights(hw + e->w_off[o.l_dw], hw + e->b_off[o.l_dw], hw + e->w_off[o.l_proj], hw + e->b_off[o.l_proj],
+                                     headn ? hw + e->w_off[o.l_head] : nullptr, headn ? hw + e->b_off[o.l_head] : nullptr, LD.cin,
+                                     LP.cout, headn, packed.data() + o.mfma_off);
+                continue;
+            }
             if (o.type != OP_LAYER) continue;
             const LayerSpec& L = kLayers[o.layer];
             if (L.kind != K_PW && L.kind != K_HEAD && L.kind != K_DECONV) continue;
@@ -477,6 +533,13 @@ int yf_create(const void* blob, size_t nbytes, int H, int W, int max_batch, int 
             }
         }
     }
+    for (int l = 0; l < 3; ++l) {
+        if (hipStreamCreateWithFlags(&e->side[l], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_join[l], hipEventDisableTiming) != hipSuccess) {
+            return fail(YF_E_HIP, "hipStreamCreate/hipEventCreate failed");
+        }
+    }
+    if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(YF_E_HIP, "hipEventCreate failed");
     *out = e;
     return YF_OK;
 }
@@ -485,6 +548,11 @@ int yf_destroy(yf_handle h)
 {
     if (!h) return YF_OK;
     (void)hipSetDevice(h->device);
+    for (int l = 0; l < 3; ++l) {
+        if (h->side[l]) (void)hipStreamDestroy(h->side[l]);
+        if (h->ev_join[l]) (void)hipEventDestroy(h->ev_join[l]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     (void)hipFree(h->d_weights);
     (void)hipFree(h->d_wmfma);
     delete h;
@@ -495,7 +563,7 @@ int yf_workspace_bytes(yf_handle h, int N, size_t* out)
 {
     if (!h || !out || N <= 0) return fail(YF_E_INVALID, "yf_workspace_bytes: bad argument");
     // layer-chain slots + internal head buffers for yf_detect
-    *out = (h->frame_floats_max() * (size_t)chunk_frames(h, N) + (h->head_l_elems + h->head_s_elems) * (size_t)N) * sizeof(float) + 256;
+    *out = (h->frame_floats_max() * (size_t)chunk_frames(h, N) * h->lanes + (h->head_l_elems + h->head_s_elems) * (size_t)N) * sizeof(float) + 256;
     return YF_OK;
 }
 
@@ -509,7 +577,7 @@ int yf_forward_probe(yf_handle h, const float* d_x, int N, const char* name, flo
 {
     if (!h || !name || !d_dst) return fail(YF_E_INVALID, "yf_forward_probe: null pointer");
     // heads go to the tail of the workspace
-    size_t chain = h->frame_floats_max() * (size_t)chunk_frames(h, N) * sizeof(float);
+    size_t chain = h->frame_floats_max() * (size_t)chunk_frames(h, N) * h->lanes * sizeof(float);
     size_t heads = (h->head_l_elems + h->head_s_elems) * (size_t)N * sizeof(float);
     if (!ws || ws_bytes < chain + heads) return fail(YF_E_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, chain + heads);
     float* hl = reinterpret_cast<float*>(static_cast<char*>(ws) + chain);
@@ -558,7 +626,7 @@ int yf_detect(yf_handle h, const float* d_x, int N, double conf_thres, double nm
               float* d_hl, float* d_hs, void* ws, size_t ws_bytes, void* stream)
 {
     if (!h) return fail(YF_E_INVALID, "yf_detect: null handle");
-    size_t chain = h->frame_floats_max() * (size_t)chunk_frames(h, N) * sizeof(float);
+    size_t chain = h->frame_floats_max() * (size_t)chunk_frames(h, N) * h->lanes * sizeof(float);
     size_t heads = (h->head_l_elems + h->head_s_elems) * (size_t)N * sizeof(float);
     if (!ws || ws_bytes < chain + ((d_hl && d_hs) ? 0 : heads)) return fail(YF_E_WORKSPACE, "workspace too small");
     float* hl = d_hl ? d_hl : reinterpret_cast<float*>(static_cast<char*>(ws) + chain);
@@ -586,6 +654,13 @@ int yf_num_launches(yf_handle h, int* out)
 {
     if (!h || !out) return fail(YF_E_INVALID, "bad argument");
     *out = (int)h->plan().ops.size();
+    return YF_OK;
+}
+
+int yf_set_lanes(yf_handle h, int lanes)
+{
+    if (!h || lanes < 1 || lanes > 4) return fail(YF_E_INVALID, "lanes must be 1..4");
+    h->lanes = lanes;
     return YF_OK;
 }
 

@@ -72,6 +72,19 @@ size_t mres_packed_floats(int cin, int cexp, int cout);
 void mres_pack_weights(const float* w1, const float* b1, const float* wd, const float* bd, const float* w2, const float* b2,
                        int cin, int cexp, int cout, float* out);
 
+struct MdwArgs {
+    const float* in;   // NHWC [N,H,W,C]
+    const float* wp;   // host-packed weight stream (mdw_pack_weights)
+    float* out;        // NHWC [N,H,W,N_out], or NCHW [N,24,H,W] when the head conv is fused
+    int H, W;
+    int tiles_y, tiles_x;
+};
+int launch_mdw(int c, int n, int headn, const MdwArgs& a, int Nf, hipStream_t s);
+bool mdw_has_kernel(int c, int n, int headn);
+size_t mdw_packed_floats(int c, int n, int headn);
+void mdw_pack_weights(const float* wd, const float* bd, const float* w, const float* b, const float* hw, const float* hb, int c,
+                      int n, int headn, float* out);
+
 struct K19Args {
     const float* in;              // NHWC [N,H,W,4] (res1_1 output, stride-2 resolution)
     const float *w8, *b8;         // conv1_8 [4][24]

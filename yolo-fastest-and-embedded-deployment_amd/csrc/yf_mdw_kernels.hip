@@ -1,0 +1,286 @@
+// yf_mdw_kernels.hip -- the detection-head pairs  dw5x5(+ReLU) -> 1x1 conv  [-> 1x1 head conv]  on chip.
+//
+//   conv5_3 -> conv5_4,   conv5_5 -> conv5_6 -> head_5      (small head, src/model_training/model/yolo_fastest.py:132-136,200-206)
+//   conv4_1_2 -> conv4_1_3,   conv4_1_4 -> conv4_1_5 -> head_4   (large head, :141-146, :211-216)
+//
+// One workgroup = one TH x TW tile of one frame (the whole frame at the shipped sizes).  Per 16-channel chunk of the
+// input: HBM --16-B loads, one chunk prefetched in registers--> LDS E[4 ch-groups][region px][4 ch] --25 ds_read_b128
+// per pixel--> depthwise FMA chains (+bias, ReLU) == A fragments of  v_mfma_f32_16x16x4_f32  against the 1x1 conv's
+// weights (B fragments from the LDS-staged weight stream); accumulators live in VGPRs across chunks.  With HEADN the
+// finished C fragments (+bias) are transposed through a wave-private LDS tile into A fragments of the head GEMM and the
+// head's logits are stored NCHW like the reference's output; otherwise the result is stored NHWC.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "yf_kernels.h"
+
+namespace yf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ constexpr int mdw_chunk_floats(int n) { return 25 * 16 + 16 + 4 * (n / 16) * 64; }
+__host__ __device__ constexpr int mdw_stream_floats(int c, int n, int headn)
+{
+    int f = (c / 16) * mdw_chunk_floats(n) + n;
+    if (headn) f += (n / 4) * 2 * 64 + 32;
+    return (f + 3) & ~3;
+}
+
+template <int C, int N, int HEADN, int TH, int TW, int NWAVE>
+__global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
+{
+    constexpr int NTHR = NWAVE * 64;
+    constexpr int RH = TH + 4, RW = TW + 4, NRP = RH * RW;
+    constexpr int MTO = (TH * TW) / 16, MTOW = (MTO + NWAVE - 1) / NWAVE;
+    constexpr int EPL = ((NRP + 7) / 8) * 8 + 2;  // pixels per 4-channel plane, == 2 (mod 8): conflict-free b128 fills
+    constexpr int NT = N / 16, NCH = C / 16;
+    constexpr int OFF_BD = 400, OFF_W = 416, CHUNK = 416 + 4 * NT * 64;
+    constexpr int OFF_BPW = NCH * CHUNK, OFF_HW = OFF_BPW + N, KSH = N / 4, NTH = 2, OFF_HB = OFF_HW + KSH * NTH * 64;
+    constexpr int WFLOATS = mdw_stream_floats(C, N, HEADN);
+    constexpr int NLD = (NRP * 4 + NTHR - 1) / NTHR;  // float4 loads per thread per chunk
+    constexpr int TP = N + 4;                         // pitch of the transposition tile
+    static_assert((TH * TW) % 16 == 0 && C % 16 == 0 && N % 16 == 0 && CHUNK == mdw_chunk_floats(N), "shape");
+    static_assert(HEADN == 0 || HEADN <= 32, "head width");
+    extern __shared__ __attribute__((aligned(16))) float mdw_smem[];
+    float* E = mdw_smem;           // [4][EPL][4]
+    float* WL = E + 16 * EPL;      // weight stream
+    float* T = WL + WFLOATS;       // [min(NWAVE,MTO)][16][TP]   (HEADN only)
+
+    const int b = blockIdx.x;
+    const int tx = b % a.tiles_x, ty = (b / a.tiles_x) % a.tiles_y, n = b / (a.tiles_x * a.tiles_y);
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const float* __restrict__ src = a.in + (long)n * a.H * a.W * C;
+
+    for (int i = threadIdx.x * 4; i < WFLOATS; i += NTHR * 4)
+        *reinterpret_cast<float4*>(&WL[i]) = *reinterpret_cast<const float4*>(a.wp + i);
+
+    // chunk-invariant addressing of this thread's NLD fill items: item id -> (region pixel, channel quad)
+    int goff[NLD];  // frame-relative pixel index, -1 = outside the image (zero fill), -2 = no item
+#pragma unroll
+    for (int m = 0; m < NLD; ++m) {
+        const int id = threadIdx.x + m * NTHR;
+        const int px = id >> 2;
+        const int ry = px / RW, rx = px - ry * RW;
+        const int iy = oy0 - 2 + ry, ix = ox0 - 2 + rx;
+        goff[m] = px >= NRP ? -2 : (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? iy * a.W + ix : -1;
+    }
+    float4 pf[NLD];
+    auto prefetch = [&](int c) {
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) {
+            const int id = threadIdx.x + m * NTHR;
+            pf[m] = goff[m] >= 0 ? *reinterpret_cast<const float4*>(src + (long)goff[m] * C + c * 16 + 4 * (id & 3))
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    prefetch(0);
+
+    f32x4 acc[MTOW][NT];
+    int rp0[MTOW];
+#pragma unroll
+    for (int i = 0; i < MTOW; ++i) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[i][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int mo = wave + i * NWAVE;
+        const int op = (mo < MTO ? mo : 0) * 16 + r;
+        const int oy = op / TW, ox = op - oy * TW;
+        rp0[i] = (oy + 2) * RW + ox + 2;
+    }
+
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        // ---- fill E with this chunk (prefetched), then request the next chunk ----
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) {
+            const int id = threadIdx.x + m * NTHR;
+            if (goff[m] != -2) *reinterpret_cast<float4*>(&E[((id & 3) * EPL + (id >> 2)) * 4]) = pf[m];
+        }
+        __syncthreads();
+        if (c + 1 < NCH) prefetch(c + 1);
+        // ---- depthwise 5x5 of channels 4q..4q+3 at this lane's output pixels (taps outer: one weight read per tap) ----
+        const float* wc = WL + c * CHUNK;
+        const float4 bd = *reinterpret_cast<const float4*>(wc + OFF_BD + 4 * q);
+        float d[MTOW][4];
+#pragma unroll
+        for (int i = 0; i < MTOW; ++i) { d[i][0] = bd.x; d[i][1] = bd.y; d[i][2] = bd.z; d[i][3] = bd.w; }
+        const float4* e4 = reinterpret_cast<const float4*>(E) + q * EPL;
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                const float4 w = *reinterpret_cast<const float4*>(wc + (ky * 5 + kx) * 16 + 4 * q);
+#pragma unroll
+                for (int i = 0; i < MTOW; ++i) {
+                    if (wave + i * NWAVE < MTO) {
+                        const float4 v = e4[rp0[i] + (ky - 2) * RW + (kx - 2)];
+                        d[i][0] = fmaf(v.x, w.x, d[i][0]); d[i][1] = fmaf(v.y, w.y, d[i][1]);
+                        d[i][2] = fmaf(v.z, w.z, d[i][2]); d[i][3] = fmaf(v.w, w.w, d[i][3]);
+                    }
+                }
+            }
+        // ---- 1x1 conv: A = relu(d) (k-step j = channel 4q+j), B fragments from the staged stream ----
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float w2f[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) w2f[nt] = wc[OFF_W + (j * NT + nt) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < MTOW; ++i) {
+                if (wave + i * NWAVE < MTO) {
+                    const float dj = fmaxf(d[i][j], 0.f);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dj, w2f[nt], acc[i][nt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    const float* bpw = WL + OFF_BPW;
+    if constexpr (HEADN == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = nt * 16 + r;
+            const float bias = bpw[col];
+#pragma unroll
+            for (int i = 0; i < MTOW; ++i) {
+                const int mo = wave + i * NWAVE;
+                if (mo >= MTO) continue;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int op = mo * 16 + 4 * q + reg;
+                    const int oy = op / TW, ox = op - oy * TW;
+                    const int gy = oy0 + oy, gx = ox0 + ox;
+                    if (gy < a.H && gx < a.W) a.out[(((long)n * a.H + gy) * a.W + gx) * N + col] = acc[i][nt][reg] + bias;
+                }
+            }
+        }
+    } else {
+        constexpr int TSLOTS = NWAVE < MTO ? NWAVE : MTO;
+        float* Tw = T + (wave < TSLOTS ? wave : 0) * 16 * TP;
+        const float* hw = WL + OFF_HW;
+        const float* hb = WL + OFF_HB;
+#pragma unroll
+        for (int i = 0; i < MTOW; ++i) {  // (unrolled: a runtime-indexed acc[] would live in scratch)
+            const int mo = wave + i * NWAVE;
+            if (mo >= MTO) continue;
+            // C fragment (+bias) -> wave-private tile [16 px][N] -> A fragments of the head GEMM
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float bias = bpw[nt * 16 + r];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) Tw[(4 * q + reg) * TP + nt * 16 + r] = acc[i][nt][reg] + bias;
+            }
+            __builtin_amdgcn_wave_barrier();
+            f32x4 h[NTH] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int kb = 0; kb < N / 16; ++kb) {
+                const float4 av = *reinterpret_cast<const float4*>(&Tw[r * TP + kb * 16 + 4 * q]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < NTH; ++nt)
+                        h[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&av)[j], hw[((kb * 4 + j) * NTH + nt) * 64 + lane],
+                                                                     h[nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int nt = 0; nt < NTH; ++nt) {
+                const int col = nt * 16 + r;
+                if (col >= HEADN) continue;
+                const float bias = hb[col];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int op = mo * 16 + 4 * q + reg;
+                    const int oy = op / TW, ox = op - oy * TW;
+                    const int gy = oy0 + oy, gx = ox0 + ox;
+                    if (gy < a.H && gx < a.W) a.out[(((long)n * HEADN + col) * a.H + gy) * a.W + gx] = h[nt][reg] + bias;  // NCHW
+                }
+            }
+        }
+    }
+}
+
+template <int C, int N, int HEADN, int TH, int TW, int NWAVE>
+static int launch_mdw_t(MdwArgs a, int Nf, hipStream_t s)
+{
+    a.tiles_y = (a.H + TH - 1) / TH;
+    a.tiles_x = (a.W + TW - 1) / TW;
+    constexpr int NRP = (TH + 4) * (TW + 4), MTO = TH * TW / 16;
+    constexpr size_t lds = ((size_t)16 * (((NRP + 7) / 8) * 8 + 2) + mdw_stream_floats(C, N, HEADN) +
+                            (HEADN ? (size_t)(NWAVE < MTO ? NWAVE : MTO) * 16 * (N + 4) : 0)) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "LDS");
+    static bool attr_done = false;
+    if (lds > 64 * 1024 && !attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mdw_kernel<C, N, HEADN, TH, TW, NWAVE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -2;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((mdw_kernel<C, N, HEADN, TH, TW, NWAVE>), dim3((unsigned)(Nf * a.tiles_y * a.tiles_x)), dim3(NWAVE * 64),
+                       lds, s, a);
+    return 0;
+}
+
+//      (c, n, head, TH, TW, waves)
+#define YF_MDW_SHAPES(MD)                                            \
+    MD(96, 128, 0, 8, 10, 8)    /* conv5_3 -> conv5_4            @ H/32 */ \
+    MD(128, 128, 24, 8, 10, 8)  /* conv5_5 -> conv5_6 -> head_5  @ H/32 */ \
+    MD(96, 96, 0, 16, 20, 8)    /* conv4_1_2 -> conv4_1_3        @ H/16 */ \
+    MD(96, 96, 24, 16, 20, 8)   /* conv4_1_4 -> conv4_1_5 -> head_4      */
+
+int launch_mdw(int c, int n, int headn, const MdwArgs& a, int Nf, hipStream_t s)
+{
+#define MD(cc, nn, hh, th, tw, nw) \
+    if (c == cc && n == nn && headn == hh) return launch_mdw_t<cc, nn, hh, th, tw, nw>(a, Nf, s);
+    YF_MDW_SHAPES(MD)
+#undef MD
+    return -1;
+}
+
+bool mdw_has_kernel(int c, int n, int headn)
+{
+#define MD(cc, nn, hh, th, tw, nw) \
+    if (c == cc && n == nn && headn == hh) return true;
+    YF_MDW_SHAPES(MD)
+#undef MD
+    return false;
+}
+
+size_t mdw_packed_floats(int c, int n, int headn) { return (size_t)mdw_stream_floats(c, n, headn); }
+
+// Weight stream: NCH chunks of [wd 25x16 | bd 16 | W frags 4 x NT x 64], then b_pw[n], then (head) frags (n/4) x 2 x 64, b_head[32].
+void mdw_pack_weights(const float* wd /*[25][c]*/, const float* bd, const float* w /*[c][n]*/, const float* b, const float* hw /*[n][headn]*/,
+                      const float* hb, int c, int n, int headn, float* out)
+{
+    const int NT = n / 16, NCH = c / 16, CH = mdw_chunk_floats(n);
+    for (int ch = 0; ch < NCH; ++ch) {
+        float* o = out + (size_t)ch * CH;
+        for (int t = 0; t < 25; ++t)
+            for (int k = 0; k < 16; ++k) o[t * 16 + k] = wd[(size_t)t * c + ch * 16 + k];
+        for (int k = 0; k < 16; ++k) o[400 + k] = bd[ch * 16 + k];
+        for (int j = 0; j < 4; ++j)
+            for (int nt = 0; nt < NT; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    o[416 + (j * NT + nt) * 64 + lane] = w[(size_t)(ch * 16 + 4 * (lane >> 4) + j) * n + nt * 16 + (lane & 15)];
+    }
+    float* o = out + (size_t)NCH * CH;
+    for (int i = 0; i < n; ++i) o[i] = b[i];
+    o += n;
+    if (headn) {
+        for (int s = 0; s < n / 4; ++s)
+            for (int nt = 0; nt < 2; ++nt)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int k = (s / 4) * 16 + 4 * (lane >> 4) + (s % 4), col = nt * 16 + (lane & 15);
+                    o[(s * 2 + nt) * 64 + lane] = col < headn ? hw[(size_t)k * headn + col] : 0.f;
+                }
+        o += (n / 4) * 2 * 64;
+        for (int i = 0; i < 32; ++i) o[i] = i < headn ? hb[i] : 0.f;
+    }
+}
+
+}  // namespace yf

@@ -55,6 +55,10 @@ class _Engine:
         _lib.check(self.lib.yf_set_chunk(self.handle, int(frames)))
         self._ws = None
 
+    def set_lanes(self, lanes):
+        _lib.check(self.lib.yf_set_lanes(self.handle, int(lanes)))
+        self._ws = None
+
     def set_fusion(self, level):
         _lib.check(self.lib.yf_set_fusion(self.handle, int(level)))
 
@@ -97,6 +101,7 @@ class YoloFastest(nn.Module):
         self._blob = None
         self.chunk = 0  # frames per pass of the layer chain (0 = whole batch); see yf_set_chunk
         self.fusion = 1  # 1 = block-fused kernels (default); 0 = one launch per layer (bring-up, all probes)
+        self.lanes = 1   # concurrent streams over chunks of the batch (needs chunk > 0); see yf_set_lanes
 
     # -- weight packing -------------------------------------------------------------------------
     def _invalidate(self):
@@ -142,6 +147,8 @@ class YoloFastest(nn.Module):
             e = _Engine(self._blob, H, W, max(N, 256), key[2])
             if self.chunk:
                 e.set_chunk(self.chunk)
+            if self.lanes > 1:
+                e.set_lanes(self.lanes)
             self._engines[key] = e
         e.set_fusion(self.fusion)
         return e
