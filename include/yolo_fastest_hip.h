@@ -116,6 +116,13 @@ int yf_detect(yf_handle h, const float *d_x, int N, double conf_thres, double nm
 int yf_preprocess_u8(yf_handle h, const uint8_t *d_u8, int N, int src_h, int src_w, float *d_x, void *stream);
 
 /* Introspection used by tests / bench. */
+/* Name ("conv1_8+conv1_9+conv2_1"), layer-granular algorithmic bytes and flops per frame of launch `op` of the
+ * current plan (each conv of the op reads its input and writes its output once, + residual read: SURVEY.md 8d). */
+int yf_op_info(yf_handle h, int op, char *name, int name_len, double *algorithmic_bytes_per_frame, double *flops_per_frame);
+/* One forward pass (whole batch in one pass) with a HIP event recorded on `stream` around every launch; blocks until
+ * the pass is done and returns each launch's duration in ms in op_ms[yf_num_launches]. */
+int yf_profile_forward(yf_handle h, const float *d_x, int N, void *d_workspace, size_t workspace_bytes, void *stream,
+                       float *op_ms, int n_ops);
 int yf_num_launches(yf_handle h, int *out);       /* kernel launches one yf_forward issues            */
 int yf_set_chunk(yf_handle h, int frames);        /* frames per pass of the layer chain (0 = whole batch) */
 int yf_set_lanes(yf_handle h, int lanes);          /* 1..4: chunks of the batch (yf_set_chunk) run on this many concurrent

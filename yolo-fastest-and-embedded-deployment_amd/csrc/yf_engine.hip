@@ -119,7 +119,7 @@ struct yf_engine {
     int fusion = 1;
     // Chunks of the batch can run on `lanes` concurrent streams (fork/join with events around the caller's stream):
     // at the deep stages one workgroup owns a CU and is latency-bound; a second chunk in flight fills the bubbles.
-    int lanes = 1;
+    int lanes = 2;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     size_t head_l_elems = 0, head_s_elems = 0;
@@ -306,18 +306,24 @@ void build_plan(Plan* e, bool fused)
 int chunk_frames(const yf_engine* e, int N)
 {
     int c = e->chunk > 0 ? e->chunk : N;
+    if (e->chunk == 0 && e->lanes > 1 && N >= 64) c = (N + e->lanes - 1) / e->lanes;  // auto: one chunk per lane
     return c < N ? c : N;
 }
 
+// per-op profiling state (yf_profile_forward): events recorded around every launch of a single-lane pass
+struct ProfileEvents {
+    std::vector<hipEvent_t> ev;  // ops.size() + 1
+};
+
 int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs, void* ws, size_t ws_bytes,
-                hipStream_t s, const char* probe, float* probe_dst, size_t probe_bytes)
+                hipStream_t s, const char* probe, float* probe_dst, size_t probe_bytes, ProfileEvents* prof = nullptr)
 {
     if (!e || !d_x || !d_hl || !d_hs || N <= 0) return fail(YF_E_INVALID, "yf_forward: null pointer or N <= 0");
     if (N > e->max_batch) return fail(YF_E_INVALID, "yf_forward: N=%d exceeds max_batch=%d", N, e->max_batch);
     const Plan& P = e->plan();
-    const int cf = chunk_frames(e, N);
+    const int cf = prof ? N : chunk_frames(e, N);  // profiling: the whole batch in one pass on the caller's stream
     const int nchunks = (N + cf - 1) / cf;
-    const int lanes = (probe || nchunks < 2) ? 1 : (e->lanes < nchunks ? e->lanes : nchunks);
+    const int lanes = (probe || prof || nchunks < 2) ? 1 : (e->lanes < nchunks ? e->lanes : nchunks);
     size_t need = P.frame_floats * (size_t)cf * sizeof(float) * lanes;
     if (!ws || ws_bytes < need) return fail(YF_E_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, need);
     HIP_OK(hipSetDevice(e->device));
@@ -349,11 +355,14 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
             if (T.slot == BUF_HEAD_SMALL) return d_hs + (size_t)f0 * T.elems();
             return lane_base + P.slot_offset[T.slot] * (size_t)cf;
         };
+        size_t op_idx = 0;
+        if (prof) HIP_OK(hipEventRecord(prof->ev[0], s));
         for (const Op& o : P.ops) {
             const LayerSpec& L = kLayers[o.layer];
             const Tensor& ti = P.tensors[o.in1];
             const Tensor& to = P.tensors[o.out];
             int rc = 0;
+            struct AtExit { ProfileEvents* p; size_t* i; hipStream_t st; ~AtExit() { if (p) { ++*i; (void)hipEventRecord(p->ev[*i], st); } } } at_exit{prof, &op_idx, s};
             if (o.type == OP_MDW) {
                 yf::MdwArgs a{ptr(o.in1), e->d_wmfma + o.mfma_off, ptr(o.out), ti.H, ti.W, 0, 0};
                 rc = yf::launch_mdw(ti.C, kLayers[o.l_proj].cout, o.l_head >= 0 ? 24 : 0, a, n, s);
@@ -563,7 +572,9 @@ int yf_workspace_bytes(yf_handle h, int N, size_t* out)
 {
     if (!h || !out || N <= 0) return fail(YF_E_INVALID, "yf_workspace_bytes: bad argument");
     // layer-chain slots + internal head buffers for yf_detect
-    *out = (h->frame_floats_max() * (size_t)chunk_frames(h, N) * h->lanes + (h->head_l_elems + h->head_s_elems) * (size_t)N) * sizeof(float) + 256;
+    size_t per_pass = (size_t)chunk_frames(h, N) * h->lanes;
+    if (per_pass < (size_t)N) per_pass = N;  // yf_profile_forward / yf_forward_probe run the whole batch in one pass
+    *out = (h->frame_floats_max() * per_pass + (h->head_l_elems + h->head_s_elems) * (size_t)N) * sizeof(float) + 256;
     return YF_OK;
 }
 
@@ -655,6 +666,66 @@ int yf_num_launches(yf_handle h, int* out)
     if (!h || !out) return fail(YF_E_INVALID, "bad argument");
     *out = (int)h->plan().ops.size();
     return YF_OK;
+}
+
+// ---- per-op introspection / timing (bench.py's roofline object) ----
+static size_t layer_io_elems(const LayerSpec& L, size_t in_px, size_t out_px) { return in_px * L.cin + out_px * L.cout; }
+
+int yf_op_info(yf_handle h, int op, char* name, int name_len, double* algorithmic_bytes_per_frame, double* flops_per_frame)
+{
+    if (!h || op < 0 || op >= (int)h->plan().ops.size()) return fail(YF_E_INVALID, "bad op index");
+    const Plan& P = h->plan();
+    const Op& o = P.ops[op];
+    const Tensor &ti = P.tensors[o.in1], &to = P.tensors[o.out];
+    std::string nm;
+    double elems = 0, macs = 0;
+    auto add = [&](int li, size_t in_px, size_t out_px, bool res) {
+        if (li < 0) return;
+        const LayerSpec& L = kLayers[li];
+        if (!nm.empty()) nm += "+";
+        nm += L.name;
+        elems += (double)layer_io_elems(L, in_px, out_px) + (res ? (double)out_px * L.cout : 0.0);
+        const double k2 = L.kind == K_DECONV ? 1.0 : (double)L.k * L.k;  // deconv 2x2 s2: each output pixel sees one tap
+        macs += (L.kind == K_DW ? (double)out_px * L.cout * k2 : (double)out_px * L.cout * L.cin * k2);
+    };
+    const size_t ipx = (size_t)ti.H * ti.W, opx = (size_t)to.H * to.W;
+    if (o.type == OP_FUSED_BLOCK || o.type == OP_MRES) {
+        size_t epx = ipx;
+        if (o.l_pre >= 0) { epx = ipx / 4; add(o.l_pre, ipx, epx, false); }
+        add(o.l_exp, epx, epx, false); add(o.l_dw, epx, opx, false); add(o.l_proj, opx, opx, o.res >= 0);
+    } else if (o.type == OP_K19) {
+        add(o.l_exp, ipx, ipx, false); add(o.l_dw, ipx, opx, false); add(o.l_proj, opx, opx, false);
+    } else if (o.type == OP_MDW) {
+        add(o.l_dw, ipx, ipx, false); add(o.l_proj, ipx, ipx, false); add(o.l_head, ipx, ipx, false);
+    } else {
+        add(o.layer, ipx, opx, o.res >= 0);
+    }
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s", nm.c_str());
+    if (algorithmic_bytes_per_frame) *algorithmic_bytes_per_frame = elems * 4.0;
+    if (flops_per_frame) *flops_per_frame = macs * 2.0;
+    return YF_OK;
+}
+
+int yf_profile_forward(yf_handle h, const float* d_x, int N, void* ws, size_t ws_bytes, void* stream, float* op_ms, int n_ops)
+{
+    if (!h || !op_ms) return fail(YF_E_INVALID, "yf_profile_forward: null pointer");
+    const size_t nops = h->plan().ops.size();
+    if (n_ops != (int)nops) return fail(YF_E_INVALID, "op_ms must hold %zu entries", nops);
+    size_t chain = h->frame_floats_max() * (size_t)N * sizeof(float);
+    size_t heads = (h->head_l_elems + h->head_s_elems) * (size_t)N * sizeof(float);
+    if (!ws || ws_bytes < chain + heads) return fail(YF_E_WORKSPACE, "workspace too small");
+    float* hl = reinterpret_cast<float*>(static_cast<char*>(ws) + chain);
+    float* hs = hl + h->head_l_elems * (size_t)N;
+    ProfileEvents pe;
+    pe.ev.resize(nops + 1);
+    for (auto& ev : pe.ev) HIP_OK(hipEventCreate(&ev));
+    int rc = run_forward(h, d_x, N, hl, hs, ws, chain, (hipStream_t)stream, nullptr, nullptr, 0, &pe);
+    if (rc == YF_OK) {
+        HIP_OK(hipEventSynchronize(pe.ev[nops]));
+        for (size_t i = 0; i < nops; ++i) HIP_OK(hipEventElapsedTime(&op_ms[i], pe.ev[i], pe.ev[i + 1]));
+    }
+    for (auto& ev : pe.ev) (void)hipEventDestroy(ev);
+    return rc;
 }
 
 int yf_set_lanes(yf_handle h, int lanes)

@@ -101,7 +101,7 @@ class YoloFastest(nn.Module):
         self._blob = None
         self.chunk = 0  # frames per pass of the layer chain (0 = whole batch); see yf_set_chunk
         self.fusion = 1  # 1 = block-fused kernels (default); 0 = one launch per layer (bring-up, all probes)
-        self.lanes = 1   # concurrent streams over chunks of the batch (needs chunk > 0); see yf_set_lanes
+        self.lanes = 2   # concurrent streams over chunks of the batch (chunk 0 = one chunk per lane); see yf_set_lanes
 
     # -- weight packing -------------------------------------------------------------------------
     def _invalidate(self):
@@ -147,8 +147,7 @@ class YoloFastest(nn.Module):
             e = _Engine(self._blob, H, W, max(N, 256), key[2])
             if self.chunk:
                 e.set_chunk(self.chunk)
-            if self.lanes > 1:
-                e.set_lanes(self.lanes)
+            e.set_lanes(self.lanes)
             self._engines[key] = e
         e.set_fusion(self.fusion)
         return e
@@ -171,6 +170,31 @@ class YoloFastest(nn.Module):
         _lib.check(e.lib.yf_forward(e.handle, x.data_ptr(), N, hl.data_ptr(), hs.data_ptr(), ws.data_ptr(), ws.numel(),
                                     ctypes.c_void_p(stream)))
         return hl, hs
+
+    def profile(self, x, reps=5):
+        """Per-launch timing of one forward pass (HIP events on the launch stream around every kernel).
+        Returns a list of dicts: name, ms (mean over reps), algorithmic_bytes, flops -- for the whole batch."""
+        x = x.contiguous().float()
+        N, _, H, W = x.shape
+        e = self.engine(H, W, N, x.device)
+        ws = e.workspace(N, x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        n = ctypes.c_int()
+        _lib.check(e.lib.yf_num_launches(e.handle, ctypes.byref(n)))
+        acc = [0.0] * n.value
+        buf = (ctypes.c_float * n.value)()
+        for _ in range(reps):
+            _lib.check(e.lib.yf_profile_forward(e.handle, x.data_ptr(), N, ws.data_ptr(), ws.numel(), ctypes.c_void_p(stream),
+                                                buf, n.value))
+            for i in range(n.value):
+                acc[i] += buf[i] / reps
+        out = []
+        for i in range(n.value):
+            name = ctypes.create_string_buffer(128)
+            b, f = ctypes.c_double(), ctypes.c_double()
+            _lib.check(e.lib.yf_op_info(e.handle, i, name, 128, ctypes.byref(b), ctypes.byref(f)))
+            out.append(dict(name=name.value.decode(), ms=acc[i], algorithmic_bytes=b.value * N, flops=f.value * N))
+        return out
 
     def probe(self, x, name):
         """Test hook: the activation the reference module attribute `name` produces, NCHW."""
