@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=2, help="concurrent streams over the chunks of the batch (1..4)")
     ap.add_argument("--kmax", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-ops", default=None, help="write the launch names of one forward pass to this JSON file")
     args = ap.parse_args()
 
     import numpy as np
@@ -155,6 +156,9 @@ def main():
         fps = n_total * args.steps / elapsed
         # per-launch timing, HIP events on the launch stream around every kernel of one forward pass (mean of 5 passes)
         ops = model.profile(x, reps=5)
+        if args.dump_ops:
+            with open(args.dump_ops, "w") as f:
+                json.dump([{"name": o["name"], "algorithmic_bytes": o["algorithmic_bytes"]} for o in ops], f)
         chain_ms = sum(o["ms"] for o in ops)
         dom = max(ops, key=lambda o: o["ms"])
         bytes_sum = sum(o["algorithmic_bytes"] for o in ops) / args.batch
