@@ -44,23 +44,29 @@ static float time_us(F&& launch, int reps = 20)
 
 using namespace yf;
 
-template <int CIN, int CEXP, int COUT, int S, bool RES, bool PRE, int TYB, int TXB, int BH, int BW, int EC, int CG>
+template <int CIN, int CEXP, int COUT, int S, bool RES, bool PRE, int TYB, int TXB, int BH, int BW, int EC, int CG, int PE = 1, bool XL = true>
 static void bench_fb(const char* tag, int N, int H, int W)
 {
     FbArgs a{};
     const int Ho = H / S, Wo = W / S;
     a.in = dev_rand(PRE ? (size_t)N * 4 * H * W : (size_t)N * H * W * CIN);
     a.w0 = dev_rand(72, 0.3f); a.b0 = dev_rand(8, 0.1f);
-    a.w1 = dev_rand((size_t)CIN * CEXP, 0.3f); a.b1 = dev_rand(CEXP, 0.1f);
-    a.wd = dev_rand(9 * CEXP, 0.3f); a.bd = dev_rand(CEXP, 0.1f);
-    a.w2 = dev_rand((size_t)CEXP * COUT, 0.3f); a.b2 = dev_rand(COUT, 0.1f);
+    a.wp = dev_rand(fb_packed_floats(CIN, CEXP, COUT, EC) + 64, 0.3f);
     float* out; CK(hipMalloc(&out, (size_t)N * Ho * Wo * COUT * 4)); a.out = out;
     a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
     a.tiles_y = (Ho + TYB * BH - 1) / (TYB * BH); a.tiles_x = (Wo + TXB * BW - 1) / (TXB * BW);
     dim3 grid(N * a.tiles_y * a.tiles_x);
-    float us = time_us([&] { hipLaunchKernelGGL((fused_block_kernel<CIN, CEXP, COUT, S, RES, false, PRE, TYB, TXB, BH, BW, EC, CG>), grid, dim3(TYB * TXB), 0, 0, a); });
+#ifdef YF_STAMP
+    CK(hipMalloc(&a.dbg, 64)); CK(hipMemset(a.dbg, 0, 64));
+#endif
+    float us = time_us([&] { hipLaunchKernelGGL((fused_block_kernel<CIN, CEXP, COUT, S, RES, false, PRE, TYB, TXB, BH, BW, EC, CG, PE, XL>), grid, dim3(TYB * TXB), 0, 0, a); });
+#ifdef YF_STAMP
+    { unsigned long long h[6]; CK(hipMemcpy(h, a.dbg, 48, hipMemcpyDeviceToHost)); double tot = 0; for (int i = 0; i < 6; ++i) tot += (double)h[i];
+      printf("    stamps%%: loop-top %.1f | expand %.1f | barrier1 %.1f | dw+project %.1f | barrier2 %.1f | epilogue %.1f   (avg cycles/wave %.0f)\n",
+             100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, 100 * h[5] / tot, tot / 23.0 / (grid.x * (TYB * TXB / 64.0))); }
+#endif
     double macs = (double)N * (PRE ? H * W * 72.0 : 0) + (double)N * H * W * CIN * CEXP + (double)N * Ho * Wo * CEXP * (9 + COUT);
-    printf("%-44s thr=%4d tile=%2dx%-2d EC=%2d CG=%2d grid=%6u  %8.1f us  %6.2f TMAC/s\n", tag, TYB * TXB, TYB * BH, TXB * BW, EC, CG, grid.x, us, macs / us * 1e-6);
+    printf("%-44s thr=%4d tile=%2dx%-2d EC=%2d CG=%2d PE=%d XL=%d grid=%6u  %8.1f us  %6.2f TMAC/s\n", tag, TYB * TXB, TYB * BH, TXB * BW, EC, CG, PE, (int)XL, grid.x, us, macs / us * 1e-6);
 }
 
 template <int K1, int N, int MT, bool RELU, bool RES>
@@ -103,40 +109,45 @@ int main(int argc, char** argv)
     const int N = 256;
     const char* which = argc > 1 ? argv[1] : "all";
     auto on = [&](const char* k) { return !strcmp(which, "all") || !strcmp(which, k); };
-    if (on("s8")) {
-        printf("--- res3_3..6: 16/96 residual block at 32x40 ---\n");
-        bench_fb<16, 96, 16, 1, true, false, 16, 20, 1, 2, 8, 8>("current 16x40 tile, 1x2", N, 32, 40);
-        bench_fb<16, 96, 16, 1, true, false, 16, 20, 1, 1, 8, 8>("16x20 tile 1x1", N, 32, 40);
-        bench_fb<16, 96, 16, 1, true, false, 16, 20, 1, 1, 16, 8>("16x20 tile 1x1 EC16", N, 32, 40);
-        bench_fb<16, 96, 16, 1, true, false, 16, 20, 1, 1, 16, 16>("16x20 tile 1x1 EC16 CG16", N, 32, 40);
-        bench_fb<16, 96, 16, 1, true, false, 8, 40, 1, 1, 8, 8>("8x40 tile 1x1", N, 32, 40);
-        bench_fb<16, 96, 16, 1, true, false, 16, 20, 1, 2, 16, 8>("16x40 tile 1x2 EC16", N, 32, 40);
-        bench_fb<16, 96, 16, 1, true, false, 16, 20, 2, 2, 8, 8>("32x40 tile 2x2 (whole frame)", N, 32, 40);
-        bench_fb<16, 96, 16, 1, true, false, 8, 16, 1, 1, 8, 8>("8x16 tile 1x1 (128 thr)", N, 32, 40);
-        bench_fb<16, 96, 16, 1, true, false, 8, 8, 1, 1, 8, 8>("8x8 tile 1x1 (64 thr)", N, 32, 40);
-        bench_fb<16, 96, 16, 1, true, false, 8, 8, 2, 2, 8, 8>("16x16 tile 2x2 (64 thr)", N, 32, 40);
-        bench_fb<16, 96, 16, 1, true, false, 8, 16, 2, 2, 8, 8>("16x32 tile 2x2 (128 thr)", N, 32, 40);
-    }
     if (on("s4")) {
         printf("--- res2_x: 8/32 residual block at 64x80 ---\n");
-        bench_fb<8, 32, 8, 1, true, false, 32, 8, 2, 2, 8, 8>("current 64x16 tile 2x2", N, 64, 80);
-        bench_fb<8, 32, 8, 1, true, false, 16, 16, 2, 2, 8, 8>("32x32 tile 2x2", N, 64, 80);
-        bench_fb<8, 32, 8, 1, true, false, 16, 8, 2, 2, 8, 8>("32x16 tile 2x2 (128 thr)", N, 64, 80);
-        bench_fb<8, 32, 8, 1, true, false, 16, 16, 1, 1, 8, 8>("16x16 tile 1x1", N, 64, 80);
-        bench_fb<8, 32, 8, 1, true, false, 32, 8, 2, 2, 16, 8>("64x16 tile 2x2 EC16", N, 64, 80);
-        bench_fb<8, 32, 8, 1, true, false, 16, 20, 1, 2, 8, 8>("16x40 tile 1x2 (320 thr)", N, 64, 80);
-        bench_fb<8, 32, 8, 1, true, false, 8, 8, 2, 2, 8, 8>("16x16 tile 2x2 (64 thr)", N, 64, 80);
-        bench_fb<8, 32, 8, 1, true, false, 8, 8, 4, 2, 8, 8>("32x16 tile 4x2 (64 thr)", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 32, 8, 2, 2, 8, 8, 1, false>("64x16 tile 2x2 (old, no X staging)", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 16, 20, 1, 2, 8, 8, 1, true>("16x40 tile 1x2", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 16, 20, 1, 2, 8, 8, 2, true>("16x40 tile 1x2 PE2", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 16, 16, 1, 2, 8, 8, 1, true>("16x32 tile 1x2", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 16, 16, 1, 1, 8, 8, 1, true>("16x16 tile 1x1", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 8, 16, 2, 2, 8, 8, 1, true>("16x32 tile 2x2 (128 thr)", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 8, 8, 2, 2, 8, 8, 1, true>("16x16 tile 2x2 (64 thr)", N, 64, 80);
     }
     if (on("stem")) {
         printf("--- stem conv0+conv1_2/1_3/1_4 and res1_1 at 128x160 ---\n");
-        bench_fb<8, 8, 4, 1, false, true, 16, 16, 2, 2, 8, 8>("stem current 32x32 2x2", N, 128, 160);
-        bench_fb<8, 8, 4, 1, false, true, 16, 16, 1, 1, 8, 8>("stem 16x16 1x1", N, 128, 160);
-        bench_fb<8, 8, 4, 1, false, true, 8, 16, 2, 2, 8, 8>("stem 16x32 2x2 (128 thr)", N, 128, 160);
-        bench_fb<8, 8, 4, 1, false, true, 16, 16, 2, 2, 8, 4>("stem 32x32 2x2 CG4", N, 128, 160);
-        bench_fb<4, 8, 4, 1, true, false, 16, 16, 2, 2, 8, 8>("res1_1 current 32x32 2x2", N, 128, 160);
-        bench_fb<4, 8, 4, 1, true, false, 16, 16, 1, 1, 8, 8>("res1_1 16x16 1x1", N, 128, 160);
-        bench_fb<4, 8, 4, 1, true, false, 8, 16, 2, 2, 8, 8>("res1_1 16x32 2x2 (128 thr)", N, 128, 160);
+        bench_fb<8, 8, 4, 1, false, true, 16, 16, 2, 2, 8, 8, 1, true>("stem 32x32 2x2", N, 128, 160);
+        bench_fb<8, 8, 4, 1, false, true, 16, 16, 2, 2, 8, 8, 2, true>("stem 32x32 2x2 PE2", N, 128, 160);
+        bench_fb<8, 8, 4, 1, false, true, 16, 16, 1, 2, 8, 8, 1, true>("stem 16x32 1x2", N, 128, 160);
+        bench_fb<8, 8, 4, 1, false, true, 16, 16, 1, 1, 8, 8, 1, true>("stem 16x16 1x1", N, 128, 160);
+        bench_fb<4, 8, 4, 1, true, false, 16, 16, 2, 2, 8, 8, 1, false>("res1_1 32x32 2x2 (old)", N, 128, 160);
+        bench_fb<4, 8, 4, 1, true, false, 16, 16, 2, 2, 8, 8, 1, true>("res1_1 32x32 2x2", N, 128, 160);
+        bench_fb<4, 8, 4, 1, true, false, 16, 16, 2, 2, 8, 8, 4, true>("res1_1 32x32 2x2 PE4", N, 128, 160);
+        bench_fb<4, 8, 4, 1, true, false, 16, 16, 1, 2, 8, 8, 1, true>("res1_1 16x32 1x2", N, 128, 160);
+    }
+    if (on("s8")) {
+        printf("--- 8/48 ---\n");
+        bench_fb<8, 48, 8, 1, true, false, 16, 20, 1, 2, 8, 8, 2, false>("8/48 PE2 (no X staging)", N, 32, 40);
+        bench_fb<8, 48, 8, 1, true, false, 16, 20, 1, 2, 8, 8, 1, true>("8/48 PE1", N, 32, 40);
+        bench_fb<8, 48, 8, 1, true, false, 16, 20, 1, 2, 8, 8, 2, true>("8/48 PE2", N, 32, 40);
+        bench_fb<8, 48, 8, 1, true, false, 16, 20, 1, 1, 8, 8, 2, true>("8/48 16x20 1x1 PE2", N, 32, 40);
+    }
+    if (on("k19")) {
+        K19Args a{};
+        a.in = dev_rand((size_t)N * 128 * 160 * 4);
+        a.w8 = dev_rand(96, 0.3f); a.b8 = dev_rand(24, 0.1f); a.w9 = dev_rand(9 * 24 * 24, 0.1f); a.b9 = dev_rand(24, 0.1f);
+        a.w21 = dev_rand(24 * 8, 0.2f); a.b21 = dev_rand(8, 0.1f);
+        float* out; CK(hipMalloc(&out, (size_t)N * 64 * 80 * 8 * 4)); a.out = out;
+        a.H = 128; a.W = 160; a.Ho = 64; a.Wo = 80;
+        double macs = (double)N * (128.0 * 160 * 96 + 64.0 * 80 * (5184 + 192));
+        a.tiles_y = 4; a.tiles_x = 5;
+        float us = time_us([&] { hipLaunchKernelGGL(k19_kernel, dim3(N * 20), dim3(256), 0, 0, a); });
+        printf("k19 1 px/lane  16x16 tile   %8.1f us  %6.2f TMAC/s\n", us, macs / us * 1e-6);
     }
     if (on("mres")) {
         printf("--- MFMA residual blocks ---\n");

@@ -376,7 +376,7 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                 yf::FbArgs a{};
                 a.in = ptr(o.in1);
                 if (pre) { a.w0 = W(o.l_pre); a.b0 = B(o.l_pre); }
-                a.w1 = W(o.l_exp); a.b1 = B(o.l_exp); a.wd = W(o.l_dw); a.bd = B(o.l_dw); a.w2 = W(o.l_proj); a.b2 = B(o.l_proj);
+                a.wp = e->d_wmfma + o.mfma_off;
                 a.out = ptr(o.out);
                 a.H = pre ? ti.H / 2 : ti.H; a.W = pre ? ti.W / 2 : ti.W; a.Ho = to.H; a.Wo = to.W;
                 rc = yf::launch_fused_block(LE.cin, LE.cout, LP.cout, LD.stride, o.res >= 0, LP.relu != 0, pre, a, n, s);
@@ -508,6 +508,17 @@ int yf_create(const void* blob, size_t nbytes, int H, int W, int max_batch, int 
                 yf::mres_pack_weights(hw + e->w_off[o.l_exp], hw + e->b_off[o.l_exp], hw + e->w_off[o.l_dw], hw + e->b_off[o.l_dw],
                                       hw + e->w_off[o.l_proj], hw + e->b_off[o.l_proj], LE.cin, LE.cout, LP.cout,
                                       packed.data() + o.mfma_off);
+                continue;
+            }
+            if (o.type == OP_FUSED_BLOCK) {
+                const LayerSpec &LE = kLayers[o.l_exp], &LD = kLayers[o.l_dw], &LP = kLayers[o.l_proj];
+                const int ec = yf::fb_chunk_channels(LE.cin, LE.cout, LP.cout, LD.stride, o.res >= 0, LP.relu != 0, o.l_pre >= 0);
+                if (ec <= 0) { (void)hipFree(e->d_weights); delete e; return fail(YF_E_INVALID, "no fused kernel for block %s", LE.name); }
+                o.mfma_off = (long)packed.size();
+                packed.resize(packed.size() + ((yf::fb_packed_floats(LE.cin, LE.cout, LP.cout, ec) + 63) & ~(size_t)63));
+                yf::fb_pack_weights(hw + e->w_off[o.l_exp], hw + e->b_off[o.l_exp], hw + e->w_off[o.l_dw], hw + e->b_off[o.l_dw],
+                                    hw + e->w_off[o.l_proj], hw + e->b_off[o.l_proj], LE.cin, LE.cout, LP.cout, ec,
+                                    packed.data() + o.mfma_off);
                 continue;
             }
             if (o.type == OP_MDW) {

@@ -21,21 +21,53 @@ namespace yf {
 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
+
+// Diagnostic build only (-DYF_STAMP, tools/kbench.hip): per-phase shader-clock sums, written to a buffer nothing else reads.
+#ifdef YF_STAMP
+__device__ __forceinline__ unsigned long long yf_stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define YF_STAMP_DECL unsigned long long st_[6] = {0, 0, 0, 0, 0, 0}, st_t_ = yf_stamp();
+#define YF_STAMP_AT(i) { unsigned long long n_ = yf_stamp(); st_[i] += n_ - st_t_; st_t_ = n_; }
+#define YF_STAMP_FLUSH(dbg) if (dbg && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&dbg[i_], st_[i_]); }
+#else
+#define YF_STAMP_DECL
+#define YF_STAMP_AT(i)
+#define YF_STAMP_FLUSH(dbg)
+#endif
+
+// Weight stream of one block (host-packed, fb_pack_weights): per EC-channel chunk, contiguous
+//   [W1 chunk CIN x EC | b1 EC | wd 9 x EC | bd EC | W2 chunk EC x COUT], then b2[COUT]
+// so that a wave fetches a chunk's weights with a few s_load_dwordx16 instead of strided single-dword loads.
+__host__ __device__ constexpr int fb_chunk_floats(int cin, int cout, int ec) { return cin * ec + ec + 9 * ec + ec + ec * cout; }
+
 template <int CIN, int CEXP, int COUT, int S, bool RES, bool RELU_OUT, bool PRE, int TYB, int TXB, int BH, int BW,
-          int EC, int CG>
+          int EC, int CG, int PE, bool XL>
 __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
 {
     constexpr int NT = TYB * TXB, NW = NT / 64;
+    constexpr int O_B1 = CIN * EC, O_WD = O_B1 + EC, O_BD = O_WD + 9 * EC, O_W2 = O_BD + EC, CHF = O_W2 + EC * COUT;
+    static_assert(CHF == fb_chunk_floats(CIN, COUT, EC), "pack layout");
     constexpr int TH = TYB * BH, TW = TXB * BW;
     constexpr int RH = (TH - 1) * S + 3, RW = (TW - 1) * S + 3;
     constexpr int RWP = (RW + 3) & ~3;            // row pitch (floats), 16-B aligned rows
     constexpr int PLANE = RH * RWP;               // one channel plane
-    constexpr int NRP = RH * RW, NPB = (NRP + 63) / 64, NCG = EC / CG, NITEM = NPB * NCG;
+    constexpr int NRP = RH * RW, NPB = (NRP + 64 * PE - 1) / (64 * PE), NCG = EC / CG, NITEM = NPB * NCG;
     constexpr int WR = (BH - 1) * S + 3, WC = (BW - 1) * S + 3;  // dw window of one thread's output block
     static_assert(NT % 64 == 0 && CEXP % EC == 0 && EC % CG == 0 && COUT % 4 == 0, "shape");
     static_assert(!RES || (CIN == COUT && S == 1 && !PRE), "residual needs same shape");
     static_assert(CIN % 4 == 0 || PRE, "NHWC 16-B loads");
+    // input tile staged once: X[region px][CIN] (pitch XP: conflict-free 16-B reads); PRE: the raw 1-channel window
+    constexpr int XP = PRE ? 0 : (CIN == 4 ? 4 : CIN + 4);
+    constexpr int IRH = 2 * RH + 1, IRW = 2 * RW + 1, IRWP = (IRW + 3) & ~3;  // PRE: input rows/cols feeding the region
+    constexpr int XFLOATS = !XL ? 4 : PRE ? IRH * IRWP : NRP * XP;  // XL = false: inputs come straight from HBM/L2
     __shared__ __attribute__((aligned(16))) float E[EC * PLANE];
+    __shared__ __attribute__((aligned(16))) float X[XFLOATS];
 
     const int b = blockIdx.x;
     const int tx = b % a.tiles_x, ty = (b / a.tiles_x) % a.tiles_y, n = b / (a.tiles_x * a.tiles_y);
@@ -43,68 +75,125 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
     const int wave = wave_id(), lane = threadIdx.x & 63;
     const int tyb = threadIdx.x / TXB, txb = threadIdx.x % TXB;
 
+    // ---------------- stage the input tile (one exposed HBM latency per workgroup) ----------------
+    if constexpr (!XL) {
+    } else if constexpr (PRE) {
+        const float* __restrict__ src = a.in + (long)n * (4L * a.H * a.W);
+        const int yy0 = 2 * iy0 - 1, xx0 = 2 * ix0 - 1;
+        for (int idx = threadIdx.x; idx < IRH * IRW; idx += NT) {
+            const int r_ = idx / IRW, c_ = idx - r_ * IRW;
+            const int yy = yy0 + r_, xx = xx0 + c_;
+            X[r_ * IRWP + c_] = (yy >= 0 && yy < 2 * a.H && xx >= 0 && xx < 2 * a.W) ? src[(long)yy * (2 * a.W) + xx] : 0.f;
+        }
+    } else {
+        constexpr int C4 = CIN / 4;
+        const float* __restrict__ src = a.in + (long)n * a.H * a.W * CIN;
+        for (int idx = threadIdx.x; idx < NRP * C4; idx += NT) {
+            const int rp = idx / C4, c4 = idx - rp * C4;
+            const int ry_ = rp / RW, rx_ = rp - ry_ * RW;
+            const int iy = iy0 + ry_, ix = ix0 + rx_;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *reinterpret_cast<const float4*>(src + ((long)iy * a.W + ix) * CIN + c4 * 4);
+            *reinterpret_cast<float4*>(&X[rp * XP + c4 * 4]) = v;
+        }
+    }
+    __syncthreads();
+
     float acc[BH * BW][COUT];
 #pragma unroll
     for (int p = 0; p < BH * BW; ++p)
 #pragma unroll
         for (int co = 0; co < COUT; ++co) acc[p][co] = 0.f;
 
+    YF_STAMP_DECL
     for (int ch = 0; ch < CEXP / EC; ++ch) {
-        // ---------------- expansion of the halo'd region into LDS ----------------
+        YF_STAMP_AT(0)
+        const float* __restrict__ wc = a.wp + ch * CHF;  // this chunk's weights (wave-uniform -> scalar loads)
+        // ---------------- expansion of the halo'd region into LDS: PE pixels per lane per item ----------------
         for (int item = wave; item < NITEM; item += NW) {
             const int pb = item % NPB, cg = item / NPB;
-            const int c0 = ch * EC + cg * CG;  // wave-uniform
-            const int rp = pb * 64 + lane;
-            const int ry = rp / RW, rx = rp - ry * RW;
-            const int iy = iy0 + ry, ix = ix0 + rx;
-            const bool inreg = rp < NRP;
-            const bool inimg = inreg && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            float x[CIN];
-            if constexpr (PRE) {
-                // conv0: 3x3 stride 2 pad 1 on the 1-channel net input [N, 2H, 2W] (+ReLU)
-                const float* __restrict__ src = a.in + (long)n * (4L * a.H * a.W);
-                float v[9];
+            float x[PE][CIN];
+            int ry[PE], rx[PE];
+            bool inreg[PE], inimg[PE];
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+            for (int p = 0; p < PE; ++p) {
+                const int rp = pb * (64 * PE) + p * 64 + lane;
+                ry[p] = rp / RW; rx[p] = rp - ry[p] * RW;
+                const int iy = iy0 + ry[p], ix = ix0 + rx[p];
+                inreg[p] = rp < NRP;
+                inimg[p] = inreg[p] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                const int rpc = inreg[p] ? rp : 0;
+                if constexpr (PRE) {
+                    // conv0: 3x3 stride 2 pad 1 on the 1-channel net input (+ReLU)
+                    float v[9];
+                    if constexpr (XL) {  // window rows 2*ry.., cols 2*rx.. of the staged input
+                        const float* win0 = X + (2 * (rpc / RW)) * IRWP + 2 * (rpc % RW);
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        int yy = 2 * iy - 1 + ky, xx = 2 * ix - 1 + kx;
-                        bool ok = inimg && yy >= 0 && yy < 2 * a.H && xx >= 0 && xx < 2 * a.W;
-                        v[ky * 3 + kx] = ok ? src[(long)yy * (2 * a.W) + xx] : 0.f;
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) v[ky * 3 + kx] = win0[ky * IRWP + kx];
+                    } else {
+                        const float* __restrict__ src = a.in + (long)n * (4L * a.H * a.W);
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) {
+                                int yy = 2 * iy - 1 + ky, xx = 2 * ix - 1 + kx;
+                                bool ok = inimg[p] && yy >= 0 && yy < 2 * a.H && xx >= 0 && xx < 2 * a.W;
+                                v[ky * 3 + kx] = ok ? src[(long)yy * (2 * a.W) + xx] : 0.f;
+                            }
                     }
 #pragma unroll
-                for (int c = 0; c < CIN; ++c) {
-                    float s = a.b0[c];
+                    for (int c = 0; c < CIN; ++c) {
+                        float s = a.b0[c];
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) s = fmaf(v[t], a.w0[t * CIN + c], s);
-                    x[c] = fmaxf(s, 0.f);
-                }
-            } else {
-                const float* __restrict__ src = a.in + (((long)n * a.H + (inimg ? iy : 0)) * a.W + (inimg ? ix : 0)) * CIN;
+                        for (int t = 0; t < 9; ++t) s = fmaf(v[t], a.w0[t * CIN + c], s);
+                        x[p][c] = fmaxf(s, 0.f);
+                    }
+                } else if constexpr (XL) {
 #pragma unroll
-                for (int k = 0; k < CIN; k += 4) {
-                    float4 t = *reinterpret_cast<const float4*>(src + k);
-                    x[k] = t.x; x[k + 1] = t.y; x[k + 2] = t.z; x[k + 3] = t.w;
+                    for (int k = 0; k < CIN; k += 4) {
+                        float4 t = *reinterpret_cast<const float4*>(&X[rpc * XP + k]);
+                        x[p][k] = t.x; x[p][k + 1] = t.y; x[p][k + 2] = t.z; x[p][k + 3] = t.w;
+                    }
+                } else {
+                    const float* __restrict__ src = a.in + (((long)n * a.H + (inimg[p] ? iy : 0)) * a.W + (inimg[p] ? ix : 0)) * CIN;
+#pragma unroll
+                    for (int k = 0; k < CIN; k += 4) {
+                        float4 t = *reinterpret_cast<const float4*>(src + k);
+                        x[p][k] = t.x; x[p][k + 1] = t.y; x[p][k + 2] = t.z; x[p][k + 3] = t.w;
+                    }
                 }
             }
-            float e[CG];
+            float e[PE][CG];
 #pragma unroll
-            for (int j = 0; j < CG; ++j) e[j] = a.b1[c0 + j];
+            for (int j = 0; j < CG; ++j) {
+                const float bv = wc[O_B1 + cg * CG + j];
+#pragma unroll
+                for (int p = 0; p < PE; ++p) e[p][j] = bv;
+            }
 #pragma unroll
             for (int k = 0; k < CIN; ++k)
 #pragma unroll
-                for (int j = 0; j < CG; ++j) e[j] = fmaf(x[k], a.w1[k * CEXP + c0 + j], e[j]);
-            if (inreg) {
-                float* dst = E + (cg * CG) * PLANE + ry * RWP + rx;
+                for (int j = 0; j < CG; ++j) {
+                    const float wv = wc[k * EC + cg * CG + j];
 #pragma unroll
-                for (int j = 0; j < CG; ++j) dst[j * PLANE] = inimg ? fmaxf(e[j], 0.f) : 0.f;
-            }
+                    for (int p = 0; p < PE; ++p) e[p][j] = fmaf(x[p][k], wv, e[p][j]);
+                }
+#pragma unroll
+            for (int p = 0; p < PE; ++p)
+                if (inreg[p]) {
+                    float* dst = E + (cg * CG) * PLANE + ry[p] * RWP + rx[p];
+#pragma unroll
+                    for (int j = 0; j < CG; ++j) dst[j * PLANE] = inimg[p] ? fmaxf(e[p][j], 0.f) : 0.f;
+                }
         }
+        YF_STAMP_AT(1)
         __syncthreads();
+        YF_STAMP_AT(2)
         // ---------------- depthwise 3x3 from LDS + projection into registers ----------------
 #pragma unroll
         for (int c = 0; c < EC; ++c) {
-            const int cc = ch * EC + c;
             const float* Ec = E + c * PLANE + (tyb * BH * S) * RWP + txb * BW * S;
             float win[WR][WC];
 #pragma unroll
@@ -128,8 +217,8 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
             }
             float wd[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) wd[t] = a.wd[t * CEXP + cc];
-            const float bd = a.bd[cc];
+            for (int t = 0; t < 9; ++t) wd[t] = wc[O_WD + t * EC + c];
+            const float bd = wc[O_BD + c];
 #pragma unroll
             for (int by = 0; by < BH; ++by)
 #pragma unroll
@@ -142,12 +231,15 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
                     d = fmaxf(d, 0.f);
 #pragma unroll
                     for (int co = 0; co < COUT; ++co)
-                        acc[by * BW + bx][co] = fmaf(d, a.w2[cc * COUT + co], acc[by * BW + bx][co]);
+                        acc[by * BW + bx][co] = fmaf(d, wc[O_W2 + c * COUT + co], acc[by * BW + bx][co]);
                 }
         }
+        YF_STAMP_AT(3)
         __syncthreads();
+        YF_STAMP_AT(4)
     }
     // ---------------- epilogue: bias (+ residual) (+ ReLU), NHWC store ----------------
+    const float* __restrict__ b2 = a.wp + (CEXP / EC) * CHF;
 #pragma unroll
     for (int by = 0; by < BH; ++by)
 #pragma unroll
@@ -158,10 +250,11 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
             float* o = a.out + opix * COUT;
 #pragma unroll
             for (int co = 0; co < COUT; co += 4) {
-                float4 v = make_float4(acc[by * BW + bx][co] + a.b2[co], acc[by * BW + bx][co + 1] + a.b2[co + 1],
-                                       acc[by * BW + bx][co + 2] + a.b2[co + 2], acc[by * BW + bx][co + 3] + a.b2[co + 3]);
-                if constexpr (RES) {
-                    float4 r = *reinterpret_cast<const float4*>(a.in + opix * CIN + co);
+                float4 v = make_float4(acc[by * BW + bx][co] + b2[co], acc[by * BW + bx][co + 1] + b2[co + 1],
+                                       acc[by * BW + bx][co + 2] + b2[co + 2], acc[by * BW + bx][co + 3] + b2[co + 3]);
+                if constexpr (RES) {  // the residual is the centre of the staged tile
+                    float4 r = XL ? *reinterpret_cast<const float4*>(&X[((tyb * BH + by + 1) * RW + txb * BW + bx + 1) * XP + co])
+                                  : *reinterpret_cast<const float4*>(a.in + opix * CIN + co);
                     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                 }
                 if constexpr (RELU_OUT) {
@@ -170,11 +263,17 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
                 *reinterpret_cast<float4*>(o + co) = v;
             }
         }
+    YF_STAMP_AT(5)
+    YF_STAMP_FLUSH(a.dbg)
 }
 
 // ------------------------------------------------------------------------------------------------
 // conv1_8 (pw 4->24, ReLU) -> conv1_9 (dense 3x3 stride 2 pad 1, 24->24, ReLU) -> conv2_1 (pw 24->8, linear)
 //   tile: 16x16 output pixels (stride-4 resolution), 256 threads, one output pixel per thread.
+//   Measured alternatives that did NOT help (tools/kbench.hip, profiles/): two pixels per lane (each scalar weight feeding
+//   two FMAs) and v_pk_fma_f32 over pixel pairs or output-channel pairs all land at the same ~250 us / 30 TMAC/s although the
+//   packed forms halve the VALU instruction count -- the kernel is not VALU-issue-bound (fully unrolled straight-line code,
+//   instruction fetch is the suspect).
 //   conv1_8's output over the (33x33) halo'd region goes to LDS in two halves of 12 channels, split into
 //   even-column and odd-column planes ("space to depth") so that lanes on consecutive output columns read
 //   consecutive 48-B pixel records: conflict-free ds_read_b128.
@@ -266,35 +365,72 @@ __global__ void __launch_bounds__(256) k19_kernel(K19Args a)
 // ------------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int CEXP, int COUT, int S, bool RES, bool RELU_OUT, bool PRE, int TYB, int TXB, int BH, int BW, int EC, int CG>
+template <int CIN, int CEXP, int COUT, int S, bool RES, bool RELU_OUT, bool PRE, int TYB, int TXB, int BH, int BW, int EC, int CG, int PE, bool XL>
 static int launch_fb_t(FbArgs a, int N, hipStream_t s)
 {
     a.tiles_y = (a.Ho + TYB * BH - 1) / (TYB * BH);
     a.tiles_x = (a.Wo + TXB * BW - 1) / (TXB * BW);
     dim3 grid((unsigned)(N * a.tiles_y * a.tiles_x));
-    hipLaunchKernelGGL((fused_block_kernel<CIN, CEXP, COUT, S, RES, RELU_OUT, PRE, TYB, TXB, BH, BW, EC, CG>), grid,
+    hipLaunchKernelGGL((fused_block_kernel<CIN, CEXP, COUT, S, RES, RELU_OUT, PRE, TYB, TXB, BH, BW, EC, CG, PE, XL>), grid,
                        dim3(TYB * TXB), 0, s, a);
     return 0;
 }
 
+//     cin cexp cout S  res    relu   pre    TYB TXB BH BW EC CG PE XL      (XL: stage the input tile in LDS -- measured
+//     slower at these shapes: it costs occupancy and LDS bandwidth, the L2-served loads were already hidden)
+#define YF_FB_SHAPES(FB)                                                                                                 \
+    FB(8, 8, 4, 1, false, false, true, 16, 16, 2, 2, 8, 8, 1, false)     /* conv0 + conv1_2/1_3/1_4      @ H/2  */          \
+    FB(4, 8, 4, 1, true, false, false, 16, 16, 2, 2, 8, 8, 1, false)     /* res1_1                        @ H/2  */          \
+    FB(8, 32, 8, 1, true, false, false, 32, 8, 2, 2, 8, 8, 1, false)     /* res2_1, res2_2                @ H/4  */          \
+    FB(8, 32, 8, 2, false, false, false, 16, 20, 1, 1, 8, 8, 1, false)   /* conv2_2/2_3/3_1               H/4 -> H/8 */      \
+    FB(8, 48, 8, 1, true, false, false, 16, 20, 1, 2, 8, 8, 2, false)    /* res3_1, res3_2                @ H/8  */          \
+    FB(8, 48, 16, 1, false, false, false, 16, 20, 1, 2, 8, 8, 2, false)  /* conv3_2/3_3/3_4 (fallback)    @ H/8  */          \
+    FB(16, 96, 16, 1, true, false, false, 16, 20, 1, 2, 8, 8, 1, false)  /* res3_3 .. res3_6 (fallback)   @ H/8  */          \
+    FB(16, 96, 24, 2, false, false, false, 16, 20, 1, 1, 8, 8, 1, false) /* conv3_5/3_6/4_1               H/8 -> H/16 */     \
+    FB(24, 136, 24, 1, true, false, false, 16, 20, 1, 1, 8, 8, 1, false) /* res4_1 .. res4_4 (fallback)   @ H/16 */
+
 int launch_fused_block(int cin, int cexp, int cout, int stride, bool res, bool relu_out, bool pre, const FbArgs& a, int N,
                        hipStream_t s)
 {
-#define FB(ci, ce, co, st, rs, ro, pr, tyb, txb, bh, bw, ec, cg)                                                  \
+#define FB(ci, ce, co, st, rs, ro, pr, tyb, txb, bh, bw, ec, cg, pe, xl)                                          \
     if (cin == ci && cexp == ce && cout == co && stride == st && res == rs && relu_out == ro && pre == pr)         \
-        return launch_fb_t<ci, ce, co, st, rs, ro, pr, tyb, txb, bh, bw, ec, cg>(a, N, s);
-    //  cin cexp cout S  res    relu   pre    TYB TXB BH BW EC CG
-    FB(8, 8, 4, 1, false, false, true, 16, 16, 2, 2, 8, 8)     // conv0 + conv1_2/1_3/1_4      @ H/2
-    FB(4, 8, 4, 1, true, false, false, 16, 16, 2, 2, 8, 8)     // res1_1                        @ H/2
-    FB(8, 32, 8, 1, true, false, false, 32, 8, 2, 2, 8, 8)     // res2_1, res2_2                @ H/4
-    FB(8, 32, 8, 2, false, false, false, 16, 20, 1, 1, 8, 8)   // conv2_2/2_3/3_1               H/4 -> H/8
-    FB(8, 48, 8, 1, true, false, false, 16, 20, 1, 2, 8, 8)    // res3_1, res3_2                @ H/8
-    FB(8, 48, 16, 1, false, false, false, 16, 20, 1, 2, 8, 8)  // conv3_2/3_3/3_4               @ H/8
-    FB(16, 96, 16, 1, true, false, false, 16, 20, 1, 2, 8, 8)  // res3_3 .. res3_6              @ H/8
-    FB(16, 96, 24, 2, false, false, false, 16, 20, 1, 1, 8, 8) // conv3_5/3_6/4_1               H/8 -> H/16
-    FB(24, 136, 24, 1, true, false, false, 16, 20, 1, 1, 8, 8) // res4_1 .. res4_4              @ H/16
+        return launch_fb_t<ci, ce, co, st, rs, ro, pr, tyb, txb, bh, bw, ec, cg, pe, xl>(a, N, s);
+    YF_FB_SHAPES(FB)
 #undef FB
     return -1;
+}
+
+int fb_chunk_channels(int cin, int cexp, int cout, int stride, bool res, bool relu_out, bool pre)
+{
+#define FB(ci, ce, co, st, rs, ro, pr, tyb, txb, bh, bw, ec, cg, pe, xl) \
+    if (cin == ci && cexp == ce && cout == co && stride == st && res == rs && relu_out == ro && pre == pr) return ec;
+    YF_FB_SHAPES(FB)
+#undef FB
+    return -1;
+}
+
+size_t fb_packed_floats(int cin, int cexp, int cout, int ec) { return (size_t)(cexp / ec) * fb_chunk_floats(cin, cout, ec) + cout; }
+
+void fb_pack_weights(const float* w1 /*[cin][cexp]*/, const float* b1, const float* wd /*[9][cexp]*/, const float* bd,
+                     const float* w2 /*[cexp][cout]*/, const float* b2, int cin, int cexp, int cout, int ec, float* out)
+{
+    const int CHF = fb_chunk_floats(cin, cout, ec);
+    for (int ch = 0; ch < cexp / ec; ++ch) {
+        float* o = out + (size_t)ch * CHF;
+        for (int k = 0; k < cin; ++k)
+            for (int j = 0; j < ec; ++j) o[k * ec + j] = w1[(size_t)k * cexp + ch * ec + j];
+        o += cin * ec;
+        for (int j = 0; j < ec; ++j) o[j] = b1[ch * ec + j];
+        o += ec;
+        for (int t = 0; t < 9; ++t)
+            for (int j = 0; j < ec; ++j) o[t * ec + j] = wd[(size_t)t * cexp + ch * ec + j];
+        o += 9 * ec;
+        for (int j = 0; j < ec; ++j) o[j] = bd[ch * ec + j];
+        o += ec;
+        for (int j = 0; j < ec; ++j)
+            for (int co = 0; co < cout; ++co) o[j * cout + co] = w2[(size_t)(ch * ec + j) * cout + co];
+    }
+    for (int co = 0; co < cout; ++co) out[(size_t)(cexp / ec) * CHF + co] = b2[co];
 }
 
 int launch_k19(K19Args a, int N, hipStream_t s)

@@ -49,15 +49,18 @@ void launch_preprocess(const uint8_t* in, float* out, long N, int H, int W, int 
 struct FbArgs {
     const float* in;              // NHWC [N,H,W,CIN]; PRE: the 1-channel net input [N,2H,2W]
     const float *w0, *b0;         // PRE only: conv0 [9][8], [8]
-    const float *w1, *b1;         // expand  [CIN][CEXP], [CEXP]
-    const float *wd, *bd;         // dw 3x3  [9][CEXP],  [CEXP]
-    const float *w2, *b2;         // project [CEXP][COUT], [COUT]
+    const float* wp;              // chunk-major weight stream of expand / depthwise / project (fb_pack_weights)
     float* out;                   // NHWC [N,Ho,Wo,COUT]
     int H, W, Ho, Wo;             // expansion-resolution and output-resolution frame sizes
     int tiles_y, tiles_x;         // filled by the launcher
+    unsigned long long* dbg;      // diagnostic builds only (-DYF_STAMP): per-phase cycle sums; null in the product
 };
 int launch_fused_block(int cin, int cexp, int cout, int stride, bool res, bool relu_out, bool pre, const FbArgs& a, int N,
                        hipStream_t s);
+int fb_chunk_channels(int cin, int cexp, int cout, int stride, bool res, bool relu_out, bool pre);  // EC of that shape, -1 if none
+size_t fb_packed_floats(int cin, int cexp, int cout, int ec);
+void fb_pack_weights(const float* w1, const float* b1, const float* wd, const float* bd, const float* w2, const float* b2, int cin,
+                     int cexp, int cout, int ec, float* out);
 
 struct MresArgs {
     const float* in;   // NHWC [N,H,W,CIN]
