@@ -104,6 +104,26 @@ static void bench_mres(const char* tag, int N, int H, int W)
     printf("%-40s tile=%2dx%-2d waves=%d lds=%6zu grid=%6u  %8.1f us  %6.2f TMAC/s\n", tag, TH, TW, NWAVE, lds, grid.x, us, macs / us * 1e-6);
 }
 
+template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NWC>
+static void bench_mres_pc(const char* tag, int N, int H, int W)
+{
+    MresArgs a{};
+    a.in = dev_rand((size_t)N * H * W * CIN);
+    a.wp = dev_rand(mres_packed_floats(CIN, CEXP, COUT) + 4096, 0.2f);
+    float* out; CK(hipMalloc(&out, (size_t)N * H * W * COUT * 4)); a.out = out;
+    a.H = H; a.W = W;
+    a.tiles_y = (H + TH - 1) / TH; a.tiles_x = (W + TW - 1) / TW;
+    constexpr int MTR = ((TH + 2) * (TW + 2) + 15) / 16;
+    constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 2 * 16 * (((MTR * 16 + 7) / 8) * 8 + 1) +
+                            ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT) + COUT + 3) & ~3)) * sizeof(float);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid(N * a.tiles_y * a.tiles_x);
+    float us = time_us([&] { hipLaunchKernelGGL((mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC>), grid, dim3((NWP + NWC) * 64), lds, 0, a); });
+    double macs = (double)N * H * W * CEXP * (CIN + 9 + COUT);
+    printf("%-40s tile=%2dx%-2d prod=%d cons=%d lds=%6zu grid=%6u  %8.1f us  %6.2f TMAC/s\n", tag, TH, TW, NWP, NWC, lds, grid.x, us, macs / us * 1e-6);
+}
+
 int main(int argc, char** argv)
 {
     const int N = 256;
@@ -148,6 +168,30 @@ int main(int argc, char** argv)
         a.tiles_y = 4; a.tiles_x = 5;
         float us = time_us([&] { hipLaunchKernelGGL(k19_kernel, dim3(N * 20), dim3(256), 0, 0, a); });
         printf("k19 1 px/lane  16x16 tile   %8.1f us  %6.2f TMAC/s\n", us, macs / us * 1e-6);
+    }
+    if (on("mrespc")) {
+        printf("--- MFMA residual blocks, producer/consumer waves ---\n");
+        bench_mres<16, 96, 16, true, 16, 20, 8>("16/96 s8 (2-barrier, 8 waves)", N, 32, 40);
+        bench_mres_pc<16, 96, 16, true, 16, 20, 4, 4>("16/96 s8", N, 32, 40);
+        bench_mres_pc<16, 96, 16, true, 16, 20, 3, 5>("16/96 s8", N, 32, 40);
+        bench_mres_pc<16, 96, 16, true, 16, 20, 2, 5>("16/96 s8", N, 32, 40);
+        bench_mres_pc<16, 96, 16, true, 16, 20, 4, 10>("16/96 s8", N, 32, 40);
+        bench_mres_pc<16, 96, 16, true, 8, 20, 2, 5>("16/96 s8", N, 32, 40);
+        bench_mres<24, 136, 24, true, 16, 20, 8>("24/136 s16 (2-barrier, 8 waves)", N, 16, 20);
+        bench_mres_pc<24, 136, 24, true, 16, 20, 4, 4>("24/136 s16", N, 16, 20);
+        bench_mres_pc<24, 136, 24, true, 16, 20, 3, 5>("24/136 s16", N, 16, 20);
+        bench_mres_pc<24, 136, 24, true, 16, 20, 5, 10>("24/136 s16", N, 16, 20);
+        bench_mres_pc<24, 136, 24, true, 16, 20, 6, 10>("24/136 s16", N, 16, 20);
+        bench_mres<48, 224, 48, true, 8, 10, 8>("48/224 s32 (2-barrier, 8 waves)", N, 8, 10);
+        bench_mres_pc<48, 224, 48, true, 8, 10, 4, 4>("48/224 s32", N, 8, 10);
+        bench_mres_pc<48, 224, 48, true, 8, 10, 4, 5>("48/224 s32", N, 8, 10);
+        bench_mres_pc<48, 224, 48, true, 8, 10, 8, 5>("48/224 s32", N, 8, 10);
+        bench_mres_pc<48, 224, 48, true, 8, 10, 3, 5>("48/224 s32", N, 8, 10);
+        bench_mres<8, 48, 16, false, 16, 20, 4>("8/48/16 s8 (2-barrier, 4 waves)", N, 32, 40);
+        bench_mres_pc<8, 48, 16, false, 16, 20, 2, 5>("8/48/16 s8", N, 32, 40);
+        bench_mres_pc<8, 48, 16, false, 16, 20, 3, 5>("8/48/16 s8", N, 32, 40);
+        bench_mres_pc<8, 32, 8, true, 16, 20, 2, 5>("8/32 s4", N, 64, 80);
+        bench_mres_pc<8, 48, 8, true, 16, 20, 2, 5>("8/48 s8", N, 32, 40);
     }
     if (on("mres")) {
         printf("--- MFMA residual blocks ---\n");
