@@ -103,6 +103,20 @@ int yf_decode_nms(yf_handle h, const float *d_head_large, const float *d_head_sm
  * of the kept box that removed it (-2 in every entry: the reference's ZeroDivisionError). */
 int yf_nms_sorted(yf_handle h, const int32_t *d_boxes, int n, double nms_thres, int32_t *d_suppressor, void *stream);
 
+/* Validation-time decode and NMS (the reference's OTHER convention, used by validate.py for mAP):
+ *   yf_val_decode_head = YOLOLossV3.forward(input, targets=None)   src/model_training/loss/yolo_loss.py:48-68, :98-141
+ *       d_head float32 [N,24,fh,fw] -> rows m_off .. m_off+3*fh*fw of d_out float32 [N,M_total,8] = (cx,cy,w,h,conf,cls0..2),
+ *       anchors: HOST double[3][2] of this head; calling it once per head with m_off = 0 / 3*fh*fw reproduces
+ *       validate.py:38-42's torch.cat over heads.
+ *   yf_val_nms = utils.general.non_max_suppression                 src/model_training/utils/general.py:87-143 (+ bbox_iou :29-52)
+ *       d_pred float32 [N,M,8]; conf >= conf_thres, per-class greedy NMS, IoU with the +1 convention, keep iou < nms_thres;
+ *       d_det float32 [N,K_max,7] = (x1,y1,x2,y2,obj_conf,class_conf,class_pred), class-ascending then conf-descending;
+ *       d_counts int32 [N] = true number of detections (0 <=> the reference's None). */
+int yf_val_decode_head(yf_handle h, const float *d_head, int N, int fh, int fw, const double *anchors, int M_total, int m_off,
+                       float *d_out, void *stream);
+int yf_val_nms(yf_handle h, const float *d_pred, int N, int M, double conf_thres, double nms_thres, int K_max, float *d_det,
+               int32_t *d_counts, void *stream);
+
 /* yf_forward + yf_decode_nms back to back on one stream (heads also returned; may be NULL to use
  * workspace-internal buffers). */
 int yf_detect(yf_handle h, const float *d_x, int N, double conf_thres, double nms_thres, const double *anchors,

@@ -239,5 +239,38 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"golden_dense_{res}.npz"), **d)
 
 
+def main_val():
+    """Validation-path goldens: the reference's own YOLOLossV3 decode branch and
+    utils.general.non_max_suppression, imported from src/model_training with an empty stub module for cv2
+    (only plot_one_box dereferences it)."""
+    import types
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    sys.path.insert(0, os.path.join(REF, "src", "model_training"))
+    from loss.yolo_loss import YOLOLossV3            # the reference
+    from utils.general import non_max_suppression    # the reference
+    model, io = load_model(256)
+    g = np.load(os.path.join(HERE, "golden_256.npz"))
+    dense = np.load(os.path.join(HERE, "golden_dense_256.npz"))
+    dev = torch.device("cpu")
+    losses = [YOLOLossV3(io["anchors"][i], io["num_cls"], io["input_shape"], dev) for i in range(2)]
+    out = {}
+    for tag, hl, hs in (("real", g["head_large"], g["head_small"]), ("dense", dense["head_large"], dense["head_small"])):
+        pred = (torch.from_numpy(hl.copy()), torch.from_numpy(hs.copy()))
+        with torch.no_grad():
+            dec = torch.cat([losses[i](pred[i]) for i in range(2)], 1)  # validate.py:38-42
+            dets = non_max_suppression(dec.clone(), io["num_cls"], conf_thres=0.5, nms_thres=0.2)
+        kmax = max([0 if d is None else d.shape[0] for d in dets] + [1])
+        det = np.zeros((len(dets), kmax, 7), np.float32)
+        cnt = np.zeros((len(dets),), np.int32)
+        for f, d in enumerate(dets):
+            if d is not None:
+                cnt[f] = d.shape[0]; det[f, :d.shape[0]] = d.numpy()
+        out[f"{tag}_decode"] = dec.numpy()[:4]
+        out[f"{tag}_det"] = det; out[f"{tag}_count"] = cnt
+        print("val", tag, "detections per frame:", cnt.tolist())
+    np.savez_compressed(os.path.join(HERE, "golden_val_256.npz"), **out)
+
+
 if __name__ == "__main__":
     main()
+    main_val()

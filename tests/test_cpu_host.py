@@ -141,3 +141,19 @@ def test_config_mirror():
     assert io["conf_thre"] == 0.5 and io["nms_thre"] == 0.2 and io["class_names"] == ["carrier", "defender", "destroyer"]
     io5 = yf.io_params_for(512)
     assert io5["input_shape"] == [512, 640, 1] and io5["anchors"][0] == [[150, 75], [100, 100], [75, 150]]
+
+
+def test_ncnn_model_files_give_the_same_blob(sd):
+    """the reference's shipped ncnn .param/.bin (BN already folded by its converter) packs to the same
+    blob as the .pth folded here -- to fp32 rounding of two different fold orders."""
+    pth = packer.unpack(packer.pack_state_dict(sd))
+    ncnn = packer.unpack(packer.pack_ncnn(os.path.join(ROOT, "tests", "golden", "ncnn", "yolo_fastest_256x320.param"),
+                                          os.path.join(ROOT, "tests", "golden", "ncnn", "yolo_fastest_256x320.bin")))
+    assert list(pth) == list(ncnn)
+    for k in pth:
+        for f in ("kind", "cin", "cout", "k", "stride", "relu"):
+            assert pth[k][f] == ncnn[k][f], (k, f)
+        assert np.abs(pth[k]["w"] - ncnn[k]["w"]).max() < 5e-6, k
+        assert np.abs(pth[k]["b"] - ncnn[k]["b"]).max() < 5e-6, k
+    with pytest.raises(ValueError):
+        packer.read_ncnn(W256, W256)  # not a .param file

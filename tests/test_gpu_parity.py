@@ -345,3 +345,48 @@ def test_post_edge_cases(models, dev):
     assert int(raw["counts"][0]) == 20
     with pytest.raises(OverflowError):
         post.to_lists(raw)
+
+
+def test_weights_from_ncnn_files(yf, golden, dev):
+    """The engine fed from the reference's ncnn .param/.bin instead of the .pth: same heads as the reference."""
+    io = yf.io_params_for(256)
+    m = yf.YoloFastest(io).eval().load_ncnn(os.path.join(ROOT, "tests", "golden", "ncnn", "yolo_fastest_256x320.param"),
+                                            os.path.join(ROOT, "tests", "golden", "ncnn", "yolo_fastest_256x320.bin")).to(dev)
+    g = golden("golden_256")
+    with torch.no_grad():
+        hl, hs = m(_x(g["input_u8"], dev))
+    _check_heads(hl, hs, g["head_large"], g["head_small"], g["head_large_f64"], g["head_small_f64"])
+
+
+def test_validation_path_decode_and_nms(yf, models, golden, dev):
+    """YOLOLossV3 decode branch + general.non_max_suppression (the +1 IoU convention) on the GPU.
+    Decode: fp32 transcendental functions differ from torch-CPU in the last bits -> 2e-6 relative.  NMS: only fp32
+    add/mul/div after that, so fed the reference's own decode tensor it must reproduce the reference bit for bit."""
+    from yolo_fastest_amd import validation as val
+    m, _, io = models[256]
+    m(_x(np.zeros((1, 256, 320), np.uint8), dev))
+    val.bind(m)
+    gv = golden("golden_val_256")
+    for tag, src in (("real", golden("golden_256")), ("dense", golden("golden_dense_256"))):
+        pred = (torch.from_numpy(src["head_large"].copy()).to(dev), torch.from_numpy(src["head_small"].copy()).to(dev))
+        dec = torch.cat([val.YOLOLossV3(io["anchors"][i], 3, io["input_shape"], dev)(pred[i]) for i in range(2)], 1)
+        want = gv[f"{tag}_decode"]
+        got = dec[:4].cpu().numpy()
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+        # NMS on the reference's own decode tensor (the stored golden, 4 frames per set): exact
+        dets = val.non_max_suppression(torch.from_numpy(want.copy()).to(dev), 3, conf_thres=0.5, nms_thres=0.2)
+        for f, d in enumerate(dets):
+            n = int(gv[f"{tag}_count"][f])
+            assert (0 if d is None else d.shape[0]) == n, (tag, f)
+            if n:
+                assert np.array_equal(d.cpu().numpy(), gv[f"{tag}_det"][f, :n]), (tag, f)
+        # end to end (own decode): same survivors, boxes to fp32 rounding of the decode
+        dets = val.non_max_suppression(dec, 3, conf_thres=0.5, nms_thres=0.2)
+        if tag == "real":
+            for f, d in enumerate(dets):
+                n = int(gv["real_count"][f])
+                assert d is not None and d.shape[0] == n
+                assert np.allclose(d.cpu().numpy(), gv["real_det"][f, :n], rtol=2e-6, atol=2e-5)
+    with pytest.raises(NotImplementedError):
+        val.YOLOLossV3(io["anchors"][0], 3, io["input_shape"], dev)(pred[0], targets=torch.zeros(1))

@@ -146,3 +146,23 @@ def test_post_oracle_edge_cases():
     assert len(out) == 1 and out[0][7] == 5 * 20 + 5
     r = poc.post_process(hl2, hs, anchors, (256, 320))
     assert list(r["src"]) == [5 * 20 + 5]
+
+
+def test_validation_oracle_matches_reference(golden):
+    """oracle/val_oracle.py against the reference's own YOLOLossV3 decode branch + utils.general.non_max_suppression."""
+    from oracle import val_oracle as vo
+    gv = golden("golden_val_256")
+    anchors = [[[10, 13], [16, 30], [33, 23]], [[150, 75], [100, 100], [75, 150]]]
+    for tag, src in (("real", golden("golden_256")), ("dense", golden("golden_dense_256"))):
+        pred = (torch.from_numpy(src["head_large"].copy()), torch.from_numpy(src["head_small"].copy()))
+        dec = vo.decode(pred, anchors, 3, (256, 320))
+        # same torch ops in the same order; torch.exp/sigmoid may differ in the last bit between CPU models
+        want = torch.from_numpy(gv[f"{tag}_decode"])
+        assert torch.allclose(dec[:4], want, rtol=1e-6, atol=1e-6)
+        # NMS is pure fp32 add/mul/div: exact when fed the reference's own decode tensor
+        dets = vo.non_max_suppression(want, 3, conf_thres=0.5, nms_thres=0.2)
+        for f, d in enumerate(dets):
+            n = int(gv[f"{tag}_count"][f])
+            assert (0 if d is None else d.shape[0]) == n
+            if n:
+                assert np.array_equal(d.numpy(), gv[f"{tag}_det"][f, :n])

@@ -31,6 +31,10 @@ _SIGS = {
                              _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "yf_preprocess_u8": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "yf_nms_sorted": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_double, _c.c_void_p, _c.c_void_p]),
+    "yf_val_decode_head": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.c_int, _c.c_int,
+                                      _c.c_void_p, _c.c_void_p]),
+    "yf_val_nms": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_int, _c.c_void_p, _c.c_void_p,
+                              _c.c_void_p]),
     "yf_num_launches": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int)]),
     "yf_op_info": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_char_p, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     "yf_profile_forward": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_size_t, _c.c_void_p,

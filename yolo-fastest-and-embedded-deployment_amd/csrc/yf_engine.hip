@@ -643,6 +643,34 @@ int yf_nms_sorted(yf_handle h, const int32_t* d_boxes, int n, double nms_thres, 
     return YF_OK;
 }
 
+// Validation-time path.  anchors: HOST double[3][2] of THIS head, net-input pixels.
+int yf_val_decode_head(yf_handle h, const float* d_head, int N, int fh, int fw, const double* anchors, int M_total, int m_off,
+                       float* d_out, void* stream)
+{
+    if (!h || !d_head || !anchors || !d_out || N <= 0 || fh <= 0 || fw <= 0 || m_off < 0 || m_off + 3 * fh * fw > M_total)
+        return fail(YF_E_INVALID, "yf_val_decode_head: bad argument");
+    HIP_OK(hipSetDevice(h->device));
+    // yolo_loss.py:52-56: strides and feature-map-scaled anchors are Python doubles, stored into FloatTensors
+    const double stride_h = (double)h->H / fh, stride_w = (double)h->W / fw;
+    float anc6[6];
+    for (int a = 0; a < 3; ++a) { anc6[2 * a] = (float)(anchors[2 * a] / stride_w); anc6[2 * a + 1] = (float)(anchors[2 * a + 1] / stride_h); }
+    yf::launch_val_decode(d_head, d_out, N, fh, fw, M_total, m_off, anc6, (float)stride_w, (float)stride_h, (hipStream_t)stream);
+    HIP_OK(hipGetLastError());
+    return YF_OK;
+}
+
+int yf_val_nms(yf_handle h, const float* d_pred, int N, int M, double conf_thres, double nms_thres, int K_max, float* d_det,
+               int32_t* d_counts, void* stream)
+{
+    if (!h || !d_pred || !d_det || !d_counts || N <= 0 || M <= 0 || K_max <= 0) return fail(YF_E_INVALID, "yf_val_nms: bad argument");
+    HIP_OK(hipSetDevice(h->device));
+    int rc = yf::launch_val_nms(d_pred, N, M, (float)conf_thres, (float)nms_thres, K_max, d_det, d_counts, (hipStream_t)stream);
+    if (rc == -1) return fail(YF_E_INVALID, "yf_val_nms: at most 8191 boxes per image");
+    if (rc) return fail(YF_E_HIP, "hipFuncSetAttribute(val_nms_kernel) failed");
+    HIP_OK(hipGetLastError());
+    return YF_OK;
+}
+
 int yf_detect(yf_handle h, const float* d_x, int N, double conf_thres, double nms_thres, const double* anchors, int origin_h,
               int origin_w, int K_max, int32_t* d_boxes, float* d_scores, int32_t* d_cls, int32_t* d_src, int32_t* d_counts,
               float* d_hl, float* d_hs, void* ws, size_t ws_bytes, void* stream)

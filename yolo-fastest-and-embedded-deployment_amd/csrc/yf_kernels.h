@@ -117,6 +117,9 @@ struct PostArgs {
 };
 int launch_post(const PostArgs& a, int N, hipStream_t s);
 size_t post_lds_bytes(int ncell);
+void launch_val_decode(const float* in, float* out, int N, int h, int w, int M_total, int m_off, const float* anc6, float stride_w,
+                       float stride_h, hipStream_t s);
+int launch_val_nms(const float* pred, int N, int M, float conf_thres, float nms_thres, int kmax, float* det, int32_t* counts, hipStream_t s);
 void launch_nms_sorted(const int32_t* boxes, int n, double nms_thres, int32_t* suppressor, hipStream_t s);
 
 }  // namespace yf

@@ -236,6 +236,159 @@ void launch_nms_sorted(const int32_t* boxes, int n, double nms_thres, int32_t* s
                        nms_thres, suppressor);
 }
 
+// ================================================================================================
+// Validation-time decode + NMS -- the OTHER convention of the reference:
+//   src/model_training/loss/yolo_loss.py:48-68,98-141   fp32 decode of one head to (cx, cy, w, h, conf, cls...)
+//   src/model_training/utils/general.py:29-52, 87-143   corners, conf >= thres, per-class greedy NMS, IoU with +1, keep iou < thres
+// ================================================================================================
+__global__ void __launch_bounds__(256) val_decode_kernel(const float* __restrict__ in, float* __restrict__ out, long total, int h, int w,
+                                                          int M_total, int m_off, float aw0, float ah0, float aw1, float ah1, float aw2,
+                                                          float ah2, float stride_w, float stride_h)
+{
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;  // (frame, anchor, i, j)
+    if (idx >= total) return;
+    const int j = (int)(idx % w);
+    long t = idx / w;
+    const int i = (int)(t % h);
+    t /= h;
+    const int a = (int)(t % 3);
+    const long n = t / 3;
+    const float* p = in + ((n * 3 + a) * 8) * (long)h * w + (long)i * w + j;
+    const long hw = (long)h * w;
+    auto sg = [](float v) { return 1.f / (1.f + expf(-v)); };
+    const float aw = a == 0 ? aw0 : a == 1 ? aw1 : aw2, ah = a == 0 ? ah0 : a == 1 ? ah1 : ah2;
+    float* o = out + (n * M_total + m_off + ((long)a * h + i) * w + j) * 8;
+    float4 v0, v1;
+    v0.x = (sg(p[0]) + (float)j) * stride_w;          // (x + grid_x) * stride_w        yolo_loss.py:133,139
+    v0.y = (sg(p[hw]) + (float)i) * stride_h;
+    v0.z = (expf(p[2 * hw]) * aw) * stride_w;         // exp(w) * anchor_w (feature-map units), then * stride
+    v0.w = (expf(p[3 * hw]) * ah) * stride_h;
+    v1.x = sg(p[4 * hw]); v1.y = sg(p[5 * hw]); v1.z = sg(p[6 * hw]); v1.w = sg(p[7 * hw]);
+    reinterpret_cast<float4*>(o)[0] = v0;
+    reinterpret_cast<float4*>(o)[1] = v1;
+}
+
+void launch_val_decode(const float* in, float* out, int N, int h, int w, int M_total, int m_off, const float* anc6, float stride_w,
+                       float stride_h, hipStream_t s)
+{
+    long total = (long)N * 3 * h * w;
+    hipLaunchKernelGGL(val_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, h, w, M_total, m_off,
+                       anc6[0], anc6[1], anc6[2], anc6[3], anc6[4], anc6[5], stride_w, stride_h);
+}
+
+// One workgroup per image.  All arithmetic after the decode is fp32 add/mul/div, so given the same prediction tensor the
+// result is bit-identical to the reference's torch code (ties in conf: index order; the reference's sort is unstable).
+__global__ void __launch_bounds__(POST_THREADS) val_nms_kernel(const float* __restrict__ pred, int M, int mpad_max, float conf_thres,
+                                                               float nms_thres, int kmax, float* __restrict__ det, int32_t* counts)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+    uint16_t* kept = reinterpret_cast<uint16_t*>(smem + (size_t)mpad_max * 8);
+    unsigned char* alive = smem + (size_t)mpad_max * 8 + (size_t)M * 2;
+    __shared__ int s_wave_cnt[POST_THREADS / 64];
+    __shared__ int s_total, s_nkept;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* P = pred + (long)blockIdx.x * M * 8;
+    if (tid == 0) { s_total = 0; s_nkept = 0; }
+    __syncthreads();
+    for (int base = 0; base < M; base += POST_THREADS) {
+        const int m = base + tid;
+        bool pass = false;
+        uint64_t key = 0;
+        if (m < M) {
+            const float conf = P[m * 8 + 4];
+            pass = conf >= conf_thres;
+            if (pass) {
+                float best = P[m * 8 + 5];
+                int cls = 0;
+                for (int k = 1; k < 3; ++k) { float v = P[m * 8 + 5 + k]; if (v > best) { best = v; cls = k; } }
+                key = ((uint64_t)cls << 45) | ((uint64_t)(~__float_as_uint(conf)) << 13) | (uint64_t)m;
+            }
+        }
+        unsigned long long bm = __ballot(pass);
+        int before = __popcll(bm & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave_cnt[wave] = __popcll(bm);
+        __syncthreads();
+        int off = s_total;
+        for (int wv = 0; wv < wave; ++wv) off += s_wave_cnt[wv];
+        if (pass) keys[off + before] = key;
+        __syncthreads();
+        if (tid == 0) { int tt = s_total; for (int wv = 0; wv < POST_THREADS / 64; ++wv) tt += s_wave_cnt[wv]; s_total = tt; }
+        __syncthreads();
+    }
+    const int K = s_total;
+    if (K == 0) { if (tid == 0) counts[blockIdx.x] = 0; return; }
+    int mpad = 64;
+    while (mpad < K) mpad <<= 1;
+    for (int i = K + tid; i < mpad; i += POST_THREADS) keys[i] = ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= mpad; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < mpad; i += POST_THREADS) {
+                int l = i ^ j;
+                if (l > i) {
+                    uint64_t x = keys[i], y = keys[l];
+                    bool up = (i & k) == 0;
+                    if ((x > y) == up) { keys[i] = y; keys[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < K; i += POST_THREADS) alive[i] = 1;
+    __syncthreads();
+    auto corners = [&](int k) {  // general.py:90-95, fp32
+        const float* q = P + (long)(keys[k] & 0x1fffu) * 8;
+        const float cx = q[0], cy = q[1], w = q[2], h = q[3];
+        return make_float4(cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2);
+    };
+    for (int i = 0; i < K; ++i) {
+        if (!alive[i]) continue;
+        if (tid == 0) { kept[s_nkept] = (uint16_t)i; s_nkept = s_nkept + 1; }
+        const float4 bi = corners(i);
+        const int ci = (int)(keys[i] >> 45);
+        const float a1 = (bi.z - bi.x + 1) * (bi.w - bi.y + 1);
+        for (int j = i + 1 + tid; j < K; j += POST_THREADS) {
+            if ((int)(keys[j] >> 45) != ci) break;
+            if (!alive[j]) continue;
+            const float4 bj = corners(j);
+            const float iw = fmaxf(fminf(bi.z, bj.z) - fmaxf(bi.x, bj.x) + 1, 0.f);
+            const float ih = fmaxf(fminf(bi.w, bj.w) - fmaxf(bi.y, bj.y) + 1, 0.f);
+            const float inter = iw * ih;
+            const float a2 = (bj.z - bj.x + 1) * (bj.w - bj.y + 1);
+            const float iou = inter / (a1 + a2 - inter + 1e-16f);
+            if (!(iou < nms_thres)) alive[j] = 0;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    const int nk = s_nkept;
+    if (tid == 0) counts[blockIdx.x] = nk;
+    for (int k = tid; k < (nk < kmax ? nk : kmax); k += POST_THREADS) {
+        const int i = kept[k];
+        const float* q = P + (long)(keys[i] & 0x1fffu) * 8;
+        const float4 c = corners(i);
+        const int cls = (int)(keys[i] >> 45);
+        float* o = det + ((long)blockIdx.x * kmax + k) * 7;
+        o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w; o[4] = q[4]; o[5] = q[5 + cls]; o[6] = (float)cls;
+    }
+}
+
+static int pow2_at_least(int n);
+int launch_val_nms(const float* pred, int N, int M, float conf_thres, float nms_thres, int kmax, float* det, int32_t* counts, hipStream_t s)
+{
+    if (M > 8191) return -1;
+    int mp = pow2_at_least(M);
+    size_t lds = (size_t)mp * 8 + (size_t)M * 3 + 16;
+    static size_t attr_set = 0;
+    if (lds > 48 * 1024 && lds > attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(val_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -2;
+        attr_set = lds;
+    }
+    hipLaunchKernelGGL(val_nms_kernel, dim3(N), dim3(POST_THREADS), lds, s, pred, M, mp, conf_thres, nms_thres, kmax, det, counts);
+    return 0;
+}
+
 static int pow2_at_least(int n)
 {
     int p = 64;

@@ -106,6 +106,7 @@ class YoloFastest(nn.Module):
     # -- weight packing -------------------------------------------------------------------------
     def _invalidate(self):
         self._blob = None
+        self._blob_from_ncnn = False
         for e in self._engines.values():
             e.close()
         self._engines = {}
@@ -117,8 +118,19 @@ class YoloFastest(nn.Module):
 
     def _apply(self, fn, *a, **kw):
         r = super()._apply(fn, *a, **kw)
+        keep = self._blob if getattr(self, "_blob_from_ncnn", False) else None
         self._invalidate()
+        if keep is not None:
+            self._blob, self._blob_from_ncnn = keep, True
         return r
+
+    def load_ncnn(self, param_path, bin_path):
+        """Alternative weight source: the reference's shipped ncnn model (models/ncnn/**, already BN-folded).
+        The engine then runs these weights; the torch parameter containers are left untouched."""
+        self._invalidate()
+        self._blob = packer.pack_ncnn(param_path, bin_path, self.num_out, self.input_channel, self.num_anchors, self.num_cls)
+        self._blob_from_ncnn = True
+        return self
 
     def refresh(self):
         """Re-pack after editing parameters in place (load_state_dict / .to() do it automatically)."""

@@ -157,3 +157,87 @@ def unpack(blob):
         out[nm] = dict(kind=kind, cin=cin, cout=cout, k=k, stride=stride, relu=relu,
                        w=data[w_off:w_off + sizes[kind](cin, cout, k)], b=data[b_off:b_off + cout])
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Alternative weight source: the reference's shipped ncnn model (models/ncnn/**/*.param + *.bin), SURVEY.md 8(f).3.
+# The .param is the BN-folded graph ncnnoptimize wrote (58 Convolution, 27 ConvolutionDepthWise, 1 Deconvolution, blobs
+# data -> head_large / head_small); the .bin holds, per weighted layer in file order, a 4-byte storage flag (0 = raw
+# fp32), weight_data_size floats in [out][in/g][kh][kw] order and, with bias_term, num_output bias floats.
+# ---------------------------------------------------------------------------------------------------------------------
+_NCNN_MAGIC = "7767517"
+
+
+def read_ncnn(param_path, bin_path):
+    """-> list of dicts (type, name, num_output, kernel, stride, pad, group, relu, w, b) for the weighted layers, in
+    file order (= execution order of the reference's forward)."""
+    with open(param_path) as f:
+        lines = [ln.split() for ln in f.read().splitlines() if ln.strip()]
+    if lines[0][0] != _NCNN_MAGIC:
+        raise ValueError("not an ncnn .param file (magic %s)" % lines[0][0])
+    raw = np.fromfile(bin_path, dtype=np.uint8)
+    pos, out = 0, []
+    for tok in lines[2:]:
+        ltype, name, nin, nout = tok[0], tok[1], int(tok[2]), int(tok[3])
+        if ltype not in ("Convolution", "ConvolutionDepthWise", "Deconvolution"):
+            continue
+        kv = dict(t.split("=") for t in tok[4 + nin + nout:])
+        p = {int(k): v for k, v in kv.items()}
+        n_out, k, wsize = int(p[0]), int(p.get(1, 1)), int(p[6])
+        flag = int(np.frombuffer(raw, np.uint32, 1, pos)[0]); pos += 4
+        if flag != 0:
+            raise ValueError("layer %s: only raw fp32 ncnn weights are supported (storage flag 0x%08x)" % (name, flag))
+        w = np.frombuffer(raw, np.float32, wsize, pos).copy(); pos += 4 * wsize
+        b = np.zeros(n_out, np.float32)
+        if int(p.get(5, 0)):
+            b = np.frombuffer(raw, np.float32, n_out, pos).copy(); pos += 4 * n_out
+        out.append(dict(type=ltype, name=name, num_output=n_out, kernel=k, stride=int(p.get(3, 1)), pad=int(p.get(4, 0)),
+                        group=int(p.get(7, 1)), relu=int(p.get(9, 0)) == 1, w=w, b=b))
+    if pos != raw.size:
+        raise ValueError("ncnn .bin has %d trailing bytes: the .param does not describe it" % (raw.size - pos))
+    return out
+
+
+def pack_ncnn(param_path, bin_path, num_out=24, input_channel=1, num_anchors=3, num_cls=3):
+    """ncnn .param/.bin -> the same blob pack_state_dict() produces (the weights are already BN-folded).
+    The weighted layers are matched to the YoloFastest layer table by order and checked shape by shape."""
+    table = layer_table(num_out, input_channel)
+    layers = read_ncnn(param_path, bin_path)
+    if len(layers) != len(table):
+        raise RuntimeError("ncnn model has %d weighted layers, YoloFastest has %d" % (len(layers), len(table)))
+    chunks, rows, off = [], [], 0
+
+    def push(a):
+        nonlocal off
+        a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+        pad = (-a.size) % 4
+        if pad:
+            a = np.concatenate([a, np.zeros(pad, np.float32)])
+        chunks.append(a)
+        o = off
+        off += a.size
+        return o
+
+    want_type = {KIND_PW: "Convolution", KIND_HEAD: "Convolution", KIND_DENSE: "Convolution",
+                 KIND_DW: "ConvolutionDepthWise", KIND_DECONV: "Deconvolution"}
+    for (name, kind, cin, cout, k, stride, relu), L in zip(table, layers):
+        exp_w = k * k * cout if kind == KIND_DW else k * k * cin * cout
+        if (L["type"] != want_type[kind] or L["num_output"] != cout or L["kernel"] != k or L["stride"] != stride
+                or L["w"].size != exp_w or L["relu"] != bool(relu) or (kind == KIND_DW and L["group"] != cout)):
+            raise RuntimeError("ncnn layer %s (%s, %d out, k%d s%d, %d weights) does not match YoloFastest layer %s"
+                               % (L["name"], L["type"], L["num_output"], L["kernel"], L["stride"], L["w"].size, name))
+        w = L["w"]
+        if kind in (KIND_PW, KIND_HEAD):
+            wl = w.reshape(cout, cin).T                                   # [cin][cout]
+        elif kind == KIND_DW:
+            wl = w.reshape(cout, k * k).T                                 # [ky*k+kx][c]
+        elif kind == KIND_DENSE:
+            wl = w.reshape(cout, cin, k, k).transpose(2, 3, 1, 0)         # [ky][kx][cin][cout]
+        else:  # ncnn Deconvolution weights: [out][in][kh][kw]
+            wl = w.reshape(cout, cin, 2, 2).transpose(2, 3, 1, 0)         # [dy][dx][cin][cout]
+        w_off = push(wl)
+        b_off = push(L["b"])
+        rows.append(struct.pack("<32s8I", name.encode(), kind, cin, cout, k, stride, relu, w_off, b_off))
+    header = struct.pack("<8s6IQ", MAGIC, VERSION, len(table), num_out, input_channel, num_anchors, num_cls, off)
+    header += b"\0" * (64 - len(header))
+    return header + b"".join(rows) + np.concatenate(chunks).tobytes()
