@@ -129,6 +129,12 @@ int yf_detect(yf_handle h, const float *d_x, int N, double conf_thres, double nm
  * box mean (a+b+c+d+2)>>2 (src == 2x net size).  Other ratios: YF_E_INVALID. */
 int yf_preprocess_u8(yf_handle h, const uint8_t *d_u8, int N, int src_h, int src_w, float *d_x, void *stream);
 
+/* yf_forward on u8 gray frames: Detect_YOLO.__pre_process's arithmetic (src/detect.py:115-124) is fused into the first
+ * kernel's loads -- d_u8 uint8 [N,src_h,src_w], src == net size or exactly 2x (2x2 box mean).  Bit-identical to
+ * yf_preprocess_u8 followed by yf_forward, one pass and 3-15 bytes per pixel less HBM traffic. */
+int yf_forward_u8(yf_handle h, const uint8_t *d_u8, int N, int src_h, int src_w, float *d_head_large, float *d_head_small,
+                  void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* Introspection used by tests / bench. */
 /* Name ("conv1_8+conv1_9+conv2_1"), layer-granular algorithmic bytes and flops per frame of launch `op` of the
  * current plan (each conv of the op reads its input and writes its output once, + residual read: SURVEY.md 8d). */

@@ -390,3 +390,29 @@ def test_validation_path_decode_and_nms(yf, models, golden, dev):
                 assert np.allclose(d.cpu().numpy(), gv["real_det"][f, :n], rtol=2e-6, atol=2e-5)
     with pytest.raises(NotImplementedError):
         val.YOLOLossV3(io["anchors"][0], 3, io["input_shape"], dev)(pred[0], targets=torch.zeros(1))
+
+
+def test_forward_u8_fused_preprocess_is_bit_identical(yf, models, golden, dev):
+    """(u8-128)/255 and the exact-2x box mean fused into the stem kernel's loads."""
+    from PIL import Image
+    names = golden("golden_256")["names"]
+    full = np.stack([np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "test_data", str(n)))) for n in names[:5]])
+    full_t = torch.from_numpy(full).to(dev)
+    for res in (256, 512):
+        m, post, io = models[res]
+        with torch.no_grad():
+            a = m(yf.preprocess_u8(m, full_t, io["input_shape"]))
+        b = m.forward_u8(full_t, io["input_shape"])
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    with pytest.raises(yf._lib.YFError):
+        models[256][0].forward_u8(full_t[:, :300, :300].contiguous(), (256, 320))
+    # Detect_YOLO's batched entry on the bundled frames reproduces the reference's boxes in original coordinates
+    import logging
+    cfg = {"io_params": yf.io_params_for(256)}
+    det = yf.Detect_YOLO(dev, WEIGHTS[256], cfg, logging.getLogger("yf-test"))
+    g = golden("golden_256")
+    got = det.detect_u8(torch.from_numpy(np.stack([np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "test_data", str(n))))
+                                                   for n in names])).to(dev))
+    for f, L in enumerate(got):
+        n = int(g["adj_count"][f])
+        assert [e[:4] for e in L] == g["adj_box"][f, :n].tolist() and [e[6] for e in L] == g["adj_cls"][f, :n].tolist()

@@ -31,6 +31,8 @@ _SIGS = {
                              _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "yf_preprocess_u8": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "yf_nms_sorted": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_double, _c.c_void_p, _c.c_void_p]),
+    "yf_forward_u8": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                 _c.c_size_t, _c.c_void_p]),
     "yf_val_decode_head": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.c_int, _c.c_int,
                                       _c.c_void_p, _c.c_void_p]),
     "yf_val_nms": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_int, _c.c_void_p, _c.c_void_p,

@@ -316,9 +316,11 @@ struct ProfileEvents {
 };
 
 int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs, void* ws, size_t ws_bytes,
-                hipStream_t s, const char* probe, float* probe_dst, size_t probe_bytes, ProfileEvents* prof = nullptr)
+                hipStream_t s, const char* probe, float* probe_dst, size_t probe_bytes, ProfileEvents* prof = nullptr,
+                const uint8_t* d_u8 = nullptr, int u8_down2 = 0)
 {
-    if (!e || !d_x || !d_hl || !d_hs || N <= 0) return fail(YF_E_INVALID, "yf_forward: null pointer or N <= 0");
+    if (!e || (!d_x && !d_u8) || !d_hl || !d_hs || N <= 0) return fail(YF_E_INVALID, "yf_forward: null pointer or N <= 0");
+    if (d_u8 && e->fusion != 1) return fail(YF_E_INVALID, "u8 input needs the fused plan (yf_set_fusion 1)");
     if (N > e->max_batch) return fail(YF_E_INVALID, "yf_forward: N=%d exceeds max_batch=%d", N, e->max_batch);
     const Plan& P = e->plan();
     const int cf = prof ? N : chunk_frames(e, N);  // profiling: the whole batch in one pass on the caller's stream
@@ -350,7 +352,7 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
         float* lane_base = base + P.frame_floats * (size_t)cf * lane_id;
         auto ptr = [&](int t) -> float* {
             const Tensor& T = P.tensors[t];
-            if (T.slot == BUF_INPUT) return const_cast<float*>(d_x) + (size_t)f0 * T.elems();
+            if (T.slot == BUF_INPUT) return d_x ? const_cast<float*>(d_x) + (size_t)f0 * T.elems() : nullptr;
             if (T.slot == BUF_HEAD_LARGE) return d_hl + (size_t)f0 * T.elems();
             if (T.slot == BUF_HEAD_SMALL) return d_hs + (size_t)f0 * T.elems();
             return lane_base + P.slot_offset[T.slot] * (size_t)cf;
@@ -376,6 +378,11 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                 yf::FbArgs a{};
                 a.in = ptr(o.in1);
                 if (pre) { a.w0 = W(o.l_pre); a.b0 = B(o.l_pre); }
+                if (pre && d_u8) {  // pre-process fused into the stem's loads
+                    a.in = nullptr;
+                    a.in_u8 = d_u8 + (size_t)f0 * (u8_down2 ? 4 : 1) * P.tensors[o.in1].elems();
+                    a.u8_down2 = u8_down2;
+                }
                 a.wp = e->d_wmfma + o.mfma_off;
                 a.out = ptr(o.out);
                 a.H = pre ? ti.H / 2 : ti.H; a.W = pre ? ti.W / 2 : ti.W; a.Ho = to.H; a.Wo = to.W;
@@ -631,6 +638,22 @@ int yf_decode_nms(yf_handle h, const float* d_hl, const float* d_hs, int N, doub
     if (rc) return fail(YF_E_HIP, "hipFuncSetAttribute(post_kernel) failed");
     HIP_OK(hipGetLastError());
     return YF_OK;
+}
+
+static int u8_mode(yf_handle h, int src_h, int src_w, int* down2)
+{
+    if (src_h == h->H && src_w == h->W) { *down2 = 0; return YF_OK; }
+    if (src_h == 2 * h->H && src_w == 2 * h->W) { *down2 = 1; return YF_OK; }
+    return fail(YF_E_INVALID, "source %dx%d: only 1x or exact 2x of the net input %dx%d is supported", src_h, src_w, h->H, h->W);
+}
+
+int yf_forward_u8(yf_handle h, const uint8_t* d_u8, int N, int src_h, int src_w, float* d_hl, float* d_hs, void* ws, size_t ws_bytes,
+                  void* stream)
+{
+    if (!h || !d_u8) return fail(YF_E_INVALID, "yf_forward_u8: null pointer");
+    int down2;
+    if (int rc = u8_mode(h, src_h, src_w, &down2)) return rc;
+    return run_forward(h, nullptr, N, d_hl, d_hs, ws, ws_bytes, (hipStream_t)stream, nullptr, nullptr, 0, nullptr, d_u8, down2);
 }
 
 int yf_nms_sorted(yf_handle h, const int32_t* d_boxes, int n, double nms_thres, int32_t* d_sup, void* stream)

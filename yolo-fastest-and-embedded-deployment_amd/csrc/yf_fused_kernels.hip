@@ -132,6 +132,29 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
                         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                             for (int kx = 0; kx < 3; ++kx) v[ky * 3 + kx] = win0[ky * IRWP + kx];
+                    } else if (a.in_u8) {
+                        // Detect_YOLO.__pre_process fused into the load (src/detect.py:115-124): u8 gray frame, optional
+                        // exact-2x box mean (a+b+c+d+2)>>2, then (v-128)/255; conv0 zero-pads the NORMALISED tensor
+                        const int sw = a.u8_down2 ? 4 * a.W : 2 * a.W;
+                        const uint8_t* __restrict__ src = a.in_u8 + (long)n * (a.u8_down2 ? 16L : 4L) * a.H * a.W;
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) {
+                                int yy = 2 * iy - 1 + ky, xx = 2 * ix - 1 + kx;
+                                bool ok = inimg[p] && yy >= 0 && yy < 2 * a.H && xx >= 0 && xx < 2 * a.W;
+                                float val = 0.f;
+                                if (ok) {
+                                    if (a.u8_down2) {
+                                        const uint8_t* q = src + (long)(2 * yy) * sw + 2 * xx;
+                                        val = (float)((q[0] + q[1] + q[sw] + q[sw + 1] + 2) >> 2);
+                                    } else {
+                                        val = (float)src[(long)yy * sw + xx];
+                                    }
+                                    val = (val - 128.0f) / 255.0f;
+                                }
+                                v[ky * 3 + kx] = val;
+                            }
                     } else {
                         const float* __restrict__ src = a.in + (long)n * (4L * a.H * a.W);
 #pragma unroll

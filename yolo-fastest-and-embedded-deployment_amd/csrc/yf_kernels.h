@@ -53,6 +53,8 @@ struct FbArgs {
     float* out;                   // NHWC [N,Ho,Wo,COUT]
     int H, W, Ho, Wo;             // expansion-resolution and output-resolution frame sizes
     int tiles_y, tiles_x;         // filled by the launcher
+    const uint8_t* in_u8;         // PRE only, optional: u8 gray frames instead of `in` (pre-process fused into the load)
+    int u8_down2;                 //   1: the u8 frame is exactly 2x the net input (2x2 box mean first)
     unsigned long long* dbg;      // diagnostic builds only (-DYF_STAMP): per-phase cycle sums; null in the product
 };
 int launch_fused_block(int cin, int cexp, int cout, int stride, bool res, bool relu_out, bool pre, const FbArgs& a, int N,

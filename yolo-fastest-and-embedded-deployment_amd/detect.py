@@ -65,9 +65,7 @@ class Detect_YOLO():
     def detect_u8(self, u8, kmax=64):
         """u8: uint8 GPU tensor [N,h,w] in the ORIGINAL image geometry. Returns per-frame lists in original
         coordinates (after __adjust_coord, detect.py:181-182)."""
-        x = preprocess_u8(self.model, u8, self.input_shape)
-        with torch.no_grad():
-            pred = self.model(x)
+        pred = self.model.forward_u8(u8, self.input_shape)  # pre-process fused into the first kernel's loads
         origin = None
         if list(self.input_shape[0:2]) != list(self.origin_img_shape[0:2]):
             origin = self.origin_img_shape

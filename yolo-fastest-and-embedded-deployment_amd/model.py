@@ -183,6 +183,25 @@ class YoloFastest(nn.Module):
                                     ctypes.c_void_p(stream)))
         return hl, hs
 
+    def forward_u8(self, u8, input_shape):
+        """model(preprocess(u8)) with the pre-process fused into the first kernel: u8 GPU tensor [N,h,w] (h,w == the net
+        input or exactly 2x) -> (head_large, head_small)."""
+        if self.training:
+            raise RuntimeError("YoloFastest (HIP engine) is inference-only: call .eval() first")
+        if not u8.is_cuda or u8.dtype != torch.uint8 or u8.dim() != 3:
+            raise ValueError("expected a uint8 GPU tensor [N,h,w]")
+        H, W = int(input_shape[0]), int(input_shape[1])
+        u8 = u8.contiguous()
+        N = u8.shape[0]
+        e = self.engine(H, W, N, u8.device)
+        hl = torch.empty((N, self.num_out, H // 16, W // 16), dtype=torch.float32, device=u8.device)
+        hs = torch.empty((N, self.num_out, H // 32, W // 32), dtype=torch.float32, device=u8.device)
+        ws = e.workspace(N, u8.device)
+        stream = torch.cuda.current_stream(u8.device).cuda_stream
+        _lib.check(e.lib.yf_forward_u8(e.handle, u8.data_ptr(), N, u8.shape[1], u8.shape[2], hl.data_ptr(), hs.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), ctypes.c_void_p(stream)))
+        return hl, hs
+
     def profile(self, x, reps=5):
         """Per-launch timing of one forward pass (HIP events on the launch stream around every kernel).
         Returns a list of dicts: name, ms (mean over reps), algorithmic_bytes, flops -- for the whole batch."""
