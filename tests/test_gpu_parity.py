@@ -416,3 +416,43 @@ def test_forward_u8_fused_preprocess_is_bit_identical(yf, models, golden, dev):
     for f, L in enumerate(got):
         n = int(g["adj_count"][f])
         assert [e[:4] for e in L] == g["adj_box"][f, :n].tolist() and [e[6] for e in L] == g["adj_cls"][f, :n].tolist()
+
+
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_forward_is_hip_graph_capturable(yf, golden, dev, lanes):
+    """yf_forward issues launches (and, with 2 lanes, event fork/join on the engine's side stream) only: it can be
+    captured into a HIP graph and replayed bit-identically."""
+    io = yf.io_params_for(256)
+    m = yf.YoloFastest(io).to(dev).eval()
+    m.lanes = lanes
+    m.load_state_dict(torch.load(WEIGHTS[256], map_location=dev))
+    x = _x(np.tile(golden("golden_256")["input_u8"], (4, 1, 1))[:64], dev)
+    with torch.no_grad():
+        ref = m(x)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s), torch.no_grad():
+        m(x)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g), torch.no_grad():
+        out = m(x)
+    out[0].zero_(); out[1].zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+
+
+def test_yf_detect_single_call_equals_two_calls(models, golden, dev):
+    m, post, io = models[256]
+    x = _x(golden("golden_256")["input_u8"], dev)
+    with torch.no_grad():
+        pred = m(x)
+    a = post.detect_raw(pred, kmax=16, origin_shape=(512, 640))
+    b = post.detect_raw_from_input(x, kmax=16, origin_shape=(512, 640))
+    assert torch.equal(b["head_large"], pred[0]) and torch.equal(b["head_small"], pred[1])
+    n = a["counts"].cpu().numpy()
+    assert np.array_equal(n, b["counts"].cpu().numpy())
+    for f, k in enumerate(n):
+        for key in ("boxes", "scores", "cls", "src"):
+            assert torch.equal(a[key][f, :k], b[key][f, :k]), key

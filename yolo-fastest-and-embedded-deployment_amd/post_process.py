@@ -65,6 +65,33 @@ class YOLO_post_process:
                                        ctypes.c_void_p(stream)))
         return out
 
+    def detect_raw_from_input(self, x, kmax=64, origin_shape=None):
+        """model forward + decode + NMS in ONE C call (yf_detect): x float32 GPU tensor [N,1,H,W] -> the same dict as
+        detect_raw, plus the two head tensors."""
+        if self._model is None:
+            raise RuntimeError("call post_process.bind(model) first")
+        if not x.is_cuda:
+            raise RuntimeError("YOLO_post_process (HIP) has no CPU path")
+        x = x.contiguous().float()
+        N, _, H, W = x.shape
+        e = self._model.engine(H, W, N, x.device)
+        dev = x.device
+        out = dict(boxes=torch.empty((N, kmax, 4), dtype=torch.int32, device=dev),
+                   scores=torch.empty((N, kmax, 2), dtype=torch.float32, device=dev),
+                   cls=torch.empty((N, kmax), dtype=torch.int32, device=dev),
+                   src=torch.empty((N, kmax), dtype=torch.int32, device=dev),
+                   counts=torch.empty((N,), dtype=torch.int32, device=dev),
+                   head_large=torch.empty((N, 24, H // 16, W // 16), dtype=torch.float32, device=dev),
+                   head_small=torch.empty((N, 24, H // 32, W // 32), dtype=torch.float32, device=dev))
+        ws = e.workspace(N, dev)
+        oh, ow = (origin_shape[0], origin_shape[1]) if origin_shape is not None else (0, 0)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(e.lib.yf_detect(e.handle, x.data_ptr(), N, float(self.conf_thres), float(self.nms_thres), self._anc, int(oh),
+                                   int(ow), kmax, out["boxes"].data_ptr(), out["scores"].data_ptr(), out["cls"].data_ptr(),
+                                   out["src"].data_ptr(), out["counts"].data_ptr(), out["head_large"].data_ptr(),
+                                   out["head_small"].data_ptr(), ws.data_ptr(), ws.numel(), ctypes.c_void_p(stream)))
+        return out
+
     @staticmethod
     def to_lists(raw, with_src=False):
         """GPU result -> per-frame Python lists in the reference's element format."""
