@@ -21,7 +21,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BYTES_PER_FRAME = {256: 42_575_360, 512: 170_301_440}   # layer-granular algorithmic bytes, fp32
+BYTES_PER_FRAME = {256: 42_575_360, 512: 170_301_440}   # layer-granular algorithmic bytes, fp32 (fp16: half)
 FLOPS_PER_FRAME = {256: 236_442_880, 512: 945_771_520}
 HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--res", type=int, default=256, choices=[256, 512])
     ap.add_argument("--chunk", type=int, default=0, help="frames per pass of the layer chain (0 = whole batch)")
     ap.add_argument("--lanes", type=int, default=2, help="concurrent streams over the chunks of the batch (1..4)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"], help="f16 = BASELINE configs[2]: fp16 storage + fp16 MFMA")
     ap.add_argument("--kmax", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-ops", default=None, help="write the launch names of one forward pass to this JSON file")
@@ -101,6 +102,8 @@ def main():
     wname = {256: "yolo_fastest_256x320_epoch28.pth", 512: "yolo_fastest_512x640_epoch27.pth"}[args.res]
     model = yf.YoloFastest(io).to(dev).eval()
     model.chunk = args.chunk
+    if args.dtype == "f16":
+        model.storage_dtype = torch.float16
     model.lanes = args.lanes
     model.load_state_dict(torch.load(os.path.join(ROOT, "yolo-fastest-and-embedded-deployment_amd", "assets",
                                                   "weights", wname), map_location=dev))
@@ -169,16 +172,17 @@ def main():
                 tj = json.load(f)
             traffic = tj.get("kernels", {}).get(dom["name"], {}).get("hbm_bytes_per_launch")
         achieved = dom["algorithmic_bytes"] / (dom["ms"] * 1e-3) / 1e9
-        chain_achieved = args.batch * BYTES_PER_FRAME[args.res] / (fwd_ms * 1e-3) / 1e9
+        bpf = BYTES_PER_FRAME[args.res] // (2 if args.dtype == "f16" else 1)
+        chain_achieved = args.batch * bpf / (fwd_ms * 1e-3) / 1e9
         out = {
             "metric": "frames/sec end-to-end (model forward + decode + per-class NMS), 320x256 batch=256 per GPU"
                       if args.res == 256 else "frames/sec end-to-end, 640x512",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "ms_per_frame": round(1e3 * elapsed / args.steps / n_total, 6),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"YOLO-Fastest {W}x{H} batch={args.batch} fp32 per GPU, synthetic uniform-u8 frames "
-                                   f"(BASELINE.json configs[1])" if args.res == 256 and args.batch == 256 else
-                                   f"YOLO-Fastest {W}x{H} batch={args.batch} fp32 per GPU, synthetic frames",
+                                   f"(BASELINE.json configs[1])" if args.res == 256 and args.batch == 256 and args.dtype == "f32" else
+                                   f"YOLO-Fastest {W}x{H} batch={args.batch} {args.dtype} per GPU, synthetic frames",
                        "global_batch": n_total, "weights": wname, "kmax": args.kmax, "chunk": args.chunk, "lanes": args.lanes,
                        "parallelism": f"dp{world} (frames sharded, one RCCL all-gather of box records)" if world > 1 else "single GPU",
                        "survivors_per_frame_mean": round(float(np.clip(counts, 0, None).mean()), 3)},
@@ -192,7 +196,7 @@ def main():
             # the whole forward pass (all launches) against the same definition
             "forward_chain": {"launches": len(ops), "forward_ms": round(fwd_ms, 4), "post_ms": round(post_ms, 4),
                               "sum_of_launch_ms_single_stream": round(chain_ms, 4),
-                              "algorithmic_bytes_per_frame": BYTES_PER_FRAME[args.res],
+                              "algorithmic_bytes_per_frame": bpf,
                               "algorithmic_bytes_per_frame_sum_over_launches": int(bytes_sum),
                               "achieved_GBps": round(chain_achieved, 1), "frac_of_hbm_peak": round(chain_achieved / HBM_PEAK_GBS, 4),
                               "compute_frac_fp32_peak": round(args.batch * FLOPS_PER_FRAME[args.res] / (fwd_ms * 1e-3) / 157.3e12, 4),

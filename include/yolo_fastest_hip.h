@@ -61,6 +61,12 @@ const char *yf_last_error_string(void);
  * layouts, self-describing layer table that is checked strictly against the YoloFastest graph).
  * The engine owns a device copy of the weights and nothing else. */
 int yf_create(const void *packed_weights, size_t nbytes, int H, int W, int max_batch, int device, yf_handle *out);
+/* dtype 0 = fp32 (yf_create); 1 = BASELINE configs[2]: activations stored fp16 in HBM, the pointwise GEMMs on
+ * v_mfma_f32_16x16x16_f16 with fp16 weights, fp32 accumulation everywhere; depthwise / small-channel kernels compute in fp32
+ * on fp16 storage.  Input x and the two head tensors stay fp32.  (model.half() selects it from Python.) */
+int yf_create_ex(const void *packed_weights, size_t nbytes, int H, int W, int max_batch, int device, int dtype, yf_handle *out);
+/* The fp32 -> fp16 rounding (nearest even) the weight packer uses on the host. */
+uint16_t yf_f32_to_f16_bits(float f);
 int yf_destroy(yf_handle h);
 
 /* Bytes of device scratch yf_forward / yf_detect need for a batch of N frames. */

@@ -157,3 +157,26 @@ def test_ncnn_model_files_give_the_same_blob(sd):
         assert np.abs(pth[k]["b"] - ncnn[k]["b"]).max() < 5e-6, k
     with pytest.raises(ValueError):
         packer.read_ncnn(W256, W256)  # not a .param file
+
+
+def test_host_f32_to_f16_rounding_is_ieee_rne():
+    """The fp16 weight streams are rounded on the host (yf_mfma_kernels.hip f32_to_f16_bits): must equal IEEE
+    round-to-nearest-even = numpy's float16 cast, including subnormals, ties, overflow to inf, signed zero, nan."""
+    from yolo_fastest_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    bits = rng.integers(0, 2 ** 32, 20000, dtype=np.uint64).astype(np.uint32)
+    vals = np.concatenate([
+        bits.view(np.float32),
+        (rng.standard_normal(5000) * 10.0 ** rng.integers(-9, 6, 5000)).astype(np.float32),
+        np.array([0.0, -0.0, 1.0, -1.0, 65504.0, 65519.9, 65520.0, 1e9, -1e9, np.inf, -np.inf, 2.0 ** -24, 2.0 ** -25,
+                  2.0 ** -25 * 1.0000001, 2.0 ** -14, 2.0 ** -14 - 2.0 ** -25, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11,
+                  1.0 + 2.0 ** -11 + 2.0 ** -20, 6.1e-5, 5.96e-8, 2.98e-8, 2.99e-8], np.float32)])
+    with np.errstate(over="ignore", invalid="ignore"):
+        want = vals.astype(np.float16).view(np.uint16)
+    for v, w in zip(vals.tolist(), want.tolist()):
+        got = L.yf_f32_to_f16_bits(v)
+        if v != v:
+            assert (got & 0x7C00) == 0x7C00 and (got & 0x3FF) != 0
+        else:
+            assert got == w, (v, hex(got), hex(w))

@@ -59,7 +59,7 @@ static void bench_fb(const char* tag, int N, int H, int W)
 #ifdef YF_STAMP
     CK(hipMalloc(&a.dbg, 64)); CK(hipMemset(a.dbg, 0, 64));
 #endif
-    float us = time_us([&] { hipLaunchKernelGGL((fused_block_kernel<CIN, CEXP, COUT, S, RES, false, PRE, TYB, TXB, BH, BW, EC, CG, PE, XL>), grid, dim3(TYB * TXB), 0, 0, a); });
+    float us = time_us([&] { hipLaunchKernelGGL((fused_block_kernel<CIN, CEXP, COUT, S, RES, false, PRE, TYB, TXB, BH, BW, EC, CG, PE, XL, float>), grid, dim3(TYB * TXB), 0, 0, a); });
 #ifdef YF_STAMP
     { unsigned long long h[6]; CK(hipMemcpy(h, a.dbg, 48, hipMemcpyDeviceToHost)); double tot = 0; for (int i = 0; i < 6; ++i) tot += (double)h[i];
       printf("    stamps%%: loop-top %.1f | expand %.1f | barrier1 %.1f | dw+project %.1f | barrier2 %.1f | epilogue %.1f   (avg cycles/wave %.0f)\n",
@@ -80,7 +80,7 @@ static void bench_mfma(const char* tag, long M)
     a.npix = M; a.HW = 320; a.W = 20;
     const long waves = (M + 16 * MT - 1) / (16 * MT);
     dim3 grid((unsigned)((waves + 3) / 4));
-    float us = time_us([&] { hipLaunchKernelGGL((pw_mfma_kernel<K1, 0, N, MT, RELU, RES, 0>), grid, dim3(256), 0, 0, a); });
+    float us = time_us([&] { hipLaunchKernelGGL((pw_mfma_kernel<K1, 0, N, MT, RELU, RES, 0, float>), grid, dim3(256), 0, 0, a); });
     printf("%-44s M=%7ld MT=%d grid=%6u  %8.1f us  %6.2f TMAC/s  out %.1f GB/s\n", tag, M, MT, grid.x, us, (double)M * K1 * N / us * 1e-6, (double)M * N * 4 / us * 1e-3);
 }
 
@@ -96,10 +96,10 @@ static void bench_mres(const char* tag, int N, int H, int W)
     constexpr int MTR = ((TH + 2) * (TW + 2) + 15) / 16;
     constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 16 * (((MTR * 16 + 7) / 8) * 8 + 1) +
                             ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT) + COUT + 3) & ~3)) * sizeof(float);
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mres_kernel<CIN, CEXP, COUT, RES, TH, TW, NWAVE>),
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mres_kernel<CIN, CEXP, COUT, RES, TH, TW, NWAVE, float>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(N * a.tiles_y * a.tiles_x);
-    float us = time_us([&] { hipLaunchKernelGGL((mres_kernel<CIN, CEXP, COUT, RES, TH, TW, NWAVE>), grid, dim3(NWAVE * 64), lds, 0, a); });
+    float us = time_us([&] { hipLaunchKernelGGL((mres_kernel<CIN, CEXP, COUT, RES, TH, TW, NWAVE, float>), grid, dim3(NWAVE * 64), lds, 0, a); });
     double macs = (double)N * H * W * CEXP * (CIN + 9 + COUT);
     printf("%-40s tile=%2dx%-2d waves=%d lds=%6zu grid=%6u  %8.1f us  %6.2f TMAC/s\n", tag, TH, TW, NWAVE, lds, grid.x, us, macs / us * 1e-6);
 }
@@ -116,10 +116,10 @@ static void bench_mres_pc(const char* tag, int N, int H, int W)
     constexpr int MTR = ((TH + 2) * (TW + 2) + 15) / 16;
     constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 2 * 16 * (((MTR * 16 + 7) / 8) * 8 + 1) +
                             ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT) + COUT + 3) & ~3)) * sizeof(float);
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC>),
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, float>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(N * a.tiles_y * a.tiles_x);
-    float us = time_us([&] { hipLaunchKernelGGL((mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC>), grid, dim3((NWP + NWC) * 64), lds, 0, a); });
+    float us = time_us([&] { hipLaunchKernelGGL((mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, float>), grid, dim3((NWP + NWC) * 64), lds, 0, a); });
     double macs = (double)N * H * W * CEXP * (CIN + 9 + COUT);
     printf("%-40s tile=%2dx%-2d prod=%d cons=%d lds=%6zu grid=%6u  %8.1f us  %6.2f TMAC/s\n", tag, TH, TW, NWP, NWC, lds, grid.x, us, macs / us * 1e-6);
 }
@@ -166,7 +166,7 @@ int main(int argc, char** argv)
         a.H = 128; a.W = 160; a.Ho = 64; a.Wo = 80;
         double macs = (double)N * (128.0 * 160 * 96 + 64.0 * 80 * (5184 + 192));
         a.tiles_y = 4; a.tiles_x = 5;
-        float us = time_us([&] { hipLaunchKernelGGL(k19_kernel, dim3(N * 20), dim3(256), 0, 0, a); });
+        float us = time_us([&] { hipLaunchKernelGGL(k19_kernel<float>, dim3(N * 20), dim3(256), 0, 0, a); });
         printf("k19 1 px/lane  16x16 tile   %8.1f us  %6.2f TMAC/s\n", us, macs / us * 1e-6);
     }
     if (on("mrespc")) {

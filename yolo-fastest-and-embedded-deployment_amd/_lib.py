@@ -17,6 +17,8 @@ _SIGS = {
     "yf_abi_version": (_c.c_int, []),
     "yf_last_error_string": (_c.c_char_p, []),
     "yf_create": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_void_p)]),
+    "yf_create_ex": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_void_p)]),
+    "yf_f32_to_f16_bits": (_c.c_uint16, [_c.c_float]),
     "yf_destroy": (_c.c_int, [_c.c_void_p]),
     "yf_workspace_bytes": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_size_t)]),
     "yf_forward": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t,

@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) pw_kernel(PwArgs a)
 // Depthwise KxK convolution (+ReLU, every depthwise layer of the net has one), stride 1 or 2, pad (K-1)/2.
 //   thread: one output pixel x 4 channels; lanes run over channel groups first (16-byte coalesced).
 // ------------------------------------------------------------------------------------------------
-template <int K, int S>
+template <int K, int S, typename T>
 __global__ void __launch_bounds__(256) dw_kernel(DwArgs a)
 {
     const int C4 = a.C >> 2;
@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256) dw_kernel(DwArgs a)
     long t = opix / a.Wo;
     int oy = (int)(t % a.Ho);
     long n = t / a.Ho;
-    const float* __restrict__ in = a.in + (n * a.H * a.W) * a.C + c4 * 4;
+    const T* __restrict__ in = reinterpret_cast<const T*>(a.in) + (n * a.H * a.W) * a.C + c4 * 4;
     const float* __restrict__ w = a.w + c4 * 4;
     float4 acc = *reinterpret_cast<const float4*>(a.b + c4 * 4);
     constexpr int PAD = (K - 1) / 2;
@@ -144,14 +144,14 @@ __global__ void __launch_bounds__(256) dw_kernel(DwArgs a)
         for (int kx = 0; kx < K; ++kx) {
             int ix = ox * S - PAD + kx;
             if (ix < 0 || ix >= a.W) continue;
-            float4 x = *reinterpret_cast<const float4*>(in + ((long)iy * a.W + ix) * a.C);
+            float4 x = ld4<T>(in + ((long)iy * a.W + ix) * a.C);
             float4 wv = *reinterpret_cast<const float4*>(w + (ky * K + kx) * a.C);
             acc.x = fmaf(x.x, wv.x, acc.x); acc.y = fmaf(x.y, wv.y, acc.y);
             acc.z = fmaf(x.z, wv.z, acc.z); acc.w = fmaf(x.w, wv.w, acc.w);
         }
     }
     acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
-    *reinterpret_cast<float4*>(a.out + opix * a.C + c4 * 4) = acc;
+    st4<T>(reinterpret_cast<T*>(a.out) + opix * a.C + c4 * 4, acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -208,7 +208,8 @@ __global__ void __launch_bounds__(256) dense3x3s2_kernel(DenseArgs a)
 }
 
 // NHWC -> NCHW copy for yf_forward_probe (test hook only).
-__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,
+template <typename T>
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out,
                                                             long total, int C, long HW)
 {
     long idx = (long)blockIdx.x * 256 + threadIdx.x;  // index into NCHW output
@@ -217,7 +218,7 @@ __global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float* __restri
     long t = idx / HW;
     int c = (int)(t % C);
     long n = t / C;
-    out[idx] = in[(n * HW + hw) * C + c];
+    out[idx] = (float)in[(n * HW + hw) * C + c];
 }
 
 // Detect_YOLO.__pre_process arithmetic (src/detect.py:115-124): optional 2x2 box mean, then (v-128)/255.
@@ -290,14 +291,20 @@ int launch_pw(int cin1, int cin2, int cout, bool relu_, bool res_, int omode, co
     return -1;
 }
 
-int launch_dw(int k, int stride, const DwArgs& a, hipStream_t s)
+template <typename T>
+static int launch_dw_t(int k, int stride, const DwArgs& a, hipStream_t s)
 {
     dim3 grid((unsigned)((a.total + 255) / 256));
-    if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_kernel<3, 1>), grid, dim3(256), 0, s, a);
-    else if (k == 3 && stride == 2) hipLaunchKernelGGL((dw_kernel<3, 2>), grid, dim3(256), 0, s, a);
-    else if (k == 5 && stride == 1) hipLaunchKernelGGL((dw_kernel<5, 1>), grid, dim3(256), 0, s, a);
+    if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_kernel<3, 1, T>), grid, dim3(256), 0, s, a);
+    else if (k == 3 && stride == 2) hipLaunchKernelGGL((dw_kernel<3, 2, T>), grid, dim3(256), 0, s, a);
+    else if (k == 5 && stride == 1) hipLaunchKernelGGL((dw_kernel<5, 1, T>), grid, dim3(256), 0, s, a);
     else return -1;
     return 0;
+}
+
+int launch_dw(int k, int stride, const DwArgs& a, hipStream_t s, int dtype)
+{
+    return dtype == DT_F16 ? launch_dw_t<half_t>(k, stride, a, s) : launch_dw_t<float>(k, stride, a, s);
 }
 
 int launch_dense3x3s2(int cin, int cout, const DenseArgs& a, hipStream_t s)
@@ -309,10 +316,14 @@ int launch_dense3x3s2(int cin, int cout, const DenseArgs& a, hipStream_t s)
     return 0;
 }
 
-void launch_nhwc_to_nchw(const float* in, float* out, long N, int C, long HW, hipStream_t s)
+void launch_nhwc_to_nchw(const float* in, float* out, long N, int C, long HW, hipStream_t s, int dtype)
 {
     long total = N * C * HW;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, C, HW);
+    if (dtype == DT_F16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<half_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                           reinterpret_cast<const half_t*>(in), out, total, C, HW);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, C, HW);
 }
 
 void launch_preprocess(const uint8_t* in, float* out, long N, int H, int W, int down2, hipStream_t s)

@@ -111,6 +111,8 @@ struct Plan {
 
 struct yf_engine {
     int device = 0, H = 0, W = 0, max_batch = 0, chunk = 0;
+    int dtype = yf::DT_F32;           // activation storage type in HBM (fp16: pointwise GEMMs on fp16 MFMA, fp32 accumulate)
+    size_t esz() const { return dtype == yf::DT_F16 ? 2 : 4; }
     float* d_weights = nullptr;
     float* d_wmfma = nullptr;         // MFMA B fragments of the GEMM-worthy pointwise layers (fused plan)
     size_t n_floats = 0;
@@ -321,12 +323,14 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
 {
     if (!e || (!d_x && !d_u8) || !d_hl || !d_hs || N <= 0) return fail(YF_E_INVALID, "yf_forward: null pointer or N <= 0");
     if (d_u8 && e->fusion != 1) return fail(YF_E_INVALID, "u8 input needs the fused plan (yf_set_fusion 1)");
+    if (e->dtype != yf::DT_F32 && e->fusion != 1) return fail(YF_E_INVALID, "fp16 storage needs the fused plan (yf_set_fusion 1)");
+    const size_t esz = e->esz();
     if (N > e->max_batch) return fail(YF_E_INVALID, "yf_forward: N=%d exceeds max_batch=%d", N, e->max_batch);
     const Plan& P = e->plan();
     const int cf = prof ? N : chunk_frames(e, N);  // profiling: the whole batch in one pass on the caller's stream
     const int nchunks = (N + cf - 1) / cf;
     const int lanes = (probe || prof || nchunks < 2) ? 1 : (e->lanes < nchunks ? e->lanes : nchunks);
-    size_t need = P.frame_floats * (size_t)cf * sizeof(float) * lanes;
+    size_t need = P.frame_floats * (size_t)cf * esz * lanes;
     if (!ws || ws_bytes < need) return fail(YF_E_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, need);
     HIP_OK(hipSetDevice(e->device));
     if (lanes > 1) {  // fork: side streams wait for everything already queued on the caller's stream
@@ -341,7 +345,7 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
         if (probe_t < 0) return fail(YF_E_NOPROBE, "no tensor named '%s' exists in device memory (fusion level %d)", probe, e->fusion);
         if (probe_bytes < P.tensors[probe_t].elems() * N * sizeof(float)) return fail(YF_E_INVALID, "probe buffer too small");
     }
-    float* base = static_cast<float*>(ws);
+    char* base = static_cast<char*>(ws);
     auto W = [&](int layer) { return e->d_weights + e->w_off[layer]; };
     auto B = [&](int layer) { return e->d_weights + e->b_off[layer]; };
     int chunk_idx = 0;
@@ -349,13 +353,13 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
         const int n = (N - f0) < cf ? (N - f0) : cf;
         const int lane_id = chunk_idx % lanes;
         s = lane_id == 0 ? s_main : e->side[lane_id - 1];
-        float* lane_base = base + P.frame_floats * (size_t)cf * lane_id;
+        char* lane_base = base + P.frame_floats * (size_t)cf * esz * lane_id;
         auto ptr = [&](int t) -> float* {
             const Tensor& T = P.tensors[t];
             if (T.slot == BUF_INPUT) return d_x ? const_cast<float*>(d_x) + (size_t)f0 * T.elems() : nullptr;
             if (T.slot == BUF_HEAD_LARGE) return d_hl + (size_t)f0 * T.elems();
             if (T.slot == BUF_HEAD_SMALL) return d_hs + (size_t)f0 * T.elems();
-            return lane_base + P.slot_offset[T.slot] * (size_t)cf;
+            return reinterpret_cast<float*>(lane_base + P.slot_offset[T.slot] * (size_t)cf * esz);  // opaque: the kernels know the type
         };
         size_t op_idx = 0;
         if (prof) HIP_OK(hipEventRecord(prof->ev[0], s));
@@ -367,11 +371,11 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
             struct AtExit { ProfileEvents* p; size_t* i; hipStream_t st; ~AtExit() { if (p) { ++*i; (void)hipEventRecord(p->ev[*i], st); } } } at_exit{prof, &op_idx, s};
             if (o.type == OP_MDW) {
                 yf::MdwArgs a{ptr(o.in1), e->d_wmfma + o.mfma_off, ptr(o.out), ti.H, ti.W, 0, 0};
-                rc = yf::launch_mdw(ti.C, kLayers[o.l_proj].cout, o.l_head >= 0 ? 24 : 0, a, n, s);
+                rc = yf::launch_mdw(ti.C, kLayers[o.l_proj].cout, o.l_head >= 0 ? 24 : 0, a, n, s, e->dtype);
             } else if (o.type == OP_MRES) {
                 const LayerSpec &LE = kLayers[o.l_exp], &LP = kLayers[o.l_proj];
                 yf::MresArgs a{ptr(o.in1), e->d_wmfma + o.mfma_off, ptr(o.out), ti.H, ti.W, 0, 0};
-                rc = yf::launch_mres(LE.cin, LE.cout, LP.cout, o.res >= 0, a, n, s);
+                rc = yf::launch_mres(LE.cin, LE.cout, LP.cout, o.res >= 0, a, n, s, e->dtype);
             } else if (o.type == OP_FUSED_BLOCK) {
                 const bool pre = o.l_pre >= 0;
                 const LayerSpec &LE = kLayers[o.l_exp], &LD = kLayers[o.l_dw], &LP = kLayers[o.l_proj];
@@ -386,27 +390,27 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                 a.wp = e->d_wmfma + o.mfma_off;
                 a.out = ptr(o.out);
                 a.H = pre ? ti.H / 2 : ti.H; a.W = pre ? ti.W / 2 : ti.W; a.Ho = to.H; a.Wo = to.W;
-                rc = yf::launch_fused_block(LE.cin, LE.cout, LP.cout, LD.stride, o.res >= 0, LP.relu != 0, pre, a, n, s);
+                rc = yf::launch_fused_block(LE.cin, LE.cout, LP.cout, LD.stride, o.res >= 0, LP.relu != 0, pre, a, n, s, e->dtype);
             } else if (o.type == OP_K19) {
                 yf::K19Args a{};
                 a.in = ptr(o.in1);
                 a.w8 = W(o.l_exp); a.b8 = B(o.l_exp); a.w9 = W(o.l_dw); a.b9 = B(o.l_dw); a.w21 = W(o.l_proj); a.b21 = B(o.l_proj);
                 a.out = ptr(o.out);
                 a.H = ti.H; a.W = ti.W; a.Ho = to.H; a.Wo = to.W;
-                rc = yf::launch_k19(a, n, s);
+                rc = yf::launch_k19(a, n, s, e->dtype);
             } else if (L.kind == K_PW || L.kind == K_HEAD || L.kind == K_DECONV) {
                 yf::PwArgs a{ptr(o.in1), o.in2 >= 0 ? ptr(o.in2) : nullptr, W(o.layer), B(o.layer), o.res >= 0 ? ptr(o.res) : nullptr,
                              ptr(o.out), (long)n * ti.H * ti.W, (long)ti.H * ti.W, ti.W};
                 int cin2 = o.in2 >= 0 ? P.tensors[o.in2].C : 0;
                 if (o.mfma_off >= 0) {
                     a.w = e->d_wmfma + o.mfma_off;
-                    rc = yf::launch_pw_mfma(ti.C, cin2, L.cout, L.relu != 0, o.res >= 0, o.omode, a, s);
+                    rc = yf::launch_pw_mfma(ti.C, cin2, L.cout, L.relu != 0, o.res >= 0, o.omode, a, s, e->dtype);
                 } else {
                     rc = yf::launch_pw(ti.C, cin2, L.cout, L.relu != 0, o.res >= 0, o.omode, a, s);
                 }
             } else if (L.kind == K_DW) {
                 yf::DwArgs a{ptr(o.in1), W(o.layer), B(o.layer), ptr(o.out), (long)n * to.H * to.W * (to.C / 4), ti.C, ti.H, ti.W, to.H, to.W};
-                rc = yf::launch_dw(L.k, L.stride, a, s);
+                rc = yf::launch_dw(L.k, L.stride, a, s, e->dtype);
             } else {
                 yf::DenseArgs a{ptr(o.in1), W(o.layer), B(o.layer), ptr(o.out), (long)n * to.H * to.W, ti.H, ti.W, to.H, to.W};
                 rc = yf::launch_dense3x3s2(L.cin, L.cout, a, s);
@@ -417,7 +421,7 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                     HIP_OK(hipMemcpyAsync(probe_dst + (size_t)f0 * to.elems(), ptr(o.out), to.elems() * n * sizeof(float),
                                           hipMemcpyDeviceToDevice, s));
                 else
-                    yf::launch_nhwc_to_nchw(ptr(o.out), probe_dst + (size_t)f0 * to.elems(), n, to.C, (long)to.H * to.W, s);
+                    yf::launch_nhwc_to_nchw(ptr(o.out), probe_dst + (size_t)f0 * to.elems(), n, to.C, (long)to.H * to.W, s, e->dtype);
             }
         }
     }
@@ -454,10 +458,17 @@ float logit_threshold(double thres)
 extern "C" {
 
 int yf_abi_version(void) { return YF_ABI_VERSION; }
+uint16_t yf_f32_to_f16_bits(float f) { return yf::f32_to_f16_bits(f); }
 const char* yf_last_error_string(void) { return g_err; }
 
 int yf_create(const void* blob, size_t nbytes, int H, int W, int max_batch, int device, yf_handle* out)
 {
+    return yf_create_ex(blob, nbytes, H, W, max_batch, device, 0, out);
+}
+
+int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, int device, int dtype, yf_handle* out)
+{
+    if (dtype != 0 && dtype != 1) return fail(YF_E_INVALID, "dtype must be 0 (fp32) or 1 (fp16 storage / fp16 MFMA, fp32 accumulate)");
     if (!blob || !out) return fail(YF_E_INVALID, "yf_create: null pointer");
     if (H <= 0 || W <= 0 || H % 32 || W % 32) return fail(YF_E_INVALID, "input shape %dx%d: rows and cols must be multiples of 32", H, W);
     if (max_batch <= 0) return fail(YF_E_INVALID, "max_batch must be positive");
@@ -471,7 +482,7 @@ int yf_create(const void* blob, size_t nbytes, int H, int W, int max_batch, int 
     size_t data_off = sizeof(BlobHeader) + sizeof(BlobLayer) * (size_t)kNumLayers;
     if (nbytes < data_off + hd.data_floats * 4) return fail(YF_E_BLOB, "blob truncated");
     yf_engine* e = new yf_engine;
-    e->device = device; e->H = H; e->W = W; e->max_batch = max_batch;
+    e->device = device; e->H = H; e->W = W; e->max_batch = max_batch; e->dtype = dtype;
     const BlobLayer* tab = reinterpret_cast<const BlobLayer*>(static_cast<const char*>(blob) + sizeof(BlobHeader));
     for (int i = 0; i < kNumLayers; ++i) {
         BlobLayer bl;
@@ -506,15 +517,16 @@ int yf_create(const void* blob, size_t nbytes, int H, int W, int max_batch, int 
     e->head_s_elems = 24u * (H / 32) * (W / 32);
     {   // matrix-core layers of the fused plan: pre-pack W[K][N] into MFMA B fragments (host) and upload
         const float* hw = reinterpret_cast<const float*>(static_cast<const char*>(blob) + data_off);
+        const bool h16 = e->dtype == yf::DT_F16;
         std::vector<float> packed;
         for (Op& o : e->plans[1].ops) {
             if (o.type == OP_MRES) {
                 const LayerSpec &LE = kLayers[o.l_exp], &LP = kLayers[o.l_proj];
                 o.mfma_off = (long)packed.size();
-                packed.resize(packed.size() + ((yf::mres_packed_floats(LE.cin, LE.cout, LP.cout) + 63) & ~(size_t)63));
+                packed.resize(packed.size() + ((yf::mres_packed_floats(LE.cin, LE.cout, LP.cout, h16) + 63) & ~(size_t)63));
                 yf::mres_pack_weights(hw + e->w_off[o.l_exp], hw + e->b_off[o.l_exp], hw + e->w_off[o.l_dw], hw + e->b_off[o.l_dw],
                                       hw + e->w_off[o.l_proj], hw + e->b_off[o.l_proj], LE.cin, LE.cout, LP.cout,
-                                      packed.data() + o.mfma_off);
+                                      packed.data() + o.mfma_off, h16);
                 continue;
             }
             if (o.type == OP_FUSED_BLOCK) {
@@ -532,10 +544,10 @@ int yf_create(const void* blob, size_t nbytes, int H, int W, int max_batch, int 
                 const LayerSpec &LD = kLayers[o.l_dw], &LP = kLayers[o.l_proj];
                 const int headn = o.l_head >= 0 ? 24 : 0;
                 o.mfma_off = (long)packed.size();
-                packed.resize(packed.size() + ((yf::mdw_packed_floats(LD.cin, LP.cout, headn) + 63) & ~(size_t)63));
+                packed.resize(packed.size() + ((yf::mdw_packed_floats(LD.cin, LP.cout, headn, h16) + 63) & ~(size_t)63));
                 yf::mdw_pack_weights(hw + e->w_off[o.l_dw], hw + e->b_off[o.l_dw], hw + e->w_off[o.l_proj], hw + e->b_off[o.l_proj],
                                      headn ? hw + e->w_off[o.l_head] : nullptr, headn ? hw + e->b_off[o.l_head] : nullptr, LD.cin,
-                                     LP.cout, headn, packed.data() + o.mfma_off);
+                                     LP.cout, headn, packed.data() + o.mfma_off, h16);
                 continue;
             }
             if (o.type != OP_LAYER) continue;
@@ -545,12 +557,15 @@ int yf_create(const void* blob, size_t nbytes, int H, int W, int max_batch, int 
             int c1 = P.tensors[o.in1].C, c2 = o.in2 >= 0 ? P.tensors[o.in2].C : 0;
             if (!yf::mfma_has_kernel(c1, c2, L.cout, L.relu != 0, o.res >= 0, o.omode)) continue;
             const int nq = L.kind == K_DECONV ? 4 : 1;
-            size_t per = yf::mfma_packed_floats(c1, c2, L.cout);
+            size_t per = h16 ? yf::mfma_packed_floats_f16(c1, c2, L.cout) : yf::mfma_packed_floats(c1, c2, L.cout);
             o.mfma_off = (long)packed.size();
             packed.resize(packed.size() + per * nq);
-            for (int qd = 0; qd < nq; ++qd)
-                yf::mfma_pack_weights(hw + e->w_off[o.layer] + (size_t)qd * L.cin * L.cout, c1, c2, L.cout,
-                                      packed.data() + o.mfma_off + per * qd);
+            for (int qd = 0; qd < nq; ++qd) {
+                if (h16) yf::mfma_pack_weights_f16(hw + e->w_off[o.layer] + (size_t)qd * L.cin * L.cout, c1, c2, L.cout,
+                                                   packed.data() + o.mfma_off + per * qd);
+                else yf::mfma_pack_weights(hw + e->w_off[o.layer] + (size_t)qd * L.cin * L.cout, c1, c2, L.cout,
+                                           packed.data() + o.mfma_off + per * qd);
+            }
         }
         if (!packed.empty()) {
             if (hipMalloc(&e->d_wmfma, packed.size() * 4) != hipSuccess ||
@@ -592,7 +607,7 @@ int yf_workspace_bytes(yf_handle h, int N, size_t* out)
     // layer-chain slots + internal head buffers for yf_detect
     size_t per_pass = (size_t)chunk_frames(h, N) * h->lanes;
     if (per_pass < (size_t)N) per_pass = N;  // yf_profile_forward / yf_forward_probe run the whole batch in one pass
-    *out = (h->frame_floats_max() * per_pass + (h->head_l_elems + h->head_s_elems) * (size_t)N) * sizeof(float) + 256;
+    *out = h->frame_floats_max() * per_pass * h->esz() + (h->head_l_elems + h->head_s_elems) * (size_t)N * sizeof(float) + 1024;
     return YF_OK;
 }
 
@@ -606,7 +621,7 @@ int yf_forward_probe(yf_handle h, const float* d_x, int N, const char* name, flo
 {
     if (!h || !name || !d_dst) return fail(YF_E_INVALID, "yf_forward_probe: null pointer");
     // heads go to the tail of the workspace
-    size_t chain = h->frame_floats_max() * (size_t)chunk_frames(h, N) * h->lanes * sizeof(float);
+    size_t chain = ((h->frame_floats_max() * (size_t)chunk_frames(h, N) * h->lanes * h->esz()) + 255) & ~(size_t)255;
     size_t heads = (h->head_l_elems + h->head_s_elems) * (size_t)N * sizeof(float);
     if (!ws || ws_bytes < chain + heads) return fail(YF_E_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, chain + heads);
     float* hl = reinterpret_cast<float*>(static_cast<char*>(ws) + chain);
@@ -699,7 +714,7 @@ int yf_detect(yf_handle h, const float* d_x, int N, double conf_thres, double nm
               float* d_hl, float* d_hs, void* ws, size_t ws_bytes, void* stream)
 {
     if (!h) return fail(YF_E_INVALID, "yf_detect: null handle");
-    size_t chain = h->frame_floats_max() * (size_t)chunk_frames(h, N) * h->lanes * sizeof(float);
+    size_t chain = ((h->frame_floats_max() * (size_t)chunk_frames(h, N) * h->lanes * h->esz()) + 255) & ~(size_t)255;
     size_t heads = (h->head_l_elems + h->head_s_elems) * (size_t)N * sizeof(float);
     if (!ws || ws_bytes < chain + ((d_hl && d_hs) ? 0 : heads)) return fail(YF_E_WORKSPACE, "workspace too small");
     float* hl = d_hl ? d_hl : reinterpret_cast<float*>(static_cast<char*>(ws) + chain);
@@ -763,7 +778,7 @@ int yf_op_info(yf_handle h, int op, char* name, int name_len, double* algorithmi
         add(o.layer, ipx, opx, o.res >= 0);
     }
     if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s", nm.c_str());
-    if (algorithmic_bytes_per_frame) *algorithmic_bytes_per_frame = elems * 4.0;
+    if (algorithmic_bytes_per_frame) *algorithmic_bytes_per_frame = elems * (double)h->esz();
     if (flops_per_frame) *flops_per_frame = macs * 2.0;
     return YF_OK;
 }
@@ -773,7 +788,7 @@ int yf_profile_forward(yf_handle h, const float* d_x, int N, void* ws, size_t ws
     if (!h || !op_ms) return fail(YF_E_INVALID, "yf_profile_forward: null pointer");
     const size_t nops = h->plan().ops.size();
     if (n_ops != (int)nops) return fail(YF_E_INVALID, "op_ms must hold %zu entries", nops);
-    size_t chain = h->frame_floats_max() * (size_t)N * sizeof(float);
+    size_t chain = ((h->frame_floats_max() * (size_t)N * h->esz()) + 255) & ~(size_t)255;
     size_t heads = (h->head_l_elems + h->head_s_elems) * (size_t)N * sizeof(float);
     if (!ws || ws_bytes < chain + heads) return fail(YF_E_WORKSPACE, "workspace too small");
     float* hl = reinterpret_cast<float*>(static_cast<char*>(ws) + chain);

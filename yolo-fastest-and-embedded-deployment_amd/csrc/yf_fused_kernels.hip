@@ -47,7 +47,7 @@ __device__ __forceinline__ unsigned long long yf_stamp()
 __host__ __device__ constexpr int fb_chunk_floats(int cin, int cout, int ec) { return cin * ec + ec + 9 * ec + ec + ec * cout; }
 
 template <int CIN, int CEXP, int COUT, int S, bool RES, bool RELU_OUT, bool PRE, int TYB, int TXB, int BH, int BW,
-          int EC, int CG, int PE, bool XL>
+          int EC, int CG, int PE, bool XL, typename T>
 __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
 {
     constexpr int NT = TYB * TXB, NW = NT / 64;
@@ -87,13 +87,13 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
         }
     } else {
         constexpr int C4 = CIN / 4;
-        const float* __restrict__ src = a.in + (long)n * a.H * a.W * CIN;
+        const T* __restrict__ src = reinterpret_cast<const T*>(a.in) + (long)n * a.H * a.W * CIN;
         for (int idx = threadIdx.x; idx < NRP * C4; idx += NT) {
             const int rp = idx / C4, c4 = idx - rp * C4;
             const int ry_ = rp / RW, rx_ = rp - ry_ * RW;
             const int iy = iy0 + ry_, ix = ix0 + rx_;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *reinterpret_cast<const float4*>(src + ((long)iy * a.W + ix) * CIN + c4 * 4);
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = ld4<T>(src + ((long)iy * a.W + ix) * CIN + c4 * 4);
             *reinterpret_cast<float4*>(&X[rp * XP + c4 * 4]) = v;
         }
     }
@@ -180,10 +180,10 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
                         x[p][k] = t.x; x[p][k + 1] = t.y; x[p][k + 2] = t.z; x[p][k + 3] = t.w;
                     }
                 } else {
-                    const float* __restrict__ src = a.in + (((long)n * a.H + (inimg[p] ? iy : 0)) * a.W + (inimg[p] ? ix : 0)) * CIN;
+                    const T* __restrict__ src = reinterpret_cast<const T*>(a.in) + (((long)n * a.H + (inimg[p] ? iy : 0)) * a.W + (inimg[p] ? ix : 0)) * CIN;
 #pragma unroll
                     for (int k = 0; k < CIN; k += 4) {
-                        float4 t = *reinterpret_cast<const float4*>(src + k);
+                        float4 t = ld4<T>(src + k);
                         x[p][k] = t.x; x[p][k + 1] = t.y; x[p][k + 2] = t.z; x[p][k + 3] = t.w;
                     }
                 }
@@ -270,20 +270,20 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
             const int oy = oy0 + tyb * BH + by, ox = ox0 + txb * BW + bx;
             if (oy >= a.Ho || ox >= a.Wo) continue;
             const long opix = ((long)n * a.Ho + oy) * a.Wo + ox;
-            float* o = a.out + opix * COUT;
+            T* o = reinterpret_cast<T*>(a.out) + opix * COUT;
 #pragma unroll
             for (int co = 0; co < COUT; co += 4) {
                 float4 v = make_float4(acc[by * BW + bx][co] + b2[co], acc[by * BW + bx][co + 1] + b2[co + 1],
                                        acc[by * BW + bx][co + 2] + b2[co + 2], acc[by * BW + bx][co + 3] + b2[co + 3]);
                 if constexpr (RES) {  // the residual is the centre of the staged tile
                     float4 r = XL ? *reinterpret_cast<const float4*>(&X[((tyb * BH + by + 1) * RW + txb * BW + bx + 1) * XP + co])
-                                  : *reinterpret_cast<const float4*>(a.in + opix * CIN + co);
+                                  : ld4<T>(reinterpret_cast<const T*>(a.in) + opix * CIN + co);
                     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                 }
                 if constexpr (RELU_OUT) {
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                 }
-                *reinterpret_cast<float4*>(o + co) = v;
+                st4<T>(o + co, v);
             }
         }
     YF_STAMP_AT(5)
@@ -301,6 +301,7 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
 //   even-column and odd-column planes ("space to depth") so that lanes on consecutive output columns read
 //   consecutive 48-B pixel records: conflict-free ds_read_b128.
 // ------------------------------------------------------------------------------------------------
+template <typename TT>
 __global__ void __launch_bounds__(256) k19_kernel(K19Args a)
 {
     constexpr int T = 16, RH = 2 * T + 1, RWE = T + 1, RWO = T;  // even cols 0,2,..,32 (17); odd cols 1,..,31 (16)
@@ -327,7 +328,7 @@ __global__ void __launch_bounds__(256) k19_kernel(K19Args a)
             const int iy = iy0 + ry, ix = ix0 + rx;
             const bool inimg = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (inimg) t = *reinterpret_cast<const float4*>(a.in + (((long)n * a.H + iy) * a.W + ix) * 4);
+            if (inimg) t = ld4<TT>(reinterpret_cast<const TT*>(a.in) + (((long)n * a.H + iy) * a.W + ix) * 4);
             float* dst = A + r * CH;
 #pragma unroll
             for (int j = 0; j < CH; j += 4) {
@@ -380,21 +381,21 @@ __global__ void __launch_bounds__(256) k19_kernel(K19Args a)
 #pragma unroll
         for (int c = 0; c < 8; ++c) o8[c] = fmaf(v, a.w21[k * 8 + c], o8[c]);
     }
-    float* o = a.out + (((long)n * a.Ho + oy) * a.Wo + ox) * 8;
-    *reinterpret_cast<float4*>(o) = make_float4(o8[0], o8[1], o8[2], o8[3]);
-    *reinterpret_cast<float4*>(o + 4) = make_float4(o8[4], o8[5], o8[6], o8[7]);
+    TT* o = reinterpret_cast<TT*>(a.out) + (((long)n * a.Ho + oy) * a.Wo + ox) * 8;
+    st4<TT>(o, make_float4(o8[0], o8[1], o8[2], o8[3]));
+    st4<TT>(o + 4, make_float4(o8[4], o8[5], o8[6], o8[7]));
 }
 
 // ------------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int CEXP, int COUT, int S, bool RES, bool RELU_OUT, bool PRE, int TYB, int TXB, int BH, int BW, int EC, int CG, int PE, bool XL>
+template <int CIN, int CEXP, int COUT, int S, bool RES, bool RELU_OUT, bool PRE, int TYB, int TXB, int BH, int BW, int EC, int CG, int PE, bool XL, typename T>
 static int launch_fb_t(FbArgs a, int N, hipStream_t s)
 {
     a.tiles_y = (a.Ho + TYB * BH - 1) / (TYB * BH);
     a.tiles_x = (a.Wo + TXB * BW - 1) / (TXB * BW);
     dim3 grid((unsigned)(N * a.tiles_y * a.tiles_x));
-    hipLaunchKernelGGL((fused_block_kernel<CIN, CEXP, COUT, S, RES, RELU_OUT, PRE, TYB, TXB, BH, BW, EC, CG, PE, XL>), grid,
+    hipLaunchKernelGGL((fused_block_kernel<CIN, CEXP, COUT, S, RES, RELU_OUT, PRE, TYB, TXB, BH, BW, EC, CG, PE, XL, T>), grid,
                        dim3(TYB * TXB), 0, s, a);
     return 0;
 }
@@ -413,11 +414,12 @@ static int launch_fb_t(FbArgs a, int N, hipStream_t s)
     FB(24, 136, 24, 1, true, false, false, 16, 20, 1, 1, 8, 8, 1, false) /* res4_1 .. res4_4 (fallback)   @ H/16 */
 
 int launch_fused_block(int cin, int cexp, int cout, int stride, bool res, bool relu_out, bool pre, const FbArgs& a, int N,
-                       hipStream_t s)
+                       hipStream_t s, int dtype)
 {
 #define FB(ci, ce, co, st, rs, ro, pr, tyb, txb, bh, bw, ec, cg, pe, xl)                                          \
     if (cin == ci && cexp == ce && cout == co && stride == st && res == rs && relu_out == ro && pre == pr)         \
-        return launch_fb_t<ci, ce, co, st, rs, ro, pr, tyb, txb, bh, bw, ec, cg, pe, xl>(a, N, s);
+        return dtype == DT_F16 ? launch_fb_t<ci, ce, co, st, rs, ro, pr, tyb, txb, bh, bw, ec, cg, pe, xl, half_t>(a, N, s)   \
+                               : launch_fb_t<ci, ce, co, st, rs, ro, pr, tyb, txb, bh, bw, ec, cg, pe, xl, float>(a, N, s);
     YF_FB_SHAPES(FB)
 #undef FB
     return -1;
@@ -456,11 +458,12 @@ void fb_pack_weights(const float* w1 /*[cin][cexp]*/, const float* b1, const flo
     for (int co = 0; co < cout; ++co) out[(size_t)(cexp / ec) * CHF + co] = b2[co];
 }
 
-int launch_k19(K19Args a, int N, hipStream_t s)
+int launch_k19(K19Args a, int N, hipStream_t s, int dtype)
 {
     a.tiles_y = (a.Ho + 15) / 16;
     a.tiles_x = (a.Wo + 15) / 16;
-    hipLaunchKernelGGL(k19_kernel, dim3((unsigned)(N * a.tiles_y * a.tiles_x)), dim3(256), 0, s, a);
+    if (dtype == DT_F16) hipLaunchKernelGGL(k19_kernel<half_t>, dim3((unsigned)(N * a.tiles_y * a.tiles_x)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k19_kernel<float>, dim3((unsigned)(N * a.tiles_y * a.tiles_x)), dim3(256), 0, s, a);
     return 0;
 }
 

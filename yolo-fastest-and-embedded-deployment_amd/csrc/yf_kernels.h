@@ -5,6 +5,36 @@
 
 namespace yf {
 
+// ---- activation storage types: fp32 (BASELINE configs[1]) or fp16 (configs[2]); all arithmetic accumulates in fp32 ----
+enum { DT_F32 = 0, DT_F16 = 1 };
+typedef _Float16 half_t;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#ifdef __HIPCC__
+template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 ld4<half_t>(const half_t* p)
+{
+    const f16x4 v = *reinterpret_cast<const f16x4*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+template <typename T> __device__ __forceinline__ float2 ld2(const T* p);
+template <> __device__ __forceinline__ float2 ld2<float>(const float* p) { return *reinterpret_cast<const float2*>(p); }
+template <> __device__ __forceinline__ float2 ld2<half_t>(const half_t* p)
+{
+    const f16x2 v = *reinterpret_cast<const f16x2*>(p);
+    return make_float2((float)v[0], (float)v[1]);
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, float4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<half_t>(half_t* p, float4 v)
+{
+    *reinterpret_cast<f16x4*>(p) = f16x4{(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+}
+template <typename T> __device__ __forceinline__ float ld1(const T* p) { return (float)*p; }
+template <typename T> __device__ __forceinline__ void st1(T* p, float v) { *p = (T)v; }
+#endif
+
 struct PwArgs {
     const float* in1;  // NHWC [npix, CIN1]
     const float* in2;  // NHWC [npix, CIN2] (second half of a channel concat) or null
@@ -36,14 +66,17 @@ struct DenseArgs {
 };
 
 int launch_pw(int cin1, int cin2, int cout, bool relu, bool res, int omode, const PwArgs& a, hipStream_t s);
-int launch_dw(int k, int stride, const DwArgs& a, hipStream_t s);
+int launch_dw(int k, int stride, const DwArgs& a, hipStream_t s, int dtype = DT_F32);
 // matrix-core pointwise GEMM (yf_mfma_kernels.hip); a.w points at the layer's PACKED B fragments
-int launch_pw_mfma(int cin1, int cin2, int cout, bool relu, bool res, int omode, const PwArgs& a, hipStream_t s);
+int launch_pw_mfma(int cin1, int cin2, int cout, bool relu, bool res, int omode, const PwArgs& a, hipStream_t s, int dtype = DT_F32);
+uint16_t f32_to_f16_bits(float f);
+size_t mfma_packed_floats_f16(int k1, int k2, int n);
+void mfma_pack_weights_f16(const float* w, int k1, int k2, int n, float* out);
 bool mfma_has_kernel(int cin1, int cin2, int cout, bool relu, bool res, int omode);
 size_t mfma_packed_floats(int k1, int k2, int n);
 void mfma_pack_weights(const float* w, int k1, int k2, int n, float* out);
 int launch_dense3x3s2(int cin, int cout, const DenseArgs& a, hipStream_t s);
-void launch_nhwc_to_nchw(const float* in, float* out, long N, int C, long HW, hipStream_t s);
+void launch_nhwc_to_nchw(const float* in, float* out, long N, int C, long HW, hipStream_t s, int dtype = DT_F32);
 void launch_preprocess(const uint8_t* in, float* out, long N, int H, int W, int down2, hipStream_t s);
 
 struct FbArgs {
@@ -58,7 +91,7 @@ struct FbArgs {
     unsigned long long* dbg;      // diagnostic builds only (-DYF_STAMP): per-phase cycle sums; null in the product
 };
 int launch_fused_block(int cin, int cexp, int cout, int stride, bool res, bool relu_out, bool pre, const FbArgs& a, int N,
-                       hipStream_t s);
+                       hipStream_t s, int dtype = DT_F32);
 int fb_chunk_channels(int cin, int cexp, int cout, int stride, bool res, bool relu_out, bool pre);  // EC of that shape, -1 if none
 size_t fb_packed_floats(int cin, int cexp, int cout, int ec);
 void fb_pack_weights(const float* w1, const float* b1, const float* wd, const float* bd, const float* w2, const float* b2, int cin,
@@ -71,11 +104,11 @@ struct MresArgs {
     int H, W;
     int tiles_y, tiles_x;  // filled by the launcher
 };
-int launch_mres(int cin, int cexp, int cout, bool res, const MresArgs& a, int N, hipStream_t s);
+int launch_mres(int cin, int cexp, int cout, bool res, const MresArgs& a, int N, hipStream_t s, int dtype = DT_F32);
 bool mres_has_kernel(int cin, int cexp, int cout, bool res);
-size_t mres_packed_floats(int cin, int cexp, int cout);
+size_t mres_packed_floats(int cin, int cexp, int cout, bool h16 = false);
 void mres_pack_weights(const float* w1, const float* b1, const float* wd, const float* bd, const float* w2, const float* b2,
-                       int cin, int cexp, int cout, float* out);
+                       int cin, int cexp, int cout, float* out, bool h16 = false);
 
 struct MdwArgs {
     const float* in;   // NHWC [N,H,W,C]
@@ -84,11 +117,11 @@ struct MdwArgs {
     int H, W;
     int tiles_y, tiles_x;
 };
-int launch_mdw(int c, int n, int headn, const MdwArgs& a, int Nf, hipStream_t s);
+int launch_mdw(int c, int n, int headn, const MdwArgs& a, int Nf, hipStream_t s, int dtype = DT_F32);
 bool mdw_has_kernel(int c, int n, int headn);
-size_t mdw_packed_floats(int c, int n, int headn);
+size_t mdw_packed_floats(int c, int n, int headn, bool h16 = false);
 void mdw_pack_weights(const float* wd, const float* bd, const float* w, const float* b, const float* hw, const float* hb, int c,
-                      int n, int headn, float* out);
+                      int n, int headn, float* out, bool h16 = false);
 
 struct K19Args {
     const float* in;              // NHWC [N,H,W,4] (res1_1 output, stride-2 resolution)
@@ -99,7 +132,7 @@ struct K19Args {
     int H, W, Ho, Wo;
     int tiles_y, tiles_x;
 };
-int launch_k19(K19Args a, int N, hipStream_t s);
+int launch_k19(K19Args a, int N, hipStream_t s, int dtype = DT_F32);
 
 struct PostArgs {
     const float* head_large;  // [N,24,hl,wl]

@@ -18,28 +18,31 @@ namespace yf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__host__ __device__ constexpr int mdw_chunk_floats(int n) { return 25 * 16 + 16 + 4 * (n / 16) * 64; }
-__host__ __device__ constexpr int mdw_stream_floats(int c, int n, int headn)
+// h16: B fragments are f16x4 per lane (one v_mfma_f32_16x16x16_f16 per 16-channel chunk and n-tile); dw weights / biases stay fp32
+__host__ __device__ constexpr int mdw_chunk_floats(int n, bool h16 = false) { return 25 * 16 + 16 + (h16 ? (n / 16) * 128 : 4 * (n / 16) * 64); }
+__host__ __device__ constexpr int mdw_stream_floats(int c, int n, int headn, bool h16 = false)
 {
-    int f = (c / 16) * mdw_chunk_floats(n) + n;
-    if (headn) f += (n / 4) * 2 * 64 + 32;
+    int f = (c / 16) * mdw_chunk_floats(n, h16) + n;
+    if (headn) f += (h16 ? (n / 16) * 2 * 128 : (n / 4) * 2 * 64) + 32;
     return (f + 3) & ~3;
 }
 
-template <int C, int N, int HEADN, int TH, int TW, int NWAVE>
+template <int C, int N, int HEADN, int TH, int TW, int NWAVE, typename TT>
 __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
 {
+    constexpr bool H16 = sizeof(TT) == 2;
     constexpr int NTHR = NWAVE * 64;
     constexpr int RH = TH + 4, RW = TW + 4, NRP = RH * RW;
     constexpr int MTO = (TH * TW) / 16, MTOW = (MTO + NWAVE - 1) / NWAVE;
     constexpr int EPL = ((NRP + 7) / 8) * 8 + 2;  // pixels per 4-channel plane, == 2 (mod 8): conflict-free b128 fills
     constexpr int NT = N / 16, NCH = C / 16;
-    constexpr int OFF_BD = 400, OFF_W = 416, CHUNK = 416 + 4 * NT * 64;
-    constexpr int OFF_BPW = NCH * CHUNK, OFF_HW = OFF_BPW + N, KSH = N / 4, NTH = 2, OFF_HB = OFF_HW + KSH * NTH * 64;
-    constexpr int WFLOATS = mdw_stream_floats(C, N, HEADN);
+    constexpr int OFF_BD = 400, OFF_W = 416, CHUNK = 416 + (H16 ? NT * 128 : 4 * NT * 64);
+    constexpr int OFF_BPW = NCH * CHUNK, OFF_HW = OFF_BPW + N, KSH = N / 4, NTH = 2;
+    constexpr int OFF_HB = OFF_HW + (H16 ? (N / 16) * NTH * 128 : KSH * NTH * 64);
+    constexpr int WFLOATS = mdw_stream_floats(C, N, HEADN, H16);
     constexpr int NLD = (NRP * 4 + NTHR - 1) / NTHR;  // float4 loads per thread per chunk
     constexpr int TP = N + 4;                         // pitch of the transposition tile
-    static_assert((TH * TW) % 16 == 0 && C % 16 == 0 && N % 16 == 0 && CHUNK == mdw_chunk_floats(N), "shape");
+    static_assert((TH * TW) % 16 == 0 && C % 16 == 0 && N % 16 == 0 && CHUNK == mdw_chunk_floats(N, H16), "shape");
     static_assert(HEADN == 0 || HEADN <= 32, "head width");
     extern __shared__ __attribute__((aligned(16))) float mdw_smem[];
     float* E = mdw_smem;           // [4][EPL][4]
@@ -51,7 +54,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-    const float* __restrict__ src = a.in + (long)n * a.H * a.W * C;
+    const TT* __restrict__ src = reinterpret_cast<const TT*>(a.in) + (long)n * a.H * a.W * C;
 
     for (int i = threadIdx.x * 4; i < WFLOATS; i += NTHR * 4)
         *reinterpret_cast<float4*>(&WL[i]) = *reinterpret_cast<const float4*>(a.wp + i);
@@ -71,7 +74,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
 #pragma unroll
         for (int m = 0; m < NLD; ++m) {
             const int id = threadIdx.x + m * NTHR;
-            pf[m] = goff[m] >= 0 ? *reinterpret_cast<const float4*>(src + (long)goff[m] * C + c * 16 + 4 * (id & 3))
+            pf[m] = goff[m] >= 0 ? ld4<TT>(src + (long)goff[m] * C + c * 16 + 4 * (id & 3))
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -121,18 +124,33 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
                 }
             }
         // ---- 1x1 conv: A = relu(d) (k-step j = channel 4q+j), B fragments from the staged stream ----
+        if constexpr (H16) {
+            f16x4 w2h[NT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float w2f[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) w2f[nt] = wc[OFF_W + (j * NT + nt) * 64 + lane];
+            for (int nt = 0; nt < NT; ++nt) w2h[nt] = reinterpret_cast<const f16x4*>(wc + OFF_W)[nt * 64 + lane];
 #pragma unroll
             for (int i = 0; i < MTOW; ++i) {
                 if (wave + i * NWAVE < MTO) {
-                    const float dj = fmaxf(d[i][j], 0.f);
+                    const f16x4 dh = f16x4{(half_t)fmaxf(d[i][0], 0.f), (half_t)fmaxf(d[i][1], 0.f), (half_t)fmaxf(d[i][2], 0.f),
+                                           (half_t)fmaxf(d[i][3], 0.f)};
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dj, w2f[nt], acc[i][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(dh, w2h[nt], acc[i][nt], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float w2f[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) w2f[nt] = wc[OFF_W + (j * NT + nt) * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < MTOW; ++i) {
+                    if (wave + i * NWAVE < MTO) {
+                        const float dj = fmaxf(d[i][j], 0.f);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dj, w2f[nt], acc[i][nt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -155,7 +173,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
                     const int op = mo * 16 + 4 * q + reg;
                     const int oy = op / TW, ox = op - oy * TW;
                     const int gy = oy0 + oy, gx = ox0 + ox;
-                    if (gy < a.H && gx < a.W) a.out[(((long)n * a.H + gy) * a.W + gx) * N + col] = acc[i][nt][reg] + bias;
+                    if (gy < a.H && gx < a.W) st1<TT>(reinterpret_cast<TT*>(a.out) + (((long)n * a.H + gy) * a.W + gx) * N + col, acc[i][nt][reg] + bias);
                 }
             }
         }
@@ -180,12 +198,19 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
 #pragma unroll
             for (int kb = 0; kb < N / 16; ++kb) {
                 const float4 av = *reinterpret_cast<const float4*>(&Tw[r * TP + kb * 16 + 4 * q]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
+                if constexpr (H16) {
+                    const f16x4 ah = f16x4{(half_t)av.x, (half_t)av.y, (half_t)av.z, (half_t)av.w};
 #pragma unroll
                     for (int nt = 0; nt < NTH; ++nt)
-                        h[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&av)[j], hw[((kb * 4 + j) * NTH + nt) * 64 + lane],
-                                                                     h[nt], 0, 0, 0);
+                        h[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, reinterpret_cast<const f16x4*>(hw)[(kb * NTH + nt) * 64 + lane], h[nt], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int nt = 0; nt < NTH; ++nt)
+                            h[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&av)[j], hw[((kb * 4 + j) * NTH + nt) * 64 + lane],
+                                                                         h[nt], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -205,23 +230,23 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
     }
 }
 
-template <int C, int N, int HEADN, int TH, int TW, int NWAVE>
+template <int C, int N, int HEADN, int TH, int TW, int NWAVE, typename T>
 static int launch_mdw_t(MdwArgs a, int Nf, hipStream_t s)
 {
     a.tiles_y = (a.H + TH - 1) / TH;
     a.tiles_x = (a.W + TW - 1) / TW;
     constexpr int NRP = (TH + 4) * (TW + 4), MTO = TH * TW / 16;
-    constexpr size_t lds = ((size_t)16 * (((NRP + 7) / 8) * 8 + 2) + mdw_stream_floats(C, N, HEADN) +
+    constexpr size_t lds = ((size_t)16 * (((NRP + 7) / 8) * 8 + 2) + mdw_stream_floats(C, N, HEADN, sizeof(T) == 2) +
                             (HEADN ? (size_t)(NWAVE < MTO ? NWAVE : MTO) * 16 * (N + 4) : 0)) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done = false;
     if (lds > 64 * 1024 && !attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mdw_kernel<C, N, HEADN, TH, TW, NWAVE>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mdw_kernel<C, N, HEADN, TH, TW, NWAVE, T>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
         attr_done = true;
     }
-    hipLaunchKernelGGL((mdw_kernel<C, N, HEADN, TH, TW, NWAVE>), dim3((unsigned)(Nf * a.tiles_y * a.tiles_x)), dim3(NWAVE * 64),
+    hipLaunchKernelGGL((mdw_kernel<C, N, HEADN, TH, TW, NWAVE, T>), dim3((unsigned)(Nf * a.tiles_y * a.tiles_x)), dim3(NWAVE * 64),
                        lds, s, a);
     return 0;
 }
@@ -233,10 +258,11 @@ static int launch_mdw_t(MdwArgs a, int Nf, hipStream_t s)
     MD(96, 96, 0, 16, 20, 8)    /* conv4_1_2 -> conv4_1_3        @ H/16 */ \
     MD(96, 96, 24, 16, 20, 8)   /* conv4_1_4 -> conv4_1_5 -> head_4      */
 
-int launch_mdw(int c, int n, int headn, const MdwArgs& a, int Nf, hipStream_t s)
+int launch_mdw(int c, int n, int headn, const MdwArgs& a, int Nf, hipStream_t s, int dtype)
 {
-#define MD(cc, nn, hh, th, tw, nw) \
-    if (c == cc && n == nn && headn == hh) return launch_mdw_t<cc, nn, hh, th, tw, nw>(a, Nf, s);
+#define MD(cc, nn, hh, th, tw, nw)                                                               \
+    if (c == cc && n == nn && headn == hh)                                                        \
+        return dtype == DT_F16 ? launch_mdw_t<cc, nn, hh, th, tw, nw, half_t>(a, Nf, s) : launch_mdw_t<cc, nn, hh, th, tw, nw, float>(a, Nf, s);
     YF_MDW_SHAPES(MD)
 #undef MD
     return -1;
@@ -251,34 +277,52 @@ bool mdw_has_kernel(int c, int n, int headn)
     return false;
 }
 
-size_t mdw_packed_floats(int c, int n, int headn) { return (size_t)mdw_stream_floats(c, n, headn); }
+size_t mdw_packed_floats(int c, int n, int headn, bool h16) { return (size_t)mdw_stream_floats(c, n, headn, h16); }
 
-// Weight stream: NCH chunks of [wd 25x16 | bd 16 | W frags 4 x NT x 64], then b_pw[n], then (head) frags (n/4) x 2 x 64, b_head[32].
+// Weight stream: NCH chunks of [wd 25x16 | bd 16 | W frags], then b_pw[n], then (head) frags, b_head[32].
+//   fp32: W frags 4 x NT x 64 floats (one per k-step), head frags (n/4) x 2 x 64;  h16: f16x4 per lane: NT x 128 / (n/16) x 2 x 128 floats
 void mdw_pack_weights(const float* wd /*[25][c]*/, const float* bd, const float* w /*[c][n]*/, const float* b, const float* hw /*[n][headn]*/,
-                      const float* hb, int c, int n, int headn, float* out)
+                      const float* hb, int c, int n, int headn, float* out, bool h16)
 {
-    const int NT = n / 16, NCH = c / 16, CH = mdw_chunk_floats(n);
+    const int NT = n / 16, NCH = c / 16, CH = mdw_chunk_floats(n, h16);
     for (int ch = 0; ch < NCH; ++ch) {
         float* o = out + (size_t)ch * CH;
         for (int t = 0; t < 25; ++t)
             for (int k = 0; k < 16; ++k) o[t * 16 + k] = wd[(size_t)t * c + ch * 16 + k];
         for (int k = 0; k < 16; ++k) o[400 + k] = bd[ch * 16 + k];
-        for (int j = 0; j < 4; ++j)
+        auto w_at = [&](int j, int nt, int lane) { return w[(size_t)(ch * 16 + 4 * (lane >> 4) + j) * n + nt * 16 + (lane & 15)]; };
+        if (h16) {
+            uint16_t* o16 = reinterpret_cast<uint16_t*>(o + 416);
             for (int nt = 0; nt < NT; ++nt)
                 for (int lane = 0; lane < 64; ++lane)
-                    o[416 + (j * NT + nt) * 64 + lane] = w[(size_t)(ch * 16 + 4 * (lane >> 4) + j) * n + nt * 16 + (lane & 15)];
+                    for (int j = 0; j < 4; ++j) o16[(nt * 64 + lane) * 4 + j] = f32_to_f16_bits(w_at(j, nt, lane));
+        } else {
+            for (int j = 0; j < 4; ++j)
+                for (int nt = 0; nt < NT; ++nt)
+                    for (int lane = 0; lane < 64; ++lane) o[416 + (j * NT + nt) * 64 + lane] = w_at(j, nt, lane);
+        }
     }
     float* o = out + (size_t)NCH * CH;
     for (int i = 0; i < n; ++i) o[i] = b[i];
     o += n;
     if (headn) {
-        for (int s = 0; s < n / 4; ++s)
-            for (int nt = 0; nt < 2; ++nt)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int k = (s / 4) * 16 + 4 * (lane >> 4) + (s % 4), col = nt * 16 + (lane & 15);
-                    o[(s * 2 + nt) * 64 + lane] = col < headn ? hw[(size_t)k * headn + col] : 0.f;
-                }
-        o += (n / 4) * 2 * 64;
+        auto h_at = [&](int s, int nt, int lane) -> float {
+            const int k = (s / 4) * 16 + 4 * (lane >> 4) + (s % 4), col = nt * 16 + (lane & 15);
+            return col < headn ? hw[(size_t)k * headn + col] : 0.f;
+        };
+        if (h16) {
+            uint16_t* o16 = reinterpret_cast<uint16_t*>(o);
+            for (int kb = 0; kb < n / 16; ++kb)
+                for (int nt = 0; nt < 2; ++nt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j) o16[((kb * 2 + nt) * 64 + lane) * 4 + j] = f32_to_f16_bits(h_at(kb * 4 + j, nt, lane));
+            o += (n / 16) * 2 * 128;
+        } else {
+            for (int s = 0; s < n / 4; ++s)
+                for (int nt = 0; nt < 2; ++nt)
+                    for (int lane = 0; lane < 64; ++lane) o[(s * 2 + nt) * 64 + lane] = h_at(s, nt, lane);
+            o += (n / 4) * 2 * 64;
+        }
         for (int i = 0; i < 32; ++i) o[i] = i < headn ? hb[i] : 0.f;
     }
 }

@@ -15,6 +15,7 @@
 //   * C fragment: col = l&15, row = 4q + reg  ->  64-B row segments on store.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "yf_kernels.h"
 
@@ -24,6 +25,43 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // number of MFMA k-steps for a source of K channels: 4 per full 16-block, 2 for a trailing 8-block
 __host__ __device__ constexpr int ksteps(int K) { return (K / 16) * 4 + ((K % 16) ? 2 : 0); }
+
+// fp16 variant (storage type half_t): one v_mfma_f32_16x16x16_f16 covers the four k-steps of a 16-wide k block -- its A/B
+// lane layout (row/col = l & 15, k = 4*(l >> 4) + j) is exactly the 16-B fragment this kernel already loads; B fragments are
+// host-packed f16x4 (8 B per lane); a trailing 8-block is one MFMA with k-slots 2,3 zero.
+template <int KS, int NT, int MT>
+__device__ __forceinline__ void mfma_source_f16(const half_t* __restrict__ in, const long (&rows)[MT], int q,
+                                                const float* __restrict__ bp, int lane, f32x4 (&acc)[MT][NT])
+{
+    constexpr int NB = KS / 16;
+    const f16x4* __restrict__ b4 = reinterpret_cast<const f16x4*>(bp);
+#pragma unroll 2
+    for (int kb = 0; kb < NB; ++kb) {
+        f16x4 av[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f16x4*>(in + rows[mt] * KS + kb * 16 + 4 * q);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const f16x4 bv = b4[(kb * NT + nt) * 64 + lane];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(av[mt], bv, acc[mt][nt], 0, 0, 0);
+        }
+    }
+    if constexpr (KS % 16 != 0) {
+        f16x4 av[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f16x2 t = *reinterpret_cast<const f16x2*>(in + rows[mt] * KS + NB * 16 + 2 * q);
+            av[mt] = f16x4{t[0], t[1], (half_t)0.f, (half_t)0.f};
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const f16x4 bv = b4[(NB * NT + nt) * 64 + lane];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(av[mt], bv, acc[mt][nt], 0, 0, 0);
+        }
+    }
+}
 
 template <int KS, int NT, int MT>
 __device__ __forceinline__ void mfma_source(const float* __restrict__ in, const long (&rows)[MT], int q,
@@ -65,11 +103,15 @@ __device__ __forceinline__ void mfma_source(const float* __restrict__ in, const 
     }
 }
 
-template <int K1, int K2, int N, int MT, bool RELU, bool RES, int OMODE>
+__host__ __device__ constexpr int kmfmas16(int K) { return K / 16 + ((K % 16) ? 1 : 0); }  // f16 MFMAs per n-tile for K channels
+
+template <int K1, int K2, int N, int MT, bool RELU, bool RES, int OMODE, typename T>
 __global__ void __launch_bounds__(256) pw_mfma_kernel(PwArgs a)
 {
+    constexpr bool H16 = sizeof(T) == 2;
     constexpr int NT = (N + 15) / 16;
-    constexpr int S1 = ksteps(K1), S2 = K2 ? ksteps(K2) : 0;
+    // packed-B floats per source: fp32 = one float per lane per k-step; fp16 = 2 floats (f16x4) per lane per 16-wide block
+    constexpr int S1 = H16 ? 2 * kmfmas16(K1) : ksteps(K1), S2 = K2 ? (H16 ? 2 * kmfmas16(K2) : ksteps(K2)) : 0;
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long row0 = wave * (16 * MT);
@@ -88,8 +130,13 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwArgs a)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    mfma_source<K1, NT, MT>(a.in1, rows, q, bp, lane, acc);
-    if constexpr (K2 > 0) mfma_source<K2, NT, MT>(a.in2, rows, q, bp + (size_t)S1 * NT * 64, lane, acc);
+    if constexpr (H16) {
+        mfma_source_f16<K1, NT, MT>(reinterpret_cast<const half_t*>(a.in1), rows, q, bp, lane, acc);
+        if constexpr (K2 > 0) mfma_source_f16<K2, NT, MT>(reinterpret_cast<const half_t*>(a.in2), rows, q, bp + (size_t)S1 * NT * 64, lane, acc);
+    } else {
+        mfma_source<K1, NT, MT>(a.in1, rows, q, bp, lane, acc);
+        if constexpr (K2 > 0) mfma_source<K2, NT, MT>(a.in2, rows, q, bp + (size_t)S1 * NT * 64, lane, acc);
+    }
 
     // epilogue: lane holds column c = nt*16 + r of rows row0 + mt*16 + 4q + reg
 #pragma unroll
@@ -104,11 +151,11 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwArgs a)
                 const long row = row0 + mt * 16 + 4 * q + reg;
                 if (row >= a.npix) continue;
                 float v = acc[mt][nt][reg] + bias;
-                if constexpr (RES) v += a.res[row * N + c];
+                if constexpr (RES) v += ld1<T>(reinterpret_cast<const T*>(a.res) + row * N + c);
                 if constexpr (RELU) v = fmaxf(v, 0.f);
                 if constexpr (OMODE == 0) {
-                    a.out[row * N + c] = v;
-                } else if constexpr (OMODE == 1) {  // NCHW (the heads)
+                    st1<T>(reinterpret_cast<T*>(a.out) + row * N + c, v);
+                } else if constexpr (OMODE == 1) {  // NCHW (the heads): always fp32, the reference's output
                     const long n = row / a.HW, hw = row - n * a.HW;
                     a.out[(n * N + c) * a.HW + hw] = v;
                 } else {  // ConvTranspose2d k=2 s=2: quadrant (dy,dx) -> pixel (2y+dy, 2x+dx)
@@ -116,7 +163,7 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwArgs a)
                     const int y = (int)(hw / a.W), x = (int)(hw - (long)y * a.W);
                     const int dy = blockIdx.z >> 1, dx = blockIdx.z & 1;
                     const long opix = (n * (2 * (a.HW / a.W)) + 2 * y + dy) * (2 * a.W) + 2 * x + dx;
-                    a.out[opix * N + c] = v;
+                    st1<T>(reinterpret_cast<T*>(a.out) + opix * N + c, v);
                 }
             }
         }
@@ -124,11 +171,12 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwArgs a)
 }
 
 template <int K1, int K2, int N, int MT, bool RELU, bool RES, int OMODE>
-static int launch_t(const PwArgs& a, hipStream_t s)
+static int launch_t(const PwArgs& a, hipStream_t s, int dtype)
 {
     const long waves = (a.npix + 16 * MT - 1) / (16 * MT);
     dim3 grid((unsigned)((waves + 3) / 4), 1, OMODE == 2 ? 4 : 1);
-    hipLaunchKernelGGL((pw_mfma_kernel<K1, K2, N, MT, RELU, RES, OMODE>), grid, dim3(256), 0, s, a);
+    if (dtype == DT_F16) hipLaunchKernelGGL((pw_mfma_kernel<K1, K2, N, MT, RELU, RES, OMODE, half_t>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((pw_mfma_kernel<K1, K2, N, MT, RELU, RES, OMODE, float>), grid, dim3(256), 0, s, a);
     return 0;
 }
 
@@ -149,11 +197,11 @@ static int launch_t(const PwArgs& a, hipStream_t s)
     MF(96, 0, 96, 2, false, false, 0)    /* conv4_1_3, conv4_1_5 */                    \
     MF(96, 0, 24, 2, false, false, 1)    /* head_4  (NCHW) */
 
-int launch_pw_mfma(int cin1, int cin2, int cout, bool relu_, bool res_, int omode, const PwArgs& a, hipStream_t s)
+int launch_pw_mfma(int cin1, int cin2, int cout, bool relu_, bool res_, int omode, const PwArgs& a, hipStream_t s, int dtype)
 {
 #define MF(k1, k2, n, mt, relu, res, om)                                                        \
     if (cin1 == k1 && cin2 == k2 && cout == n && relu_ == relu && res_ == res && omode == om)    \
-        return launch_t<k1, k2, n, mt, relu, res, om>(a, s);
+        return launch_t<k1, k2, n, mt, relu, res, om>(a, s, dtype);
     YF_MFMA_SHAPES(MF)
 #undef MF
     return -1;
@@ -171,6 +219,55 @@ bool mfma_has_kernel(int cin1, int cin2, int cout, bool relu_, bool res_, int om
 // Host-side packing of W[K][N] (row-major, as in the blob) into MFMA B fragments, see the file header.
 //   out[(step*NT + nt)*64 + lane] = W[kidx(step, lane>>4)][nt*16 + (lane&15)]   (0 beyond N)
 // Sources of a concat are packed one after the other (K = K1 + K2 rows of W).
+// IEEE fp32 -> fp16 bits, round to nearest even (what v_cvt_f16_f32 does), on the host
+uint16_t f32_to_f16_bits(float f)
+{
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));   // nan / inf
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                                    // overflows to inf after rounding
+    if (x < 0x33000001u) return (uint16_t)sign;                                                 // underflows to zero
+    if (x < 0x38800000u) {                                                                      // subnormal half
+        const int shift = 126 - (int)(x >> 23);   // 14 .. 24
+        uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        uint32_t r = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (r & 1u))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = ((x - 0x38000000u) >> 13), rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;
+    return (uint16_t)(sign | r);
+}
+
+size_t mfma_packed_floats_f16(int k1, int k2, int n) { return (size_t)2 * (kmfmas16(k1) + (k2 ? kmfmas16(k2) : 0)) * ((n + 15) / 16) * 64; }
+
+// fp16 B fragments: out16[((blk*NT + nt)*64 + lane)*4 + j] = half(W[kbase + blk*16 + (blk < NB ? 4 : 2)*q + j][nt*16 + (lane&15)]), j beyond the block = 0
+void mfma_pack_weights_f16(const float* w, int k1, int k2, int n, float* out)
+{
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(out);
+    const int NT = (n + 15) / 16;
+    size_t blk = 0;
+    int kbase = 0;
+    for (int src = 0; src < 2; ++src) {
+        const int K = src == 0 ? k1 : k2;
+        if (K == 0) continue;
+        const int NB = K / 16, NK = kmfmas16(K);
+        for (int kb = 0; kb < NK; ++kb, ++blk) {
+            const int per = kb < NB ? 4 : 2;
+            for (int nt = 0; nt < NT; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        const int q = lane >> 4, c = nt * 16 + (lane & 15);
+                        const int k = kbase + kb * 16 + per * q + j;
+                        o16[((blk * NT + nt) * 64 + lane) * 4 + j] = (j < per && c < n) ? f32_to_f16_bits(w[(size_t)k * n + c]) : 0;
+                    }
+        }
+        kbase += K;
+    }
+}
+
 size_t mfma_packed_floats(int k1, int k2, int n) { return (size_t)(ksteps(k1) + (k2 ? ksteps(k2) : 0)) * ((n + 15) / 16) * 64; }
 
 void mfma_pack_weights(const float* w, int k1, int k2, int n, float* out)

@@ -27,12 +27,13 @@ namespace yf {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ constexpr int mres_ksteps(int K) { return (K / 16) * 4 + ((K % 16) ? 2 : 0); }
-__host__ __device__ constexpr int mres_chunk_floats(int cin, int cout)
+__host__ __device__ constexpr int mres_chunk_floats(int cin, int cout, bool h16 = false)
 {
-    return mres_ksteps(cin) * 64 + 16 + 9 * 16 + 16 + 4 * ((cout + 15) / 16) * 64;
+    return h16 ? ((mres_ksteps(cin) + 3) / 4) * 128 + 16 + 9 * 16 + 16 + ((cout + 15) / 16) * 128
+               : mres_ksteps(cin) * 64 + 16 + 9 * 16 + 16 + 4 * ((cout + 15) / 16) * 64;
 }
 
-template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWAVE>
+template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWAVE, typename T>
 __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
 {
     constexpr int RH = TH + 2, RW = TW + 2, NRP = RH * RW;
@@ -40,12 +41,14 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
     constexpr int MTRW = (MTR + NWAVE - 1) / NWAVE, MTOW = (MTO + NWAVE - 1) / NWAVE;
     constexpr int XP = CIN + 4;                           // X row pitch: conflict-free b128/b64 fragment reads
     constexpr int EPL = ((MTR * 16 + 7) / 8) * 8 + 1;     // pixels per 4-channel plane, == 1 (mod 8): conflict-free writes
+    constexpr bool H16 = sizeof(T) == 2;  // fp16 storage: the pointwise GEMMs run on v_mfma_f32_16x16x16_f16 (4 k-steps each)
     constexpr int KS1 = mres_ksteps(CIN), NB1 = CIN / 16, NT2 = (COUT + 15) / 16, NCH = (CEXP + 15) / 16;
-    constexpr int OFF_B1 = KS1 * 64, OFF_WD = OFF_B1 + 16, OFF_BD = OFF_WD + 144, OFF_W2 = OFF_BD + 16;
-    constexpr int CHUNK = OFF_W2 + 4 * NT2 * 64;
+    constexpr int NK1 = (KS1 + 3) / 4;    // f16 MFMAs per expansion tile
+    constexpr int OFF_B1 = H16 ? NK1 * 128 : KS1 * 64, OFF_WD = OFF_B1 + 16, OFF_BD = OFF_WD + 144, OFF_W2 = OFF_BD + 16;
+    constexpr int CHUNK = OFF_W2 + (H16 ? NT2 * 128 : 4 * NT2 * 64);
     static_assert((TH * TW) % 16 == 0 && CIN % 8 == 0 && COUT % 4 == 0, "shape");
     static_assert(!RES || CIN == COUT, "residual needs same shape");
-    static_assert(CHUNK == mres_chunk_floats(CIN, COUT), "pack layout");
+    static_assert(CHUNK == mres_chunk_floats(CIN, COUT, H16), "pack layout");
     static_assert(MTRW * 4 <= 32, "in-image mask bits");
     extern __shared__ __attribute__((aligned(16))) float mres_smem[];
     float* X = mres_smem;                 // [MTR*16][XP]
@@ -65,14 +68,14 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
     // ---- stage the halo'd input tile (zeros outside the image / beyond the region) ----
     {
         constexpr int C4 = CIN / 4;
-        const float* __restrict__ src = a.in + (long)n * a.H * a.W * CIN;
+        const T* __restrict__ src = reinterpret_cast<const T*>(a.in) + (long)n * a.H * a.W * CIN;
         for (int idx = threadIdx.x; idx < MTR * 16 * C4; idx += NWAVE * 64) {
             const int rp = idx / C4, c4 = idx - rp * C4;
             const int ry = rp / RW, rx = rp - ry * RW;
             const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (rp < NRP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                v = *reinterpret_cast<const float4*>(src + ((long)iy * a.W + ix) * CIN + c4 * 4);
+                v = ld4<T>(src + ((long)iy * a.W + ix) * CIN + c4 * 4);
             *reinterpret_cast<float4*>(&X[rp * XP + c4 * 4]) = v;
         }
     }
@@ -119,18 +122,30 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
     for (int c = 0; c < NCH; ++c) {
         const float* wc = WL + c * CHUNK;
         float w1f[KS1];
+        f16x4 w1h[NK1];
+        if constexpr (H16) {
 #pragma unroll
-        for (int s = 0; s < KS1; ++s) w1f[s] = wc[s * 64 + lane];
+            for (int s = 0; s < NK1; ++s) w1h[s] = reinterpret_cast<const f16x4*>(wc)[s * 64 + lane];
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) w1f[s] = wc[s * 64 + lane];
+        }
         const float b1 = wc[OFF_B1 + r];
         float4 wd[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) wd[t] = *reinterpret_cast<const float4*>(wc + OFF_WD + t * 16 + 4 * q);
         const float4 bd = *reinterpret_cast<const float4*>(wc + OFF_BD + 4 * q);
         float w2f[4][NT2];
+        f16x4 w2h[NT2];
+        if constexpr (H16) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int nt = 0; nt < NT2; ++nt) w2h[nt] = reinterpret_cast<const f16x4*>(wc + OFF_W2)[nt * 64 + lane];
+        } else {
 #pragma unroll
-            for (int nt = 0; nt < NT2; ++nt) w2f[j][nt] = wc[OFF_W2 + (j * NT2 + nt) * 64 + lane];
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nt = 0; nt < NT2; ++nt) w2f[j][nt] = wc[OFF_W2 + (j * NT2 + nt) * 64 + lane];
+        }
 
         // ---- expand: E[ch r][pixels mt*16 + 4q .. +3] ----
 #pragma unroll
@@ -138,8 +153,17 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
             const int mt = wave + i * NWAVE;
             if (mt < MTR) {
                 f32x4 cf = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (H16) {
 #pragma unroll
-                for (int s = 0; s < KS1; ++s) cf = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][s], w1f[s], cf, 0, 0, 0);
+                    for (int s = 0; s < NK1; ++s) {
+                        const f16x4 ah = f16x4{(half_t)a1[i][4 * s], (half_t)a1[i][4 * s + 1], 4 * s + 2 < KS1 ? (half_t)a1[i][(4 * s + 2) % KS1] : (half_t)0.f,
+                                               4 * s + 3 < KS1 ? (half_t)a1[i][(4 * s + 3) % KS1] : (half_t)0.f};
+                        cf = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, w1h[s], cf, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < KS1; ++s) cf = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][s], w1f[s], cf, 0, 0, 0);
+                }
                 float* dst = E + ((r >> 2) * EPL + mt * 16 + 4 * q) * 4 + (r & 3);  // channel r of pixels 4q..4q+3
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg)
@@ -165,12 +189,18 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                         d[2] = fmaf(v.z, w.z, d[2]);
                         d[3] = fmaf(v.w, w.w, d[3]);
                     }
+                if constexpr (H16) {
+                    const f16x4 dh = f16x4{(half_t)fmaxf(d[0], 0.f), (half_t)fmaxf(d[1], 0.f), (half_t)fmaxf(d[2], 0.f), (half_t)fmaxf(d[3], 0.f)};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float dj = fmaxf(d[j], 0.f);
+                    for (int nt = 0; nt < NT2; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(dh, w2h[nt], acc[i][nt], 0, 0, 0);
+                } else {
 #pragma unroll
-                    for (int nt = 0; nt < NT2; ++nt)
-                        acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dj, w2f[j][nt], acc[i][nt], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) {
+                        const float dj = fmaxf(d[j], 0.f);
+#pragma unroll
+                        for (int nt = 0; nt < NT2; ++nt)
+                            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dj, w2f[j][nt], acc[i][nt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -196,7 +226,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                 if (gy >= a.H || gx >= a.W) continue;
                 float v = acc[i][nt][reg] + bias;
                 if constexpr (RES) v += X[((oy + 1) * RW + ox + 1) * XP + col];
-                a.out[(((long)n * a.H + gy) * a.W + gx) * COUT + col] = v;
+                st1<T>(reinterpret_cast<T*>(a.out) + (((long)n * a.H + gy) * a.W + gx) * COUT + col, v);
             }
         }
     }
@@ -209,7 +239,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
 // two.  The two roles run in different branches of a wave-uniform condition (disjoint register live ranges); both execute
 // exactly NCH + 1 barriers.
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NWC>
+template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NWC, typename T>
 __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
 {
     constexpr int NWAVE = NWP + NWC;
@@ -218,9 +248,11 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
     constexpr int MTRW = (MTR + NWP - 1) / NWP, MTOW = (MTO + NWC - 1) / NWC;
     constexpr int XP = CIN + 4;
     constexpr int EPL = ((MTR * 16 + 7) / 8) * 8 + 1;
+    constexpr bool H16 = sizeof(T) == 2;  // fp16 storage: the pointwise GEMMs run on v_mfma_f32_16x16x16_f16 (4 k-steps each)
     constexpr int KS1 = mres_ksteps(CIN), NB1 = CIN / 16, NT2 = (COUT + 15) / 16, NCH = (CEXP + 15) / 16;
-    constexpr int OFF_B1 = KS1 * 64, OFF_WD = OFF_B1 + 16, OFF_BD = OFF_WD + 144, OFF_W2 = OFF_BD + 16;
-    constexpr int CHUNK = OFF_W2 + 4 * NT2 * 64;
+    constexpr int NK1 = (KS1 + 3) / 4;    // f16 MFMAs per expansion tile
+    constexpr int OFF_B1 = H16 ? NK1 * 128 : KS1 * 64, OFF_WD = OFF_B1 + 16, OFF_BD = OFF_WD + 144, OFF_W2 = OFF_BD + 16;
+    constexpr int CHUNK = OFF_W2 + (H16 ? NT2 * 128 : 4 * NT2 * 64);
     static_assert((TH * TW) % 16 == 0 && CIN % 8 == 0 && COUT % 4 == 0, "shape");
     static_assert(!RES || CIN == COUT, "residual needs same shape");
     static_assert(MTRW * 4 <= 64, "in-image mask bits");
@@ -240,14 +272,14 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
         *reinterpret_cast<float4*>(&WL[i]) = *reinterpret_cast<const float4*>(a.wp + i);
     {
         constexpr int C4 = CIN / 4;
-        const float* __restrict__ src = a.in + (long)n * a.H * a.W * CIN;
+        const T* __restrict__ src = reinterpret_cast<const T*>(a.in) + (long)n * a.H * a.W * CIN;
         for (int idx = threadIdx.x; idx < MTR * 16 * C4; idx += NWAVE * 64) {
             const int rp = idx / C4, c4 = idx - rp * C4;
             const int ry = rp / RW, rx = rp - ry * RW;
             const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (rp < NRP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                v = *reinterpret_cast<const float4*>(src + ((long)iy * a.W + ix) * CIN + c4 * 4);
+                v = ld4<T>(src + ((long)iy * a.W + ix) * CIN + c4 * 4);
             *reinterpret_cast<float4*>(&X[rp * XP + c4 * 4]) = v;
         }
     }
@@ -284,16 +316,32 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
                 const float* wc = WL + s * CHUNK;
                 float* Eb = E + (s & 1) * 16 * EPL;
                 float w1f[KS1];
+                f16x4 w1h[NK1];
+                if constexpr (H16) {
 #pragma unroll
-                for (int k = 0; k < KS1; ++k) w1f[k] = wc[k * 64 + lane];
+                    for (int k = 0; k < NK1; ++k) w1h[k] = reinterpret_cast<const f16x4*>(wc)[k * 64 + lane];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < KS1; ++k) w1f[k] = wc[k * 64 + lane];
+                }
                 const float b1 = wc[OFF_B1 + r];
 #pragma unroll
                 for (int i = 0; i < MTRW; ++i) {
                     const int mt = wave + i * NWP;
                     if (mt < MTR) {
                         f32x4 cf = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if constexpr (H16) {
 #pragma unroll
-                        for (int k = 0; k < KS1; ++k) cf = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][k], w1f[k], cf, 0, 0, 0);
+                            for (int k = 0; k < NK1; ++k) {
+                                const f16x4 ah = f16x4{(half_t)a1[i][4 * k], (half_t)a1[i][4 * k + 1],
+                                                       4 * k + 2 < KS1 ? (half_t)a1[i][(4 * k + 2) % KS1] : (half_t)0.f,
+                                                       4 * k + 3 < KS1 ? (half_t)a1[i][(4 * k + 3) % KS1] : (half_t)0.f};
+                                cf = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, w1h[k], cf, 0, 0, 0);
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < KS1; ++k) cf = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][k], w1f[k], cf, 0, 0, 0);
+                        }
                         float* dst = Eb + ((r >> 2) * EPL + mt * 16 + 4 * q) * 4 + (r & 3);
 #pragma unroll
                         for (int reg = 0; reg < 4; ++reg)
@@ -327,10 +375,16 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
                 for (int t = 0; t < 9; ++t) wd[t] = *reinterpret_cast<const float4*>(wc + OFF_WD + t * 16 + 4 * q);
                 const float4 bd = *reinterpret_cast<const float4*>(wc + OFF_BD + 4 * q);
                 float w2f[4][NT2];
+                f16x4 w2h[NT2];
+                if constexpr (H16) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                    for (int nt = 0; nt < NT2; ++nt) w2h[nt] = reinterpret_cast<const f16x4*>(wc + OFF_W2)[nt * 64 + lane];
+                } else {
 #pragma unroll
-                    for (int nt = 0; nt < NT2; ++nt) w2f[j][nt] = wc[OFF_W2 + (j * NT2 + nt) * 64 + lane];
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int nt = 0; nt < NT2; ++nt) w2f[j][nt] = wc[OFF_W2 + (j * NT2 + nt) * 64 + lane];
+                }
 #pragma unroll
                 for (int i = 0; i < MTOW; ++i) {
                     const int mo = cw + i * NWC;
@@ -346,12 +400,20 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
                                 d[0] = fmaf(v.x, w.x, d[0]); d[1] = fmaf(v.y, w.y, d[1]);
                                 d[2] = fmaf(v.z, w.z, d[2]); d[3] = fmaf(v.w, w.w, d[3]);
                             }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float dj = fmaxf(d[j], 0.f);
+                        if constexpr (H16) {
+                            const f16x4 dh = f16x4{(half_t)fmaxf(d[0], 0.f), (half_t)fmaxf(d[1], 0.f), (half_t)fmaxf(d[2], 0.f),
+                                                   (half_t)fmaxf(d[3], 0.f)};
 #pragma unroll
                             for (int nt = 0; nt < NT2; ++nt)
-                                acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dj, w2f[j][nt], acc[i][nt], 0, 0, 0);
+                                acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(dh, w2h[nt], acc[i][nt], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float dj = fmaxf(d[j], 0.f);
+#pragma unroll
+                                for (int nt = 0; nt < NT2; ++nt)
+                                    acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dj, w2f[j][nt], acc[i][nt], 0, 0, 0);
+                            }
                         }
                     }
                 }
@@ -376,51 +438,51 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
                     if (gy >= a.H || gx >= a.W) continue;
                     float v = acc[i][nt][reg] + bias;
                     if constexpr (RES) v += X[((oy + 1) * RW + ox + 1) * XP + col];
-                    a.out[(((long)n * a.H + gy) * a.W + gx) * COUT + col] = v;
+                    st1<T>(reinterpret_cast<T*>(a.out) + (((long)n * a.H + gy) * a.W + gx) * COUT + col, v);
                 }
             }
         }
     }
 }
 
-template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NWC>
+template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NWC, typename T>
 static int launch_mres_pc_t(MresArgs a, int N, hipStream_t s)
 {
     a.tiles_y = (a.H + TH - 1) / TH;
     a.tiles_x = (a.W + TW - 1) / TW;
     constexpr int MTR = ((TH + 2) * (TW + 2) + 15) / 16;
     constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 2 * 16 * (((MTR * 16 + 7) / 8) * 8 + 1) +
-                            ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT) + COUT + 3) & ~3)) * sizeof(float);
+                            ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT, sizeof(T) == 2) + COUT + 3) & ~3)) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done = false;
     if (lds > 64 * 1024 && !attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, T>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
         attr_done = true;
     }
-    hipLaunchKernelGGL((mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC>), dim3((unsigned)(N * a.tiles_y * a.tiles_x)),
+    hipLaunchKernelGGL((mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, T>), dim3((unsigned)(N * a.tiles_y * a.tiles_x)),
                        dim3((NWP + NWC) * 64), lds, s, a);
     return 0;
 }
 
-template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWAVE>
+template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWAVE, typename T>
 static int launch_mres_t(MresArgs a, int N, hipStream_t s)
 {
     a.tiles_y = (a.H + TH - 1) / TH;
     a.tiles_x = (a.W + TW - 1) / TW;
     constexpr int MTR = ((TH + 2) * (TW + 2) + 15) / 16;
     constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 16 * (((MTR * 16 + 7) / 8) * 8 + 1) +
-                            ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT) + COUT + 3) & ~3)) * sizeof(float);
+                            ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT, sizeof(T) == 2) + COUT + 3) & ~3)) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done = false;
     if (lds > 64 * 1024 && !attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mres_kernel<CIN, CEXP, COUT, RES, TH, TW, NWAVE>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mres_kernel<CIN, CEXP, COUT, RES, TH, TW, NWAVE, T>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
         attr_done = true;
     }
-    hipLaunchKernelGGL((mres_kernel<CIN, CEXP, COUT, RES, TH, TW, NWAVE>), dim3((unsigned)(N * a.tiles_y * a.tiles_x)),
+    hipLaunchKernelGGL((mres_kernel<CIN, CEXP, COUT, RES, TH, TW, NWAVE, T>), dim3((unsigned)(N * a.tiles_y * a.tiles_x)),
                        dim3(NWAVE * 64), lds, s, a);
     return 0;
 }
@@ -434,17 +496,19 @@ static int launch_mres_t(MresArgs a, int N, hipStream_t s)
     MR(24, 136, 24, true, 16, 20, 6, 10) /* res4_1 .. res4_4         @ H/16 */         \
     MR(48, 224, 48, true, 8, 10, 4, 5)   /* res5_1 .. res5_5         @ H/32 */
 
-template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NW>
+template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NW, typename T>
 static int launch_mres_any(const MresArgs& a, int N, hipStream_t s)
 {
-    if constexpr (NWP == 0) return launch_mres_t<CIN, CEXP, COUT, RES, TH, TW, NW>(a, N, s);
-    else return launch_mres_pc_t<CIN, CEXP, COUT, RES, TH, TW, NWP, NW>(a, N, s);
+    if constexpr (NWP == 0) return launch_mres_t<CIN, CEXP, COUT, RES, TH, TW, NW, T>(a, N, s);
+    else return launch_mres_pc_t<CIN, CEXP, COUT, RES, TH, TW, NWP, NW, T>(a, N, s);
 }
 
-int launch_mres(int cin, int cexp, int cout, bool res, const MresArgs& a, int N, hipStream_t s)
+int launch_mres(int cin, int cexp, int cout, bool res, const MresArgs& a, int N, hipStream_t s, int dtype)
 {
-#define MR(ci, ce, co, rs, th, tw, np, nw) \
-    if (cin == ci && cexp == ce && cout == co && res == rs) return launch_mres_any<ci, ce, co, rs, th, tw, np, nw>(a, N, s);
+#define MR(ci, ce, co, rs, th, tw, np, nw)                                                                        \
+    if (cin == ci && cexp == ce && cout == co && res == rs)                                                       \
+        return dtype == DT_F16 ? launch_mres_any<ci, ce, co, rs, th, tw, np, nw, half_t>(a, N, s)                  \
+                               : launch_mres_any<ci, ce, co, rs, th, tw, np, nw, float>(a, N, s);
     YF_MRES_SHAPES(MR)
 #undef MR
     return -1;
@@ -460,24 +524,38 @@ bool mres_has_kernel(int cin, int cexp, int cout, bool res)
 }
 
 // Host-side weight stream of one block: NCH chunks of [W1 frags | b1 | wd 9x16 | bd | W2 frags], then b2.
-size_t mres_packed_floats(int cin, int cexp, int cout) { return (((size_t)((cexp + 15) / 16) * mres_chunk_floats(cin, cout) + cout) + 3) & ~(size_t)3; }
+// h16: the fragments are f16x4 per lane (one v_mfma_f32_16x16x16_f16 per 4 k-steps); b1 / wd / bd / b2 stay fp32.
+size_t mres_packed_floats(int cin, int cexp, int cout, bool h16)
+{
+    return (((size_t)((cexp + 15) / 16) * mres_chunk_floats(cin, cout, h16) + cout) + 3) & ~(size_t)3;
+}
 
 void mres_pack_weights(const float* w1 /*[cin][cexp]*/, const float* b1, const float* wd /*[9][cexp]*/, const float* bd,
-                       const float* w2 /*[cexp][cout]*/, const float* b2, int cin, int cexp, int cout, float* out)
+                       const float* w2 /*[cexp][cout]*/, const float* b2, int cin, int cexp, int cout, float* out, bool h16)
 {
-    const int KS1 = mres_ksteps(cin), NB1 = cin / 16, NT2 = (cout + 15) / 16, NCH = (cexp + 15) / 16;
-    const int CH = mres_chunk_floats(cin, cout);
+    const int KS1 = mres_ksteps(cin), NB1 = cin / 16, NK1 = (KS1 + 3) / 4, NT2 = (cout + 15) / 16, NCH = (cexp + 15) / 16;
+    const int CH = mres_chunk_floats(cin, cout, h16);
     for (int c = 0; c < NCH; ++c) {
         float* o = out + (size_t)c * CH;
         auto ch_ok = [&](int ch) { return c * 16 + ch < cexp; };
-        for (int s = 0; s < KS1; ++s)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int q = lane >> 4, nn = lane & 15;
-                const int kb = s / 4, j = s % 4;
-                const int k = kb < NB1 ? kb * 16 + 4 * q + j : NB1 * 16 + 2 * q + j;  // trailing 8-block: j in {0,1}
-                o[s * 64 + lane] = ch_ok(nn) ? w1[(size_t)k * cexp + c * 16 + nn] : 0.f;
-            }
-        o += KS1 * 64;
+        auto w1_at = [&](int s, int lane) -> float {  // k-step s of the fp32 scheme, lane (q, n)
+            const int q = lane >> 4, nn = lane & 15;
+            const int kb = s / 4, j = s % 4;
+            if (s >= KS1) return 0.f;
+            const int k = kb < NB1 ? kb * 16 + 4 * q + j : NB1 * 16 + 2 * q + j;  // trailing 8-block: j in {0,1}
+            return ch_ok(nn) ? w1[(size_t)k * cexp + c * 16 + nn] : 0.f;
+        };
+        if (h16) {
+            uint16_t* o16 = reinterpret_cast<uint16_t*>(o);
+            for (int m = 0; m < NK1; ++m)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) o16[(m * 64 + lane) * 4 + j] = f32_to_f16_bits(w1_at(4 * m + j, lane));
+            o += NK1 * 128;
+        } else {
+            for (int s = 0; s < KS1; ++s)
+                for (int lane = 0; lane < 64; ++lane) o[s * 64 + lane] = w1_at(s, lane);
+            o += KS1 * 64;
+        }
         for (int ch = 0; ch < 16; ++ch) o[ch] = ch_ok(ch) ? b1[c * 16 + ch] : 0.f;
         o += 16;
         for (int t = 0; t < 9; ++t)
@@ -485,12 +563,20 @@ void mres_pack_weights(const float* w1 /*[cin][cexp]*/, const float* b1, const f
         o += 144;
         for (int ch = 0; ch < 16; ++ch) o[ch] = ch_ok(ch) ? bd[c * 16 + ch] : 0.f;
         o += 16;
-        for (int j = 0; j < 4; ++j)
+        auto w2_at = [&](int j, int nt, int lane) -> float {
+            const int q = lane >> 4, nn = nt * 16 + (lane & 15), ch = 4 * q + j;
+            return (ch_ok(ch) && nn < cout) ? w2[(size_t)(c * 16 + ch) * cout + nn] : 0.f;
+        };
+        if (h16) {
+            uint16_t* o16 = reinterpret_cast<uint16_t*>(o);
             for (int nt = 0; nt < NT2; ++nt)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int q = lane >> 4, nn = nt * 16 + (lane & 15), ch = 4 * q + j;
-                    o[(j * NT2 + nt) * 64 + lane] = (ch_ok(ch) && nn < cout) ? w2[(size_t)(c * 16 + ch) * cout + nn] : 0.f;
-                }
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) o16[(nt * 64 + lane) * 4 + j] = f32_to_f16_bits(w2_at(j, nt, lane));
+        } else {
+            for (int j = 0; j < 4; ++j)
+                for (int nt = 0; nt < NT2; ++nt)
+                    for (int lane = 0; lane < 64; ++lane) o[(j * NT2 + nt) * 64 + lane] = w2_at(j, nt, lane);
+        }
     }
     for (int i = 0; i < cout; ++i) out[(size_t)NCH * CH + i] = b2[i];
 }

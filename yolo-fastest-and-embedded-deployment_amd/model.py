@@ -36,11 +36,12 @@ def _container(kind, cin, cout, k, stride, relu):
 class _Engine:
     """One yf_handle (+ its workspace) for a given (H, W, device)."""
 
-    def __init__(self, blob, H, W, max_batch, device_index):
+    def __init__(self, blob, H, W, max_batch, device_index, dtype=0):
         self.lib = _lib.lib()
         self.handle = ctypes.c_void_p()
         buf = ctypes.create_string_buffer(blob, len(blob))
-        _lib.check(self.lib.yf_create(buf, len(blob), H, W, max_batch, device_index, ctypes.byref(self.handle)))
+        _lib.check(self.lib.yf_create_ex(buf, len(blob), H, W, max_batch, device_index, dtype, ctypes.byref(self.handle)))
+        self.dtype = dtype
         self.H, self.W, self.max_batch, self.device_index = H, W, max_batch, device_index
         self._ws = None
 
@@ -102,6 +103,10 @@ class YoloFastest(nn.Module):
         self.chunk = 0  # frames per pass of the layer chain (0 = whole batch); see yf_set_chunk
         self.fusion = 1  # 1 = block-fused kernels (default); 0 = one launch per layer (bring-up, all probes)
         self.lanes = 2   # concurrent streams over chunks of the batch (chunk 0 = one chunk per lane); see yf_set_lanes
+        # activation storage / pointwise-GEMM operand type: torch.float32, or torch.float16 (BASELINE configs[2]: fp16 in HBM,
+        # fp16 MFMA, fp32 accumulate).  `model.half()` selects fp16 like it would for the reference module; setting
+        # `model.storage_dtype = torch.float16` keeps the fp32 master weights for the BN fold (more accurate).
+        self.storage_dtype = torch.float32
 
     # -- weight packing -------------------------------------------------------------------------
     def _invalidate(self):
@@ -147,8 +152,12 @@ class YoloFastest(nn.Module):
                 m.bias.data.fill_(0)
         self._invalidate()
 
+    def _dtype_code(self):
+        p = self.conv0[0].weight
+        return 1 if (self.storage_dtype == torch.float16 or p.dtype == torch.float16) else 0
+
     def engine(self, H, W, N, device):
-        key = (H, W, device.index if device.index is not None else torch.cuda.current_device())
+        key = (H, W, device.index if device.index is not None else torch.cuda.current_device(), self._dtype_code())
         e = self._engines.get(key)
         if e is None or e.max_batch < N:
             if e is not None:
@@ -156,7 +165,7 @@ class YoloFastest(nn.Module):
             if self._blob is None:
                 self._blob = packer.pack_state_dict(self.state_dict(), self.num_out, self.input_channel,
                                                     self.num_anchors, self.num_cls)
-            e = _Engine(self._blob, H, W, max(N, 256), key[2])
+            e = _Engine(self._blob, H, W, max(N, 256), key[2], key[3])
             if self.chunk:
                 e.set_chunk(self.chunk)
             e.set_lanes(self.lanes)
@@ -172,6 +181,7 @@ class YoloFastest(nn.Module):
             raise RuntimeError("YoloFastest (HIP engine) has no CPU path: move the model and input to the GPU")
         if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] % 32 or x.shape[3] % 32:
             raise ValueError("expected [N,1,H,W] with H and W multiples of 32, got %s" % (tuple(x.shape),))
+        in_dtype = x.dtype
         x = x.contiguous().float()
         N, _, H, W = x.shape
         e = self.engine(H, W, N, x.device)
@@ -181,6 +191,8 @@ class YoloFastest(nn.Module):
         stream = torch.cuda.current_stream(x.device).cuda_stream
         _lib.check(e.lib.yf_forward(e.handle, x.data_ptr(), N, hl.data_ptr(), hs.data_ptr(), ws.data_ptr(), ws.numel(),
                                     ctypes.c_void_p(stream)))
+        if in_dtype == torch.float16:  # a .half() reference module returns half heads
+            return hl.half(), hs.half()
         return hl, hs
 
     def forward_u8(self, u8, input_shape):
