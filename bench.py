@@ -161,7 +161,7 @@ def main():
         ops = model.profile(x, reps=5)
         if args.dump_ops:
             with open(args.dump_ops, "w") as f:
-                json.dump([{"name": o["name"], "algorithmic_bytes": o["algorithmic_bytes"]} for o in ops], f)
+                json.dump([{"name": o["name"], "ms": o["ms"], "algorithmic_bytes": o["algorithmic_bytes"]} for o in ops], f)
         chain_ms = sum(o["ms"] for o in ops)
         dom = max(ops, key=lambda o: o["ms"])
         bytes_sum = sum(o["algorithmic_bytes"] for o in ops) / args.batch

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "yf_fused_kernels.hip"
+#include "yf_k19_kernels.hip"
 #include "yf_mfma_kernels.hip"
 #include "yf_conv_kernels.hip"
 #include "yf_mres_kernels.hip"
@@ -159,7 +160,7 @@ int main(int argc, char** argv)
     }
     if (on("k19")) {
         K19Args a{};
-        a.in = dev_rand((size_t)N * 128 * 160 * 4);
+        a.in = dev_rand((size_t)N * 128 * 160 * 4 + 8192) + 4096;  // k19m reads a guard band around its input
         a.w8 = dev_rand(96, 0.3f); a.b8 = dev_rand(24, 0.1f); a.w9 = dev_rand(9 * 24 * 24, 0.1f); a.b9 = dev_rand(24, 0.1f);
         a.w21 = dev_rand(24 * 8, 0.2f); a.b21 = dev_rand(8, 0.1f);
         float* out; CK(hipMalloc(&out, (size_t)N * 64 * 80 * 8 * 4)); a.out = out;
@@ -168,6 +169,24 @@ int main(int argc, char** argv)
         a.tiles_y = 4; a.tiles_x = 5;
         float us = time_us([&] { hipLaunchKernelGGL(k19_kernel<float>, dim3(N * 20), dim3(256), 0, 0, a); });
         printf("k19 1 px/lane  16x16 tile   %8.1f us  %6.2f TMAC/s\n", us, macs / us * 1e-6);
+        // matrix-core version (random fragments: timing only)
+        a.wp = dev_rand(k19_packed_floats(false) + 64, 0.1f);
+        a.tiles_y = 8; a.tiles_x = 5; a.n_frames = N;
+        auto run = [&](auto kern, int dt, unsigned grid, const char* tag) {
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k19m_lds_bytes(dt)));
+            float t = time_us([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), k19m_lds_bytes(dt), 0, a); });
+            printf("k19m %-28s grid %4u %8.1f us  %6.2f TMAC/s\n", tag, grid, t, macs / t * 1e-6);
+        };
+        for (unsigned grid : {128u, 256u, 512u}) {
+            run(&k19m_kernel<float, 0>, DT_F32, grid, "f32");
+            run(&k19m_kernel<half_t, 0>, DT_F16, grid, "f16");
+        }
+        run(&k19m_kernel<float, 1>, DT_F32, 256, "f32 no phase 1");
+        run(&k19m_kernel<float, 2>, DT_F32, 256, "f32 no phase-2 MFMAs");
+        run(&k19m_kernel<float, 3>, DT_F32, 256, "f32 neither");
+        run(&k19m_kernel<half_t, 1>, DT_F16, 256, "f16 no phase 1");
+        run(&k19m_kernel<half_t, 2>, DT_F16, 256, "f16 no phase-2 MFMAs");
+        run(&k19m_kernel<half_t, 3>, DT_F16, 256, "f16 neither");
     }
     if (on("mrespc")) {
         printf("--- MFMA residual blocks, producer/consumer waves ---\n");

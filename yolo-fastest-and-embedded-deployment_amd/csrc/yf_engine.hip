@@ -297,12 +297,15 @@ void build_plan(Plan* e, bool fused)
         }
     }
     e->slot_offset.resize(e->slot_elems.size());
-    size_t off = 0;
+    // guard band before the first and after the last slot: k19m_kernel reads its input without bounds checks, up to one
+    // region row beyond either end of the tensor (the values are discarded); per-frame units, so >= the guard for any batch
+    const size_t guard = fused ? yf::k19m_guard_elems(e->W / 2) : 0;
+    size_t off = guard;
     for (size_t s = 0; s < e->slot_elems.size(); ++s) {
         e->slot_offset[s] = off;
         off += (e->slot_elems[s] + 63) & ~(size_t)63;
     }
-    e->frame_floats = off;
+    e->frame_floats = off + guard;
 }
 
 int chunk_frames(const yf_engine* e, int N)
@@ -397,7 +400,8 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                 a.w8 = W(o.l_exp); a.b8 = B(o.l_exp); a.w9 = W(o.l_dw); a.b9 = B(o.l_dw); a.w21 = W(o.l_proj); a.b21 = B(o.l_proj);
                 a.out = ptr(o.out);
                 a.H = ti.H; a.W = ti.W; a.Ho = to.H; a.Wo = to.W;
-                rc = yf::launch_k19(a, n, s, e->dtype);
+                a.wp = e->d_wmfma + o.mfma_off;
+                rc = yf::launch_k19m(a, n, s, e->dtype);
             } else if (L.kind == K_PW || L.kind == K_HEAD || L.kind == K_DECONV) {
                 yf::PwArgs a{ptr(o.in1), o.in2 >= 0 ? ptr(o.in2) : nullptr, W(o.layer), B(o.layer), o.res >= 0 ? ptr(o.res) : nullptr,
                              ptr(o.out), (long)n * ti.H * ti.W, (long)ti.H * ti.W, ti.W};
@@ -527,6 +531,12 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
                 yf::mres_pack_weights(hw + e->w_off[o.l_exp], hw + e->b_off[o.l_exp], hw + e->w_off[o.l_dw], hw + e->b_off[o.l_dw],
                                       hw + e->w_off[o.l_proj], hw + e->b_off[o.l_proj], LE.cin, LE.cout, LP.cout,
                                       packed.data() + o.mfma_off, h16);
+                continue;
+            }
+            if (o.type == OP_K19) {
+                o.mfma_off = (long)packed.size();
+                packed.resize(packed.size() + ((yf::k19_packed_floats(h16) + 63) & ~(size_t)63));
+                yf::k19_pack_weights(hw + e->w_off[o.l_dw], hw + e->w_off[o.l_proj], packed.data() + o.mfma_off, h16);
                 continue;
             }
             if (o.type == OP_FUSED_BLOCK) {

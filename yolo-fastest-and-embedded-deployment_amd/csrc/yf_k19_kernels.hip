@@ -1,0 +1,327 @@
+// yf_k19_kernels.hip -- conv1_8 (pw 4->24, ReLU) -> conv1_9 (dense 3x3 stride 2 pad 1, 24->24, ReLU) -> conv2_1 (pw 24->8,
+// linear) in one launch, the dense 3x3 on the matrix cores.            (reference: src/model_training/model/yolo_fastest.py:86-89)
+//
+// conv1_9 is 22 % of the network's MACs: an implicit GEMM  D[cout][pixel] = sum_k W[cout][k] X[k][pixel]  with k = (tap, cin),
+// K = 9 x 24 = 216.  The VALU version (k19_kernel, yf_fused_kernels.hip) runs at ~30 TMAC/s (250 us for 256 frames); this one
+// at 37 TMAC/s fp32 (200 us) and 80 us with fp16 storage:
+//   * a persistent workgroup (512 threads: 8 waves, two per SIMD, one output row each) per CU walks over 8x16-pixel output
+//     tiles; two region buffers in LDS (2 x 55 KB fp32), ONE barrier per tile;
+//   * phase 1 (conv1_8 over the tile's 17x33 input region -> LDS, as even-column / odd-column planes of 24-channel records,
+//     so that the 16 pixels of an output row, at a fixed tap, are 16 consecutive records) ALSO runs on the matrix cores (K = 4
+//     is one v_mfma_f32_16x16x4_f32 k-step, the bias is the C operand, the result layout is one 16-byte LDS record write per
+//     lane) and is spread over the k groups of phase 2 of the previous tile; its input elements are requested two tiles ahead;
+//   * phase 2: K is walked in 14 groups of 16 k-values; lane (pixel p = l & 15, j = l >> 4) supplies the 4 consecutive
+//     channels of flat chunk 4 g + j -- ONE ds_read_b128 (fp32: four v_mfma_f32_16x16x4_f32 k-steps, exact fp32) or ONE
+//     ds_read_b64 (fp16: one v_mfma_f32_16x16x16_f16) -- as the B operand; the weights are the A operand and live in registers
+//     for the lifetime of the workgroup (112 VGPRs fp32 / 56 fp16).  24 output channels = 1.5 M-tiles (25 % of the MFMA rows
+//     are padding), 216 = 13.5 groups (the last half group has zero weights);
+//   * epilogue: the accumulator layout (lane: pixel p, channels 16 mt + 4 j + r) IS the B operand of conv2_1's GEMM with the
+//     k-order permuted on the host, so bias + ReLU + conv2_1 stay in registers; lanes j < 2 store 4 channels each.
+// Measured on the way (tools/kbench.hip k19, SQ counters): the fp32 MFMA floor of this shape is 128 us (SQ_VALU_MFMA_BUSY =
+// 32.3 cycles per MFMA, 68 % busy); fp32 MFMAs and VALU instructions do not overlap (each VALU instruction adds its 4 cycles:
+// the fp32 matrix rate equals the packed fp32 vector rate), which is why phase 1 went from VALU (68 us) to MFMA and why its
+// loads carry no address arithmetic; two workgroups per CU with one buffer each run in lockstep and never overlap their
+// phases (offsets between them are neutrally stable), hence the in-wave interleave; LDS strides are padded so that both the
+// reads and phase 1's writes are conflict-free (bank rules of MI355X_MICROARCH.md).
+#include "yf_kernels.h"
+#include <type_traits>
+
+namespace yf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int TH = 8, TW = 16;             // output tile
+constexpr int RH = 2 * TH + 1;             // region rows
+constexpr int RS = 24;                     // record stride in elements
+// plane / row strides in elements: padded so that BOTH the phase-2 reads (b128 / b64 lane groups, 64 banks) and the phase-1
+// writes (8- / 16-lane groups, 32 banks) are conflict-free -- unpadded, the writes are 2.3-way conflicted and the LDS write
+// path, not the VALU, is what phase 1 costs (measured: 47 us of 210)
+constexpr int plane_stride(bool h16) { return 17 * RS + (h16 ? 20 : 4); }
+constexpr int row_stride(bool h16) { return 2 * plane_stride(h16) + (h16 ? 20 : 4); }
+constexpr int NG = 14;                     // k groups
+constexpr int NU = 5;                      // px-tiles of phase 1 per wave (36 over 8 waves)
+constexpr int NCHUNK = 54;                 // 9 taps x 6 chunks of 4 channels
+constexpr int W9_F32 = NG * 4 * 2 * 64, W21_F32 = 2 * 4 * 64;
+constexpr int W9_F16 = NG * 2 * 64 * 2, W21_F16 = 2 * 64 * 2;  // in floats (f16x4 = 2 floats per lane)
+}  // namespace
+
+// DBG (tools/kbench.hip only): 1 = skip phase 1, 2 = skip phase 2's MFMAs
+template <typename TT, int DBG = 0>
+__global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
+{
+    constexpr bool H16 = sizeof(TT) == 2;
+    constexpr int PS = plane_stride(H16), RWS = row_stride(H16);
+    constexpr int BUF = RH * RWS;  // elements per region buffer
+    extern __shared__ __attribute__((aligned(16))) unsigned char k19_smem[];
+    TT* const R = reinterpret_cast<TT*>(k19_smem);  // [2][BUF]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // = the tile's output row this wave owns
+    const int p = lane & 15, j = lane >> 4;
+
+    // ---- weights: registers for the lifetime of the workgroup ----
+    float wf[H16 ? 1 : NG][4][2];
+    f16x4 wh[H16 ? NG : 1][2];
+    float w21f[2][4];
+    f16x4 w21h[2];
+    if constexpr (H16) {
+        const f16x4* w = reinterpret_cast<const f16x4*>(a.wp);
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) wh[g][mt] = w[(g * 2 + mt) * 64 + lane];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) w21h[mt] = reinterpret_cast<const f16x4*>(a.wp + W9_F16)[mt * 64 + lane];
+    } else {
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) wf[g][s][mt] = a.wp[((g * 4 + s) * 2 + mt) * 64 + lane];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w21f[mt][r] = a.wp[W9_F32 + (mt * 4 + r) * 64 + lane];
+    }
+    float bias9[2][4], bias21[4], w8a[2], bias8[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int c = 16 * mt + p;
+        w8a[mt] = c < 24 ? a.w8[j * 24 + c] : 0.f;  // conv1_8's A operand: row = cout, k = cin
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cc = 16 * mt + 4 * j + r;
+            bias9[mt][r] = cc < 24 ? a.b9[cc] : 0.f;
+            bias8[mt][r] = cc < 24 ? a.b8[cc] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias21[r] = j < 2 ? a.b21[4 * j + r] : 0.f;
+
+    // ---- per-lane LDS element offsets (relative to a region buffer) of the 14 B-operand reads of phase 2 ----
+    int adr[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        int fc = 4 * g + j;
+        if (fc >= NCHUNK) fc = 0;  // zero weights there; any finite data will do
+        const int tap = fc / 6, c4 = fc - 6 * tap, ky = tap / 3, kx = tap - 3 * ky;
+        adr[g] = (2 * wave + ky) * RWS + (kx == 1 ? PS : 0) + (p + (kx >> 1)) * RS + c4 * 4;
+    }
+
+    // ---- phase 1 bookkeeping: the wave's px-tiles are wave, wave + 8, .. (NU of them, the last only for waves 0..3) ----
+    // rr: region row | column << 8 of the lane's pixel; vo: element offset of the lane's input element from the region origin;
+    // wo0 / wo1: where the lane's two 4-channel results go.  Lanes without a pixel, and the M-tile-1 lanes whose channels
+    // 24..31 do not exist, write into the unused 17th record of an odd-column plane (one slot per lane: no same-address
+    // serialisation) and load the region origin's element, so phase 1 is branch-free.
+    int rr[NU], wo0[NU], wo1[NU];
+    unsigned vo[NU];
+    {
+        const int dummy = (lane / 6) * RWS + PS + 16 * RS + 4 * (lane % 6);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int pt = wave + 8 * u, q = 16 * pt + p;
+            const bool v = pt < 36 && q < RH * 33;
+            const int ry = v ? q / 33 : 0, rx = v ? q - 33 * ry : 0;
+            rr[u] = v ? (ry | (rx << 8)) : 0xffff;  // 0xffff: never inside any image window
+            vo[u] = (unsigned)((ry * a.W + rx) * 4 + j);
+            const int o = ry * RWS + (rx & 1) * PS + (rx >> 1) * RS + 4 * j;
+            wo0[u] = v ? o : dummy;
+            wo1[u] = (v && j < 2) ? o + 16 : dummy;
+        }
+    }
+
+    const int tiles = a.tiles_y * a.tiles_x;
+    const int total = a.n_frames * tiles;
+    const TT* const in = reinterpret_cast<const TT*>(a.in);
+    float xin[NU];
+    struct Tile { int n, oy0, ox0; };
+    auto decode = [&](int t) {
+        t = min(t, total - 1);  // beyond the end: a harmless repeat of the last tile (its results are never used)
+        const int n = t / tiles, tt = t - n * tiles;
+        const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
+        return Tile{n, ty * TH, tx * TW};
+    };
+    // The region origin (row 2 oy0 - 1, column 2 ox0 - 1) may lie one row / column outside the image, and a partial tile's
+    // region reaches beyond its far edges: the loads are NOT bounds-checked (wave-uniform base + per-lane constant offset, no
+    // address arithmetic on the VALU) -- the engine keeps a guard band around the workspace slots (k19m_guard_elems) and
+    // whatever is read there is replaced by zeros in p1_store.
+    auto origin = [&](const Tile& c) { return in + (((long)c.n * a.H + (2 * c.oy0 - 1)) * a.W + (2 * c.ox0 - 1)) * 4; };
+    auto p1_mfma = [&](int u, f32x4* d) {  // C operand = bias
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+            d[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w8a[mt], xin[u], f32x4{bias8[mt][0], bias8[mt][1], bias8[mt][2], bias8[mt][3]}, 0, 0, 0);
+    };
+    // window of region rows / columns that are inside the image, as one packed compare per axis: inside <=> (unsigned)(r - lo) < n
+    struct Win { bool border; int ylo, yn, xlo, xn; };
+    auto window = [&](const Tile& c) {
+        const int iy0 = 2 * c.oy0 - 1, ix0 = 2 * c.ox0 - 1;
+        const int ylo = max(0, -iy0), yhi = min(RH, a.H - iy0), xlo = max(0, -ix0), xhi = min(33, a.W - ix0);
+        return Win{ylo > 0 || yhi < RH || xlo > 0 || xhi < 33, ylo, yhi - ylo, xlo, xhi - xlo};
+    };
+    auto p1_store = [&](int u, const f32x4* d, TT* buf, const Win& w) {
+        float o[2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[mt][r] = __int_as_float(max(__float_as_int(d[mt][r]), 0));  // ReLU as ONE v_max_i32 (fmaxf costs a canonicalising second op)
+        if (w.border) {  // wave-uniform; zeros outside the image: conv1_9 pads conv1_8's OUTPUT
+            const bool inimg = (unsigned)((rr[u] & 255) - w.ylo) < (unsigned)w.yn && (unsigned)((rr[u] >> 8) - w.xlo) < (unsigned)w.xn;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[mt][r] = inimg ? o[mt][r] : 0.f;
+        }
+        st4<TT>(buf + wo0[u], make_float4(o[0][0], o[0][1], o[0][2], o[0][3]));
+        st4<TT>(buf + wo1[u], make_float4(o[1][0], o[1][1], o[1][2], o[1][3]));
+    };
+
+    int t = blockIdx.x;  // grid <= total
+    const int step = gridDim.x;
+    // ---- prologue: region of the first tile -> buffer 0; input elements of the second tile on their way ----
+    {
+        const Tile c = decode(t);
+        const TT* const o0 = origin(c);
+        const Win w0 = window(c);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) xin[u] = ld1<TT>(o0 + vo[u]);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            f32x4 d[2];
+            p1_mfma(u, d);
+            p1_store(u, d, R, w0);
+        }
+        const TT* const o1 = origin(decode(t + step));
+#pragma unroll
+        for (int u = 0; u < NU; ++u) xin[u] = ld1<TT>(o1 + vo[u]);
+        __syncthreads();
+    }
+
+    int cur = 0;  // element offset of the buffer phase 2 reads
+    for (; t < total; t += step) {
+        const Tile c = decode(t);
+        const Win w1 = window(decode(t + step));              // the tile phase 1 prepares during this iteration
+        long off2 = origin(decode(t + 2 * step)) - in;        // the tile whose input elements are requested during this iteration
+        asm volatile("" : "+s"(off2));  // computed here, once: without this the scalar tile arithmetic is re-done before every load
+        const TT* const o2 = in + off2;
+        const TT* const Rc = R + cur;
+        TT* const Rn = R + (BUF - cur);
+
+        // ---- phase 2 of tile t (conv1_9 on the matrix cores; acc[mt]: channels 16 mt + 4 j + r of the wave's row), with phase 1
+        // of tile t + step spread over its k groups: px-tile u's two MFMAs go out in group 2 u, their results are finished and
+        // stored in group 2 u + 1, and the element of tile t + 2 step that replaces xin[u] is requested right after.  fp32 MFMAs
+        // and VALU instructions do NOT overlap on this part (measured: the two phases' times add up exactly; the fp32 matrix
+        // rate equals the fp32 vector rate), so phase 1 is written for the fewest VALU instructions, not for overlap ----
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        using xfrag = typename std::conditional<H16, f16x4, f32x4>::type;
+        xfrag xc = *reinterpret_cast<const xfrag*>(Rc + adr[0]), xn = xc;
+        f32x4 d[2];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) xn = *reinterpret_cast<const xfrag*>(Rc + adr[g + 1]);
+            if (!(DBG & 1) && (g & 1) == 0 && g / 2 < NU) p1_mfma(g / 2, d);
+            if constexpr (!(DBG & 2)) {
+                if constexpr (H16) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[g][mt], xc, acc[mt], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][s][mt], xc[s], acc[mt], 0, 0, 0);
+                }
+            }
+            if (!(DBG & 1) && (g & 1) == 1 && g / 2 < NU) {
+                p1_store(g / 2, d, Rn, w1);
+                xin[g / 2] = ld1<TT>(o2 + vo[g / 2]);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keeps the one-group-ahead LDS read where it is (hoisting all 14 costs 56 VGPRs)
+            xc = xn;
+        }
+
+        // ---- epilogue: bias + ReLU, conv2_1 (24 -> 8) chained in registers, store ----
+        {
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x4 h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = fmaxf(acc[mt][r] + bias9[mt][r], 0.f);
+                if constexpr (H16) {
+                    const f16x4 hh = f16x4{(half_t)h[0], (half_t)h[1], (half_t)h[2], (half_t)h[3]};
+                    o = __builtin_amdgcn_mfma_f32_16x16x16f16(w21h[mt], hh, o, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(w21f[mt][r], h[r], o, 0, 0, 0);
+                }
+            }
+            const int oy = c.oy0 + wave, ox = c.ox0 + p;
+            if (j < 2 && oy < a.Ho && ox < a.Wo)
+                st4<TT>(reinterpret_cast<TT*>(a.out) + (((long)c.n * a.Ho + oy) * a.Wo + ox) * 8 + 4 * j,
+                        make_float4(o[0] + bias21[0], o[1] + bias21[1], o[2] + bias21[2], o[3] + bias21[3]));
+        }
+        __syncthreads();  // buffer `cur` is free for the tile after next; the other one is complete
+        cur = BUF - cur;
+    }
+}
+
+size_t k19_packed_floats(bool h16) { return h16 ? (size_t)(W9_F16 + W21_F16) : (size_t)(W9_F32 + W21_F32); }
+
+// w9: [tap][cin][cout] (blob layout of the dense 3x3), w21: [cin][cout]
+void k19_pack_weights(const float* w9, const float* w21, float* out, bool h16)
+{
+    uint16_t* oh = reinterpret_cast<uint16_t*>(out);
+    for (int g = 0; g < NG; ++g)
+        for (int s = 0; s < 4; ++s)
+            for (int mt = 0; mt < 2; ++mt)
+                for (int l = 0; l < 64; ++l) {
+                    const int cout = 16 * mt + (l & 15), jj = l >> 4, fc = 4 * g + jj;
+                    const int tap = fc / 6, c = (fc % 6) * 4 + s;
+                    const float v = (fc < NCHUNK && cout < 24) ? w9[((size_t)tap * 24 + c) * 24 + cout] : 0.f;
+                    if (h16) oh[((size_t)(g * 2 + mt) * 64 + l) * 4 + s] = f32_to_f16_bits(v);
+                    else out[((g * 4 + s) * 2 + mt) * 64 + l] = v;
+                }
+    for (int mt = 0; mt < 2; ++mt)
+        for (int r = 0; r < 4; ++r)
+            for (int l = 0; l < 64; ++l) {
+                const int c2 = l & 15, jj = l >> 4, c1 = 16 * mt + 4 * jj + r;
+                const float v = (c2 < 8 && c1 < 24) ? w21[c1 * 8 + c2] : 0.f;
+                if (h16) oh[(size_t)W9_F16 * 2 + ((size_t)mt * 64 + l) * 4 + r] = f32_to_f16_bits(v);
+                else out[W9_F32 + (mt * 4 + r) * 64 + l] = v;
+            }
+}
+
+// elements the kernel may read before / after its input tensor (one region row beyond either end)
+size_t k19m_guard_elems(int W) { return ((size_t)(W + 34) * 4 + 63) & ~(size_t)63; }
+
+size_t k19m_lds_bytes(int dtype) { return (size_t)2 * RH * row_stride(dtype == DT_F16) * (dtype == DT_F16 ? 2 : 4); }
+
+int launch_k19m(K19Args a, int N, hipStream_t s, int dtype)
+{
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            return -1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k19m_kernel<float, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)k19m_lds_bytes(DT_F32)) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k19m_kernel<half_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)k19m_lds_bytes(DT_F16)) != hipSuccess)
+            return -1;
+        n_cu = v;
+    }
+    a.tiles_y = (a.Ho + TH - 1) / TH;
+    a.tiles_x = (a.Wo + TW - 1) / TW;
+    a.n_frames = N;
+    const long total = (long)N * a.tiles_y * a.tiles_x;
+    // persistent: one workgroup (8 waves, two per SIMD) per CU
+    const long want = (long)n_cu;
+    const unsigned grid = (unsigned)(total < want ? total : want);
+    if (dtype == DT_F16) hipLaunchKernelGGL((k19m_kernel<half_t, 0>), dim3(grid), dim3(512), k19m_lds_bytes(DT_F16), s, a);
+    else hipLaunchKernelGGL((k19m_kernel<float, 0>), dim3(grid), dim3(512), k19m_lds_bytes(DT_F32), s, a);
+    return 0;
+}
+
+}  // namespace yf

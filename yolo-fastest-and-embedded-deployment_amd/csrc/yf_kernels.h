@@ -29,7 +29,8 @@ template <typename T> __device__ __forceinline__ void st4(T* p, float4 v);
 template <> __device__ __forceinline__ void st4<float>(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 template <> __device__ __forceinline__ void st4<half_t>(half_t* p, float4 v)
 {
-    *reinterpret_cast<f16x4*>(p) = f16x4{(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<f16x4*>(p) = __builtin_convertvector((f32x4v{v.x, v.y, v.z, v.w}), f16x4);  // 2 x v_cvt_pk_f16_f32 (RNE)
 }
 template <typename T> __device__ __forceinline__ float ld1(const T* p) { return (float)*p; }
 template <typename T> __device__ __forceinline__ void st1(T* p, float v) { *p = (T)v; }
@@ -131,8 +132,15 @@ struct K19Args {
     float* out;                   // NHWC [N,Ho,Wo,8]
     int H, W, Ho, Wo;
     int tiles_y, tiles_x;
+    const float* wp;              // k19m: MFMA A fragments of conv1_9 and conv2_1 (k19_pack_weights)
+    int n_frames;
 };
-int launch_k19(K19Args a, int N, hipStream_t s, int dtype = DT_F32);
+int launch_k19(K19Args a, int N, hipStream_t s, int dtype = DT_F32);    // VALU version (kept for tools/kbench.hip)
+int launch_k19m(K19Args a, int N, hipStream_t s, int dtype = DT_F32);   // matrix-core version (the plan's)
+size_t k19_packed_floats(bool h16 = false);
+size_t k19m_lds_bytes(int dtype);
+size_t k19m_guard_elems(int W);   // the engine keeps this many elements free before and after the workspace slots
+void k19_pack_weights(const float* w9, const float* w21, float* out, bool h16 = false);
 
 struct PostArgs {
     const float* head_large;  // [N,24,hl,wl]
