@@ -97,10 +97,10 @@ static void bench_mres(const char* tag, int N, int H, int W)
     constexpr int MTR = ((TH + 2) * (TW + 2) + 15) / 16;
     constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 16 * (((MTR * 16 + 7) / 8) * 8 + 1) +
                             ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT) + COUT + 3) & ~3)) * sizeof(float);
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mres_kernel<CIN, CEXP, COUT, RES, TH, TW, NWAVE, float>),
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mres_kernel<CIN, CEXP, COUT, RES, 1, TH, TW, NWAVE, float>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(N * a.tiles_y * a.tiles_x);
-    float us = time_us([&] { hipLaunchKernelGGL((mres_kernel<CIN, CEXP, COUT, RES, TH, TW, NWAVE, float>), grid, dim3(NWAVE * 64), lds, 0, a); });
+    float us = time_us([&] { hipLaunchKernelGGL((mres_kernel<CIN, CEXP, COUT, RES, 1, TH, TW, NWAVE, float>), grid, dim3(NWAVE * 64), lds, 0, a); });
     double macs = (double)N * H * W * CEXP * (CIN + 9 + COUT);
     printf("%-40s tile=%2dx%-2d waves=%d lds=%6zu grid=%6u  %8.1f us  %6.2f TMAC/s\n", tag, TH, TW, NWAVE, lds, grid.x, us, macs / us * 1e-6);
 }

@@ -177,7 +177,7 @@ struct Builder {
         int H = pre ? ti.H / 2 : ti.H, W = pre ? ti.W / 2 : ti.W;  // expansion resolution
         int st = kLayers[o.l_dw].stride;
         o.in1 = in; o.in2 = -1; o.res = res ? in : -1; o.omode = 0;
-        if (!pre && st == 1 && yf::mres_has_kernel(kLayers[o.l_exp].cin, kLayers[o.l_exp].cout, kLayers[o.l_proj].cout, res))
+        if (!pre && yf::mres_has_kernel(kLayers[o.l_exp].cin, kLayers[o.l_exp].cout, kLayers[o.l_proj].cout, res, st))
             o.type = OP_MRES;  // both pointwise convs on the matrix cores
         o.out = add_tensor(out_name, kLayers[o.l_proj].cout, H / st, W / st);
         e->ops.push_back(o);
@@ -378,7 +378,7 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
             } else if (o.type == OP_MRES) {
                 const LayerSpec &LE = kLayers[o.l_exp], &LP = kLayers[o.l_proj];
                 yf::MresArgs a{ptr(o.in1), e->d_wmfma + o.mfma_off, ptr(o.out), ti.H, ti.W, 0, 0};
-                rc = yf::launch_mres(LE.cin, LE.cout, LP.cout, o.res >= 0, a, n, s, e->dtype);
+                rc = yf::launch_mres(LE.cin, LE.cout, LP.cout, o.res >= 0, kLayers[o.l_dw].stride, a, n, s, e->dtype);
             } else if (o.type == OP_FUSED_BLOCK) {
                 const bool pre = o.l_pre >= 0;
                 const LayerSpec &LE = kLayers[o.l_exp], &LD = kLayers[o.l_dw], &LP = kLayers[o.l_proj];

@@ -105,8 +105,8 @@ struct MresArgs {
     int H, W;
     int tiles_y, tiles_x;  // filled by the launcher
 };
-int launch_mres(int cin, int cexp, int cout, bool res, const MresArgs& a, int N, hipStream_t s, int dtype = DT_F32);
-bool mres_has_kernel(int cin, int cexp, int cout, bool res);
+int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArgs& a, int N, hipStream_t s, int dtype = DT_F32);
+bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride = 1);
 size_t mres_packed_floats(int cin, int cexp, int cout, bool h16 = false);
 void mres_pack_weights(const float* w1, const float* b1, const float* wd, const float* bd, const float* w2, const float* b2,
                        int cin, int cexp, int cout, float* out, bool h16 = false);

@@ -33,10 +33,12 @@ __host__ __device__ constexpr int mres_chunk_floats(int cin, int cout, bool h16 
                : mres_ksteps(cin) * 64 + 16 + 9 * 16 + 16 + 4 * ((cout + 15) / 16) * 64;
 }
 
-template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWAVE, typename T>
+// S = 2: the stride-2 triples (pw-expand -> dw3x3 stride 2 -> pw-project, no residual): a.H / a.W are the INPUT dims, the tile
+// is TH x TW OUTPUT pixels and the region (TH - 1) S + 3 rows.
+template <int CIN, int CEXP, int COUT, bool RES, int S, int TH, int TW, int NWAVE, typename T>
 __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
 {
-    constexpr int RH = TH + 2, RW = TW + 2, NRP = RH * RW;
+    constexpr int RH = (TH - 1) * S + 3, RW = (TW - 1) * S + 3, NRP = RH * RW;
     constexpr int MTR = (NRP + 15) / 16, MTO = (TH * TW) / 16;
     constexpr int MTRW = (MTR + NWAVE - 1) / NWAVE, MTOW = (MTO + NWAVE - 1) / NWAVE;
     constexpr int XP = CIN + 4;                           // X row pitch: conflict-free b128/b64 fragment reads
@@ -47,7 +49,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
     constexpr int OFF_B1 = H16 ? NK1 * 128 : KS1 * 64, OFF_WD = OFF_B1 + 16, OFF_BD = OFF_WD + 144, OFF_W2 = OFF_BD + 16;
     constexpr int CHUNK = OFF_W2 + (H16 ? NT2 * 128 : 4 * NT2 * 64);
     static_assert((TH * TW) % 16 == 0 && CIN % 8 == 0 && COUT % 4 == 0, "shape");
-    static_assert(!RES || CIN == COUT, "residual needs same shape");
+    static_assert(!RES || (CIN == COUT && S == 1), "residual needs same shape");
     static_assert(CHUNK == mres_chunk_floats(CIN, COUT, H16), "pack layout");
     static_assert(MTRW * 4 <= 32, "in-image mask bits");
     extern __shared__ __attribute__((aligned(16))) float mres_smem[];
@@ -58,7 +60,8 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
 
     const int b = blockIdx.x;
     const int tx = b % a.tiles_x, ty = (b / a.tiles_x) % a.tiles_y, n = b / (a.tiles_x * a.tiles_y);
-    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int oy0 = ty * TH, ox0 = tx * TW;   // output coordinates
+    const int Ho = a.H / S, Wo = a.W / S;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
 
@@ -72,7 +75,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
         for (int idx = threadIdx.x; idx < MTR * 16 * C4; idx += NWAVE * 64) {
             const int rp = idx / C4, c4 = idx - rp * C4;
             const int ry = rp / RW, rx = rp - ry * RW;
-            const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
+            const int iy = oy0 * S - 1 + ry, ix = ox0 * S - 1 + rx;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (rp < NRP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
                 v = ld4<T>(src + ((long)iy * a.W + ix) * CIN + c4 * 4);
@@ -101,7 +104,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
         for (int reg = 0; reg < 4; ++reg) {
             const int rp = mt * 16 + 4 * q + reg;
             const int ry = rp / RW, rx = rp - ry * RW;
-            const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
+            const int iy = oy0 * S - 1 + ry, ix = ox0 * S - 1 + rx;
             if (mt < MTR && rp < NRP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) inmask |= 1u << (i * 4 + reg);
         }
     }
@@ -115,7 +118,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
         const int mo = wave + i * NWAVE;
         const int op = (mo < MTO ? mo : 0) * 16 + r;
         const int oy = op / TW, ox = op - oy * TW;
-        rp0[i] = (oy + 1) * RW + ox + 1;
+        rp0[i] = (oy * S + 1) * RW + ox * S + 1;
     }
 
 #pragma unroll 1
@@ -223,10 +226,10 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                 const int op = mo * 16 + 4 * q + reg;
                 const int oy = op / TW, ox = op - oy * TW;
                 const int gy = oy0 + oy, gx = ox0 + ox;
-                if (gy >= a.H || gx >= a.W) continue;
+                if (gy >= Ho || gx >= Wo) continue;
                 float v = acc[i][nt][reg] + bias;
                 if constexpr (RES) v += X[((oy + 1) * RW + ox + 1) * XP + col];
-                st1<T>(reinterpret_cast<T*>(a.out) + (((long)n * a.H + gy) * a.W + gx) * COUT + col, v);
+                st1<T>(reinterpret_cast<T*>(a.out) + (((long)n * Ho + gy) * Wo + gx) * COUT + col, v);
             }
         }
     }
@@ -466,58 +469,59 @@ static int launch_mres_pc_t(MresArgs a, int N, hipStream_t s)
     return 0;
 }
 
-template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWAVE, typename T>
+template <int CIN, int CEXP, int COUT, bool RES, int S, int TH, int TW, int NWAVE, typename T>
 static int launch_mres_t(MresArgs a, int N, hipStream_t s)
 {
-    a.tiles_y = (a.H + TH - 1) / TH;
-    a.tiles_x = (a.W + TW - 1) / TW;
-    constexpr int MTR = ((TH + 2) * (TW + 2) + 15) / 16;
+    a.tiles_y = (a.H / S + TH - 1) / TH;
+    a.tiles_x = (a.W / S + TW - 1) / TW;
+    constexpr int MTR = (((TH - 1) * S + 3) * ((TW - 1) * S + 3) + 15) / 16;
     constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 16 * (((MTR * 16 + 7) / 8) * 8 + 1) +
                             ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT, sizeof(T) == 2) + COUT + 3) & ~3)) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done = false;
     if (lds > 64 * 1024 && !attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mres_kernel<CIN, CEXP, COUT, RES, TH, TW, NWAVE, T>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mres_kernel<CIN, CEXP, COUT, RES, S, TH, TW, NWAVE, T>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
         attr_done = true;
     }
-    hipLaunchKernelGGL((mres_kernel<CIN, CEXP, COUT, RES, TH, TW, NWAVE, T>), dim3((unsigned)(N * a.tiles_y * a.tiles_x)),
+    hipLaunchKernelGGL((mres_kernel<CIN, CEXP, COUT, RES, S, TH, TW, NWAVE, T>), dim3((unsigned)(N * a.tiles_y * a.tiles_x)),
                        dim3(NWAVE * 64), lds, s, a);
     return 0;
 }
 
-//      (cin, cexp, cout, residual, TH, TW, producer waves (0 = two-barrier kernel), waves / consumer waves)
+//      (cin, cexp, cout, residual, stride, TH, TW, producer waves (0 = two-barrier kernel), waves / consumer waves)
 // Producer/consumer pays where one workgroup owns the CU anyway (strides 16, 32); at stride 8 its second E buffer
 // halves the workgroups per CU and it is slower (tools/kbench.hip mrespc).
 #define YF_MRES_SHAPES(MR)                                                            \
-    MR(8, 48, 16, false, 16, 20, 0, 4)   /* conv3_2/3_3/3_4          @ H/8  */         \
-    MR(16, 96, 16, true, 16, 20, 0, 8)   /* res3_3 .. res3_6         @ H/8  */         \
-    MR(24, 136, 24, true, 16, 20, 6, 10) /* res4_1 .. res4_4         @ H/16 */         \
-    MR(48, 224, 48, true, 8, 10, 4, 5)   /* res5_1 .. res5_5         @ H/32 */
+    MR(8, 48, 16, false, 1, 16, 20, 0, 4)   /* conv3_2/3_3/3_4          @ H/8  */         \
+    MR(16, 96, 16, true, 1, 16, 20, 0, 8)   /* res3_3 .. res3_6         @ H/8  */         \
+    MR(16, 96, 24, false, 2, 8, 10, 0, 8)   /* conv3_5/3_6/4_1          H/8 -> H/16 */    \
+    MR(24, 136, 24, true, 1, 16, 20, 6, 10) /* res4_1 .. res4_4         @ H/16 */         \
+    MR(48, 224, 48, true, 1, 8, 10, 4, 5)   /* res5_1 .. res5_5         @ H/32 */
 
-template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NW, typename T>
+template <int CIN, int CEXP, int COUT, bool RES, int S, int TH, int TW, int NWP, int NW, typename T>
 static int launch_mres_any(const MresArgs& a, int N, hipStream_t s)
 {
-    if constexpr (NWP == 0) return launch_mres_t<CIN, CEXP, COUT, RES, TH, TW, NW, T>(a, N, s);
-    else return launch_mres_pc_t<CIN, CEXP, COUT, RES, TH, TW, NWP, NW, T>(a, N, s);
+    if constexpr (NWP == 0) return launch_mres_t<CIN, CEXP, COUT, RES, S, TH, TW, NW, T>(a, N, s);
+    else { static_assert(S == 1, "producer/consumer kernel: stride 1 only"); return launch_mres_pc_t<CIN, CEXP, COUT, RES, TH, TW, NWP, NW, T>(a, N, s); }
 }
 
-int launch_mres(int cin, int cexp, int cout, bool res, const MresArgs& a, int N, hipStream_t s, int dtype)
+int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArgs& a, int N, hipStream_t s, int dtype)
 {
-#define MR(ci, ce, co, rs, th, tw, np, nw)                                                                        \
-    if (cin == ci && cexp == ce && cout == co && res == rs)                                                       \
-        return dtype == DT_F16 ? launch_mres_any<ci, ce, co, rs, th, tw, np, nw, half_t>(a, N, s)                  \
-                               : launch_mres_any<ci, ce, co, rs, th, tw, np, nw, float>(a, N, s);
+#define MR(ci, ce, co, rs, st, th, tw, np, nw)                                                                    \
+    if (cin == ci && cexp == ce && cout == co && res == rs && stride == st)                                       \
+        return dtype == DT_F16 ? launch_mres_any<ci, ce, co, rs, st, th, tw, np, nw, half_t>(a, N, s)              \
+                               : launch_mres_any<ci, ce, co, rs, st, th, tw, np, nw, float>(a, N, s);
     YF_MRES_SHAPES(MR)
 #undef MR
     return -1;
 }
 
-bool mres_has_kernel(int cin, int cexp, int cout, bool res)
+bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride)
 {
-#define MR(ci, ce, co, rs, th, tw, np, nw) \
-    if (cin == ci && cexp == ce && cout == co && res == rs) return true;
+#define MR(ci, ce, co, rs, st, th, tw, np, nw) \
+    if (cin == ci && cexp == ce && cout == co && res == rs && stride == st) return true;
     YF_MRES_SHAPES(MR)
 #undef MR
     return false;
