@@ -232,6 +232,27 @@ int main(int argc, char** argv)
         bench_mres<8, 32, 8, true, 16, 20, 4>("8/32 s4", N, 64, 80);
         bench_mres<8, 32, 8, true, 16, 40, 8>("8/32 s4", N, 64, 80);
     }
+    if (on("ws")) {
+        printf("--- weight-stationary GEMM, conv4_1_1 shape (232 -> 96, 81920 rows) ---\n");
+        PwArgs a{};
+        const long M = 81920;
+        a.in1 = dev_rand((size_t)M * 136); a.in2 = dev_rand((size_t)M * 96);
+        a.w = dev_rand(mfma_packed_floats(136, 96, 96), 0.2f); a.b = dev_rand(96, 0.1f);
+        float* out; CK(hipMalloc(&out, (size_t)M * 96 * 4)); a.out = out;
+        a.npix = M; a.HW = 320; a.W = 20;
+        auto run = [&](auto kern, int threads, unsigned grid, const char* tag) {
+            float t = time_us([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, 0, a); });
+            printf("ws %-36s grid %4u x %4d  %8.1f us  %6.2f TMAC/s\n", tag, grid, threads, t, (double)M * 232 * 96 / t * 1e-6);
+        };
+        run(&pw_ws_kernel<136, 96, 96, 1, 2, true, 0, 0>, 768, 256, "UPW1 RS2");
+        run(&pw_ws_kernel<136, 96, 96, 1, 2, true, 0, 1>, 768, 256, "UPW1 RS2 no A refill");
+        run(&pw_ws_kernel<136, 96, 96, 1, 2, true, 0, 2>, 768, 256, "UPW1 RS2 no stores");
+        run(&pw_ws_kernel<136, 96, 96, 1, 2, true, 0, 3>, 768, 256, "UPW1 RS2 neither");
+        run(&pw_ws_kernel<136, 96, 96, 2, 4, true, 0, 0>, 768, 256, "UPW2 RS4");
+        run(&pw_ws_kernel<136, 96, 96, 2, 4, true, 0, 3>, 768, 256, "UPW2 RS4 neither");
+        run(&pw_ws_kernel<136, 96, 96, 3, 2, true, 0, 0>, 256, 256, "UPW3 RS2 (4 waves)");
+        run(&pw_ws_kernel<136, 96, 96, 3, 2, true, 0, 0>, 256, 512, "UPW3 RS2 (4 waves) 2x grid");
+    }
     if (on("mfma")) {
         printf("--- MFMA pointwise GEMMs ---\n");
         bench_mfma<48, 224, 1, true, false>("48->224 s32", 20480);

@@ -170,6 +170,177 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// pw_ws_kernel: the same GEMM, weight-stationary (fp32).  pw_mfma_kernel re-reads every B fragment per wave: on conv4_1_1
+// (K = 232, N = 96) that is 89 KB through the L2 -> L1 fill path per 32 rows, the matrix pipe sits at 33 % and the waves
+// are issue-stalled 67 % of the time (SQ counters, profiles/).  Here a wave owns UPW n-tiles ("units"; a deconv quadrant x
+// n-tile is a unit too) and keeps ALL their B fragments in registers (58 k-steps x 2 units = 116 VGPRs on conv4_1_1); the
+// waves of a workgroup own different units and walk over the same row tiles (persistent: tile t, t + grid, ..), so A comes
+// through L1 once per workgroup and B is read once per wave for the whole launch.
+// The A fragments of a row tile (K/4 registers) form a ring: each 16-byte piece is re-requested for the NEXT row tile
+// right after the MFMAs that consumed it -- a full tile of prefetch distance with no extra registers.  No LDS, no barriers.
+// ------------------------------------------------------------------------------------------------
+// A workgroup is RS "row streams" x NUG unit groups of waves, sized to a multiple of 4 waves: the dispatcher deals a workgroup's
+// waves to the SIMDs in a fixed pattern, so a 6-wave workgroup loads SIMDs 2,2,1,1 and a second one does not fit beside it
+// (measured: 1 workgroup per CU resident, two sequential rounds).
+__device__ __forceinline__ bool v0guard(float v) { return v != 123456.f; }  // DBG: keeps the value alive, never stores
+
+// DBG (tools/kbench.hip only): 1 = no A refill, 2 = no stores
+template <int K1, int K2, int N, int UPW, int RS, bool RELU, int OMODE, int DBG = 0>
+__global__ void __launch_bounds__(64 * RS * ((((N + 15) / 16) * (OMODE == 2 ? 4 : 1) + UPW - 1) / UPW)) pw_ws_kernel(PwArgs a)
+{
+    constexpr int NT = (N + 15) / 16, NQ = OMODE == 2 ? 4 : 1, NU = NT * NQ;
+    constexpr int NB1 = K1 / 16, NB2 = K2 / 16;
+    constexpr bool T1 = (K1 % 16) != 0, T2 = (K2 % 16) != 0;
+    constexpr int S1 = ksteps(K1), S2 = K2 ? ksteps(K2) : 0, SS = S1 + S2;
+    static_assert(OMODE == 0 || OMODE == 2, "NHWC outputs only");
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    constexpr int NUG = (NU + UPW - 1) / UPW;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ug = wv % NUG, rs = wv / NUG;  // unit group and row stream of this wave
+
+    // ---- this wave's B fragments and biases ----
+    float bw[UPW][SS], bias[UPW];
+    int un[UPW], uq[UPW];
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) {
+        const int u = ug * UPW + i;
+        const bool v = u < NU;             // a workgroup's last wave may have fewer units: it recomputes the last one, stores nothing
+        const int uc = v ? u : NU - 1;
+        uq[i] = uc / NT;
+        un[i] = uc - uq[i] * NT;
+        const float* w = a.w + ((size_t)uq[i] * SS * NT + un[i]) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < SS; ++s) bw[i][s] = w[(size_t)s * NT * 64];
+        bias[i] = un[i] * 16 + r < N ? a.b[un[i] * 16 + r] : 0.f;
+        if (!v) un[i] = NT;  // marks "no stores"
+    }
+
+    const long ntiles = (a.npix + 15) / 16;
+    const long t0 = (long)blockIdx.x * RS + rs, tstep = (long)gridDim.x * RS;
+    auto rowptr1 = [&](long t) { long rr = t * 16 + r; rr = rr < a.npix ? rr : a.npix - 1; return a.in1 + rr * K1 + 4 * q; };
+    auto rowptr2 = [&](long t) { long rr = t * 16 + r; rr = rr < a.npix ? rr : a.npix - 1; return a.in2 + rr * K2 + 4 * q; };
+
+    // ---- the A ring, filled for the first tile ----
+    float4 a1[NB1 > 0 ? NB1 : 1], a2[NB2 > 0 ? NB2 : 1];
+    float2 a1t = make_float2(0.f, 0.f), a2t = make_float2(0.f, 0.f);
+    {
+        const float* p1 = rowptr1(t0 < ntiles ? t0 : ntiles - 1);
+#pragma unroll
+        for (int kb = 0; kb < NB1; ++kb) a1[kb] = *reinterpret_cast<const float4*>(p1 + kb * 16);
+        if constexpr (T1) a1t = *reinterpret_cast<const float2*>(p1 - 4 * q + NB1 * 16 + 2 * q);
+        if constexpr (K2 > 0) {
+            const float* p2 = rowptr2(t0 < ntiles ? t0 : ntiles - 1);
+#pragma unroll
+            for (int kb = 0; kb < NB2; ++kb) a2[kb] = *reinterpret_cast<const float4*>(p2 + kb * 16);
+            if constexpr (T2) a2t = *reinterpret_cast<const float2*>(p2 - 4 * q + NB2 * 16 + 2 * q);
+        }
+    }
+
+#pragma unroll 1
+    for (long t = t0; t < ntiles; t += tstep) {
+        const long tn = (t + tstep < ntiles) ? t + tstep : t;  // the tile whose fragments are requested while this one is computed
+        const float* p1 = rowptr1(tn);
+        f32x4 acc[UPW];
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NB1; ++kb) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < UPW; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a1[kb])[j], bw[i][kb * 4 + j], acc[i], 0, 0, 0);
+            if constexpr (!(DBG & 1)) a1[kb] = *reinterpret_cast<const float4*>(p1 + kb * 16);
+        }
+        if constexpr (T1) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < UPW; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a1t)[j], bw[i][NB1 * 4 + j], acc[i], 0, 0, 0);
+            if constexpr (!(DBG & 1)) a1t = *reinterpret_cast<const float2*>(p1 - 4 * q + NB1 * 16 + 2 * q);
+        }
+        if constexpr (K2 > 0) {
+            const float* p2 = rowptr2(tn);
+#pragma unroll
+            for (int kb = 0; kb < NB2; ++kb) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < UPW; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a2[kb])[j], bw[i][S1 + kb * 4 + j], acc[i], 0, 0, 0);
+                if constexpr (!(DBG & 1)) a2[kb] = *reinterpret_cast<const float4*>(p2 + kb * 16);
+            }
+            if constexpr (T2) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < UPW; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a2t)[j], bw[i][S1 + NB2 * 4 + j], acc[i], 0, 0, 0);
+                a2t = *reinterpret_cast<const float2*>(p2 - 4 * q + NB2 * 16 + 2 * q);
+            }
+        }
+        // ---- epilogue: lane holds column un*16 + r of rows t*16 + 4q + reg ----
+        long obase[4];  // element offset of the row's output pixel (deconv: of its 2x2 block's top-left pixel)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const long row = t * 16 + 4 * q + reg;
+            if constexpr (OMODE == 0) {
+                obase[reg] = row * N;
+            } else {  // ConvTranspose2d k=2 s=2: quadrant (dy,dx) of input pixel (y,x) -> output pixel (2y+dy, 2x+dx)
+                const long n = row / a.HW, hw = row - n * a.HW;
+                const int y = (int)(hw / a.W), x = (int)(hw - (long)y * a.W);
+                obase[reg] = ((n * (2 * (a.HW / a.W)) + 2 * y) * (2 * a.W) + 2 * x) * N;
+            }
+            if (row >= a.npix) obase[reg] = -1;
+        }
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int c = un[i] * 16 + r;
+            if (c >= N) continue;  // also the "no unit" marker
+            const long qoff = OMODE == 2 ? ((long)(uq[i] >> 1) * (2 * a.W) + (uq[i] & 1)) * N : 0;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                if (obase[reg] < 0 || ((DBG & 2) && v0guard(acc[i][reg]))) continue;
+                float v = acc[i][reg] + bias[i];
+                if constexpr (RELU) v = fmaxf(v, 0.f);
+                a.out[obase[reg] + qoff + c] = v;
+            }
+        }
+    }
+}
+
+//      (k1, k2, n, units per wave, row streams, relu, omode)  -- fp32 storage only.  UPW as large as the registers allow: every
+//      wave of a row stream re-reads the same A tile through the texture path (16 B per lane, 16 rows per instruction), and that
+//      path, not the matrix pipe, limits this kernel: conv4_1_1 with 1 / 2 / 3 units per wave runs 67 / 58 / 37 us (tools/kbench ws)
+//      last column: workgroups that fit a CU (registers), for the persistent grid
+#define YF_WS_SHAPES(WS)                                                              \
+    WS(24, 0, 136, 9, 4, true, 0, 3)    /* conv4_2: all 9 n-tiles per wave, 4 streams  (stride 16) */  \
+    WS(136, 0, 48, 3, 4, true, 0, 3)    /* conv5_1: 3 n-tiles per wave, 4 streams      (stride 32) */  \
+    WS(48, 0, 96, 6, 4, true, 0, 3)     /* conv5_2: 6 n-tiles per wave, 4 streams */                   \
+    WS(96, 0, 96, 6, 2, true, 2, 1)     /* deconv5_1: 4 quadrants x 6 n-tiles = 24 units: 4 waves x 2 streams */ \
+    WS(136, 96, 96, 3, 2, true, 0, 1)   /* conv4_1_1 over cat(conv4_2, deconv5_1): 2 waves x 2 streams */
+
+template <int K1, int K2, int N, int UPW, int RS, bool RELU, int OMODE, int WPC>
+static int launch_ws(const PwArgs& a, hipStream_t s)
+{
+    constexpr int NU = ((N + 15) / 16) * (OMODE == 2 ? 4 : 1), NUG = (NU + UPW - 1) / UPW;
+    static_assert((NUG * RS) % 4 == 0 && NUG * RS <= 16, "whole waves per SIMD");
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            return -2;
+        n_cu = v;
+    }
+    const long ntiles = (a.npix + 15) / 16, streams = (ntiles + RS - 1) / RS;
+    // persistent grid: every workgroup gets the same number of row tiles (no ragged last round)
+    const long cap = (long)n_cu * WPC, rounds = (streams + cap - 1) / cap, grid = (streams + rounds - 1) / rounds;
+    hipLaunchKernelGGL((pw_ws_kernel<K1, K2, N, UPW, RS, RELU, OMODE>), dim3((unsigned)grid), dim3(64 * NUG * RS), 0, s, a);
+    return 0;
+}
+
 template <int K1, int K2, int N, int MT, bool RELU, bool RES, int OMODE>
 static int launch_t(const PwArgs& a, hipStream_t s, int dtype)
 {
@@ -199,6 +370,11 @@ static int launch_t(const PwArgs& a, hipStream_t s, int dtype)
 
 int launch_pw_mfma(int cin1, int cin2, int cout, bool relu_, bool res_, int omode, const PwArgs& a, hipStream_t s, int dtype)
 {
+#define WS(k1, k2, n, upw, rs, relu, om, wpc)                                                                  \
+    if (dtype == DT_F32 && cin1 == k1 && cin2 == k2 && cout == n && relu_ == relu && !res_ && omode == om)      \
+        return launch_ws<k1, k2, n, upw, rs, relu, om, wpc>(a, s);
+    YF_WS_SHAPES(WS)
+#undef WS
 #define MF(k1, k2, n, mt, relu, res, om)                                                        \
     if (cin1 == k1 && cin2 == k2 && cout == n && relu_ == relu && res_ == res && omode == om)    \
         return launch_t<k1, k2, n, mt, relu, res, om>(a, s, dtype);
