@@ -83,3 +83,88 @@ def non_max_suppression(prediction, num_classes, conf_thres=0.5, nms_thres=0.4):
             keep = torch.cat(keep)
             output[i] = keep if output[i] is None else torch.cat((output[i], keep))
     return output
+
+
+# ---- mAP bookkeeping (validate.py:27-122) ----------------------------------------------------------------------------------
+
+def recover_targets(targets, input_shape):
+    """validate.py:112-122: normalised (xc, yc, w, h, cls, marker) -> input-image corners (x1, y1, x2, y2, cls, marker)."""
+    t = targets.clone().float()
+    in_h, in_w = input_shape[0], input_shape[1]
+    t[:, :, (0, 2)] = t[:, :, (0, 2)] * in_w
+    t[:, :, (1, 3)] = t[:, :, (1, 3)] * in_h
+    out = t.clone()
+    out[:, :, 0] = t[:, :, 0] - t[:, :, 2] / 2
+    out[:, :, 1] = t[:, :, 1] - t[:, :, 3] / 2
+    out[:, :, 2] = t[:, :, 0] + t[:, :, 2] / 2
+    out[:, :, 3] = t[:, :, 1] + t[:, :, 3] / 2
+    return out
+
+
+def match_image(img_pred, img_target, num_cls, iou_thr, match_list, target_num):
+    """validate.py:47-74 for one image: img_pred [n,7] or None (NMS output), img_target [64,6] recovered targets.
+    Appends (sort key, is_tp) to match_list[c]; the key is the printed form of the 0-d confidence tensor, which is what
+    np.array([t[4], 'TP']) stores in the reference."""
+    img_target = img_target[img_target[:, 5] > 1]
+    for t in img_target:
+        target_num[int(t[4])] += 1
+    if img_pred is None:
+        return
+    for c in img_pred[:, 6].unique():
+        target_c = img_target[img_target[:, 4] == c]
+        pred_c = img_pred[img_pred[:, 6] == c]
+        c = int(c)
+        for t in pred_c:
+            if target_c.size(0) == 0:
+                match_list[c].append((str(t[4]), False))
+                continue
+            ious = bbox_iou(t.unsqueeze(0), target_c)
+            hit = False
+            for index, iou in enumerate(ious):
+                if iou > iou_thr:
+                    match_list[c].append((str(t[4]), True))
+                    hit = True
+                    target_c = torch.cat((target_c[0:index], target_c[index + 1:]), dim=0)  # general.py:76-79
+                    break
+            if not hit:
+                match_list[c].append((str(t[4]), False))
+
+
+def calculate_ap(matches, n_targets):
+    """validate.py:87-119, literally (O(n^2)).  matches: [(key, is_tp)] already sorted; n_targets: float32 tensor scalar."""
+    import numpy as np
+    pr = []
+    for i in range(len(matches)):
+        tp = fp = 0
+        for index in range(i + 1):
+            if matches[index][1]:
+                tp += 1
+            else:
+                fp += 1
+        fn = n_targets - tp                       # float32 tensor
+        precision = tp / (tp + fp)
+        recall = tp / (tp + fn)                   # float32 tensor
+        if i > 0 and recall == pr[-1][1]:
+            if precision > pr[-1][0]:
+                pr[-1][0] = precision
+        else:
+            pr.append(np.array([precision, recall]))
+    ap, pre = 0, 0
+    pr = np.array(pr)
+    for i in range(pr.shape[0]):
+        ap += (pr[i][1] - pre) * np.max(pr[i:], axis=0)[0]
+        pre = pr[i][1]
+    return ap
+
+
+def get_map(dets, targets, num_cls, input_shape, iou_thr):
+    """dets: list of [n,7] tensors / None per image (NMS output); targets [N,64,6] normalised.  -> (mAP, [AP], target_num, match_list)"""
+    match_list = [[] for _ in range(num_cls)]
+    target_num = torch.zeros((num_cls))
+    rec = recover_targets(targets, input_shape)
+    for f, d in enumerate(dets):
+        match_image(d, rec[f], num_cls, iou_thr, match_list, target_num)
+    for c in range(num_cls):
+        match_list[c].sort(key=lambda x: x[0], reverse=True)     # validate.py:77: a sort of STRINGS
+    aps = [calculate_ap(match_list[c], target_num[c]) for c in range(num_cls)]
+    return sum(aps) / num_cls, aps, target_num, match_list

@@ -271,6 +271,85 @@ def main_val():
     np.savez_compressed(os.path.join(HERE, "golden_val_256.npz"), **out)
 
 
+def main_map():
+    """mAP goldens (validate.py:27-122): the reference's own `Validation.get_mAP` run on the 20 bundled
+    frames with SYNTHETIC targets (the dataset is not shipped).  `validate.py` imports `dataloader.detect_dataset`, which
+    imports cv2 and tensorboardX at module level (neither is used by the code under test): empty stub modules.
+    The dataset yields u8 - 128 as float (DetectDataset.collate_fn :115 divides by 255, so the net sees detect.py's
+    (u8 - 128) / 255: with plain u8 / 255 the shipped checkpoint detects nothing on these frames).  Targets are built from
+    the reference's own detections on them, then perturbed so that every branch is hit: shifted boxes (IoU above / below the 0.5
+    match threshold), a wrong class, images without targets, targets without detections, duplicate targets."""
+    import types, logging
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    tb = types.ModuleType("tensorboardX"); tb.SummaryWriter = object
+    sys.modules.setdefault("tensorboardX", tb)
+    sys.path.insert(0, os.path.join(REF, "src", "model_training"))
+    from loss.yolo_loss import YOLOLossV3            # the reference
+    from utils.general import non_max_suppression    # the reference
+    from validate import Validation                  # the reference
+    model, io = load_model(256)
+    g = np.load(os.path.join(HERE, "golden_256.npz"))
+    u8 = g["input_u8"]                                # [20,256,320]
+    dev = torch.device("cpu")
+    losses = [YOLOLossV3(io["anchors"][i], io["num_cls"], io["input_shape"], dev) for i in range(2)]
+    H, W = io["input_shape"][0], io["input_shape"][1]
+    with torch.no_grad():
+        x = (torch.from_numpy(u8.astype(np.float32))[:, None] - 128.0) / 255.0
+        pred = model(x)
+        dec = torch.cat([losses[i](pred[i]) for i in range(2)], 1)
+        dets = non_max_suppression(dec.clone(), io["num_cls"], conf_thres=io["conf_thre"], nms_thres=io["nms_thre"])
+    targets = np.zeros((len(dets), 64, 6), np.float32)
+    for f, d in enumerate(dets):
+        rows = []
+        if d is not None and f % 7 != 6:              # every 7th image: no targets at all (all its detections are FP)
+            for k, t in enumerate(d.numpy()):
+                x1, y1, x2, y2 = t[:4]
+                shift = [0, 1, 3, 9, 30][(f + k) % 5]  # 30 px: no overlap left
+                cls = int(t[6]) if (f + k) % 6 != 5 else (int(t[6]) + 1) % 3   # sometimes the wrong class
+                rows.append([(x1 + x2) / 2 + shift, (y1 + y2) / 2, x2 - x1, y2 - y1, cls])
+                if (f + k) % 4 == 3:
+                    rows.append(rows[-1][:])          # duplicate target: only one of them can be matched
+        if f % 3 == 0:
+            rows.append([40.0 + f, 200.0, 20.0, 10.0, f % 3])   # a target nobody detects (FN)
+        for k, r in enumerate(rows):
+            targets[f, k] = [r[0] / W, r[1] / H, r[2] / W, r[3] / H, r[4], 255.0]
+
+    class Frames(torch.utils.data.Dataset):           # what DetectDataset yields: (h,w,1) image, (64,6) boxes
+        def __len__(self): return len(u8)
+        def __getitem__(self, i): return u8[i][:, :, None].astype(np.float32) - 128.0, targets[i].copy()   # collate_fn divides by 255
+
+    params = {"train_params": {"batch_size": 4, "IOU_val_thre": 0.5},
+              "io_params": dict(io, class_names=["carrier", "defender", "destroyer"])}
+    logger = logging.getLogger("ref-val"); logger.addHandler(logging.NullHandler())
+    torch.manual_seed(0)
+    val = Validation(params, logger, Frames(), dev, losses)
+    mAP = float(val.get_mAP(model, 0))
+    APs = [float(val._Validation__calculate_AP(cls=c)) for c in range(3)]
+    out = {"targets": targets,   # the frames are golden_256.npz's input_u8
+           "mAP": np.float64(mAP), "AP": np.array(APs, np.float64),
+           "target_num": val.target_num.numpy().astype(np.float32)}
+    for c in range(3):
+        ml = val.match_list[c]
+        # the entries are np.array([tensor_scalar, 'TP']) = STRINGS like 'tensor(0.8714)': the reference's sort (:77) is a
+        # lexicographic sort of that 4-decimal printed form
+        out[f"match_key_{c}"] = np.array([str(m[0]) for m in ml])
+        out[f"match_conf_{c}"] = np.array([float(str(m[0])[7:-1]) for m in ml], np.float64)
+        out[f"match_tp_{c}"] = np.array([m[1] == "TP" for m in ml], np.bool_)
+    kmax = max([0 if d is None else d.shape[0] for d in dets] + [1])
+    det = np.zeros((len(dets), kmax, 7), np.float32); cnt = np.zeros((len(dets),), np.int32)
+    for f, d in enumerate(dets):
+        if d is not None:
+            cnt[f] = d.shape[0]; det[f, :d.shape[0]] = d.numpy()
+    out["det"] = det; out["count"] = cnt
+    np.savez_compressed(os.path.join(HERE, "golden_map_256.npz"), **out)
+    print("mAP", mAP, "AP", APs, "targets", val.target_num.tolist(), "matches", [len(m) for m in val.match_list],
+          "TP", [int(out[f"match_tp_{c}"].sum()) for c in range(3)])
+
+
 if __name__ == "__main__":
-    main()
-    main_val()
+    if len(sys.argv) > 1 and sys.argv[1] == "map":
+        main_map()
+    else:
+        main()
+        main_val()
+        main_map()

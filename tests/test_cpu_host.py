@@ -180,3 +180,36 @@ def test_host_f32_to_f16_rounding_is_ieee_rne():
             assert (got & 0x7C00) == 0x7C00 and (got & 0x3FF) != 0
         else:
             assert got == w, (v, hex(got), hex(w))
+
+
+def test_validation_bookkeeping_matches_the_oracle(golden):
+    """Host logic of yolo_fastest_amd.validation.Validation (matching + AP arithmetic, validate.py:47-119) against the
+    oracle's literal restatement: on the reference's stored NMS output, and on random match lists (ties, repeated recalls)."""
+    import logging
+    from oracle import val_oracle as vo
+    from yolo_fastest_amd import validation as V
+    g = golden("golden_map_256")
+    params = {"train_params": {"batch_size": 4, "IOU_val_thre": 0.5},
+              "io_params": {"input_shape": (256, 320, 1), "num_cls": 3, "class_names": ["carrier", "defender", "destroyer"],
+                            "conf_thre": 0.5, "nms_thre": 0.2}}
+    frames = [(np.zeros((2, 2, 1), np.float32), np.zeros((64, 6), np.float32))] * 4   # the loader is not used here
+    val = V.Validation(params, logging.getLogger("t"), frames, "cpu", None)
+    rec = val._recover_targets(torch.from_numpy(g["targets"]))
+    assert torch.equal(rec, vo.recover_targets(torch.from_numpy(g["targets"]), (256, 320, 1)))
+    for f in range(len(g["count"])):
+        val._match_image(torch.from_numpy(g["det"][f, :g["count"][f]]) if g["count"][f] else None, rec[f])
+    for c in range(3):
+        val.match_list[c].sort(key=lambda x: x[0], reverse=True)
+    aps = [val._calculate_AP(c) for c in range(3)]
+    assert [float(a) for a in aps] == g["AP"].tolist()
+    assert val.target_num.tolist() == g["target_num"].tolist()
+    rng = np.random.default_rng(0)
+    for trial in range(50):
+        n = int(rng.integers(0, 40))
+        val.clear()
+        val.match_list[0] = [("k", bool(rng.integers(0, 2))) for _ in range(n)]
+        tp = sum(m[1] for m in val.match_list[0])
+        val.target_num[0] = tp + int(rng.integers(0, 5)) if n else int(rng.integers(0, 3))
+        want = vo.calculate_ap(val.match_list[0], val.target_num[0]) if n else 0
+        got = float(val._calculate_AP(0))
+        assert got == float(want) or (got != got and float(want) != float(want)), (trial, n)   # 0 targets and 0 TP: nan in both

@@ -497,3 +497,33 @@ def test_fp16_path_logits_and_boxes(yf, golden, dev, res):
     assert hh[0].dtype == torch.float16
     # here the BN statistics themselves were rounded to fp16 by .half() (as they would be in the reference module)
     assert np.abs(hh[0].float().cpu().numpy() - g["head_large"][:2]).max() < 1.5
+
+
+def test_validation_get_map_end_to_end(yf, models, golden, dev):
+    """`Validation.get_mAP` (validate.py:27-122) with the model, the decode and the NMS on the GPU against the
+    reference's own run on the same frames and synthetic targets (tests/golden/make_golden.py main_map).  The TP / FP
+    decisions and the per-class target counts must be the reference's; AP within 2e-3: the reference orders a class's matches
+    by the confidence PRINTED to 4 decimals, so last-bit differences between two fp32 evaluations of the net (and its own
+    shuffle order among equal printed values) can swap neighbours."""
+    import logging
+    from yolo_fastest_amd import validation as V
+    m, _, io = models[256]
+    g, gm = golden("golden_256"), golden("golden_map_256")
+    u8, targets = g["input_u8"], gm["targets"]
+
+    class Frames(torch.utils.data.Dataset):   # what the reference's DetectDataset yields; collate_fn divides by 255
+        def __len__(self): return len(u8)
+        def __getitem__(self, i): return u8[i][:, :, None].astype(np.float32) - 128.0, targets[i].copy()
+
+    params = {"train_params": {"batch_size": 4, "IOU_val_thre": 0.5},
+              "io_params": dict(io, class_names=["carrier", "defender", "destroyer"])}
+    losses = [V.YOLOLossV3(io["anchors"][i], io["num_cls"], io["input_shape"], dev) for i in range(2)]
+    torch.manual_seed(0)
+    val = V.Validation(params, logging.getLogger("yf-val"), Frames(), dev, losses)
+    mAP = float(val.get_mAP(m, 0))
+    assert val.target_num.tolist() == gm["target_num"].tolist()
+    for c in range(3):
+        assert len(val.match_list[c]) == len(gm[f"match_tp_{c}"])
+        assert sum(t for _, t in val.match_list[c]) == int(gm[f"match_tp_{c}"].sum())
+        assert abs(float(val._calculate_AP(c)) - gm["AP"][c]) < 2e-3
+    assert abs(mAP - float(gm["mAP"])) < 2e-3, (mAP, float(gm["mAP"]))

@@ -166,3 +166,17 @@ def test_validation_oracle_matches_reference(golden):
             assert (0 if d is None else d.shape[0]) == n
             if n:
                 assert np.array_equal(d.numpy(), gv[f"{tag}_det"][f, :n])
+
+
+def test_map_oracle_reproduces_reference_validation(golden):
+    """oracle/val_oracle.get_map (validate.py:27-122 restated) on the reference's own NMS output and the synthetic targets
+    reproduces the reference's Validation.get_mAP result exactly (tests/golden/make_golden.py main_map)."""
+    from oracle import val_oracle as vo
+    g = golden("golden_map_256")
+    dets = [torch.from_numpy(g["det"][f, :g["count"][f]]) if g["count"][f] else None for f in range(len(g["count"]))]
+    mAP, aps, tn, ml = vo.get_map(dets, torch.from_numpy(g["targets"]), 3, (256, 320, 1), 0.5)
+    assert mAP == float(g["mAP"])
+    assert [float(a) for a in aps] == g["AP"].tolist()
+    assert tn.tolist() == g["target_num"].tolist()
+    for c in range(3):
+        assert sum(m[1] for m in ml[c]) == int(g[f"match_tp_{c}"].sum()) and len(ml[c]) == len(g[f"match_tp_{c}"])

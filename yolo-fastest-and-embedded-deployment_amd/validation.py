@@ -72,3 +72,148 @@ def non_max_suppression(prediction, num_classes, conf_thres=0.5, nms_thres=0.4, 
     if max(counts) > kmax:
         raise OverflowError("more than kmax detections in an image")
     return [det[i, :n].clone() if n else None for i, n in enumerate(counts)]
+
+
+def collate_fn(batch):
+    """What the reference's DetectDataset.collate_fn does (dataloader/detect_dataset.py:106-117): stack (h,w,c) images and
+    (64,6) boxes, NHWC -> NCHW, divide the images by 255."""
+    import numpy as np
+    images = np.concatenate([[img] for img, _ in batch], axis=0).transpose(0, 3, 1, 2)
+    bboxes = np.concatenate([[box] for _, box in batch], axis=0)
+    return torch.from_numpy(images).div(255.0), torch.from_numpy(bboxes)
+
+
+class Validation:
+    """Mirror of the reference's `Validation` (src/model_training/validate.py:8-122): same constructor, `get_mAP(model,
+    epoch)`, `clear()`, same log lines.  Model forward, decode and NMS run on the GPU (this package's kernels, one batch at a
+    time); the matching and the AP arithmetic are the reference's host bookkeeping with its exact conventions:
+      * targets: normalised (xc, yc, w, h, cls, marker > 1) -> input-image corners (:112-122);
+      * a prediction matches the FIRST remaining same-class target with IoU (+1 pixel convention, general.py:29-52) > the
+        threshold; the matched target is removed (:62-70);
+      * each class's list is sorted by the PRINTED form of the confidence ('tensor(0.8714)': the reference stores
+        np.array([t[4], 'TP']), a string array, and sorts that, :77) -- 4 decimals, lexicographic, stable;
+      * recall is float32 (target_num is a float32 tensor), precision a Python float; equal consecutive recalls keep the
+        larger precision; AP = sum over the P-R points of (recall step) x (max precision from that point on) (:87-119).
+    `dataset` is anything a DataLoader accepts; items are ((h,w,c) image, (64,6) boxes) like DetectDataset's, batched with
+    `collate_fn` above (images / 255)."""
+
+    def __init__(self, params, logger, dataset, device, model_loss):
+        from torch.utils.data import DataLoader
+        self.logger = logger
+        self.model_loss = model_loss
+        self.device = device
+        self.bs = params["train_params"]["batch_size"]
+        self.input_shape = params["io_params"]["input_shape"]
+        self.num_cls = params["io_params"]["num_cls"]
+        self.cls_name = params["io_params"]["class_names"]
+        self.IOU_threshold = params["train_params"]["IOU_val_thre"]
+        self.conf_thres = params["io_params"]["conf_thre"]
+        self.nms_thres = params["io_params"]["nms_thre"]
+        self.dataloader = DataLoader(dataset, batch_size=self.bs, num_workers=0, drop_last=True, pin_memory=True, shuffle=True,
+                                     collate_fn=collate_fn)
+        self.target_num = torch.zeros((self.num_cls))
+        self.match_list = [[] for _ in range(self.num_cls)]
+
+    def clear(self):
+        self.match_list = [[] for _ in range(self.num_cls)]
+        self.target_num.zero_()
+
+    def _recover_targets(self, targets):
+        in_h, in_w = self.input_shape[0], self.input_shape[1]
+        t = targets.clone()
+        t[:, :, (0, 2)] = t[:, :, (0, 2)] * in_w
+        t[:, :, (1, 3)] = t[:, :, (1, 3)] * in_h
+        out = t.clone()
+        out[:, :, 0] = t[:, :, 0] - t[:, :, 2] / 2
+        out[:, :, 1] = t[:, :, 1] - t[:, :, 3] / 2
+        out[:, :, 2] = t[:, :, 0] + t[:, :, 2] / 2
+        out[:, :, 3] = t[:, :, 1] + t[:, :, 3] / 2
+        return out
+
+    @staticmethod
+    def _iou(t, targets):  # general.py:29-52, float32, one prediction against all remaining targets
+        ix1 = torch.max(t[0], targets[:, 0]); iy1 = torch.max(t[1], targets[:, 1])
+        ix2 = torch.min(t[2], targets[:, 2]); iy2 = torch.min(t[3], targets[:, 3])
+        inter = torch.clamp(ix2 - ix1 + 1, min=0) * torch.clamp(iy2 - iy1 + 1, min=0)
+        a1 = (t[2] - t[0] + 1) * (t[3] - t[1] + 1)
+        a2 = (targets[:, 2] - targets[:, 0] + 1) * (targets[:, 3] - targets[:, 1] + 1)
+        return inter / (a1 + a2 - inter + 1e-16)
+
+    def _match_image(self, img_pred, img_target):
+        """validate.py:47-74 for one image (host tensors): img_pred [n,7] NMS output or None, img_target [64,6] recovered."""
+        img_target = img_target[img_target[:, 5] > 1]
+        for t in img_target:
+            self.target_num[int(t[4])] += 1
+        if img_pred is None:
+            return
+        for c in img_pred[:, 6].unique():
+            target_c = img_target[img_target[:, 4] == c]
+            pred_c = img_pred[img_pred[:, 6] == c]
+            c = int(c)
+            for t in pred_c:
+                hit = False
+                if target_c.size(0):
+                    over = (self._iou(t, target_c) > self.IOU_threshold).nonzero()
+                    if over.numel():
+                        index = int(over[0])
+                        target_c = torch.cat((target_c[:index], target_c[index + 1:]), dim=0)
+                        hit = True
+                self.match_list[c].append((str(t[4]), hit))
+
+    def get_mAP(self, model, epoch):
+        self.clear()
+        model.eval()
+        bind(model)
+        with torch.no_grad():
+            for imgs, targets in self.dataloader:
+                targets = self._recover_targets(targets.float())                      # host: the bookkeeping stays on the CPU
+                imgs = imgs.to(self.device).float()
+                pred = model(imgs)
+                output = torch.cat([self.model_loss[i](p) for i, p in enumerate(pred)], 1)
+                output = non_max_suppression(output, self.num_cls, conf_thres=self.conf_thres, nms_thres=self.nms_thres)
+                output = [None if o is None else o.cpu() for o in output]
+                for img_id, img_pred in enumerate(output):
+                    self._match_image(img_pred, targets[img_id])
+            for c in range(self.num_cls):
+                self.match_list[c].sort(key=lambda x: x[0], reverse=True)
+            mAP = 0
+            self.logger.info("—————— epoch: %d validation results —————" % (epoch))
+            for c in range(self.num_cls):
+                AP = self._calculate_AP(c)
+                self.logger.info("class: %s, target_num = %d, AP = %.3f" % (self.cls_name[c], self.target_num[c], AP))
+                mAP += AP
+            mAP /= self.num_cls
+            self.logger.info("mean AP: %.3f" % (mAP))
+            self.logger.info("——————————————————————————")
+        return mAP
+
+    def _calculate_AP(self, cls):
+        """validate.py:87-119 in one pass (running TP / FP counts instead of the reference's re-count per prefix)."""
+        import numpy as np
+        pr = []
+        tp = fp = 0
+        for _, is_tp in self.match_list[cls]:
+            if is_tp:
+                tp += 1
+            else:
+                fp += 1
+            fn = self.target_num[cls] - tp
+            if fn < 0:
+                self.logger.error("error: FN less than 0!")
+            precision = tp / (tp + fp)
+            recall = float(tp / (tp + fn))          # float32 division, like the reference's tensor arithmetic
+            if pr and recall == pr[-1][1]:
+                if precision > pr[-1][0]:
+                    pr[-1][0] = precision
+            else:
+                pr.append([precision, recall])
+        ap, pre = 0, 0
+        best = 0.0
+        suffix_max = [0.0] * len(pr)
+        for i in range(len(pr) - 1, -1, -1):
+            best = max(best, pr[i][0])
+            suffix_max[i] = best
+        for i in range(len(pr)):
+            ap += (np.float64(pr[i][1]) - pre) * suffix_max[i]
+            pre = np.float64(pr[i][1])
+        return ap
