@@ -213,3 +213,18 @@ def test_validation_bookkeeping_matches_the_oracle(golden):
         want = vo.calculate_ap(val.match_list[0], val.target_num[0]) if n else 0
         got = float(val._calculate_AP(0))
         assert got == float(want) or (got != got and float(want) != float(want)), (trial, n)   # 0 targets and 0 TP: nan in both
+
+
+def test_onnx_export_gives_the_same_state_dict(sd):
+    """the reference's shipped ONNX export (models/onnx/256x320, copied to tests/golden/onnx) read with the
+    built-in protobuf reader is the shipped .pth, key for key and bit for bit, hence the same blob."""
+    from yolo_fastest_amd import packer
+    got = packer.read_onnx(os.path.join(ROOT, "tests", "golden", "onnx", "yolo_fastest_256x320.onnx"))
+    assert set(got) == set(sd)
+    for k, v in sd.items():
+        if v.is_floating_point():
+            assert torch.equal(v.float().cpu(), got[k]), k
+    assert packer.pack_state_dict(got) == packer.pack_state_dict(sd)
+    # structure checks: a truncated graph is refused
+    with pytest.raises(Exception):
+        packer.read_onnx(os.path.join(ROOT, "tests", "golden", "ncnn", "yolo_fastest_256x320.param"))

@@ -137,6 +137,12 @@ class YoloFastest(nn.Module):
         self._blob_from_ncnn = True
         return self
 
+    def load_onnx(self, path):
+        """Alternative weight source: the reference's ONNX export (models/onnx/**).  Unlike the ncnn file it still has the
+        un-folded BatchNorm parameters, so this is a plain strict load_state_dict of the 508 keys read from the file."""
+        self.load_state_dict(packer.read_onnx(path, self.num_out, self.input_channel))
+        return self
+
     def refresh(self):
         """Re-pack after editing parameters in place (load_state_dict / .to() do it automatically)."""
         self._invalidate()

@@ -198,6 +198,140 @@ def read_ncnn(param_path, bin_path):
     return out
 
 
+# ---- ONNX (models/onnx/**: the reference's torch.onnx export, BN not folded, raw fp32 initializers) -------------------------
+# A minimal protobuf wire-format reader: the `onnx` package is not a dependency.  Field numbers from onnx.proto3:
+# ModelProto.graph = 7; GraphProto.node = 1, .initializer = 5; NodeProto.input = 1, .output = 2, .op_type = 4, .attribute = 5;
+# AttributeProto.name = 1, .f = 2, .i = 3, .ints = 8; TensorProto.dims = 1, .data_type = 2, .float_data = 4, .name = 8, .raw_data = 9.
+
+def _pb_varint(b, i):
+    r = s = 0
+    while True:
+        c = b[i]; i += 1
+        r |= (c & 0x7F) << s; s += 7
+        if not c & 0x80:
+            return r, i
+
+
+def _pb_fields(b):
+    i, n = 0, len(b)
+    while i < n:
+        key, i = _pb_varint(b, i)
+        f, wt = key >> 3, key & 7
+        if wt == 0:
+            v, i = _pb_varint(b, i)
+        elif wt == 1:
+            v = b[i:i + 8]; i += 8
+        elif wt == 2:
+            ln, i = _pb_varint(b, i)
+            v = b[i:i + ln]; i += ln
+        elif wt == 5:
+            v = b[i:i + 4]; i += 4
+        else:
+            raise ValueError("unsupported protobuf wire type %d" % wt)
+        yield f, wt, v
+
+
+def _pb_ints(wt, v):
+    if wt == 0:
+        return [v]
+    out, j = [], 0
+    while j < len(v):
+        d, j = _pb_varint(v, j)
+        out.append(d)
+    return out
+
+
+def _onnx_graph(path):
+    with open(path, "rb") as f:
+        data = f.read()
+    graph = None
+    for f_, wt, v in _pb_fields(data):
+        if f_ == 7 and wt == 2:
+            graph = v
+    if graph is None:
+        raise ValueError("not an ONNX ModelProto (no graph)")
+    nodes, inits = [], {}
+    for f_, wt, v in _pb_fields(graph):
+        if f_ == 1:
+            node = {"op": None, "in": [], "out": [], "attr": {}}
+            for f2, w2, v2 in _pb_fields(v):
+                if f2 == 1: node["in"].append(bytes(v2).decode())
+                elif f2 == 2: node["out"].append(bytes(v2).decode())
+                elif f2 == 4: node["op"] = bytes(v2).decode()
+                elif f2 == 5:
+                    name, val = None, None
+                    for f3, w3, v3 in _pb_fields(v2):
+                        if f3 == 1: name = bytes(v3).decode()
+                        elif f3 == 2: val = struct.unpack("<f", v3)[0]
+                        elif f3 == 3: val = v3
+                        elif f3 == 8: val = (val or []) + _pb_ints(w3, v3)
+                    node["attr"][name] = val
+            nodes.append(node)
+        elif f_ == 5:
+            name, dims, dt, arr = None, [], None, None
+            for f2, w2, v2 in _pb_fields(v):
+                if f2 == 1: dims += _pb_ints(w2, v2)
+                elif f2 == 2: dt = v2
+                elif f2 == 8: name = bytes(v2).decode()
+                elif f2 == 9: arr = np.frombuffer(bytes(v2), np.float32) if dt in (None, 1) else bytes(v2)
+                elif f2 == 4: arr = np.frombuffer(bytes(v2), np.float32) if w2 == 2 else np.append(arr if arr is not None else [], struct.unpack("<f", v2)[0])
+            if dt == 1 and arr is not None:
+                inits[name] = np.asarray(arr, np.float32).reshape(dims).copy()
+    return nodes, inits
+
+
+def read_onnx(path, num_out=24, input_channel=1):
+    """ONNX file -> the reference's 508-key state-dict (torch tensors), so that `model.load_state_dict(read_onnx(p))` is the
+    ONNX twin of `torch.load(pth)`.  The Conv / ConvTranspose nodes are matched to the YoloFastest layer table by order
+    (the export traces forward(), the table is in forward order) and checked: weight shape, stride, group, a
+    BatchNormalization on every non-head layer (epsilon must be the 1e-5 this package folds with), Relu where the table has one."""
+    nodes, inits = _onnx_graph(path)
+    table = layer_table(num_out, input_channel)
+    consumers = {}
+    for n in nodes:
+        for i in n["in"]:
+            consumers.setdefault(i, []).append(n)
+    convs = [n for n in nodes if n["op"] in ("Conv", "ConvTranspose")]
+    if len(convs) != len(table):
+        raise RuntimeError("ONNX model has %d convolutions, YoloFastest has %d" % (len(convs), len(table)))
+    sd = {}
+    for (name, kind, cin, cout, k, stride, relu), n in zip(table, convs):
+        w = inits.get(n["in"][1])
+        if w is None:
+            raise RuntimeError("ONNX conv for %s: weight %s is not an fp32 initializer" % (name, n["in"][1]))
+        group = int(n["attr"].get("group", 1) or 1)
+        strides = n["attr"].get("strides", [1, 1])
+        want = {KIND_PW: (cout, cin, 1, 1), KIND_HEAD: (cout, cin, 1, 1), KIND_DENSE: (cout, cin, k, k), KIND_DW: (cout, 1, k, k),
+                KIND_DECONV: (cin, cout, 2, 2)}[kind]
+        ok = (tuple(w.shape) == want and list(strides) == [stride, stride] and group == (cout if kind == KIND_DW else 1)
+              and (n["op"] == "ConvTranspose") == (kind == KIND_DECONV))
+        if not ok:
+            raise RuntimeError("ONNX node %s %s (weight %s, strides %s, group %d) does not match YoloFastest layer %s"
+                               % (n["op"], n["out"][0], w.shape, strides, group, name))
+        out, nxt = n["out"][0], consumers.get(n["out"][0], [])
+        if kind == KIND_HEAD:
+            if len(n["in"]) < 3:
+                raise RuntimeError("ONNX head conv %s has no bias" % name)
+            sd[name + ".weight"] = torch.from_numpy(w.copy())
+            sd[name + ".bias"] = torch.from_numpy(inits[n["in"][2]].copy())
+            continue
+        if len(nxt) != 1 or nxt[0]["op"] != "BatchNormalization":
+            raise RuntimeError("ONNX layer %s: expected a BatchNormalization after the convolution (an export with folded "
+                               "BN is not the reference's)" % name)
+        bn = nxt[0]
+        eps = bn["attr"].get("epsilon", 1e-5)
+        if abs(eps - BN_EPS) > 1e-12:
+            raise RuntimeError("ONNX layer %s: BatchNormalization epsilon %g, expected %g" % (name, eps, BN_EPS))
+        has_relu = any(c["op"] == "Relu" for c in consumers.get(bn["out"][0], []))
+        if has_relu != bool(relu):
+            raise RuntimeError("ONNX layer %s: Relu %s, the YoloFastest layer has relu=%d" % (name, has_relu, relu))
+        sd[name + ".0.weight"] = torch.from_numpy(w.copy())
+        for key, src in zip(("weight", "bias", "running_mean", "running_var"), bn["in"][1:5]):
+            sd[name + ".1." + key] = torch.from_numpy(inits[src].copy())
+        sd[name + ".1.num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+    return sd
+
+
 def pack_ncnn(param_path, bin_path, num_out=24, input_channel=1, num_anchors=3, num_cls=3):
     """ncnn .param/.bin -> the same blob pack_state_dict() produces (the weights are already BN-folded).
     The weighted layers are matched to the YoloFastest layer table by order and checked shape by shape."""
