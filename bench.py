@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="frames per pass of the layer chain (0 = whole batch)")
     ap.add_argument("--lanes", type=int, default=2, help="concurrent streams over the chunks of the batch (1..4)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"], help="f16 = BASELINE configs[2]: fp16 storage + fp16 MFMA")
+    ap.add_argument("--frames", default="noise", choices=["noise", "fixtures"],
+                    help="noise: u8 ~ U{0..255} (BASELINE configs[1]); fixtures: the reference's 20 bundled frames tiled to the "
+                         "batch (SURVEY.md 8(d) config 2 'realistic': dark IR frames, >= 1 box per frame)")
     ap.add_argument("--kmax", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-ops", default=None, help="write the launch names of one forward pass to this JSON file")
@@ -111,7 +114,11 @@ def main():
                                 io["input_shape"]).bind(model)
     H, W = io["input_shape"][:2]
     g = torch.Generator(device="cpu").manual_seed(rank)
-    u8 = torch.randint(0, 256, (args.batch, H, W), generator=g, dtype=torch.uint8)
+    if args.frames == "fixtures":
+        fx = np.load(os.path.join(ROOT, "tests", "golden", "golden_%d.npz" % args.res))["input_u8"]
+        u8 = torch.from_numpy(fx[np.arange(args.batch) % len(fx)])
+    else:
+        u8 = torch.randint(0, 256, (args.batch, H, W), generator=g, dtype=torch.uint8)
     x = ((u8.float() - 128.0) / 255.0)[:, None].contiguous().to(dev)   # resident in HBM before timing
     n_total = args.batch * world
 
@@ -179,10 +186,11 @@ def main():
                       if args.res == 256 else "frames/sec end-to-end, 640x512",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "ms_per_frame": round(1e3 * elapsed / args.steps / n_total, 6),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic" if args.frames == "noise" else "the reference's 20 bundled frames tiled to the batch",
             "config": {"workload": f"YOLO-Fastest {W}x{H} batch={args.batch} fp32 per GPU, synthetic uniform-u8 frames "
-                                   f"(BASELINE.json configs[1])" if args.res == 256 and args.batch == 256 and args.dtype == "f32" else
-                                   f"YOLO-Fastest {W}x{H} batch={args.batch} {args.dtype} per GPU, synthetic frames",
+                                   f"(BASELINE.json configs[1])" if args.res == 256 and args.batch == 256 and args.dtype == "f32" and args.frames == "noise" else
+                                   f"YOLO-Fastest {W}x{H} batch={args.batch} {args.dtype} per GPU, {args.frames} frames",
                        "global_batch": n_total, "weights": wname, "kmax": args.kmax, "chunk": args.chunk, "lanes": args.lanes,
                        "parallelism": f"dp{world} (frames sharded, one RCCL all-gather of box records)" if world > 1 else "single GPU",
                        "survivors_per_frame_mean": round(float(np.clip(counts, 0, None).mean()), 3)},
