@@ -45,9 +45,11 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
     static_assert((TH * TW) % 16 == 0 && C % 16 == 0 && N % 16 == 0 && CHUNK == mdw_chunk_floats(N, H16), "shape");
     static_assert(HEADN == 0 || HEADN <= 32, "head width");
     extern __shared__ __attribute__((aligned(16))) float mdw_smem[];
-    float* E = mdw_smem;           // [4][EPL][4]
-    float* WL = E + 16 * EPL;      // weight stream
-    float* T = WL + WFLOATS;       // [min(NWAVE,MTO)][16][TP]   (HEADN only)
+    float* E = mdw_smem;           // [2][4][EPL][4]: chunk c is computed from buffer c & 1 while chunk c + 1 is filled into the other
+    float* WL = E + 2 * 16 * EPL;  // weight stream
+    // [min(NWAVE,MTO)][16][TP] (HEADN only): reuses the E buffers after the chunk loop's last barrier when it fits there
+    constexpr bool T_IN_E = (NWAVE < MTO ? NWAVE : MTO) * 16 * TP <= 2 * 16 * EPL;
+    float* T = T_IN_E ? E : WL + WFLOATS;
 
     const int b = blockIdx.x;
     const int tx = b % a.tiles_x, ty = (b / a.tiles_x) % a.tiles_y, n = b / (a.tiles_x * a.tiles_y);
@@ -92,23 +94,28 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
         rp0[i] = (oy + 2) * RW + ox + 2;
     }
 
-#pragma unroll 1
-    for (int c = 0; c < NCH; ++c) {
-        // ---- fill E with this chunk (prefetched), then request the next chunk ----
+    auto fill = [&](float* Eb) {
 #pragma unroll
         for (int m = 0; m < NLD; ++m) {
             const int id = threadIdx.x + m * NTHR;
-            if (goff[m] != -2) *reinterpret_cast<float4*>(&E[((id & 3) * EPL + (id >> 2)) * 4]) = pf[m];
+            if (goff[m] != -2) *reinterpret_cast<float4*>(&Eb[((id & 3) * EPL + (id >> 2)) * 4]) = pf[m];
         }
-        __syncthreads();
-        if (c + 1 < NCH) prefetch(c + 1);
+    };
+    fill(E);
+    __syncthreads();
+    if (NCH > 1) prefetch(1);
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        // ONE barrier per chunk: the next chunk (requested a whole chunk of compute ago) is written into the other buffer
+        // after this chunk's arithmetic, and the chunk after it is requested right after the barrier
+        const float* Ec = E + (c & 1) * 16 * EPL;
         // ---- depthwise 5x5 of channels 4q..4q+3 at this lane's output pixels (taps outer: one weight read per tap) ----
         const float* wc = WL + c * CHUNK;
         const float4 bd = *reinterpret_cast<const float4*>(wc + OFF_BD + 4 * q);
         float d[MTOW][4];
 #pragma unroll
         for (int i = 0; i < MTOW; ++i) { d[i][0] = bd.x; d[i][1] = bd.y; d[i][2] = bd.z; d[i][3] = bd.w; }
-        const float4* e4 = reinterpret_cast<const float4*>(E) + q * EPL;
+        const float4* e4 = reinterpret_cast<const float4*>(Ec) + q * EPL;
 #pragma unroll
         for (int ky = 0; ky < 5; ++ky)
 #pragma unroll
@@ -154,7 +161,9 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
                 }
             }
         }
+        if (c + 1 < NCH) fill(E + ((c + 1) & 1) * 16 * EPL);
         __syncthreads();
+        if (c + 2 < NCH) prefetch(c + 2);
     }
 
     // ---- epilogue ----
@@ -236,8 +245,8 @@ static int launch_mdw_t(MdwArgs a, int Nf, hipStream_t s)
     a.tiles_y = (a.H + TH - 1) / TH;
     a.tiles_x = (a.W + TW - 1) / TW;
     constexpr int NRP = (TH + 4) * (TW + 4), MTO = TH * TW / 16;
-    constexpr size_t lds = ((size_t)16 * (((NRP + 7) / 8) * 8 + 2) + mdw_stream_floats(C, N, HEADN, sizeof(T) == 2) +
-                            (HEADN ? (size_t)(NWAVE < MTO ? NWAVE : MTO) * 16 * (N + 4) : 0)) * sizeof(float);
+    constexpr size_t e_floats = (size_t)2 * 16 * (((NRP + 7) / 8) * 8 + 2), t_floats = HEADN ? (size_t)(NWAVE < MTO ? NWAVE : MTO) * 16 * (N + 4) : 0;
+    constexpr size_t lds = (e_floats + mdw_stream_floats(C, N, HEADN, sizeof(T) == 2) + (t_floats <= e_floats ? 0 : t_floats)) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done = false;
     if (lds > 64 * 1024 && !attr_done) {
