@@ -17,6 +17,10 @@
 
 #include "yf_kernels.h"
 
+#ifndef YF_FB_DW_UNROLL
+#define YF_FB_DW_UNROLL 1
+#endif
+
 namespace yf {
 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
@@ -215,7 +219,10 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
         __syncthreads();
         YF_STAMP_AT(2)
         // ---------------- depthwise 3x3 from LDS + projection into registers ----------------
-#pragma unroll
+        // NOT fully unrolled: unrolled, the scalar loads of all EC channels' weights are hoisted to the top and, with the
+        // expansion's, exceed the SGPR file -- the compiler then spills SGPRs to VGPR lanes and 30-50 % of the VALU
+        // instructions of the stride-2 kernels were v_readlane / v_writelane (tools/isa_stats.py)
+#pragma unroll YF_FB_DW_UNROLL
         for (int c = 0; c < EC; ++c) {
             const float* Ec = E + c * PLANE + (tyb * BH * S) * RWP + txb * BW * S;
             float win[WR][WC];
