@@ -34,6 +34,8 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
     constexpr int NTHR = NWAVE * 64;
     constexpr int RH = TH + 4, RW = TW + 4, NRP = RH * RW;
     constexpr int MTO = (TH * TW) / 16, MTOW = (MTO + NWAVE - 1) / NWAVE;
+    constexpr bool EVEN = MTO % NWAVE == 0;  // every wave owns MTOW tiles: no wave-uniform branches in the chunk loop (with them the
+                                             // fp16 build copied all accumulators around every branch: 1300 v_mov of 1900 VALU instructions)
     constexpr int EPL = ((NRP + 7) / 8) * 8 + 2;  // pixels per 4-channel plane, == 2 (mod 8): conflict-free b128 fills
     constexpr int NT = N / 16, NCH = C / 16;
     constexpr int OFF_BD = 400, OFF_W = 416, CHUNK = 416 + (H16 ? NT * 128 : 4 * NT * 64);
@@ -45,11 +47,9 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
     static_assert((TH * TW) % 16 == 0 && C % 16 == 0 && N % 16 == 0 && CHUNK == mdw_chunk_floats(N, H16), "shape");
     static_assert(HEADN == 0 || HEADN <= 32, "head width");
     extern __shared__ __attribute__((aligned(16))) float mdw_smem[];
-    float* E = mdw_smem;           // [2][4][EPL][4]: chunk c is computed from buffer c & 1 while chunk c + 1 is filled into the other
-    float* WL = E + 2 * 16 * EPL;  // weight stream
-    // [min(NWAVE,MTO)][16][TP] (HEADN only): reuses the E buffers after the chunk loop's last barrier when it fits there
-    constexpr bool T_IN_E = (NWAVE < MTO ? NWAVE : MTO) * 16 * TP <= 2 * 16 * EPL;
-    float* T = T_IN_E ? E : WL + WFLOATS;
+    float* E = mdw_smem;           // [4][EPL][4]
+    float* WL = E + 16 * EPL;      // weight stream
+    float* T = WL + WFLOATS;       // [min(NWAVE,MTO)][16][TP]   (HEADN only)
 
     const int b = blockIdx.x;
     const int tx = b % a.tiles_x, ty = (b / a.tiles_x) % a.tiles_y, n = b / (a.tiles_x * a.tiles_y);
@@ -94,28 +94,23 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
         rp0[i] = (oy + 2) * RW + ox + 2;
     }
 
-    auto fill = [&](float* Eb) {
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        // ---- fill E with this chunk (prefetched), then request the next chunk ----
 #pragma unroll
         for (int m = 0; m < NLD; ++m) {
             const int id = threadIdx.x + m * NTHR;
-            if (goff[m] != -2) *reinterpret_cast<float4*>(&Eb[((id & 3) * EPL + (id >> 2)) * 4]) = pf[m];
+            if (goff[m] != -2) *reinterpret_cast<float4*>(&E[((id & 3) * EPL + (id >> 2)) * 4]) = pf[m];
         }
-    };
-    fill(E);
-    __syncthreads();
-    if (NCH > 1) prefetch(1);
-#pragma unroll 1
-    for (int c = 0; c < NCH; ++c) {
-        // ONE barrier per chunk: the next chunk (requested a whole chunk of compute ago) is written into the other buffer
-        // after this chunk's arithmetic, and the chunk after it is requested right after the barrier
-        const float* Ec = E + (c & 1) * 16 * EPL;
+        __syncthreads();
+        if (c + 1 < NCH) prefetch(c + 1);
         // ---- depthwise 5x5 of channels 4q..4q+3 at this lane's output pixels (taps outer: one weight read per tap) ----
         const float* wc = WL + c * CHUNK;
         const float4 bd = *reinterpret_cast<const float4*>(wc + OFF_BD + 4 * q);
         float d[MTOW][4];
 #pragma unroll
         for (int i = 0; i < MTOW; ++i) { d[i][0] = bd.x; d[i][1] = bd.y; d[i][2] = bd.z; d[i][3] = bd.w; }
-        const float4* e4 = reinterpret_cast<const float4*>(Ec) + q * EPL;
+        const float4* e4 = reinterpret_cast<const float4*>(E) + q * EPL;
 #pragma unroll
         for (int ky = 0; ky < 5; ++ky)
 #pragma unroll
@@ -123,7 +118,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
                 const float4 w = *reinterpret_cast<const float4*>(wc + (ky * 5 + kx) * 16 + 4 * q);
 #pragma unroll
                 for (int i = 0; i < MTOW; ++i) {
-                    if (wave + i * NWAVE < MTO) {
+                    if (EVEN || wave + i * NWAVE < MTO) {
                         const float4 v = e4[rp0[i] + (ky - 2) * RW + (kx - 2)];
                         d[i][0] = fmaf(v.x, w.x, d[i][0]); d[i][1] = fmaf(v.y, w.y, d[i][1]);
                         d[i][2] = fmaf(v.z, w.z, d[i][2]); d[i][3] = fmaf(v.w, w.w, d[i][3]);
@@ -137,7 +132,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
             for (int nt = 0; nt < NT; ++nt) w2h[nt] = reinterpret_cast<const f16x4*>(wc + OFF_W)[nt * 64 + lane];
 #pragma unroll
             for (int i = 0; i < MTOW; ++i) {
-                if (wave + i * NWAVE < MTO) {
+                if (EVEN || wave + i * NWAVE < MTO) {
                     const f16x4 dh = f16x4{(half_t)fmaxf(d[i][0], 0.f), (half_t)fmaxf(d[i][1], 0.f), (half_t)fmaxf(d[i][2], 0.f),
                                            (half_t)fmaxf(d[i][3], 0.f)};
 #pragma unroll
@@ -152,7 +147,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
                 for (int nt = 0; nt < NT; ++nt) w2f[nt] = wc[OFF_W + (j * NT + nt) * 64 + lane];
 #pragma unroll
                 for (int i = 0; i < MTOW; ++i) {
-                    if (wave + i * NWAVE < MTO) {
+                    if (EVEN || wave + i * NWAVE < MTO) {
                         const float dj = fmaxf(d[i][j], 0.f);
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
@@ -161,9 +156,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
                 }
             }
         }
-        if (c + 1 < NCH) fill(E + ((c + 1) & 1) * 16 * EPL);
         __syncthreads();
-        if (c + 2 < NCH) prefetch(c + 2);
     }
 
     // ---- epilogue ----
@@ -176,7 +169,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
 #pragma unroll
             for (int i = 0; i < MTOW; ++i) {
                 const int mo = wave + i * NWAVE;
-                if (mo >= MTO) continue;
+                if (!EVEN && mo >= MTO) continue;
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int op = mo * 16 + 4 * q + reg;
@@ -194,7 +187,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
 #pragma unroll
         for (int i = 0; i < MTOW; ++i) {  // (unrolled: a runtime-indexed acc[] would live in scratch)
             const int mo = wave + i * NWAVE;
-            if (mo >= MTO) continue;
+            if (!EVEN && mo >= MTO) continue;
             // C fragment (+bias) -> wave-private tile [16 px][N] -> A fragments of the head GEMM
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -245,8 +238,8 @@ static int launch_mdw_t(MdwArgs a, int Nf, hipStream_t s)
     a.tiles_y = (a.H + TH - 1) / TH;
     a.tiles_x = (a.W + TW - 1) / TW;
     constexpr int NRP = (TH + 4) * (TW + 4), MTO = TH * TW / 16;
-    constexpr size_t e_floats = (size_t)2 * 16 * (((NRP + 7) / 8) * 8 + 2), t_floats = HEADN ? (size_t)(NWAVE < MTO ? NWAVE : MTO) * 16 * (N + 4) : 0;
-    constexpr size_t lds = (e_floats + mdw_stream_floats(C, N, HEADN, sizeof(T) == 2) + (t_floats <= e_floats ? 0 : t_floats)) * sizeof(float);
+    constexpr size_t lds = ((size_t)16 * (((NRP + 7) / 8) * 8 + 2) + mdw_stream_floats(C, N, HEADN, sizeof(T) == 2) +
+                            (HEADN ? (size_t)(NWAVE < MTO ? NWAVE : MTO) * 16 * (N + 4) : 0)) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done = false;
     if (lds > 64 * 1024 && !attr_done) {
@@ -262,10 +255,10 @@ static int launch_mdw_t(MdwArgs a, int Nf, hipStream_t s)
 
 //      (c, n, head, TH, TW, waves)
 #define YF_MDW_SHAPES(MD)                                            \
-    MD(96, 128, 0, 8, 10, 8)    /* conv5_3 -> conv5_4            @ H/32 */ \
-    MD(128, 128, 24, 8, 10, 8)  /* conv5_5 -> conv5_6 -> head_5  @ H/32 */ \
-    MD(96, 96, 0, 16, 20, 8)    /* conv4_1_2 -> conv4_1_3        @ H/16 */ \
-    MD(96, 96, 24, 16, 20, 8)   /* conv4_1_4 -> conv4_1_5 -> head_4      */
+    MD(96, 128, 0, 8, 10, 5)    /* conv5_3 -> conv5_4            @ H/32 */ \
+    MD(128, 128, 24, 8, 10, 5)  /* conv5_5 -> conv5_6 -> head_5  @ H/32 */ \
+    MD(96, 96, 0, 16, 20, 10)   /* conv4_1_2 -> conv4_1_3        @ H/16 */ \
+    MD(96, 96, 24, 16, 20, 10)  /* conv4_1_4 -> conv4_1_5 -> head_4      */
 
 int launch_mdw(int c, int n, int headn, const MdwArgs& a, int Nf, hipStream_t s, int dtype)
 {
