@@ -199,11 +199,16 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
     }
 
     int cur = 0;  // element offset of the buffer phase 2 reads
+    // The scalar bookkeeping of the NEXT iteration (one tile decode with two integer divisions, the image window, the load
+    // origin) is computed inside this iteration's k groups 10..12, in the shadow of MFMA issue, and carried over: at the top of
+    // an iteration, where both waves of a SIMD arrive together from the barrier and the matrix pipe is idle, nothing is left to do.
+    Tile c = decode(t);                                    // the tile of phase 2 (and of the output store)
+    Win w1 = window(decode(t + step));                     // the tile phase 1 prepares during the iteration
+    Tile tl = decode(t + 2 * step);                        // the tile whose input elements are requested during the iteration
+    long off2 = origin(tl) - in;
+    Tile c_n = c; Win w1_n = w1; Tile tl_n = tl; long off2_n = off2;
     for (; t < total; t += step) {
-        const Tile c = decode(t);
-        const Win w1 = window(decode(t + step));              // the tile phase 1 prepares during this iteration
-        long off2 = origin(decode(t + 2 * step)) - in;        // the tile whose input elements are requested during this iteration
-        asm volatile("" : "+s"(off2));  // computed here, once: without this the scalar tile arithmetic is re-done before every load
+        asm volatile("" : "+s"(off2));  // a plain SGPR value from here on (otherwise the origin arithmetic is re-done before every load)
         const TT* const o2 = in + off2;
         const TT* const Rc = R + cur;
         TT* const Rn = R + (BUF - cur);
@@ -237,6 +242,9 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
                 p1_store(g / 2, d, Rn, w1);
                 xin[g / 2] = ld1<TT>(o2 + vo[g / 2]);
             }
+            if (g == 10) { c_n = decode(t + step); w1_n = window(tl); }
+            if (g == 11) { tl_n = decode(t + 3 * step); }
+            if (g == 12) { off2_n = origin(tl_n) - in; }
             __builtin_amdgcn_sched_barrier(0);  // keeps the one-group-ahead LDS read where it is (hoisting all 14 costs 56 VGPRs)
             xc = xn;
         }
@@ -264,6 +272,7 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
         }
         __syncthreads();  // buffer `cur` is free for the tile after next; the other one is complete
         cur = BUF - cur;
+        c = c_n; w1 = w1_n; tl = tl_n; off2 = off2_n;
     }
 }
 
