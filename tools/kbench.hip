@@ -215,7 +215,9 @@ int main(int argc, char** argv)
     if (on("mres")) {
         printf("--- MFMA residual blocks ---\n");
         bench_mres<16, 96, 16, true, 16, 20, 4>("16/96 s8", N, 32, 40);
+        bench_mres<16, 96, 16, true, 16, 20, 5>("16/96 s8 (25 / 20 tiles: even)", N, 32, 40);
         bench_mres<16, 96, 16, true, 16, 20, 8>("16/96 s8", N, 32, 40);
+        bench_mres<16, 96, 16, true, 16, 20, 10>("16/96 s8", N, 32, 40);
         bench_mres<16, 96, 16, true, 32, 20, 8>("16/96 s8", N, 32, 40);
         bench_mres<16, 96, 16, true, 16, 40, 8>("16/96 s8", N, 32, 40);
         bench_mres<16, 96, 16, true, 8, 20, 4>("16/96 s8", N, 32, 40);

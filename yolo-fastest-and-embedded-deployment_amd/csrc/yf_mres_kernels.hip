@@ -41,6 +41,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
     constexpr int RH = (TH - 1) * S + 3, RW = (TW - 1) * S + 3, NRP = RH * RW;
     constexpr int MTR = (NRP + 15) / 16, MTO = (TH * TW) / 16;
     constexpr int MTRW = (MTR + NWAVE - 1) / NWAVE, MTOW = (MTO + NWAVE - 1) / NWAVE;
+    constexpr bool EVEN_R = MTR % NWAVE == 0, EVEN_O = MTO % NWAVE == 0;  // every wave owns the same number of tiles: no branches
     constexpr int XP = CIN + 4;                           // X row pitch: conflict-free b128/b64 fragment reads
     constexpr int EPL = ((MTR * 16 + 7) / 8) * 8 + 1;     // pixels per 4-channel plane, == 1 (mod 8): conflict-free writes
     constexpr bool H16 = sizeof(T) == 2;  // fp16 storage: the pointwise GEMMs run on v_mfma_f32_16x16x16_f16 (4 k-steps each)
@@ -154,7 +155,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
 #pragma unroll
         for (int i = 0; i < MTRW; ++i) {
             const int mt = wave + i * NWAVE;
-            if (mt < MTR) {
+            if (EVEN_R || mt < MTR) {
                 f32x4 cf = f32x4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (H16) {
 #pragma unroll
@@ -178,7 +179,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
 #pragma unroll
         for (int i = 0; i < MTOW; ++i) {
             const int mo = wave + i * NWAVE;
-            if (mo < MTO) {
+            if (EVEN_O || mo < MTO) {
                 const float4* e = reinterpret_cast<const float4*>(E) + q * EPL + rp0[i];
                 float d[4] = {bd.x, bd.y, bd.z, bd.w};
 #pragma unroll
@@ -220,7 +221,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
 #pragma unroll
         for (int i = 0; i < MTOW; ++i) {
             const int mo = wave + i * NWAVE;
-            if (mo >= MTO) continue;
+            if (!EVEN_O && mo >= MTO) continue;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int op = mo * 16 + 4 * q + reg;
