@@ -140,6 +140,7 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
     t0 = time.perf_counter()
+    pending = None  # the exchange of step k runs on RCCL's stream while step k + 1 computes; all K exchanges end inside the timed region
     for k in range(args.steps):
         ev[k][0].record()
         with torch.no_grad():
@@ -148,7 +149,11 @@ def main():
         raw = post.detect_raw(pred, kmax=args.kmax)
         ev[k][2].record()
         if world > 1:
-            raw = yfd.all_gather_detections(raw, n_total)
+            if pending is not None:
+                gathered = pending.wait()
+            pending = yfd.all_gather_detections_async(raw, n_total)
+    if pending is not None:
+        raw = pending.wait()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()

@@ -46,6 +46,9 @@ def _worker(rank, world, port, n_total, kmax, q):
     lo, hi = yfd.shard_range(n_total, rank, world)
     mine = {k: v[lo:hi].contiguous() for k, v in full.items()}
     got = yfd.all_gather_detections(mine, n_total)
+    pending = yfd.all_gather_detections_async(mine, n_total)   # the overlapped form bench.py uses
+    got2 = pending.wait()
+    assert all(torch.equal(got[k], got2[k]) for k in got)
     ok = all(torch.equal(got[k], full[k]) for k in full)
     q.put((rank, ok))
     dist.destroy_process_group()

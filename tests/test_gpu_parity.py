@@ -527,3 +527,28 @@ def test_validation_get_map_end_to_end(yf, models, golden, dev):
         assert sum(t for _, t in val.match_list[c]) == int(gm[f"match_tp_{c}"].sum())
         assert abs(float(val._calculate_AP(c)) - gm["AP"][c]) < 2e-3
     assert abs(mAP - float(gm["mAP"])) < 2e-3, (mAP, float(gm["mAP"]))
+
+
+def test_rccl_gather_path_single_rank(models, golden, dev):
+    """the exchange step on the real backend.  The box has one GPU, so this is a 1-rank RCCL group: it exercises
+    exactly the calls bench.py / dist.all_gather_detections make with backend "nccl" (init with device_id, all_gather_into_tensor of
+    the packed int32 records) -- the 2-rank semantics (padding, frame order) are covered on gloo in tests/test_dist_gloo.py."""
+    import torch.distributed as dist
+    from yolo_fastest_amd import dist as yfd
+    m, post, _ = models[256]
+    g = golden("golden_256")
+    pred = (torch.from_numpy(g["head_large"]).to(dev), torch.from_numpy(g["head_small"]).to(dev))
+    m(_x(np.zeros((1, 256, 320), np.uint8), dev))
+    raw = post.detect_raw(pred, kmax=8)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29537", rank=0, world_size=1, device_id=dev)
+    try:
+        out = yfd.all_gather_detections(raw, raw["counts"].shape[0])
+        h = yfd.all_gather_detections_async(raw, raw["counts"].shape[0])   # the overlapped form bench.py uses
+        out2 = h.wait()
+        assert all(torch.equal(out[k], out2[k]) for k in out)
+        torch.cuda.synchronize(dev)
+    finally:
+        dist.destroy_process_group()
+    for k in ("counts", "boxes", "scores", "cls", "src"):
+        assert torch.equal(out[k].cpu(), raw[k].cpu()), k

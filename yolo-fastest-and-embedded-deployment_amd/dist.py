@@ -32,8 +32,29 @@ def unpack_records(buf, kmax):
                 src=src.contiguous())
 
 
-def all_gather_detections(raw, n_total, group=None):
-    """Every rank contributes its shard's records; every rank gets all n_total frames in frame order.
+class _PendingGather:
+    """Handle of an exchange in flight: `wait()` makes the caller's stream wait for the collective (RCCL: a stream-level
+    dependency, the host does not block) and returns the unpacked records of all frames in frame order."""
+
+    def __init__(self, work, out, parts, world, per, n_total, kmax):
+        self._work, self._out, self._parts = work, out, parts
+        self._world, self._per, self._n_total, self._kmax = world, per, n_total, kmax
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        out = torch.cat(self._parts, dim=0) if self._parts is not None else self._out
+        keep = []
+        for r in range(self._world):
+            lo, hi = shard_range(self._n_total, r, self._world)
+            keep.append(out[r * self._per:r * self._per + (hi - lo)])
+        return unpack_records(torch.cat(keep, dim=0), self._kmax)
+
+
+def all_gather_detections_async(raw, n_total, group=None):
+    """Start the exchange and return at once: the collective runs on the backend's own stream, so the next batch's kernels
+    (queued right after this call) overlap with it; `wait()` on the returned handle when the gathered records are needed.
     Shards may differ by one frame: each rank pads to the largest shard, the pad is dropped after the gather."""
     world = dist.get_world_size(group)
     kmax = raw["cls"].shape[1]
@@ -41,15 +62,16 @@ def all_gather_detections(raw, n_total, group=None):
     per = -(-n_total // world)
     if rec.shape[0] < per:
         rec = torch.cat([rec, rec.new_zeros((per - rec.shape[0], rec.shape[1]))], dim=0)
-    out = rec.new_empty((world * per, rec.shape[1]))
+    rec = rec.contiguous()
     if dist.get_backend(group) == "nccl":
-        dist.all_gather_into_tensor(out, rec.contiguous(), group=group)
-    else:
-        parts = [rec.new_empty(rec.shape) for _ in range(world)]
-        dist.all_gather(parts, rec.contiguous(), group=group)
-        out = torch.cat(parts, dim=0)
-    keep = []
-    for r in range(world):
-        lo, hi = shard_range(n_total, r, world)
-        keep.append(out[r * per:r * per + (hi - lo)])
-    return unpack_records(torch.cat(keep, dim=0), kmax)
+        out = rec.new_empty((world * per, rec.shape[1]))
+        work = dist.all_gather_into_tensor(out, rec, group=group, async_op=True)
+        return _PendingGather(work, out, None, world, per, n_total, kmax)
+    parts = [rec.new_empty(rec.shape) for _ in range(world)]
+    work = dist.all_gather(parts, rec, group=group, async_op=True)
+    return _PendingGather(work, None, parts, world, per, n_total, kmax)
+
+
+def all_gather_detections(raw, n_total, group=None):
+    """Every rank contributes its shard's records; every rank gets all n_total frames in frame order."""
+    return all_gather_detections_async(raw, n_total, group).wait()
