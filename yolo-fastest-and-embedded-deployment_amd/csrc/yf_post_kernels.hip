@@ -23,7 +23,9 @@
 
 namespace yf {
 
-static constexpr int POST_THREADS = 256;
+static constexpr int POST_THREADS = 1024;  // one workgroup per frame owns the CU (LDS): 16 waves hide the LDS / fp64 latencies of the
+                                           // sort, decode and NMS loops (with 4 waves the dense frames took 3x longer)
+static constexpr int POST_PARTS = POST_THREADS / 64, POST_CPT = 64 / POST_PARTS;  // window row i = tid / PARTS tests CPT candidates
 
 __device__ inline uint32_t orderable(float f)
 {
@@ -57,6 +59,7 @@ __device__ inline CellRef locate(const PostArgs& a, long frame, int cell)
     r.pp = t / r.h;
     return r;
 }
+__device__ inline long s_area(const int4& b) { return ((long)b.z - b.x) * ((long)b.w - b.y); }
 __device__ inline float logit_at(const CellRef& r, int k) { return r.p[((r.pp * 8 + k) * r.h + r.i) * r.w + r.j]; }
 
 // LDS carve: keys u64[mpad] | boxes int4[ncell] | kept u16[ncell] | alive u8[ncell] | small scalars
@@ -69,11 +72,11 @@ __global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncel
     uint16_t* kept = reinterpret_cast<uint16_t*>(smem + (size_t)mpad_max * 8 + (size_t)ncell * 16);
     unsigned char* alive = smem + (size_t)mpad_max * 8 + (size_t)ncell * 18;
     __shared__ int s_wave_cnt[POST_THREADS / 64];
-    __shared__ int s_total, s_nkept, s_err;
+    __shared__ int s_total, s_nkept, s_err, s_zero_area;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long frame = blockIdx.x;
-    if (tid == 0) { s_total = 0; s_nkept = 0; s_err = 0; }
+    if (tid == 0) { s_total = 0; s_nkept = 0; s_err = 0; s_zero_area = 0; }
     __syncthreads();
 
     // ---- phase 1: threshold + order-preserving compaction of candidate keys (decode order) ----
@@ -149,33 +152,139 @@ __global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncel
         boxes[k] = make_int4(clamp_i32(rint(x - bw / 2)), clamp_i32(rint(y - bh / 2)), clamp_i32(rint(x + bw / 2)),
                              clamp_i32(rint(y + bh / 2)));
         alive[k] = 1;
+        if (s_area(boxes[k]) == 0) s_zero_area = 1;
     }
     __syncthreads();
 
     // ---- phase 4: greedy NMS, class segments are contiguous in the sorted list ----
-    for (int i = 0; i < M; ++i) {
-        if (!alive[i]) continue;  // settled by the barrier that ended the sweep which could clear it
-        if (tid == 0) { kept[s_nkept] = (uint16_t)i; s_nkept = s_nkept + 1; }
-        const int4 bi = boxes[i];
-        const int ci = (int)(keys[i] >> 45);
-        const long area_i = ((long)bi.z - bi.x) * ((long)bi.w - bi.y);
-        bool any = false;
-        for (int j = i + 1 + tid; j < M; j += POST_THREADS) {
-            if ((int)(keys[j] >> 45) != ci) break;  // past this class
-            any = true;
-            if (!alive[j]) continue;
-            const int4 bj = boxes[j];
-            long iw = (long)min(bj.z, bi.z) - (long)max(bj.x, bi.x);
-            long ih = (long)min(bj.w, bi.w) - (long)max(bj.y, bi.y);
-            long inter = (iw > 0 && ih > 0) ? iw * ih : 0;
-            long uni = ((long)bj.z - bj.x) * ((long)bj.w - bj.y) + area_i - inter;
-            if (uni == 0) { s_err = 1; continue; }  // the reference raises ZeroDivisionError here
-            if ((double)inter / (double)uni > a.nms_thres) alive[j] = 0;
+    // The reference's loop (detect.py:69-84) keeps the best remaining box of a class and drops every later box it overlaps; one
+    // barrier-separated sweep per kept box costs ~1.3 us each (dense frames: 260 survivors of 1200 candidates = 0.36 ms).  The same
+    // decisions in windows of 64 consecutive candidates of one class:
+    //   (1) all pairs inside the window at once: thread (row i = tid / PARTS, part q = tid % PARTS) tests i against the CPT candidates
+    //       of its part -> a piece of row i's suppression mask (and of its "union == 0" mask, the reference's
+    //       ZeroDivisionError, which must only count if the reference would have evaluated that pair);
+    //   (2) wave 0 resolves the window greedily on 64-bit masks: take the lowest remaining bit, keep it, clear what it suppresses;
+    //   (3) every later candidate of the class tests itself against the window's survivors, in order, until one drops it.
+    // Identical to the sequential procedure: a box is dropped iff an EARLIER KEPT box of its class overlaps it.
+    __shared__ uint16_t s_pm[64][POST_PARTS], s_pz[64][POST_PARTS];
+    __shared__ int4 s_wb[64];   // the window's survivors: boxes and areas
+    __shared__ long s_wa[64];
+    __shared__ int s_wlen, s_wk;
+    const bool skip0 = !(0.0 > a.nms_thres);  // with a non-negative threshold a zero intersection can never suppress
+    for (int pos = 0; pos < M;) {
+        const int cls = (int)(keys[pos] >> 45);
+        if (wave == 0) {  // window = the run of this class starting at pos, at most 64 long (sorted: the class is a contiguous run)
+            const bool in = pos + lane < M && (int)(keys[pos + lane] >> 45) == cls;
+            const unsigned long long b = __ballot(in);
+            if (lane == 0) s_wlen = __popcll(b);   // the lanes of this class form a prefix
         }
-        (void)any;
         __syncthreads();
+        const int wlen = s_wlen;
+        {   // (1)
+            const int i = tid / POST_PARTS, q = tid % POST_PARTS;
+            unsigned pm = 0, pz = 0;
+            if (i < wlen && alive[pos + i]) {
+                const int4 bi = boxes[pos + i];
+                const long area_i = ((long)bi.z - bi.x) * ((long)bi.w - bi.y);
+                for (int t = 0; t < POST_CPT; ++t) {
+                    const int j = POST_CPT * q + t;
+                    if (j <= i || j >= wlen || !alive[pos + j]) continue;
+                    const int4 bj = boxes[pos + j];
+                    const long iw = (long)min(bj.z, bi.z) - (long)max(bj.x, bi.x);
+                    const long ih = (long)min(bj.w, bi.w) - (long)max(bj.y, bi.y);
+                    if ((iw <= 0 || ih <= 0) && skip0) {  // disjoint (most pairs of a dense frame): IoU = 0 can never exceed a threshold >= 0;
+                        if ((area_i | s_area(bj)) == 0) pz |= 1u << t;  // ... but 0 / 0 is the reference's ZeroDivisionError
+                        continue;
+                    }
+                    const long inter = (iw > 0 && ih > 0) ? iw * ih : 0;
+                    const long uni = s_area(bj) + area_i - inter;
+                    if (uni == 0) { pz |= 1u << t; continue; }
+                    if ((double)inter / (double)uni > a.nms_thres) pm |= 1u << t;
+                }
+            }
+            s_pm[i][q] = (uint16_t)pm; s_pz[i][q] = (uint16_t)pz;
+        }
+        __syncthreads();
+        if (wave == 0) {  // (2)
+            unsigned long long row = 0, zrow = 0;
+#pragma unroll
+            for (int q = 0; q < POST_PARTS; ++q) {
+                row |= (unsigned long long)s_pm[lane][q] << (POST_CPT * q); zrow |= (unsigned long long)s_pz[lane][q] << (POST_CPT * q);
+            }
+            const bool al = lane < wlen && alive[pos + lane];
+            unsigned long long rem = __ballot(al);   // candidates not yet decided
+            const bool zany = __ballot(zrow != 0) != 0;   // (almost never: two zero-area boxes in one window)
+            unsigned long long keptbits = 0;
+            int err = 0;
+            while (rem) {
+                const int i = __ffsll((long long)rem) - 1;   // wave-uniform
+                const unsigned lo = __builtin_amdgcn_readlane((unsigned)row, i), hi = __builtin_amdgcn_readlane((unsigned)(row >> 32), i);
+                rem &= ~(1ull << i);
+                if (zany) {
+                    const unsigned zlo = __builtin_amdgcn_readlane((unsigned)zrow, i), zhi = __builtin_amdgcn_readlane((unsigned)(zrow >> 32), i);
+                    if ((((unsigned long long)zhi << 32) | zlo) & rem) err = 1;  // the reference divides by this pair's union while both are in its list
+                }
+                rem &= ~(((unsigned long long)hi << 32) | lo);
+                keptbits |= 1ull << i;
+            }
+            // every lane publishes its own decision: alive := kept; the window's survivors (in order) with boxes and areas
+            const int nk0 = s_nkept, wk = __popcll(keptbits);
+            if (lane < wlen) alive[pos + lane] = (keptbits >> lane) & 1;
+            if ((keptbits >> lane) & 1) {
+                const int rank = __popcll(keptbits & ((1ull << lane) - 1));
+                const int4 b = boxes[pos + lane];
+                kept[nk0 + rank] = (uint16_t)(pos + lane);
+                s_wb[rank] = b; s_wa[rank] = s_area(b);
+            }
+            if (lane == 0) { s_nkept = nk0 + wk; s_wk = wk; if (err) s_err = 1; }
+        }
+        __syncthreads();
+        {   // (3)
+            const int wk = s_wk;
+            if (!s_zero_area && skip0) {
+                // no zero-area box in the frame: a union can never be 0, so "dropped by the FIRST survivor that overlaps it" is just
+                // "dropped if ANY survivor overlaps it" -- order-free: SPLIT threads share a candidate and take every SPLIT-th survivor
+                constexpr int SPLIT = 4;
+                const int sub = tid % SPLIT;
+                for (int j = pos + wlen + tid / SPLIT; j < M; j += POST_THREADS / SPLIT) {
+                    if ((int)(keys[j] >> 45) != cls) break;  // past this class
+                    if (!alive[j]) continue;
+                    const int4 bj = boxes[j];
+                    const long area_j = s_area(bj);
+                    for (int k = sub; k < wk; k += SPLIT) {
+                        const int4 bi = s_wb[k];
+                        const long iw = (long)min(bj.z, bi.z) - (long)max(bj.x, bi.x);
+                        const long ih = (long)min(bj.w, bi.w) - (long)max(bj.y, bi.y);
+                        if (iw <= 0 || ih <= 0) continue;
+                        const long inter = iw * ih;
+                        if ((double)inter / (double)(area_j + s_wa[k] - inter) > a.nms_thres) { alive[j] = 0; break; }
+                    }
+                }
+            } else {
+                for (int j = pos + wlen + tid; j < M; j += POST_THREADS) {
+                    if ((int)(keys[j] >> 45) != cls) break;  // past this class
+                    if (!alive[j]) continue;
+                    const int4 bj = boxes[j];
+                    const long area_j = s_area(bj);
+                    for (int k = 0; k < wk; ++k) {
+                        const int4 bi = s_wb[k];           // the same address for every lane: an LDS broadcast
+                        const long iw = (long)min(bj.z, bi.z) - (long)max(bj.x, bi.x);
+                        const long ih = (long)min(bj.w, bi.w) - (long)max(bj.y, bi.y);
+                        if ((iw <= 0 || ih <= 0) && skip0) {
+                            if ((area_j | s_wa[k]) == 0) s_err = 1;
+                            continue;
+                        }
+                        const long inter = (iw > 0 && ih > 0) ? iw * ih : 0;
+                        const long uni = area_j + s_wa[k] - inter;
+                        if (uni == 0) { s_err = 1; continue; }  // the reference raises ZeroDivisionError here
+                        if ((double)inter / (double)uni > a.nms_thres) { alive[j] = 0; break; }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        pos += wlen;
     }
-    __syncthreads();
 
     // ---- phase 5: write survivors ----
     const int nk = s_nkept;
