@@ -552,3 +552,26 @@ def test_rccl_gather_path_single_rank(models, golden, dev):
         dist.destroy_process_group()
     for k in ("counts", "boxes", "scores", "cls", "src"):
         assert torch.equal(out[k].cpu(), raw[k].cpu()), k
+
+
+def test_fp16_other_input_sizes_and_u8(yf, dev):
+    """fp16 storage at sizes whose tiles are partial (W/4 not a multiple of 16: the matrix-core k19 kernel's border windows and
+    guard band, the stride-2 block kernel's ragged tiles), through the fused u8 pre-process too.  Bounds as in
+    test_fp16_path_logits_and_boxes (relative to the logit range of the fp32 oracle)."""
+    from oracle import backbone_oracle as bo
+    io = yf.io_params_for(256)
+    m = yf.YoloFastest(io).to(dev).eval()
+    sd = torch.load(WEIGHTS[256], map_location="cpu")
+    m.load_state_dict(sd)
+    m.storage_dtype = torch.float16
+    g = np.random.default_rng(11)
+    for (H, W, N) in ((32, 32, 2), (64, 96, 3), (160, 224, 2), (256, 352, 1)):
+        u8 = g.integers(0, 256, size=(N, H, W), dtype=np.uint8)
+        ol, os_ = bo.forward(sd, bo.preprocess(u8))
+        with torch.no_grad():
+            hl, hs = m(_x(u8, dev))
+            ul, us = m.forward_u8(torch.from_numpy(u8).to(dev), (H, W))
+        for got, ref in ((hl, ol), (hs, os_)):
+            d = (got.cpu() - ref).abs()
+            assert d.max().item() <= 3e-3 * max(1.0, ref.abs().max().item()) + 1e-2, (H, W, d.max().item())
+        assert torch.equal(ul, hl) and torch.equal(us, hs)   # the fused u8 load computes the same (x - 128) / 255
