@@ -140,6 +140,33 @@ int main(int argc, char** argv)
         bench_fb<8, 32, 8, 1, true, false, 8, 16, 2, 2, 8, 8, 1, true>("16x32 tile 2x2 (128 thr)", N, 64, 80);
         bench_fb<8, 32, 8, 1, true, false, 8, 8, 2, 2, 8, 8, 1, true>("16x16 tile 2x2 (64 thr)", N, 64, 80);
     }
+    if (on("xl0")) {
+        printf("--- tile shapes WITHOUT input staging (the production form), after the SGPR-spill fix ---\n");
+        bench_fb<8, 8, 4, 1, false, true, 16, 16, 2, 2, 8, 8, 1, false>("stem 32x32 2x2 (production)", N, 128, 160);
+        bench_fb<8, 8, 4, 1, false, true, 16, 16, 1, 2, 8, 8, 1, false>("stem 16x32 1x2", N, 128, 160);
+        bench_fb<8, 8, 4, 1, false, true, 16, 16, 2, 1, 8, 8, 1, false>("stem 32x16 2x1", N, 128, 160);
+        bench_fb<8, 8, 4, 1, false, true, 16, 16, 1, 1, 8, 8, 1, false>("stem 16x16 1x1", N, 128, 160);
+        bench_fb<8, 8, 4, 1, false, true, 8, 32, 2, 2, 8, 8, 1, false>("stem 16x64 2x2", N, 128, 160);
+        bench_fb<8, 8, 4, 1, false, true, 16, 16, 2, 4, 8, 8, 1, false>("stem 32x64 2x4", N, 128, 160);
+        bench_fb<4, 8, 4, 1, true, false, 16, 16, 2, 2, 8, 8, 1, false>("res1_1 32x32 2x2 (production)", N, 128, 160);
+        bench_fb<4, 8, 4, 1, true, false, 16, 16, 1, 2, 8, 8, 1, false>("res1_1 16x32 1x2", N, 128, 160);
+        bench_fb<4, 8, 4, 1, true, false, 16, 16, 2, 4, 8, 8, 1, false>("res1_1 32x64 2x4", N, 128, 160);
+        bench_fb<4, 8, 4, 1, true, false, 8, 32, 2, 2, 8, 8, 1, false>("res1_1 16x64 2x2", N, 128, 160);
+        bench_fb<4, 8, 4, 1, true, false, 16, 16, 4, 2, 8, 8, 1, false>("res1_1 64x32 4x2", N, 128, 160);
+        bench_fb<8, 32, 8, 1, true, false, 32, 8, 2, 2, 8, 8, 1, false>("res2 64x16 2x2 (production)", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 16, 16, 2, 2, 8, 8, 1, false>("res2 32x32 2x2", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 16, 20, 2, 2, 8, 8, 1, false>("res2 32x40 2x2", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 16, 20, 1, 2, 8, 8, 1, false>("res2 16x40 1x2", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 16, 20, 2, 1, 8, 8, 1, false>("res2 32x20 2x1", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 16, 20, 1, 1, 8, 8, 1, false>("res2 16x20 1x1", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 16, 20, 2, 4, 8, 8, 1, false>("res2 32x80 2x4", N, 64, 80);
+        bench_fb<8, 32, 8, 2, false, false, 16, 20, 1, 1, 8, 8, 1, false>("conv2_2 s2 16x20 1x1 (production)", N, 64, 80);
+        bench_fb<8, 32, 8, 2, false, false, 16, 20, 1, 2, 8, 8, 1, false>("conv2_2 s2 16x40 1x2", N, 64, 80);
+        bench_fb<8, 48, 8, 1, true, false, 16, 20, 1, 2, 8, 8, 2, false>("res3_1 16x40 1x2 PE2 (production)", N, 32, 40);
+        bench_fb<8, 48, 8, 1, true, false, 16, 20, 1, 1, 8, 8, 2, false>("res3_1 16x20 1x1 PE2", N, 32, 40);
+        bench_fb<8, 48, 8, 1, true, false, 16, 20, 2, 2, 8, 8, 2, false>("res3_1 32x40 2x2 PE2", N, 32, 40);
+        bench_fb<8, 48, 8, 1, true, false, 16, 20, 1, 2, 8, 8, 1, false>("res3_1 16x40 1x2 PE1", N, 32, 40);
+    }
     if (on("stem")) {
         printf("--- stem conv0+conv1_2/1_3/1_4 and res1_1 at 128x160 ---\n");
         bench_fb<8, 8, 4, 1, false, true, 16, 16, 2, 2, 8, 8, 1, true>("stem 32x32 2x2", N, 128, 160);
