@@ -239,6 +239,27 @@ int main(int argc, char** argv)
         bench_mres_pc<8, 32, 8, true, 16, 20, 2, 5>("8/32 s4", N, 64, 80);
         bench_mres_pc<8, 48, 8, true, 16, 20, 2, 5>("8/48 s8", N, 32, 40);
     }
+    if (on("mres2")) {
+        printf("--- MFMA blocks, small tiles / many waves ---\n");
+        bench_mres<8, 32, 8, true, 8, 10, 8>("8/32 s4", N, 64, 80);
+        bench_mres<8, 32, 8, true, 8, 20, 8>("8/32 s4", N, 64, 80);
+        bench_mres<8, 32, 8, true, 16, 10, 8>("8/32 s4", N, 64, 80);
+        bench_mres<8, 32, 8, true, 8, 10, 4>("8/32 s4", N, 64, 80);
+        bench_mres<8, 32, 8, true, 8, 20, 4>("8/32 s4", N, 64, 80);
+        bench_mres<8, 48, 8, true, 8, 10, 8>("8/48 s8", N, 32, 40);
+        bench_mres<8, 48, 8, true, 8, 20, 8>("8/48 s8", N, 32, 40);
+        bench_mres<8, 48, 8, true, 8, 10, 4>("8/48 s8", N, 32, 40);
+        bench_mres<8, 48, 8, true, 16, 20, 8>("8/48 s8", N, 32, 40);
+        bench_mres<8, 48, 16, false, 8, 10, 8>("8/48/16 s8", N, 32, 40);
+        bench_mres<8, 48, 16, false, 8, 20, 8>("8/48/16 s8", N, 32, 40);
+        bench_mres<8, 48, 16, false, 16, 20, 8>("8/48/16 s8", N, 32, 40);
+        bench_mres<16, 96, 16, true, 8, 10, 8>("16/96 s8", N, 32, 40);
+        bench_mres<16, 96, 16, true, 8, 20, 8>("16/96 s8", N, 32, 40);
+        bench_mres<16, 96, 16, true, 16, 10, 8>("16/96 s8", N, 32, 40);
+        bench_mres<16, 96, 16, true, 8, 10, 4>("16/96 s8", N, 32, 40);
+        bench_mres<24, 136, 24, true, 8, 10, 8>("24/136 s16", N, 16, 20);
+        bench_mres<24, 136, 24, true, 8, 20, 8>("24/136 s16", N, 16, 20);
+    }
     if (on("mres")) {
         printf("--- MFMA residual blocks ---\n");
         bench_mres<16, 96, 16, true, 16, 20, 4>("16/96 s8", N, 32, 40);

@@ -495,9 +495,11 @@ static int launch_mres_t(MresArgs a, int N, hipStream_t s)
 // Producer/consumer pays where one workgroup owns the CU anyway (strides 16, 32); at stride 8 its second E buffer
 // halves the workgroups per CU and it is slower (tools/kbench.hip mrespc).
 #define YF_MRES_SHAPES(MR)                                                            \
-    MR(8, 48, 16, false, 1, 16, 20, 0, 4)   /* conv3_2/3_3/3_4          @ H/8  */         \
+    MR(8, 48, 8, true, 1, 16, 20, 0, 8)     /* res3_1, res3_2           @ H/8  */         \
+    MR(8, 48, 16, false, 1, 16, 20, 0, 8)   /* conv3_2/3_3/3_4          @ H/8  */         \
     MR(16, 96, 16, true, 1, 16, 20, 0, 8)   /* res3_3 .. res3_6         @ H/8  */         \
     MR(16, 96, 24, false, 2, 8, 10, 0, 8)   /* conv3_5/3_6/4_1          H/8 -> H/16 */    \
+    MR(8, 32, 8, false, 2, 8, 10, 0, 8)     /* conv2_2/2_3/3_1          H/4 -> H/8  */    \
     MR(24, 136, 24, true, 1, 16, 20, 6, 10) /* res4_1 .. res4_4         @ H/16 */         \
     MR(48, 224, 48, true, 1, 8, 10, 4, 5)   /* res5_1 .. res5_5         @ H/32 */
 
