@@ -232,6 +232,17 @@ int main(int argc, char** argv)
         bench_mres_pc<48, 224, 48, true, 8, 10, 4, 4>("48/224 s32", N, 8, 10);
         bench_mres_pc<48, 224, 48, true, 8, 10, 4, 5>("48/224 s32", N, 8, 10);
         bench_mres_pc<48, 224, 48, true, 8, 10, 8, 5>("48/224 s32", N, 8, 10);
+        bench_mres_pc<48, 224, 48, true, 8, 10, 10, 5>("48/224 s32", N, 8, 10);
+        bench_mres_pc<48, 224, 48, true, 8, 10, 11, 5>("48/224 s32", N, 8, 10);
+        bench_mres_pc<48, 224, 48, true, 8, 10, 8, 8>("48/224 s32", N, 8, 10);
+        bench_mres_pc<48, 224, 48, true, 8, 10, 6, 5>("48/224 s32", N, 8, 10);
+        bench_mres_pc<24, 136, 24, true, 16, 20, 6, 10>("24/136 s16", N, 16, 20);
+        bench_mres_pc<24, 136, 24, true, 16, 20, 8, 8>("24/136 s16", N, 16, 20);
+        bench_mres_pc<24, 136, 24, true, 16, 20, 10, 5>("24/136 s16", N, 16, 20);
+        bench_mres_pc<24, 136, 24, true, 16, 20, 8, 5>("24/136 s16", N, 16, 20);
+        bench_mres_pc<24, 136, 24, true, 16, 20, 7, 7>("24/136 s16", N, 16, 20);
+        bench_mres_pc<24, 136, 24, true, 8, 20, 4, 5>("24/136 s16", N, 16, 20);
+        bench_mres_pc<24, 136, 24, true, 8, 20, 8, 5>("24/136 s16", N, 16, 20);
         bench_mres_pc<48, 224, 48, true, 8, 10, 3, 5>("48/224 s32", N, 8, 10);
         bench_mres<8, 48, 16, false, 16, 20, 4>("8/48/16 s8 (2-barrier, 4 waves)", N, 32, 40);
         bench_mres_pc<8, 48, 16, false, 16, 20, 2, 5>("8/48/16 s8", N, 32, 40);

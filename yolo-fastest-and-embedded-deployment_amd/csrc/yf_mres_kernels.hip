@@ -500,7 +500,7 @@ static int launch_mres_t(MresArgs a, int N, hipStream_t s)
     MR(16, 96, 16, true, 1, 16, 20, 0, 8)   /* res3_3 .. res3_6         @ H/8  */         \
     MR(16, 96, 24, false, 2, 8, 10, 0, 8)   /* conv3_5/3_6/4_1          H/8 -> H/16 */    \
     MR(8, 32, 8, false, 2, 8, 10, 0, 8)     /* conv2_2/2_3/3_1          H/4 -> H/8  */    \
-    MR(24, 136, 24, true, 1, 16, 20, 6, 10) /* res4_1 .. res4_4         @ H/16 */         \
+    MR(24, 136, 24, true, 1, 16, 20, 8, 8)  /* res4_1 .. res4_4         @ H/16 */         \
     MR(48, 224, 48, true, 1, 8, 10, 8, 5)   /* res5_1 .. res5_5         @ H/32 */
 
 template <int CIN, int CEXP, int COUT, bool RES, int S, int TH, int TW, int NWP, int NW, typename T>
