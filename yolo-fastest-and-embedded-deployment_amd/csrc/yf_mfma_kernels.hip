@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(64 * RS * ((((N + 15) / 16) * (OMODE == 2 ? 4 
     const int ug = wv % NUG, rs = wv / NUG;  // unit group and row stream of this wave
 
     // ---- this wave's B fragments and biases ----
-    float bw[UPW][SS], bias[UPW];
+    float bw[UPW][SS], bias[UPW][4];
     int un[UPW], uq[UPW];
 #pragma unroll
     for (int i = 0; i < UPW; ++i) {
@@ -212,7 +212,8 @@ __global__ void __launch_bounds__(64 * RS * ((((N + 15) / 16) * (OMODE == 2 ? 4 
         const float* w = a.w + ((size_t)uq[i] * SS * NT + un[i]) * 64 + lane;
 #pragma unroll
         for (int s = 0; s < SS; ++s) bw[i][s] = w[(size_t)s * NT * 64];
-        bias[i] = un[i] * 16 + r < N ? a.b[un[i] * 16 + r] : 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) bias[i][reg] = un[i] * 16 + 4 * q + reg < N ? a.b[un[i] * 16 + 4 * q + reg] : 0.f;
         if (!v) un[i] = NT;  // marks "no stores"
     }
 
@@ -250,7 +251,7 @@ __global__ void __launch_bounds__(64 * RS * ((((N + 15) / 16) * (OMODE == 2 ? 4 
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < UPW; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a1[kb])[j], bw[i][kb * 4 + j], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[i][kb * 4 + j], ((const float*)&a1[kb])[j], acc[i], 0, 0, 0);
             if constexpr (!(DBG & 1)) a1[kb] = *reinterpret_cast<const float4*>(p1 + kb * 16);
         }
         if constexpr (T1) {
@@ -258,7 +259,7 @@ __global__ void __launch_bounds__(64 * RS * ((((N + 15) / 16) * (OMODE == 2 ? 4 
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int i = 0; i < UPW; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a1t)[j], bw[i][NB1 * 4 + j], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[i][NB1 * 4 + j], ((const float*)&a1t)[j], acc[i], 0, 0, 0);
             if constexpr (!(DBG & 1)) a1t = *reinterpret_cast<const float2*>(p1 - 4 * q + NB1 * 16 + 2 * q);
         }
         if constexpr (K2 > 0) {
@@ -269,7 +270,7 @@ __global__ void __launch_bounds__(64 * RS * ((((N + 15) / 16) * (OMODE == 2 ? 4 
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int i = 0; i < UPW; ++i)
-                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a2[kb])[j], bw[i][S1 + kb * 4 + j], acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[i][S1 + kb * 4 + j], ((const float*)&a2[kb])[j], acc[i], 0, 0, 0);
                 if constexpr (!(DBG & 1)) a2[kb] = *reinterpret_cast<const float4*>(p2 + kb * 16);
             }
             if constexpr (T2) {
@@ -277,36 +278,31 @@ __global__ void __launch_bounds__(64 * RS * ((((N + 15) / 16) * (OMODE == 2 ? 4 
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int i = 0; i < UPW; ++i)
-                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a2t)[j], bw[i][S1 + NB2 * 4 + j], acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[i][S1 + NB2 * 4 + j], ((const float*)&a2t)[j], acc[i], 0, 0, 0);
                 a2t = *reinterpret_cast<const float2*>(p2 - 4 * q + NB2 * 16 + 2 * q);
             }
         }
-        // ---- epilogue: lane holds column un*16 + r of rows t*16 + 4q + reg ----
-        long obase[4];  // element offset of the row's output pixel (deconv: of its 2x2 block's top-left pixel)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const long row = t * 16 + 4 * q + reg;
-            if constexpr (OMODE == 0) {
-                obase[reg] = row * N;
-            } else {  // ConvTranspose2d k=2 s=2: quadrant (dy,dx) of input pixel (y,x) -> output pixel (2y+dy, 2x+dx)
-                const long n = row / a.HW, hw = row - n * a.HW;
-                const int y = (int)(hw / a.W), x = (int)(hw - (long)y * a.W);
-                obase[reg] = ((n * (2 * (a.HW / a.W)) + 2 * y) * (2 * a.W) + 2 * x) * N;
-            }
-            if (row >= a.npix) obase[reg] = -1;
+        // ---- epilogue.  The weights are the MFMA's A operand and the activations its B operand (both fragment layouts index
+        // (l & 15, l >> 4) the same way, so this is the same registers with the operands swapped): D = (X W)^T, lane (r, q) holds
+        // output channels un*16 + 4q .. +3 of row t*16 + r -- one 16-byte store per lane and unit instead of four 4-byte ones ----
+        const long row = t * 16 + r;
+        long obase;  // element offset of the row's output pixel (deconv: of its 2x2 block's top-left pixel)
+        if constexpr (OMODE == 0) {
+            obase = row * N;
+        } else {  // ConvTranspose2d k=2 s=2: quadrant (dy,dx) of input pixel (y,x) -> output pixel (2y+dy, 2x+dx)
+            const long n = row / a.HW, hw = row - n * a.HW;
+            const int y = (int)(hw / a.W), x = (int)(hw - (long)y * a.W);
+            obase = ((n * (2 * (a.HW / a.W)) + 2 * y) * (2 * a.W) + 2 * x) * N;
         }
 #pragma unroll
         for (int i = 0; i < UPW; ++i) {
-            const int c = un[i] * 16 + r;
-            if (c >= N) continue;  // also the "no unit" marker
+            const int c = un[i] * 16 + 4 * q;
+            if (c >= N || row >= a.npix) continue;  // c >= N: also the "no unit" marker (N is a multiple of 4)
             const long qoff = OMODE == 2 ? ((long)(uq[i] >> 1) * (2 * a.W) + (uq[i] & 1)) * N : 0;
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                if (obase[reg] < 0 || ((DBG & 2) && v0guard(acc[i][reg]))) continue;
-                float v = acc[i][reg] + bias[i];
-                if constexpr (RELU) v = fmaxf(v, 0.f);
-                a.out[obase[reg] + qoff + c] = v;
-            }
+            float4 v = make_float4(acc[i][0] + bias[i][0], acc[i][1] + bias[i][1], acc[i][2] + bias[i][2], acc[i][3] + bias[i][3]);
+            if constexpr (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if ((DBG & 2) && v0guard(v.x)) continue;
+            *reinterpret_cast<float4*>(a.out + obase + qoff + c) = v;
         }
     }
 }
