@@ -196,14 +196,14 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                 if constexpr (H16) {
                     const f16x4 dh = f16x4{(half_t)fmaxf(d[0], 0.f), (half_t)fmaxf(d[1], 0.f), (half_t)fmaxf(d[2], 0.f), (half_t)fmaxf(d[3], 0.f)};
 #pragma unroll
-                    for (int nt = 0; nt < NT2; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(dh, w2h[nt], acc[i][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT2; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(w2h[nt], dh, acc[i][nt], 0, 0, 0);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float dj = fmaxf(d[j], 0.f);
 #pragma unroll
                         for (int nt = 0; nt < NT2; ++nt)
-                            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dj, w2f[j][nt], acc[i][nt], 0, 0, 0);
+                            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[j][nt], dj, acc[i][nt], 0, 0, 0);
                     }
                 }
             }
@@ -211,27 +211,29 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
         __syncthreads();
     }
 
-    // ---- epilogue: + bias (+ residual from X), NHWC store; lane holds cout = nt*16 + r of pixels 4q + reg ----
+    // ---- epilogue: + bias (+ residual from X), NHWC store.  The projection ran with the weights as the MFMA's A operand and the
+    // depthwise result as B (same fragments, swapped): lane (r, q) holds output channels nt*16 + 4q .. +3 of pixel mo*16 + r
+    // -- one 16-byte residual read and one 16-byte store per lane and n-tile ----
     const float* b2 = WL + NCH * CHUNK;
 #pragma unroll
-    for (int nt = 0; nt < NT2; ++nt) {
-        const int col = nt * 16 + r;
-        if (col >= COUT) continue;
-        const float bias = b2[col];
+    for (int i = 0; i < MTOW; ++i) {
+        const int mo = wave + i * NWAVE;
+        if (!EVEN_O && mo >= MTO) continue;
+        const int op = mo * 16 + r;
+        const int oy = op / TW, ox = op - oy * TW;
+        const int gy = oy0 + oy, gx = ox0 + ox;
+        if (gy >= Ho || gx >= Wo) continue;
 #pragma unroll
-        for (int i = 0; i < MTOW; ++i) {
-            const int mo = wave + i * NWAVE;
-            if (!EVEN_O && mo >= MTO) continue;
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int op = mo * 16 + 4 * q + reg;
-                const int oy = op / TW, ox = op - oy * TW;
-                const int gy = oy0 + oy, gx = ox0 + ox;
-                if (gy >= Ho || gx >= Wo) continue;
-                float v = acc[i][nt][reg] + bias;
-                if constexpr (RES) v += X[((oy + 1) * RW + ox + 1) * XP + col];
-                st1<T>(reinterpret_cast<T*>(a.out) + (((long)n * Ho + gy) * Wo + gx) * COUT + col, v);
+        for (int nt = 0; nt < NT2; ++nt) {
+            const int col = nt * 16 + 4 * q;
+            if (col >= COUT) continue;
+            const float4 bias = *reinterpret_cast<const float4*>(b2 + col);
+            float4 v = make_float4(acc[i][nt][0] + bias.x, acc[i][nt][1] + bias.y, acc[i][nt][2] + bias.z, acc[i][nt][3] + bias.w);
+            if constexpr (RES) {
+                const float4 x = *reinterpret_cast<const float4*>(&X[((oy + 1) * RW + ox + 1) * XP + col]);
+                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
             }
+            st4<T>(reinterpret_cast<T*>(a.out) + (((long)n * Ho + gy) * Wo + gx) * COUT + col, v);
         }
     }
 }
@@ -409,14 +411,14 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
                                                    (half_t)fmaxf(d[3], 0.f)};
 #pragma unroll
                             for (int nt = 0; nt < NT2; ++nt)
-                                acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(dh, w2h[nt], acc[i][nt], 0, 0, 0);
+                                acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(w2h[nt], dh, acc[i][nt], 0, 0, 0);
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 const float dj = fmaxf(d[j], 0.f);
 #pragma unroll
                                 for (int nt = 0; nt < NT2; ++nt)
-                                    acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dj, w2f[j][nt], acc[i][nt], 0, 0, 0);
+                                    acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[j][nt], dj, acc[i][nt], 0, 0, 0);
                             }
                         }
                     }
@@ -424,26 +426,26 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
             }
             __syncthreads();
         }
-        const float* b2 = WL + NCH * CHUNK;
+        const float* b2 = WL + NCH * CHUNK;   // lane (r, q): output channels nt*16 + 4q .. +3 of pixel mo*16 + r (see mres_kernel)
 #pragma unroll
-        for (int nt = 0; nt < NT2; ++nt) {
-            const int col = nt * 16 + r;
-            if (col >= COUT) continue;
-            const float bias = b2[col];
+        for (int i = 0; i < MTOW; ++i) {
+            const int mo = cw + i * NWC;
+            if (mo >= MTO) continue;
+            const int op = mo * 16 + r;
+            const int oy = op / TW, ox = op - oy * TW;
+            const int gy = oy0 + oy, gx = ox0 + ox;
+            if (gy >= a.H || gx >= a.W) continue;
 #pragma unroll
-            for (int i = 0; i < MTOW; ++i) {
-                const int mo = cw + i * NWC;
-                if (mo >= MTO) continue;
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int op = mo * 16 + 4 * q + reg;
-                    const int oy = op / TW, ox = op - oy * TW;
-                    const int gy = oy0 + oy, gx = ox0 + ox;
-                    if (gy >= a.H || gx >= a.W) continue;
-                    float v = acc[i][nt][reg] + bias;
-                    if constexpr (RES) v += X[((oy + 1) * RW + ox + 1) * XP + col];
-                    st1<T>(reinterpret_cast<T*>(a.out) + (((long)n * a.H + gy) * a.W + gx) * COUT + col, v);
+            for (int nt = 0; nt < NT2; ++nt) {
+                const int col = nt * 16 + 4 * q;
+                if (col >= COUT) continue;
+                const float4 bias = *reinterpret_cast<const float4*>(b2 + col);
+                float4 v = make_float4(acc[i][nt][0] + bias.x, acc[i][nt][1] + bias.y, acc[i][nt][2] + bias.z, acc[i][nt][3] + bias.w);
+                if constexpr (RES) {
+                    const float4 x = *reinterpret_cast<const float4*>(&X[((oy + 1) * RW + ox + 1) * XP + col]);
+                    v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
                 }
+                st4<T>(reinterpret_cast<T*>(a.out) + (((long)n * a.H + gy) * a.W + gx) * COUT + col, v);
             }
         }
     }
