@@ -6,9 +6,9 @@
 // One workgroup = one TH x TW tile of one frame (the whole frame at the shipped sizes).  Per 16-channel chunk of the
 // input: HBM --16-B loads, one chunk prefetched in registers--> LDS E[4 ch-groups][region px][4 ch] --25 ds_read_b128
 // per pixel--> depthwise FMA chains (+bias, ReLU) == A fragments of  v_mfma_f32_16x16x4_f32  against the 1x1 conv's
-// weights (B fragments from the LDS-staged weight stream); accumulators live in VGPRs across chunks.  With HEADN the
-// finished C fragments (+bias) are transposed through a wave-private LDS tile into A fragments of the head GEMM and the
-// head's logits are stored NCHW like the reference's output; otherwise the result is stored NHWC.
+// weights (fragments from the LDS-staged weight stream, as the MFMA's A operand); accumulators live in VGPRs across chunks.
+// With HEADN the finished fragments (+bias) are directly the B operand of the head GEMM (chained in registers) and the
+// head's logits are stored NCHW like the reference's output; otherwise the result is stored NHWC, 16 bytes per lane.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -43,13 +43,11 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
     constexpr int OFF_HB = OFF_HW + (H16 ? (N / 16) * NTH * 128 : KSH * NTH * 64);
     constexpr int WFLOATS = mdw_stream_floats(C, N, HEADN, H16);
     constexpr int NLD = (NRP * 4 + NTHR - 1) / NTHR;  // float4 loads per thread per chunk
-    constexpr int TP = N + 4;                         // pitch of the transposition tile
     static_assert((TH * TW) % 16 == 0 && C % 16 == 0 && N % 16 == 0 && CHUNK == mdw_chunk_floats(N, H16), "shape");
     static_assert(HEADN == 0 || HEADN <= 32, "head width");
     extern __shared__ __attribute__((aligned(16))) float mdw_smem[];
     float* E = mdw_smem;           // [4][EPL][4]
     float* WL = E + 16 * EPL;      // weight stream
-    float* T = WL + WFLOATS;       // [min(NWAVE,MTO)][16][TP]   (HEADN only)
 
     const int b = blockIdx.x;
     const int tx = b % a.tiles_x, ty = (b / a.tiles_x) % a.tiles_y, n = b / (a.tiles_x * a.tiles_y);
@@ -136,7 +134,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
                     const f16x4 dh = f16x4{(half_t)fmaxf(d[i][0], 0.f), (half_t)fmaxf(d[i][1], 0.f), (half_t)fmaxf(d[i][2], 0.f),
                                            (half_t)fmaxf(d[i][3], 0.f)};
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(dh, w2h[nt], acc[i][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(w2h[nt], dh, acc[i][nt], 0, 0, 0);
                 }
             }
         } else {
@@ -151,7 +149,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
                         const float dj = fmaxf(d[i][j], 0.f);
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
-                            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dj, w2f[nt], acc[i][nt], 0, 0, 0);
+                            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[nt], dj, acc[i][nt], 0, 0, 0);
                     }
                 }
             }
@@ -159,75 +157,56 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
         __syncthreads();
     }
 
-    // ---- epilogue ----
+    // ---- epilogue.  The 1x1 conv ran with its weights as the MFMA's A operand and the depthwise result as B (the same
+    // fragments, swapped), so lane (r, q) holds output channels nt*16 + 4q .. +3 of pixel mo*16 + r.  Without a head that is one
+    // 16-byte NHWC store per lane and n-tile; with a head it IS the B operand of the head GEMM (k-step (nt, reg) <-> channel
+    // nt*16 + 4q + reg, which is how the head's fragments are packed anyway), so the head conv chains in registers -- no LDS
+    // transposition -- and its logits come out as lane (pixel r, head channels 4q .. +3): NCHW stores of 16 consecutive pixels ----
     const float* bpw = WL + OFF_BPW;
-    if constexpr (HEADN == 0) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = nt * 16 + r;
-            const float bias = bpw[col];
-#pragma unroll
-            for (int i = 0; i < MTOW; ++i) {
-                const int mo = wave + i * NWAVE;
-                if (!EVEN && mo >= MTO) continue;
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int op = mo * 16 + 4 * q + reg;
-                    const int oy = op / TW, ox = op - oy * TW;
-                    const int gy = oy0 + oy, gx = ox0 + ox;
-                    if (gy < a.H && gx < a.W) st1<TT>(reinterpret_cast<TT*>(a.out) + (((long)n * a.H + gy) * a.W + gx) * N + col, acc[i][nt][reg] + bias);
-                }
-            }
-        }
-    } else {
-        constexpr int TSLOTS = NWAVE < MTO ? NWAVE : MTO;
-        float* Tw = T + (wave < TSLOTS ? wave : 0) * 16 * TP;
-        const float* hw = WL + OFF_HW;
-        const float* hb = WL + OFF_HB;
-#pragma unroll
-        for (int i = 0; i < MTOW; ++i) {  // (unrolled: a runtime-indexed acc[] would live in scratch)
-            const int mo = wave + i * NWAVE;
-            if (!EVEN && mo >= MTO) continue;
-            // C fragment (+bias) -> wave-private tile [16 px][N] -> A fragments of the head GEMM
+    for (int i = 0; i < MTOW; ++i) {  // (unrolled: a runtime-indexed acc[] would live in scratch)
+        const int mo = wave + i * NWAVE;
+        if (!EVEN && mo >= MTO) continue;
+        const int op = mo * 16 + r;
+        const int oy = op / TW, ox = op - oy * TW;
+        const int gy = oy0 + oy, gx = ox0 + ox;
+        const bool inside = gy < a.H && gx < a.W;
+        if constexpr (HEADN == 0) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const float bias = bpw[nt * 16 + r];
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) Tw[(4 * q + reg) * TP + nt * 16 + r] = acc[i][nt][reg] + bias;
+                const float4 bias = *reinterpret_cast<const float4*>(bpw + nt * 16 + 4 * q);
+                if (inside)
+                    st4<TT>(reinterpret_cast<TT*>(a.out) + (((long)n * a.H + gy) * a.W + gx) * N + nt * 16 + 4 * q,
+                            make_float4(acc[i][nt][0] + bias.x, acc[i][nt][1] + bias.y, acc[i][nt][2] + bias.z, acc[i][nt][3] + bias.w));
             }
-            __builtin_amdgcn_wave_barrier();
+        } else {
+            const float* hw = WL + OFF_HW;
+            const float* hb = WL + OFF_HB;
             f32x4 h[NTH] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-            for (int kb = 0; kb < N / 16; ++kb) {
-                const float4 av = *reinterpret_cast<const float4*>(&Tw[r * TP + kb * 16 + 4 * q]);
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 bias = *reinterpret_cast<const float4*>(bpw + nt * 16 + 4 * q);
+                const float hv[4] = {acc[i][nt][0] + bias.x, acc[i][nt][1] + bias.y, acc[i][nt][2] + bias.z, acc[i][nt][3] + bias.w};
                 if constexpr (H16) {
-                    const f16x4 ah = f16x4{(half_t)av.x, (half_t)av.y, (half_t)av.z, (half_t)av.w};
+                    const f16x4 bh = f16x4{(half_t)hv[0], (half_t)hv[1], (half_t)hv[2], (half_t)hv[3]};
 #pragma unroll
-                    for (int nt = 0; nt < NTH; ++nt)
-                        h[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, reinterpret_cast<const f16x4*>(hw)[(kb * NTH + nt) * 64 + lane], h[nt], 0, 0, 0);
+                    for (int nth = 0; nth < NTH; ++nth)
+                        h[nth] = __builtin_amdgcn_mfma_f32_16x16x16f16(reinterpret_cast<const f16x4*>(hw)[(nt * NTH + nth) * 64 + lane], bh, h[nth], 0, 0, 0);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int nt = 0; nt < NTH; ++nt)
-                            h[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&av)[j], hw[((kb * 4 + j) * NTH + nt) * 64 + lane],
-                                                                         h[nt], 0, 0, 0);
+                        for (int nth = 0; nth < NTH; ++nth)
+                            h[nth] = __builtin_amdgcn_mfma_f32_16x16x4f32(hw[((nt * 4 + j) * NTH + nth) * 64 + lane], hv[j], h[nth], 0, 0, 0);
                 }
             }
-            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int nt = 0; nt < NTH; ++nt) {
-                const int col = nt * 16 + r;
-                if (col >= HEADN) continue;
-                const float bias = hb[col];
+            for (int nth = 0; nth < NTH; ++nth)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    const int op = mo * 16 + 4 * q + reg;
-                    const int oy = op / TW, ox = op - oy * TW;
-                    const int gy = oy0 + oy, gx = ox0 + ox;
-                    if (gy < a.H && gx < a.W) a.out[(((long)n * HEADN + col) * a.H + gy) * a.W + gx] = h[nt][reg] + bias;  // NCHW
+                    const int hc = nth * 16 + 4 * q + reg;
+                    if (hc < HEADN && inside) a.out[(((long)n * HEADN + hc) * a.H + gy) * a.W + gx] = h[nth][reg] + hb[hc];  // NCHW
                 }
-            }
         }
     }
 }
@@ -237,9 +216,8 @@ static int launch_mdw_t(MdwArgs a, int Nf, hipStream_t s)
 {
     a.tiles_y = (a.H + TH - 1) / TH;
     a.tiles_x = (a.W + TW - 1) / TW;
-    constexpr int NRP = (TH + 4) * (TW + 4), MTO = TH * TW / 16;
-    constexpr size_t lds = ((size_t)16 * (((NRP + 7) / 8) * 8 + 2) + mdw_stream_floats(C, N, HEADN, sizeof(T) == 2) +
-                            (HEADN ? (size_t)(NWAVE < MTO ? NWAVE : MTO) * 16 * (N + 4) : 0)) * sizeof(float);
+    constexpr int NRP = (TH + 4) * (TW + 4);
+    constexpr size_t lds = ((size_t)16 * (((NRP + 7) / 8) * 8 + 2) + mdw_stream_floats(C, N, HEADN, sizeof(T) == 2)) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done = false;
     if (lds > 64 * 1024 && !attr_done) {
