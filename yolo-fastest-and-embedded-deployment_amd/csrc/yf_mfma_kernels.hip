@@ -44,7 +44,7 @@ __device__ __forceinline__ void mfma_source_f16(const half_t* __restrict__ in, c
         for (int nt = 0; nt < NT; ++nt) {
             const f16x4 bv = b4[(kb * NT + nt) * 64 + lane];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(av[mt], bv, acc[mt][nt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(bv, av[mt], acc[mt][nt], 0, 0, 0);
         }
     }
     if constexpr (KS % 16 != 0) {
@@ -58,7 +58,7 @@ __device__ __forceinline__ void mfma_source_f16(const half_t* __restrict__ in, c
         for (int nt = 0; nt < NT; ++nt) {
             const f16x4 bv = b4[(NB * NT + nt) * 64 + lane];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(av[mt], bv, acc[mt][nt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(bv, av[mt], acc[mt][nt], 0, 0, 0);
         }
     }
 }
@@ -81,7 +81,7 @@ __device__ __forceinline__ void mfma_source(const float* __restrict__ in, const 
                 const float bv = bp[((kb * 4 + j) * NT + nt) * 64 + lane];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&av[mt])[j], bv, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, ((const float*)&av[mt])[j], acc[mt][nt], 0, 0, 0);
             }
         }
     }
@@ -97,7 +97,7 @@ __device__ __forceinline__ void mfma_source(const float* __restrict__ in, const 
                 const float bv = bp[((NB * 4 + j) * NT + nt) * 64 + lane];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&av[mt])[j], bv, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, ((const float*)&av[mt])[j], acc[mt][nt], 0, 0, 0);
             }
         }
     }
@@ -138,33 +138,37 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwArgs a)
         if constexpr (K2 > 0) mfma_source<K2, NT, MT>(a.in2, rows, q, bp + (size_t)S1 * NT * 64, lane, acc);
     }
 
-    // epilogue: lane holds column c = nt*16 + r of rows row0 + mt*16 + 4q + reg
+    // epilogue.  The weights are the MFMA's A operand and the activations its B operand (the two fragment layouts index
+    // (l & 15, l >> 4) the same way: the same registers, swapped), so lane (r, q) holds output channels nt*16 + 4q .. +3 of row
+    // row0 + mt*16 + r: one 16-byte (fp16: 8-byte) residual read and store per lane and n-tile
+    static_assert(N % 4 == 0, "channel counts are multiples of 4");
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int c = nt * 16 + r;
-        if (c >= N) continue;
-        const float bias = a.b[c];
+    for (int mt = 0; mt < MT; ++mt) {
+        const long row = row0 + mt * 16 + r;
+        if (row >= a.npix) continue;
+        long opix = row;
+        if constexpr (OMODE == 2) {  // ConvTranspose2d k=2 s=2: quadrant (dy,dx) -> pixel (2y+dy, 2x+dx)
+            const long n = row / a.HW, hw = row - n * a.HW;
+            const int y = (int)(hw / a.W), x = (int)(hw - (long)y * a.W);
+            const int dy = blockIdx.z >> 1, dx = blockIdx.z & 1;
+            opix = (n * (2 * (a.HW / a.W)) + 2 * y + dy) * (2 * a.W) + 2 * x + dx;
+        }
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const long row = row0 + mt * 16 + 4 * q + reg;
-                if (row >= a.npix) continue;
-                float v = acc[mt][nt][reg] + bias;
-                if constexpr (RES) v += ld1<T>(reinterpret_cast<const T*>(a.res) + row * N + c);
-                if constexpr (RELU) v = fmaxf(v, 0.f);
-                if constexpr (OMODE == 0) {
-                    st1<T>(reinterpret_cast<T*>(a.out) + row * N + c, v);
-                } else if constexpr (OMODE == 1) {  // NCHW (the heads): always fp32, the reference's output
-                    const long n = row / a.HW, hw = row - n * a.HW;
-                    a.out[(n * N + c) * a.HW + hw] = v;
-                } else {  // ConvTranspose2d k=2 s=2: quadrant (dy,dx) -> pixel (2y+dy, 2x+dx)
-                    const long n = row / a.HW, hw = row - n * a.HW;
-                    const int y = (int)(hw / a.W), x = (int)(hw - (long)y * a.W);
-                    const int dy = blockIdx.z >> 1, dx = blockIdx.z & 1;
-                    const long opix = (n * (2 * (a.HW / a.W)) + 2 * y + dy) * (2 * a.W) + 2 * x + dx;
-                    st1<T>(reinterpret_cast<T*>(a.out) + opix * N + c, v);
-                }
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = nt * 16 + 4 * q;
+            if (c >= N) continue;
+            float4 v = make_float4(acc[mt][nt][0] + a.b[c], acc[mt][nt][1] + a.b[c + 1], acc[mt][nt][2] + a.b[c + 2], acc[mt][nt][3] + a.b[c + 3]);
+            if constexpr (RES) {
+                const float4 x = ld4<T>(reinterpret_cast<const T*>(a.res) + row * N + c);
+                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+            }
+            if constexpr (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if constexpr (OMODE == 1) {  // NCHW (the heads): always fp32, the reference's output
+                const long n = row / a.HW, hw = row - n * a.HW;
+                a.out[(n * N + c) * a.HW + hw] = v.x; a.out[(n * N + c + 1) * a.HW + hw] = v.y;
+                a.out[(n * N + c + 2) * a.HW + hw] = v.z; a.out[(n * N + c + 3) * a.HW + hw] = v.w;
+            } else {
+                st4<T>(reinterpret_cast<T*>(a.out) + opix * N + c, v);
             }
         }
     }
