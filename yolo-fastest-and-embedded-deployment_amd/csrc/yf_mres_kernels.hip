@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
     static_assert((TH * TW) % 16 == 0 && CIN % 8 == 0 && COUT % 4 == 0, "shape");
     static_assert(!RES || (CIN == COUT && S == 1), "residual needs same shape");
     static_assert(CHUNK == mres_chunk_floats(CIN, COUT, H16), "pack layout");
-    static_assert(MTRW * 4 <= 32, "in-image mask bits");
+    static_assert(MTRW <= 32, "in-image mask bits");
     extern __shared__ __attribute__((aligned(16))) float mres_smem[];
     float* X = mres_smem;                 // [MTR*16][XP]
     float* E = mres_smem + MTR * 16 * XP; // [4][EPL][4]
@@ -101,12 +101,11 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
             const float2 t = *reinterpret_cast<const float2*>(&X[row * XP + NB1 * 16 + 2 * q]);
             a1[i][NB1 * 4 + 0] = t.x; a1[i][NB1 * 4 + 1] = t.y;
         }
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int rp = mt * 16 + 4 * q + reg;
+        {   // this lane's pixel of the expansion result (see the expand step): region pixel mt*16 + r
+            const int rp = mt * 16 + r;
             const int ry = rp / RW, rx = rp - ry * RW;
             const int iy = oy0 * S - 1 + ry, ix = ox0 * S - 1 + rx;
-            if (mt < MTR && rp < NRP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) inmask |= 1u << (i * 4 + reg);
+            if (mt < MTR && rp < NRP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) inmask |= 1u << i;
         }
     }
     // ---- projection accumulators and the E offsets of this lane's output pixel (as A-fragment row r) ----
@@ -134,7 +133,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
 #pragma unroll
             for (int s = 0; s < KS1; ++s) w1f[s] = wc[s * 64 + lane];
         }
-        const float b1 = wc[OFF_B1 + r];
+        const float4 b1 = *reinterpret_cast<const float4*>(wc + OFF_B1 + 4 * q);
         float4 wd[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) wd[t] = *reinterpret_cast<const float4*>(wc + OFF_WD + t * 16 + 4 * q);
@@ -151,7 +150,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                 for (int nt = 0; nt < NT2; ++nt) w2f[j][nt] = wc[OFF_W2 + (j * NT2 + nt) * 64 + lane];
         }
 
-        // ---- expand: E[ch r][pixels mt*16 + 4q .. +3] ----
+        // ---- expand: E[channels 4q .. 4q+3][pixel mt*16 + r] ----
 #pragma unroll
         for (int i = 0; i < MTRW; ++i) {
             const int mt = wave + i * NWAVE;
@@ -162,16 +161,17 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                     for (int s = 0; s < NK1; ++s) {
                         const f16x4 ah = f16x4{(half_t)a1[i][4 * s], (half_t)a1[i][4 * s + 1], 4 * s + 2 < KS1 ? (half_t)a1[i][(4 * s + 2) % KS1] : (half_t)0.f,
                                                4 * s + 3 < KS1 ? (half_t)a1[i][(4 * s + 3) % KS1] : (half_t)0.f};
-                        cf = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, w1h[s], cf, 0, 0, 0);
+                        cf = __builtin_amdgcn_mfma_f32_16x16x16f16(w1h[s], ah, cf, 0, 0, 0);
                     }
                 } else {
 #pragma unroll
-                    for (int s = 0; s < KS1; ++s) cf = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][s], w1f[s], cf, 0, 0, 0);
+                    for (int s = 0; s < KS1; ++s) cf = __builtin_amdgcn_mfma_f32_16x16x4f32(w1f[s], a1[i][s], cf, 0, 0, 0);
                 }
-                float* dst = E + ((r >> 2) * EPL + mt * 16 + 4 * q) * 4 + (r & 3);  // channel r of pixels 4q..4q+3
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg)
-                    dst[reg * 4] = (inmask >> (i * 4 + reg)) & 1 ? fmaxf(cf[reg] + b1, 0.f) : 0.f;
+                // weights as the A operand: the lane holds channels 4q .. 4q+3 of region pixel mt*16 + r = one E record
+                const bool in = (inmask >> i) & 1;
+                *reinterpret_cast<float4*>(E + (q * EPL + mt * 16 + r) * 4) =
+                    make_float4(in ? fmaxf(cf[0] + b1.x, 0.f) : 0.f, in ? fmaxf(cf[1] + b1.y, 0.f) : 0.f,
+                                in ? fmaxf(cf[2] + b1.z, 0.f) : 0.f, in ? fmaxf(cf[3] + b1.w, 0.f) : 0.f);
             }
         }
         __syncthreads();
@@ -308,12 +308,11 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
                 const float2 t = *reinterpret_cast<const float2*>(&X[row * XP + NB1 * 16 + 2 * q]);
                 a1[i][NB1 * 4 + 0] = t.x; a1[i][NB1 * 4 + 1] = t.y;
             }
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int rp = mt * 16 + 4 * q + reg;
+            {
+                const int rp = mt * 16 + r;
                 const int ry = rp / RW, rx = rp - ry * RW;
                 const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
-                if (mt < MTR && rp < NRP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) inmask |= 1ull << (i * 4 + reg);
+                if (mt < MTR && rp < NRP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) inmask |= 1ull << i;
             }
         }
 #pragma unroll 1
@@ -330,7 +329,7 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
 #pragma unroll
                     for (int k = 0; k < KS1; ++k) w1f[k] = wc[k * 64 + lane];
                 }
-                const float b1 = wc[OFF_B1 + r];
+                const float4 b1 = *reinterpret_cast<const float4*>(wc + OFF_B1 + 4 * q);
 #pragma unroll
                 for (int i = 0; i < MTRW; ++i) {
                     const int mt = wave + i * NWP;
@@ -342,16 +341,16 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
                                 const f16x4 ah = f16x4{(half_t)a1[i][4 * k], (half_t)a1[i][4 * k + 1],
                                                        4 * k + 2 < KS1 ? (half_t)a1[i][(4 * k + 2) % KS1] : (half_t)0.f,
                                                        4 * k + 3 < KS1 ? (half_t)a1[i][(4 * k + 3) % KS1] : (half_t)0.f};
-                                cf = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, w1h[k], cf, 0, 0, 0);
+                                cf = __builtin_amdgcn_mfma_f32_16x16x16f16(w1h[k], ah, cf, 0, 0, 0);
                             }
                         } else {
 #pragma unroll
-                            for (int k = 0; k < KS1; ++k) cf = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][k], w1f[k], cf, 0, 0, 0);
+                            for (int k = 0; k < KS1; ++k) cf = __builtin_amdgcn_mfma_f32_16x16x4f32(w1f[k], a1[i][k], cf, 0, 0, 0);
                         }
-                        float* dst = Eb + ((r >> 2) * EPL + mt * 16 + 4 * q) * 4 + (r & 3);
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg)
-                            dst[reg * 4] = (inmask >> (i * 4 + reg)) & 1 ? fmaxf(cf[reg] + b1, 0.f) : 0.f;
+                        const bool in = (inmask >> i) & 1;
+                        *reinterpret_cast<float4*>(Eb + (q * EPL + mt * 16 + r) * 4) =
+                            make_float4(in ? fmaxf(cf[0] + b1.x, 0.f) : 0.f, in ? fmaxf(cf[1] + b1.y, 0.f) : 0.f,
+                                        in ? fmaxf(cf[2] + b1.z, 0.f) : 0.f, in ? fmaxf(cf[3] + b1.w, 0.f) : 0.f);
                     }
                 }
             }
