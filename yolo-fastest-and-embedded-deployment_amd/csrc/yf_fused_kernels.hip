@@ -303,7 +303,9 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
 //   Measured alternatives that did NOT help (tools/kbench.hip, profiles/): two pixels per lane (each scalar weight feeding
 //   two FMAs) and v_pk_fma_f32 over pixel pairs or output-channel pairs all land at the same ~250 us / 30 TMAC/s although the
 //   packed forms halve the VALU instruction count -- the kernel is not VALU-issue-bound (fully unrolled straight-line code,
-//   instruction fetch is the suspect).
+//   instruction fetch is the suspect).  Later finding (tools/isa_mix.py): this fully unrolled form also spills ~900 SGPR values to
+//   VGPR lanes (v_readlane / v_writelane are a third of its VALU instructions).  Superseded by k19m_kernel (yf_k19_kernels.hip);
+//   kept as the VALU reference point of tools/kbench.hip.
 //   conv1_8's output over the (33x33) halo'd region goes to LDS in two halves of 12 channels, split into
 //   even-column and odd-column planes ("space to depth") so that lanes on consecutive output columns read
 //   consecutive 48-B pixel records: conflict-free ds_read_b128.
