@@ -575,3 +575,87 @@ def test_fp16_other_input_sizes_and_u8(yf, dev):
             d = (got.cpu() - ref).abs()
             assert d.max().item() <= 3e-3 * max(1.0, ref.abs().max().item()) + 1e-2, (H, W, d.max().item())
         assert torch.equal(ul, hl) and torch.equal(us, hs)   # the fused u8 load computes the same (x - 128) / 255
+
+
+@pytest.mark.parametrize("res", [256, 512])
+def test_post_process_randomised_against_c_oracle(yf, models, dev, res):
+    """Windowed NMS / 16-wave post kernel against oracle/post_oracle.c (the reference's loop, restated) on random logit fields:
+    sparse to very dense, thresholds at the extremes (nms_thres 0 and 1, a NEGATIVE one -- where even disjoint boxes suppress each
+    other --, conf_thres low), quantised confidences (many exact ties), tiny boxes (zero-area -> the reference's ZeroDivisionError
+    path must agree too).  Bit-exact boxes, classes and survivor order."""
+    from oracle import post_oracle_c as poc
+    m, _, io = models[res]
+    H, W = io["input_shape"][:2]
+    m(_x(np.zeros((1, H, W), np.uint8), dev))
+    cases = [(0.5, 0.2, -1.0, 1.5, 0.5, None), (0.5, 0.0, -1.0, 1.5, 0.5, None), (0.5, 1.0, -2.0, 1.0, 0.5, None),
+             (0.5, -0.1, -2.5, 1.0, 0.5, None), (0.2, 0.5, 0.0, 2.0, 1.0, None), (0.5, 0.3, -1.0, 1.5, 0.5, 0.5),
+             (0.5, 0.2, -2.0, 1.0, -6.0, None), (0.9, 0.45, 1.0, 2.0, 0.3, 1.0)]
+    for ci, (conf, nms, mu, sd, wh_mu, quant) in enumerate(cases):
+        hl, hs = [], []
+        for f in range(3):
+            g = np.random.default_rng(1000 * ci + f)
+            for (h, w), dst in (((H // 16, W // 16), hl), ((H // 32, W // 32), hs)):
+                t = np.empty((3, 8, h, w), np.float32)
+                t[:, 0:2] = g.normal(0.0, 1.0, (3, 2, h, w)); t[:, 2:4] = g.normal(wh_mu, 0.5, (3, 2, h, w))
+                t[:, 4] = g.normal(mu, sd, (3, h, w)); t[:, 5:8] = g.normal(0.0, 2.0, (3, 3, h, w))
+                if quant:
+                    t[:, 4:8] = np.round(t[:, 4:8] / quant) * quant   # exact ties in confidence and class scores
+                dst.append(t.reshape(24, h, w))
+        post = yf.YOLO_post_process(conf, nms, 3, 3, io["anchors"], io["input_shape"]).bind(m)
+        pred = (torch.from_numpy(np.stack(hl)).to(dev), torch.from_numpy(np.stack(hs)).to(dev))
+        kmax = 3 * (hl[0].shape[1] * hl[0].shape[2] + hs[0].shape[1] * hs[0].shape[2])
+        raw = post.detect_raw(pred, kmax=kmax)
+        counts = raw["counts"].cpu().numpy()
+        for f in range(3):
+            try:
+                r = poc.post_process(hl[f], hs[f], io["anchors"], io["input_shape"][:2], conf_thres=conf, nms_thres=nms)
+            except ZeroDivisionError:       # the reference raises (detect.py:39): the kernel reports count -2
+                assert counts[f] == -2, (res, ci, f, counts[f])
+                continue
+            assert counts[f] == r["count"], (res, ci, f, counts[f], r["count"], r["n_candidates"])
+            n = r["count"]
+            if n > 0:
+                assert np.array_equal(raw["src"][f, :n].cpu().numpy(), r["src"]), (res, ci, f)
+                assert np.array_equal(raw["boxes"][f, :n].cpu().numpy(), r["box"]), (res, ci, f)
+                assert np.array_equal(raw["cls"][f, :n].cpu().numpy(), r["cls"]), (res, ci, f)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_random_weights_against_oracle(yf, dev, seed):
+    """Not only the two shipped checkpoints: a random 508-key state-dict (He-style conv weights, BN statistics away from the
+    identity, negative biases) through every kernel of the fused plan, fp32 and fp16 storage, against the oracle evaluated in
+    fp32 and fp64 (same accuracy-class bound as for the shipped weights)."""
+    from oracle import backbone_oracle as bo
+    from yolo_fastest_amd import packer
+    io = yf.io_params_for(256)
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, kind, cin, cout, k, stride, relu in packer.layer_table(24, 1):
+        if kind == packer.KIND_HEAD:
+            sd[name + ".weight"] = torch.randn((cout, cin, 1, 1), generator=g) * (1.0 / cin) ** 0.5
+            sd[name + ".bias"] = torch.randn((cout,), generator=g) * 0.5
+            continue
+        shape = {packer.KIND_PW: (cout, cin, 1, 1), packer.KIND_DENSE: (cout, cin, k, k), packer.KIND_DW: (cout, 1, k, k),
+                 packer.KIND_DECONV: (cin, cout, 2, 2)}[kind]
+        fan = cin * (k * k if kind == packer.KIND_DENSE else 1) if kind != packer.KIND_DW else k * k
+        sd[name + ".0.weight"] = torch.randn(shape, generator=g) * (1.0 / fan) ** 0.5   # keeps the 86-layer chain in range
+        sd[name + ".1.weight"] = 0.5 + torch.rand((cout,), generator=g)
+        sd[name + ".1.bias"] = torch.randn((cout,), generator=g) * 0.2
+        sd[name + ".1.running_mean"] = torch.randn((cout,), generator=g) * 0.2
+        sd[name + ".1.running_var"] = 0.5 + torch.rand((cout,), generator=g)
+        sd[name + ".1.num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+    m = yf.YoloFastest(io).to(dev).eval()
+    m.load_state_dict(sd)
+    u8 = np.random.default_rng(seed).integers(0, 256, size=(3, 256, 320), dtype=np.uint8)
+    with torch.no_grad():
+        hl, hs = m(_x(u8, dev))
+    ol, os_ = bo.forward(sd, bo.preprocess(u8))
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    tl, ts = bo.forward(sd64, bo.preprocess(u8).double())
+    _check_heads(hl, hs, ol, os_, tl.numpy(), ts.numpy(), metric_size=False)
+    m.storage_dtype = torch.float16
+    with torch.no_grad():
+        fl, fs = m(_x(u8, dev))
+    for got, ref in ((fl, ol), (fs, os_)):
+        d = (got.cpu() - ref).abs()
+        assert d.max().item() <= 5e-3 * max(1.0, ref.abs().max().item()), d.max().item()
