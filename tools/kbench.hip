@@ -13,6 +13,7 @@
 #include "yf_mfma_kernels.hip"
 #include "yf_conv_kernels.hip"
 #include "yf_mres_kernels.hip"
+#include "yf_mdw_kernels.hip"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -292,6 +293,31 @@ int main(int argc, char** argv)
         bench_mres<8, 48, 16, false, 16, 40, 8>("8/48/16 s8", N, 32, 40);
         bench_mres<8, 32, 8, true, 16, 20, 4>("8/32 s4", N, 64, 80);
         bench_mres<8, 32, 8, true, 16, 40, 8>("8/32 s4", N, 64, 80);
+    }
+    if (on("mdw")) {
+        printf("--- dw5x5 -> 1x1 (-> head) kernels, 256 frames of 16x20 ---\n");
+        auto bench_mdw = [&](int c, int n, int headn, int H, int W, const char* tag) {
+            MdwArgs a{};
+            a.in = dev_rand((size_t)N * H * W * c);
+            a.wp = dev_rand(mdw_packed_floats(c, n, headn) + 64, 0.1f);
+            float* out; CK(hipMalloc(&out, (size_t)N * H * W * (headn ? 24 : n) * 4)); a.out = out;
+            a.H = H; a.W = W;
+#ifdef YF_MDW_STAMP
+            unsigned long long z[8] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(yf_mdw_dbg), z, sizeof z));
+#endif
+            float us = time_us([&] { launch_mdw(c, n, headn, a, N, 0, DT_F32); });
+            printf("mdw %-32s %8.1f us\n", tag, us);
+#ifdef YF_MDW_STAMP
+            unsigned long long h[8]; CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(yf_mdw_dbg), sizeof h));
+            double tot = 0; for (int i = 0; i < 7; ++i) tot += (double)h[i];
+            printf("    stamps%%: prologue %.1f | fill %.1f | barrier1 %.1f | depthwise %.1f | 1x1 MFMA %.1f | barrier2 %.1f | epilogue %.1f  (cycles/WG %.0f)\n",
+                   100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, 100 * h[5] / tot, 100 * h[6] / tot, tot / 23.0 / N);
+#endif
+        };
+        bench_mdw(96, 96, 0, 16, 20, "96->96 s16");
+        bench_mdw(96, 96, 24, 16, 20, "96->96->head s16");
+        bench_mdw(96, 128, 0, 8, 10, "96->128 s32");
+        bench_mdw(128, 128, 24, 8, 10, "128->128->head s32");
     }
     if (on("ws")) {
         printf("--- weight-stationary GEMM, conv4_1_1 shape (232 -> 96, 81920 rows) ---\n");

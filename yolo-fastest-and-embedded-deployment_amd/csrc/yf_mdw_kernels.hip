@@ -18,6 +18,26 @@ namespace yf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic build only (-DYF_MDW_STAMP, tools/kbench.hip mdw): per-phase shader-clock sums of wave 0 of every workgroup.
+#ifdef YF_MDW_STAMP
+__device__ unsigned long long yf_mdw_dbg[8];
+__device__ __forceinline__ unsigned long long mdw_clock()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define MDW_STAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t_ = mdw_clock();
+#define MDW_STAMP(i) { unsigned long long n_ = mdw_clock(); st_[i] += n_ - st_t_; st_t_ = n_; }
+#define MDW_STAMP_FLUSH if (threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&yf_mdw_dbg[i_], st_[i_]); }
+#else
+#define MDW_STAMP_DECL
+#define MDW_STAMP(i)
+#define MDW_STAMP_FLUSH
+#endif
+
 // h16: B fragments are f16x4 per lane (one v_mfma_f32_16x16x16_f16 per 16-channel chunk and n-tile); dw weights / biases stay fp32
 __host__ __device__ constexpr int mdw_chunk_floats(int n, bool h16 = false) { return 25 * 16 + 16 + (h16 ? (n / 16) * 128 : 4 * (n / 16) * 64); }
 __host__ __device__ constexpr int mdw_stream_floats(int c, int n, int headn, bool h16 = false)
@@ -56,6 +76,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const TT* __restrict__ src = reinterpret_cast<const TT*>(a.in) + (long)n * a.H * a.W * C;
 
+    MDW_STAMP_DECL
     for (int i = threadIdx.x * 4; i < WFLOATS; i += NTHR * 4)
         *reinterpret_cast<float4*>(&WL[i]) = *reinterpret_cast<const float4*>(a.wp + i);
 
@@ -80,18 +101,27 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
     };
     prefetch(0);
 
+    // Which output pixel row r of the wave's i-th M-tile is.  ADJ: the MTOW tiles of a wave interleave, so that a lane's pixels
+    // are horizontally ADJACENT (x, x + 1, ..): their 5x5 windows overlap and a window row costs 4 + MTOW LDS reads instead of
+    // 5 MTOW (the depthwise phase is the kernel's largest and it is LDS-bound: 43 % of the time by the phase stamps).
+    constexpr bool ADJ = EVEN && MTOW > 1 && TW % MTOW == 0;
+    auto out_pixel = [&](int w, int i, int rr) {
+        if constexpr (ADJ) return (w * 16 + rr) * MTOW + i;
+        const int mo = w + i * NWAVE;
+        return (mo < MTO ? mo : 0) * 16 + rr;
+    };
     f32x4 acc[MTOW][NT];
     int rp0[MTOW];
 #pragma unroll
     for (int i = 0; i < MTOW; ++i) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[i][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int mo = wave + i * NWAVE;
-        const int op = (mo < MTO ? mo : 0) * 16 + r;
+        const int op = out_pixel(wave, i, r);
         const int oy = op / TW, ox = op - oy * TW;
         rp0[i] = (oy + 2) * RW + ox + 2;
     }
 
+    MDW_STAMP(0)   // prologue: weight staging requests, addressing, first prefetch
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
         // ---- fill E with this chunk (prefetched), then request the next chunk ----
@@ -100,7 +130,9 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
             const int id = threadIdx.x + m * NTHR;
             if (goff[m] != -2) *reinterpret_cast<float4*>(&E[((id & 3) * EPL + (id >> 2)) * 4]) = pf[m];
         }
+        MDW_STAMP(1)   // E fill (waits for the prefetched chunk)
         __syncthreads();
+        MDW_STAMP(2)   // barrier 1
         if (c + 1 < NCH) prefetch(c + 1);
         // ---- depthwise 5x5 of channels 4q..4q+3 at this lane's output pixels (taps outer: one weight read per tap) ----
         const float* wc = WL + c * CHUNK;
@@ -109,20 +141,36 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
 #pragma unroll
         for (int i = 0; i < MTOW; ++i) { d[i][0] = bd.x; d[i][1] = bd.y; d[i][2] = bd.z; d[i][3] = bd.w; }
         const float4* e4 = reinterpret_cast<const float4*>(E) + q * EPL;
+        // One window row at a time: all of the row's LDS reads (activations AND its five tap weights) are issued together, then
+        // its FMAs.  (Reading each tap's weight right before its 8 FMAs exposed an LDS round trip per tap: 230 cycles per tap,
+        // 43 % of the kernel by the phase stamps; double-buffering whole rows spills at 10 waves per workgroup.)
+        constexpr int NV = ADJ ? 4 + MTOW : 5 * MTOW;   // activation reads per window row
 #pragma unroll
-        for (int ky = 0; ky < 5; ++ky)
+        for (int ky = 0; ky < 5; ++ky) {
+            float4 vc[NV], wr[5];
 #pragma unroll
-            for (int kx = 0; kx < 5; ++kx) {
-                const float4 w = *reinterpret_cast<const float4*>(wc + (ky * 5 + kx) * 16 + 4 * q);
+            for (int kx = 0; kx < 5; ++kx) wr[kx] = *reinterpret_cast<const float4*>(wc + (ky * 5 + kx) * 16 + 4 * q);
+            if constexpr (ADJ) {
+#pragma unroll
+                for (int j = 0; j < NV; ++j) vc[j] = e4[rp0[0] + (ky - 2) * RW + (j - 2)];
+            } else {
+#pragma unroll
+                for (int i = 0; i < MTOW; ++i)
+#pragma unroll
+                    for (int kx = 0; kx < 5; ++kx) vc[i * 5 + kx] = e4[rp0[i] + (ky - 2) * RW + (kx - 2)];   // (clamped tile for idle slots)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx)
 #pragma unroll
                 for (int i = 0; i < MTOW; ++i) {
-                    if (EVEN || wave + i * NWAVE < MTO) {
-                        const float4 v = e4[rp0[i] + (ky - 2) * RW + (kx - 2)];
-                        d[i][0] = fmaf(v.x, w.x, d[i][0]); d[i][1] = fmaf(v.y, w.y, d[i][1]);
-                        d[i][2] = fmaf(v.z, w.z, d[i][2]); d[i][3] = fmaf(v.w, w.w, d[i][3]);
-                    }
+                    const float4 v = ADJ ? vc[kx + i] : vc[i * 5 + kx];
+                    d[i][0] = fmaf(v.x, wr[kx].x, d[i][0]); d[i][1] = fmaf(v.y, wr[kx].y, d[i][1]);
+                    d[i][2] = fmaf(v.z, wr[kx].z, d[i][2]); d[i][3] = fmaf(v.w, wr[kx].w, d[i][3]);
                 }
-            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        MDW_STAMP(3)   // depthwise
         // ---- 1x1 conv: A = relu(d) (k-step j = channel 4q+j), B fragments from the staged stream ----
         if constexpr (H16) {
             f16x4 w2h[NT];
@@ -154,7 +202,9 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
                 }
             }
         }
+        MDW_STAMP(4)   // 1x1 conv MFMAs
         __syncthreads();
+        MDW_STAMP(5)   // barrier 2
     }
 
     // ---- epilogue.  The 1x1 conv ran with its weights as the MFMA's A operand and the depthwise result as B (the same
@@ -167,7 +217,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
     for (int i = 0; i < MTOW; ++i) {  // (unrolled: a runtime-indexed acc[] would live in scratch)
         const int mo = wave + i * NWAVE;
         if (!EVEN && mo >= MTO) continue;
-        const int op = mo * 16 + r;
+        const int op = out_pixel(wave, i, r);
         const int oy = op / TW, ox = op - oy * TW;
         const int gy = oy0 + oy, gx = ox0 + ox;
         const bool inside = gy < a.H && gx < a.W;
@@ -209,6 +259,8 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
                 }
         }
     }
+    MDW_STAMP(6)   // epilogue
+    MDW_STAMP_FLUSH
 }
 
 template <int C, int N, int HEADN, int TH, int TW, int NWAVE, typename T>
