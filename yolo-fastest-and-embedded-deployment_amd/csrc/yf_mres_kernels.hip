@@ -182,17 +182,26 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
             if (EVEN_O || mo < MTO) {
                 const float4* e = reinterpret_cast<const float4*>(E) + q * EPL + rp0[i];
                 float d[4] = {bd.x, bd.y, bd.z, bd.w};
+                // All nine window reads go out together (left to the scheduler they were split 3 + 1 + 5 with a wait each) ... except in
+                // the smallest block (8/32 stride-2 triple), where three workgroups fit a CU's LDS and the +24 VGPRs of the batch take it
+                // from 74 to 98 registers = from three resident workgroups to two (measured 35 -> 42 us).
+                constexpr bool BATCH9 = CEXP > 32;
+                float4 v9[9];
+                if constexpr (BATCH9) {
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                    for (int t = 0; t < 9; ++t) v9[t] = e[(t / 3 - 1) * RW + (t % 3 - 1)];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const float4 v = e[(ky - 1) * RW + (kx - 1)];
-                        const float4 w = wd[ky * 3 + kx];
-                        d[0] = fmaf(v.x, w.x, d[0]);
-                        d[1] = fmaf(v.y, w.y, d[1]);
-                        d[2] = fmaf(v.z, w.z, d[2]);
-                        d[3] = fmaf(v.w, w.w, d[3]);
-                    }
+                for (int t = 0; t < 9; ++t) {
+                    float4 v;
+                    if constexpr (BATCH9) v = v9[t]; else v = e[(t / 3 - 1) * RW + (t % 3 - 1)];
+                    const float4 w = wd[t];
+                    d[0] = fmaf(v.x, w.x, d[0]);
+                    d[1] = fmaf(v.y, w.y, d[1]);
+                    d[2] = fmaf(v.z, w.z, d[2]);
+                    d[3] = fmaf(v.w, w.w, d[3]);
+                }
                 if constexpr (H16) {
                     const f16x4 dh = f16x4{(half_t)fmaxf(d[0], 0.f), (half_t)fmaxf(d[1], 0.f), (half_t)fmaxf(d[2], 0.f), (half_t)fmaxf(d[3], 0.f)};
 #pragma unroll
@@ -396,15 +405,16 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
                     if (mo < MTO) {
                         const float4* e = reinterpret_cast<const float4*>(Eb) + q * EPL + rp0[i];
                         float d[4] = {bd.x, bd.y, bd.z, bd.w};
+                        float4 v9[9];   // all nine window reads go out together
 #pragma unroll
-                        for (int ky = 0; ky < 3; ++ky)
+                        for (int t = 0; t < 9; ++t) v9[t] = e[(t / 3 - 1) * RW + (t % 3 - 1)];
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int kx = 0; kx < 3; ++kx) {
-                                const float4 v = e[(ky - 1) * RW + (kx - 1)];
-                                const float4 w = wd[ky * 3 + kx];
-                                d[0] = fmaf(v.x, w.x, d[0]); d[1] = fmaf(v.y, w.y, d[1]);
-                                d[2] = fmaf(v.z, w.z, d[2]); d[3] = fmaf(v.w, w.w, d[3]);
-                            }
+                        for (int t = 0; t < 9; ++t) {
+                            const float4 v = v9[t], w = wd[t];
+                            d[0] = fmaf(v.x, w.x, d[0]); d[1] = fmaf(v.y, w.y, d[1]);
+                            d[2] = fmaf(v.z, w.z, d[2]); d[3] = fmaf(v.w, w.w, d[3]);
+                        }
                         if constexpr (H16) {
                             const f16x4 dh = f16x4{(half_t)fmaxf(d[0], 0.f), (half_t)fmaxf(d[1], 0.f), (half_t)fmaxf(d[2], 0.f),
                                                    (half_t)fmaxf(d[3], 0.f)};
