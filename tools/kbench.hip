@@ -101,9 +101,19 @@ static void bench_mres(const char* tag, int N, int H, int W)
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mres_kernel<CIN, CEXP, COUT, RES, 1, TH, TW, NWAVE, float>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(N * a.tiles_y * a.tiles_x);
+#ifdef YF_MRES_STAMP
+    { unsigned long long z[16] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(yf_mres_dbg), z, sizeof z)); }
+#endif
     float us = time_us([&] { hipLaunchKernelGGL((mres_kernel<CIN, CEXP, COUT, RES, 1, TH, TW, NWAVE, float>), grid, dim3(NWAVE * 64), lds, 0, a); });
     double macs = (double)N * H * W * CEXP * (CIN + 9 + COUT);
     printf("%-40s tile=%2dx%-2d waves=%d lds=%6zu grid=%6u  %8.1f us  %6.2f TMAC/s\n", tag, TH, TW, NWAVE, lds, grid.x, us, macs / us * 1e-6);
+#ifdef YF_MRES_STAMP
+    { unsigned long long h[16]; CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(yf_mres_dbg), sizeof h));
+      for (int w = 0; w < 2; ++w) { double tot = 0; for (int i = 0; i < 8; ++i) tot += (double)h[w * 8 + i];
+        printf("    %s wave cycles/WG: stage %.0f | frags %.0f | chunk weights %.0f | expand %.0f | barrier1 %.0f | dw+project %.0f | barrier2 %.0f | epilogue %.0f | total %.0f\n",
+               w ? "last " : "first", h[w*8+0] / 23.0 / grid.x, h[w*8+1] / 23.0 / grid.x, h[w*8+2] / 23.0 / grid.x, h[w*8+3] / 23.0 / grid.x, h[w*8+4] / 23.0 / grid.x,
+               h[w*8+5] / 23.0 / grid.x, h[w*8+6] / 23.0 / grid.x, h[w*8+7] / 23.0 / grid.x, tot / 23.0 / grid.x); } }
+#endif
 }
 
 template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NWC>
@@ -271,6 +281,13 @@ int main(int argc, char** argv)
         bench_mres<16, 96, 16, true, 8, 10, 4>("16/96 s8", N, 32, 40);
         bench_mres<24, 136, 24, true, 8, 10, 8>("24/136 s16", N, 16, 20);
         bench_mres<24, 136, 24, true, 8, 20, 8>("24/136 s16", N, 16, 20);
+    }
+    if (on("mresp")) {
+        printf("--- MFMA blocks, production shapes (YF_MRES_DBG=%d) ---\n", YF_MRES_DBG);
+        bench_mres<8, 48, 8, true, 16, 20, 8>("8/48 s8", N, 32, 40);
+        bench_mres<16, 96, 16, true, 16, 20, 8>("16/96 s8", N, 32, 40);
+        bench_mres<16, 96, 16, true, 16, 20, 5>("16/96 s8 5 waves", N, 32, 40);
+        bench_mres<16, 96, 16, true, 16, 20, 10>("16/96 s8 10 waves", N, 32, 40);
     }
     if (on("mres")) {
         printf("--- MFMA residual blocks ---\n");

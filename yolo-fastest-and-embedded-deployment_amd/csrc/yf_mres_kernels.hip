@@ -22,7 +22,33 @@
 
 #include "yf_kernels.h"
 
+#ifndef YF_MRES_DBG
+#define YF_MRES_DBG 0   // tools/kbench.hip only: 1 = one dw window address, 2 / 4 = one k-step in expansion / projection, 8 = one dw tap
+#endif
+
 namespace yf {
+
+// Diagnostic build only (-DYF_MRES_STAMP, tools/kbench.hip mresp): per-phase shader-clock sums of the first ([0..7]) and the last
+// ([8..15]) wave of every workgroup.
+#ifdef YF_MRES_STAMP
+__device__ unsigned long long yf_mres_dbg[16];
+__device__ __forceinline__ unsigned long long mres_clock()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define MRES_STAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t_ = mres_clock();
+#define MRES_STAMP(i) { unsigned long long n_ = mres_clock(); st_[i] += n_ - st_t_; st_t_ = n_; }
+#define MRES_STAMP_FLUSH(NW) if ((threadIdx.x & 63) == 0 && (wave == 0 || wave == NW - 1)) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&yf_mres_dbg[(wave ? 8 : 0) + i_], st_[i_]); }
+#else
+#define MRES_STAMP_DECL
+#define MRES_STAMP(i)
+#define MRES_STAMP_FLUSH(NW)
+#endif
+
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -31,6 +57,43 @@ __host__ __device__ constexpr int mres_chunk_floats(int cin, int cout, bool h16 
 {
     return h16 ? ((mres_ksteps(cin) + 3) / 4) * 128 + 16 + 9 * 16 + 16 + ((cout + 15) / 16) * 128
                : mres_ksteps(cin) * 64 + 16 + 9 * 16 + 16 + 4 * ((cout + 15) / 16) * 64;
+}
+
+// Stage the block's weight stream and the halo'd input tile (zeros outside the image / beyond the region) in LDS.  ALL global loads
+// are issued before the first LDS write: as rolled loops with the load under a bounds branch, every iteration exposed its own
+// L2/HBM round trip -- six to seven serial trips were 40-50 % of a workgroup's life (tools/kbench.hip mresp, -DYF_MRES_STAMP).
+template <int CIN, int S, int RW, int NRP, int MTR, int XP, int WFLOATS, int NTHR, typename T>
+__device__ __forceinline__ void mres_stage(const MresArgs& a, int n, int oy0, int ox0, float* X, float* WL)
+{
+    constexpr int C4 = CIN / 4, NX = MTR * 16 * C4, NXI = (NX + NTHR - 1) / NTHR, NW4 = WFLOATS / 4, NWI = (NW4 + NTHR - 1) / NTHR;
+    const T* __restrict__ src = reinterpret_cast<const T*>(a.in) + (long)n * a.H * a.W * CIN;
+    float4 wv[NWI], xv[NXI];
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+        const int idx = threadIdx.x + i * NTHR;
+        wv[i] = (YF_MRES_DBG & 32) ? make_float4(0.01f, 0.02f, 0.03f, 0.04f) : *reinterpret_cast<const float4*>(a.wp + 4 * (idx < NW4 ? idx : NW4 - 1));
+    }
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+        const int idx = threadIdx.x + i * NTHR;
+        const int rp = idx / C4, c4 = idx - rp * C4;
+        const int ry = rp / RW, rx = rp - ry * RW;
+        const int iy = oy0 * S - 1 + ry, ix = ox0 * S - 1 + rx;
+        const bool ok = rp < NRP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        xv[i] = (YF_MRES_DBG & 16) ? make_float4(0.1f, 0.2f, 0.3f, 0.4f) : ld4<T>(src + (ok ? (iy * a.W + ix) * CIN + c4 * 4 : 0));
+        if (!ok) xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+        const int idx = threadIdx.x + i * NTHR;
+        if (idx < NW4) *reinterpret_cast<float4*>(&WL[4 * idx]) = wv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+        const int idx = threadIdx.x + i * NTHR;
+        const int rp = idx / C4, c4 = idx - rp * C4;
+        if (idx < NX) *reinterpret_cast<float4*>(&X[rp * XP + c4 * 4]) = xv[i];
+    }
 }
 
 // S = 2: the stride-2 triples (pw-expand -> dw3x3 stride 2 -> pw-project, no residual): a.H / a.W are the INPUT dims, the tile
@@ -66,24 +129,10 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
 
-    // ---- stage the weight stream (coalesced 16-B copies; every wave reads its fragments from LDS afterwards) ----
-    for (int i = threadIdx.x * 4; i < WFLOATS; i += NWAVE * 64 * 4)
-        *reinterpret_cast<float4*>(&WL[i]) = *reinterpret_cast<const float4*>(a.wp + i);
-    // ---- stage the halo'd input tile (zeros outside the image / beyond the region) ----
-    {
-        constexpr int C4 = CIN / 4;
-        const T* __restrict__ src = reinterpret_cast<const T*>(a.in) + (long)n * a.H * a.W * CIN;
-        for (int idx = threadIdx.x; idx < MTR * 16 * C4; idx += NWAVE * 64) {
-            const int rp = idx / C4, c4 = idx - rp * C4;
-            const int ry = rp / RW, rx = rp - ry * RW;
-            const int iy = oy0 * S - 1 + ry, ix = ox0 * S - 1 + rx;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rp < NRP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                v = ld4<T>(src + ((long)iy * a.W + ix) * CIN + c4 * 4);
-            *reinterpret_cast<float4*>(&X[rp * XP + c4 * 4]) = v;
-        }
-    }
+    MRES_STAMP_DECL
+    mres_stage<CIN, S, RW, NRP, MTR, XP, WFLOATS, NWAVE * 64, T>(a, n, oy0, ox0, X, WL);
     __syncthreads();
+    MRES_STAMP(0)   // staging + barrier
 
     // ---- expansion A fragments (constant over chunks) and the in-image mask of this lane's 4 C rows ----
     float a1[MTRW][KS1];
@@ -121,6 +170,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
         rp0[i] = (oy * S + 1) * RW + ox * S + 1;
     }
 
+    MRES_STAMP(1)   // fragments, offsets
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
         const float* wc = WL + c * CHUNK;
@@ -150,11 +200,12 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                 for (int nt = 0; nt < NT2; ++nt) w2f[j][nt] = wc[OFF_W2 + (j * NT2 + nt) * 64 + lane];
         }
 
+        MRES_STAMP(2)   // chunk weights from LDS
         // ---- expand: E[channels 4q .. 4q+3][pixel mt*16 + r] ----
 #pragma unroll
         for (int i = 0; i < MTRW; ++i) {
             const int mt = wave + i * NWAVE;
-            if (EVEN_R || mt < MTR) {
+            if (EVEN_R || i < MTRW - 1 || mt < MTR) {   // only a wave's LAST tile can be missing: the others share one basic block
                 f32x4 cf = f32x4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (H16) {
 #pragma unroll
@@ -165,7 +216,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                     }
                 } else {
 #pragma unroll
-                    for (int s = 0; s < KS1; ++s) cf = __builtin_amdgcn_mfma_f32_16x16x4f32(w1f[s], a1[i][s], cf, 0, 0, 0);
+                    for (int s = 0; s < ((YF_MRES_DBG & 2) ? 1 : KS1); ++s) cf = __builtin_amdgcn_mfma_f32_16x16x4f32(w1f[s], a1[i][s], cf, 0, 0, 0);
                 }
                 // weights as the A operand: the lane holds channels 4q .. 4q+3 of region pixel mt*16 + r = one E record
                 const bool in = (inmask >> i) & 1;
@@ -174,12 +225,14 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                                 in ? fmaxf(cf[2] + b1.z, 0.f) : 0.f, in ? fmaxf(cf[3] + b1.w, 0.f) : 0.f);
             }
         }
+        MRES_STAMP(3)   // expansion
         __syncthreads();
+        MRES_STAMP(4)   // barrier 1
         // ---- depthwise 3x3 of channels 4q..4q+3 at output pixel r  ==  A fragment of the projection ----
 #pragma unroll
         for (int i = 0; i < MTOW; ++i) {
             const int mo = wave + i * NWAVE;
-            if (EVEN_O || mo < MTO) {
+            if (EVEN_O || i < MTOW - 1 || mo < MTO) {
                 const float4* e = reinterpret_cast<const float4*>(E) + q * EPL + rp0[i];
                 float d[4] = {bd.x, bd.y, bd.z, bd.w};
                 // All nine window reads go out together (left to the scheduler they were split 3 + 1 + 5 with a wait each) ... except in
@@ -189,11 +242,11 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                 float4 v9[9];
                 if constexpr (BATCH9) {
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) v9[t] = e[(t / 3 - 1) * RW + (t % 3 - 1)];
+                    for (int t = 0; t < 9; ++t) v9[t] = e[((YF_MRES_DBG & 1) ? 0 : (t / 3 - 1) * RW + (t % 3 - 1))];
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
+                for (int t = 0; t < ((YF_MRES_DBG & 8) ? 1 : 9); ++t) {
                     float4 v;
                     if constexpr (BATCH9) v = v9[t]; else v = e[(t / 3 - 1) * RW + (t % 3 - 1)];
                     const float4 w = wd[t];
@@ -208,8 +261,8 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                     for (int nt = 0; nt < NT2; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(w2h[nt], dh, acc[i][nt], 0, 0, 0);
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float dj = fmaxf(d[j], 0.f);
+                    for (int j = 0; j < ((YF_MRES_DBG & 4) ? 1 : 4); ++j) {
+                        const float dj = fmaxf(d[j] + ((YF_MRES_DBG & 4) ? d[1] + d[2] + d[3] : 0.f), 0.f);
 #pragma unroll
                         for (int nt = 0; nt < NT2; ++nt)
                             acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[j][nt], dj, acc[i][nt], 0, 0, 0);
@@ -217,7 +270,9 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                 }
             }
         }
+        MRES_STAMP(5)   // depthwise + projection
         __syncthreads();
+        MRES_STAMP(6)   // barrier 2
     }
 
     // ---- epilogue: + bias (+ residual from X), NHWC store.  The projection ran with the weights as the MFMA's A operand and the
@@ -227,7 +282,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
 #pragma unroll
     for (int i = 0; i < MTOW; ++i) {
         const int mo = wave + i * NWAVE;
-        if (!EVEN_O && mo >= MTO) continue;
+        if (!EVEN_O && i == MTOW - 1 && mo >= MTO) continue;
         const int op = mo * 16 + r;
         const int oy = op / TW, ox = op - oy * TW;
         const int gy = oy0 + oy, gx = ox0 + ox;
@@ -245,6 +300,8 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
             st4<T>(reinterpret_cast<T*>(a.out) + (((long)n * Ho + gy) * Wo + gx) * COUT + col, v);
         }
     }
+    MRES_STAMP(7)   // epilogue
+    MRES_STAMP_FLUSH(NWAVE)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -283,21 +340,7 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
 
-    for (int i = threadIdx.x * 4; i < WFLOATS; i += NWAVE * 64 * 4)
-        *reinterpret_cast<float4*>(&WL[i]) = *reinterpret_cast<const float4*>(a.wp + i);
-    {
-        constexpr int C4 = CIN / 4;
-        const T* __restrict__ src = reinterpret_cast<const T*>(a.in) + (long)n * a.H * a.W * CIN;
-        for (int idx = threadIdx.x; idx < MTR * 16 * C4; idx += NWAVE * 64) {
-            const int rp = idx / C4, c4 = idx - rp * C4;
-            const int ry = rp / RW, rx = rp - ry * RW;
-            const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rp < NRP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                v = ld4<T>(src + ((long)iy * a.W + ix) * CIN + c4 * 4);
-            *reinterpret_cast<float4*>(&X[rp * XP + c4 * 4]) = v;
-        }
-    }
+    mres_stage<CIN, 1, RW, NRP, MTR, XP, WFLOATS, NWAVE * 64, T>(a, n, oy0, ox0, X, WL);
     __syncthreads();
 
     if (wave < NWP) {
@@ -342,7 +385,7 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
 #pragma unroll
                 for (int i = 0; i < MTRW; ++i) {
                     const int mt = wave + i * NWP;
-                    if (mt < MTR) {
+                    if (i < MTRW - 1 || mt < MTR) {
                         f32x4 cf = f32x4{0.f, 0.f, 0.f, 0.f};
                         if constexpr (H16) {
 #pragma unroll
@@ -402,7 +445,7 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
 #pragma unroll
                 for (int i = 0; i < MTOW; ++i) {
                     const int mo = cw + i * NWC;
-                    if (mo < MTO) {
+                    if (i < MTOW - 1 || mo < MTO) {
                         const float4* e = reinterpret_cast<const float4*>(Eb) + q * EPL + rp0[i];
                         float d[4] = {bd.x, bd.y, bd.z, bd.w};
                         float4 v9[9];   // all nine window reads go out together
@@ -439,7 +482,7 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
 #pragma unroll
         for (int i = 0; i < MTOW; ++i) {
             const int mo = cw + i * NWC;
-            if (mo >= MTO) continue;
+            if (i == MTOW - 1 && mo >= MTO) continue;
             const int op = mo * 16 + r;
             const int oy = op / TW, ox = op - oy * TW;
             const int gy = oy0 + oy, gx = ox0 + ox;
