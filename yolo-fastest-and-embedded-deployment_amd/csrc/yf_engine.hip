@@ -95,6 +95,7 @@ struct Op {
     int type = OP_LAYER;
     int l_pre = -1, l_exp = -1, l_dw = -1, l_proj = -1;  // fused block: conv0 (optional), expand, depthwise, project
     int l_head = -1;     // OP_MDW: fused head conv (or -1)
+    int out2 = -1;       // OP_MRES conv4_2 + conv4_3 + conv5_1: the expanded tensor (conv4_2) is a second output
     long mfma_off = -1;  // >= 0: pointwise layer runs on the matrix cores; offset of its packed B fragments
 };
 
@@ -177,7 +178,7 @@ struct Builder {
         int H = pre ? ti.H / 2 : ti.H, W = pre ? ti.W / 2 : ti.W;  // expansion resolution
         int st = kLayers[o.l_dw].stride;
         o.in1 = in; o.in2 = -1; o.res = res ? in : -1; o.omode = 0;
-        if (!pre && yf::mres_has_kernel(kLayers[o.l_exp].cin, kLayers[o.l_exp].cout, kLayers[o.l_proj].cout, res, st))
+        if (!pre && yf::mres_has_kernel(kLayers[o.l_exp].cin, kLayers[o.l_exp].cout, kLayers[o.l_proj].cout, res, st, kLayers[o.l_proj].relu != 0))
             o.type = OP_MRES;  // both pointwise convs on the matrix cores
         o.out = add_tensor(out_name, kLayers[o.l_proj].cout, H / st, W / st);
         e->ops.push_back(o);
@@ -199,6 +200,21 @@ struct Builder {
         o.out = add_tensor(head ? out_name : pw, head ? 24 : LP.cout, ti.H, ti.W, head ? ext : 0);
         e->ops.push_back(o);
         return o.out;
+    }
+    // conv4_2 (a skip tensor: the large head concatenates it) -> conv4_3 -> conv5_1 as one launch that also writes conv4_2
+    int triple_keep_expansion(const char* a, const char* b, const char* c, int x, int* expanded)
+    {
+        const LayerSpec &LA = kLayers[find_layer(a)], &LC = kLayers[find_layer(c)];
+        const int st = kLayers[find_layer(b)].stride;
+        if (!fused || !yf::mres_has_kernel(LA.cin, LA.cout, LC.cout, false, st, LC.relu != 0)) {
+            *expanded = unit(a, x);
+            return unit(c, unit(b, *expanded));
+        }
+        const int H = e->tensors[x].H, W = e->tensors[x].W;
+        *expanded = add_tensor(a, LA.cout, H, W);
+        const int out = fused_block(nullptr, a, b, c, x, c, false);
+        e->ops.back().out2 = *expanded;
+        return out;
     }
     int triple(const char* a, const char* b, const char* c, int x)
     {
@@ -238,11 +254,8 @@ void build_plan(Plan* e, bool fused)
     x = b.triple("conv3_5", "conv3_6", "conv4_1", x);
     for (const char* n : {"res4_1", "res4_2", "res4_3", "res4_4"}) x = b.resblock(n, x);
     const bool fused_deep = fused;
-    b.fused = false;  // conv4_2 (skip tensor), conv4_3, conv5_1 and the heads: matrix-core GEMMs + depthwise kernels
-    int conv4_2 = b.unit("conv4_2", x);
-    x = b.unit("conv4_3", conv4_2);
-    x = b.unit("conv5_1", x);
-    b.fused = fused_deep;
+    int conv4_2 = -1;
+    x = b.triple_keep_expansion("conv4_2", "conv4_3", "conv5_1", x, &conv4_2);
     for (const char* n : {"res5_1", "res5_2", "res5_3", "res5_4", "res5_5"}) x = b.resblock(n, x);
     b.fused = false;
     int conv5_2 = b.unit("conv5_2", x);
@@ -266,7 +279,9 @@ void build_plan(Plan* e, bool fused)
     // slot assignment: smallest free slot that fits, else grow the largest free one, else a new slot
     std::vector<int> free_slots;
     for (size_t i = 0; i < e->ops.size(); ++i) {
-        Tensor& t = e->tensors[e->ops[i].out];
+      for (int ot : {e->ops[i].out, e->ops[i].out2}) {
+        if (ot < 0) continue;
+        Tensor& t = e->tensors[ot];
         if (t.slot >= 0) {
             size_t need = t.elems();
             int best = -1, largest = -1;
@@ -285,6 +300,7 @@ void build_plan(Plan* e, bool fused)
                 e->slot_elems.push_back(need);
             }
         }
+      }
         const Op& o = e->ops[i];
         for (int in : {o.in1, o.in2, o.res}) {
             if (in < 0) continue;
@@ -385,7 +401,7 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                 rc = yf::launch_mdw(ti.C, kLayers[o.l_proj].cout, o.l_head >= 0 ? 24 : 0, a, n, s, e->dtype);
             } else if (o.type == OP_MRES) {
                 const LayerSpec &LE = kLayers[o.l_exp], &LP = kLayers[o.l_proj];
-                yf::MresArgs a{ptr(o.in1), e->d_wmfma + o.mfma_off, ptr(o.out), ti.H, ti.W, 0, 0};
+                yf::MresArgs a{ptr(o.in1), e->d_wmfma + o.mfma_off, ptr(o.out), ti.H, ti.W, 0, 0, o.out2 >= 0 ? ptr(o.out2) : nullptr};
                 rc = yf::launch_mres(LE.cin, LE.cout, LP.cout, o.res >= 0, kLayers[o.l_dw].stride, a, n, s, e->dtype);
             } else if (o.type == OP_FUSED_BLOCK) {
                 const bool pre = o.l_pre >= 0;
@@ -434,6 +450,10 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                                           hipMemcpyDeviceToDevice, s));
                 else
                     yf::launch_nhwc_to_nchw(ptr(o.out), probe_dst + (size_t)f0 * to.elems(), n, to.C, (long)to.H * to.W, s, e->dtype);
+            }
+            if (o.out2 >= 0 && o.out2 == probe_t) {
+                const Tensor& t2 = P.tensors[o.out2];
+                yf::launch_nhwc_to_nchw(ptr(o.out2), probe_dst + (size_t)f0 * t2.elems(), n, t2.C, (long)t2.H * t2.W, s, e->dtype);
             }
         }
        }

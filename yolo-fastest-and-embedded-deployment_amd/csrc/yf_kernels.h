@@ -104,9 +104,10 @@ struct MresArgs {
     float* out;        // NHWC [N,H,W,COUT]
     int H, W;
     int tiles_y, tiles_x;  // filled by the launcher
+    float* out_exp;    // optional: the EXPANDED tensor (after ReLU) is also written, NHWC [N,H,W,CEXP] -- conv4_2 is a skip tensor
 };
 int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArgs& a, int N, hipStream_t s, int dtype = DT_F32);
-bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride = 1);
+bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride = 1, bool relu_out = false);  // relu_out: ReLU after the projection
 size_t mres_packed_floats(int cin, int cexp, int cout, bool h16 = false);
 void mres_pack_weights(const float* w1, const float* b1, const float* wd, const float* bd, const float* w2, const float* b2,
                        int cin, int cexp, int cout, float* out, bool h16 = false);

@@ -96,6 +96,12 @@ __device__ __forceinline__ void mres_stage(const MresArgs& a, int n, int oy0, in
     }
 }
 
+// The one block whose EXPANDED tensor is needed later (conv4_2 feeds the large head's concat, yolo_fastest.py:209): the kernel also
+// writes it (MresArgs::out_exp).
+__host__ __device__ constexpr bool mres_writes_expansion(int cin, int cexp, int cout, int s) { return cin == 24 && cexp == 136 && cout == 48 && s == 2; }
+// ... and the one whose projection is a conv_norm_relu (conv5_1, yolo_fastest.py:124); every other block projects linearly (:62, :86-118)
+__host__ __device__ constexpr bool mres_relu_out(int cin, int cexp, int cout, int s) { return mres_writes_expansion(cin, cexp, cout, s); }
+
 // S = 2: the stride-2 triples (pw-expand -> dw3x3 stride 2 -> pw-project, no residual): a.H / a.W are the INPUT dims, the tile
 // is TH x TW OUTPUT pixels and the region (TH - 1) S + 3 rows.
 template <int CIN, int CEXP, int COUT, bool RES, int S, int TH, int TW, int NWAVE, typename T>
@@ -105,6 +111,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
     constexpr int MTR = (NRP + 15) / 16, MTO = (TH * TW) / 16;
     constexpr int MTRW = (MTR + NWAVE - 1) / NWAVE, MTOW = (MTO + NWAVE - 1) / NWAVE;
     constexpr bool EVEN_R = MTR % NWAVE == 0, EVEN_O = MTO % NWAVE == 0;  // every wave owns the same number of tiles: no branches
+    constexpr bool WEXP = mres_writes_expansion(CIN, CEXP, COUT, S);       // conv4_2 + conv4_3 + conv5_1: conv4_2 is a skip tensor
     constexpr int XP = CIN + 4;                           // X row pitch: conflict-free b128/b64 fragment reads
     constexpr int EPL = ((MTR * 16 + 7) / 8) * 8 + 1;     // pixels per 4-channel plane, == 1 (mod 8): conflict-free writes
     constexpr bool H16 = sizeof(T) == 2;  // fp16 storage: the pointwise GEMMs run on v_mfma_f32_16x16x16_f16 (4 k-steps each)
@@ -137,6 +144,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
     // ---- expansion A fragments (constant over chunks) and the in-image mask of this lane's 4 C rows ----
     float a1[MTRW][KS1];
     unsigned inmask = 0;
+    int eoff[MTRW];
 #pragma unroll
     for (int i = 0; i < MTRW; ++i) {
         const int mt = wave + i * NWAVE;
@@ -155,6 +163,9 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
             const int ry = rp / RW, rx = rp - ry * RW;
             const int iy = oy0 * S - 1 + ry, ix = ox0 * S - 1 + rx;
             if (mt < MTR && rp < NRP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) inmask |= 1u << i;
+            // expanded-tensor writeback (a.out_exp): each in-image pixel is written by ONE tile -- the first region row / column is
+            // the previous tile's last
+            eoff[i] = (inmask >> i & 1) && ry > 0 && rx > 0 ? (iy * a.W + ix) * CEXP + 4 * q : -1;  // within frame n
         }
     }
     // ---- projection accumulators and the E offsets of this lane's output pixel (as A-fragment row r) ----
@@ -220,9 +231,12 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                 }
                 // weights as the A operand: the lane holds channels 4q .. 4q+3 of region pixel mt*16 + r = one E record
                 const bool in = (inmask >> i) & 1;
-                *reinterpret_cast<float4*>(E + (q * EPL + mt * 16 + r) * 4) =
-                    make_float4(in ? fmaxf(cf[0] + b1.x, 0.f) : 0.f, in ? fmaxf(cf[1] + b1.y, 0.f) : 0.f,
-                                in ? fmaxf(cf[2] + b1.z, 0.f) : 0.f, in ? fmaxf(cf[3] + b1.w, 0.f) : 0.f);
+                const float4 ev = make_float4(in ? fmaxf(cf[0] + b1.x, 0.f) : 0.f, in ? fmaxf(cf[1] + b1.y, 0.f) : 0.f,
+                                              in ? fmaxf(cf[2] + b1.z, 0.f) : 0.f, in ? fmaxf(cf[3] + b1.w, 0.f) : 0.f);
+                *reinterpret_cast<float4*>(E + (q * EPL + mt * 16 + r) * 4) = ev;
+                if constexpr (WEXP)
+                    if (eoff[i] >= 0 && c * 16 + 4 * q < CEXP)
+                        st4<T>(reinterpret_cast<T*>(a.out_exp) + (long)n * a.H * a.W * CEXP + eoff[i] + c * 16, ev);
             }
         }
         MRES_STAMP(3)   // expansion
@@ -297,6 +311,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                 const float4 x = *reinterpret_cast<const float4*>(&X[((oy + 1) * RW + ox + 1) * XP + col]);
                 v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
             }
+            if constexpr (mres_relu_out(CIN, CEXP, COUT, S)) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
             st4<T>(reinterpret_cast<T*>(a.out) + (((long)n * Ho + gy) * Wo + gx) * COUT + col, v);
         }
     }
@@ -529,6 +544,7 @@ static int launch_mres_t(MresArgs a, int N, hipStream_t s)
 {
     a.tiles_y = (a.H / S + TH - 1) / TH;
     a.tiles_x = (a.W / S + TW - 1) / TW;
+    if (mres_writes_expansion(CIN, CEXP, COUT, S) && !a.out_exp) return -3;
     constexpr int MTR = (((TH - 1) * S + 3) * ((TW - 1) * S + 3) + 15) / 16;
     constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 16 * (((MTR * 16 + 7) / 8) * 8 + 1) +
                             ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT, sizeof(T) == 2) + COUT + 3) & ~3)) * sizeof(float);
@@ -554,6 +570,7 @@ static int launch_mres_t(MresArgs a, int N, hipStream_t s)
     MR(16, 96, 16, true, 1, 16, 20, 0, 8)   /* res3_3 .. res3_6         @ H/8  */         \
     MR(16, 96, 24, false, 2, 8, 10, 0, 8)   /* conv3_5/3_6/4_1          H/8 -> H/16 */    \
     MR(8, 32, 8, false, 2, 8, 10, 0, 8)     /* conv2_2/2_3/3_1          H/4 -> H/8  */    \
+    MR(24, 136, 48, false, 2, 8, 10, 0, 8)  /* conv4_2/4_3/5_1 (+ conv4_2 written) H/16 -> H/32 */ \
     MR(24, 136, 24, true, 1, 16, 20, 8, 8)  /* res4_1 .. res4_4         @ H/16 */         \
     MR(48, 224, 48, true, 1, 8, 10, 8, 5)   /* res5_1 .. res5_5         @ H/32 */
 
@@ -575,10 +592,10 @@ int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArg
     return -1;
 }
 
-bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride)
+bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride, bool relu_out)
 {
 #define MR(ci, ce, co, rs, st, th, tw, np, nw) \
-    if (cin == ci && cexp == ce && cout == co && res == rs && stride == st) return true;
+    if (cin == ci && cexp == ce && cout == co && res == rs && stride == st) return relu_out == mres_relu_out(ci, ce, co, st);
     YF_MRES_SHAPES(MR)
 #undef MR
     return false;
