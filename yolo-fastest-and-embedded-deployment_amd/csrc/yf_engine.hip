@@ -96,6 +96,8 @@ struct Op {
     int l_pre = -1, l_exp = -1, l_dw = -1, l_proj = -1;  // fused block: conv0 (optional), expand, depthwise, project
     int l_head = -1;     // OP_MDW: fused head conv (or -1)
     int out2 = -1;       // OP_MRES conv4_2 + conv4_3 + conv5_1: the expanded tensor (conv4_2) is a second output
+    int nblk = 1;        // OP_MRES: > 1 = a chain of residual blocks in one launch; block k's layers are l_exp/l_dw/l_proj + 3k
+    long wstride = 0;    //          floats between the packed weight streams of consecutive chained blocks
     long mfma_off = -1;  // >= 0: pointwise layer runs on the matrix cores; offset of its packed B fragments
 };
 
@@ -165,6 +167,23 @@ struct Builder {
         int a = unit((n + ".conv1").c_str(), x);
         int b = unit((n + ".conv2").c_str(), a);
         return unit((n + ".conv3").c_str(), b, n.c_str(), -1, x);
+    }
+    // Consecutive residual blocks of one shape.  Where a workgroup's tile is the whole frame (strides 16 and 32 of the 320x256
+    // net) they need no halo exchange and run as ONE launch (yf_mres_kernels.hip, "CHAIN"); the intermediate results stay in LDS.
+    int reschain(std::initializer_list<const char*> names, int x)
+    {
+        const LayerSpec& L0 = kLayers[find_layer((std::string(*names.begin()) + ".conv1").c_str())];
+        const Tensor& tx = e->tensors[x];
+        if (!fused || names.size() < 2 || !yf::mres_can_chain(L0.cin, L0.cout, L0.cin, tx.H, tx.W)) {
+            for (const char* n : names) x = resblock(n, x);
+            return x;
+        }
+        const char* first = *names.begin();
+        const char* last = *(names.end() - 1);
+        const int out = fused_block(nullptr, (std::string(first) + ".conv1").c_str(), (std::string(first) + ".conv2").c_str(),
+                                    (std::string(first) + ".conv3").c_str(), x, last, true);
+        e->ops.back().nblk = (int)names.size();
+        return out;
     }
     // pw-expand -> dw3x3 -> pw-project in one launch (optionally conv0 in front, optionally + residual)
     int fused_block(const char* pre, const char* ex, const char* dw, const char* pj, int in, const char* out_name, bool res)
@@ -252,11 +271,11 @@ void build_plan(Plan* e, bool fused)
     x = b.triple("conv3_2", "conv3_3", "conv3_4", x);
     for (const char* n : {"res3_3", "res3_4", "res3_5", "res3_6"}) x = b.resblock(n, x);
     x = b.triple("conv3_5", "conv3_6", "conv4_1", x);
-    for (const char* n : {"res4_1", "res4_2", "res4_3", "res4_4"}) x = b.resblock(n, x);
+    x = b.reschain({"res4_1", "res4_2", "res4_3", "res4_4"}, x);
     const bool fused_deep = fused;
     int conv4_2 = -1;
     x = b.triple_keep_expansion("conv4_2", "conv4_3", "conv5_1", x, &conv4_2);
-    for (const char* n : {"res5_1", "res5_2", "res5_3", "res5_4", "res5_5"}) x = b.resblock(n, x);
+    x = b.reschain({"res5_1", "res5_2", "res5_3", "res5_4", "res5_5"}, x);
     b.fused = false;
     int conv5_2 = b.unit("conv5_2", x);
     b.fused = fused_deep;
@@ -401,7 +420,8 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                 rc = yf::launch_mdw(ti.C, kLayers[o.l_proj].cout, o.l_head >= 0 ? 24 : 0, a, n, s, e->dtype);
             } else if (o.type == OP_MRES) {
                 const LayerSpec &LE = kLayers[o.l_exp], &LP = kLayers[o.l_proj];
-                yf::MresArgs a{ptr(o.in1), e->d_wmfma + o.mfma_off, ptr(o.out), ti.H, ti.W, 0, 0, o.out2 >= 0 ? ptr(o.out2) : nullptr};
+                yf::MresArgs a{ptr(o.in1), e->d_wmfma + o.mfma_off, ptr(o.out), ti.H, ti.W, 0, 0, o.out2 >= 0 ? ptr(o.out2) : nullptr,
+                               o.nblk, o.wstride};
                 rc = yf::launch_mres(LE.cin, LE.cout, LP.cout, o.res >= 0, kLayers[o.l_dw].stride, a, n, s, e->dtype);
             } else if (o.type == OP_FUSED_BLOCK) {
                 const bool pre = o.l_pre >= 0;
@@ -557,10 +577,12 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
             if (o.type == OP_MRES) {
                 const LayerSpec &LE = kLayers[o.l_exp], &LP = kLayers[o.l_proj];
                 o.mfma_off = (long)packed.size();
-                packed.resize(packed.size() + ((yf::mres_packed_floats(LE.cin, LE.cout, LP.cout, h16) + 63) & ~(size_t)63));
-                yf::mres_pack_weights(hw + e->w_off[o.l_exp], hw + e->b_off[o.l_exp], hw + e->w_off[o.l_dw], hw + e->b_off[o.l_dw],
-                                      hw + e->w_off[o.l_proj], hw + e->b_off[o.l_proj], LE.cin, LE.cout, LP.cout,
-                                      packed.data() + o.mfma_off, h16);
+                o.wstride = (long)((yf::mres_packed_floats(LE.cin, LE.cout, LP.cout, h16) + 63) & ~(size_t)63);
+                packed.resize(packed.size() + (size_t)o.wstride * o.nblk);
+                for (int k = 0; k < o.nblk; ++k)   // chained blocks: same shape, layers 3 apart, streams wstride apart
+                    yf::mres_pack_weights(hw + e->w_off[o.l_exp + 3 * k], hw + e->b_off[o.l_exp + 3 * k], hw + e->w_off[o.l_dw + 3 * k],
+                                          hw + e->b_off[o.l_dw + 3 * k], hw + e->w_off[o.l_proj + 3 * k], hw + e->b_off[o.l_proj + 3 * k],
+                                          LE.cin, LE.cout, LP.cout, packed.data() + o.mfma_off + (size_t)o.wstride * k, h16);
                 continue;
             }
             if (o.type == OP_K19) {
@@ -809,7 +831,9 @@ int yf_op_info(yf_handle h, int op, char* name, int name_len, double* algorithmi
     if (o.type == OP_FUSED_BLOCK || o.type == OP_MRES) {
         size_t epx = ipx;
         if (o.l_pre >= 0) { epx = ipx / 4; add(o.l_pre, ipx, epx, false); }
-        add(o.l_exp, epx, epx, false); add(o.l_dw, epx, opx, false); add(o.l_proj, opx, opx, o.res >= 0);
+        for (int k = 0; k < o.nblk; ++k) {
+            add(o.l_exp + 3 * k, epx, epx, false); add(o.l_dw + 3 * k, epx, opx, false); add(o.l_proj + 3 * k, opx, opx, o.res >= 0);
+        }
     } else if (o.type == OP_K19) {
         add(o.l_exp, ipx, ipx, false); add(o.l_dw, ipx, opx, false); add(o.l_proj, opx, opx, false);
     } else if (o.type == OP_MDW) {

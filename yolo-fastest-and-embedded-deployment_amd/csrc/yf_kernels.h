@@ -105,9 +105,12 @@ struct MresArgs {
     int H, W;
     int tiles_y, tiles_x;  // filled by the launcher
     float* out_exp;    // optional: the EXPANDED tensor (after ReLU) is also written, NHWC [N,H,W,CEXP] -- conv4_2 is a skip tensor
+    int nblk;          // > 1: a chain of that many residual blocks of this shape in one launch (tile == frame only)
+    long wstride;      // floats between the packed weight streams of consecutive chained blocks
 };
 int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArgs& a, int N, hipStream_t s, int dtype = DT_F32);
-bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride = 1, bool relu_out = false);  // relu_out: ReLU after the projection
+bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride = 1, bool relu_out = false);
+bool mres_can_chain(int cin, int cexp, int cout, int H, int W);  // relu_out: ReLU after the projection
 size_t mres_packed_floats(int cin, int cexp, int cout, bool h16 = false);
 void mres_pack_weights(const float* w1, const float* b1, const float* wd, const float* bd, const float* w2, const float* b2,
                        int cin, int cexp, int cout, float* out, bool h16 = false);

@@ -324,7 +324,12 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
 // into one of two E buffers) and NWC *consumers* (depthwise + projection of chunk c from the other buffer): the matrix
 // pipe and the LDS/VALU pipes work on different chunks at the same time and there is ONE barrier per chunk instead of
 // two.  The two roles run in different branches of a wave-uniform condition (disjoint register live ranges); both execute
-// exactly NCH + 1 barriers.
+// exactly NCH + 1 barriers per block.
+// CHAIN (a.nblk > 1): when the tile is the whole frame (strides 16 / 32 of the 320x256 net) consecutive residual blocks of the same
+// shape need no halo exchange, so one launch runs a.nblk of them: a block's result replaces X in LDS (each lane overwrites exactly
+// the residual it read), only the last block stores to HBM, and the next block's weight stream (a.wp + blk * a.wstride) is
+// requested into registers before the epilogue and lands in LDS behind two barriers.  Saves, per chained block, a launch's
+// fill/drain, the input staging and the output round trip.
 // ------------------------------------------------------------------------------------------------
 template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NWC, typename T>
 __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
@@ -358,10 +363,26 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
     mres_stage<CIN, 1, RW, NRP, MTR, XP, WFLOATS, NWAVE * 64, T>(a, n, oy0, ox0, X, WL);
     __syncthreads();
 
+    // next block's weight stream, moved by the PRODUCER waves (idle while the consumers finish the last chunk and the epilogue, and
+    // their A fragments are dead by then): global -> registers after their last expansion, registers -> LDS between the two block
+    // barriers
+    constexpr int NW4 = WFLOATS / 4, NWI = (NW4 + NWP * 64 - 1) / (NWP * 64);
+    const int nblk = a.nblk > 1 ? a.nblk : 1;
+
     if (wave < NWP) {
         // ================= producer: expansion of chunk s into E[s & 1] =================
-        float a1[MTRW][KS1];
         unsigned long long inmask = 0;
+#pragma unroll
+        for (int i = 0; i < MTRW; ++i) {
+            const int mt = wave + i * NWP;
+            const int rp = mt * 16 + r;
+            const int ry = rp / RW, rx = rp - ry * RW;
+            const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
+            if (mt < MTR && rp < NRP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) inmask |= 1ull << i;
+        }
+#pragma unroll 1
+      for (int blk = 0; blk < nblk; ++blk) {
+        float a1[MTRW][KS1];
 #pragma unroll
         for (int i = 0; i < MTRW; ++i) {
             const int mt = wave + i * NWP;
@@ -374,12 +395,6 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
             if constexpr (CIN % 16 != 0) {
                 const float2 t = *reinterpret_cast<const float2*>(&X[row * XP + NB1 * 16 + 2 * q]);
                 a1[i][NB1 * 4 + 0] = t.x; a1[i][NB1 * 4 + 1] = t.y;
-            }
-            {
-                const int rp = mt * 16 + r;
-                const int ry = rp / RW, rx = rp - ry * RW;
-                const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
-                if (mt < MTR && rp < NRP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) inmask |= 1ull << i;
             }
         }
 #pragma unroll 1
@@ -423,20 +438,42 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
             }
             __syncthreads();
         }
+        if (blk + 1 < nblk) {   // block boundary (the consumers run the same two barriers)
+            f32x4 wv[NWI];   // (a native vector: as HIP's float4 struct the copies become memcpys through a scratch array)
+            const float* wsrc = a.wp + (long)(blk + 1) * a.wstride;
+#pragma unroll
+            for (int i = 0; i < NWI; ++i) {
+                const int idx = threadIdx.x + i * NWP * 64;
+                wv[i] = *reinterpret_cast<const f32x4*>(wsrc + 4 * (idx < NW4 ? idx : NW4 - 1));
+            }
+            // epilogue done: X holds the block's result, nobody reads WL any more
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NWI; ++i) {
+                const int idx = threadIdx.x + i * NWP * 64;
+                if (idx < NW4) *reinterpret_cast<f32x4*>(&WL[4 * idx]) = wv[i];
+            }
+            __syncthreads();
+        }
+      }
     } else {
         // ================= consumer: depthwise + projection of chunk s - 1 from E[(s - 1) & 1] =================
         const int cw = wave - NWP;
-        f32x4 acc[MTOW][NT2];
         int rp0[MTOW];
 #pragma unroll
         for (int i = 0; i < MTOW; ++i) {
-#pragma unroll
-            for (int nt = 0; nt < NT2; ++nt) acc[i][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int mo = cw + i * NWC;
             const int op = (mo < MTO ? mo : 0) * 16 + r;
             const int oy = op / TW, ox = op - oy * TW;
             rp0[i] = (oy + 1) * RW + ox + 1;
         }
+#pragma unroll 1
+      for (int blk = 0; blk < nblk; ++blk) {
+        f32x4 acc[MTOW][NT2];
+#pragma unroll
+        for (int i = 0; i < MTOW; ++i)
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) acc[i][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int s = 0; s <= NCH; ++s) {
             if (s >= 1) {
@@ -493,6 +530,7 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
             }
             __syncthreads();
         }
+        const bool last = blk + 1 == nblk;
         const float* b2 = WL + NCH * CHUNK;   // lane (r, q): output channels nt*16 + 4q .. +3 of pixel mo*16 + r (see mres_kernel)
 #pragma unroll
         for (int i = 0; i < MTOW; ++i) {
@@ -508,13 +546,20 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
                 if (col >= COUT) continue;
                 const float4 bias = *reinterpret_cast<const float4*>(b2 + col);
                 float4 v = make_float4(acc[i][nt][0] + bias.x, acc[i][nt][1] + bias.y, acc[i][nt][2] + bias.z, acc[i][nt][3] + bias.w);
+                float* xr = &X[((oy + 1) * RW + ox + 1) * XP + col];
                 if constexpr (RES) {
-                    const float4 x = *reinterpret_cast<const float4*>(&X[((oy + 1) * RW + ox + 1) * XP + col]);
+                    const float4 x = *reinterpret_cast<const float4*>(xr);
                     v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
                 }
-                st4<T>(reinterpret_cast<T*>(a.out) + (((long)n * a.H + gy) * a.W + gx) * COUT + col, v);
+                if (last) st4<T>(reinterpret_cast<T*>(a.out) + (((long)n * a.H + gy) * a.W + gx) * COUT + col, v);
+                else *reinterpret_cast<float4*>(xr) = v;   // the next block's input (CIN == COUT), in place
             }
         }
+        if (!last) {
+            __syncthreads();
+            __syncthreads();
+        }
+      }
     }
 }
 
@@ -534,6 +579,7 @@ static int launch_mres_pc_t(MresArgs a, int N, hipStream_t s)
             return -2;
         attr_done = true;
     }
+    if (a.nblk > 1 && (a.tiles_y != 1 || a.tiles_x != 1 || !RES)) return -4;  // a chain needs tile == frame
     hipLaunchKernelGGL((mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, T>), dim3((unsigned)(N * a.tiles_y * a.tiles_x)),
                        dim3((NWP + NWC) * 64), lds, s, a);
     return 0;
@@ -545,6 +591,7 @@ static int launch_mres_t(MresArgs a, int N, hipStream_t s)
     a.tiles_y = (a.H / S + TH - 1) / TH;
     a.tiles_x = (a.W / S + TW - 1) / TW;
     if (mres_writes_expansion(CIN, CEXP, COUT, S) && !a.out_exp) return -3;
+    if (a.nblk > 1) return -4;  // chains: producer/consumer kernel only
     constexpr int MTR = (((TH - 1) * S + 3) * ((TW - 1) * S + 3) + 15) / 16;
     constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 16 * (((MTR * 16 + 7) / 8) * 8 + 1) +
                             ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT, sizeof(T) == 2) + COUT + 3) & ~3)) * sizeof(float);
@@ -590,6 +637,16 @@ int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArg
     YF_MRES_SHAPES(MR)
 #undef MR
     return -1;
+}
+
+// Can consecutive residual blocks of this shape run as ONE launch on H x W frames?  (producer/consumer kernel whose tile is the frame)
+bool mres_can_chain(int cin, int cexp, int cout, int H, int W)
+{
+#define MR(ci, ce, co, rs, st, th, tw, np, nw) \
+    if (cin == ci && cexp == ce && cout == co && rs && st == 1) return np > 0 && H <= th && W <= tw;
+    YF_MRES_SHAPES(MR)
+#undef MR
+    return false;
 }
 
 bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride, bool relu_out)

@@ -239,9 +239,9 @@ class YoloFastest(nn.Module):
                 acc[i] += buf[i] / reps
         out = []
         for i in range(n.value):
-            name = ctypes.create_string_buffer(128)
+            name = ctypes.create_string_buffer(512)
             b, f = ctypes.c_double(), ctypes.c_double()
-            _lib.check(e.lib.yf_op_info(e.handle, i, name, 128, ctypes.byref(b), ctypes.byref(f)))
+            _lib.check(e.lib.yf_op_info(e.handle, i, name, 512, ctypes.byref(b), ctypes.byref(f)))
             out.append(dict(name=name.value.decode(), ms=acc[i], algorithmic_bytes=b.value * N, flops=f.value * N))
         return out
 
