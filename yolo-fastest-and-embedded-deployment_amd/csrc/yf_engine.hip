@@ -359,7 +359,7 @@ struct ProfileEvents {
 
 int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs, void* ws, size_t ws_bytes,
                 hipStream_t s, const char* probe, float* probe_dst, size_t probe_bytes, ProfileEvents* prof = nullptr,
-                const uint8_t* d_u8 = nullptr, int u8_down2 = 0)
+                const uint8_t* d_u8 = nullptr, int u8_down2 = 0, const yf::PostArgs* post = nullptr)
 {
     if (!e || (!d_x && !d_u8) || !d_hl || !d_hs || N <= 0) return fail(YF_E_INVALID, "yf_forward: null pointer or N <= 0");
     if (d_u8 && e->fusion != 1) return fail(YF_E_INVALID, "u8 input needs the fused plan (yf_set_fusion 1)");
@@ -478,6 +478,20 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
         }
        }
       }
+      // decode + NMS of each chunk on ITS lane (yf_detect): frames are independent, so a lane's post-process overlaps the other
+      // lane's tail instead of running after the join
+      if (post)
+        for (int lane_id = 0; lane_id < gcount; ++lane_id) {
+            const int f0 = (g0 + lane_id) * cf;
+            const int n = (N - f0) < cf ? (N - f0) : cf;
+            yf::PostArgs a = *post;
+            a.head_large += (size_t)f0 * e->head_l_elems; a.head_small += (size_t)f0 * e->head_s_elems;
+            a.boxes += (size_t)f0 * a.kmax * 4; a.scores += (size_t)f0 * a.kmax * 2;
+            a.cls += (size_t)f0 * a.kmax; a.src += (size_t)f0 * a.kmax; a.counts += f0;
+            const int rc = yf::launch_post(a, n, lane_id == 0 ? s_main : e->side[lane_id - 1]);
+            if (rc == -1) return fail(YF_E_INVALID, "frame of %dx%d has too many cells for the on-chip NMS (limit 8191 cells / 160 KiB LDS)", e->H, e->W);
+            if (rc) return fail(YF_E_HIP, "hipFuncSetAttribute(post_kernel) failed");
+        }
     }
     if (lanes > 1) {  // join: the caller's stream continues only after every side stream has drained
         for (int l = 1; l < lanes; ++l) {
@@ -691,13 +705,10 @@ int yf_forward_probe(yf_handle h, const float* d_x, int N, const char* name, flo
     return run_forward(h, d_x, N, hl, hs, ws, chain, (hipStream_t)stream, name, d_dst, dst_bytes);
 }
 
-int yf_decode_nms(yf_handle h, const float* d_hl, const float* d_hs, int N, double conf_thres, double nms_thres,
-                  const double* anchors, int origin_h, int origin_w, int K_max, int32_t* d_boxes, float* d_scores,
-                  int32_t* d_cls, int32_t* d_src, int32_t* d_counts, void* stream)
+static yf::PostArgs make_post_args(yf_handle h, const float* d_hl, const float* d_hs, double conf_thres, double nms_thres,
+                                   const double* anchors, int origin_h, int origin_w, int K_max, int32_t* d_boxes, float* d_scores,
+                                   int32_t* d_cls, int32_t* d_src, int32_t* d_counts)
 {
-    if (!h || !d_hl || !d_hs || !anchors || !d_boxes || !d_scores || !d_cls || !d_src || !d_counts || N <= 0 || K_max <= 0)
-        return fail(YF_E_INVALID, "yf_decode_nms: null pointer or non-positive size");
-    HIP_OK(hipSetDevice(h->device));
     yf::PostArgs a;
     a.head_large = d_hl; a.head_small = d_hs;
     a.hl = h->H / 16; a.wl = h->W / 16; a.hs = h->H / 32; a.ws = h->W / 32;
@@ -710,6 +721,18 @@ int yf_decode_nms(yf_handle h, const float* d_hl, const float* d_hs, int N, doub
     a.adj_w = adj ? (double)origin_w / h->W : 0.0;
     a.kmax = K_max;
     a.boxes = d_boxes; a.scores = d_scores; a.cls = d_cls; a.src = d_src; a.counts = d_counts;
+    return a;
+}
+
+int yf_decode_nms(yf_handle h, const float* d_hl, const float* d_hs, int N, double conf_thres, double nms_thres,
+                  const double* anchors, int origin_h, int origin_w, int K_max, int32_t* d_boxes, float* d_scores,
+                  int32_t* d_cls, int32_t* d_src, int32_t* d_counts, void* stream)
+{
+    if (!h || !d_hl || !d_hs || !anchors || !d_boxes || !d_scores || !d_cls || !d_src || !d_counts || N <= 0 || K_max <= 0)
+        return fail(YF_E_INVALID, "yf_decode_nms: null pointer or non-positive size");
+    HIP_OK(hipSetDevice(h->device));
+    const yf::PostArgs a = make_post_args(h, d_hl, d_hs, conf_thres, nms_thres, anchors, origin_h, origin_w, K_max, d_boxes, d_scores,
+                                          d_cls, d_src, d_counts);
     int rc = yf::launch_post(a, N, (hipStream_t)stream);
     if (rc == -1) return fail(YF_E_INVALID, "frame of %dx%d has too many cells for the on-chip NMS (limit 8191 cells / 160 KiB LDS)", h->H, h->W);
     if (rc) return fail(YF_E_HIP, "hipFuncSetAttribute(post_kernel) failed");
@@ -781,10 +804,14 @@ int yf_detect(yf_handle h, const float* d_x, int N, double conf_thres, double nm
     if (!ws || ws_bytes < chain + ((d_hl && d_hs) ? 0 : heads)) return fail(YF_E_WORKSPACE, "workspace too small");
     float* hl = d_hl ? d_hl : reinterpret_cast<float*>(static_cast<char*>(ws) + chain);
     float* hs = d_hs ? d_hs : reinterpret_cast<float*>(static_cast<char*>(ws) + chain) + h->head_l_elems * (size_t)N;
-    int rc = run_forward(h, d_x, N, hl, hs, ws, chain, (hipStream_t)stream, nullptr, nullptr, 0);
+    if (!anchors || !d_boxes || !d_scores || !d_cls || !d_src || !d_counts || N <= 0 || K_max <= 0)
+        return fail(YF_E_INVALID, "yf_detect: null pointer or non-positive size");
+    const yf::PostArgs pa = make_post_args(h, hl, hs, conf_thres, nms_thres, anchors, origin_h, origin_w, K_max, d_boxes, d_scores,
+                                           d_cls, d_src, d_counts);
+    int rc = run_forward(h, d_x, N, hl, hs, ws, chain, (hipStream_t)stream, nullptr, nullptr, 0, nullptr, nullptr, 0, &pa);
     if (rc) return rc;
-    return yf_decode_nms(h, hl, hs, N, conf_thres, nms_thres, anchors, origin_h, origin_w, K_max, d_boxes, d_scores, d_cls,
-                         d_src, d_counts, stream);
+    HIP_OK(hipGetLastError());
+    return YF_OK;
 }
 
 int yf_preprocess_u8(yf_handle h, const uint8_t* d_u8, int N, int src_h, int src_w, float* d_x, void* stream)
