@@ -51,6 +51,12 @@ __device__ __forceinline__ unsigned long long mres_clock()
 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef YF_MRES_PK
+#define YF_MRES_PK 1   // depthwise taps as v_pk_fma_f32 (two channels per instruction; same fused multiply-add per element)
+#endif
+// ReLU of a value that is not NaN: one v_max_i32 (fmaxf() on an FMA / MFMA result costs a canonicalising v_add first)
+__device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 
 __host__ __device__ constexpr int mres_ksteps(int K) { return (K / 16) * 4 + ((K % 16) ? 2 : 0); }
 __host__ __device__ constexpr int mres_chunk_floats(int cin, int cout, bool h16 = false)
@@ -259,6 +265,18 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                     for (int t = 0; t < 9; ++t) v9[t] = e[((YF_MRES_DBG & 1) ? 0 : (t / 3 - 1) * RW + (t % 3 - 1))];
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#if YF_MRES_PK
+                f32x2 dl = {d[0], d[1]}, dh2 = {d[2], d[3]};
+#pragma unroll
+                for (int t = 0; t < ((YF_MRES_DBG & 8) ? 1 : 9); ++t) {
+                    float4 v;
+                    if constexpr (BATCH9) v = v9[t]; else v = e[(t / 3 - 1) * RW + (t % 3 - 1)];
+                    const float4 w = wd[t];
+                    dl = __builtin_elementwise_fma(f32x2{v.x, v.y}, f32x2{w.x, w.y}, dl);
+                    dh2 = __builtin_elementwise_fma(f32x2{v.z, v.w}, f32x2{w.z, w.w}, dh2);
+                }
+                d[0] = dl[0]; d[1] = dl[1]; d[2] = dh2[0]; d[3] = dh2[1];
+#else
 #pragma unroll
                 for (int t = 0; t < ((YF_MRES_DBG & 8) ? 1 : 9); ++t) {
                     float4 v;
@@ -269,6 +287,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                     d[2] = fmaf(v.z, w.z, d[2]);
                     d[3] = fmaf(v.w, w.w, d[3]);
                 }
+#endif
                 if constexpr (H16) {
                     const f16x4 dh = f16x4{(half_t)fmaxf(d[0], 0.f), (half_t)fmaxf(d[1], 0.f), (half_t)fmaxf(d[2], 0.f), (half_t)fmaxf(d[3], 0.f)};
 #pragma unroll
@@ -276,7 +295,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                 } else {
 #pragma unroll
                     for (int j = 0; j < ((YF_MRES_DBG & 4) ? 1 : 4); ++j) {
-                        const float dj = fmaxf(d[j] + ((YF_MRES_DBG & 4) ? d[1] + d[2] + d[3] : 0.f), 0.f);
+                        const float dj = relu_bits(d[j] + ((YF_MRES_DBG & 4) ? d[1] + d[2] + d[3] : 0.f));
 #pragma unroll
                         for (int nt = 0; nt < NT2; ++nt)
                             acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[j][nt], dj, acc[i][nt], 0, 0, 0);
@@ -504,12 +523,23 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
 #pragma unroll
                         for (int t = 0; t < 9; ++t) v9[t] = e[(t / 3 - 1) * RW + (t % 3 - 1)];
                         __builtin_amdgcn_sched_barrier(0);
+#if YF_MRES_PK
+                        f32x2 dl = {d[0], d[1]}, dh2 = {d[2], d[3]};
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) {
+                            const float4 v = v9[t], w = wd[t];
+                            dl = __builtin_elementwise_fma(f32x2{v.x, v.y}, f32x2{w.x, w.y}, dl);
+                            dh2 = __builtin_elementwise_fma(f32x2{v.z, v.w}, f32x2{w.z, w.w}, dh2);
+                        }
+                        d[0] = dl[0]; d[1] = dl[1]; d[2] = dh2[0]; d[3] = dh2[1];
+#else
 #pragma unroll
                         for (int t = 0; t < 9; ++t) {
                             const float4 v = v9[t], w = wd[t];
                             d[0] = fmaf(v.x, w.x, d[0]); d[1] = fmaf(v.y, w.y, d[1]);
                             d[2] = fmaf(v.z, w.z, d[2]); d[3] = fmaf(v.w, w.w, d[3]);
                         }
+#endif
                         if constexpr (H16) {
                             const f16x4 dh = f16x4{(half_t)fmaxf(d[0], 0.f), (half_t)fmaxf(d[1], 0.f), (half_t)fmaxf(d[2], 0.f),
                                                    (half_t)fmaxf(d[3], 0.f)};
@@ -519,7 +549,7 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                const float dj = fmaxf(d[j], 0.f);
+                                const float dj = relu_bits(d[j]);
 #pragma unroll
                                 for (int nt = 0; nt < NT2; ++nt)
                                     acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[j][nt], dj, acc[i][nt], 0, 0, 0);
