@@ -21,7 +21,13 @@
 #define YF_FB_DW_UNROLL 1
 #endif
 
+#ifndef YF_FB_PK
+#define YF_FB_PK 1   // expansion / projection / conv0 FMAs over output-channel PAIRS as v_pk_fma_f32 (scalar weight pair x broadcast value)
+#endif
+
 namespace yf {
+
+typedef float fb_f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
@@ -103,11 +109,11 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
     }
     __syncthreads();
 
-    float acc[BH * BW][COUT];
+    fb_f32x2 acc2[BH * BW][COUT / 2];   // projection accumulators, output-channel pairs
 #pragma unroll
     for (int p = 0; p < BH * BW; ++p)
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) acc[p][co] = 0.f;
+        for (int co = 0; co < COUT / 2; ++co) acc2[p][co] = fb_f32x2{0.f, 0.f};
 
     YF_STAMP_DECL
     for (int ch = 0; ch < CEXP / EC; ++ch) {
@@ -170,6 +176,16 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
                                 v[ky * 3 + kx] = ok ? src[(long)yy * (2 * a.W) + xx] : 0.f;
                             }
                     }
+#if YF_FB_PK
+#pragma unroll
+                    for (int c = 0; c < CIN; c += 2) {
+                        fb_f32x2 s2 = *reinterpret_cast<const fb_f32x2*>(a.b0 + c);
+#pragma unroll
+                        for (int t = 0; t < 9; ++t)
+                            s2 = __builtin_elementwise_fma(fb_f32x2{v[t], v[t]}, *reinterpret_cast<const fb_f32x2*>(a.w0 + t * CIN + c), s2);
+                        x[p][c] = fmaxf(s2[0], 0.f); x[p][c + 1] = fmaxf(s2[1], 0.f);
+                    }
+#else
 #pragma unroll
                     for (int c = 0; c < CIN; ++c) {
                         float s = a.b0[c];
@@ -177,6 +193,7 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
                         for (int t = 0; t < 9; ++t) s = fmaf(v[t], a.w0[t * CIN + c], s);
                         x[p][c] = fmaxf(s, 0.f);
                     }
+#endif
                 } else if constexpr (XL) {
 #pragma unroll
                     for (int k = 0; k < CIN; k += 4) {
@@ -193,6 +210,28 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
                 }
             }
             float e[PE][CG];
+#if YF_FB_PK
+            static_assert(CG % 2 == 0 && EC % 2 == 0, "channel pairs");
+            fb_f32x2 e2[PE][CG / 2];
+#pragma unroll
+            for (int j = 0; j < CG; j += 2) {
+                const fb_f32x2 bv = *reinterpret_cast<const fb_f32x2*>(wc + O_B1 + cg * CG + j);
+#pragma unroll
+                for (int p = 0; p < PE; ++p) e2[p][j / 2] = bv;
+            }
+#pragma unroll
+            for (int k = 0; k < CIN; ++k)
+#pragma unroll
+                for (int j = 0; j < CG; j += 2) {
+                    const fb_f32x2 wv = *reinterpret_cast<const fb_f32x2*>(wc + k * EC + cg * CG + j);
+#pragma unroll
+                    for (int p = 0; p < PE; ++p) e2[p][j / 2] = __builtin_elementwise_fma(fb_f32x2{x[p][k], x[p][k]}, wv, e2[p][j / 2]);
+                }
+#pragma unroll
+            for (int p = 0; p < PE; ++p)
+#pragma unroll
+                for (int j = 0; j < CG; ++j) e[p][j] = e2[p][j / 2][j & 1];
+#else
 #pragma unroll
             for (int j = 0; j < CG; ++j) {
                 const float bv = wc[O_B1 + cg * CG + j];
@@ -207,6 +246,7 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
 #pragma unroll
                     for (int p = 0; p < PE; ++p) e[p][j] = fmaf(x[p][k], wv, e[p][j]);
                 }
+#endif
 #pragma unroll
             for (int p = 0; p < PE; ++p)
                 if (inreg[p]) {
@@ -259,9 +299,16 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx) d = fmaf(win[by * S + ky][bx * S + kx], wd[ky * 3 + kx], d);
                     d = fmaxf(d, 0.f);
+#if YF_FB_PK
+#pragma unroll
+                    for (int co = 0; co < COUT; co += 2)
+                        acc2[by * BW + bx][co / 2] = __builtin_elementwise_fma(fb_f32x2{d, d}, *reinterpret_cast<const fb_f32x2*>(wc + O_W2 + c * COUT + co),
+                                                                                acc2[by * BW + bx][co / 2]);
+#else
 #pragma unroll
                     for (int co = 0; co < COUT; ++co)
-                        acc[by * BW + bx][co] = fmaf(d, wc[O_W2 + c * COUT + co], acc[by * BW + bx][co]);
+                        acc2[by * BW + bx][co / 2][co & 1] = fmaf(d, wc[O_W2 + c * COUT + co], acc2[by * BW + bx][co / 2][co & 1]);
+#endif
                 }
         }
         YF_STAMP_AT(3)
@@ -280,8 +327,8 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
             T* o = reinterpret_cast<T*>(a.out) + opix * COUT;
 #pragma unroll
             for (int co = 0; co < COUT; co += 4) {
-                float4 v = make_float4(acc[by * BW + bx][co] + b2[co], acc[by * BW + bx][co + 1] + b2[co + 1],
-                                       acc[by * BW + bx][co + 2] + b2[co + 2], acc[by * BW + bx][co + 3] + b2[co + 3]);
+                float4 v = make_float4(acc2[by * BW + bx][co / 2][0] + b2[co], acc2[by * BW + bx][co / 2][1] + b2[co + 1],
+                                       acc2[by * BW + bx][co / 2 + 1][0] + b2[co + 2], acc2[by * BW + bx][co / 2 + 1][1] + b2[co + 3]);
                 if constexpr (RES) {  // the residual is the centre of the staged tile
                     float4 r = XL ? *reinterpret_cast<const float4*>(&X[((tyb * BH + by + 1) * RW + txb * BW + bx + 1) * XP + co])
                                   : ld4<T>(reinterpret_cast<const T*>(a.in) + opix * CIN + co);
