@@ -47,6 +47,8 @@ __host__ __device__ constexpr int mdw_stream_floats(int c, int n, int headn, boo
     return (f + 3) & ~3;
 }
 
+typedef float mdw_f32x2 __attribute__((ext_vector_type(2)));
+
 template <int C, int N, int HEADN, int TH, int TW, int NWAVE, typename TT>
 __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
 {
@@ -137,9 +139,9 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
         // ---- depthwise 5x5 of channels 4q..4q+3 at this lane's output pixels (taps outer: one weight read per tap) ----
         const float* wc = WL + c * CHUNK;
         const float4 bd = *reinterpret_cast<const float4*>(wc + OFF_BD + 4 * q);
-        float d[MTOW][4];
+        mdw_f32x2 d2[MTOW][2];   // channel pairs (4q, 4q+1), (4q+2, 4q+3): the taps are v_pk_fma_f32
 #pragma unroll
-        for (int i = 0; i < MTOW; ++i) { d[i][0] = bd.x; d[i][1] = bd.y; d[i][2] = bd.z; d[i][3] = bd.w; }
+        for (int i = 0; i < MTOW; ++i) { d2[i][0] = mdw_f32x2{bd.x, bd.y}; d2[i][1] = mdw_f32x2{bd.z, bd.w}; }
         const float4* e4 = reinterpret_cast<const float4*>(E) + q * EPL;
         // One window row at a time: all of the row's LDS reads (activations AND its five tap weights) are issued together, then
         // its FMAs.  (Reading each tap's weight right before its 8 FMAs exposed an LDS round trip per tap: 230 cycles per tap,
@@ -165,8 +167,9 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
 #pragma unroll
                 for (int i = 0; i < MTOW; ++i) {
                     const float4 v = ADJ ? vc[kx + i] : vc[i * 5 + kx];
-                    d[i][0] = fmaf(v.x, wr[kx].x, d[i][0]); d[i][1] = fmaf(v.y, wr[kx].y, d[i][1]);
-                    d[i][2] = fmaf(v.z, wr[kx].z, d[i][2]); d[i][3] = fmaf(v.w, wr[kx].w, d[i][3]);
+                    // two channels per instruction (v_pk_fma_f32): the same fused multiply-add per element
+                    d2[i][0] = __builtin_elementwise_fma(mdw_f32x2{v.x, v.y}, mdw_f32x2{wr[kx].x, wr[kx].y}, d2[i][0]);
+                    d2[i][1] = __builtin_elementwise_fma(mdw_f32x2{v.z, v.w}, mdw_f32x2{wr[kx].z, wr[kx].w}, d2[i][1]);
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -179,8 +182,8 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
 #pragma unroll
             for (int i = 0; i < MTOW; ++i) {
                 if (EVEN || wave + i * NWAVE < MTO) {
-                    const f16x4 dh = f16x4{(half_t)fmaxf(d[i][0], 0.f), (half_t)fmaxf(d[i][1], 0.f), (half_t)fmaxf(d[i][2], 0.f),
-                                           (half_t)fmaxf(d[i][3], 0.f)};
+                    const f16x4 dh = f16x4{(half_t)fmaxf(d2[i][0][0], 0.f), (half_t)fmaxf(d2[i][0][1], 0.f), (half_t)fmaxf(d2[i][1][0], 0.f),
+                                           (half_t)fmaxf(d2[i][1][1], 0.f)};
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(w2h[nt], dh, acc[i][nt], 0, 0, 0);
                 }
@@ -194,7 +197,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
 #pragma unroll
                 for (int i = 0; i < MTOW; ++i) {
                     if (EVEN || wave + i * NWAVE < MTO) {
-                        const float dj = fmaxf(d[i][j], 0.f);
+                        const float dj = __int_as_float(max(__float_as_int(d2[i][j >> 1][j & 1]), 0));   // ReLU of a non-NaN as one v_max_i32
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
                             acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[nt], dj, acc[i][nt], 0, 0, 0);
