@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
     constexpr int TH = TYB * BH, TW = TXB * BW;
     constexpr int RH = (TH - 1) * S + 3, RW = (TW - 1) * S + 3;
     constexpr int RWP = (RW + 3) & ~3;            // row pitch (floats), 16-B aligned rows
-    constexpr int PLANE = RH * RWP;               // one channel plane
+    constexpr int PLANE = RH * RWP;               // floats per channel (E interleaves channel pairs: [EC/2][RH][RWP][2])
     constexpr int NRP = RH * RW, NPB = (NRP + 64 * PE - 1) / (64 * PE), NCG = EC / CG, NITEM = NPB * NCG;
     constexpr int WR = (BH - 1) * S + 3, WC = (BW - 1) * S + 3;  // dw window of one thread's output block
     static_assert(NT % 64 == 0 && CEXP % EC == 0 && EC % CG == 0 && COUT % 4 == 0, "shape");
@@ -247,12 +247,16 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
                     for (int p = 0; p < PE; ++p) e[p][j] = fmaf(x[p][k], wv, e[p][j]);
                 }
 #endif
+            // E holds channel PAIRS interleaved: [EC/2][RH][RWP][2] -- one 8-byte write per pair here, and the depthwise below runs
+            // its taps on both channels of a pair with one v_pk_fma_f32
 #pragma unroll
             for (int p = 0; p < PE; ++p)
                 if (inreg[p]) {
-                    float* dst = E + (cg * CG) * PLANE + ry[p] * RWP + rx[p];
+                    float* dst = E + (cg * CG) * PLANE + (ry[p] * RWP + rx[p]) * 2;
 #pragma unroll
-                    for (int j = 0; j < CG; ++j) dst[j * PLANE] = inimg[p] ? fmaxf(e[p][j], 0.f) : 0.f;
+                    for (int j = 0; j < CG; j += 2)
+                        *reinterpret_cast<float2*>(dst + j * PLANE) =
+                            make_float2(inimg[p] ? fmaxf(e[p][j], 0.f) : 0.f, inimg[p] ? fmaxf(e[p][j + 1], 0.f) : 0.f);
                 }
         }
         YF_STAMP_AT(1)
@@ -263,52 +267,44 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
         // expansion's, exceed the SGPR file -- the compiler then spills SGPRs to VGPR lanes and 30-50 % of the VALU
         // instructions of the stride-2 kernels were v_readlane / v_writelane (tools/isa_stats.py)
 #pragma unroll YF_FB_DW_UNROLL
-        for (int c = 0; c < EC; ++c) {
-            const float* Ec = E + c * PLANE + (tyb * BH * S) * RWP + txb * BW * S;
-            float win[WR][WC];
+        for (int c = 0; c < EC; c += 2) {
+            const float* Ec = E + c * PLANE + ((tyb * BH * S) * RWP + txb * BW * S) * 2;
+            fb_f32x2 win[WR][WC];   // (channel c, channel c + 1) of every window pixel
 #pragma unroll
             for (int r = 0; r < WR; ++r) {
-                if constexpr ((BW * S) % 4 == 0 && WC >= 4) {
-                    float4 t = *reinterpret_cast<const float4*>(Ec + r * RWP);
-                    win[r][0] = t.x; win[r][1] = t.y; win[r][2] = t.z; win[r][3] = t.w;
-#pragma unroll
-                    for (int q = 4; q < WC; ++q) win[r][q] = Ec[r * RWP + q];
-                } else if constexpr ((BW * S) % 2 == 0) {
+                if constexpr ((BW * S) % 2 == 0) {   // 16-byte aligned: two pixels x two channels per read
 #pragma unroll
                     for (int q = 0; q + 1 < WC; q += 2) {
-                        float2 t = *reinterpret_cast<const float2*>(Ec + r * RWP + q);
-                        win[r][q] = t.x; win[r][q + 1] = t.y;
+                        const float4 t = *reinterpret_cast<const float4*>(Ec + (r * RWP + q) * 2);
+                        win[r][q] = fb_f32x2{t.x, t.y}; win[r][q + 1] = fb_f32x2{t.z, t.w};
                     }
-                    if constexpr (WC % 2) win[r][WC - 1] = Ec[r * RWP + WC - 1];
+                    if constexpr (WC % 2) win[r][WC - 1] = *reinterpret_cast<const fb_f32x2*>(Ec + (r * RWP + WC - 1) * 2);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < WC; ++q) win[r][q] = Ec[r * RWP + q];
+                    for (int q = 0; q < WC; ++q) win[r][q] = *reinterpret_cast<const fb_f32x2*>(Ec + (r * RWP + q) * 2);
                 }
             }
-            float wd[9];
+            fb_f32x2 wd[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) wd[t] = wc[O_WD + t * EC + c];
-            const float bd = wc[O_BD + c];
+            for (int t = 0; t < 9; ++t) wd[t] = *reinterpret_cast<const fb_f32x2*>(wc + O_WD + t * EC + c);
+            const fb_f32x2 bd = *reinterpret_cast<const fb_f32x2*>(wc + O_BD + c);
 #pragma unroll
             for (int by = 0; by < BH; ++by)
 #pragma unroll
                 for (int bx = 0; bx < BW; ++bx) {
-                    float d = bd;
+                    fb_f32x2 d2 = bd;
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) d = fmaf(win[by * S + ky][bx * S + kx], wd[ky * 3 + kx], d);
-                    d = fmaxf(d, 0.f);
-#if YF_FB_PK
+                        for (int kx = 0; kx < 3; ++kx) d2 = __builtin_elementwise_fma(win[by * S + ky][bx * S + kx], wd[ky * 3 + kx], d2);
 #pragma unroll
-                    for (int co = 0; co < COUT; co += 2)
-                        acc2[by * BW + bx][co / 2] = __builtin_elementwise_fma(fb_f32x2{d, d}, *reinterpret_cast<const fb_f32x2*>(wc + O_W2 + c * COUT + co),
-                                                                                acc2[by * BW + bx][co / 2]);
-#else
+                    for (int h = 0; h < 2; ++h) {
+                        const float d = fmaxf(d2[h], 0.f);
 #pragma unroll
-                    for (int co = 0; co < COUT; ++co)
-                        acc2[by * BW + bx][co / 2][co & 1] = fmaf(d, wc[O_W2 + c * COUT + co], acc2[by * BW + bx][co / 2][co & 1]);
-#endif
+                        for (int co = 0; co < COUT; co += 2)
+                            acc2[by * BW + bx][co / 2] = __builtin_elementwise_fma(fb_f32x2{d, d}, *reinterpret_cast<const fb_f32x2*>(wc + O_W2 + (c + h) * COUT + co),
+                                                                                    acc2[by * BW + bx][co / 2]);
+                    }
                 }
         }
         YF_STAMP_AT(3)
