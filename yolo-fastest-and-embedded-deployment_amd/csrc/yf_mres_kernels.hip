@@ -236,9 +236,10 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                     for (int s = 0; s < ((YF_MRES_DBG & 2) ? 1 : KS1); ++s) cf = __builtin_amdgcn_mfma_f32_16x16x4f32(w1f[s], a1[i][s], cf, 0, 0, 0);
                 }
                 // weights as the A operand: the lane holds channels 4q .. 4q+3 of region pixel mt*16 + r = one E record
-                const bool in = (inmask >> i) & 1;
-                const float4 ev = make_float4(in ? fmaxf(cf[0] + b1.x, 0.f) : 0.f, in ? fmaxf(cf[1] + b1.y, 0.f) : 0.f,
-                                              in ? fmaxf(cf[2] + b1.z, 0.f) : 0.f, in ? fmaxf(cf[3] + b1.w, 0.f) : 0.f);
+                // ReLU and the zero outside the image in ONE instruction: median(x, 0, lim) with lim = +inf inside, 0 outside
+                const float lim = (inmask >> i) & 1 ? __builtin_inff() : 0.f;
+                const float4 ev = make_float4(__builtin_amdgcn_fmed3f(cf[0] + b1.x, 0.f, lim), __builtin_amdgcn_fmed3f(cf[1] + b1.y, 0.f, lim),
+                                              __builtin_amdgcn_fmed3f(cf[2] + b1.z, 0.f, lim), __builtin_amdgcn_fmed3f(cf[3] + b1.w, 0.f, lim));
                 *reinterpret_cast<float4*>(E + (q * EPL + mt * 16 + r) * 4) = ev;
                 if constexpr (WEXP)
                     if (eoff[i] >= 0 && c * 16 + 4 * q < CEXP)
@@ -448,10 +449,10 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
 #pragma unroll
                             for (int k = 0; k < KS1; ++k) cf = __builtin_amdgcn_mfma_f32_16x16x4f32(w1f[k], a1[i][k], cf, 0, 0, 0);
                         }
-                        const bool in = (inmask >> i) & 1;
+                        const float lim = (inmask >> i) & 1 ? __builtin_inff() : 0.f;   // median(x, 0, lim): ReLU + outside-the-image zero
                         *reinterpret_cast<float4*>(Eb + (q * EPL + mt * 16 + r) * 4) =
-                            make_float4(in ? fmaxf(cf[0] + b1.x, 0.f) : 0.f, in ? fmaxf(cf[1] + b1.y, 0.f) : 0.f,
-                                        in ? fmaxf(cf[2] + b1.z, 0.f) : 0.f, in ? fmaxf(cf[3] + b1.w, 0.f) : 0.f);
+                            make_float4(__builtin_amdgcn_fmed3f(cf[0] + b1.x, 0.f, lim), __builtin_amdgcn_fmed3f(cf[1] + b1.y, 0.f, lim),
+                                        __builtin_amdgcn_fmed3f(cf[2] + b1.z, 0.f, lim), __builtin_amdgcn_fmed3f(cf[3] + b1.w, 0.f, lim));
                     }
                 }
             }
