@@ -43,9 +43,22 @@ constexpr int NG = 14;                     // k groups
 constexpr int NU = 5;                      // px-tiles of phase 1 per wave (36 over 8 waves)
 constexpr int NCHUNK = 54;                 // 9 taps x 6 chunks of 4 channels
 constexpr int W9_F32 = NG * 4 * 2 * 64, W21_F32 = 2 * 4 * 64;
+// fp32 only: channels 16..23 of conv1_9 (the half-empty second M-tile) on v_mfma_f32_4x4x1_16B_f32 instead -- weights
+// [g][cg][lane][s] (staged in LDS) and conv2_1's two k-steps for those channels [t][lane]
+constexpr int WQ_F32 = NG * 2 * 64 * 4, W21Q_F32 = 2 * 64;
 constexpr int W9_F16 = NG * 2 * 64 * 2, W21_F16 = 2 * 64 * 2;  // in floats (f16x4 = 2 floats per lane)
 }  // namespace
 
+#ifndef YF_K19_Q4
+#define YF_K19_Q4 1
+#endif
+// Q4 (fp32): output channels 16..23 of conv1_9 do not ride in a second 16-row M-tile (half of whose rows are padding: 25 % of all
+// MFMA cycles) but in 4x4 blocks: v_mfma_f32_4x4x1_16B_f32 is 16 independent 4x4 outer products, block b = lanes 4b..4b+3, and
+// with lane = (pixel p, chunk j) block (j, p >> 2) multiplies 4 channels x the 4 pixels of its lanes at the k-value THAT lane
+// group holds anyway (the same B register as the 16x16x4 k-step).  Each lane group accumulates its own k-values, so the four
+// partial sums are added across lane groups once per tile (ds_bpermute), and conv2_1 takes channel 16 + 4 t + j from lane group
+// j.  Measured (tools/mfma4_probe.hip): a wave issues one 4x4x1 per 12 cycles and two waves of a SIMD do not slow each other,
+// against 32 cycles of pipe per 16x16x4.
 // DBG (tools/kbench.hip only): 1 = skip phase 1, 2 = skip phase 2's MFMAs
 template <typename TT, int DBG = 0>
 __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
@@ -55,6 +68,8 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
     constexpr int BUF = RH * RWS;  // elements per region buffer
     extern __shared__ __attribute__((aligned(16))) unsigned char k19_smem[];
     TT* const R = reinterpret_cast<TT*>(k19_smem);  // [2][BUF]
+    constexpr bool Q4 = !H16 && YF_K19_Q4;
+    float* const WQ = reinterpret_cast<float*>(k19_smem + (size_t)2 * BUF * sizeof(TT));  // Q4: [NG][2][64][4]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // = the tile's output row this wave owns
@@ -79,11 +94,21 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) wf[g][s][mt] = a.wp[((g * 4 + s) * 2 + mt) * 64 + lane];
+                for (int mt = 0; mt < (Q4 ? 1 : 2); ++mt) wf[g][s][mt] = a.wp[((g * 4 + s) * 2 + mt) * 64 + lane];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < (Q4 ? 1 : 2); ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) w21f[mt][r] = a.wp[W9_F32 + (mt * 4 + r) * 64 + lane];
+    }
+    float w21q[2] = {0.f, 0.f}, biasq[2] = {0.f, 0.f};
+    if constexpr (Q4) {
+        for (int i = threadIdx.x; i < WQ_F32 / 4; i += 512)
+            reinterpret_cast<float4*>(WQ)[i] = reinterpret_cast<const float4*>(a.wp + W9_F32 + W21_F32)[i];   // visible after the prologue's barrier
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            w21q[t] = a.wp[W9_F32 + W21_F32 + WQ_F32 + t * 64 + lane];
+            biasq[t] = a.b9[16 + 4 * t + j];
+        }
     }
     float bias9[2][4], bias21[4], w8a[2], bias8[2][4];
 #pragma unroll
@@ -219,17 +244,36 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
         // and VALU instructions do NOT overlap on this part (measured: the two phases' times add up exactly; the fp32 matrix
         // rate equals the fp32 vector rate), so phase 1 is written for the fewest VALU instructions, not for overlap ----
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        f32x4 accq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // Q4: channels 16 + 4 cg + i, this lane group's k-values only
         using xfrag = typename std::conditional<H16, f16x4, f32x4>::type;
         xfrag xc = *reinterpret_cast<const xfrag*>(Rc + adr[0]), xn = xc;
+        f32x4 wq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, wqn[2] = {wq[0], wq[1]};
+        if constexpr (Q4) {
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) wq[cg] = wqn[cg] = *reinterpret_cast<const f32x4*>(WQ + (cg * 64 + lane) * 4);
+        }
         f32x4 d[2];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) xn = *reinterpret_cast<const xfrag*>(Rc + adr[g + 1]);
+            if (g + 1 < NG) {
+                xn = *reinterpret_cast<const xfrag*>(Rc + adr[g + 1]);
+                if constexpr (Q4) {
+#pragma unroll
+                    for (int cg = 0; cg < 2; ++cg) wqn[cg] = *reinterpret_cast<const f32x4*>(WQ + (((g + 1) * 2 + cg) * 64 + lane) * 4);
+                }
+            }
             if (!(DBG & 1) && (g & 1) == 0 && g / 2 < NU) p1_mfma(g / 2, d);
             if constexpr (!(DBG & 2)) {
                 if constexpr (H16) {
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[g][mt], xc, acc[mt], 0, 0, 0);
+                } else if constexpr (Q4) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][s][0], xc[s], acc[0], 0, 0, 0);
+#pragma unroll
+                        for (int cg = 0; cg < 2; ++cg) accq[cg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[cg][s], xc[s], accq[cg], 0, 0, 0);
+                    }
                 } else {
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
@@ -247,13 +291,31 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
             if (g == 12) { off2_n = origin(tl_n) - in; }
             __builtin_amdgcn_sched_barrier(0);  // keeps the one-group-ahead LDS read where it is (hoisting all 14 costs 56 VGPRs)
             xc = xn;
+            if constexpr (Q4) { wq[0] = wqn[0]; wq[1] = wqn[1]; }
         }
 
         // ---- epilogue: bias + ReLU, conv2_1 (24 -> 8) chained in registers, store ----
         {
             f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (Q4) {
+                // channels 16..23: add the four lane groups' partial sums (every lane group then holds all eight totals of its
+                // pixel), bias + ReLU, and hand channel 16 + 4 t + j to conv2_1's k-step t from lane group j
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+                for (int t = 0; t < 2; ++t) {
+                    float tot[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = accq[t][i];
+                        v += __shfl_xor(v, 16);
+                        v += __shfl_xor(v, 32);
+                        tot[i] = v;
+                    }
+                    const float mine = j == 0 ? tot[0] : j == 1 ? tot[1] : j == 2 ? tot[2] : tot[3];
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(w21q[t], fmaxf(mine + biasq[t], 0.f), o, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < (Q4 ? 1 : 2); ++mt) {
                 f32x4 h;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h[r] = fmaxf(acc[mt][r] + bias9[mt][r], 0.f);
@@ -276,7 +338,7 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
     }
 }
 
-size_t k19_packed_floats(bool h16) { return h16 ? (size_t)(W9_F16 + W21_F16) : (size_t)(W9_F32 + W21_F32); }
+size_t k19_packed_floats(bool h16) { return h16 ? (size_t)(W9_F16 + W21_F16) : (size_t)(W9_F32 + W21_F32 + WQ_F32 + W21Q_F32); }
 
 // w9: [tap][cin][cout] (blob layout of the dense 3x3), w21: [cin][cout]
 void k19_pack_weights(const float* w9, const float* w21, float* out, bool h16)
@@ -300,12 +362,31 @@ void k19_pack_weights(const float* w9, const float* w21, float* out, bool h16)
                 if (h16) oh[(size_t)W9_F16 * 2 + ((size_t)mt * 64 + l) * 4 + r] = f32_to_f16_bits(v);
                 else out[W9_F32 + (mt * 4 + r) * 64 + l] = v;
             }
+    if (!h16) {   // the 4x4-block form of channels 16..23 (k19m_kernel, Q4)
+        float* wq = out + W9_F32 + W21_F32;
+        for (int g = 0; g < NG; ++g)
+            for (int cg = 0; cg < 2; ++cg)
+                for (int l = 0; l < 64; ++l)
+                    for (int s = 0; s < 4; ++s) {
+                        const int jj = l >> 4, fc = 4 * g + jj, tap = fc / 6, c = (fc % 6) * 4 + s, cout = 16 + 4 * cg + (l & 3);
+                        wq[((g * 2 + cg) * 64 + l) * 4 + s] = fc < NCHUNK ? w9[((size_t)tap * 24 + c) * 24 + cout] : 0.f;
+                    }
+        float* w21q = wq + WQ_F32;
+        for (int t = 0; t < 2; ++t)
+            for (int l = 0; l < 64; ++l) {
+                const int c2 = l & 15, c1 = 16 + 4 * t + (l >> 4);
+                w21q[t * 64 + l] = c2 < 8 ? w21[c1 * 8 + c2] : 0.f;
+            }
+    }
 }
 
 // elements the kernel may read before / after its input tensor (one region row beyond either end)
 size_t k19m_guard_elems(int W) { return ((size_t)(W + 34) * 4 + 63) & ~(size_t)63; }
 
-size_t k19m_lds_bytes(int dtype) { return (size_t)2 * RH * row_stride(dtype == DT_F16) * (dtype == DT_F16 ? 2 : 4); }
+size_t k19m_lds_bytes(int dtype)
+{
+    return (size_t)2 * RH * row_stride(dtype == DT_F16) * (dtype == DT_F16 ? 2 : 4) + (dtype == DT_F16 || !YF_K19_Q4 ? 0 : (size_t)WQ_F32 * 4);
+}
 
 int launch_k19m(K19Args a, int N, hipStream_t s, int dtype)
 {
