@@ -260,7 +260,9 @@ def test_other_input_sizes(yf, dev):
     sd = torch.load(WEIGHTS[256], map_location="cpu")
     m.load_state_dict(sd)
     g = np.random.default_rng(3)
-    for (H, W, N) in ((32, 32, 3), (64, 96, 2), (96, 32, 1), (160, 224, 2)):
+    # (160, 224): the stride-16/32 frames fit one tile -> chained residual launches on partial tiles; (288, 320) and (256, 352):
+    # one row / column of tiles more than the chain allows -> one launch per block, ragged tiles
+    for (H, W, N) in ((32, 32, 3), (64, 96, 2), (96, 32, 1), (160, 224, 2), (288, 320, 2), (256, 352, 1)):
         u8 = g.integers(0, 256, size=(N, H, W), dtype=np.uint8)
         with torch.no_grad():
             hl, hs = m(_x(u8, dev))
@@ -457,6 +459,17 @@ def test_yf_detect_single_call_equals_two_calls(models, golden, dev):
     for f, k in enumerate(n):
         for key in ("boxes", "scores", "cls", "src"):
             assert torch.equal(a[key][f, :k], b[key][f, :k]), key
+    # chunks of 7 frames on two lanes: yf_detect runs each chunk's decode + NMS on the chunk's own stream
+    e = m.engine(256, 320, 20, dev)
+    e.set_chunk(7)
+    try:
+        c = post.detect_raw_from_input(x, kmax=16, origin_shape=(512, 640))
+    finally:
+        e.set_chunk(0)
+    assert np.array_equal(n, c["counts"].cpu().numpy())
+    for f, k in enumerate(n):
+        for key in ("boxes", "scores", "cls", "src"):
+            assert torch.equal(a[key][f, :k], c[key][f, :k]), key
 
 
 # ---- BASELINE configs[2]: fp16 storage + fp16 MFMA pointwise path (parity target: 2e-2 on logits vs the fp32 reference) ----

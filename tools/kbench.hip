@@ -156,6 +156,8 @@ int main(int argc, char** argv)
         bench_fb<8, 8, 4, 1, false, true, 16, 16, 2, 2, 8, 8, 1, false>("stem 32x32 2x2", N, 128, 160);
         bench_fb<4, 8, 4, 1, true, false, 16, 16, 1, 2, 8, 8, 1, false>("res1_1 16x32 1x2", N, 128, 160);
         bench_fb<8, 32, 8, 1, true, false, 16, 16, 2, 2, 8, 8, 1, false>("res2 32x32 2x2", N, 64, 80);
+        bench_fb<8, 32, 8, 1, true, false, 16, 16, 2, 2, 8, 8, 1, false>("res2 32x32 2x2, 64x64 frames (no partial tiles)", N, 64, 64);
+        bench_fb<8, 32, 8, 1, true, false, 16, 16, 2, 2, 8, 8, 1, false>("res2 32x32 2x2, 64x96 frames", N, 64, 96);
     }
     if (on("xl0")) {
         printf("--- tile shapes WITHOUT input staging (the production form), after the SGPR-spill fix ---\n");
