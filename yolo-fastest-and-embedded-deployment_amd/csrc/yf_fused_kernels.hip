@@ -28,6 +28,8 @@
 namespace yf {
 
 typedef float fb_f32x2 __attribute__((ext_vector_type(2)));
+typedef float __attribute__((address_space(4))) cfloat;               // constant address space: scalar (s_load) reads of uniform data
+typedef fb_f32x2 __attribute__((address_space(4))) cfloat2;
 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
@@ -118,7 +120,7 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
     YF_STAMP_DECL
     for (int ch = 0; ch < CEXP / EC; ++ch) {
         YF_STAMP_AT(0)
-        const float* __restrict__ wc = a.wp + ch * CHF;  // this chunk's weights (wave-uniform -> scalar loads)
+        const cfloat* __restrict__ wc = (const cfloat*)(a.wp + ch * CHF);  // this chunk's weights (wave-uniform, constant address space -> scalar loads)
         // ---------------- expansion of the halo'd region into LDS: PE pixels per lane per item ----------------
         for (int item = wave; item < NITEM; item += NW) {
             const int pb = item % NPB, cg = item / NPB;
@@ -179,10 +181,10 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
 #if YF_FB_PK
 #pragma unroll
                     for (int c = 0; c < CIN; c += 2) {
-                        fb_f32x2 s2 = *reinterpret_cast<const fb_f32x2*>(a.b0 + c);
+                        fb_f32x2 s2 = *(const cfloat2*)(const cfloat*)(a.b0 + c);
 #pragma unroll
                         for (int t = 0; t < 9; ++t)
-                            s2 = __builtin_elementwise_fma(fb_f32x2{v[t], v[t]}, *reinterpret_cast<const fb_f32x2*>(a.w0 + t * CIN + c), s2);
+                            s2 = __builtin_elementwise_fma(fb_f32x2{v[t], v[t]}, *(const cfloat2*)(const cfloat*)(a.w0 + t * CIN + c), s2);
                         x[p][c] = fmaxf(s2[0], 0.f); x[p][c + 1] = fmaxf(s2[1], 0.f);
                     }
 #else
@@ -215,7 +217,7 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
             fb_f32x2 e2[PE][CG / 2];
 #pragma unroll
             for (int j = 0; j < CG; j += 2) {
-                const fb_f32x2 bv = *reinterpret_cast<const fb_f32x2*>(wc + O_B1 + cg * CG + j);
+                const fb_f32x2 bv = *(const cfloat2*)(wc + O_B1 + cg * CG + j);
 #pragma unroll
                 for (int p = 0; p < PE; ++p) e2[p][j / 2] = bv;
             }
@@ -223,7 +225,7 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
             for (int k = 0; k < CIN; ++k)
 #pragma unroll
                 for (int j = 0; j < CG; j += 2) {
-                    const fb_f32x2 wv = *reinterpret_cast<const fb_f32x2*>(wc + k * EC + cg * CG + j);
+                    const fb_f32x2 wv = *(const cfloat2*)(wc + k * EC + cg * CG + j);
 #pragma unroll
                     for (int p = 0; p < PE; ++p) e2[p][j / 2] = __builtin_elementwise_fma(fb_f32x2{x[p][k], x[p][k]}, wv, e2[p][j / 2]);
                 }
@@ -286,8 +288,8 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
             }
             fb_f32x2 wd[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) wd[t] = *reinterpret_cast<const fb_f32x2*>(wc + O_WD + t * EC + c);
-            const fb_f32x2 bd = *reinterpret_cast<const fb_f32x2*>(wc + O_BD + c);
+            for (int t = 0; t < 9; ++t) wd[t] = *(const cfloat2*)(wc + O_WD + t * EC + c);
+            const fb_f32x2 bd = *(const cfloat2*)(wc + O_BD + c);
 #pragma unroll
             for (int by = 0; by < BH; ++by)
 #pragma unroll
@@ -302,7 +304,7 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
                         const float d = fmaxf(d2[h], 0.f);
 #pragma unroll
                         for (int co = 0; co < COUT; co += 2)
-                            acc2[by * BW + bx][co / 2] = __builtin_elementwise_fma(fb_f32x2{d, d}, *reinterpret_cast<const fb_f32x2*>(wc + O_W2 + (c + h) * COUT + co),
+                            acc2[by * BW + bx][co / 2] = __builtin_elementwise_fma(fb_f32x2{d, d}, *(const cfloat2*)(wc + O_W2 + (c + h) * COUT + co),
                                                                                     acc2[by * BW + bx][co / 2]);
                     }
                 }
@@ -312,7 +314,7 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
         YF_STAMP_AT(4)
     }
     // ---------------- epilogue: bias (+ residual) (+ ReLU), NHWC store ----------------
-    const float* __restrict__ b2 = a.wp + (CEXP / EC) * CHF;
+    const cfloat* __restrict__ b2 = (const cfloat*)(a.wp + (CEXP / EC) * CHF);
 #pragma unroll
     for (int by = 0; by < BH; ++by)
 #pragma unroll
