@@ -3,20 +3,24 @@
 //   x -> pw-expand(+ReLU) -> dw3x3(+ReLU) -> pw-project (+ x)       src/model_training/model/yolo_fastest.py:52-66
 //
 // One workgroup = one TH x TW tile of one frame (whole frame at strides 16/32).  Both pointwise convs are
-// v_mfma_f32_16x16x4_f32 GEMMs (exact fp32) whose B operands (weights) sit in VGPR fragments, loaded once per
-// 16-channel chunk from a host-packed stream; only the depthwise conv runs on the VALU.  Nothing wide touches HBM:
+// v_mfma_f32_16x16x4_f32 GEMMs (exact fp32; v_mfma_f32_16x16x16_f16 with fp16 storage) with the WEIGHTS as the MFMA's A operand
+// and the activations as B, so a lane's four result registers are four consecutive channels of ONE pixel: 16-byte LDS records
+// and 16-byte HBM stores, and the depthwise result feeds the projection without leaving registers.  Only the depthwise conv
+// runs on the VALU (packed fp32 FMAs over channel pairs).  Nothing wide touches HBM:
 //
-//   HBM --16-B loads--> LDS X[region px][CIN]      (halo'd input tile, also the residual)
-//   X --A fragments (kept in VGPRs for the whole kernel)--> MFMA expand --C frag: 4 consecutive pixels of one
-//   channel--> bias, ReLU, zero outside the image --4 conflict-free ds_write_b32--> LDS E[4 ch-groups][region px][4 ch]
-//   E --9 ds_read_b128 per pixel (4 channels each)--> depthwise FMA chain + ReLU --is directly the A fragment of-->
-//   MFMA project (accumulators live in VGPRs across all chunks) --> + bias + residual(X) --> HBM
+//   HBM --16-B loads, all issued before the first LDS write--> LDS X[region px][CIN]   (halo'd input tile, also the residual)
+//   X --activation fragments (kept in VGPRs for the whole kernel)--> MFMA expand --lane: 4 consecutive channels of one region
+//   pixel--> bias, ReLU + zero outside the image (one v_med3_f32) --one ds_write_b128--> LDS E[4-ch group][region px][4 ch]
+//   E --9 ds_read_b128 per pixel, issued together--> depthwise taps (v_pk_fma_f32) + ReLU --is directly the B fragment of-->
+//   MFMA project (accumulators live in VGPRs across all chunks) --> + bias + residual(X) --> HBM (or back into X: chains)
 //
 // Fragment conventions (16x16x4 f32): lane l = (r = l & 15, q = l >> 4).
 //   A: row r, k = q (per k-step);  B: k = q, col r;  C/D: col r, rows 4q + reg.
-//   expand : rows = region pixels (linear index rp = ry*RW + rx), cols = the chunk's 16 channels;
-//   project: rows = output pixels (linear index op = oy*TW + ox), k = chunk channel 4q + j for k-step j, cols = cout.
-// The k permutations are folded into the host-packed B fragments (mres_pack_weights).
+//   expand : A rows = the chunk's 16 channels (weights), B cols = region pixels (linear index rp = ry*RW + rx);
+//   project: A rows = output channels (weights), k = chunk channel 4q + j for k-step j, B cols = output pixels (op = oy*TW + ox).
+// The k permutations are folded into the host-packed weight fragments (mres_pack_weights).
+// Variants: stride 2 (the un-named bottleneck triples; the conv4_2 triple also WRITES its expanded tensor and applies conv5_1's
+// ReLU), producer/consumer waves (mres_pc_kernel, strides 16/32), and chains of blocks in one launch where the tile is the frame.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
