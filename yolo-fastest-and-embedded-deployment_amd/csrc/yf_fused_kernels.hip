@@ -7,7 +7,7 @@
 // k19_kernel:          conv1_8 (pw 4->24 +ReLU) -> conv1_9 (dense 3x3 s2 24->24 +ReLU) -> conv2_1 (pw 24->8)   (:86-89)
 //
 // One workgroup = one spatial tile of one frame.  Data flow per tile:
-//   HBM --(narrow NHWC input tile + halo, 16-B loads)--> registers --expand--> LDS (channel-planar chunk of EC
+//   HBM --(narrow NHWC input tile + halo, 16-B loads)--> registers --expand--> LDS (chunk of EC, channel pairs interleaved:
 //   expanded channels over the halo'd region) --sliding window--> registers (dw) --> project accumulators in
 //   registers --> HBM (narrow NHWC output).  Padding semantics: the depthwise conv pads ITS input, i.e. the
 //   expanded tensor is zero outside the image (not relu(bias)).
