@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
         for (int i = 0; i < MTRW; ++i) {
             const int mt = wave + i * NWAVE;
             if (EVEN_R || i < MTRW - 1 || mt < MTR) {   // only a wave's LAST tile can be missing: the others share one basic block
-                f32x4 cf = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 cf = f32x4{b1.x, b1.y, b1.z, b1.w};   // the bias rides in as the MFMA's C operand
                 if constexpr (H16) {
 #pragma unroll
                     for (int s = 0; s < NK1; ++s) {
@@ -242,8 +242,8 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                 // weights as the A operand: the lane holds channels 4q .. 4q+3 of region pixel mt*16 + r = one E record
                 // ReLU and the zero outside the image in ONE instruction: median(x, 0, lim) with lim = +inf inside, 0 outside
                 const float lim = (inmask >> i) & 1 ? __builtin_inff() : 0.f;
-                const float4 ev = make_float4(__builtin_amdgcn_fmed3f(cf[0] + b1.x, 0.f, lim), __builtin_amdgcn_fmed3f(cf[1] + b1.y, 0.f, lim),
-                                              __builtin_amdgcn_fmed3f(cf[2] + b1.z, 0.f, lim), __builtin_amdgcn_fmed3f(cf[3] + b1.w, 0.f, lim));
+                const float4 ev = make_float4(__builtin_amdgcn_fmed3f(cf[0], 0.f, lim), __builtin_amdgcn_fmed3f(cf[1], 0.f, lim),
+                                              __builtin_amdgcn_fmed3f(cf[2], 0.f, lim), __builtin_amdgcn_fmed3f(cf[3], 0.f, lim));
                 *reinterpret_cast<float4*>(E + (q * EPL + mt * 16 + r) * 4) = ev;
                 if constexpr (WEXP)
                     if (eoff[i] >= 0 && c * 16 + 4 * q < CEXP)
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
                 for (int i = 0; i < MTRW; ++i) {
                     const int mt = wave + i * NWP;
                     if (i < MTRW - 1 || mt < MTR) {
-                        f32x4 cf = f32x4{0.f, 0.f, 0.f, 0.f};
+                        f32x4 cf = f32x4{b1.x, b1.y, b1.z, b1.w};   // bias as the C operand
                         if constexpr (H16) {
 #pragma unroll
                             for (int k = 0; k < NK1; ++k) {
@@ -455,8 +455,8 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
                         }
                         const float lim = (inmask >> i) & 1 ? __builtin_inff() : 0.f;   // median(x, 0, lim): ReLU + outside-the-image zero
                         *reinterpret_cast<float4*>(Eb + (q * EPL + mt * 16 + r) * 4) =
-                            make_float4(__builtin_amdgcn_fmed3f(cf[0] + b1.x, 0.f, lim), __builtin_amdgcn_fmed3f(cf[1] + b1.y, 0.f, lim),
-                                        __builtin_amdgcn_fmed3f(cf[2] + b1.z, 0.f, lim), __builtin_amdgcn_fmed3f(cf[3] + b1.w, 0.f, lim));
+                            make_float4(__builtin_amdgcn_fmed3f(cf[0], 0.f, lim), __builtin_amdgcn_fmed3f(cf[1], 0.f, lim),
+                                        __builtin_amdgcn_fmed3f(cf[2], 0.f, lim), __builtin_amdgcn_fmed3f(cf[3], 0.f, lim));
                     }
                 }
             }
