@@ -96,7 +96,7 @@ static void bench_mres(const char* tag, int N, int H, int W)
     a.H = H; a.W = W;
     a.tiles_y = (H + TH - 1) / TH; a.tiles_x = (W + TW - 1) / TW;
     constexpr int MTR = ((TH + 2) * (TW + 2) + 15) / 16;
-    constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 16 * (((MTR * 16 + 7) / 8) * 8 + 1) +
+    constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 16 * mres_epl(MTR) +
                             ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT) + COUT + 3) & ~3)) * sizeof(float);
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mres_kernel<CIN, CEXP, COUT, RES, 1, TH, TW, NWAVE, float>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -126,7 +126,7 @@ static void bench_mres_pc(const char* tag, int N, int H, int W)
     a.H = H; a.W = W;
     a.tiles_y = (H + TH - 1) / TH; a.tiles_x = (W + TW - 1) / TW;
     constexpr int MTR = ((TH + 2) * (TW + 2) + 15) / 16;
-    constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 2 * 16 * (((MTR * 16 + 7) / 8) * 8 + 1) +
+    constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 2 * 16 * mres_epl(MTR) +
                             ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT) + COUT + 3) & ~3)) * sizeof(float);
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, float>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
