@@ -69,7 +69,8 @@ __device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(
 #ifndef YF_MRES_EPL_PAD
 #define YF_MRES_EPL_PAD 0
 #endif
-__host__ __device__ constexpr int mres_epl(int mtr) { return mtr * 16 + YF_MRES_EPL_PAD; }
+// Stride-2 blocks read every second pixel: quad q + 1 then wants the ODD records (pitch == 1 mod 16).
+__host__ __device__ constexpr int mres_epl(int mtr, int s = 1) { return mtr * 16 + (s == 2 ? 1 : 0) + YF_MRES_EPL_PAD; }
 __host__ __device__ constexpr int mres_ksteps(int K) { return (K / 16) * 4 + ((K % 16) ? 2 : 0); }
 __host__ __device__ constexpr int mres_chunk_floats(int cin, int cout, bool h16 = false)
 {
@@ -120,6 +121,27 @@ __host__ __device__ constexpr bool mres_writes_expansion(int cin, int cexp, int 
 // ... and the one whose projection is a conv_norm_relu (conv5_1, yolo_fastest.py:124); every other block projects linearly (:62, :86-118)
 __host__ __device__ constexpr bool mres_relu_out(int cin, int cexp, int cout, int s) { return mres_writes_expansion(cin, cexp, cout, s); }
 
+// Output pixel (oy, ox) of row r of depthwise / projection M-tile mo.  Row-major 16-pixel runs cross a tile row in most M-tiles and
+// the step of RW - TW = 2 records at the crossing puts two lane pairs of a ds_read_b128 lane group on the same banks.  Where the
+// E row pitch is 6 (mod 16) records (RW = 22: the 16x20 tiles) an M-tile of 2 columns x 8 rows has all 16 lanes on different
+// record slots: rows advance by 6 (mod 16), each takes two consecutive slots.
+#ifndef YF_MRES_TILE2X8
+#define YF_MRES_TILE2X8 1
+#endif
+template <int TH, int TW, int RW, int S>
+__device__ __forceinline__ void mres_out_px(int mo, int r, int& oy, int& ox)
+{
+    if constexpr (YF_MRES_TILE2X8 && S == 1 && RW % 16 == 6 && TW % 2 == 0 && TH % 8 == 0) {
+        const int rb = mo / (TW / 2), cp = mo - rb * (TW / 2);
+        oy = rb * 8 + (r >> 1);
+        ox = cp * 2 + (r & 1);
+    } else {
+        const int op = mo * 16 + r;
+        oy = op / TW;
+        ox = op - oy * TW;
+    }
+}
+
 // S = 2: the stride-2 triples (pw-expand -> dw3x3 stride 2 -> pw-project, no residual): a.H / a.W are the INPUT dims, the tile
 // is TH x TW OUTPUT pixels and the region (TH - 1) S + 3 rows.
 template <int CIN, int CEXP, int COUT, bool RES, int S, int TH, int TW, int NWAVE, typename T>
@@ -131,7 +153,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
     constexpr bool EVEN_R = MTR % NWAVE == 0, EVEN_O = MTO % NWAVE == 0;  // every wave owns the same number of tiles: no branches
     constexpr bool WEXP = mres_writes_expansion(CIN, CEXP, COUT, S);       // conv4_2 + conv4_3 + conv5_1: conv4_2 is a skip tensor
     constexpr int XP = CIN + 4;                           // X row pitch: conflict-free b128/b64 fragment reads
-    constexpr int EPL = mres_epl(MTR);   // pixels per 4-channel plane
+    constexpr int EPL = mres_epl(MTR, S);   // pixels per 4-channel plane
     constexpr bool H16 = sizeof(T) == 2;  // fp16 storage: the pointwise GEMMs run on v_mfma_f32_16x16x16_f16 (4 k-steps each)
     constexpr int KS1 = mres_ksteps(CIN), NB1 = CIN / 16, NT2 = (COUT + 15) / 16, NCH = (CEXP + 15) / 16;
     constexpr int NK1 = (KS1 + 3) / 4;    // f16 MFMAs per expansion tile
@@ -194,8 +216,8 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) acc[i][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int mo = wave + i * NWAVE;
-        const int op = (mo < MTO ? mo : 0) * 16 + r;
-        const int oy = op / TW, ox = op - oy * TW;
+        int oy, ox;
+        mres_out_px<TH, TW, RW, S>(mo < MTO ? mo : 0, r, oy, ox);
         rp0[i] = (oy * S + 1) * RW + ox * S + 1;
     }
 
@@ -329,8 +351,8 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
     for (int i = 0; i < MTOW; ++i) {
         const int mo = wave + i * NWAVE;
         if (!EVEN_O && i == MTOW - 1 && mo >= MTO) continue;
-        const int op = mo * 16 + r;
-        const int oy = op / TW, ox = op - oy * TW;
+        int oy, ox;
+        mres_out_px<TH, TW, RW, S>(mo, r, oy, ox);
         const int gy = oy0 + oy, gx = ox0 + ox;
         if (gy >= Ho || gx >= Wo) continue;
 #pragma unroll
@@ -495,8 +517,8 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
 #pragma unroll
         for (int i = 0; i < MTOW; ++i) {
             const int mo = cw + i * NWC;
-            const int op = (mo < MTO ? mo : 0) * 16 + r;
-            const int oy = op / TW, ox = op - oy * TW;
+            int oy, ox;
+            mres_out_px<TH, TW, RW, 1>(mo < MTO ? mo : 0, r, oy, ox);
             rp0[i] = (oy + 1) * RW + ox + 1;
         }
 #pragma unroll 1
@@ -579,8 +601,8 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
         for (int i = 0; i < MTOW; ++i) {
             const int mo = cw + i * NWC;
             if (i == MTOW - 1 && mo >= MTO) continue;
-            const int op = mo * 16 + r;
-            const int oy = op / TW, ox = op - oy * TW;
+            int oy, ox;
+            mres_out_px<TH, TW, RW, 1>(mo, r, oy, ox);
             const int gy = oy0 + oy, gx = ox0 + ox;
             if (gy >= a.H || gx >= a.W) continue;
 #pragma unroll
@@ -636,7 +658,7 @@ static int launch_mres_t(MresArgs a, int N, hipStream_t s)
     if (mres_writes_expansion(CIN, CEXP, COUT, S) && !a.out_exp) return -3;
     if (a.nblk > 1) return -4;  // chains: producer/consumer kernel only
     constexpr int MTR = (((TH - 1) * S + 3) * ((TW - 1) * S + 3) + 15) / 16;
-    constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 16 * mres_epl(MTR) +
+    constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 16 * mres_epl(MTR, S) +
                             ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT, sizeof(T) == 2) + COUT + 3) & ~3)) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done = false;
