@@ -135,6 +135,11 @@ __device__ __forceinline__ void mres_out_px(int mo, int r, int& oy, int& ox)
         const int rb = mo / (TW / 2), cp = mo - rb * (TW / 2);
         oy = rb * 8 + (r >> 1);
         ox = cp * 2 + (r & 1);
+    } else if constexpr (YF_MRES_TILE2X8 && S == 1 && RW % 16 == 12 && TW == 10 && TH == 8) {
+        // row pitch 12 (mod 16) records (the 8x10 tiles of stride 32): rows advance by -4, so 4-column x 4-row M-tiles are
+        // conflict-free; the last two columns go as one 2 x 8 M-tile (two of its lanes share a slot)
+        if (mo < 4) { oy = (mo >> 1) * 4 + (r >> 2); ox = (mo & 1) * 4 + (r & 3); }
+        else { oy = r >> 1; ox = 8 + (r & 1); }
     } else {
         const int op = mo * 16 + r;
         oy = op / TW;
