@@ -2,8 +2,11 @@
 """bench.py -- BASELINE.json's metric on BASELINE.json's config.
 
   python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+
+N = 1 runs in this process.  N > 1 and no WORLD_SIZE in the environment: this process starts
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same args>
+as a child BEFORE it touches the GPU, relays rank 0's JSON line and exits with the child's code; fewer than N visible
+GPUs -> non-zero exit and a message.  Launched by torch.distributed.run from outside (the driver), WORLD_SIZE must equal --gpus.
 
 A "step" = one pass of the hot path (model forward -> decode -> per-class NMS [-> all-gather of the decoded
 boxes when N > 1]) over one batch of synthetic frames that is already resident in HBM.
@@ -11,19 +14,48 @@ Workload at N = 1: BASELINE.json configs[1], "YOLO-Fastest 320x256 batch=256 fp3
 (u8 ~ Uniform{0..255} i.i.d., x = (u8-128)/255, seed = rank).  N > 1: the same per GPU (weak
 scaling, frames are independent units; one RCCL all-gather of the fixed-capacity box records).
 Rank 0 prints ONE JSON line.
+
+The `roofline` object is the PHYSICAL roof of the dominant launch (README "Reading the bench line"):
+  * the launch's flops, split by the pipe they run on in the plan (matrix cores / vector ALU, yf_op_info_ex), over its
+    average duration (HIP events on the launch stream), against the dense peak of that pipe and type;
+  * its HBM bytes from the PMC counters (profiles/pmc_traffic.json, taken with tools/refresh_profiles.sh at the source hash
+    recorded in the file; null when the file is from other sources) over the same duration against 8 TB/s;
+  * `bound` names the larger of the two fractions ("hbm" when the counter bytes per second exceed half of the 6.3 TB/s a
+    streaming kernel reaches).
+SURVEY.md 8(d)'s layer-granular figure (what an UNFUSED network would move) is kept under `layer_granular_equiv`; a fused
+plan exceeds 1.0 on it by construction, so it is not a roofline fraction.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+PKG = os.path.join(ROOT, "yolo-fastest-and-embedded-deployment_amd")
 
 BYTES_PER_FRAME = {256: 42_575_360, 512: 170_301_440}   # SURVEY.md 8(d): layer-granular algorithmic bytes, fp32 (fp16: half)
 FLOPS_PER_FRAME = {256: 236_442_880, 512: 945_771_520}
-HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# MI355X_MICROARCH.md, chip-level parameters
+HBM_PEAK_GBS = 8000.0          # HBM3E spec
+HBM_STREAM_GBS = 6290.0        # measured float4 copy
+FP32_PEAK_TF = 157.3           # vector fp32 == fp32-input MFMA (64 FLOP/clk/SIMD each; they share the issue rate)
+F16_MFMA_PEAK_TF = 2500.0      # dense fp16/bf16 MFMA
+
+
+def source_hash():
+    """sha256 over the kernel sources: identifies the build a profile under profiles/ belongs to."""
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(seconds=12.0):
@@ -35,8 +67,7 @@ def cpu_baseline(seconds=12.0):
     from oracle import post_oracle as po
     import yolo_fastest_amd as yf
     io = yf.io_params_for(256)
-    sd = bo.load_state_dict(os.path.join(ROOT, "yolo-fastest-and-embedded-deployment_amd", "assets", "weights",
-                                         "yolo_fastest_256x320_epoch28.pth"))
+    sd = bo.load_state_dict(os.path.join(PKG, "assets", "weights", "yolo_fastest_256x320_epoch28.pth"))
     g = np.load(os.path.join(ROOT, "tests", "golden", "golden_256.npz"))
     xs = [bo.preprocess(g["input_u8"][i]) for i in range(20)]
     default_threads = torch.get_num_threads()
@@ -65,11 +96,54 @@ def cpu_baseline(seconds=12.0):
                       + f"; host has {os.cpu_count()} logical CPUs"}
 
 
+def self_launch(n_gpus):
+    """--gpus N > 1 without a launcher: start the N ranks as a CHILD process tree (never exec: this process must not have
+    touched the GPU, and it has not -- device_count() does not initialise it) and relay its output."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n_gpus:
+        sys.stderr.write(f"bench.py: --gpus {n_gpus} but only {have} GPU(s) are visible on this host; refusing to run a smaller "
+                         f"job under that label\n")
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def launch_roofline(o, dtype, traffic):
+    """Physical roof of one launch.  fp32: MFMA and vector FMAs share one issue rate on this part (measured), so the
+    floor is (all flops) / 157.3 TF.  fp16: the matrix cores run beside the vector ALU, the floor is the larger of the two."""
+    t = o["ms"] * 1e-3
+    if dtype == "f16":
+        floor = max(o["mfma_flops"] / (F16_MFMA_PEAK_TF * 1e12), o["valu_flops"] / (FP32_PEAK_TF * 1e12))
+        on_mfma = o["mfma_flops"] / (F16_MFMA_PEAK_TF * 1e12) >= o["valu_flops"] / (FP32_PEAK_TF * 1e12)
+        peak_tf = F16_MFMA_PEAK_TF if on_mfma else FP32_PEAK_TF
+        flops = o["mfma_flops"] if on_mfma else o["valu_flops"]
+    else:
+        floor = o["flops"] / (FP32_PEAK_TF * 1e12)
+        on_mfma = o["mfma_flops"] >= o["valu_flops"]
+        peak_tf, flops = FP32_PEAK_TF, o["flops"]
+    r = {"compute_frac": floor / t, "on_mfma": on_mfma, "peak_tf": peak_tf, "achieved_tf": flops / t / 1e12, "hbm_frac": None,
+         "hbm_gbs": None}
+    if traffic is not None:
+        r["hbm_gbs"] = traffic / t / 1e9
+        r["hbm_frac"] = r["hbm_gbs"] / HBM_PEAK_GBS
+    hbm_bound = r["hbm_gbs"] is not None and r["hbm_gbs"] > 0.5 * HBM_STREAM_GBS
+    r["bound"] = "hbm" if hbm_bound else ("mfma" if on_mfma else "valu")
+    r["frac"] = r["hbm_frac"] if hbm_bound else r["compute_frac"]
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--res", type=int, default=256, choices=[256, 512])
     ap.add_argument("--chunk", type=int, default=0, help="frames per pass of the layer chain (0 = whole batch)")
@@ -85,6 +159,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-ops", default=None, help="write the launch names of one forward pass to this JSON file")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
+    world = int(env_world) if env_world is not None else 1
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; "
+                         f"use --nproc-per-node == --gpus (or run plain `python bench.py --gpus N`, which launches the ranks itself)")
 
     import numpy as np
     import torch
@@ -92,9 +176,10 @@ def main():
     import yolo_fastest_amd as yf
     from yolo_fastest_amd import dist as yfd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.device_count() < (world if world > 1 else 1):
+        raise SystemExit(f"bench.py: {world} rank(s) but only {torch.cuda.device_count()} GPU(s) visible")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP extension is the only implementation (no CPU fallback)")
     dev = torch.device("cuda", local_rank)
@@ -102,7 +187,8 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: RCCL world size {dist.get_world_size()} != --gpus {args.gpus}")
 
     io = yf.io_params_for(args.res)
     wname = {256: "yolo_fastest_256x320_epoch28.pth", 512: "yolo_fastest_512x640_epoch27.pth"}[args.res]
@@ -111,8 +197,7 @@ def main():
     if args.dtype == "f16":
         model.storage_dtype = torch.float16
     model.lanes = args.lanes
-    model.load_state_dict(torch.load(os.path.join(ROOT, "yolo-fastest-and-embedded-deployment_amd", "assets",
-                                                  "weights", wname), map_location=dev))
+    model.load_state_dict(torch.load(os.path.join(PKG, "assets", "weights", wname), map_location=dev))
     post = yf.YOLO_post_process(io["conf_thre"], io["nms_thre"], io["num_anchors"], io["num_cls"], io["anchors"],
                                 io["input_shape"]).bind(model)
     H, W = io["input_shape"][:2]
@@ -193,19 +278,55 @@ def main():
         ops = model.profile(x, reps=5)
         if args.dump_ops:
             with open(args.dump_ops, "w") as f:
-                json.dump([{"name": o["name"], "ms": o["ms"], "algorithmic_bytes": o["algorithmic_bytes"]} for o in ops], f)
+                json.dump([{"name": o["name"], "ms": o["ms"], "algorithmic_bytes": o["algorithmic_bytes"], "mfma_flops": o["mfma_flops"],
+                            "valu_flops": o["valu_flops"]} for o in ops], f)
         chain_ms = sum(o["ms"] for o in ops)
-        dom = max(ops, key=lambda o: o["ms"])
-        bytes_sum = sum(o["algorithmic_bytes"] for o in ops) / args.batch
-        traffic = None
+        # measured HBM bytes per launch (PMC passes of tools/refresh_profiles.sh), valid for this build and this workload only
+        traffic, traffic_note = {}, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        wl = {"res": args.res, "batch": args.batch, "dtype": args.dtype}
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            traffic = tj.get("kernels", {}).get(dom["name"], {}).get("hbm_bytes_per_launch")
-        achieved = dom["algorithmic_bytes"] / (dom["ms"] * 1e-3) / 1e9
+            if tj.get("source_hash") != source_hash():
+                traffic_note = f"profiles/pmc_traffic.json was taken at source hash {tj.get('source_hash')}, this build is {source_hash()}"
+            elif tj.get("workload") != wl:
+                traffic_note = f"profiles/pmc_traffic.json is for {tj.get('workload')}, this run is {wl}"
+            else:
+                traffic = {k: v.get("hbm_bytes_per_launch") for k, v in tj.get("kernels", {}).items()}
+        else:
+            traffic_note = "profiles/pmc_traffic.json not found"
+        for o in ops:
+            o["roof"] = launch_roofline(o, args.dtype, traffic.get(o["name"]))
+        dom = max(ops, key=lambda o: o["ms"])
+        dr = dom["roof"]
+        bytes_sum = sum(o["algorithmic_bytes"] for o in ops) / args.batch
         bpf = BYTES_PER_FRAME[args.res] // (2 if args.dtype == "f16" else 1)
-        chain_achieved = args.batch * bpf / (fwd_ms * 1e-3) / 1e9
+        total_traffic = sum(traffic.get(o["name"], 0) or 0 for o in ops) if traffic else None
+        if args.dtype == "f16":
+            chain_floor = sum(max(o["mfma_flops"] / (F16_MFMA_PEAK_TF * 1e12), o["valu_flops"] / (FP32_PEAK_TF * 1e12)) for o in ops)
+        else:
+            chain_floor = sum(o["flops"] for o in ops) / (FP32_PEAK_TF * 1e12)
+        roofline = {"bound": dr["bound"], "kernel": dom["name"], "launch_ms": round(dom["ms"], 4),
+                    "share_of_forward": round(dom["ms"] / chain_ms, 4), "traffic": traffic.get(dom["name"]),
+                    "compute": {"achieved": round(dr["achieved_tf"], 2), "peak": dr["peak_tf"], "unit": "TFLOP/s",
+                                "frac": round(dr["compute_frac"], 4),
+                                "pipe": ("fp16 MFMA" if args.dtype == "f16" and dr["on_mfma"] else
+                                         "fp32 issue: MFMA f32 + VALU share 64 FLOP/clk/SIMD" if args.dtype == "f32" else "fp32 VALU"),
+                                "mfma_flops_per_launch": int(dom["mfma_flops"]), "valu_flops_per_launch": int(dom["valu_flops"])},
+                    "hbm": {"achieved": None if dr["hbm_gbs"] is None else round(dr["hbm_gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": None if dr["hbm_frac"] is None else round(dr["hbm_frac"], 4)},
+                    # NOT a roofline: what the layers of this launch would move if every conv read its input and wrote its
+                    # output through HBM, over the fused launch's time; > 1.0 by construction for a fused plan
+                    "layer_granular_equiv": {"algorithmic_bytes_per_launch": int(dom["algorithmic_bytes"]),
+                                             "GBps_equiv": round(dom["algorithmic_bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
+                                             "over_hbm_peak": round(dom["algorithmic_bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+        if dr["bound"] == "hbm":
+            roofline.update(achieved=roofline["hbm"]["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=roofline["hbm"]["frac"])
+        else:
+            roofline.update(achieved=roofline["compute"]["achieved"], peak=dr["peak_tf"], unit="TFLOP/s", frac=roofline["compute"]["frac"])
+        if traffic_note:
+            roofline["traffic_note"] = traffic_note
         out = {
             "metric": "frames/sec end-to-end (model forward + decode + per-class NMS), 320x256 batch=256 per GPU"
                       if args.res == 256 else "frames/sec end-to-end, 640x512",
@@ -218,23 +339,25 @@ def main():
                                    f"YOLO-Fastest {W}x{H} batch={args.batch} {args.dtype} per GPU, {args.frames} frames"
                                    + (", dense synthetic head logits (SURVEY.md 8(d) config 5)" if args.dense else ""),
                        "global_batch": n_total, "weights": wname, "kmax": args.kmax, "chunk": args.chunk, "lanes": args.lanes,
+                       "world_size": world,
                        "parallelism": f"dp{world} (frames sharded, one RCCL all-gather of box records)" if world > 1 else "single GPU",
                        "survivors_per_frame_mean": round(float(np.clip(counts, 0, None).mean()), 3)},
-            # dominant kernel of the forward pass: algorithmic (layer-granular) bytes of ITS layers per launch
-            # over ITS average launch duration
-            "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "launch_ms": round(dom["ms"], 4), "algorithmic_bytes_per_launch": int(dom["algorithmic_bytes"]),
-                         "compute_frac_fp32_peak": round(dom["flops"] / (dom["ms"] * 1e-3) / 157.3e12, 4),
-                         "share_of_forward": round(dom["ms"] / chain_ms, 4)},
-            # the whole forward pass (all launches) against the same definition
+            "roofline": roofline,
+            # the whole forward pass (all launches)
             "forward_chain": {"launches": len(ops), "forward_ms": round(fwd_ms, 4), "post_ms": round(post_ms, 4),
                               "sum_of_launch_ms_single_stream": round(chain_ms, 4),
-                              "algorithmic_bytes_per_frame": bpf,
-                              "algorithmic_bytes_per_frame_sum_over_launches": int(bytes_sum),
-                              "achieved_GBps": round(chain_achieved, 1), "frac_of_hbm_peak": round(chain_achieved / HBM_PEAK_GBS, 4),
-                              "compute_frac_fp32_peak": round(args.batch * FLOPS_PER_FRAME[args.res] / (fwd_ms * 1e-3) / 157.3e12, 4),
-                              "top_launches": [{"name": o["name"], "ms": round(o["ms"], 4)} for o in sorted(ops, key=lambda o: -o["ms"])[:6]]},
+                              "compute_frac": round(chain_floor / (fwd_ms * 1e-3), 4),
+                              "hbm_traffic_bytes": total_traffic,
+                              "hbm_GBps": None if not total_traffic else round(total_traffic / (fwd_ms * 1e-3) / 1e9, 1),
+                              "hbm_frac": None if not total_traffic else round(total_traffic / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "layer_granular_equiv": {"algorithmic_bytes_per_frame": bpf,
+                                                       "algorithmic_bytes_per_frame_sum_over_launches": int(bytes_sum),
+                                                       "GBps_equiv": round(args.batch * bpf / (fwd_ms * 1e-3) / 1e9, 1),
+                                                       "over_hbm_peak": round(args.batch * bpf / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                              "per_launch": [{"name": o["name"] if len(o["name"]) < 48 else o["name"][:20] + ".." + o["name"][-24:],
+                                              "ms": round(o["ms"], 4), "bound": o["roof"]["bound"], "frac": round(o["roof"]["frac"], 3),
+                                              "hbm_GBps": None if o["roof"]["hbm_gbs"] is None else round(o["roof"]["hbm_gbs"])}
+                                             for o in ops]},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -145,6 +145,10 @@ int yf_forward_u8(yf_handle h, const uint8_t *d_u8, int N, int src_h, int src_w,
 /* Name ("conv1_8+conv1_9+conv2_1"), layer-granular algorithmic bytes and flops per frame of launch `op` of the
  * current plan (each conv of the op reads its input and writes its output once, + residual read: SURVEY.md 8d). */
 int yf_op_info(yf_handle h, int op, char *name, int name_len, double *algorithmic_bytes_per_frame, double *flops_per_frame);
+/* The same with the flops split by the pipe they run on in this plan: matrix cores (pointwise / dense / deconv layers of the
+ * MFMA kernels) and vector ALU (depthwise convs, the small-channel VALU block kernels).  bench.py prices each against its peak. */
+int yf_op_info_ex(yf_handle h, int op, char *name, int name_len, double *algorithmic_bytes_per_frame, double *mfma_flops_per_frame,
+                  double *valu_flops_per_frame);
 /* One forward pass (whole batch in one pass) with a HIP event recorded on `stream` around every launch; blocks until
  * the pass is done and returns each launch's duration in ms in op_ms[yf_num_launches]. */
 int yf_profile_forward(yf_handle h, const float *d_x, int N, void *d_workspace, size_t workspace_bytes, void *stream,

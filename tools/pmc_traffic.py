@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
 """HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over `bench.py --lanes 1`.
 
-  tools/pmc_traffic.py <ops.json> <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
+  tools/pmc_traffic.py <ops.json> <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [source_hash.txt] [res batch dtype]
+
+The output is stamped with the hash of the kernel sources the profiled build was made from (bench.source_hash(), written on the
+GPU box by tools/refresh_profiles.sh) and with the workload; bench.py reports `roofline.traffic` from it only when both match.
 
 Units and corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB of 64-B fabric requests;
 on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read (16 B/lane), so it is
 doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores.  Launches of one forward pass are matched to the
 plan's ops by order (single lane => deterministic order)."""
-import csv, json, sys
+import csv, json, os, subprocess, sys
 
 ops = json.load(open(sys.argv[1]))
 n = len(ops)
@@ -27,7 +30,14 @@ def per_op(path, counter):
 
 fetch, knames, p1 = per_op(sys.argv[2], "FETCH_SIZE")
 write, _, p2 = per_op(sys.argv[3], "WRITE_SIZE")
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --lanes 1, batch 256, 320x256",
+src_hash = open(sys.argv[5]).read().strip() if len(sys.argv) > 5 else None
+wl = {"res": int(sys.argv[6]), "batch": int(sys.argv[7]), "dtype": sys.argv[8]} if len(sys.argv) > 8 else {"res": 256, "batch": 256, "dtype": "f32"}
+try:
+    commit = subprocess.check_output(["git", "-C", os.path.dirname(os.path.abspath(__file__)), "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    commit = None
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --lanes 1",
+       "source_hash": src_hash, "workload": wl, "git_head_when_processed": commit,
        "corrections": "bytes = FETCH_SIZE*1024*2 (gfx950 half-count of wide streaming reads) + WRITE_SIZE*1024",
        "passes_averaged": [p1, p2], "kernels": {}, "forward_total_hbm_bytes": 0.0, "forward_total_algorithmic_bytes": 0.0}
 for i, o in enumerate(ops):

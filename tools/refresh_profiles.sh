@@ -5,6 +5,7 @@
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r01}
+python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.source_hash())" > $R/gpurun_out/${TAG}_source_hash.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_default -o d --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof_default.log 2>&1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_lanes1 -o l --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --lanes 1 > $R/gpurun_out/prof_lanes1.log 2>&1

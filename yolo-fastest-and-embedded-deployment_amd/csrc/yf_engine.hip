@@ -839,12 +839,24 @@ static size_t layer_io_elems(const LayerSpec& L, size_t in_px, size_t out_px) { 
 
 int yf_op_info(yf_handle h, int op, char* name, int name_len, double* algorithmic_bytes_per_frame, double* flops_per_frame)
 {
+    double mfma = 0, valu = 0;
+    int rc = yf_op_info_ex(h, op, name, name_len, algorithmic_bytes_per_frame, &mfma, &valu);
+    if (rc == YF_OK && flops_per_frame) *flops_per_frame = mfma + valu;
+    return rc;
+}
+
+int yf_op_info_ex(yf_handle h, int op, char* name, int name_len, double* algorithmic_bytes_per_frame, double* mfma_flops_per_frame,
+                  double* valu_flops_per_frame)
+{
     if (!h || op < 0 || op >= (int)h->plan().ops.size()) return fail(YF_E_INVALID, "bad op index");
     const Plan& P = h->plan();
     const Op& o = P.ops[op];
     const Tensor &ti = P.tensors[o.in1], &to = P.tensors[o.out];
     std::string nm;
-    double elems = 0, macs = 0;
+    double elems = 0, macs_mfma = 0, macs_valu = 0;
+    // which pipe a layer's MACs run on in THIS plan: depthwise convs and everything inside the VALU block kernels are vector
+    // FMAs; the pointwise / dense / deconv layers of the k19m, mres, mdw and pw_mfma / pw_ws kernels are MFMAs
+    const bool op_mfma = o.type == OP_K19 || o.type == OP_MRES || o.type == OP_MDW || (o.type == OP_LAYER && o.mfma_off >= 0);
     auto add = [&](int li, size_t in_px, size_t out_px, bool res) {
         if (li < 0) return;
         const LayerSpec& L = kLayers[li];
@@ -852,7 +864,8 @@ int yf_op_info(yf_handle h, int op, char* name, int name_len, double* algorithmi
         nm += L.name;
         elems += (double)layer_io_elems(L, in_px, out_px) + (res ? (double)out_px * L.cout : 0.0);
         const double k2 = L.kind == K_DECONV ? 1.0 : (double)L.k * L.k;  // deconv 2x2 s2: each output pixel sees one tap
-        macs += (L.kind == K_DW ? (double)out_px * L.cout * k2 : (double)out_px * L.cout * L.cin * k2);
+        const double m = (L.kind == K_DW ? (double)out_px * L.cout * k2 : (double)out_px * L.cout * L.cin * k2);
+        if (op_mfma && L.kind != K_DW) macs_mfma += m; else macs_valu += m;
     };
     const size_t ipx = (size_t)ti.H * ti.W, opx = (size_t)to.H * to.W;
     if (o.type == OP_FUSED_BLOCK || o.type == OP_MRES) {
@@ -870,7 +883,8 @@ int yf_op_info(yf_handle h, int op, char* name, int name_len, double* algorithmi
     }
     if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s", nm.c_str());
     if (algorithmic_bytes_per_frame) *algorithmic_bytes_per_frame = elems * (double)h->esz();
-    if (flops_per_frame) *flops_per_frame = macs * 2.0;
+    if (mfma_flops_per_frame) *mfma_flops_per_frame = macs_mfma * 2.0;
+    if (valu_flops_per_frame) *valu_flops_per_frame = macs_valu * 2.0;
     return YF_OK;
 }
 

@@ -222,7 +222,8 @@ class YoloFastest(nn.Module):
 
     def profile(self, x, reps=5):
         """Per-launch timing of one forward pass (HIP events on the launch stream around every kernel).
-        Returns a list of dicts: name, ms (mean over reps), algorithmic_bytes, flops -- for the whole batch."""
+        Returns a list of dicts: name, ms (mean over reps), algorithmic_bytes, flops (= mfma_flops + valu_flops, by the pipe
+        the layer runs on in this plan) -- for the whole batch."""
         x = x.contiguous().float()
         N, _, H, W = x.shape
         e = self.engine(H, W, N, x.device)
@@ -240,9 +241,10 @@ class YoloFastest(nn.Module):
         out = []
         for i in range(n.value):
             name = ctypes.create_string_buffer(512)
-            b, f = ctypes.c_double(), ctypes.c_double()
-            _lib.check(e.lib.yf_op_info(e.handle, i, name, 512, ctypes.byref(b), ctypes.byref(f)))
-            out.append(dict(name=name.value.decode(), ms=acc[i], algorithmic_bytes=b.value * N, flops=f.value * N))
+            b, fm, fv = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+            _lib.check(e.lib.yf_op_info_ex(e.handle, i, name, 512, ctypes.byref(b), ctypes.byref(fm), ctypes.byref(fv)))
+            out.append(dict(name=name.value.decode(), ms=acc[i], algorithmic_bytes=b.value * N, flops=(fm.value + fv.value) * N,
+                            mfma_flops=fm.value * N, valu_flops=fv.value * N))
         return out
 
     def probe(self, x, name):
