@@ -175,7 +175,7 @@ def main():
     torch.manual_seed(0)
     for res in (256, 512):
         model, io = load_model(res)
-        names = files if res == 256 else [files[i] for i in (0, 3, 7, 11, 14, 19)]  # 14 = noCloud_2m_4359 (no targets)
+        names = files  # all 20 bundled frames at both sizes (frame 14 = noCloud_2m_4359: no targets at 512x640)
         u8 = np.stack([preprocess_u8(os.path.join(REF, "test_data", f), res) for f in names])
         hl_all, hs_all, cands, finals, adjs = [], [], [], [], []
         with torch.no_grad():
@@ -346,10 +346,51 @@ def main_map():
           "TP", [int(out[f"match_tp_{c}"].sum()) for c in range(3)])
 
 
+def main_results():
+    """Result-writer goldens (detect.py:176-192): what the reference's own detect.py run left under
+    test_result/<size>/<laptop cpu (python)>_test_result/ -- DATA of the reference, not source:
+      * from cpu-test.log: per image, whether the line says 'detect finished' or 'no targets' (+ the logged average time);
+      * from the result_<name>.jpg images: the RGB value at the midpoint of each edge of every box the goldens predict
+        (adj_box of golden_<size>.npz), i.e. where plot_one_box drew the class-coloured frame, plus one pixel 12 px INSIDE
+        the frame (background) -- ties the golden boxes and the class colours to the reference's real output images."""
+    import re
+    from PIL import Image
+    out = {}
+    for res, sub in ((256, "256x320"), (512, "512x640")):
+        d = [x for x in os.listdir(os.path.join(REF, "test_result", sub)) if "cpu" in x][0]
+        d = os.path.join(REF, "test_result", sub, d)
+        log = open(os.path.join(d, "cpu-test.log"), "rb").read().decode("latin-1")
+        rows = re.findall(r"image_name:(\S+) -> (detect finished|no targets), infer time:([0-9.]+)ms, post_process time:([0-9.]+)ms, "
+                          r"total time:([0-9.]+)ms", log)
+        avg = float(re.search(r"detect avg_time: ([0-9.]+)ms", log).group(1))
+        g = np.load(os.path.join(HERE, f"golden_{res}.npz"))
+        names = [str(n) for n in g["names"]]
+        assert [r[0] for r in rows] == names, "log order == sorted test_data order"
+        flags = np.array([r[1] == "detect finished" for r in rows], np.bool_)
+        assert flags.tolist() == [bool(c > 0) for c in g["adj_count"]], "the goldens reproduce the reference's logged flags"
+        edge = np.zeros((len(names), 16, 5, 3), np.uint8)
+        for f, n in enumerate(names):
+            im = np.asarray(Image.open(os.path.join(d, "result_" + n)).convert("RGB"))
+            assert im.shape == (512, 640, 3)
+            for k in range(int(g["adj_count"][f])):
+                x1, y1, x2, y2 = [int(v) for v in g["adj_box"][f, k]]
+                pts = [((x1 + x2) // 2, y1), ((x1 + x2) // 2, y2), (x1, (y1 + y2) // 2), (x2, (y1 + y2) // 2),
+                       (min(x1 + 12, (x1 + x2) // 2), (y1 + y2) // 2)]
+                for j, (x, y) in enumerate(pts):
+                    edge[f, k, j] = im[min(max(y, 0), 511), min(max(x, 0), 639)]
+        out[f"names_{res}"] = np.array(names); out[f"finished_{res}"] = flags; out[f"avg_time_ms_{res}"] = np.float64(avg)
+        out[f"edge_rgb_{res}"] = edge
+        print(res, "logged flags", flags.astype(int).tolist(), "avg", avg)
+    np.savez_compressed(os.path.join(HERE, "golden_results.npz"), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "map":
         main_map()
+    elif len(sys.argv) > 1 and sys.argv[1] == "results":
+        main_results()
     else:
         main()
         main_val()
         main_map()
+        main_results()

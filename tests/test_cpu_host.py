@@ -268,3 +268,49 @@ def test_bench_roofline_arithmetic():
     assert r["bound"] in ("mfma", "valu") and r["compute_frac"] <= 1.0
     assert abs(r["compute_frac"] - max(12e9 / 2.5e15, 3.73e9 / 157.3e12) / 1e-4) < 1e-9
     assert len(b.source_hash()) == 16
+
+
+CLASS_RGB = {0: (205, 90, 106), 1: (20, 97, 199), 2: (105, 128, 112)}   # detect.py:105 colours are BGR (cv2); these are what a viewer sees
+
+
+def test_reference_result_images_carry_the_golden_boxes(golden):
+    """SURVEY.md 8(f).3 pin: tests/golden/golden_results.npz holds pixels sampled from the reference's OWN result images
+    (test_result/*/<laptop cpu>_test_result/result_*.jpg) at the edge midpoints of the boxes the goldens predict: every one
+    has its class colour there (JPEG tolerance), for all 20 frames x both checkpoints; and the logged has-target flags are the
+    goldens' (make_golden.py main_results asserts that when it builds the file)."""
+    r = golden("golden_results")
+    for res in (256, 512):
+        g = golden(f"golden_{res}")
+        assert [str(n) for n in r[f"names_{res}"]] == [str(n) for n in g["names"]]
+        assert r[f"finished_{res}"].tolist() == [bool(c) for c in g["adj_count"]]
+        nbox = 0
+        for f in range(20):
+            for k in range(int(g["adj_count"][f])):
+                want = np.array(CLASS_RGB[int(g["adj_cls"][f, k])], np.int32)
+                for j in range(4):
+                    assert np.abs(r[f"edge_rgb_{res}"][f, k, j].astype(np.int32) - want).max() <= 40, (res, f, k, j)
+                nbox += 1
+        assert nbox >= 25
+    assert not r["finished_512"][14] and r["finished_256"].all()
+
+
+def test_plot_one_box_geometry():
+    """plot.plot_one_box (general.py:56-67 without cv2): a frame of width `line_thickness` centred on the box edges in the class
+    colour (as a viewer sees the reference's BGR colour), a filled label box above the top-left corner, nothing elsewhere."""
+    from yolo_fastest_amd.plot import plot_one_box
+    img = np.zeros((120, 200, 3), np.uint8)
+    out = plot_one_box([40, 50, 120, 90], img, color=[106, 90, 205], label="carrier 0.63", line_thickness=3)
+    assert out is img
+    rgb = (205, 90, 106)
+    for (x, y) in ((80, 50), (80, 90), (40, 70), (120, 70), (80, 49), (80, 51), (39, 70), (121, 70)):
+        assert tuple(img[y, x]) == rgb, (x, y, img[y, x])
+    for (x, y) in ((80, 70), (80, 47 + 60), (37, 70), (123, 70), (150, 20)):
+        assert tuple(img[y, x]) == (0, 0, 0), (x, y)
+    lab = img[50 - 3 - 13:50 - 1, 40:60].astype(np.int32)     # label box: from c1 upwards, th = round(22 * 3/5) = 13
+    lo, hi = np.minimum(rgb, (255, 255, 225)), np.maximum(rgb, (255, 255, 225))   # anti-aliased text: box colour .. text colour
+    assert ((lab >= lo - 1) & (lab <= hi + 1)).all() and tuple(lab[0, 0]) == rgb
+    assert (img.astype(np.int32).sum(-1) > 600).sum() > 20     # some (near-)text-coloured pixels: [225, 255, 255] BGR
+    # no label, default thickness round(0.002 * (h + w) / 2) + 1 = 1
+    img2 = np.zeros((120, 200, 3), np.uint8)
+    plot_one_box([10, 10, 30, 30], img2, color=[0, 0, 255])
+    assert tuple(img2[10, 20]) == (255, 0, 0) and tuple(img2[11, 20]) == (0, 0, 0)

@@ -654,10 +654,14 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
     for (int l = 0; l < 3; ++l) {
         if (hipStreamCreateWithFlags(&e->side[l], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_join[l], hipEventDisableTiming) != hipSuccess) {
+            (void)yf_destroy(e);  // frees the weights, whatever streams / events exist so far, and the engine
             return fail(YF_E_HIP, "hipStreamCreate/hipEventCreate failed");
         }
     }
-    if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(YF_E_HIP, "hipEventCreate failed");
+    if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) {
+        (void)yf_destroy(e);
+        return fail(YF_E_HIP, "hipEventCreate failed");
+    }
     *out = e;
     return YF_OK;
 }

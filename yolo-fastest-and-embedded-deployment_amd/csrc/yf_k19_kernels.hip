@@ -390,17 +390,16 @@ size_t k19m_lds_bytes(int dtype)
 
 int launch_k19m(K19Args a, int N, hipStream_t s, int dtype)
 {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-            return -1;
+    const int dev = current_device(), n_cu = device_cu_count(dev);
+    if (n_cu <= 0) return -1;
+    static bool attr_done[YF_MAX_DEVICES] = {};
+    if (!attr_done[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k19m_kernel<float, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)k19m_lds_bytes(DT_F32)) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k19m_kernel<half_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)k19m_lds_bytes(DT_F16)) != hipSuccess)
             return -1;
-        n_cu = v;
+        attr_done[dev] = true;
     }
     a.tiles_y = (a.Ho + TH - 1) / TH;
     a.tiles_x = (a.Wo + TW - 1) / TW;

@@ -36,6 +36,26 @@ template <typename T> __device__ __forceinline__ float ld1(const T* p) { return 
 template <typename T> __device__ __forceinline__ void st1(T* p, float v) { *p = (T)v; }
 #endif
 
+// hipFuncSetAttribute (dynamic LDS above 64 KiB) and the CU count belong to (kernel, DEVICE), not to the process: launchers keep
+// their "done once" state per device so that a second GPU in the same process gets the attribute too.
+enum { YF_MAX_DEVICES = 64 };
+inline int current_device()
+{
+    int d = -1;
+    return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < YF_MAX_DEVICES) ? d : -1;
+}
+inline int device_cu_count(int dev)   // cached per device; <= 0 on failure
+{
+    static int n[YF_MAX_DEVICES] = {};
+    if (dev < 0) return -1;
+    if (n[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return -1;
+        n[dev] = v;
+    }
+    return n[dev];
+}
+
 struct PwArgs {
     const float* in1;  // NHWC [npix, CIN1]
     const float* in2;  // NHWC [npix, CIN2] (second half of a channel concat) or null

@@ -290,12 +290,14 @@ static int launch_mdw_t(MdwArgs a, int Nf, hipStream_t s)
     constexpr int NRP = (TH + 4) * (TW + 4);
     constexpr size_t lds = ((size_t)16 * mdw_epl(TH, TW, NWAVE) + mdw_stream_floats(C, N, HEADN, sizeof(T) == 2)) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
-    static bool attr_done = false;
-    if (lds > 64 * 1024 && !attr_done) {
+    static bool attr_done[YF_MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (dev < 0) return -2;
+    if (lds > 64 * 1024 && !attr_done[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(mdw_kernel<C, N, HEADN, TH, TW, NWAVE, T>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
-        attr_done = true;
+        attr_done[dev] = true;
     }
     hipLaunchKernelGGL((mdw_kernel<C, N, HEADN, TH, TW, NWAVE, T>), dim3((unsigned)(Nf * a.tiles_y * a.tiles_x)), dim3(NWAVE * 64),
                        lds, s, a);

@@ -327,13 +327,8 @@ static int launch_ws(const PwArgs& a, hipStream_t s)
 {
     constexpr int NU = ((N + 15) / 16) * (OMODE == 2 ? 4 : 1), NUG = (NU + UPW - 1) / UPW;
     static_assert((NUG * RS) % 4 == 0 && NUG * RS <= 16, "whole waves per SIMD");
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-            return -2;
-        n_cu = v;
-    }
+    const int n_cu = device_cu_count(current_device());
+    if (n_cu <= 0) return -2;
     const long ntiles = (a.npix + 15) / 16, streams = (ntiles + RS - 1) / RS;
     // persistent grid: every workgroup gets the same number of row tiles (no ragged last round)
     const long cap = (long)n_cu * WPC, rounds = (streams + cap - 1) / cap, grid = (streams + rounds - 1) / rounds;

@@ -642,12 +642,14 @@ static int launch_mres_pc_t(MresArgs a, int N, hipStream_t s)
     constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 2 * 16 * mres_epl(MTR) +
                             ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT, sizeof(T) == 2) + COUT + 3) & ~3)) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
-    static bool attr_done = false;
-    if (lds > 64 * 1024 && !attr_done) {
+    static bool attr_done[YF_MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (dev < 0) return -2;
+    if (lds > 64 * 1024 && !attr_done[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, T>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
-        attr_done = true;
+        attr_done[dev] = true;
     }
     if (a.nblk > 1 && (a.tiles_y != 1 || a.tiles_x != 1 || !RES)) return -4;  // a chain needs tile == frame
     hipLaunchKernelGGL((mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, T>), dim3((unsigned)(N * a.tiles_y * a.tiles_x)),
@@ -666,12 +668,14 @@ static int launch_mres_t(MresArgs a, int N, hipStream_t s)
     constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 16 * mres_epl(MTR, S) +
                             ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT, sizeof(T) == 2) + COUT + 3) & ~3)) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
-    static bool attr_done = false;
-    if (lds > 64 * 1024 && !attr_done) {
+    static bool attr_done[YF_MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (dev < 0) return -2;
+    if (lds > 64 * 1024 && !attr_done[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(mres_kernel<CIN, CEXP, COUT, RES, S, TH, TW, NWAVE, T>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
-        attr_done = true;
+        attr_done[dev] = true;
     }
     hipLaunchKernelGGL((mres_kernel<CIN, CEXP, COUT, RES, S, TH, TW, NWAVE, T>), dim3((unsigned)(N * a.tiles_y * a.tiles_x)),
                        dim3(NWAVE * 64), lds, s, a);

@@ -488,11 +488,13 @@ int launch_val_nms(const float* pred, int N, int M, float conf_thres, float nms_
     if (M > 8191) return -1;
     int mp = pow2_at_least(M);
     size_t lds = (size_t)mp * 8 + (size_t)M * 3 + 16;
-    static size_t attr_set = 0;
-    if (lds > 48 * 1024 && lds > attr_set) {
+    static size_t attr_set[YF_MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (dev < 0) return -2;
+    if (lds > 48 * 1024 && lds > attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(val_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
-        attr_set = lds;
+        attr_set[dev] = lds;
     }
     hipLaunchKernelGGL(val_nms_kernel, dim3(N), dim3(POST_THREADS), lds, s, pred, M, mp, conf_thres, nms_thres, kmax, det, counts);
     return 0;
@@ -517,12 +519,14 @@ int launch_post(const PostArgs& a, int N, hipStream_t s)
     if (ncell > 8191) return -1;  // 13-bit cell field of the sort key
     size_t lds = post_lds_bytes(ncell);
     if (lds > 160 * 1024 - 64) return -1;  // + 28 B of static LDS
-    static size_t attr_set = 0;
-    if (lds > attr_set) {
+    static size_t attr_set[YF_MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (dev < 0) return -2;
+    if (lds > attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(post_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return -2;
-        attr_set = lds;
+        attr_set[dev] = lds;
     }
     hipLaunchKernelGGL(post_kernel, dim3(N), dim3(POST_THREADS), lds, s, a, ncell, pow2_at_least(ncell));
     return 0;

@@ -7,7 +7,8 @@ Same constructor and `batch_detect(data_path, result_path)`; one log line per im
     image decode uses PIL (this image has no cv2);
   * model + post-process are stream-ordered launches (yf_forward, yf_decode_nms); times in the log are
     per-batch wall times divided by the batch size.
-Drawing (`plot_one_box`, :185-188) is SURVEY.md 8(f).3 "next" and is reduced to rectangle outlines.
+Result writer: `result_<name>` images with the reference's boxes and labels (`plot.plot_one_box`, the
+reference's general.py:56-67 without cv2) and the reference's log lines; `self.last_labels` keeps the label strings per image.
 """
 import ctypes
 import os
@@ -18,6 +19,7 @@ import torch
 
 from . import _lib
 from .model import YoloFastest
+from .plot import plot_one_box
 from .post_process import YOLO_post_process
 
 
@@ -72,9 +74,10 @@ class Detect_YOLO():
         return self.post_process.detect(pred, kmax=kmax, origin_shape=origin)
 
     def batch_detect(self, data_path, result_path, batch_size=256):
-        img_list = sorted(os.listdir(data_path))
+        img_list = sorted(os.listdir(data_path))   # the reference iterates os.listdir order; its logs show it sorted
         num = len(img_list)
         avg_time = 0.0
+        self.last_labels = {}
         for b0 in range(0, num, batch_size):
             names = img_list[b0:b0 + batch_size]
             grays, oris = zip(*[self._read_gray(os.path.join(data_path, n)) for n in names])
@@ -96,23 +99,25 @@ class Detect_YOLO():
             avg_time += total_time * len(names)
             for filename, ori, boxes in zip(names, oris, results):
                 if len(boxes) == 0:
-                    self._save(os.path.join(result_path, "result_" + filename), ori, [])
+                    self.last_labels[filename] = self._save(os.path.join(result_path, "result_" + filename), ori, [])
                     self.logger.info("image_name:%s -> no targets, infer time:%.2fms, post_process time:%.2fms, "
                                      "total time:%.2fms" % (filename, infer_time, post_process_time, total_time))
                     continue
-                self._save(os.path.join(result_path, "result_" + filename), ori, boxes)
+                self.last_labels[filename] = self._save(os.path.join(result_path, "result_" + filename), ori, boxes)
                 self.logger.info("image_name:%s -> detect finished, infer time:%.2fms, post_process time:%.2fms, "
                                  "total time:%.2fms" % (filename, infer_time, post_process_time, total_time))
         self.logger.info("detect avg_time: %.2fms" % (avg_time / max(num, 1)))
 
     def _save(self, path, ori, boxes):
-        if path is None or not os.path.isdir(os.path.dirname(path)):
-            return
-        from PIL import Image, ImageDraw
-        im = Image.fromarray(ori)
-        d = ImageDraw.Draw(im)
+        """detect.py:184-190: one box + label per detection (plot.plot_one_box), then the image file.  Returns the label
+        strings it drew ('%s %.2f' % (class name, conf * cls_score), :186)."""
+        img = np.ascontiguousarray(ori).copy()
+        labels = []
         for *xyxy, conf, cls_score, cls_pred in boxes:
-            d.rectangle([xyxy[0], xyxy[1], xyxy[2], xyxy[3]], outline=tuple(self.colors[int(cls_pred)]), width=3)
-            d.text((xyxy[0], max(0, xyxy[1] - 12)), "%s %.2f" % (self.class_names[int(cls_pred)], conf * cls_score),
-                   fill=tuple(self.colors[int(cls_pred)]))
-        im.save(path)
+            label = '%s %.2f' % (self.class_names[int(cls_pred)], conf * cls_score)
+            plot_one_box(xyxy, img, label=label, color=self.colors[int(cls_pred)], line_thickness=3)
+            labels.append(label)
+        if path is not None and os.path.isdir(os.path.dirname(path)):
+            from PIL import Image
+            Image.fromarray(img).save(path, quality=95)   # cv2.imwrite's default JPEG quality
+        return labels

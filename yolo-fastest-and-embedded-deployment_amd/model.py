@@ -44,6 +44,7 @@ class _Engine:
         self.dtype = dtype
         self.H, self.W, self.max_batch, self.device_index = H, W, max_batch, device_index
         self._ws = None
+        self.chunk, self.lanes = 0, 2     # the C side's defaults (yf_engine: chunk 0, lanes 2)
 
     def workspace(self, N, device):
         need = ctypes.c_size_t()
@@ -54,10 +55,12 @@ class _Engine:
 
     def set_chunk(self, frames):
         _lib.check(self.lib.yf_set_chunk(self.handle, int(frames)))
+        self.chunk = int(frames)
         self._ws = None
 
     def set_lanes(self, lanes):
         _lib.check(self.lib.yf_set_lanes(self.handle, int(lanes)))
+        self.lanes = int(lanes)
         self._ws = None
 
     def set_fusion(self, level):
@@ -172,12 +175,23 @@ class YoloFastest(nn.Module):
                 self._blob = packer.pack_state_dict(self.state_dict(), self.num_out, self.input_channel,
                                                     self.num_anchors, self.num_cls)
             e = _Engine(self._blob, H, W, max(N, 256), key[2], key[3])
-            if self.chunk:
-                e.set_chunk(self.chunk)
-            e.set_lanes(self.lanes)
             self._engines[key] = e
+        # the knobs are re-applied on every call, so changing model.chunk / .lanes / .fusion after an engine exists takes effect
+        if e.chunk != self.chunk:
+            e.set_chunk(self.chunk)
+        if e.lanes != self.lanes:
+            e.set_lanes(self.lanes)
         e.set_fusion(self.fusion)
         return e
+
+    def engine_on(self, device):
+        """Some engine of this model on `device` (for the size-agnostic entry points: yf_nms_sorted, yf_val_nms); one is created
+        at the smallest legal input size if the model has not run there yet."""
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        for (H, W, d, dt), e in self._engines.items():
+            if d == idx and dt == self._dtype_code():
+                return e
+        return self.engine(32, 32, 1, torch.device("cuda", idx))
 
     # -- forward --------------------------------------------------------------------------------
     def forward(self, x):

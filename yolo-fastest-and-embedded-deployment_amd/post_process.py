@@ -134,9 +134,12 @@ class YOLO_post_process:
         n = len(bbox_list)
         if n == 0:
             return []
-        if self._model is None or not self._model._engines:
-            raise RuntimeError("call post_process.bind(model) and run the model once first")
-        e = next(iter(self._model._engines.values()))
+        if self._model is None:
+            raise RuntimeError("call post_process.bind(model) first (the engine handle carries the device)")
+        p = next(self._model.parameters())
+        if not p.is_cuda:
+            raise RuntimeError("YOLO_post_process (HIP) has no CPU path: the bound model is not on a GPU")
+        e = self._model.engine_on(p.device)   # the bound model's device; yf_nms_sorted is size-agnostic
         dev = torch.device("cuda", e.device_index)
         boxes = torch.tensor([[int(b[0]), int(b[1]), int(b[2]), int(b[3])] for b in bbox_list], dtype=torch.int32,
                              device=dev)

@@ -1,8 +1,9 @@
 """Validation-time decode + NMS on the GPU behind the reference's own names:
   `YOLOLossV3(anchors, num_classes, input_shape, device)(input)`   src/model_training/loss/yolo_loss.py:27-141 (decode branch)
   `non_max_suppression(prediction, num_classes, conf_thres, nms_thres)`   src/model_training/utils/general.py:87-143
-Training (targets given) is out of scope and raises.  Both need the engine handle of the model that produced the heads
-(`bind(model)`), which carries H, W and the device."""
+Training (targets given) is out of scope and raises.  Both need an engine handle (it carries the device; the decode also needs
+H and W, which come from `input_shape`).  The model is passed explicitly (`model=` / `loss.model = m`); `bind(model)` sets the
+default used when none is given.  The engine is chosen by (H, W, device of the tensor) -- never "whichever exists"."""
 import ctypes
 
 import torch
@@ -13,21 +14,27 @@ _bound = {"model": None}
 
 
 def bind(model):
+    """Default model for calls that do not name one (the reference's signatures have no model argument)."""
     _bound["model"] = model
 
 
-def _engine(t, H, W):
-    m = _bound["model"]
+def _model(explicit):
+    m = explicit if explicit is not None else _bound["model"]
     if m is None:
-        raise RuntimeError("call validation.bind(model) first")
+        raise RuntimeError("pass model=... (or call validation.bind(model) first): the kernels need an engine handle")
+    return m
+
+
+def _engine(t, H, W, model=None):
     if not t.is_cuda:
         raise RuntimeError("validation path (HIP) has no CPU implementation: pass GPU tensors")
-    return m.engine(H, W, t.shape[0], t.device)
+    return _model(model).engine(H, W, t.shape[0], t.device)
 
 
 class YOLOLossV3(torch.nn.Module):
-    def __init__(self, anchors, num_classes, input_shape, device):
+    def __init__(self, anchors, num_classes, input_shape, device, model=None):
         super().__init__()
+        self.model = model          # the YoloFastest whose heads this decodes (None: validation.bind's default)
         self.anchors = anchors
         self.num_anchors = len(anchors)
         self.num_classes = num_classes
@@ -42,7 +49,10 @@ class YOLOLossV3(torch.nn.Module):
             raise NotImplementedError("the training loss is out of scope of this inference path (SURVEY.md 8f.4)")
         x = input.contiguous().float()
         bs, _, fh, fw = x.shape
-        e = _engine(x, int(self.input_shape[0]), int(self.input_shape[1]))
+        if (fh * 16, fw * 16) != (int(self.input_shape[0]), int(self.input_shape[1])) and \
+           (fh * 32, fw * 32) != (int(self.input_shape[0]), int(self.input_shape[1])):
+            raise ValueError("head of %dx%d cells does not belong to a %s input" % (fh, fw, tuple(self.input_shape[:2])))
+        e = _engine(x, int(self.input_shape[0]), int(self.input_shape[1]), self.model)
         M = 3 * fh * fw
         out = torch.empty((bs, M, self.bbox_attrs), dtype=torch.float32, device=x.device)
         anc = (ctypes.c_double * 6)(*[float(v) for a in self.anchors for v in a])
@@ -51,17 +61,16 @@ class YOLOLossV3(torch.nn.Module):
         return out
 
 
-def non_max_suppression(prediction, num_classes, conf_thres=0.5, nms_thres=0.4, kmax=None):
+def non_max_suppression(prediction, num_classes, conf_thres=0.5, nms_thres=0.4, kmax=None, model=None):
     """-> list with one [n,7] tensor (x1,y1,x2,y2,obj_conf,class_conf,class_pred) or None per image, like the reference.
     (The reference also overwrites prediction[..., :4] with the corners in place; this does not touch its input.)"""
     if num_classes != 3:
         raise NotImplementedError("3 classes")
+    if not prediction.is_cuda:
+        raise RuntimeError("validation path (HIP) has no CPU implementation: pass GPU tensors")
     p = prediction.contiguous().float()
     bs, M, _ = p.shape
-    m = _bound["model"]
-    if m is None or not m._engines:
-        raise RuntimeError("call validation.bind(model) and run the model once first")
-    e = next(iter(m._engines.values()))
+    e = _model(model).engine_on(p.device)   # yf_val_nms is size-agnostic: any engine of that model on the tensor's device
     kmax = kmax or M
     det = torch.empty((bs, kmax, 7), dtype=torch.float32, device=p.device)
     cnt = torch.empty((bs,), dtype=torch.int32, device=p.device)
@@ -163,14 +172,15 @@ class Validation:
     def get_mAP(self, model, epoch):
         self.clear()
         model.eval()
-        bind(model)
+        for loss in self.model_loss:
+            loss.model = model
         with torch.no_grad():
             for imgs, targets in self.dataloader:
                 targets = self._recover_targets(targets.float())                      # host: the bookkeeping stays on the CPU
                 imgs = imgs.to(self.device).float()
                 pred = model(imgs)
                 output = torch.cat([self.model_loss[i](p) for i, p in enumerate(pred)], 1)
-                output = non_max_suppression(output, self.num_cls, conf_thres=self.conf_thres, nms_thres=self.nms_thres)
+                output = non_max_suppression(output, self.num_cls, conf_thres=self.conf_thres, nms_thres=self.nms_thres, model=model)
                 output = [None if o is None else o.cpu() for o in output]
                 for img_id, img_pred in enumerate(output):
                     self._match_image(img_pred, targets[img_id])
