@@ -64,6 +64,10 @@ int yf_create(const void *packed_weights, size_t nbytes, int H, int W, int max_b
 /* dtype 0 = fp32 (yf_create); 1 = BASELINE configs[2]: activations stored fp16 in HBM, the pointwise GEMMs on
  * v_mfma_f32_16x16x16_f16 with fp16 weights, fp32 accumulation everywhere; depthwise / small-channel kernels compute in fp32
  * on fp16 storage.  Input x and the two head tensors stay fp32.  (model.half() selects it from Python.) */
+/* dtype 2 = fp32 storage everywhere (HBM and LDS: the residual trunk is never rounded), the pointwise GEMMs on the fp16 matrix
+ * pipe with SPLIT operands: every MFMA operand a is carried as two fp16 halves hi = rne(a), lo = rne(a - hi) (22 bits) and a k-group
+ * issues w_lo*a_hi + w_hi*a_lo + w_hi*a_hi into the fp32 accumulator.  As accurate as dtype 0 (same distance from the graph in fp64);
+ * the accuracy answer to BASELINE configs[2]'s "2e-2 on logits", which single fp16 operands cannot meet (weights alone: 4.5e-2). */
 int yf_create_ex(const void *packed_weights, size_t nbytes, int H, int W, int max_batch, int device, int dtype, yf_handle *out);
 /* The fp32 -> fp16 rounding (nearest even) the weight packer uses on the host. */
 uint16_t yf_f32_to_f16_bits(float f);
@@ -149,6 +153,9 @@ int yf_op_info(yf_handle h, int op, char *name, int name_len, double *algorithmi
  * MFMA kernels) and vector ALU (depthwise convs, the small-channel VALU block kernels).  bench.py prices each against its peak. */
 int yf_op_info_ex(yf_handle h, int op, char *name, int name_len, double *algorithmic_bytes_per_frame, double *mfma_flops_per_frame,
                   double *valu_flops_per_frame);
+/* Arithmetic the kernel of launch `op` runs in: 0 fp32, 1 fp16 storage + fp16 MFMA, 2 fp32 storage + split-operand fp16 MFMA (a
+ * dtype-2 engine runs the launches that have no split-operand kernel in exact fp32: same storage, same accuracy class). */
+int yf_op_dtype(yf_handle h, int op, int *kernel_dtype);
 /* One forward pass (whole batch in one pass) with a HIP event recorded on `stream` around every launch; blocks until
  * the pass is done and returns each launch's duration in ms in op_ms[yf_num_launches]. */
 int yf_profile_forward(yf_handle h, const float *d_x, int N, void *d_workspace, size_t workspace_bytes, void *stream,

@@ -474,7 +474,63 @@ def test_yf_detect_single_call_equals_two_calls(models, golden, dev):
             assert torch.equal(a[key][f, :k], c[key][f, :k]), key
 
 
-# ---- BASELINE configs[2]: fp16 storage + fp16 MFMA pointwise path (parity target: 2e-2 on logits vs the fp32 reference) ----
+# ---- BASELINE configs[2]: the fp16 MFMA pointwise path (parity target, SURVEY.md 8(d).3: 2e-2 on logits vs the fp32 reference) ----
+# Two variants (include/yolo_fastest_hip.h, yf_create_ex dtype):
+#   "f16x3" -- fp32 storage, every MFMA operand split into two fp16 halves (hi + lo), three fp16 MFMAs per k-group, fp32 accumulate.
+#              THIS is the variant that meets the stated 2e-2 -- by two orders of magnitude: it is held to the SAME bounds as the
+#              fp32 path (_check_heads: same accuracy class as the reference's own fp32 evaluation) and gives identical boxes.
+#   "f16"   -- fp16 storage + single fp16 operands: the fastest, and 2e-2 is NOT reachable with it (tools/fp16_sim.py: rounding the
+#              weights alone to fp16 moves the 640x512 logits by 4.5e-2, the activations by another 4e-2); its test below states
+#              the bounds it does meet.  Treat it as the throughput variant; detections on the bundled frames are still identical.
+
+
+@pytest.mark.parametrize("res", [512, 256])
+def test_f16x3_path_meets_the_fp32_bounds(yf, golden, dev, res):
+    io = yf.io_params_for(res)
+    m = yf.YoloFastest(io).to(dev).eval()
+    m.load_state_dict(torch.load(WEIGHTS[res], map_location=dev))
+    m.precision = "f16x3"
+    g = golden(f"golden_{res}")
+    with torch.no_grad():
+        hl, hs = m(_x(g["input_u8"], dev))
+    for got, ref in ((hl.cpu().numpy(), g["head_large"]), (hs.cpu().numpy(), g["head_small"])):
+        assert np.abs(got - ref).max() <= 2e-2                     # SURVEY.md 8(d).3, as stated
+    _check_heads(hl, hs, g["head_large"], g["head_small"], g["head_large_f64"], g["head_small_f64"], res == 256)   # and the fp32 path's own bounds
+    e = m.engine(res, res * 5 // 4, 20, dev)
+    kinds = [o["kernel_dtype"] for o in m.profile(_x(g["input_u8"][:2], dev), reps=1)]
+    assert kinds.count("f16x3") >= len(kinds) - 5 and "f16" not in kinds, kinds     # only the four small-channel VALU launches run fp32
+    post = yf.YOLO_post_process(io["conf_thre"], io["nms_thre"], io["num_anchors"], io["num_cls"], io["anchors"], io["input_shape"]).bind(m)
+    got = post.detect((hl, hs), with_src=True)
+    for f, L in enumerate(got):
+        n = int(g["final_count"][f])
+        assert [e[:4] for e in L] == g["final_box"][f, :n].tolist(), (res, f)
+        assert [e[7] for e in L] == g["final_src"][f, :n].tolist() and [e[6] for e in L] == g["final_cls"][f, :n].tolist()
+        assert np.allclose([e[4] for e in L], g["final_conf"][f, :n], atol=1e-4, rtol=0)
+    with torch.no_grad():
+        hl, hs = m(_x(g["syn_input_u8"], dev))
+    t = _truth64(res, g["syn_input_u8"])
+    _check_heads(hl, hs, g["syn_head_large"], g["syn_head_small"], t[0], t[1], res == 256)
+
+
+def test_f16x3_other_sizes_random_weights_and_u8(yf, dev):
+    """The split-operand kernels on partial tiles, un-chained residual blocks (sizes whose stride-16/32 frame is not one tile), a
+    random state-dict, and through the fused u8 pre-process: same bounds as the fp32 path."""
+    from oracle import backbone_oracle as bo
+    io = yf.io_params_for(256)
+    m = yf.YoloFastest(io).to(dev).eval()
+    sd = torch.load(WEIGHTS[256], map_location="cpu")
+    m.load_state_dict(sd)
+    m.precision = "f16x3"
+    g = np.random.default_rng(5)
+    for (H, W, N) in ((32, 32, 3), (64, 96, 2), (160, 224, 2), (288, 320, 2), (256, 352, 1)):
+        u8 = g.integers(0, 256, size=(N, H, W), dtype=np.uint8)
+        with torch.no_grad():
+            hl, hs = m(_x(u8, dev))
+            ul, us = m.forward_u8(torch.from_numpy(u8).to(dev), (H, W))
+        ol, os_ = bo.forward(sd, bo.preprocess(u8))
+        t = _truth64(256, u8)
+        _check_heads(hl, hs, ol, os_, t[0], t[1])
+        assert torch.equal(ul, hl) and torch.equal(us, hs)
 
 
 @pytest.mark.parametrize("res", [512, 256])
@@ -487,10 +543,11 @@ def test_fp16_path_logits_and_boxes(yf, golden, dev, res):
     with torch.no_grad():
         hl, hs = m(_x(g["input_u8"], dev))
     assert hl.dtype == torch.float32
-    # SURVEY.md 8(d) config 3 asks for "2e-2 on logits (state it)".  Stated: with fp16 storage (eps 4.9e-4 per rounding, 86
-    # layers, logits reach +-36) the measured deviation from the reference's fp32 logits is mean 1.7e-3 / p99 9e-3 / max 2.5e-2
-    # at 256x320 and mean 4.5e-3 / p99 2.3e-2 / max 8.2e-2 at 512x640 (tools/fp16_error_report.py).  The test bounds:
-    # max <= 3e-3 of the logit range, p99 <= 3e-2, mean <= 7e-3; scores within 2.5e-2 (sigmoid' <= 1/4 of the max logit deviation); detections identical.
+    # The single-operand fp16 variant: SURVEY.md 8(d).3's "2e-2 on logits" is out of its reach (see the header above; the f16x3
+    # variant meets it).  Stated instead: with fp16 storage (eps 4.9e-4 per rounding, 86 layers, logits reach +-36) the measured
+    # deviation from the reference's fp32 logits is mean 2.1e-3 / max 4.2e-2 at 256x320 and mean 5.4e-3 / p99 2.7e-2 / max 8.5e-2 at
+    # 512x640 over the 20 bundled frames (tools/x3_check.py).  The test bounds: max <= 3e-3 of the logit range, p99 <= 3e-2,
+    # mean <= 7e-3; scores within 2.5e-2 (sigmoid' <= 1/4 of the max logit deviation); detections identical.
     for got, ref in ((hl.cpu().numpy(), g["head_large"]), (hs.cpu().numpy(), g["head_small"])):
         d = np.abs(got - ref)
         assert d.max() <= 3e-3 * np.abs(ref).max(), (d.max(), np.abs(ref).max())
@@ -671,6 +728,11 @@ def test_random_weights_against_oracle(yf, dev, seed):
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     tl, ts = bo.forward(sd64, bo.preprocess(u8).double())
     _check_heads(hl, hs, ol, os_, tl.numpy(), ts.numpy(), metric_size=False)
+    m.precision = "f16x3"       # split-operand fp16 MFMA: the fp32 bounds
+    with torch.no_grad():
+        xl, xs = m(_x(u8, dev))
+    _check_heads(xl, xs, ol, os_, tl.numpy(), ts.numpy(), metric_size=False)
+    m.precision = None
     m.storage_dtype = torch.float16
     with torch.no_grad():
         fl, fs = m(_x(u8, dev))
@@ -711,7 +773,7 @@ def test_all_cell_score_error_at_640x512_is_pinned(models, golden, dev, capsys):
         assert e64 <= r, (name, e64, r)                        # closer to the real-number result than the reference's own fp32 run
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("dtype", ["f32", "f16x3", "f16"])
 def test_full_size_640x512_batch128_two_lanes(yf, golden, dev, dtype):
     """BASELINE configs[2] at full size: 640x512, batch 128 -- the size at which the engine splits the batch over its two stream
     lanes by itself (chunk_frames: >= 64 frames of 640x512).  Frames are independent units: bitwise the same result at any position
@@ -727,8 +789,7 @@ def test_full_size_640x512_batch128_two_lanes(yf, golden, dev, dtype):
     def make(lanes):
         m = yf.YoloFastest(io).to(dev).eval()
         m.lanes = lanes
-        if dtype == "f16":
-            m.storage_dtype = torch.float16
+        m.precision = dtype
         m.load_state_dict(torch.load(WEIGHTS[512], map_location=dev))
         return m
     m = make(2)
@@ -748,13 +809,13 @@ def test_full_size_640x512_batch128_two_lanes(yf, golden, dev, dtype):
     got2 = post.to_lists(raw2, with_src=True)
     assert got2 == got
     sl = torch.from_numpy(slots).to(dev)
-    if dtype == "f32":
+    if dtype != "f16":
         _check_heads(hl[sl], hs[sl], g["head_large"], g["head_small"], g["head_large_f64"], g["head_small_f64"], metric_size=False)
     for k, f in enumerate(slots):
         n = int(g["final_count"][k])
         assert [e[7] for e in got[f]] == g["final_src"][k, :n].tolist(), (dtype, k)
         assert [e[6] for e in got[f]] == g["final_cls"][k, :n].tolist()
-        if dtype == "f32":
+        if dtype != "f16":
             assert [e[:4] for e in got[f]] == g["final_box"][k, :n].tolist()
         else:
             assert np.abs(np.array([e[:4] for e in got[f]]).reshape(-1, 4) - g["final_box"][k, :n]).max(initial=0) <= 1

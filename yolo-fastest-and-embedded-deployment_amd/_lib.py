@@ -43,6 +43,7 @@ _SIGS = {
     "yf_op_info": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_char_p, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     "yf_op_info_ex": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_char_p, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double),
                                  _c.POINTER(_c.c_double)]),
+    "yf_op_dtype": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_int)]),
     "yf_profile_forward": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_size_t, _c.c_void_p,
                                       _c.POINTER(_c.c_float), _c.c_int]),
     "yf_set_chunk": (_c.c_int, [_c.c_void_p, _c.c_int]),

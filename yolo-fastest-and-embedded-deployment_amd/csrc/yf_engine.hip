@@ -99,6 +99,8 @@ struct Op {
     int nblk = 1;        // OP_MRES: > 1 = a chain of residual blocks in one launch; block k's layers are l_exp/l_dw/l_proj + 3k
     long wstride = 0;    //          floats between the packed weight streams of consecutive chained blocks
     long mfma_off = -1;  // >= 0: pointwise layer runs on the matrix cores; offset of its packed B fragments
+    int kdt = 0;         // dtype handed to this op's kernel launcher (yf::DT_*): the engine's, or DT_F32 where a DT_F16X3 engine has
+                         // no split-operand instantiation of the kernel (same fp32 storage, exact fp32 arithmetic instead)
 };
 
 }  // namespace
@@ -114,7 +116,8 @@ struct Plan {
 
 struct yf_engine {
     int device = 0, H = 0, W = 0, max_batch = 0, chunk = 0;
-    int dtype = yf::DT_F32;           // activation storage type in HBM (fp16: pointwise GEMMs on fp16 MFMA, fp32 accumulate)
+    int dtype = yf::DT_F32;           // yf::DT_F32 / DT_F16 (fp16 storage, fp16 MFMA) / DT_F16X3 (fp32 storage, split-operand fp16 MFMA)
+    int sdt() const { return dtype == yf::DT_F16 ? yf::DT_F16 : yf::DT_F32; }   // storage type of the activations in HBM
     size_t esz() const { return dtype == yf::DT_F16 ? 2 : 4; }
     float* d_weights = nullptr;
     float* d_wmfma = nullptr;         // MFMA B fragments of the GEMM-worthy pointwise layers (fused plan)
@@ -363,7 +366,7 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
 {
     if (!e || (!d_x && !d_u8) || !d_hl || !d_hs || N <= 0) return fail(YF_E_INVALID, "yf_forward: null pointer or N <= 0");
     if (d_u8 && e->fusion != 1) return fail(YF_E_INVALID, "u8 input needs the fused plan (yf_set_fusion 1)");
-    if (e->dtype != yf::DT_F32 && e->fusion != 1) return fail(YF_E_INVALID, "fp16 storage needs the fused plan (yf_set_fusion 1)");
+    if (e->dtype == yf::DT_F16 && e->fusion != 1) return fail(YF_E_INVALID, "fp16 storage needs the fused plan (yf_set_fusion 1)");
     const size_t esz = e->esz();
     if (N > e->max_batch) return fail(YF_E_INVALID, "yf_forward: N=%d exceeds max_batch=%d", N, e->max_batch);
     const Plan& P = e->plan();
@@ -417,12 +420,12 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
             struct AtExit { ProfileEvents* p; size_t* i; hipStream_t st; ~AtExit() { if (p) { ++*i; (void)hipEventRecord(p->ev[*i], st); } } } at_exit{prof, &op_idx, s};
             if (o.type == OP_MDW) {
                 yf::MdwArgs a{ptr(o.in1), e->d_wmfma + o.mfma_off, ptr(o.out), ti.H, ti.W, 0, 0};
-                rc = yf::launch_mdw(ti.C, kLayers[o.l_proj].cout, o.l_head >= 0 ? 24 : 0, a, n, s, e->dtype);
+                rc = yf::launch_mdw(ti.C, kLayers[o.l_proj].cout, o.l_head >= 0 ? 24 : 0, a, n, s, o.kdt);
             } else if (o.type == OP_MRES) {
                 const LayerSpec &LE = kLayers[o.l_exp], &LP = kLayers[o.l_proj];
                 yf::MresArgs a{ptr(o.in1), e->d_wmfma + o.mfma_off, ptr(o.out), ti.H, ti.W, 0, 0, o.out2 >= 0 ? ptr(o.out2) : nullptr,
                                o.nblk, o.wstride};
-                rc = yf::launch_mres(LE.cin, LE.cout, LP.cout, o.res >= 0, kLayers[o.l_dw].stride, a, n, s, e->dtype);
+                rc = yf::launch_mres(LE.cin, LE.cout, LP.cout, o.res >= 0, kLayers[o.l_dw].stride, a, n, s, o.kdt);
             } else if (o.type == OP_FUSED_BLOCK) {
                 const bool pre = o.l_pre >= 0;
                 const LayerSpec &LE = kLayers[o.l_exp], &LD = kLayers[o.l_dw], &LP = kLayers[o.l_proj];
@@ -437,7 +440,7 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                 a.wp = e->d_wmfma + o.mfma_off;
                 a.out = ptr(o.out);
                 a.H = pre ? ti.H / 2 : ti.H; a.W = pre ? ti.W / 2 : ti.W; a.Ho = to.H; a.Wo = to.W;
-                rc = yf::launch_fused_block(LE.cin, LE.cout, LP.cout, LD.stride, o.res >= 0, LP.relu != 0, pre, a, n, s, e->dtype);
+                rc = yf::launch_fused_block(LE.cin, LE.cout, LP.cout, LD.stride, o.res >= 0, LP.relu != 0, pre, a, n, s, o.kdt);
             } else if (o.type == OP_K19) {
                 yf::K19Args a{};
                 a.in = ptr(o.in1);
@@ -445,20 +448,20 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                 a.out = ptr(o.out);
                 a.H = ti.H; a.W = ti.W; a.Ho = to.H; a.Wo = to.W;
                 a.wp = e->d_wmfma + o.mfma_off;
-                rc = yf::launch_k19m(a, n, s, e->dtype);
+                rc = yf::launch_k19m(a, n, s, o.kdt);
             } else if (L.kind == K_PW || L.kind == K_HEAD || L.kind == K_DECONV) {
                 yf::PwArgs a{ptr(o.in1), o.in2 >= 0 ? ptr(o.in2) : nullptr, W(o.layer), B(o.layer), o.res >= 0 ? ptr(o.res) : nullptr,
                              ptr(o.out), (long)n * ti.H * ti.W, (long)ti.H * ti.W, ti.W};
                 int cin2 = o.in2 >= 0 ? P.tensors[o.in2].C : 0;
                 if (o.mfma_off >= 0) {
                     a.w = e->d_wmfma + o.mfma_off;
-                    rc = yf::launch_pw_mfma(ti.C, cin2, L.cout, L.relu != 0, o.res >= 0, o.omode, a, s, e->dtype);
+                    rc = yf::launch_pw_mfma(ti.C, cin2, L.cout, L.relu != 0, o.res >= 0, o.omode, a, s, o.kdt);
                 } else {
                     rc = yf::launch_pw(ti.C, cin2, L.cout, L.relu != 0, o.res >= 0, o.omode, a, s);
                 }
             } else if (L.kind == K_DW) {
                 yf::DwArgs a{ptr(o.in1), W(o.layer), B(o.layer), ptr(o.out), (long)n * to.H * to.W * (to.C / 4), ti.C, ti.H, ti.W, to.H, to.W};
-                rc = yf::launch_dw(L.k, L.stride, a, s, e->dtype);
+                rc = yf::launch_dw(L.k, L.stride, a, s, e->sdt());
             } else {
                 yf::DenseArgs a{ptr(o.in1), W(o.layer), B(o.layer), ptr(o.out), (long)n * to.H * to.W, ti.H, ti.W, to.H, to.W};
                 rc = yf::launch_dense3x3s2(L.cin, L.cout, a, s);
@@ -469,11 +472,11 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                     HIP_OK(hipMemcpyAsync(probe_dst + (size_t)f0 * to.elems(), ptr(o.out), to.elems() * n * sizeof(float),
                                           hipMemcpyDeviceToDevice, s));
                 else
-                    yf::launch_nhwc_to_nchw(ptr(o.out), probe_dst + (size_t)f0 * to.elems(), n, to.C, (long)to.H * to.W, s, e->dtype);
+                    yf::launch_nhwc_to_nchw(ptr(o.out), probe_dst + (size_t)f0 * to.elems(), n, to.C, (long)to.H * to.W, s, e->sdt());
             }
             if (o.out2 >= 0 && o.out2 == probe_t) {
                 const Tensor& t2 = P.tensors[o.out2];
-                yf::launch_nhwc_to_nchw(ptr(o.out2), probe_dst + (size_t)f0 * t2.elems(), n, t2.C, (long)t2.H * t2.W, s, e->dtype);
+                yf::launch_nhwc_to_nchw(ptr(o.out2), probe_dst + (size_t)f0 * t2.elems(), n, t2.C, (long)t2.H * t2.W, s, e->sdt());
             }
         }
        }
@@ -536,7 +539,8 @@ int yf_create(const void* blob, size_t nbytes, int H, int W, int max_batch, int 
 
 int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, int device, int dtype, yf_handle* out)
 {
-    if (dtype != 0 && dtype != 1) return fail(YF_E_INVALID, "dtype must be 0 (fp32) or 1 (fp16 storage / fp16 MFMA, fp32 accumulate)");
+    if (dtype < 0 || dtype > 2)
+        return fail(YF_E_INVALID, "dtype must be 0 (fp32), 1 (fp16 storage / fp16 MFMA) or 2 (fp32 storage / split-operand fp16 MFMA)");
     if (!blob || !out) return fail(YF_E_INVALID, "yf_create: null pointer");
     if (H <= 0 || W <= 0 || H % 32 || W % 32) return fail(YF_E_INVALID, "input shape %dx%d: rows and cols must be multiples of 32", H, W);
     if (max_batch <= 0) return fail(YF_E_INVALID, "max_batch must be positive");
@@ -586,23 +590,29 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
     {   // matrix-core layers of the fused plan: pre-pack W[K][N] into MFMA B fragments (host) and upload
         const float* hw = reinterpret_cast<const float*>(static_cast<const char*>(blob) + data_off);
         const bool h16 = e->dtype == yf::DT_F16;
+        const bool x3 = e->dtype == yf::DT_F16X3;
         std::vector<float> packed;
+        for (Op& o : e->plans[0].ops) o.kdt = e->sdt();
         for (Op& o : e->plans[1].ops) {
+            o.kdt = e->sdt();
             if (o.type == OP_MRES) {
                 const LayerSpec &LE = kLayers[o.l_exp], &LP = kLayers[o.l_proj];
+                if (x3) o.kdt = yf::DT_F16X3;
+                const int wm = o.kdt;   // WM_* == DT_*
                 o.mfma_off = (long)packed.size();
-                o.wstride = (long)((yf::mres_packed_floats(LE.cin, LE.cout, LP.cout, h16) + 63) & ~(size_t)63);
+                o.wstride = (long)((yf::mres_packed_floats(LE.cin, LE.cout, LP.cout, wm) + 63) & ~(size_t)63);
                 packed.resize(packed.size() + (size_t)o.wstride * o.nblk);
                 for (int k = 0; k < o.nblk; ++k)   // chained blocks: same shape, layers 3 apart, streams wstride apart
                     yf::mres_pack_weights(hw + e->w_off[o.l_exp + 3 * k], hw + e->b_off[o.l_exp + 3 * k], hw + e->w_off[o.l_dw + 3 * k],
                                           hw + e->b_off[o.l_dw + 3 * k], hw + e->w_off[o.l_proj + 3 * k], hw + e->b_off[o.l_proj + 3 * k],
-                                          LE.cin, LE.cout, LP.cout, packed.data() + o.mfma_off + (size_t)o.wstride * k, h16);
+                                          LE.cin, LE.cout, LP.cout, packed.data() + o.mfma_off + (size_t)o.wstride * k, wm);
                 continue;
             }
             if (o.type == OP_K19) {
+                if (x3) o.kdt = yf::DT_F16X3;
                 o.mfma_off = (long)packed.size();
-                packed.resize(packed.size() + ((yf::k19_packed_floats(h16) + 63) & ~(size_t)63));
-                yf::k19_pack_weights(hw + e->w_off[o.l_dw], hw + e->w_off[o.l_proj], packed.data() + o.mfma_off, h16);
+                packed.resize(packed.size() + ((yf::k19_packed_floats(o.kdt) + 63) & ~(size_t)63));
+                yf::k19_pack_weights(hw + e->w_off[o.l_dw], hw + e->w_off[o.l_proj], packed.data() + o.mfma_off, o.kdt);
                 continue;
             }
             if (o.type == OP_FUSED_BLOCK) {
@@ -619,11 +629,12 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
             if (o.type == OP_MDW) {
                 const LayerSpec &LD = kLayers[o.l_dw], &LP = kLayers[o.l_proj];
                 const int headn = o.l_head >= 0 ? 24 : 0;
+                if (x3) o.kdt = yf::DT_F16X3;
                 o.mfma_off = (long)packed.size();
-                packed.resize(packed.size() + ((yf::mdw_packed_floats(LD.cin, LP.cout, headn, h16) + 63) & ~(size_t)63));
+                packed.resize(packed.size() + ((yf::mdw_packed_floats(LD.cin, LP.cout, headn, o.kdt) + 63) & ~(size_t)63));
                 yf::mdw_pack_weights(hw + e->w_off[o.l_dw], hw + e->b_off[o.l_dw], hw + e->w_off[o.l_proj], hw + e->b_off[o.l_proj],
                                      headn ? hw + e->w_off[o.l_head] : nullptr, headn ? hw + e->b_off[o.l_head] : nullptr, LD.cin,
-                                     LP.cout, headn, packed.data() + o.mfma_off, h16);
+                                     LP.cout, headn, packed.data() + o.mfma_off, o.kdt);
                 continue;
             }
             if (o.type != OP_LAYER) continue;
@@ -633,11 +644,16 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
             int c1 = P.tensors[o.in1].C, c2 = o.in2 >= 0 ? P.tensors[o.in2].C : 0;
             if (!yf::mfma_has_kernel(c1, c2, L.cout, L.relu != 0, o.res >= 0, o.omode)) continue;
             const int nq = L.kind == K_DECONV ? 4 : 1;
-            size_t per = h16 ? yf::mfma_packed_floats_f16(c1, c2, L.cout) : yf::mfma_packed_floats(c1, c2, L.cout);
+            const bool ox3 = x3 && yf::mfma_has_x3_kernel(c1, c2, L.cout, L.relu != 0, o.res >= 0, o.omode);
+            if (ox3) o.kdt = yf::DT_F16X3;
+            size_t per = ox3 ? yf::mfma_packed_floats_x3(c1, c2, L.cout)
+                       : h16 ? yf::mfma_packed_floats_f16(c1, c2, L.cout) : yf::mfma_packed_floats(c1, c2, L.cout);
             o.mfma_off = (long)packed.size();
             packed.resize(packed.size() + per * nq);
             for (int qd = 0; qd < nq; ++qd) {
-                if (h16) yf::mfma_pack_weights_f16(hw + e->w_off[o.layer] + (size_t)qd * L.cin * L.cout, c1, c2, L.cout,
+                if (ox3) yf::mfma_pack_weights_x3(hw + e->w_off[o.layer] + (size_t)qd * L.cin * L.cout, c1, c2, L.cout,
+                                                  packed.data() + o.mfma_off + per * qd);
+                else if (h16) yf::mfma_pack_weights_f16(hw + e->w_off[o.layer] + (size_t)qd * L.cin * L.cout, c1, c2, L.cout,
                                                    packed.data() + o.mfma_off + per * qd);
                 else yf::mfma_pack_weights(hw + e->w_off[o.layer] + (size_t)qd * L.cin * L.cout, c1, c2, L.cout,
                                            packed.data() + o.mfma_off + per * qd);
@@ -889,6 +905,13 @@ int yf_op_info_ex(yf_handle h, int op, char* name, int name_len, double* algorit
     if (algorithmic_bytes_per_frame) *algorithmic_bytes_per_frame = elems * (double)h->esz();
     if (mfma_flops_per_frame) *mfma_flops_per_frame = macs_mfma * 2.0;
     if (valu_flops_per_frame) *valu_flops_per_frame = macs_valu * 2.0;
+    return YF_OK;
+}
+
+int yf_op_dtype(yf_handle h, int op, int* kernel_dtype)
+{
+    if (!h || !kernel_dtype || op < 0 || op >= (int)h->plan().ops.size()) return fail(YF_E_INVALID, "bad op index");
+    *kernel_dtype = h->plan().ops[op].kdt;
     return YF_OK;
 }
 

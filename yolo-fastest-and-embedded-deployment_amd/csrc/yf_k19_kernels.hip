@@ -24,6 +24,7 @@
 // phases (offsets between them are neutrally stable), hence the in-wave interleave; LDS strides are padded so that both the
 // reads and phase 1's writes are conflict-free (bank rules of MI355X_MICROARCH.md).
 #include "yf_kernels.h"
+#include <math.h>
 #include <type_traits>
 
 namespace yf {
@@ -47,6 +48,9 @@ constexpr int W9_F32 = NG * 4 * 2 * 64, W21_F32 = 2 * 4 * 64;
 // [g][cg][lane][s] (staged in LDS) and conv2_1's two k-steps for those channels [t][lane]
 constexpr int WQ_F32 = NG * 2 * 64 * 4, W21Q_F32 = 2 * 64;
 constexpr int W9_F16 = NG * 2 * 64 * 2, W21_F16 = 2 * 64 * 2;  // in floats (f16x4 = 2 floats per lane)
+// split-operand mode (DT_F16X3): [W9 hi | W21 hi | W9 lo | W21 lo], each in the fp16 layout
+constexpr int WX3_HALF = W9_F16 + W21_F16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 }  // namespace
 
 #ifndef YF_K19_Q4
@@ -63,12 +67,18 @@ constexpr int W9_F16 = NG * 2 * 64 * 2, W21_F16 = 2 * 64 * 2;  // in floats (f16
 template <typename TT, int DBG = 0>
 __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
 {
+    // X3 (DT_F16X3): fp32 in HBM; conv1_8 (K = 4) stays an exact fp32 MFMA; its result is SPLIT ONCE, where phase 1 stores it: a
+    // region record of 4 channels is 16 bytes either way -- four floats (fp32 mode) or [hi f16x4 | lo f16x4] -- so phase 2 reads
+    // both halves of its B operand with the one ds_read_b128 it issues anyway and spends no VALU on splitting; conv1_9's weights
+    // are register-resident as hi and lo fragments (2 x 56 VGPRs) and a k group issues w_lo*x_hi + w_hi*x_lo + w_hi*x_hi.
+    constexpr bool X3 = is_x3<TT>::value;
     constexpr bool H16 = sizeof(TT) == 2;
+    constexpr bool M16 = H16 || X3;                // conv1_9 / conv2_1 on v_mfma_f32_16x16x16_f16
     constexpr int PS = plane_stride(H16), RWS = row_stride(H16);
     constexpr int BUF = RH * RWS;  // elements per region buffer
     extern __shared__ __attribute__((aligned(16))) unsigned char k19_smem[];
     TT* const R = reinterpret_cast<TT*>(k19_smem);  // [2][BUF]
-    constexpr bool Q4 = !H16 && YF_K19_Q4;
+    constexpr bool Q4 = !M16 && YF_K19_Q4;
     float* const WQ = reinterpret_cast<float*>(k19_smem + (size_t)2 * BUF * sizeof(TT));  // Q4: [NG][2][64][4]
 
     const int lane = threadIdx.x & 63;
@@ -76,11 +86,11 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
     const int p = lane & 15, j = lane >> 4;
 
     // ---- weights: registers for the lifetime of the workgroup ----
-    float wf[H16 ? 1 : NG][4][2];
-    f16x4 wh[H16 ? NG : 1][2];
+    float wf[M16 ? 1 : NG][4][2];
+    f16x4 wh[M16 ? NG : 1][2], wl[X3 ? NG : 1][2];
     float w21f[2][4];
-    f16x4 w21h[2];
-    if constexpr (H16) {
+    f16x4 w21h[2], w21l[2];
+    if constexpr (M16) {
         const f16x4* w = reinterpret_cast<const f16x4*>(a.wp);
 #pragma unroll
         for (int g = 0; g < NG; ++g)
@@ -88,6 +98,15 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
             for (int mt = 0; mt < 2; ++mt) wh[g][mt] = w[(g * 2 + mt) * 64 + lane];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) w21h[mt] = reinterpret_cast<const f16x4*>(a.wp + W9_F16)[mt * 64 + lane];
+        if constexpr (X3) {
+            const f16x4* wlo = reinterpret_cast<const f16x4*>(a.wp + WX3_HALF);
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) wl[g][mt] = wlo[(g * 2 + mt) * 64 + lane];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) w21l[mt] = reinterpret_cast<const f16x4*>(a.wp + WX3_HALF + W9_F16)[mt * 64 + lane];
+        }
     } else {
 #pragma unroll
         for (int g = 0; g < NG; ++g)
@@ -198,8 +217,17 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[mt][r] = inimg ? o[mt][r] : 0.f;
         }
-        st4<TT>(buf + wo0[u], make_float4(o[0][0], o[0][1], o[0][2], o[0][3]));
-        st4<TT>(buf + wo1[u], make_float4(o[1][0], o[1][1], o[1][2], o[1][3]));
+        if constexpr (X3) {   // the record holds the two fp16 halves of its four channels
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f16x4 hi, lo;
+                split_f16x4(o[mt][0], o[mt][1], o[mt][2], o[mt][3], hi, lo);
+                *reinterpret_cast<f16x8*>(buf + (mt ? wo1[u] : wo0[u])) = __builtin_shufflevector(hi, lo, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        } else {
+            st4<TT>(buf + wo0[u], make_float4(o[0][0], o[0][1], o[0][2], o[0][3]));
+            st4<TT>(buf + wo1[u], make_float4(o[1][0], o[1][1], o[1][2], o[1][3]));
+        }
     };
 
     int t = blockIdx.x;  // grid <= total
@@ -245,7 +273,7 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
         // rate equals the fp32 vector rate), so phase 1 is written for the fewest VALU instructions, not for overlap ----
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         f32x4 accq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // Q4: channels 16 + 4 cg + i, this lane group's k-values only
-        using xfrag = typename std::conditional<H16, f16x4, f32x4>::type;
+        using xfrag = typename std::conditional<H16, f16x4, typename std::conditional<X3, f16x8, f32x4>::type>::type;
         xfrag xc = *reinterpret_cast<const xfrag*>(Rc + adr[0]), xn = xc;
         f32x4 wq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, wqn[2] = {wq[0], wq[1]};
         if constexpr (Q4) {
@@ -264,7 +292,15 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
             }
             if (!(DBG & 1) && (g & 1) == 0 && g / 2 < NU) p1_mfma(g / 2, d);
             if constexpr (!(DBG & 2)) {
-                if constexpr (H16) {
+                if constexpr (X3) {
+                    const f16x4 xh = __builtin_shufflevector(xc, xc, 0, 1, 2, 3), xl = __builtin_shufflevector(xc, xc, 4, 5, 6, 7);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl[g][mt], xh, acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[g][mt], xl, acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[g][mt], xh, acc[mt], 0, 0, 0);
+                } else if constexpr (H16) {
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[g][mt], xc, acc[mt], 0, 0, 0);
                 } else if constexpr (Q4) {
@@ -319,7 +355,13 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
                 f32x4 h;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h[r] = fmaxf(acc[mt][r] + bias9[mt][r], 0.f);
-                if constexpr (H16) {
+                if constexpr (X3) {
+                    f16x4 hh, hl;
+                    split_f16x4(h[0], h[1], h[2], h[3], hh, hl);
+                    o = __builtin_amdgcn_mfma_f32_16x16x16f16(w21l[mt], hh, o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_16x16x16f16(w21h[mt], hl, o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_16x16x16f16(w21h[mt], hh, o, 0, 0, 0);
+                } else if constexpr (H16) {
                     const f16x4 hh = f16x4{(half_t)h[0], (half_t)h[1], (half_t)h[2], (half_t)h[3]};
                     o = __builtin_amdgcn_mfma_f32_16x16x16f16(w21h[mt], hh, o, 0, 0, 0);
                 } else {
@@ -338,12 +380,17 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
     }
 }
 
-size_t k19_packed_floats(bool h16) { return h16 ? (size_t)(W9_F16 + W21_F16) : (size_t)(W9_F32 + W21_F32 + WQ_F32 + W21Q_F32); }
+size_t k19_packed_floats(int wmode)
+{
+    return wmode == WM_F16X3 ? (size_t)2 * WX3_HALF : wmode == WM_F16 ? (size_t)(W9_F16 + W21_F16) : (size_t)(W9_F32 + W21_F32 + WQ_F32 + W21Q_F32);
+}
 
 // w9: [tap][cin][cout] (blob layout of the dense 3x3), w21: [cin][cout]
-void k19_pack_weights(const float* w9, const float* w21, float* out, bool h16)
+void k19_pack_weights(const float* w9, const float* w21, float* out, int wmode)
 {
+    const bool h16 = wmode != WM_F32, x3 = wmode == WM_F16X3;
     uint16_t* oh = reinterpret_cast<uint16_t*>(out);
+    uint16_t* ol = reinterpret_cast<uint16_t*>(out + WX3_HALF);   // x3: the lo halves, same layout
     for (int g = 0; g < NG; ++g)
         for (int s = 0; s < 4; ++s)
             for (int mt = 0; mt < 2; ++mt)
@@ -353,6 +400,7 @@ void k19_pack_weights(const float* w9, const float* w21, float* out, bool h16)
                     const float v = (fc < NCHUNK && cout < 24) ? w9[((size_t)tap * 24 + c) * 24 + cout] : 0.f;
                     if (h16) oh[((size_t)(g * 2 + mt) * 64 + l) * 4 + s] = f32_to_f16_bits(v);
                     else out[((g * 4 + s) * 2 + mt) * 64 + l] = v;
+                    if (x3) ol[((size_t)(g * 2 + mt) * 64 + l) * 4 + s] = f16_lo_bits(v);
                 }
     for (int mt = 0; mt < 2; ++mt)
         for (int r = 0; r < 4; ++r)
@@ -361,6 +409,7 @@ void k19_pack_weights(const float* w9, const float* w21, float* out, bool h16)
                 const float v = (c2 < 8 && c1 < 24) ? w21[c1 * 8 + c2] : 0.f;
                 if (h16) oh[(size_t)W9_F16 * 2 + ((size_t)mt * 64 + l) * 4 + r] = f32_to_f16_bits(v);
                 else out[W9_F32 + (mt * 4 + r) * 64 + l] = v;
+                if (x3) ol[(size_t)W9_F16 * 2 + ((size_t)mt * 64 + l) * 4 + r] = f16_lo_bits(v);
             }
     if (!h16) {   // the 4x4-block form of channels 16..23 (k19m_kernel, Q4)
         float* wq = out + W9_F32 + W21_F32;
@@ -385,7 +434,7 @@ size_t k19m_guard_elems(int W) { return ((size_t)(W + 34) * 4 + 63) & ~(size_t)6
 
 size_t k19m_lds_bytes(int dtype)
 {
-    return (size_t)2 * RH * row_stride(dtype == DT_F16) * (dtype == DT_F16 ? 2 : 4) + (dtype == DT_F16 || !YF_K19_Q4 ? 0 : (size_t)WQ_F32 * 4);
+    return (size_t)2 * RH * row_stride(dtype == DT_F16) * (dtype == DT_F16 ? 2 : 4) + (dtype != DT_F32 || !YF_K19_Q4 ? 0 : (size_t)WQ_F32 * 4);
 }
 
 int launch_k19m(K19Args a, int N, hipStream_t s, int dtype)
@@ -397,7 +446,9 @@ int launch_k19m(K19Args a, int N, hipStream_t s, int dtype)
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k19m_kernel<float, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)k19m_lds_bytes(DT_F32)) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k19m_kernel<half_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)k19m_lds_bytes(DT_F16)) != hipSuccess)
+                                (int)k19m_lds_bytes(DT_F16)) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k19m_kernel<x3_t, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)k19m_lds_bytes(DT_F16X3)) != hipSuccess)
             return -1;
         attr_done[dev] = true;
     }
@@ -409,6 +460,7 @@ int launch_k19m(K19Args a, int N, hipStream_t s, int dtype)
     const long want = (long)n_cu;
     const unsigned grid = (unsigned)(total < want ? total : want);
     if (dtype == DT_F16) hipLaunchKernelGGL((k19m_kernel<half_t, 0>), dim3(grid), dim3(512), k19m_lds_bytes(DT_F16), s, a);
+    else if (dtype == DT_F16X3) hipLaunchKernelGGL((k19m_kernel<x3_t, 0>), dim3(grid), dim3(512), k19m_lds_bytes(DT_F16X3), s, a);
     else hipLaunchKernelGGL((k19m_kernel<float, 0>), dim3(grid), dim3(512), k19m_lds_bytes(DT_F32), s, a);
     return 0;
 }

@@ -1,18 +1,31 @@
 // yf_kernels.h -- internal launch interface between the engine (yf_engine.hip) and the kernel files.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 namespace yf {
 
 // ---- activation storage types: fp32 (BASELINE configs[1]) or fp16 (configs[2]); all arithmetic accumulates in fp32 ----
-enum { DT_F32 = 0, DT_F16 = 1 };
+//   DT_F32   fp32 storage, fp32 arithmetic (v_mfma_f32_16x16x4_f32 / VALU): BASELINE configs[1]
+//   DT_F16   fp16 storage in HBM, single fp16 MFMA operands: the fastest, but 11-bit operands cost up to 8e-2 on the logits
+//   DT_F16X3 fp32 storage (HBM and LDS), the pointwise GEMMs on the fp16 matrix pipe with SPLIT operands: a = hi + lo (two fp16
+//            halves, lo = fp16(a - hi) computed exactly in fp32), products w_lo*a_hi + w_hi*a_lo + w_hi*a_hi accumulated in fp32 --
+//            22-bit operands, as accurate as the fp32 path (tools/mfma16_probe.hip, tools/fp16_sim.py), at 3 fp16 MFMAs (17 cycles
+//            each for K = 16) instead of 4 fp32 MFMAs (32 cycles each for K = 4)
+enum { DT_F32 = 0, DT_F16 = 1, DT_F16X3 = 2 };
+enum { WM_F32 = 0, WM_F16 = 1, WM_F16X3 = 2 };   // host-side weight-fragment packing of the MFMA kernels
 typedef _Float16 half_t;
+struct x3_t { float v; };   // storage tag of DT_F16X3: a float in memory; kernels instantiated on it use the split-fp16 MFMAs
+template <typename T> struct is_x3 { static constexpr bool value = false; };
+template <> struct is_x3<x3_t> { static constexpr bool value = true; };
+template <typename T> constexpr int wmode_of() { return is_x3<T>::value ? WM_F16X3 : sizeof(T) == 2 ? WM_F16 : WM_F32; }
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #ifdef __HIPCC__
 template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
 template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 ld4<x3_t>(const x3_t* p) { return *reinterpret_cast<const float4*>(p); }
 template <> __device__ __forceinline__ float4 ld4<half_t>(const half_t* p)
 {
     const f16x4 v = *reinterpret_cast<const f16x4*>(p);
@@ -20,6 +33,7 @@ template <> __device__ __forceinline__ float4 ld4<half_t>(const half_t* p)
 }
 template <typename T> __device__ __forceinline__ float2 ld2(const T* p);
 template <> __device__ __forceinline__ float2 ld2<float>(const float* p) { return *reinterpret_cast<const float2*>(p); }
+template <> __device__ __forceinline__ float2 ld2<x3_t>(const x3_t* p) { return *reinterpret_cast<const float2*>(p); }
 template <> __device__ __forceinline__ float2 ld2<half_t>(const half_t* p)
 {
     const f16x2 v = *reinterpret_cast<const f16x2*>(p);
@@ -27,13 +41,24 @@ template <> __device__ __forceinline__ float2 ld2<half_t>(const half_t* p)
 }
 template <typename T> __device__ __forceinline__ void st4(T* p, float4 v);
 template <> __device__ __forceinline__ void st4<float>(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<x3_t>(x3_t* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 template <> __device__ __forceinline__ void st4<half_t>(half_t* p, float4 v)
 {
     typedef float f32x4v __attribute__((ext_vector_type(4)));
     *reinterpret_cast<f16x4*>(p) = __builtin_convertvector((f32x4v{v.x, v.y, v.z, v.w}), f16x4);  // 2 x v_cvt_pk_f16_f32 (RNE)
 }
 template <typename T> __device__ __forceinline__ float ld1(const T* p) { return (float)*p; }
+template <> __device__ __forceinline__ float ld1<x3_t>(const x3_t* p) { return p->v; }
 template <typename T> __device__ __forceinline__ void st1(T* p, float v) { *p = (T)v; }
+template <> __device__ __forceinline__ void st1<x3_t>(x3_t* p, float v) { p->v = v; }
+// split four fp32 values into fp16 hi and lo halves: hi = rne(a), lo = rne(a - hi); a - hi is exact in fp32
+__device__ __forceinline__ void split_f16x4(float a0, float a1, float a2, float a3, f16x4& hi, f16x4& lo)
+{
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    const f32x4v a = {a0, a1, a2, a3};
+    hi = __builtin_convertvector(a, f16x4);
+    lo = __builtin_convertvector(a - __builtin_convertvector(hi, f32x4v), f16x4);
+}
 #endif
 
 // hipFuncSetAttribute (dynamic LDS above 64 KiB) and the CU count belong to (kernel, DEVICE), not to the process: launchers keep
@@ -91,9 +116,21 @@ int launch_dw(int k, int stride, const DwArgs& a, hipStream_t s, int dtype = DT_
 // matrix-core pointwise GEMM (yf_mfma_kernels.hip); a.w points at the layer's PACKED B fragments
 int launch_pw_mfma(int cin1, int cin2, int cout, bool relu, bool res, int omode, const PwArgs& a, hipStream_t s, int dtype = DT_F32);
 uint16_t f32_to_f16_bits(float f);
+// WM_F16X3 packing: the lo half of a weight, rne(w - (float)rne_f16(w)), as fp16 bits (the hi half is f32_to_f16_bits(w))
+inline uint16_t f16_lo_bits(float w)
+{
+    const uint16_t h = f32_to_f16_bits(w);
+    const int e = (h >> 10) & 31, m = h & 1023;
+    float hf = e == 0 ? ldexpf((float)m, -24) : e == 31 ? (m ? NAN : INFINITY) : ldexpf((float)(m | 1024), e - 25);
+    if (h & 0x8000) hf = -hf;
+    return f32_to_f16_bits(w - hf);
+}
 size_t mfma_packed_floats_f16(int k1, int k2, int n);
 void mfma_pack_weights_f16(const float* w, int k1, int k2, int n, float* out);
 bool mfma_has_kernel(int cin1, int cin2, int cout, bool relu, bool res, int omode);
+bool mfma_has_x3_kernel(int cin1, int cin2, int cout, bool relu, bool res, int omode);   // DT_F16X3 instantiation exists
+size_t mfma_packed_floats_x3(int k1, int k2, int n);
+void mfma_pack_weights_x3(const float* w, int k1, int k2, int n, float* out);
 size_t mfma_packed_floats(int k1, int k2, int n);
 void mfma_pack_weights(const float* w, int k1, int k2, int n, float* out);
 int launch_dense3x3s2(int cin, int cout, const DenseArgs& a, hipStream_t s);
@@ -131,9 +168,9 @@ struct MresArgs {
 int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArgs& a, int N, hipStream_t s, int dtype = DT_F32);
 bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride = 1, bool relu_out = false);
 bool mres_can_chain(int cin, int cexp, int cout, int H, int W);  // relu_out: ReLU after the projection
-size_t mres_packed_floats(int cin, int cexp, int cout, bool h16 = false);
+size_t mres_packed_floats(int cin, int cexp, int cout, int wmode = WM_F32);
 void mres_pack_weights(const float* w1, const float* b1, const float* wd, const float* bd, const float* w2, const float* b2,
-                       int cin, int cexp, int cout, float* out, bool h16 = false);
+                       int cin, int cexp, int cout, float* out, int wmode = WM_F32);
 
 struct MdwArgs {
     const float* in;   // NHWC [N,H,W,C]
@@ -144,9 +181,9 @@ struct MdwArgs {
 };
 int launch_mdw(int c, int n, int headn, const MdwArgs& a, int Nf, hipStream_t s, int dtype = DT_F32);
 bool mdw_has_kernel(int c, int n, int headn);
-size_t mdw_packed_floats(int c, int n, int headn, bool h16 = false);
+size_t mdw_packed_floats(int c, int n, int headn, int wmode = WM_F32);
 void mdw_pack_weights(const float* wd, const float* bd, const float* w, const float* b, const float* hw, const float* hb, int c,
-                      int n, int headn, float* out, bool h16 = false);
+                      int n, int headn, float* out, int wmode = WM_F32);
 
 struct K19Args {
     const float* in;              // NHWC [N,H,W,4] (res1_1 output, stride-2 resolution)
@@ -161,10 +198,10 @@ struct K19Args {
 };
 int launch_k19(K19Args a, int N, hipStream_t s, int dtype = DT_F32);    // VALU version (kept for tools/kbench.hip)
 int launch_k19m(K19Args a, int N, hipStream_t s, int dtype = DT_F32);   // matrix-core version (the plan's)
-size_t k19_packed_floats(bool h16 = false);
+size_t k19_packed_floats(int wmode = WM_F32);
 size_t k19m_lds_bytes(int dtype);
 size_t k19m_guard_elems(int W);   // the engine keeps this many elements free before and after the workspace slots
-void k19_pack_weights(const float* w9, const float* w21, float* out, bool h16 = false);
+void k19_pack_weights(const float* w9, const float* w21, float* out, int wmode = WM_F32);
 
 struct PostArgs {
     const float* head_large;  // [N,24,hl,wl]

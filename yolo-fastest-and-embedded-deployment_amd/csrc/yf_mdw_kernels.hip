@@ -39,11 +39,15 @@ __device__ __forceinline__ unsigned long long mdw_clock()
 #endif
 
 // h16: B fragments are f16x4 per lane (one v_mfma_f32_16x16x16_f16 per 16-channel chunk and n-tile); dw weights / biases stay fp32
-__host__ __device__ constexpr int mdw_chunk_floats(int n, bool h16 = false) { return 25 * 16 + 16 + (h16 ? (n / 16) * 128 : 4 * (n / 16) * 64); }
-__host__ __device__ constexpr int mdw_stream_floats(int c, int n, int headn, bool h16 = false)
+// wmode WM_F16X3 (split operands): every fp16 fragment block is followed by its lo halves (same layout)
+__host__ __device__ constexpr int mdw_chunk_floats(int n, int wmode = WM_F32)
 {
-    int f = (c / 16) * mdw_chunk_floats(n, h16) + n;
-    if (headn) f += (h16 ? (n / 16) * 2 * 128 : (n / 4) * 2 * 64) + 32;
+    return 25 * 16 + 16 + (wmode != WM_F32 ? (wmode == WM_F16X3 ? 2 : 1) * (n / 16) * 128 : 4 * (n / 16) * 64);
+}
+__host__ __device__ constexpr int mdw_stream_floats(int c, int n, int headn, int wmode = WM_F32)
+{
+    int f = (c / 16) * mdw_chunk_floats(n, wmode) + n;
+    if (headn) f += (wmode != WM_F32 ? (wmode == WM_F16X3 ? 2 : 1) * (n / 16) * 2 * 128 : (n / 4) * 2 * 64) + 32;
     return (f + 3) & ~3;
 }
 
@@ -68,7 +72,9 @@ __host__ __device__ constexpr int mdw_epl(int th, int tw, int nwave)
 template <int C, int N, int HEADN, int TH, int TW, int NWAVE, typename TT>
 __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
 {
-    constexpr bool H16 = sizeof(TT) == 2;
+    constexpr bool X3 = is_x3<TT>::value;       // fp32 storage, split-operand fp16 MFMAs (yf_kernels.h DT_F16X3)
+    constexpr bool H16 = sizeof(TT) == 2 || X3;  // the 1x1 convs run on v_mfma_f32_16x16x16_f16
+    constexpr int WM = X3 ? 2 : 1;
     constexpr int NTHR = NWAVE * 64;
     constexpr int RH = TH + 4, RW = TW + 4, NRP = RH * RW;
     constexpr int MTO = (TH * TW) / 16, MTOW = (MTO + NWAVE - 1) / NWAVE;
@@ -76,12 +82,12 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
                                              // fp16 build copied all accumulators around every branch: 1300 v_mov of 1900 VALU instructions)
     constexpr int EPL = mdw_epl(TH, TW, NWAVE);   // pixels per 4-channel plane (see mdw_epl)
     constexpr int NT = N / 16, NCH = C / 16;
-    constexpr int OFF_BD = 400, OFF_W = 416, CHUNK = 416 + (H16 ? NT * 128 : 4 * NT * 64);
+    constexpr int OFF_BD = 400, OFF_W = 416, CHUNK = 416 + (H16 ? WM * NT * 128 : 4 * NT * 64);
     constexpr int OFF_BPW = NCH * CHUNK, OFF_HW = OFF_BPW + N, KSH = N / 4, NTH = 2;
-    constexpr int OFF_HB = OFF_HW + (H16 ? (N / 16) * NTH * 128 : KSH * NTH * 64);
-    constexpr int WFLOATS = mdw_stream_floats(C, N, HEADN, H16);
+    constexpr int OFF_HB = OFF_HW + (H16 ? WM * (N / 16) * NTH * 128 : KSH * NTH * 64);
+    constexpr int WFLOATS = mdw_stream_floats(C, N, HEADN, wmode_of<TT>());
     constexpr int NLD = (NRP * 4 + NTHR - 1) / NTHR;  // float4 loads per thread per chunk
-    static_assert((TH * TW) % 16 == 0 && C % 16 == 0 && N % 16 == 0 && CHUNK == mdw_chunk_floats(N, H16), "shape");
+    static_assert((TH * TW) % 16 == 0 && C % 16 == 0 && N % 16 == 0 && CHUNK == mdw_chunk_floats(N, wmode_of<TT>()), "shape");
     static_assert(HEADN == 0 || HEADN <= 32, "head width");
     extern __shared__ __attribute__((aligned(16))) float mdw_smem[];
     float* E = mdw_smem;           // [4][EPL][4]
@@ -191,7 +197,27 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
         }
         MDW_STAMP(3)   // depthwise
         // ---- 1x1 conv: A = relu(d) (k-step j = channel 4q+j), B fragments from the staged stream ----
-        if constexpr (H16) {
+        if constexpr (X3) {
+            f16x4 w2h[NT], w2l[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                w2h[nt] = reinterpret_cast<const f16x4*>(wc + OFF_W)[nt * 64 + lane];
+                w2l[nt] = reinterpret_cast<const f16x4*>(wc + OFF_W)[(NT + nt) * 64 + lane];
+            }
+#pragma unroll
+            for (int i = 0; i < MTOW; ++i) {
+                if (EVEN || wave + i * NWAVE < MTO) {
+                    f16x4 dh, dl;
+                    split_f16x4(fmaxf(d2[i][0][0], 0.f), fmaxf(d2[i][0][1], 0.f), fmaxf(d2[i][1][0], 0.f), fmaxf(d2[i][1][1], 0.f), dh, dl);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(w2l[nt], dh, acc[i][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(w2h[nt], dl, acc[i][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(w2h[nt], dh, acc[i][nt], 0, 0, 0);
+                }
+            }
+        } else if constexpr (H16) {
             f16x4 w2h[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) w2h[nt] = reinterpret_cast<const f16x4*>(wc + OFF_W)[nt * 64 + lane];
@@ -256,7 +282,18 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
             for (int nt = 0; nt < NT; ++nt) {
                 const float4 bias = *reinterpret_cast<const float4*>(bpw + nt * 16 + 4 * q);
                 const float hv[4] = {acc[i][nt][0] + bias.x, acc[i][nt][1] + bias.y, acc[i][nt][2] + bias.z, acc[i][nt][3] + bias.w};
-                if constexpr (H16) {
+                if constexpr (X3) {
+                    f16x4 bh, bl;
+                    split_f16x4(hv[0], hv[1], hv[2], hv[3], bh, bl);
+                    const f16x4* hwh = reinterpret_cast<const f16x4*>(hw);
+                    const f16x4* hwl = hwh + (N / 16) * NTH * 64;
+#pragma unroll
+                    for (int nth = 0; nth < NTH; ++nth) {
+                        h[nth] = __builtin_amdgcn_mfma_f32_16x16x16f16(hwl[(nt * NTH + nth) * 64 + lane], bh, h[nth], 0, 0, 0);
+                        h[nth] = __builtin_amdgcn_mfma_f32_16x16x16f16(hwh[(nt * NTH + nth) * 64 + lane], bl, h[nth], 0, 0, 0);
+                        h[nth] = __builtin_amdgcn_mfma_f32_16x16x16f16(hwh[(nt * NTH + nth) * 64 + lane], bh, h[nth], 0, 0, 0);
+                    }
+                } else if constexpr (H16) {
                     const f16x4 bh = f16x4{(half_t)hv[0], (half_t)hv[1], (half_t)hv[2], (half_t)hv[3]};
 #pragma unroll
                     for (int nth = 0; nth < NTH; ++nth)
@@ -288,7 +325,7 @@ static int launch_mdw_t(MdwArgs a, int Nf, hipStream_t s)
     a.tiles_y = (a.H + TH - 1) / TH;
     a.tiles_x = (a.W + TW - 1) / TW;
     constexpr int NRP = (TH + 4) * (TW + 4);
-    constexpr size_t lds = ((size_t)16 * mdw_epl(TH, TW, NWAVE) + mdw_stream_floats(C, N, HEADN, sizeof(T) == 2)) * sizeof(float);
+    constexpr size_t lds = ((size_t)16 * mdw_epl(TH, TW, NWAVE) + mdw_stream_floats(C, N, HEADN, wmode_of<T>())) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done[YF_MAX_DEVICES] = {};
     const int dev = current_device();
@@ -315,7 +352,8 @@ int launch_mdw(int c, int n, int headn, const MdwArgs& a, int Nf, hipStream_t s,
 {
 #define MD(cc, nn, hh, th, tw, nw)                                                               \
     if (c == cc && n == nn && headn == hh)                                                        \
-        return dtype == DT_F16 ? launch_mdw_t<cc, nn, hh, th, tw, nw, half_t>(a, Nf, s) : launch_mdw_t<cc, nn, hh, th, tw, nw, float>(a, Nf, s);
+        return dtype == DT_F16 ? launch_mdw_t<cc, nn, hh, th, tw, nw, half_t>(a, Nf, s)           \
+             : dtype == DT_F16X3 ? launch_mdw_t<cc, nn, hh, th, tw, nw, x3_t>(a, Nf, s) : launch_mdw_t<cc, nn, hh, th, tw, nw, float>(a, Nf, s);
     YF_MDW_SHAPES(MD)
 #undef MD
     return -1;
@@ -330,14 +368,15 @@ bool mdw_has_kernel(int c, int n, int headn)
     return false;
 }
 
-size_t mdw_packed_floats(int c, int n, int headn, bool h16) { return (size_t)mdw_stream_floats(c, n, headn, h16); }
+size_t mdw_packed_floats(int c, int n, int headn, int wmode) { return (size_t)mdw_stream_floats(c, n, headn, wmode); }
 
 // Weight stream: NCH chunks of [wd 25x16 | bd 16 | W frags], then b_pw[n], then (head) frags, b_head[32].
 //   fp32: W frags 4 x NT x 64 floats (one per k-step), head frags (n/4) x 2 x 64;  h16: f16x4 per lane: NT x 128 / (n/16) x 2 x 128 floats
 void mdw_pack_weights(const float* wd /*[25][c]*/, const float* bd, const float* w /*[c][n]*/, const float* b, const float* hw /*[n][headn]*/,
-                      const float* hb, int c, int n, int headn, float* out, bool h16)
+                      const float* hb, int c, int n, int headn, float* out, int wmode)
 {
-    const int NT = n / 16, NCH = c / 16, CH = mdw_chunk_floats(n, h16);
+    const bool h16 = wmode != WM_F32, x3 = wmode == WM_F16X3;
+    const int NT = n / 16, NCH = c / 16, CH = mdw_chunk_floats(n, wmode);
     for (int ch = 0; ch < NCH; ++ch) {
         float* o = out + (size_t)ch * CH;
         for (int t = 0; t < 25; ++t)
@@ -348,7 +387,10 @@ void mdw_pack_weights(const float* wd /*[25][c]*/, const float* bd, const float*
             uint16_t* o16 = reinterpret_cast<uint16_t*>(o + 416);
             for (int nt = 0; nt < NT; ++nt)
                 for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 4; ++j) o16[(nt * 64 + lane) * 4 + j] = f32_to_f16_bits(w_at(j, nt, lane));
+                    for (int j = 0; j < 4; ++j) {
+                        o16[(nt * 64 + lane) * 4 + j] = f32_to_f16_bits(w_at(j, nt, lane));
+                        if (x3) o16[((NT + nt) * 64 + lane) * 4 + j] = f16_lo_bits(w_at(j, nt, lane));
+                    }
         } else {
             for (int j = 0; j < 4; ++j)
                 for (int nt = 0; nt < NT; ++nt)
@@ -368,8 +410,11 @@ void mdw_pack_weights(const float* wd /*[25][c]*/, const float* bd, const float*
             for (int kb = 0; kb < n / 16; ++kb)
                 for (int nt = 0; nt < 2; ++nt)
                     for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 4; ++j) o16[((kb * 2 + nt) * 64 + lane) * 4 + j] = f32_to_f16_bits(h_at(kb * 4 + j, nt, lane));
-            o += (n / 16) * 2 * 128;
+                        for (int j = 0; j < 4; ++j) {
+                            o16[((kb * 2 + nt) * 64 + lane) * 4 + j] = f32_to_f16_bits(h_at(kb * 4 + j, nt, lane));
+                            if (x3) o16[(((n / 16 + kb) * 2 + nt) * 64 + lane) * 4 + j] = f16_lo_bits(h_at(kb * 4 + j, nt, lane));
+                        }
+            o += (x3 ? 2 : 1) * (n / 16) * 2 * 128;
         } else {
             for (int s = 0; s < n / 4; ++s)
                 for (int nt = 0; nt < 2; ++nt)

@@ -190,6 +190,124 @@ __global__ void __launch_bounds__(256) pw_mfma_kernel(PwArgs a)
 __device__ __forceinline__ bool v0guard(float v) { return v != 123456.f; }  // DBG: keeps the value alive, never stores
 
 // DBG (tools/kbench.hip only): 1 = no A refill, 2 = no stores
+// pw_ws_x3_kernel: the same weight-stationary GEMM for DT_F16X3 (fp32 in HBM, split-operand fp16 MFMAs).  A wave keeps the hi AND
+// lo f16x4 fragments of its units' weights in registers (the same register count as the fp32 fragments); every 16-byte piece of
+// the A ring is split into its fp16 halves once per row tile (ten VALU instructions that run beside the matrix pipe) and feeds
+// 3 x UPW MFMAs: w_lo*a_hi + w_hi*a_lo + w_hi*a_hi.
+template <int K1, int K2, int N, int UPW, int RS, bool RELU, int OMODE>
+__global__ void __launch_bounds__(64 * RS * ((((N + 15) / 16) * (OMODE == 2 ? 4 : 1) + UPW - 1) / UPW)) pw_ws_x3_kernel(PwArgs a)
+{
+    constexpr int NT = (N + 15) / 16, NQ = OMODE == 2 ? 4 : 1, NU = NT * NQ;
+    constexpr int NB1 = K1 / 16, NB2 = K2 / 16;
+    constexpr bool T1 = (K1 % 16) != 0, T2 = (K2 % 16) != 0;
+    constexpr int NK1 = kmfmas16(K1), NK2 = K2 ? kmfmas16(K2) : 0, NK = NK1 + NK2;   // f16 MFMA k-blocks
+    static_assert(OMODE == 0 || OMODE == 2, "NHWC outputs only");
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    constexpr int NUG = (NU + UPW - 1) / UPW;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ug = wv % NUG, rs = wv / NUG;
+
+    f16x4 bh[UPW][NK], bl[UPW][NK];
+    float bias[UPW][4];
+    int un[UPW], uq[UPW];
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) {
+        const int u = ug * UPW + i;
+        const bool v = u < NU;
+        const int uc = v ? u : NU - 1;
+        uq[i] = uc / NT;
+        un[i] = uc - uq[i] * NT;
+        // per quadrant: [hi fragments NK x NT x 64 | lo fragments, same layout] (mfma_pack_weights_x3)
+        const f16x4* w = reinterpret_cast<const f16x4*>(a.w) + ((size_t)uq[i] * 2 * NK * NT + un[i]) * 64 + lane;
+#pragma unroll
+        for (int kb = 0; kb < NK; ++kb) {
+            bh[i][kb] = w[(size_t)kb * NT * 64];
+            bl[i][kb] = w[(size_t)(NK + kb) * NT * 64];
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) bias[i][reg] = un[i] * 16 + 4 * q + reg < N ? a.b[un[i] * 16 + 4 * q + reg] : 0.f;
+        if (!v) un[i] = NT;
+    }
+
+    const long ntiles = (a.npix + 15) / 16;
+    const long t0 = (long)blockIdx.x * RS + rs, tstep = (long)gridDim.x * RS;
+    auto rowptr1 = [&](long t) { long rr = t * 16 + r; rr = rr < a.npix ? rr : a.npix - 1; return a.in1 + rr * K1 + 4 * q; };
+    auto rowptr2 = [&](long t) { long rr = t * 16 + r; rr = rr < a.npix ? rr : a.npix - 1; return a.in2 + rr * K2 + 4 * q; };
+
+    float4 a1[NB1 > 0 ? NB1 : 1], a2[NB2 > 0 ? NB2 : 1];
+    float2 a1t = make_float2(0.f, 0.f), a2t = make_float2(0.f, 0.f);
+    {
+        const float* p1 = rowptr1(t0 < ntiles ? t0 : ntiles - 1);
+#pragma unroll
+        for (int kb = 0; kb < NB1; ++kb) a1[kb] = *reinterpret_cast<const float4*>(p1 + kb * 16);
+        if constexpr (T1) a1t = *reinterpret_cast<const float2*>(p1 - 4 * q + NB1 * 16 + 2 * q);
+        if constexpr (K2 > 0) {
+            const float* p2 = rowptr2(t0 < ntiles ? t0 : ntiles - 1);
+#pragma unroll
+            for (int kb = 0; kb < NB2; ++kb) a2[kb] = *reinterpret_cast<const float4*>(p2 + kb * 16);
+            if constexpr (T2) a2t = *reinterpret_cast<const float2*>(p2 - 4 * q + NB2 * 16 + 2 * q);
+        }
+    }
+    auto mac = [&](f32x4 (&acc)[UPW], int kb, float x0, float x1, float x2, float x3) {
+        f16x4 ah, al;
+        split_f16x4(x0, x1, x2, x3, ah, al);
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(bl[i][kb], ah, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(bh[i][kb], al, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(bh[i][kb], ah, acc[i], 0, 0, 0);
+    };
+
+#pragma unroll 1
+    for (long t = t0; t < ntiles; t += tstep) {
+        const long tn = (t + tstep < ntiles) ? t + tstep : t;
+        const float* p1 = rowptr1(tn);
+        f32x4 acc[UPW];
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NB1; ++kb) {
+            mac(acc, kb, a1[kb].x, a1[kb].y, a1[kb].z, a1[kb].w);
+            a1[kb] = *reinterpret_cast<const float4*>(p1 + kb * 16);
+        }
+        if constexpr (T1) {
+            mac(acc, NB1, a1t.x, a1t.y, 0.f, 0.f);
+            a1t = *reinterpret_cast<const float2*>(p1 - 4 * q + NB1 * 16 + 2 * q);
+        }
+        if constexpr (K2 > 0) {
+            const float* p2 = rowptr2(tn);
+#pragma unroll
+            for (int kb = 0; kb < NB2; ++kb) {
+                mac(acc, NK1 + kb, a2[kb].x, a2[kb].y, a2[kb].z, a2[kb].w);
+                a2[kb] = *reinterpret_cast<const float4*>(p2 + kb * 16);
+            }
+            if constexpr (T2) {
+                mac(acc, NK1 + NB2, a2t.x, a2t.y, 0.f, 0.f);
+                a2t = *reinterpret_cast<const float2*>(p2 - 4 * q + NB2 * 16 + 2 * q);
+            }
+        }
+        const long row = t * 16 + r;
+        long obase;
+        if constexpr (OMODE == 0) {
+            obase = row * N;
+        } else {
+            const long n = row / a.HW, hw = row - n * a.HW;
+            const int y = (int)(hw / a.W), x = (int)(hw - (long)y * a.W);
+            obase = ((n * (2 * (a.HW / a.W)) + 2 * y) * (2 * a.W) + 2 * x) * N;
+        }
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int c = un[i] * 16 + 4 * q;
+            if (c >= N || row >= a.npix) continue;
+            const long qoff = OMODE == 2 ? ((long)(uq[i] >> 1) * (2 * a.W) + (uq[i] & 1)) * N : 0;
+            float4 v = make_float4(acc[i][0] + bias[i][0], acc[i][1] + bias[i][1], acc[i][2] + bias[i][2], acc[i][3] + bias[i][3]);
+            if constexpr (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(a.out + obase + qoff + c) = v;
+        }
+    }
+}
+
 template <int K1, int K2, int N, int UPW, int RS, bool RELU, int OMODE, int DBG = 0>
 __global__ void __launch_bounds__(64 * RS * ((((N + 15) / 16) * (OMODE == 2 ? 4 : 1) + UPW - 1) / UPW)) pw_ws_kernel(PwArgs a)
 {
@@ -323,7 +441,7 @@ __global__ void __launch_bounds__(64 * RS * ((((N + 15) / 16) * (OMODE == 2 ? 4 
     WS(136, 96, 96, 3, 2, true, 0, 1)   /* conv4_1_1 over cat(conv4_2, deconv5_1): 2 waves x 2 streams */
 
 template <int K1, int K2, int N, int UPW, int RS, bool RELU, int OMODE, int WPC>
-static int launch_ws(const PwArgs& a, hipStream_t s)
+static int launch_ws(const PwArgs& a, hipStream_t s, bool x3 = false)
 {
     constexpr int NU = ((N + 15) / 16) * (OMODE == 2 ? 4 : 1), NUG = (NU + UPW - 1) / UPW;
     static_assert((NUG * RS) % 4 == 0 && NUG * RS <= 16, "whole waves per SIMD");
@@ -332,7 +450,8 @@ static int launch_ws(const PwArgs& a, hipStream_t s)
     const long ntiles = (a.npix + 15) / 16, streams = (ntiles + RS - 1) / RS;
     // persistent grid: every workgroup gets the same number of row tiles (no ragged last round)
     const long cap = (long)n_cu * WPC, rounds = (streams + cap - 1) / cap, grid = (streams + rounds - 1) / rounds;
-    hipLaunchKernelGGL((pw_ws_kernel<K1, K2, N, UPW, RS, RELU, OMODE>), dim3((unsigned)grid), dim3(64 * NUG * RS), 0, s, a);
+    if (x3) hipLaunchKernelGGL((pw_ws_x3_kernel<K1, K2, N, UPW, RS, RELU, OMODE>), dim3((unsigned)grid), dim3(64 * NUG * RS), 0, s, a);
+    else hipLaunchKernelGGL((pw_ws_kernel<K1, K2, N, UPW, RS, RELU, OMODE>), dim3((unsigned)grid), dim3(64 * NUG * RS), 0, s, a);
     return 0;
 }
 
@@ -366,16 +485,26 @@ static int launch_t(const PwArgs& a, hipStream_t s, int dtype)
 int launch_pw_mfma(int cin1, int cin2, int cout, bool relu_, bool res_, int omode, const PwArgs& a, hipStream_t s, int dtype)
 {
 #define WS(k1, k2, n, upw, rs, relu, om, wpc)                                                                  \
-    if (dtype == DT_F32 && cin1 == k1 && cin2 == k2 && cout == n && relu_ == relu && !res_ && omode == om)      \
-        return launch_ws<k1, k2, n, upw, rs, relu, om, wpc>(a, s);
+    if (dtype != DT_F16 && cin1 == k1 && cin2 == k2 && cout == n && relu_ == relu && !res_ && omode == om)      \
+        return launch_ws<k1, k2, n, upw, rs, relu, om, wpc>(a, s, dtype == DT_F16X3);
     YF_WS_SHAPES(WS)
 #undef WS
+    if (dtype == DT_F16X3) return -1;   // split-operand mode: weight-stationary shapes only (the engine falls back to fp32 elsewhere)
 #define MF(k1, k2, n, mt, relu, res, om)                                                        \
     if (cin1 == k1 && cin2 == k2 && cout == n && relu_ == relu && res_ == res && omode == om)    \
         return launch_t<k1, k2, n, mt, relu, res, om>(a, s, dtype);
     YF_MFMA_SHAPES(MF)
 #undef MF
     return -1;
+}
+
+bool mfma_has_x3_kernel(int cin1, int cin2, int cout, bool relu_, bool res_, int omode)
+{
+#define WS(k1, k2, n, upw, rs, relu, om, wpc) \
+    if (cin1 == k1 && cin2 == k2 && cout == n && relu_ == relu && !res_ && omode == om) return true;
+    YF_WS_SHAPES(WS)
+#undef WS
+    return false;
 }
 
 bool mfma_has_kernel(int cin1, int cin2, int cout, bool relu_, bool res_, int omode)
@@ -415,7 +544,17 @@ uint16_t f32_to_f16_bits(float f)
 size_t mfma_packed_floats_f16(int k1, int k2, int n) { return (size_t)2 * (kmfmas16(k1) + (k2 ? kmfmas16(k2) : 0)) * ((n + 15) / 16) * 64; }
 
 // fp16 B fragments: out16[((blk*NT + nt)*64 + lane)*4 + j] = half(W[kbase + blk*16 + (blk < NB ? 4 : 2)*q + j][nt*16 + (lane&15)]), j beyond the block = 0
-void mfma_pack_weights_f16(const float* w, int k1, int k2, int n, float* out)
+// WM_F16X3: [hi fragments | lo fragments], each in the fp16 layout
+size_t mfma_packed_floats_x3(int k1, int k2, int n) { return 2 * mfma_packed_floats_f16(k1, k2, n); }
+static void mfma_pack_weights_f16_part(const float* w, int k1, int k2, int n, float* out, bool lo);
+void mfma_pack_weights_x3(const float* w, int k1, int k2, int n, float* out)
+{
+    mfma_pack_weights_f16_part(w, k1, k2, n, out, false);
+    mfma_pack_weights_f16_part(w, k1, k2, n, out + mfma_packed_floats_f16(k1, k2, n), true);
+}
+void mfma_pack_weights_f16(const float* w, int k1, int k2, int n, float* out) { mfma_pack_weights_f16_part(w, k1, k2, n, out, false); }
+
+static void mfma_pack_weights_f16_part(const float* w, int k1, int k2, int n, float* out, bool lo)
 {
     uint16_t* o16 = reinterpret_cast<uint16_t*>(out);
     const int NT = (n + 15) / 16;
@@ -432,7 +571,8 @@ void mfma_pack_weights_f16(const float* w, int k1, int k2, int n, float* out)
                     for (int j = 0; j < 4; ++j) {
                         const int q = lane >> 4, c = nt * 16 + (lane & 15);
                         const int k = kbase + kb * 16 + per * q + j;
-                        o16[((blk * NT + nt) * 64 + lane) * 4 + j] = (j < per && c < n) ? f32_to_f16_bits(w[(size_t)k * n + c]) : 0;
+                        const float v = (j < per && c < n) ? w[(size_t)k * n + c] : 0.f;
+                        o16[((blk * NT + nt) * 64 + lane) * 4 + j] = lo ? f16_lo_bits(v) : f32_to_f16_bits(v);
                     }
         }
         kbase += K;

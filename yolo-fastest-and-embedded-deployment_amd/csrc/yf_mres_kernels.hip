@@ -22,6 +22,7 @@
 // Variants: stride 2 (the un-named bottleneck triples; the conv4_2 triple also WRITES its expanded tensor and applies conv5_1's
 // ReLU), producer/consumer waves (mres_pc_kernel, strides 16/32), and chains of blocks in one launch where the tile is the frame.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "yf_kernels.h"
@@ -72,10 +73,12 @@ __device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(
 // Stride-2 blocks read every second pixel: quad q + 1 then wants the ODD records (pitch == 1 mod 16).
 __host__ __device__ constexpr int mres_epl(int mtr, int s = 1) { return mtr * 16 + (s == 2 ? 1 : 0) + YF_MRES_EPL_PAD; }
 __host__ __device__ constexpr int mres_ksteps(int K) { return (K / 16) * 4 + ((K % 16) ? 2 : 0); }
-__host__ __device__ constexpr int mres_chunk_floats(int cin, int cout, bool h16 = false)
+// wmode WM_F16X3: the hi fragments of a matrix are followed by its lo fragments (same layout)
+__host__ __device__ constexpr int mres_chunk_floats(int cin, int cout, int wmode = WM_F32)
 {
-    return h16 ? ((mres_ksteps(cin) + 3) / 4) * 128 + 16 + 9 * 16 + 16 + ((cout + 15) / 16) * 128
-               : mres_ksteps(cin) * 64 + 16 + 9 * 16 + 16 + 4 * ((cout + 15) / 16) * 64;
+    return wmode != WM_F32 ? (wmode == WM_F16X3 ? 2 : 1) * ((mres_ksteps(cin) + 3) / 4) * 128 + 16 + 9 * 16 + 16 +
+                                 (wmode == WM_F16X3 ? 2 : 1) * ((cout + 15) / 16) * 128
+                           : mres_ksteps(cin) * 64 + 16 + 9 * 16 + 16 + 4 * ((cout + 15) / 16) * 64;
 }
 
 // Stage the block's weight stream and the halo'd input tile (zeros outside the image / beyond the region) in LDS.  ALL global loads
@@ -159,14 +162,16 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
     constexpr bool WEXP = mres_writes_expansion(CIN, CEXP, COUT, S);       // conv4_2 + conv4_3 + conv5_1: conv4_2 is a skip tensor
     constexpr int XP = CIN + 4;                           // X row pitch: conflict-free b128/b64 fragment reads
     constexpr int EPL = mres_epl(MTR, S);   // pixels per 4-channel plane
-    constexpr bool H16 = sizeof(T) == 2;  // fp16 storage: the pointwise GEMMs run on v_mfma_f32_16x16x16_f16 (4 k-steps each)
+    constexpr bool X3 = is_x3<T>::value;  // fp32 storage, split-operand fp16 MFMAs (3 per k-group): yf_kernels.h DT_F16X3
+    constexpr bool H16 = sizeof(T) == 2 || X3;  // the pointwise GEMMs run on v_mfma_f32_16x16x16_f16 (4 k-steps each)
+    constexpr int WM = X3 ? 2 : 1;
     constexpr int KS1 = mres_ksteps(CIN), NB1 = CIN / 16, NT2 = (COUT + 15) / 16, NCH = (CEXP + 15) / 16;
     constexpr int NK1 = (KS1 + 3) / 4;    // f16 MFMAs per expansion tile
-    constexpr int OFF_B1 = H16 ? NK1 * 128 : KS1 * 64, OFF_WD = OFF_B1 + 16, OFF_BD = OFF_WD + 144, OFF_W2 = OFF_BD + 16;
-    constexpr int CHUNK = OFF_W2 + (H16 ? NT2 * 128 : 4 * NT2 * 64);
+    constexpr int OFF_B1 = H16 ? WM * NK1 * 128 : KS1 * 64, OFF_WD = OFF_B1 + 16, OFF_BD = OFF_WD + 144, OFF_W2 = OFF_BD + 16;
+    constexpr int CHUNK = OFF_W2 + (H16 ? WM * NT2 * 128 : 4 * NT2 * 64);
     static_assert((TH * TW) % 16 == 0 && CIN % 8 == 0 && COUT % 4 == 0, "shape");
     static_assert(!RES || (CIN == COUT && S == 1), "residual needs same shape");
-    static_assert(CHUNK == mres_chunk_floats(CIN, COUT, H16), "pack layout");
+    static_assert(CHUNK == mres_chunk_floats(CIN, COUT, wmode_of<T>()), "pack layout");
     static_assert(MTRW <= 32, "in-image mask bits");
     extern __shared__ __attribute__((aligned(16))) float mres_smem[];
     float* X = mres_smem;                 // [MTR*16][XP]
@@ -213,6 +218,16 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
             eoff[i] = (inmask >> i & 1) && ry > 0 && rx > 0 ? (iy * a.W + ix) * CEXP + 4 * q : -1;  // within frame n
         }
     }
+    // split-operand mode: the activation operand of the expansion is split ONCE per block (hi and lo halves, 4 k-steps per f16x4)
+    f16x4 a1h[X3 ? MTRW : 1][NK1], a1l[X3 ? MTRW : 1][NK1];
+    if constexpr (X3) {
+#pragma unroll
+        for (int i = 0; i < MTRW; ++i)
+#pragma unroll
+            for (int s = 0; s < NK1; ++s)
+                split_f16x4(a1[i][4 * s], a1[i][4 * s + 1], 4 * s + 2 < KS1 ? a1[i][(4 * s + 2) % KS1] : 0.f,
+                            4 * s + 3 < KS1 ? a1[i][(4 * s + 3) % KS1] : 0.f, a1h[i][s], a1l[i][s]);
+    }
     // ---- projection accumulators and the E offsets of this lane's output pixel (as A-fragment row r) ----
     f32x4 acc[MTOW][NT2];
     int rp0[MTOW];
@@ -231,10 +246,14 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
     for (int c = 0; c < NCH; ++c) {
         const float* wc = WL + c * CHUNK;
         float w1f[KS1];
-        f16x4 w1h[NK1];
+        f16x4 w1h[NK1], w1l[X3 ? NK1 : 1];
         if constexpr (H16) {
 #pragma unroll
             for (int s = 0; s < NK1; ++s) w1h[s] = reinterpret_cast<const f16x4*>(wc)[s * 64 + lane];
+            if constexpr (X3) {
+#pragma unroll
+                for (int s = 0; s < NK1; ++s) w1l[s] = reinterpret_cast<const f16x4*>(wc)[(NK1 + s) * 64 + lane];
+            }
         } else {
 #pragma unroll
             for (int s = 0; s < KS1; ++s) w1f[s] = wc[s * 64 + lane];
@@ -245,10 +264,14 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
         for (int t = 0; t < 9; ++t) wd[t] = *reinterpret_cast<const float4*>(wc + OFF_WD + t * 16 + 4 * q);
         const float4 bd = *reinterpret_cast<const float4*>(wc + OFF_BD + 4 * q);
         float w2f[4][NT2];
-        f16x4 w2h[NT2];
+        f16x4 w2h[NT2], w2l[X3 ? NT2 : 1];
         if constexpr (H16) {
 #pragma unroll
             for (int nt = 0; nt < NT2; ++nt) w2h[nt] = reinterpret_cast<const f16x4*>(wc + OFF_W2)[nt * 64 + lane];
+            if constexpr (X3) {
+#pragma unroll
+                for (int nt = 0; nt < NT2; ++nt) w2l[nt] = reinterpret_cast<const f16x4*>(wc + OFF_W2)[(NT2 + nt) * 64 + lane];
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -263,7 +286,15 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
             const int mt = wave + i * NWAVE;
             if (EVEN_R || i < MTRW - 1 || mt < MTR) {   // only a wave's LAST tile can be missing: the others share one basic block
                 f32x4 cf = f32x4{b1.x, b1.y, b1.z, b1.w};   // the bias rides in as the MFMA's C operand
-                if constexpr (H16) {
+                if constexpr (X3) {   // small terms first, then hi * hi
+#pragma unroll
+                    for (int s = 0; s < NK1; ++s) {
+                        cf = __builtin_amdgcn_mfma_f32_16x16x16f16(w1l[s], a1h[i][s], cf, 0, 0, 0);
+                        cf = __builtin_amdgcn_mfma_f32_16x16x16f16(w1h[s], a1l[i][s], cf, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int s = 0; s < NK1; ++s) cf = __builtin_amdgcn_mfma_f32_16x16x16f16(w1h[s], a1h[i][s], cf, 0, 0, 0);
+                } else if constexpr (H16) {
 #pragma unroll
                     for (int s = 0; s < NK1; ++s) {
                         const f16x4 ah = f16x4{(half_t)a1[i][4 * s], (half_t)a1[i][4 * s + 1], 4 * s + 2 < KS1 ? (half_t)a1[i][(4 * s + 2) % KS1] : (half_t)0.f,
@@ -328,7 +359,16 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                     d[3] = fmaf(v.w, w.w, d[3]);
                 }
 #endif
-                if constexpr (H16) {
+                if constexpr (X3) {
+                    f16x4 dh, dl;
+                    split_f16x4(relu_bits(d[0]), relu_bits(d[1]), relu_bits(d[2]), relu_bits(d[3]), dh, dl);
+#pragma unroll
+                    for (int nt = 0; nt < NT2; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(w2l[nt], dh, acc[i][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT2; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(w2h[nt], dl, acc[i][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT2; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(w2h[nt], dh, acc[i][nt], 0, 0, 0);
+                } else if constexpr (H16) {
                     const f16x4 dh = f16x4{(half_t)fmaxf(d[0], 0.f), (half_t)fmaxf(d[1], 0.f), (half_t)fmaxf(d[2], 0.f), (half_t)fmaxf(d[3], 0.f)};
 #pragma unroll
                     for (int nt = 0; nt < NT2; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(w2h[nt], dh, acc[i][nt], 0, 0, 0);
@@ -399,12 +439,15 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
     constexpr int MTRW = (MTR + NWP - 1) / NWP, MTOW = (MTO + NWC - 1) / NWC;
     constexpr int XP = CIN + 4;
     constexpr int EPL = mres_epl(MTR);
-    constexpr bool H16 = sizeof(T) == 2;  // fp16 storage: the pointwise GEMMs run on v_mfma_f32_16x16x16_f16 (4 k-steps each)
+    constexpr bool X3 = is_x3<T>::value;  // fp32 storage, split-operand fp16 MFMAs (see mres_kernel)
+    constexpr bool H16 = sizeof(T) == 2 || X3;  // the pointwise GEMMs run on v_mfma_f32_16x16x16_f16 (4 k-steps each)
+    constexpr int WM = X3 ? 2 : 1;
     constexpr int KS1 = mres_ksteps(CIN), NB1 = CIN / 16, NT2 = (COUT + 15) / 16, NCH = (CEXP + 15) / 16;
     constexpr int NK1 = (KS1 + 3) / 4;    // f16 MFMAs per expansion tile
-    constexpr int OFF_B1 = H16 ? NK1 * 128 : KS1 * 64, OFF_WD = OFF_B1 + 16, OFF_BD = OFF_WD + 144, OFF_W2 = OFF_BD + 16;
-    constexpr int CHUNK = OFF_W2 + (H16 ? NT2 * 128 : 4 * NT2 * 64);
+    constexpr int OFF_B1 = H16 ? WM * NK1 * 128 : KS1 * 64, OFF_WD = OFF_B1 + 16, OFF_BD = OFF_WD + 144, OFF_W2 = OFF_BD + 16;
+    constexpr int CHUNK = OFF_W2 + (H16 ? WM * NT2 * 128 : 4 * NT2 * 64);
     static_assert((TH * TW) % 16 == 0 && CIN % 8 == 0 && COUT % 4 == 0, "shape");
+    static_assert(CHUNK == mres_chunk_floats(CIN, COUT, wmode_of<T>()), "pack layout");
     static_assert(!RES || CIN == COUT, "residual needs same shape");
     static_assert(MTRW * 4 <= 64, "in-image mask bits");
     extern __shared__ __attribute__((aligned(16))) float mres_smem[];
@@ -456,16 +499,29 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
                 a1[i][NB1 * 4 + 0] = t.x; a1[i][NB1 * 4 + 1] = t.y;
             }
         }
+        f16x4 a1h[X3 ? MTRW : 1][NK1], a1l[X3 ? MTRW : 1][NK1];   // split once per block
+        if constexpr (X3) {
+#pragma unroll
+            for (int i = 0; i < MTRW; ++i)
+#pragma unroll
+                for (int k = 0; k < NK1; ++k)
+                    split_f16x4(a1[i][4 * k], a1[i][4 * k + 1], 4 * k + 2 < KS1 ? a1[i][(4 * k + 2) % KS1] : 0.f,
+                                4 * k + 3 < KS1 ? a1[i][(4 * k + 3) % KS1] : 0.f, a1h[i][k], a1l[i][k]);
+        }
 #pragma unroll 1
         for (int s = 0; s <= NCH; ++s) {
             if (s < NCH) {
                 const float* wc = WL + s * CHUNK;
                 float* Eb = E + (s & 1) * 16 * EPL;
                 float w1f[KS1];
-                f16x4 w1h[NK1];
+                f16x4 w1h[NK1], w1l[X3 ? NK1 : 1];
                 if constexpr (H16) {
 #pragma unroll
                     for (int k = 0; k < NK1; ++k) w1h[k] = reinterpret_cast<const f16x4*>(wc)[k * 64 + lane];
+                    if constexpr (X3) {
+#pragma unroll
+                        for (int k = 0; k < NK1; ++k) w1l[k] = reinterpret_cast<const f16x4*>(wc)[(NK1 + k) * 64 + lane];
+                    }
                 } else {
 #pragma unroll
                     for (int k = 0; k < KS1; ++k) w1f[k] = wc[k * 64 + lane];
@@ -476,7 +532,15 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
                     const int mt = wave + i * NWP;
                     if (i < MTRW - 1 || mt < MTR) {
                         f32x4 cf = f32x4{b1.x, b1.y, b1.z, b1.w};   // bias as the C operand
-                        if constexpr (H16) {
+                        if constexpr (X3) {
+#pragma unroll
+                            for (int k = 0; k < NK1; ++k) {
+                                cf = __builtin_amdgcn_mfma_f32_16x16x16f16(w1l[k], a1h[i][k], cf, 0, 0, 0);
+                                cf = __builtin_amdgcn_mfma_f32_16x16x16f16(w1h[k], a1l[i][k], cf, 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int k = 0; k < NK1; ++k) cf = __builtin_amdgcn_mfma_f32_16x16x16f16(w1h[k], a1h[i][k], cf, 0, 0, 0);
+                        } else if constexpr (H16) {
 #pragma unroll
                             for (int k = 0; k < NK1; ++k) {
                                 const f16x4 ah = f16x4{(half_t)a1[i][4 * k], (half_t)a1[i][4 * k + 1],
@@ -543,10 +607,14 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
                 for (int t = 0; t < 9; ++t) wd[t] = *reinterpret_cast<const float4*>(wc + OFF_WD + t * 16 + 4 * q);
                 const float4 bd = *reinterpret_cast<const float4*>(wc + OFF_BD + 4 * q);
                 float w2f[4][NT2];
-                f16x4 w2h[NT2];
+                f16x4 w2h[NT2], w2l[X3 ? NT2 : 1];
                 if constexpr (H16) {
 #pragma unroll
                     for (int nt = 0; nt < NT2; ++nt) w2h[nt] = reinterpret_cast<const f16x4*>(wc + OFF_W2)[nt * 64 + lane];
+                    if constexpr (X3) {
+#pragma unroll
+                        for (int nt = 0; nt < NT2; ++nt) w2l[nt] = reinterpret_cast<const f16x4*>(wc + OFF_W2)[(NT2 + nt) * 64 + lane];
+                    }
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -580,7 +648,16 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
                             d[2] = fmaf(v.z, w.z, d[2]); d[3] = fmaf(v.w, w.w, d[3]);
                         }
 #endif
-                        if constexpr (H16) {
+                        if constexpr (X3) {
+                            f16x4 dh, dl;
+                            split_f16x4(relu_bits(d[0]), relu_bits(d[1]), relu_bits(d[2]), relu_bits(d[3]), dh, dl);
+#pragma unroll
+                            for (int nt = 0; nt < NT2; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(w2l[nt], dh, acc[i][nt], 0, 0, 0);
+#pragma unroll
+                            for (int nt = 0; nt < NT2; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(w2h[nt], dl, acc[i][nt], 0, 0, 0);
+#pragma unroll
+                            for (int nt = 0; nt < NT2; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(w2h[nt], dh, acc[i][nt], 0, 0, 0);
+                        } else if constexpr (H16) {
                             const f16x4 dh = f16x4{(half_t)fmaxf(d[0], 0.f), (half_t)fmaxf(d[1], 0.f), (half_t)fmaxf(d[2], 0.f),
                                                    (half_t)fmaxf(d[3], 0.f)};
 #pragma unroll
@@ -640,7 +717,7 @@ static int launch_mres_pc_t(MresArgs a, int N, hipStream_t s)
     a.tiles_x = (a.W + TW - 1) / TW;
     constexpr int MTR = ((TH + 2) * (TW + 2) + 15) / 16;
     constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 2 * 16 * mres_epl(MTR) +
-                            ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT, sizeof(T) == 2) + COUT + 3) & ~3)) * sizeof(float);
+                            ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT, wmode_of<T>()) + COUT + 3) & ~3)) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done[YF_MAX_DEVICES] = {};
     const int dev = current_device();
@@ -666,7 +743,7 @@ static int launch_mres_t(MresArgs a, int N, hipStream_t s)
     if (a.nblk > 1) return -4;  // chains: producer/consumer kernel only
     constexpr int MTR = (((TH - 1) * S + 3) * ((TW - 1) * S + 3) + 15) / 16;
     constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 16 * mres_epl(MTR, S) +
-                            ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT, sizeof(T) == 2) + COUT + 3) & ~3)) * sizeof(float);
+                            ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT, wmode_of<T>()) + COUT + 3) & ~3)) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done[YF_MAX_DEVICES] = {};
     const int dev = current_device();
@@ -707,6 +784,7 @@ int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArg
 #define MR(ci, ce, co, rs, st, th, tw, np, nw)                                                                    \
     if (cin == ci && cexp == ce && cout == co && res == rs && stride == st)                                       \
         return dtype == DT_F16 ? launch_mres_any<ci, ce, co, rs, st, th, tw, np, nw, half_t>(a, N, s)              \
+             : dtype == DT_F16X3 ? launch_mres_any<ci, ce, co, rs, st, th, tw, np, nw, x3_t>(a, N, s)              \
                                : launch_mres_any<ci, ce, co, rs, st, th, tw, np, nw, float>(a, N, s);
     YF_MRES_SHAPES(MR)
 #undef MR
@@ -734,16 +812,17 @@ bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride, bool rel
 
 // Host-side weight stream of one block: NCH chunks of [W1 frags | b1 | wd 9x16 | bd | W2 frags], then b2.
 // h16: the fragments are f16x4 per lane (one v_mfma_f32_16x16x16_f16 per 4 k-steps); b1 / wd / bd / b2 stay fp32.
-size_t mres_packed_floats(int cin, int cexp, int cout, bool h16)
+size_t mres_packed_floats(int cin, int cexp, int cout, int wmode)
 {
-    return (((size_t)((cexp + 15) / 16) * mres_chunk_floats(cin, cout, h16) + cout) + 3) & ~(size_t)3;
+    return (((size_t)((cexp + 15) / 16) * mres_chunk_floats(cin, cout, wmode) + cout) + 3) & ~(size_t)3;
 }
 
 void mres_pack_weights(const float* w1 /*[cin][cexp]*/, const float* b1, const float* wd /*[9][cexp]*/, const float* bd,
-                       const float* w2 /*[cexp][cout]*/, const float* b2, int cin, int cexp, int cout, float* out, bool h16)
+                       const float* w2 /*[cexp][cout]*/, const float* b2, int cin, int cexp, int cout, float* out, int wmode)
 {
+    const bool h16 = wmode != WM_F32, x3 = wmode == WM_F16X3;
     const int KS1 = mres_ksteps(cin), NB1 = cin / 16, NK1 = (KS1 + 3) / 4, NT2 = (cout + 15) / 16, NCH = (cexp + 15) / 16;
-    const int CH = mres_chunk_floats(cin, cout, h16);
+    const int CH = mres_chunk_floats(cin, cout, wmode);
     for (int c = 0; c < NCH; ++c) {
         float* o = out + (size_t)c * CH;
         auto ch_ok = [&](int ch) { return c * 16 + ch < cexp; };
@@ -758,8 +837,12 @@ void mres_pack_weights(const float* w1 /*[cin][cexp]*/, const float* b1, const f
             uint16_t* o16 = reinterpret_cast<uint16_t*>(o);
             for (int m = 0; m < NK1; ++m)
                 for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 4; ++j) o16[(m * 64 + lane) * 4 + j] = f32_to_f16_bits(w1_at(4 * m + j, lane));
-            o += NK1 * 128;
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = w1_at(4 * m + j, lane);
+                        o16[(m * 64 + lane) * 4 + j] = f32_to_f16_bits(v);
+                        if (x3) o16[((NK1 + m) * 64 + lane) * 4 + j] = f16_lo_bits(v);
+                    }
+            o += (x3 ? 2 : 1) * NK1 * 128;
         } else {
             for (int s = 0; s < KS1; ++s)
                 for (int lane = 0; lane < 64; ++lane) o[s * 64 + lane] = w1_at(s, lane);
@@ -780,7 +863,11 @@ void mres_pack_weights(const float* w1 /*[cin][cexp]*/, const float* b1, const f
             uint16_t* o16 = reinterpret_cast<uint16_t*>(o);
             for (int nt = 0; nt < NT2; ++nt)
                 for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 4; ++j) o16[(nt * 64 + lane) * 4 + j] = f32_to_f16_bits(w2_at(j, nt, lane));
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = w2_at(j, nt, lane);
+                        o16[(nt * 64 + lane) * 4 + j] = f32_to_f16_bits(v);
+                        if (x3) o16[((NT2 + nt) * 64 + lane) * 4 + j] = f16_lo_bits(v);
+                    }
         } else {
             for (int j = 0; j < 4; ++j)
                 for (int nt = 0; nt < NT2; ++nt)

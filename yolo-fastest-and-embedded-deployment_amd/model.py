@@ -110,6 +110,9 @@ class YoloFastest(nn.Module):
         # fp16 MFMA, fp32 accumulate).  `model.half()` selects fp16 like it would for the reference module; setting
         # `model.storage_dtype = torch.float16` keeps the fp32 master weights for the BN fold (more accurate).
         self.storage_dtype = torch.float32
+        # "f16x3": fp32 storage, the pointwise GEMMs on the fp16 matrix pipe with split (hi + lo) operands -- as accurate as fp32
+        # (yf_create_ex dtype 2; include/yolo_fastest_hip.h).  None: decided by storage_dtype / the parameters' dtype.
+        self.precision = None
 
     # -- weight packing -------------------------------------------------------------------------
     def _invalidate(self):
@@ -163,7 +166,11 @@ class YoloFastest(nn.Module):
 
     def _dtype_code(self):
         p = self.conv0[0].weight
-        return 1 if (self.storage_dtype == torch.float16 or p.dtype == torch.float16) else 0
+        if self.precision not in (None, "f32", "f16", "f16x3"):
+            raise ValueError("precision must be None, 'f32', 'f16' or 'f16x3'")
+        if self.precision == "f16x3":
+            return 2
+        return 1 if (self.precision == "f16" or self.storage_dtype == torch.float16 or p.dtype == torch.float16) else 0
 
     def engine(self, H, W, N, device):
         key = (H, W, device.index if device.index is not None else torch.cuda.current_device(), self._dtype_code())
@@ -257,8 +264,10 @@ class YoloFastest(nn.Module):
             name = ctypes.create_string_buffer(512)
             b, fm, fv = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
             _lib.check(e.lib.yf_op_info_ex(e.handle, i, name, 512, ctypes.byref(b), ctypes.byref(fm), ctypes.byref(fv)))
+            kdt = ctypes.c_int()
+            _lib.check(e.lib.yf_op_dtype(e.handle, i, ctypes.byref(kdt)))
             out.append(dict(name=name.value.decode(), ms=acc[i], algorithmic_bytes=b.value * N, flops=(fm.value + fv.value) * N,
-                            mfma_flops=fm.value * N, valu_flops=fv.value * N))
+                            mfma_flops=fm.value * N, valu_flops=fv.value * N, kernel_dtype=("f32", "f16", "f16x3")[kdt.value]))
         return out
 
     def probe(self, x, name):
