@@ -161,6 +161,7 @@ def main():
                          "added to the heads of the noise frames, to stress decode + sort + NMS; use with --res 512 --batch 64 --kmax 1024")
     ap.add_argument("--kmax", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra f16x3 measurement of the same workload")
     ap.add_argument("--dump-ops", default=None, help="write the launch names of one forward pass to this JSON file")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -277,6 +278,32 @@ def main():
     fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     post_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
 
+    # The same workload on the split-operand fp16-MFMA variant (fp32 storage, fp32-class accuracy), measured in the SAME
+    # run with the same loop: an extra object of the JSON line, never the headline `value` (which is the dtype named by --dtype).
+    variant = None
+    if world == 1 and args.dtype == "f32" and not args.no_variants and not args.dense:
+        m2 = yf.YoloFastest(io).to(dev).eval()
+        m2.chunk, m2.lanes, m2.precision = args.chunk, args.lanes, "f16x3"
+        m2.load_state_dict(torch.load(os.path.join(PKG, "assets", "weights", wname), map_location=dev))
+        post2 = yf.YOLO_post_process(io["conf_thre"], io["nms_thre"], io["num_anchors"], io["num_cls"], io["anchors"], io["input_shape"]).bind(m2)
+        with torch.no_grad():
+            for _ in range(args.warmup):
+                raw2 = post2.detect_raw(m2(x), kmax=args.kmax)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                p2 = m2(x)
+                raw2 = post2.detect_raw(p2, kmax=args.kmax)
+            torch.cuda.synchronize(dev)
+            e2 = time.perf_counter() - t1
+            p1 = model(x)
+        same = all(torch.equal(raw[k], raw2[k]) for k in ("counts", "boxes", "cls", "src"))
+        variant = {"dtype": "f16x3", "what": "fp32 storage, pointwise/dense GEMMs on the fp16 matrix pipe with split (hi + lo) operands, fp32 accumulate",
+                   "value": round(args.batch * args.steps / e2, 1), "unit": "frames/s", "ms_per_step": round(1e3 * e2 / args.steps, 4),
+                   "max_abs_logit_diff_vs_f32_on_this_batch": round(max(float((p1[0] - p2[0]).abs().max()), float((p1[1] - p2[1]).abs().max())), 6),
+                   "detections_identical_to_f32_on_this_batch": bool(same)}
+        del m2, post2
+
     if rank == 0:
         counts = raw["counts"].cpu().numpy()
         fps = n_total * args.steps / elapsed
@@ -363,6 +390,8 @@ def main():
                                               "hbm_GBps": None if o["roof"]["hbm_gbs"] is None else round(o["roof"]["hbm_gbs"])}
                                              for o in ops]},
         }
+        if variant is not None:
+            out["variants"] = [variant]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
