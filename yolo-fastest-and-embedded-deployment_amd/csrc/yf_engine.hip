@@ -200,7 +200,7 @@ struct Builder {
         int H = pre ? ti.H / 2 : ti.H, W = pre ? ti.W / 2 : ti.W;  // expansion resolution
         int st = kLayers[o.l_dw].stride;
         o.in1 = in; o.in2 = -1; o.res = res ? in : -1; o.omode = 0;
-        if (!pre && yf::mres_has_kernel(kLayers[o.l_exp].cin, kLayers[o.l_exp].cout, kLayers[o.l_proj].cout, res, st, kLayers[o.l_proj].relu != 0))
+        if (!pre && yf::mres_has_kernel(kLayers[o.l_exp].cin, kLayers[o.l_exp].cout, kLayers[o.l_proj].cout, res, st, kLayers[o.l_proj].relu != 0, dtype))
             o.type = OP_MRES;  // both pointwise convs on the matrix cores
         o.out = add_tensor(out_name, kLayers[o.l_proj].cout, H / st, W / st);
         e->ops.push_back(o);
@@ -228,7 +228,7 @@ struct Builder {
     {
         const LayerSpec &LA = kLayers[find_layer(a)], &LC = kLayers[find_layer(c)];
         const int st = kLayers[find_layer(b)].stride;
-        if (!fused || !yf::mres_has_kernel(LA.cin, LA.cout, LC.cout, false, st, LC.relu != 0)) {
+        if (!fused || !yf::mres_has_kernel(LA.cin, LA.cout, LC.cout, false, st, LC.relu != 0, dtype)) {
             *expanded = unit(a, x);
             return unit(c, unit(b, *expanded));
         }
@@ -244,12 +244,14 @@ struct Builder {
         return unit(c, unit(b, unit(a, x)));
     }
     bool fused = false;
+    int dtype = yf::DT_F32;   // the engine's: some blocks are planned on a different kernel per dtype (mres_has_kernel)
 };
 
-void build_plan(Plan* e, bool fused)
+void build_plan(Plan* e, bool fused, int dtype)
 {
     Builder b{e};
     b.fused = fused;
+    b.dtype = dtype;
     int x = b.add_tensor("input", 1, e->H, e->W, BUF_INPUT);
     if (fused) {
         x = b.fused_block("conv0", "conv1_2", "conv1_3", "conv1_4", x, "conv1_4", false);
@@ -583,7 +585,7 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
     }
     for (int f = 0; f < 2; ++f) {
         e->plans[f].H = H; e->plans[f].W = W;
-        build_plan(&e->plans[f], f == 1);
+        build_plan(&e->plans[f], f == 1, dtype);
     }
     e->head_l_elems = 24u * (H / 16) * (W / 16);
     e->head_s_elems = 24u * (H / 32) * (W / 32);

@@ -166,7 +166,7 @@ struct MresArgs {
     long wstride;      // floats between the packed weight streams of consecutive chained blocks
 };
 int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArgs& a, int N, hipStream_t s, int dtype = DT_F32);
-bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride = 1, bool relu_out = false);
+bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride = 1, bool relu_out = false, int dtype = DT_F32);
 bool mres_can_chain(int cin, int cexp, int cout, int H, int W);  // relu_out: ReLU after the projection
 size_t mres_packed_floats(int cin, int cexp, int cout, int wmode = WM_F32);
 void mres_pack_weights(const float* w1, const float* b1, const float* wd, const float* bd, const float* w2, const float* b2,

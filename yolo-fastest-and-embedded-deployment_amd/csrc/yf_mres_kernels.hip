@@ -768,6 +768,7 @@ static int launch_mres_t(MresArgs a, int N, hipStream_t s)
     MR(16, 96, 16, true, 1, 16, 20, 0, 8)   /* res3_3 .. res3_6         @ H/8  */         \
     MR(16, 96, 24, false, 2, 8, 10, 0, 8)   /* conv3_5/3_6/4_1          H/8 -> H/16 */    \
     MR(8, 32, 8, false, 2, 8, 10, 0, 8)     /* conv2_2/2_3/3_1          H/4 -> H/8  */    \
+    MR(8, 32, 8, true, 1, 16, 20, 0, 8)     /* res2_1, res2_2 @ H/4: planned for DT_F16X3 only (fp32: the VALU block is as fast) */ \
     MR(24, 136, 48, false, 2, 8, 10, 0, 8)  /* conv4_2/4_3/5_1 (+ conv4_2 written) H/16 -> H/32 */ \
     MR(24, 136, 24, true, 1, 16, 20, 8, 8)  /* res4_1 .. res4_4         @ H/16 */         \
     MR(48, 224, 48, true, 1, 8, 10, 8, 5)   /* res5_1 .. res5_5         @ H/32 */
@@ -801,8 +802,11 @@ bool mres_can_chain(int cin, int cexp, int cout, int H, int W)
     return false;
 }
 
-bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride, bool relu_out)
+bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride, bool relu_out, int dtype)
 {
+    // the 8/32 residual blocks at stride 4: on fp32 MFMAs this kernel only ties the VALU block kernel (61.5 vs 64 us alone, nothing end
+    // to end); with split-operand fp16 MFMAs, which run beside the depthwise VALU work, it wins
+    if (cin == 8 && cexp == 32 && cout == 8 && res && stride == 1) return dtype == DT_F16X3 && !relu_out;
 #define MR(ci, ce, co, rs, st, th, tw, np, nw) \
     if (cin == ci && cexp == ce && cout == co && res == rs && stride == st) return relu_out == mres_relu_out(ci, ce, co, st);
     YF_MRES_SHAPES(MR)
