@@ -159,6 +159,7 @@ def main():
     ap.add_argument("--dense", action="store_true",
                     help="SURVEY.md 8(d) config 5: synthetic dense head logits (~1200 candidates, ~260 survivors per 640x512 frame) are "
                          "added to the heads of the noise frames, to stress decode + sort + NMS; use with --res 512 --batch 64 --kmax 1024")
+    ap.add_argument("--branches", type=int, default=1, choices=[0, 1], help="1: the small head's launches on a side stream of their lane (default)")
     ap.add_argument("--kmax", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra f16x3 measurement of the same workload")
@@ -204,6 +205,7 @@ def main():
     elif args.dtype == "f16x3":
         model.precision = "f16x3"
     model.lanes = args.lanes
+    model.branches = args.branches
     model.load_state_dict(torch.load(os.path.join(PKG, "assets", "weights", wname), map_location=dev))
     post = yf.YOLO_post_process(io["conf_thre"], io["nms_thre"], io["num_anchors"], io["num_cls"], io["anchors"],
                                 io["input_shape"]).bind(model)
@@ -283,7 +285,7 @@ def main():
     variant = None
     if world == 1 and args.dtype == "f32" and not args.no_variants and not args.dense:
         m2 = yf.YoloFastest(io).to(dev).eval()
-        m2.chunk, m2.lanes, m2.precision = args.chunk, args.lanes, "f16x3"
+        m2.chunk, m2.lanes, m2.branches, m2.precision = args.chunk, args.lanes, args.branches, "f16x3"
         m2.load_state_dict(torch.load(os.path.join(PKG, "assets", "weights", wname), map_location=dev))
         post2 = yf.YOLO_post_process(io["conf_thre"], io["nms_thre"], io["num_anchors"], io["num_cls"], io["anchors"], io["input_shape"]).bind(m2)
         with torch.no_grad():
@@ -368,7 +370,7 @@ def main():
                                    f"(BASELINE.json configs[1])" if args.res == 256 and args.batch == 256 and args.dtype == "f32" and args.frames == "noise" else
                                    f"YOLO-Fastest {W}x{H} batch={args.batch} {args.dtype} per GPU, {args.frames} frames"
                                    + (", dense synthetic head logits (SURVEY.md 8(d) config 5)" if args.dense else ""),
-                       "global_batch": n_total, "weights": wname, "kmax": args.kmax, "chunk": args.chunk, "lanes": args.lanes,
+                       "global_batch": n_total, "weights": wname, "kmax": args.kmax, "chunk": args.chunk, "lanes": args.lanes, "branches": args.branches,
                        "world_size": world,
                        "parallelism": f"dp{world} (frames sharded, one RCCL all-gather of box records)" if world > 1 else "single GPU",
                        "survivors_per_frame_mean": round(float(np.clip(counts, 0, None).mean()), 3)},

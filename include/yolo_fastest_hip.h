@@ -164,6 +164,8 @@ int yf_num_launches(yf_handle h, int *out);       /* kernel launches one yf_forw
 int yf_set_chunk(yf_handle h, int frames);        /* frames per pass of the layer chain (0 = whole batch) */
 int yf_set_lanes(yf_handle h, int lanes);          /* 1..4: chunks of the batch (yf_set_chunk) run on this many concurrent
                                                      streams, forked from / joined to the caller's stream by events    */
+int yf_set_branches(yf_handle h, int on);         /* 1 (default): the small head's launches (conv5_3 .. head_5) run on a side stream of
+                                                     their lane, beside the large head's (deconv5_1 .. head_4); 0 = in line */
 int yf_set_fusion(yf_handle h, int level);        /* 1 (default) = block-fused kernels; 0 = one launch per layer, every
                                                      named tensor probe-able (bring-up / layer-wise parity tests)    */
 

@@ -910,3 +910,29 @@ def test_two_models_of_different_sizes_in_one_process(yf, models, golden, dev):
     finally:
         m256.chunk = 0
         m256.engine(256, 320, 3, dev)
+
+
+def test_small_head_branch_stream_is_identical(yf, golden, dev):
+    """The small head's launches run on a side stream of their lane beside the large head's (yf_set_branches, default on): same bits as
+    issuing them in line -- one lane, two lanes, several groups of chunks, through yf_detect, repeated (a slot shared between the two
+    concurrent branches would show up as a difference sooner or later)."""
+    io = yf.io_params_for(256)
+    g = golden("golden_256")
+    x = _x(np.tile(g["input_u8"], (7, 1, 1))[:132], dev)
+    outs = {}
+    for lanes, chunk, branches in ((1, 0, 0), (1, 0, 1), (2, 0, 1), (2, 33, 1), (2, 20, 0)):
+        m = yf.YoloFastest(io).to(dev).eval()
+        m.lanes, m.chunk, m.branches = lanes, chunk, branches
+        m.load_state_dict(torch.load(WEIGHTS[256], map_location=dev))
+        post = yf.YOLO_post_process(io["conf_thre"], io["nms_thre"], io["num_anchors"], io["num_cls"], io["anchors"], io["input_shape"]).bind(m)
+        with torch.no_grad():
+            for rep in range(3):
+                hl, hs = m(x)
+                raw = post.detect_raw_from_input(x, kmax=16)
+                valid = torch.arange(16, device=dev)[None, :] < raw["counts"][:, None]      # entries beyond a frame's count are unwritten
+                key = (hl, hs, raw["counts"], raw["boxes"] * valid[:, :, None], raw["src"] * valid)
+                if "ref" not in outs:
+                    outs["ref"] = key
+                for a, b in zip(outs["ref"], key):
+                    assert torch.equal(a, b), (lanes, chunk, branches, rep)
+                assert torch.equal(raw["head_large"], hl) and torch.equal(raw["head_small"], hs)

@@ -99,6 +99,8 @@ struct Op {
     int nblk = 1;        // OP_MRES: > 1 = a chain of residual blocks in one launch; block k's layers are l_exp/l_dw/l_proj + 3k
     long wstride = 0;    //          floats between the packed weight streams of consecutive chained blocks
     long mfma_off = -1;  // >= 0: pointwise layer runs on the matrix cores; offset of its packed B fragments
+    int branch = 0;      // 1: the small head's launches (conv5_3 .. head_5) -- independent of the large head's once conv5_2 exists, so a
+                         // forward pass issues them on a side stream of the lane, beside deconv5_1 .. head_4 (yolo_fastest.py:200-216)
     int kdt = 0;         // dtype handed to this op's kernel launcher (yf::DT_*): the engine's, or DT_F32 where a DT_F16X3 engine has
                          // no split-operand instantiation of the kernel (same fp32 storage, exact fp32 arithmetic instead)
 };
@@ -130,6 +132,10 @@ struct yf_engine {
     int lanes = 2;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    // per lane: the side stream of the small-head branch and its fork / join events
+    int branches = 1;                 // 0: issue the small head's launches in line (yf_set_branches)
+    hipStream_t bside[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_bfork[4] = {nullptr, nullptr, nullptr, nullptr}, ev_bjoin[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t head_l_elems = 0, head_s_elems = 0;
     const Plan& plan() const { return plans[fusion]; }
     size_t frame_floats_max() const { return plans[0].frame_floats > plans[1].frame_floats ? plans[0].frame_floats : plans[1].frame_floats; }
@@ -284,8 +290,11 @@ void build_plan(Plan* e, bool fused, int dtype)
     b.fused = false;
     int conv5_2 = b.unit("conv5_2", x);
     b.fused = fused_deep;
+    const size_t br0 = e->ops.size();
     x = b.dwpw("conv5_3", "conv5_4", nullptr, conv5_2, nullptr, 0);
     b.dwpw("conv5_5", "conv5_6", "head_5", x, "head_small", BUF_HEAD_SMALL);
+    if (fused)
+        for (size_t i = br0; i < e->ops.size(); ++i) e->ops[i].branch = 1;
     b.fused = false;
     int d = b.unit("deconv5_1", conv5_2);
     x = b.unit("conv4_1_1", conv4_2, nullptr, d);  // torch.cat((conv4_2, deconv5_1), 1), yolo_fastest.py:209
@@ -299,6 +308,14 @@ void build_plan(Plan* e, bool fused, int dtype)
         const Op& o = e->ops[i];
         for (int t : {o.in1, o.in2, o.res})
             if (t >= 0) e->tensors[t].last_use = (int)i;
+    }
+    // tensors the side-stream branch reads or writes stay live to the end of the pass: the main stream's later launches run
+    // CONCURRENTLY with the branch and must not be handed their slots
+    for (size_t i = 0; i < e->ops.size(); ++i) {
+        const Op& o = e->ops[i];
+        if (!o.branch) continue;
+        for (int t : {o.in1, o.in2, o.res, o.out})
+            if (t >= 0) e->tensors[t].last_use = (int)e->ops.size() - 1;
     }
     // slot assignment: smallest free slot that fits, else grow the largest free one, else a new slot
     std::vector<int> free_slots;
@@ -397,15 +414,35 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
     // are issued OP-MAJOR (op k of every lane, then op k + 1): issued lane-major, the second lane's first kernel was queued
     // only after the first lane's 33 launches had gone through the host (~0.15 ms of a 1.3 ms step), and the lanes overlapped
     // for little more than half of the step (rocprofv3 kernel trace, profiles/).
+    // The small head's launches (Op::branch) go to a side stream of the lane, forked after conv5_2 and joined before the lane's
+    // post-process: two under-filled launch chains (80 and 320 pixels per frame) run beside each other instead of in sequence.
+    // Not while profiling / probing (one stream, one launch at a time).
+    bool use_branch = e->branches && !prof && !probe && e->fusion == 1;
+    if (use_branch && lanes > 1) {
+        // Under stream capture a branch forked from a lane's side stream is a fork nested in a fork; hipStreamEndCapture of ROCm 7.2
+        // crashes on that topology (tools/cap_try.py 2 1), so a captured multi-lane pass issues the small head in line.
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s_main, &st) != hipSuccess || st != hipStreamCaptureStatusNone) use_branch = false;
+    }
     for (int g0 = 0; g0 < nchunks; g0 += lanes) {
       const int gcount = (nchunks - g0) < lanes ? (nchunks - g0) : lanes;
       size_t op_idx = 0;
+      bool forked[4] = {false, false, false, false};
       if (prof) HIP_OK(hipEventRecord(prof->ev[0], s_main));
-      for (const Op& o : P.ops) {
+      for (size_t oi = 0; oi < P.ops.size(); ++oi) {
+       const Op& o = P.ops[oi];
        for (int lane_id = 0; lane_id < gcount; ++lane_id) {
         const int f0 = (g0 + lane_id) * cf;
         const int n = (N - f0) < cf ? (N - f0) : cf;
         s = lane_id == 0 ? s_main : e->side[lane_id - 1];
+        if (use_branch && o.branch) {
+            if (!forked[lane_id]) {   // everything queued on the lane so far (conv5_2 included) precedes the branch
+                HIP_OK(hipEventRecord(e->ev_bfork[lane_id], s));
+                HIP_OK(hipStreamWaitEvent(e->bside[lane_id], e->ev_bfork[lane_id], 0));
+                forked[lane_id] = true;
+            }
+            s = e->bside[lane_id];
+        }
         char* lane_base = base + P.frame_floats * (size_t)cf * esz * lane_id;
         auto ptr = [&](int t) -> float* {
             const Tensor& T = P.tensors[t];
@@ -483,6 +520,12 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
         }
        }
       }
+      for (int lane_id = 0; lane_id < gcount; ++lane_id)   // join the small-head branch back into its lane
+        if (forked[lane_id]) {
+            hipStream_t sl = lane_id == 0 ? s_main : e->side[lane_id - 1];
+            HIP_OK(hipEventRecord(e->ev_bjoin[lane_id], e->bside[lane_id]));
+            HIP_OK(hipStreamWaitEvent(sl, e->ev_bjoin[lane_id], 0));
+        }
       // decode + NMS of each chunk on ITS lane (yf_detect): frames are independent, so a lane's post-process overlaps the other
       // lane's tail instead of running after the join
       if (post)
@@ -680,6 +723,14 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
         (void)yf_destroy(e);
         return fail(YF_E_HIP, "hipEventCreate failed");
     }
+    for (int l = 0; l < 4; ++l) {
+        if (hipStreamCreateWithFlags(&e->bside[l], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_bfork[l], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_bjoin[l], hipEventDisableTiming) != hipSuccess) {
+            (void)yf_destroy(e);
+            return fail(YF_E_HIP, "hipStreamCreate/hipEventCreate (branch) failed");
+        }
+    }
     *out = e;
     return YF_OK;
 }
@@ -693,6 +744,11 @@ int yf_destroy(yf_handle h)
         if (h->ev_join[l]) (void)hipEventDestroy(h->ev_join[l]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (int l = 0; l < 4; ++l) {
+        if (h->bside[l]) (void)hipStreamDestroy(h->bside[l]);
+        if (h->ev_bfork[l]) (void)hipEventDestroy(h->ev_bfork[l]);
+        if (h->ev_bjoin[l]) (void)hipEventDestroy(h->ev_bjoin[l]);
+    }
     (void)hipFree(h->d_weights);
     (void)hipFree(h->d_wmfma);
     delete h;
@@ -943,6 +999,13 @@ int yf_set_lanes(yf_handle h, int lanes)
 {
     if (!h || lanes < 1 || lanes > 4) return fail(YF_E_INVALID, "lanes must be 1..4");
     h->lanes = lanes;
+    return YF_OK;
+}
+
+int yf_set_branches(yf_handle h, int on)
+{
+    if (!h || on < 0 || on > 1) return fail(YF_E_INVALID, "branches must be 0 or 1");
+    h->branches = on;
     return YF_OK;
 }
 

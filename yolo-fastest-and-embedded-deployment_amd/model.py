@@ -44,7 +44,7 @@ class _Engine:
         self.dtype = dtype
         self.H, self.W, self.max_batch, self.device_index = H, W, max_batch, device_index
         self._ws = None
-        self.chunk, self.lanes = 0, 2     # the C side's defaults (yf_engine: chunk 0, lanes 2)
+        self.chunk, self.lanes, self.branches = 0, 2, 1     # the C side's defaults (yf_engine: chunk 0, lanes 2, branches on)
 
     def workspace(self, N, device):
         need = ctypes.c_size_t()
@@ -65,6 +65,10 @@ class _Engine:
 
     def set_fusion(self, level):
         _lib.check(self.lib.yf_set_fusion(self.handle, int(level)))
+
+    def set_branches(self, on):
+        _lib.check(self.lib.yf_set_branches(self.handle, int(on)))
+        self.branches = int(on)
 
     def close(self):
         if self.handle:
@@ -106,6 +110,7 @@ class YoloFastest(nn.Module):
         self.chunk = 0  # frames per pass of the layer chain (0 = whole batch); see yf_set_chunk
         self.fusion = 1  # 1 = block-fused kernels (default); 0 = one launch per layer (bring-up, all probes)
         self.lanes = 2   # concurrent streams over chunks of the batch (chunk 0 = one chunk per lane); see yf_set_lanes
+        self.branches = 1  # 1: the small head's launches run on a side stream beside the large head's; see yf_set_branches
         # activation storage / pointwise-GEMM operand type: torch.float32, or torch.float16 (BASELINE configs[2]: fp16 in HBM,
         # fp16 MFMA, fp32 accumulate).  `model.half()` selects fp16 like it would for the reference module; setting
         # `model.storage_dtype = torch.float16` keeps the fp32 master weights for the BN fold (more accurate).
@@ -189,6 +194,8 @@ class YoloFastest(nn.Module):
         if e.lanes != self.lanes:
             e.set_lanes(self.lanes)
         e.set_fusion(self.fusion)
+        if e.branches != self.branches:
+            e.set_branches(self.branches)
         return e
 
     def engine_on(self, device):
