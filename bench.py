@@ -9,7 +9,11 @@ as a child BEFORE it touches the GPU, relays rank 0's JSON line and exits with t
 GPUs -> non-zero exit and a message.  Launched by torch.distributed.run from outside (the driver), WORLD_SIZE must equal --gpus.
 
 A "step" = one pass of the hot path (model forward -> decode -> per-class NMS [-> all-gather of the decoded
-boxes when N > 1]) over one batch of synthetic frames that is already resident in HBM.
+boxes when N > 1]) over one batch of synthetic frames that is already resident in HBM.  By default TWO batches are in flight
+(--in-flight 2, yolo_fastest_amd.BatchPipeline): consecutive steps are issued round-robin on two HIP streams, each with its own
+engine, so a batch's late per-frame stages run beside the next batch's early machine-filling ones; all K steps (and exchanges)
+complete inside the timed region, `ms_per_step` is elapsed / K.  The one-step-at-a-time figure is reported beside it
+(`one_batch_in_flight`), as are the per-pass model / post-process times (`forward_chain.forward_ms`, `post_ms`).
 Workload at N = 1: BASELINE.json configs[1], "YOLO-Fastest 320x256 batch=256 fp32, synthetic frames"
 (u8 ~ Uniform{0..255} i.i.d., x = (u8-128)/255, seed = rank).  N > 1: the same per GPU (weak
 scaling, frames are independent units; one RCCL all-gather of the fixed-capacity box records).
@@ -149,7 +153,11 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--res", type=int, default=256, choices=[256, 512])
     ap.add_argument("--chunk", type=int, default=0, help="frames per pass of the layer chain (0 = whole batch)")
-    ap.add_argument("--lanes", type=int, default=2, help="concurrent streams over the chunks of the batch (1..4)")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="batches in flight: consecutive steps are issued round-robin on this many streams, each with its own engine "
+                         "(yolo_fastest_amd.BatchPipeline); 1 = one step at a time")
+    ap.add_argument("--lanes", type=int, default=0, help="concurrent streams over the chunks of ONE batch (1..4); 0 = 1 with several "
+                                                        "batches in flight, else 2")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f16x3"],
                     help="f16 = fp16 storage + single-operand fp16 MFMA; f16x3 = fp32 storage + split-operand fp16 MFMA (fp32-class accuracy: "
                          "BASELINE configs[2] within its stated 2e-2)")
@@ -159,7 +167,8 @@ def main():
     ap.add_argument("--dense", action="store_true",
                     help="SURVEY.md 8(d) config 5: synthetic dense head logits (~1200 candidates, ~260 survivors per 640x512 frame) are "
                          "added to the heads of the noise frames, to stress decode + sort + NMS; use with --res 512 --batch 64 --kmax 1024")
-    ap.add_argument("--branches", type=int, default=1, choices=[0, 1], help="1: the small head's launches on a side stream of their lane (default)")
+    ap.add_argument("--branches", type=int, default=-1, choices=[-1, 0, 1],
+                    help="1: the small head's launches on a side stream of their lane; -1 = 0 with several batches in flight, else 1")
     ap.add_argument("--kmax", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra f16x3 measurement of the same workload")
@@ -198,17 +207,6 @@ def main():
 
     io = yf.io_params_for(args.res)
     wname = {256: "yolo_fastest_256x320_epoch28.pth", 512: "yolo_fastest_512x640_epoch27.pth"}[args.res]
-    model = yf.YoloFastest(io).to(dev).eval()
-    model.chunk = args.chunk
-    if args.dtype == "f16":
-        model.storage_dtype = torch.float16
-    elif args.dtype == "f16x3":
-        model.precision = "f16x3"
-    model.lanes = args.lanes
-    model.branches = args.branches
-    model.load_state_dict(torch.load(os.path.join(PKG, "assets", "weights", wname), map_location=dev))
-    post = yf.YOLO_post_process(io["conf_thre"], io["nms_thre"], io["num_anchors"], io["num_cls"], io["anchors"],
-                                io["input_shape"]).bind(model)
     H, W = io["input_shape"][:2]
     g = torch.Generator(device="cpu").manual_seed(rank)
     if args.frames == "fixtures":
@@ -230,81 +228,114 @@ def main():
                 t[:, 4] = gg.normal(-1.0, 1.5, (3, h, w)); t[:, 5:8] = gg.normal(0.0, 2.0, (3, 3, h, w))
                 parts[i].append(t.reshape(24, h, w))
         syn = tuple(torch.from_numpy(np.stack(p)).to(dev) for p in parts)
+    in_flight = 1 if syn is not None else args.in_flight    # the dense field is spliced in between model and post-process: one at a time
+    lanes = args.lanes if args.lanes else (1 if in_flight > 1 else 2)
+    branches = args.branches if args.branches >= 0 else (0 if in_flight > 1 else 1)
 
-    def forward():
+    def make(dtype, lanes_, branches_):
+        m = yf.YoloFastest(io).to(dev).eval()
+        m.chunk, m.lanes, m.branches = args.chunk, lanes_, branches_
+        m.precision = dtype
+        m.load_state_dict(torch.load(os.path.join(PKG, "assets", "weights", wname), map_location=dev))
+        p = yf.YOLO_post_process(io["conf_thre"], io["nms_thre"], io["num_anchors"], io["num_cls"], io["anchors"], io["input_shape"]).bind(m)
+        return m, p
+
+    def forward(m):
         with torch.no_grad():
-            pred = model(x)
+            pred = m(x)
         if syn is not None:   # the net's own logits on noise are ~no detections: the synthetic field replaces them
             pred = (pred[0] * 0 + syn[0], pred[1] * 0 + syn[1])
         return pred
 
-    def step():
-        pred = forward()
-        raw = post.detect_raw(pred, kmax=args.kmax)
-        if world > 1:
-            raw = yfd.all_gather_detections(raw, n_total)
-        return raw
+    REC = ("counts", "boxes", "scores", "cls", "src")
 
-    for _ in range(args.warmup):
-        raw = step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    # HIP events on the stream the kernels are launched on (torch's current stream is the one handed to the C ABI)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    pending = None  # the exchange of step k runs on RCCL's stream while step k + 1 computes; all K exchanges end inside the timed region
-    for k in range(args.steps):
-        ev[k][0].record()
-        pred = forward()
-        ev[k][1].record()
-        raw = post.detect_raw(pred, kmax=args.kmax)
-        ev[k][2].record()
+    def timed(m, p, depth, steps, warmup, exchange):
+        """W untimed + K timed steps; a step = model -> decode -> NMS over the resident batch [-> all-gather].  depth > 1: consecutive
+        steps are issued round-robin on `depth` streams, each with its own engine (yolo_fastest_amd.BatchPipeline): a batch's late,
+        per-frame stages run beside the next batch's early, machine-filling ones.  Every step -- and every exchange -- completes
+        inside the timed region (device synchronisation + barrier on both sides).  Returns (seconds, last step's records)."""
+        pipe = yf.BatchPipeline(m, p, depth=depth, kmax=args.kmax, lanes=m.lanes, branches=m.branches) if depth > 1 else None
+        gather = (lambda out: yfd.all_gather_detections_async({k: out[k] for k in REC}, n_total)) if exchange else None
+
+        def run(n):
+            last, pend = None, []
+            for _ in range(n):
+                if pipe is not None:
+                    last = pipe.submit(x, then=gather)
+                    if gather is not None:
+                        pend.append(last.extra)
+                else:
+                    raw = p.detect_raw(forward(m), kmax=args.kmax)
+                    last = raw
+                    if gather is not None:
+                        pend.append(gather(raw))
+                while len(pend) > 2 * depth:     # the exchange of step k runs on RCCL's stream while later steps compute
+                    pend.pop(0).wait()
+            for h in pend:
+                h.wait()
+            if pipe is not None:
+                pipe.drain()
+                return last.synchronize()
+            return last
+
+        run(warmup)
+        torch.cuda.synchronize(dev)
         if world > 1:
-            if pending is not None:
-                gathered = pending.wait()
-            pending = yfd.all_gather_detections_async(raw, n_total)
-    if pending is not None:
-        raw = pending.wait()
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        raw = run(steps)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item()), raw
+
+    def same_detections(a, b):
+        if not torch.equal(a["counts"], b["counts"]):
+            return False
+        valid = torch.arange(a["cls"].shape[1], device=dev)[None, :] < a["counts"][:, None]
+        return all(torch.equal(a[k][valid], b[k][valid]) for k in ("boxes", "cls", "src"))
+
+    model, post = make(args.dtype, lanes, branches)
+    elapsed, raw = timed(model, post, in_flight, args.steps, args.warmup, world > 1)
+
+    # model / post-process split and the one-batch-at-a-time figure (two half-batch lanes, the small head on its side stream): measured
+    # after the headline's timed region, same process
+    m1, p1 = (model, post) if in_flight == 1 else make(args.dtype, 2, 1)
+    es = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    fwd_ms = post_ms = 0.0
+    for _ in range(3):
+        p1.detect_raw(forward(m1), kmax=args.kmax)
     torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
-    post_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    for _ in range(5):
+        es[0].record(); pred = forward(m1); es[1].record(); raw1 = p1.detect_raw(pred, kmax=args.kmax); es[2].record()
+        torch.cuda.synchronize(dev)
+        fwd_ms += es[0].elapsed_time(es[1]) / 5; post_ms += es[1].elapsed_time(es[2]) / 5
+    single = None
+    if in_flight > 1 and world == 1:
+        e1, r1 = timed(m1, p1, 1, args.steps, args.warmup, False)
+        single = {"in_flight": 1, "lanes": 2, "branches": 1, "value": round(args.batch * args.steps / e1, 1), "unit": "frames/s",
+                  "ms_per_step": round(1e3 * e1 / args.steps, 4), "detections_identical": bool(same_detections(raw, r1))}
 
     # The same workload on the split-operand fp16-MFMA variant (fp32 storage, fp32-class accuracy; DESIGN.md 4), measured in the SAME
     # run with the same loop: an extra object of the JSON line, never the headline `value` (which is the dtype named by --dtype).
     variant = None
     if world == 1 and args.dtype == "f32" and not args.no_variants and not args.dense:
-        m2 = yf.YoloFastest(io).to(dev).eval()
-        m2.chunk, m2.lanes, m2.branches, m2.precision = args.chunk, args.lanes, args.branches, "f16x3"
-        m2.load_state_dict(torch.load(os.path.join(PKG, "assets", "weights", wname), map_location=dev))
-        post2 = yf.YOLO_post_process(io["conf_thre"], io["nms_thre"], io["num_anchors"], io["num_cls"], io["anchors"], io["input_shape"]).bind(m2)
+        m2, p2 = make("f16x3", lanes, branches)
+        e2, raw2 = timed(m2, p2, in_flight, args.steps, args.warmup, False)
         with torch.no_grad():
-            for _ in range(args.warmup):
-                raw2 = post2.detect_raw(m2(x), kmax=args.kmax)
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                p2 = m2(x)
-                raw2 = post2.detect_raw(p2, kmax=args.kmax)
-            torch.cuda.synchronize(dev)
-            e2 = time.perf_counter() - t1
-            p1 = model(x)
-        same = all(torch.equal(raw[k], raw2[k]) for k in ("counts", "boxes", "cls", "src"))
+            a, b = model(x), m2(x)
         variant = {"dtype": "f16x3", "what": "fp32 storage, pointwise/dense GEMMs on the fp16 matrix pipe with split (hi + lo) operands, fp32 accumulate",
-                   "value": round(args.batch * args.steps / e2, 1), "unit": "frames/s", "ms_per_step": round(1e3 * e2 / args.steps, 4),
-                   "max_abs_logit_diff_vs_f32_on_this_batch": round(max(float((p1[0] - p2[0]).abs().max()), float((p1[1] - p2[1]).abs().max())), 6),
-                   "detections_identical_to_f32_on_this_batch": bool(same)}
-        del m2, post2
+                   "in_flight": in_flight, "value": round(args.batch * args.steps / e2, 1), "unit": "frames/s",
+                   "ms_per_step": round(1e3 * e2 / args.steps, 4),
+                   "max_abs_logit_diff_vs_f32_on_this_batch": round(max(float((a[0] - b[0]).abs().max()), float((a[1] - b[1]).abs().max())), 6),
+                   "detections_identical_to_f32_on_this_batch": bool(same_detections(raw, raw2))}
+        del m2, p2
 
     if rank == 0:
         counts = raw["counts"].cpu().numpy()
@@ -370,7 +401,7 @@ def main():
                                    f"(BASELINE.json configs[1])" if args.res == 256 and args.batch == 256 and args.dtype == "f32" and args.frames == "noise" else
                                    f"YOLO-Fastest {W}x{H} batch={args.batch} {args.dtype} per GPU, {args.frames} frames"
                                    + (", dense synthetic head logits (SURVEY.md 8(d) config 5)" if args.dense else ""),
-                       "global_batch": n_total, "weights": wname, "kmax": args.kmax, "chunk": args.chunk, "lanes": args.lanes, "branches": args.branches,
+                       "global_batch": n_total, "weights": wname, "kmax": args.kmax, "chunk": args.chunk, "in_flight": in_flight, "lanes": lanes, "branches": branches,
                        "world_size": world,
                        "parallelism": f"dp{world} (frames sharded, one RCCL all-gather of box records)" if world > 1 else "single GPU",
                        "survivors_per_frame_mean": round(float(np.clip(counts, 0, None).mean()), 3)},
@@ -392,6 +423,8 @@ def main():
                                               "hbm_GBps": None if o["roof"]["hbm_gbs"] is None else round(o["roof"]["hbm_gbs"])}
                                              for o in ops]},
         }
+        if single is not None:
+            out["one_batch_in_flight"] = single
         if variant is not None:
             out["variants"] = [variant]
         if world == 1 and not args.no_cpu_baseline:

@@ -617,10 +617,22 @@ def test_rccl_gather_path_single_rank(models, golden, dev):
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29537", rank=0, world_size=1, device_id=dev)
     try:
         out = yfd.all_gather_detections(raw, raw["counts"].shape[0])
-        h = yfd.all_gather_detections_async(raw, raw["counts"].shape[0])   # the overlapped form bench.py uses
+        h = yfd.all_gather_detections_async(raw, raw["counts"].shape[0])   # the overlapped form
         out2 = h.wait()
         assert all(torch.equal(out[k], out2[k]) for k in out)
         torch.cuda.synchronize(dev)
+        # ... and started from inside a batch's stream context, as bench.py does with two batches in flight
+        import yolo_fastest_amd as yf_
+        pipe = yf_.BatchPipeline(m, post, depth=2, kmax=8)
+        x20 = _x(g["input_u8"], dev)
+        REC = ("counts", "boxes", "scores", "cls", "src")
+        ts = [pipe.submit(x20, then=lambda o: yfd.all_gather_detections_async({k: o[k] for k in REC}, 20)) for _ in range(3)]
+        for t in ts:
+            got = t.extra.wait()
+            assert torch.equal(got["counts"].cpu(), raw["counts"].cpu())
+        pipe.drain()
+        torch.cuda.synchronize(dev)
+        m.lanes, m.branches = 2, 1
     finally:
         dist.destroy_process_group()
     for k in ("counts", "boxes", "scores", "cls", "src"):
@@ -936,3 +948,45 @@ def test_small_head_branch_stream_is_identical(yf, golden, dev):
                 for a, b in zip(outs["ref"], key):
                     assert torch.equal(a, b), (lanes, chunk, branches, rep)
                 assert torch.equal(raw["head_large"], hl) and torch.equal(raw["head_small"], hs)
+
+
+@pytest.mark.parametrize("depth", [2, 3])
+def test_batch_pipeline_is_identical(yf, golden, dev, depth):
+    """yolo_fastest_amd.BatchPipeline (several batches in flight on separate streams, each with its own engine): every batch's heads
+    and detections are bitwise those of the one-at-a-time path, tickets come back in submit order, for DIFFERENT inputs per batch
+    (a shared workspace or a missing stream dependency would mix them)."""
+    io = yf.io_params_for(256)
+    g = golden("golden_256")
+    m = yf.YoloFastest(io).to(dev).eval()
+    m.load_state_dict(torch.load(WEIGHTS[256], map_location=dev))
+    post = yf.YOLO_post_process(io["conf_thre"], io["nms_thre"], io["num_anchors"], io["num_cls"], io["anchors"], io["input_shape"]).bind(m)
+    rng = np.random.default_rng(3)
+    batches = []
+    for b in range(7):
+        u8 = rng.integers(0, 256, size=(96, 256, 320), dtype=np.uint8)
+        u8[b::7][:20] = g["input_u8"][:len(u8[b::7][:20])]
+        batches.append(_x(u8, dev))
+    want = []
+    with torch.no_grad():
+        for x in batches:
+            pred = m(x)
+            want.append((pred, post.detect_raw(pred, kmax=16)))
+    torch.cuda.synchronize()
+    pipe = yf.BatchPipeline(m, post, depth=depth, kmax=16)
+    tickets = [pipe.submit(x) for x in batches]
+    for (pred, raw), t in zip(want, tickets):
+        out = t.result()
+        assert torch.equal(out["head_large"], pred[0]) and torch.equal(out["head_small"], pred[1])
+        assert torch.equal(out["counts"], raw["counts"])
+        valid = torch.arange(16, device=dev)[None, :] < raw["counts"][:, None]
+        for k in ("boxes", "cls", "src", "scores"):
+            assert torch.equal(out[k][valid], raw[k][valid]), k
+    pipe.drain()
+    assert len({id(e) for e in m._engines.values()}) >= depth      # one engine per stream
+    # `then`: work queued behind ONE batch inside its stream context (what bench.py uses for the RCCL exchange)
+    seen = []
+    t = pipe.submit(batches[0], then=lambda out: seen.append(int(out["counts"].shape[0])) or "tag")
+    assert t.extra == "tag" and seen == [96]
+    assert torch.equal(t.synchronize()["head_small"], want[0][0][1])
+    with pytest.raises(RuntimeError):
+        yf.BatchPipeline(yf.YoloFastest(io).eval(), post)

@@ -11,6 +11,7 @@ from .model import YoloFastest
 from .post_process import YOLO_post_process
 from .detect import Detect_YOLO, preprocess_u8
 from . import validation
+from .pipeline import BatchPipeline
 
 __all__ = ["YoloFastest", "YOLO_post_process", "Detect_YOLO", "preprocess_u8", "config_params", "io_params_for",
-           "packer"]
+           "packer", "BatchPipeline"]

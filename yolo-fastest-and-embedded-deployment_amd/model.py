@@ -177,8 +177,11 @@ class YoloFastest(nn.Module):
             return 2
         return 1 if (self.precision == "f16" or self.storage_dtype == torch.float16 or p.dtype == torch.float16) else 0
 
-    def engine(self, H, W, N, device):
-        key = (H, W, device.index if device.index is not None else torch.cuda.current_device(), self._dtype_code())
+    def engine(self, H, W, N, device, slot=0):
+        """The engine (yf_handle + workspace + its side streams) for this input size on this device.  `slot` > 0: a further engine
+        of the same kind, so that several batches can be in flight on different streams (pipeline.BatchPipeline): one engine serves
+        one stream at a time."""
+        key = (H, W, device.index if device.index is not None else torch.cuda.current_device(), self._dtype_code(), slot)
         e = self._engines.get(key)
         if e is None or e.max_batch < N:
             if e is not None:
@@ -202,13 +205,13 @@ class YoloFastest(nn.Module):
         """Some engine of this model on `device` (for the size-agnostic entry points: yf_nms_sorted, yf_val_nms); one is created
         at the smallest legal input size if the model has not run there yet."""
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        for (H, W, d, dt), e in self._engines.items():
-            if d == idx and dt == self._dtype_code():
+        for (H, W, d, dt, slot), e in self._engines.items():
+            if d == idx and dt == self._dtype_code() and slot == 0:
                 return e
         return self.engine(32, 32, 1, torch.device("cuda", idx))
 
     # -- forward --------------------------------------------------------------------------------
-    def forward(self, x):
+    def forward(self, x, slot=0):
         if self.training:
             raise RuntimeError("YoloFastest (HIP engine) is inference-only: call .eval() first (detect.py:89)")
         if not x.is_cuda:
@@ -218,7 +221,7 @@ class YoloFastest(nn.Module):
         in_dtype = x.dtype
         x = x.contiguous().float()
         N, _, H, W = x.shape
-        e = self.engine(H, W, N, x.device)
+        e = self.engine(H, W, N, x.device, slot)
         hl = torch.empty((N, self.num_out, H // 16, W // 16), dtype=torch.float32, device=x.device)
         hs = torch.empty((N, self.num_out, H // 32, W // 32), dtype=torch.float32, device=x.device)
         ws = e.workspace(N, x.device)

@@ -1,0 +1,70 @@
+"""Several batches in flight: `BatchPipeline` runs consecutive batches of the hot path (model -> decode -> per-class NMS) round-robin on
+`depth` HIP streams, each with its own engine (weights copy, workspace, side streams), so that a batch's late, per-frame,
+latency-bound stages (strides 16 / 32 and the two heads: one 80- or 320-pixel frame per workgroup) run beside the next batch's
+early, machine-filling stages (stem .. stride 8) instead of beside more of the same.
+
+The reference has no counterpart (it loops one image per iteration, src/detect.py:146); this is the throughput mode of the batched
+driver.  Measured on MI355X, 320x256, batch 256 (tools/inflight_try.py): one batch in flight as two half-batch lanes 243 k frames/s;
+two batches in flight, one lane each, 279 k (fp32); 302 k -> 354 k with the f16x3 variant; a third batch in flight loses again.
+Results are bitwise those of the one-at-a-time path (tests/test_gpu_parity.py::test_batch_pipeline_is_identical).
+"""
+import torch
+
+
+class _Ticket:
+    """One submitted batch.  `result()` makes the CALLER's current stream wait for the batch (a stream-level dependency, the host does
+    not block) and returns what was submitted for: the raw detection dict (plus the head tensors under 'head_large' / 'head_small')."""
+
+    def __init__(self, event, out, extra=None):
+        self._event, self._out, self.extra = event, out, extra     # extra: what submit()'s `then` callback returned
+
+    def result(self):
+        cur = torch.cuda.current_stream(self._out["counts"].device)
+        cur.wait_event(self._event)
+        for t in self._out.values():
+            t.record_stream(cur)     # the caching allocator must not hand the buffers out again before the caller's stream is done
+        return self._out
+
+    def synchronize(self):
+        self._event.synchronize()
+        return self._out
+
+
+class BatchPipeline:
+    def __init__(self, model, post, depth=2, kmax=64, origin_shape=None, lanes=1, branches=0):
+        """model: yolo_fastest_amd.YoloFastest on a GPU; post: YOLO_post_process bound to it.  depth: batches in flight (2 is the
+        measured optimum).  lanes / branches: the per-engine concurrency knobs while the pipeline is used -- with two batches in
+        flight the best setting is one lane and the small head in line (the other batch fills the machine instead)."""
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        p = next(model.parameters())
+        if not p.is_cuda:
+            raise RuntimeError("BatchPipeline (HIP) has no CPU path: move the model to the GPU")
+        self.model, self.post, self.depth, self.kmax, self.origin_shape = model, post, depth, kmax, origin_shape
+        model.lanes, model.branches = lanes, branches
+        self.device = p.device
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(depth)]
+        self._n = 0
+
+    def submit(self, x, then=None):
+        """x: float32 GPU tensor [N,1,H,W], ready on the caller's current stream.  Returns a ticket at once.
+        then(out): optional, called with the batch's result dict INSIDE the batch's stream context -- work it queues (e.g. the
+        asynchronous all-gather of the records, dist.all_gather_detections_async) is ordered behind this batch only, not behind the
+        caller's stream; its return value is kept in the ticket's `extra`."""
+        k = self._n % self.depth
+        self._n += 1
+        s = self.streams[k]
+        s.wait_stream(torch.cuda.current_stream(self.device))      # the input (and everything the caller queued before) first
+        with torch.cuda.stream(s), torch.no_grad():
+            x.record_stream(s)
+            pred = self.model(x, slot=k)
+            out = self.post.detect_raw(pred, kmax=self.kmax, origin_shape=self.origin_shape, slot=k)
+            out["head_large"], out["head_small"] = pred
+            extra = then(out) if then is not None else None
+            ev = torch.cuda.Event()
+            ev.record(s)
+        return _Ticket(ev, out, extra)
+
+    def drain(self):
+        for s in self.streams:
+            s.synchronize()

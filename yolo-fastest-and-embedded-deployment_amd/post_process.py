@@ -34,7 +34,7 @@ class YOLO_post_process:
         self._model = model
         return self
 
-    def _engine(self, pred):
+    def _engine(self, pred, slot=0):
         hl = pred[0]
         if not hl.is_cuda:
             raise RuntimeError("YOLO_post_process (HIP) has no CPU path: pass the GPU tensors the model returned")
@@ -43,13 +43,13 @@ class YOLO_post_process:
         H, W = hl.shape[2] * 16, hl.shape[3] * 16
         if [H, W] != list(self.input_shape[:2]):
             raise ValueError("pred is for a %dx%d input, input_shape says %s" % (H, W, self.input_shape[:2]))
-        return self._model.engine(H, W, hl.shape[0], hl.device)
+        return self._model.engine(H, W, hl.shape[0], hl.device, slot)
 
-    def detect_raw(self, pred, kmax=64, nms_thres=None, origin_shape=None):
+    def detect_raw(self, pred, kmax=64, nms_thres=None, origin_shape=None, slot=0):
         """Batched. Returns dict of GPU tensors: boxes [N,kmax,4] i32, scores [N,kmax,2] f32, cls, src [N,kmax] i32,
         counts [N] i32 (see include/yolo_fastest_hip.h for the conventions)."""
         hl, hs = pred[0].contiguous(), pred[1].contiguous()
-        e = self._engine(pred)
+        e = self._engine(pred, slot)
         N, dev = hl.shape[0], hl.device
         out = dict(boxes=torch.empty((N, kmax, 4), dtype=torch.int32, device=dev),
                    scores=torch.empty((N, kmax, 2), dtype=torch.float32, device=dev),
