@@ -170,6 +170,8 @@ def main():
     ap.add_argument("--branches", type=int, default=-1, choices=[-1, 0, 1],
                     help="1: the small head's launches on a side stream of their lane; -1 = 0 with several batches in flight, else 1")
     ap.add_argument("--kmax", type=int, default=64)
+    ap.add_argument("--exchange-at-1", action="store_true",
+                    help="rehearsal of the N > 1 code path on one GPU: a 1-rank RCCL group and the all-gather of every step's records")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra f16x3 measurement of the same workload")
     ap.add_argument("--dump-ops", default=None, help="write the launch names of one forward pass to this JSON file")
@@ -199,8 +201,13 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP extension is the only implementation (no CPU fallback)")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    multi = world > 1 or args.exchange_at_1
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1 and "MASTER_ADDR" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: RCCL world size {dist.get_world_size()} != --gpus {args.gpus}")
@@ -280,18 +287,18 @@ def main():
 
         run(warmup)
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         raw = run(steps)
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
         tt = torch.tensor([el], dtype=torch.float64, device=dev)
-        if world > 1:
+        if multi:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item()), raw
 
@@ -302,7 +309,7 @@ def main():
         return all(torch.equal(a[k][valid], b[k][valid]) for k in ("boxes", "cls", "src"))
 
     model, post = make(args.dtype, lanes, branches)
-    elapsed, raw = timed(model, post, in_flight, args.steps, args.warmup, world > 1)
+    elapsed, raw = timed(model, post, in_flight, args.steps, args.warmup, multi)
 
     # model / post-process split and the one-batch-at-a-time figure (two half-batch lanes, the small head on its side stream): measured
     # after the headline's timed region, same process
@@ -430,7 +437,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -990,3 +990,30 @@ def test_batch_pipeline_is_identical(yf, golden, dev, depth):
     assert torch.equal(t.synchronize()["head_small"], want[0][0][1])
     with pytest.raises(RuntimeError):
         yf.BatchPipeline(yf.YoloFastest(io).eval(), post)
+
+
+def test_bench_line_and_multi_gpu_rehearsal(dev):
+    """bench.py end to end on the one GPU of the box: the default line (two batches in flight) carries the contract's keys, and
+    `--exchange-at-1` runs the N > 1 code path -- RCCL process group, the all-gather of every step's records started from inside each
+    batch's stream context, barrier + max-over-ranks timing -- with a 1-rank group."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--batch", "64"]
+    for extra in ([], ["--exchange-at-1", "--no-variants"], ["--exchange-at-1", "--no-variants", "--in-flight", "1"]):
+        r = subprocess.run(base + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                  "data", "config", "roofline"):
+            assert k in j, k
+        assert j["n_gpus"] == 1 and j["steps"] == 4 and j["value"] > 1000 and j["config"]["world_size"] == 1
+        assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
+        assert 0 < j["roofline"]["frac"] < 1
+        if not extra:
+            assert j["config"]["in_flight"] == 2 and j["one_batch_in_flight"]["detections_identical"]
+            assert j["variants"][0]["dtype"] == "f16x3" and j["variants"][0]["detections_identical_to_f32_on_this_batch"]
+            assert j["variants"][0]["max_abs_logit_diff_vs_f32_on_this_batch"] < 1e-3
