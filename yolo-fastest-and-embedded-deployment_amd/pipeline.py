@@ -57,8 +57,10 @@ class BatchPipeline:
         s.wait_stream(torch.cuda.current_stream(self.device))      # the input (and everything the caller queued before) first
         with torch.cuda.stream(s), torch.no_grad():
             x.record_stream(s)
-            pred = self.model(x, slot=k)
-            out = self.post.detect_raw(pred, kmax=self.kmax, origin_shape=self.origin_shape, slot=k)
+            # engine slots 1 .. depth: slot 0 stays the engine of plain `model(x)` calls on the caller's own stream, so those may
+            # be mixed with batches in flight
+            pred = self.model(x, slot=k + 1)
+            out = self.post.detect_raw(pred, kmax=self.kmax, origin_shape=self.origin_shape, slot=k + 1)
             out["head_large"], out["head_small"] = pred
             extra = then(out) if then is not None else None
             ev = torch.cuda.Event()
