@@ -127,6 +127,19 @@ int yf_val_decode_head(yf_handle h, const float *d_head, int N, int fh, int fw, 
 int yf_val_nms(yf_handle h, const float *d_pred, int N, int M, double conf_thres, double nms_thres, int K_max, float *d_det,
                int32_t *d_counts, void *stream);
 
+/* The loss end of the reference's training step (first slice; the layers' backward is not part of it):
+ *   yf_train_loss = YOLOLossV3.forward(input, targets) for ONE head   src/model_training/loss/yolo_loss.py:48-97 (+ get_target :144-196)
+ *                   and, if d_grad_head is not NULL, d(total loss)/d(input): what loss.backward() (train.py:131) leaves in input.grad.
+ *   d_head float32 [N,24,fh,fw]; anchors: HOST double[3][2] of this head (net-input pixels); d_targets float32 [N,T,6] =
+ *   (x, y, w, h normalised to 0..1, class, marker >= 1; the first row with marker < 1 ends an image's list, yolo_loss.py:158);
+ *   ignore_thres = config train_params.IOU_loss_thre.
+ *   d_losses float32 [8] = total, x, y, w, h, conf, cls (the 7-tuple of yolo_loss.py:94-95) and, in [7], the number of targets whose
+ *   cell lies outside the feature map (the reference raises IndexError for those; they are skipped here).
+ *   d_work: yf_train_loss_workspace_bytes(N, fh, fw) bytes of device scratch, 8-byte aligned. */
+int yf_train_loss_workspace_bytes(yf_handle h, int N, int fh, int fw, size_t *out);
+int yf_train_loss(yf_handle h, const float *d_head, int N, int fh, int fw, const double *anchors, const float *d_targets, int T,
+                  double ignore_thres, void *d_work, size_t work_bytes, float *d_losses, float *d_grad_head, void *stream);
+
 /* yf_forward + yf_decode_nms back to back on one stream (heads also returned; may be NULL to use
  * workspace-internal buffers). */
 int yf_detect(yf_handle h, const float *d_x, int N, double conf_thres, double nms_thres, const double *anchors,

@@ -346,6 +346,37 @@ def main_map():
           "TP", [int(out[f"match_tp_{c}"].sum()) for c in range(3)])
 
 
+def main_loss():
+    """Training-loss goldens (first slice): the reference's own `YOLOLossV3(...)(input, targets)`
+    (loss/yolo_loss.py:48-97, get_target :144-196) on the reference's head tensors of the 20 bundled frames, with the synthetic
+    targets of main_map plus rows that hit the loop's special cases (two targets in one cell: the later one wins and the one-hot
+    classes accumulate; a zero-size target that is skipped; the end marker), and `loss.backward()` for d(total)/d(input)."""
+    import types
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    sys.path.insert(0, os.path.join(REF, "src", "model_training"))
+    from loss.yolo_loss import YOLOLossV3            # the reference
+    model, io = load_model(256)
+    g = np.load(os.path.join(HERE, "golden_256.npz"))
+    targets = np.load(os.path.join(HERE, "golden_map_256.npz"))["targets"].copy()   # [20,64,6]
+    # special cases on image 0 / 1: same cell twice with different classes; zero-width target in the middle of the list
+    n0 = int((targets[0, :, 5] > 1).sum())
+    targets[0, n0] = targets[0, 0]; targets[0, n0, 4] = (targets[0, 0, 4] + 1) % 3; targets[0, n0, 2] *= 1.1
+    n1 = int((targets[1, :, 5] > 1).sum())
+    targets[1, n1] = [0.5, 0.5, 0.0, 0.1, 1.0, 255.0]
+    targets[1, n1 + 1] = [0.31, 0.62, 0.12, 0.07, 2.0, 255.0]
+    dev = torch.device("cpu")
+    out = {"targets": targets}
+    tt = torch.from_numpy(targets)
+    for i, name in enumerate(("head_large", "head_small")):
+        x = torch.from_numpy(g[name].copy()).requires_grad_(True)
+        res = YOLOLossV3(io["anchors"][i], io["num_cls"], io["input_shape"], dev)(x, tt)
+        res[0].backward()
+        out[f"{name}_losses"] = np.array([res[0].item()] + [float(v) for v in res[1:]], np.float32)
+        out[f"{name}_grad"] = x.grad.numpy().copy()
+        print("loss", name, out[f"{name}_losses"].tolist(), "grad max", float(np.abs(out[f"{name}_grad"]).max()))
+    np.savez_compressed(os.path.join(HERE, "golden_loss_256.npz"), **out)
+
+
 def main_results():
     """Result-writer goldens (detect.py:176-192): what the reference's own detect.py run left under
     test_result/<size>/<laptop cpu (python)>_test_result/ -- DATA of the reference, not source:
@@ -389,8 +420,11 @@ if __name__ == "__main__":
         main_map()
     elif len(sys.argv) > 1 and sys.argv[1] == "results":
         main_results()
+    elif len(sys.argv) > 1 and sys.argv[1] == "loss":
+        main_loss()
     else:
         main()
         main_val()
         main_map()
         main_results()
+        main_loss()

@@ -392,7 +392,7 @@ def test_validation_path_decode_and_nms(yf, models, golden, dev):
                 n = int(gv["real_count"][f])
                 assert d is not None and d.shape[0] == n
                 assert np.allclose(d.cpu().numpy(), gv["real_det"][f, :n], rtol=2e-6, atol=2e-5)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):       # targets must be [batch, T, 6] (the training loss: test_training_loss_matches_the_reference)
         val.YOLOLossV3(io["anchors"][0], 3, io["input_shape"], dev)(pred[0], targets=torch.zeros(1))
 
 
@@ -1017,3 +1017,52 @@ def test_bench_line_and_multi_gpu_rehearsal(dev):
             assert j["config"]["in_flight"] == 2 and j["one_batch_in_flight"]["detections_identical"]
             assert j["variants"][0]["dtype"] == "f16x3" and j["variants"][0]["detections_identical_to_f32_on_this_batch"]
             assert j["variants"][0]["max_abs_logit_diff_vs_f32_on_this_batch"] < 1e-3
+
+
+def test_training_loss_matches_the_reference(yf, models, golden, dev):
+    """SURVEY.md 8(f).4, first slice: `YOLOLossV3(...)(input, targets)` (loss/yolo_loss.py:48-97, get_target :144-196) and the
+    gradient `loss.backward()` leaves in the head tensor (train.py:131), on the GPU, against the reference's own run
+    (tests/golden/golden_loss_256.npz: its heads of the 20 bundled frames, synthetic targets incl. two targets in one cell, a skipped
+    zero-size target, the end marker).  fp32 transcendental functions and the summation order differ from torch-CPU: 2e-5 relative."""
+    from yolo_fastest_amd import validation as val
+    from oracle import loss_oracle as lo
+    m, _, io = models[256]
+    g, gl = golden("golden_256"), golden("golden_loss_256")
+    targets = torch.from_numpy(gl["targets"]).to(dev)
+    total = 0
+    for i, name in enumerate(("head_large", "head_small")):
+        x = torch.from_numpy(g[name].copy()).to(dev).requires_grad_(True)
+        out = val.YOLOLossV3(io["anchors"][i], 3, io["input_shape"], dev, model=m)(x, targets)
+        want = gl[name + "_losses"]
+        got = np.array([out[0].item()] + list(out[1:]), np.float32)
+        assert np.allclose(got, want, rtol=2e-5, atol=1e-8), (name, got, want)
+        out[0].backward()
+        gw = gl[name + "_grad"]
+        assert x.grad.shape == x.shape
+        assert np.abs(x.grad.cpu().numpy() - gw).max() <= 2e-5 * np.abs(gw).max() + 1e-10, name
+        assert (x.grad.cpu().numpy() != 0).sum() == (gw != 0).sum() or np.abs(x.grad.cpu().numpy()[gw == 0]).max() < 1e-12
+        total = total + out[0]
+    # the training loop's sum over the two heads (train.py:124-130) is differentiable too, and scales through backward
+    x = torch.from_numpy(g["head_small"].copy()).to(dev).requires_grad_(True)
+    (3.0 * val.YOLOLossV3(io["anchors"][1], 3, io["input_shape"], dev, model=m)(x, targets)[0]).backward()
+    assert np.abs(x.grad.cpu().numpy() - 3.0 * gl["head_small_grad"]).max() <= 1e-4 * np.abs(gl["head_small_grad"]).max()
+    # random logits and targets against the oracle (more positives, saturated sigmoids, empty images, no positive at all -> nan cls loss)
+    rng = np.random.default_rng(0)
+    for trial, (bs, T, npos) in enumerate(((3, 8, 5), (2, 4, 0), (5, 64, 40))):
+        h = torch.from_numpy(rng.normal(0, 4.0, size=(bs, 24, 16, 20)).astype(np.float32))
+        t = np.zeros((bs, T, 6), np.float32)
+        for b in range(bs):
+            k = min(T, npos if b else max(npos - 2, 0))
+            t[b, :k, 0:2] = rng.uniform(0.02, 0.98, (k, 2)); t[b, :k, 2:4] = rng.uniform(0.02, 0.9, (k, 2))
+            t[b, :k, 4] = rng.integers(0, 3, k); t[b, :k, 5] = 255.0
+        wl, wg = lo.loss_and_grad(h, torch.from_numpy(t), io["anchors"][0], 3, io["input_shape"])
+        x = h.clone().to(dev).requires_grad_(True)
+        out = val.YOLOLossV3(io["anchors"][0], 3, io["input_shape"], dev, model=m)(x, torch.from_numpy(t).to(dev))
+        got = np.array([out[0].item()] + list(out[1:]), np.float32)
+        assert np.allclose(got, wl, rtol=3e-5, atol=1e-7, equal_nan=True), (trial, got, wl)
+        out[0].backward()
+        if np.isfinite(wl[0]):
+            assert np.abs(x.grad.cpu().numpy() - wg.numpy()).max() <= 3e-5 * np.abs(wg.numpy()).max() + 1e-10, trial
+    bad = np.zeros((1, 2, 6), np.float32); bad[0, 0] = [1.0, 0.5, 0.1, 0.1, 0, 255.0]       # x == 1.0: column index == width
+    with pytest.raises(IndexError):
+        val.YOLOLossV3(io["anchors"][0], 3, io["input_shape"], dev, model=m)(torch.zeros(1, 24, 16, 20, device=dev), torch.from_numpy(bad).to(dev))

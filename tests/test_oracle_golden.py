@@ -180,3 +180,17 @@ def test_map_oracle_reproduces_reference_validation(golden):
     assert tn.tolist() == g["target_num"].tolist()
     for c in range(3):
         assert sum(m[1] for m in ml[c]) == int(g[f"match_tp_{c}"].sum()) and len(ml[c]) == len(g[f"match_tp_{c}"])
+
+
+def test_loss_oracle_matches_the_reference(golden):
+    """oracle/loss_oracle.py (training loss of one head + autograd gradient) against the reference's own YOLOLossV3 run with targets
+    (tests/golden/make_golden.py main_loss): identical arithmetic (same torch ops), so exact."""
+    import torch
+    import yolo_fastest_amd as yf
+    from oracle import loss_oracle as lo
+    g, gl = golden("golden_256"), golden("golden_loss_256")
+    io = yf.io_params_for(256)
+    for i, name in enumerate(("head_large", "head_small")):
+        L, G = lo.loss_and_grad(torch.from_numpy(g[name].copy()), torch.from_numpy(gl["targets"]), io["anchors"][i], 3, io["input_shape"])
+        assert np.array_equal(L, gl[name + "_losses"]), name
+        assert np.array_equal(G.numpy(), gl[name + "_grad"]), name

@@ -39,6 +39,9 @@ _SIGS = {
                                       _c.c_void_p, _c.c_void_p]),
     "yf_val_nms": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_int, _c.c_void_p, _c.c_void_p,
                               _c.c_void_p]),
+    "yf_train_loss_workspace_bytes": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_size_t)]),
+    "yf_train_loss": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.c_void_p, _c.c_int,
+                                 _c.c_double, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "yf_num_launches": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int)]),
     "yf_op_info": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_char_p, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     "yf_op_info_ex": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_char_p, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double),

@@ -872,6 +872,31 @@ int yf_val_nms(yf_handle h, const float* d_pred, int N, int M, double conf_thres
     return YF_OK;
 }
 
+// Training-time loss of ONE head (first slice).  anchors: HOST double[3][2] of this head, net-input pixels.
+int yf_train_loss_workspace_bytes(yf_handle h, int N, int fh, int fw, size_t* out)
+{
+    if (!h || !out || N <= 0 || fh <= 0 || fw <= 0) return fail(YF_E_INVALID, "yf_train_loss_workspace_bytes: bad argument");
+    *out = yf::train_loss_workspace_bytes(N, fh, fw);
+    return YF_OK;
+}
+
+int yf_train_loss(yf_handle h, const float* d_head, int N, int fh, int fw, const double* anchors, const float* d_targets, int T,
+                  double ignore_thres, void* d_work, size_t work_bytes, float* d_losses, float* d_grad_head, void* stream)
+{
+    if (!h || !d_head || !anchors || !d_targets || !d_work || !d_losses || N <= 0 || fh <= 0 || fw <= 0 || T <= 0)
+        return fail(YF_E_INVALID, "yf_train_loss: bad argument");
+    if (work_bytes < yf::train_loss_workspace_bytes(N, fh, fw)) return fail(YF_E_WORKSPACE, "yf_train_loss: workspace too small");
+    if (reinterpret_cast<uintptr_t>(d_work) & 7) return fail(YF_E_INVALID, "yf_train_loss: workspace must be 8-byte aligned");
+    HIP_OK(hipSetDevice(h->device));
+    // yolo_loss.py:52-56: strides and feature-map-scaled anchors are Python doubles; torch uses them as float32
+    const double stride_h = (double)h->H / fh, stride_w = (double)h->W / fw;
+    float anc6[6];
+    for (int a = 0; a < 3; ++a) { anc6[2 * a] = (float)(anchors[2 * a] / stride_w); anc6[2 * a + 1] = (float)(anchors[2 * a + 1] / stride_h); }
+    yf::launch_train_loss(d_head, N, fh, fw, anc6, d_targets, T, (float)ignore_thres, d_work, d_losses, d_grad_head, (hipStream_t)stream);
+    HIP_OK(hipGetLastError());
+    return YF_OK;
+}
+
 int yf_detect(yf_handle h, const float* d_x, int N, double conf_thres, double nms_thres, const double* anchors, int origin_h,
               int origin_w, int K_max, int32_t* d_boxes, float* d_scores, int32_t* d_cls, int32_t* d_src, int32_t* d_counts,
               float* d_hl, float* d_hs, void* ws, size_t ws_bytes, void* stream)

@@ -224,6 +224,10 @@ size_t post_lds_bytes(int ncell);
 void launch_val_decode(const float* in, float* out, int N, int h, int w, int M_total, int m_off, const float* anc6, float stride_w,
                        float stride_h, hipStream_t s);
 int launch_val_nms(const float* pred, int N, int M, float conf_thres, float nms_thres, int kmax, float* det, int32_t* counts, hipStream_t s);
+// training-time loss of one head and its gradient with respect to the head tensor (yf_loss_kernels.hip)
+size_t train_loss_workspace_bytes(int N, int fh, int fw);
+void launch_train_loss(const float* head, int N, int fh, int fw, const float* anc6, const float* targets, int T, float ignore_thres,
+                       void* work, float* losses, float* grad, hipStream_t s);
 void launch_nms_sorted(const int32_t* boxes, int n, double nms_thres, int32_t* suppressor, hipStream_t s);
 
 }  // namespace yf

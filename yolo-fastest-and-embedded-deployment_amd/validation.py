@@ -1,7 +1,8 @@
 """Validation-time decode + NMS on the GPU behind the reference's own names:
   `YOLOLossV3(anchors, num_classes, input_shape, device)(input)`   src/model_training/loss/yolo_loss.py:27-141 (decode branch)
   `non_max_suppression(prediction, num_classes, conf_thres, nms_thres)`   src/model_training/utils/general.py:87-143
-Training (targets given) is out of scope and raises.  Both need an engine handle (it carries the device; the decode also needs
+With targets, `YOLOLossV3(...)(input, targets)` is the reference's TRAINING loss of that head (yolo_loss.py:70-97, :144-196) with an
+analytic backward to the head tensor (yf_train_loss; SURVEY.md 8(f).4, first slice -- the layers' backward is not built).  All need an engine handle (it carries the device; the decode also needs
 H and W, which come from `input_shape`).  The model is passed explicitly (`model=` / `loss.model = m`); `bind(model)` sets the
 default used when none is given.  The engine is chosen by (H, W, device of the tensor) -- never "whichever exists"."""
 import ctypes
@@ -41,12 +42,13 @@ class YOLOLossV3(torch.nn.Module):
         self.bbox_attrs = 5 + num_classes
         self.input_shape = input_shape
         self.device = device
+        self.ignore_threshold = 0.5    # config_params["train_params"]["IOU_loss_thre"] (_config.py:45)
         if self.num_anchors != 3 or num_classes != 3:
             raise NotImplementedError("the HIP decode implements 3 anchors x 3 classes")
 
     def forward(self, input, targets=None):
         if targets is not None:
-            raise NotImplementedError("the training loss is out of scope of this inference path (SURVEY.md 8f.4)")
+            return self._train_loss(input, targets)
         x = input.contiguous().float()
         bs, _, fh, fw = x.shape
         if (fh * 16, fw * 16) != (int(self.input_shape[0]), int(self.input_shape[1])) and \
@@ -59,6 +61,55 @@ class YOLOLossV3(torch.nn.Module):
         stream = torch.cuda.current_stream(x.device).cuda_stream
         _lib.check(e.lib.yf_val_decode_head(e.handle, x.data_ptr(), bs, fh, fw, anc, M, 0, out.data_ptr(), ctypes.c_void_p(stream)))
         return out
+
+
+class _TrainLossFn(torch.autograd.Function):
+    """total loss of one head with its analytic gradient (yf_train_loss): `loss.backward()` reaches the head tensor."""
+
+    @staticmethod
+    def forward(ctx, x, targets, loss_mod):
+        bs, _, fh, fw = x.shape
+        H, W = int(loss_mod.input_shape[0]), int(loss_mod.input_shape[1])
+        e = _engine(x, H, W, loss_mod.model)
+        need = ctypes.c_size_t()
+        _lib.check(e.lib.yf_train_loss_workspace_bytes(e.handle, bs, fh, fw, ctypes.byref(need)))
+        work = torch.empty((need.value + 7) // 8, dtype=torch.float64, device=x.device)     # 8-byte aligned scratch
+        losses = torch.empty(8, dtype=torch.float32, device=x.device)
+        grad = torch.empty_like(x)
+        anc = (ctypes.c_double * 6)(*[float(v) for a in loss_mod.anchors for v in a])
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(e.lib.yf_train_loss(e.handle, x.data_ptr(), bs, fh, fw, anc, targets.data_ptr(), targets.shape[1],
+                                       float(loss_mod.ignore_threshold), work.data_ptr(), work.numel() * 8, losses.data_ptr(),
+                                       grad.data_ptr(), ctypes.c_void_p(stream)))
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(losses)
+        return losses[0].clone(), losses
+
+    @staticmethod
+    def backward(ctx, g_total, _g_losses):
+        (grad,) = ctx.saved_tensors
+        return grad * g_total, None, None
+
+
+def _train_loss(self, input, targets):
+    """yolo_loss.py:70-97 with targets: (loss, x, y, w, h, conf, cls) -- loss a 0-dim tensor whose backward() fills input.grad, the rest
+    Python floats like the reference's .item() values.  Targets outside the feature map raise IndexError like the reference's indexing."""
+    if self.num_anchors != 3 or self.num_classes != 3:
+        raise NotImplementedError("3 anchors x 3 classes")
+    if not input.is_cuda:
+        raise RuntimeError("training loss (HIP) has no CPU implementation: pass GPU tensors")
+    x = input if (input.is_contiguous() and input.dtype == torch.float32) else input.contiguous().float()
+    t = targets.to(x.device).contiguous().float()
+    if t.dim() != 3 or t.shape[0] != x.shape[0] or t.shape[2] != 6:
+        raise ValueError("targets must be [batch, T, 6] = (x, y, w, h, class, marker)")
+    loss, parts = _TrainLossFn.apply(x, t, self)
+    v = parts.tolist()
+    if v[7] > 0:
+        raise IndexError("%d target(s) fall outside the %dx%d feature map" % (int(v[7]), x.shape[2], x.shape[3]))
+    return loss, v[1], v[2], v[3], v[4], v[5], v[6]
+
+
+YOLOLossV3._train_loss = _train_loss
 
 
 def non_max_suppression(prediction, num_classes, conf_thres=0.5, nms_thres=0.4, kmax=None, model=None):
