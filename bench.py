@@ -319,13 +319,13 @@ def main():
     m1, p1 = (model, post) if in_flight == 1 else make(args.dtype, 2, 1)
     es = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     fwd_ms = post_ms = 0.0
-    for _ in range(3):
+    for _ in range(10):
         p1.detect_raw(forward(m1), kmax=args.kmax)
     torch.cuda.synchronize(dev)
-    for _ in range(5):
+    for _ in range(10):
         es[0].record(); pred = forward(m1); es[1].record(); raw1 = p1.detect_raw(pred, kmax=args.kmax); es[2].record()
         torch.cuda.synchronize(dev)
-        fwd_ms += es[0].elapsed_time(es[1]) / 5; post_ms += es[1].elapsed_time(es[2]) / 5
+        fwd_ms += es[0].elapsed_time(es[1]) / 10; post_ms += es[1].elapsed_time(es[2]) / 10
     single = None
     if in_flight > 1 and world == 1:
         e1, r1 = timed(m1, p1, 1, args.steps, args.warmup, False)
