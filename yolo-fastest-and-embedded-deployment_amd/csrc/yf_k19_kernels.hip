@@ -50,6 +50,9 @@ constexpr int WQ_F32 = NG * 2 * 64 * 4, W21Q_F32 = 2 * 64;
 constexpr int W9_F16 = NG * 2 * 64 * 2, W21_F16 = 2 * 64 * 2;  // in floats (f16x4 = 2 floats per lane)
 // split-operand mode (DT_F16X3): [W9 hi | W21 hi | W9 lo | W21 lo], each in the fp16 layout
 constexpr int WX3_HALF = W9_F16 + W21_F16;
+// X3 walks K in NG2 = 7 groups of 32 k-values on v_mfma_f32_16x16x32_f16 (the K = 32 form issues in the cycles of the K = 16 one:
+// tools/mfma16_probe.hip): lane group j holds the PAIR of 4-channel chunks 2 (4 g + j), 2 (4 g + j) + 1 -- 27 pairs = 9 taps x 3
+constexpr int NG2 = 7, NPAIR = 27;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 }  // namespace
 
@@ -69,11 +72,11 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
 {
     // X3 (DT_F16X3): fp32 in HBM; conv1_8 (K = 4) stays an exact fp32 MFMA; its result is SPLIT ONCE, where phase 1 stores it: a
     // region record of 4 channels is 16 bytes either way -- four floats (fp32 mode) or [hi f16x4 | lo f16x4] -- so phase 2 reads
-    // both halves of its B operand with the one ds_read_b128 it issues anyway and spends no VALU on splitting; conv1_9's weights
-    // are register-resident as hi and lo fragments (2 x 56 VGPRs) and a k group issues w_lo*x_hi + w_hi*x_lo + w_hi*x_hi.
+    // both halves of its B operand with plain ds_read_b128s and spends no VALU on splitting; conv1_9's weights are register-resident
+    // as hi and lo fragments (2 x 56 VGPRs) and a k group (32 k-values, v_mfma_f32_16x16x32_f16) issues w_lo*x_hi + w_hi*x_lo + w_hi*x_hi.
     constexpr bool X3 = is_x3<TT>::value;
     constexpr bool H16 = sizeof(TT) == 2;
-    constexpr bool M16 = H16 || X3;                // conv1_9 / conv2_1 on v_mfma_f32_16x16x16_f16
+    constexpr bool M16 = H16 || X3;                // conv1_9 / conv2_1 on the fp16 matrix pipe
     constexpr int PS = plane_stride(H16), RWS = row_stride(H16);
     constexpr int BUF = RH * RWS;  // elements per region buffer
     extern __shared__ __attribute__((aligned(16))) unsigned char k19_smem[];
@@ -87,10 +90,23 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
 
     // ---- weights: registers for the lifetime of the workgroup ----
     float wf[M16 ? 1 : NG][4][2];
-    f16x4 wh[M16 ? NG : 1][2], wl[X3 ? NG : 1][2];
+    f16x4 wh[H16 ? NG : 1][2];
+    f16x8 wh8[X3 ? NG2 : 1][2], wl8[X3 ? NG2 : 1][2];
     float w21f[2][4];
     f16x4 w21h[2], w21l[2];
-    if constexpr (M16) {
+    if constexpr (X3) {
+        const f16x8* w = reinterpret_cast<const f16x8*>(a.wp);
+        const f16x8* wlo = reinterpret_cast<const f16x8*>(a.wp + WX3_HALF);
+#pragma unroll
+        for (int g = 0; g < NG2; ++g)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) { wh8[g][mt] = w[(g * 2 + mt) * 64 + lane]; wl8[g][mt] = wlo[(g * 2 + mt) * 64 + lane]; }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            w21h[mt] = reinterpret_cast<const f16x4*>(a.wp + W9_F16)[mt * 64 + lane];
+            w21l[mt] = reinterpret_cast<const f16x4*>(a.wp + WX3_HALF + W9_F16)[mt * 64 + lane];
+        }
+    } else if constexpr (H16) {
         const f16x4* w = reinterpret_cast<const f16x4*>(a.wp);
 #pragma unroll
         for (int g = 0; g < NG; ++g)
@@ -98,15 +114,6 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
             for (int mt = 0; mt < 2; ++mt) wh[g][mt] = w[(g * 2 + mt) * 64 + lane];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) w21h[mt] = reinterpret_cast<const f16x4*>(a.wp + W9_F16)[mt * 64 + lane];
-        if constexpr (X3) {
-            const f16x4* wlo = reinterpret_cast<const f16x4*>(a.wp + WX3_HALF);
-#pragma unroll
-            for (int g = 0; g < NG; ++g)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) wl[g][mt] = wlo[(g * 2 + mt) * 64 + lane];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) w21l[mt] = reinterpret_cast<const f16x4*>(a.wp + WX3_HALF + W9_F16)[mt * 64 + lane];
-        }
     } else {
 #pragma unroll
         for (int g = 0; g < NG; ++g)
@@ -154,6 +161,17 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
         adr[g] = (2 * wave + ky) * RWS + (kx == 1 ? PS : 0) + (p + (kx >> 1)) * RS + c4 * 4;
     }
 
+    int adr2[X3 ? NG2 : 1];   // X3: the pair record (32 bytes: [hi8 | lo8]) lane group j reads in group g
+    if constexpr (X3) {
+#pragma unroll
+        for (int g = 0; g < NG2; ++g) {
+            int fp = 4 * g + j;
+            if (fp >= NPAIR) fp = 0;   // zero weights there
+            const int tap = fp / 3, pr = fp - 3 * tap, ky = tap / 3, kx = tap - 3 * ky;
+            adr2[g] = (2 * wave + ky) * RWS + (kx == 1 ? PS : 0) + (p + (kx >> 1)) * RS + pr * 8;
+        }
+    }
+
     // ---- phase 1 bookkeeping: the wave's px-tiles are wave, wave + 8, .. (NU of them, the last only for waves 0..3) ----
     // rr: region row | column << 8 of the lane's pixel; vo: element offset of the lane's input element from the region origin;
     // wo0 / wo1: where the lane's two 4-channel results go.  Lanes without a pixel, and the M-tile-1 lanes whose channels
@@ -170,9 +188,14 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
             const int ry = v ? q / 33 : 0, rx = v ? q - 33 * ry : 0;
             rr[u] = v ? (ry | (rx << 8)) : 0xffff;  // 0xffff: never inside any image window
             vo[u] = (unsigned)((ry * a.W + rx) * 4 + j);
-            const int o = ry * RWS + (rx & 1) * PS + (rx >> 1) * RS + 4 * j;
-            wo0[u] = v ? o : dummy;
-            wo1[u] = (v && j < 2) ? o + 16 : dummy;
+            const int o = ry * RWS + (rx & 1) * PS + (rx >> 1) * RS + (X3 ? 0 : 4 * j);
+            if constexpr (X3) {   // chunk c = j (M-tile 0) / 4 + j (M-tile 1) -> hi4 slot of its pair record
+                wo0[u] = v ? o + 8 * (j >> 1) + 2 * (j & 1) : dummy;
+                wo1[u] = (v && j < 2) ? o + 16 + 2 * j : dummy;
+            } else {
+                wo0[u] = v ? o : dummy;
+                wo1[u] = (v && j < 2) ? o + 16 : dummy;
+            }
         }
     }
 
@@ -217,12 +240,17 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[mt][r] = inimg ? o[mt][r] : 0.f;
         }
-        if constexpr (X3) {   // the record holds the two fp16 halves of its four channels
+        if constexpr (X3) {
+            // a 24-channel record is three PAIR records of 32 bytes, [hi4(chunk 2m) hi4(chunk 2m+1) | lo4(chunk 2m) lo4(chunk 2m+1)]:
+            // phase 2 reads hi8 and lo8 of a pair as two 16-byte pieces that ARE the K = 32 MFMA's B fragments.  wo0 / wo1 point at
+            // the lane's chunk (4 floats per chunk): chunk c -> pair c >> 1, half c & 1; hi4 at 8 (c >> 1) + 2 (c & 1), lo4 4 floats on
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 f16x4 hi, lo;
                 split_f16x4(o[mt][0], o[mt][1], o[mt][2], o[mt][3], hi, lo);
-                *reinterpret_cast<f16x8*>(buf + (mt ? wo1[u] : wo0[u])) = __builtin_shufflevector(hi, lo, 0, 1, 2, 3, 4, 5, 6, 7);
+                TT* dst = buf + (mt ? wo1[u] : wo0[u]);
+                *reinterpret_cast<f16x4*>(dst) = hi;
+                *reinterpret_cast<f16x4*>(dst + 4) = lo;
             }
         } else {
             st4<TT>(buf + wo0[u], make_float4(o[0][0], o[0][1], o[0][2], o[0][3]));
@@ -273,16 +301,47 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
         // rate equals the fp32 vector rate), so phase 1 is written for the fewest VALU instructions, not for overlap ----
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         f32x4 accq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // Q4: channels 16 + 4 cg + i, this lane group's k-values only
-        using xfrag = typename std::conditional<H16, f16x4, typename std::conditional<X3, f16x8, f32x4>::type>::type;
+        f32x4 d[2];
+        if constexpr (X3) {
+            // split-operand phase 2: 7 groups x (2 M-tiles x 3) v_mfma_f32_16x16x32_f16; phase 1 of the next tile rides along:
+            // px-tile u's two fp32 MFMAs in group u, its split + store in group u + 1
+            f16x8 xh = *reinterpret_cast<const f16x8*>(Rc + adr2[0]), xl = *reinterpret_cast<const f16x8*>(Rc + adr2[0] + 4);
+#pragma unroll
+            for (int g = 0; g < NG2; ++g) {
+                f16x8 xhn = xh, xln = xl;
+                if (g + 1 < NG2) {
+                    xhn = *reinterpret_cast<const f16x8*>(Rc + adr2[g + 1]);
+                    xln = *reinterpret_cast<const f16x8*>(Rc + adr2[g + 1] + 4);
+                }
+                if (!(DBG & 1) && g >= 1 && g - 1 < NU) {
+                    p1_store(g - 1, d, Rn, w1);
+                    xin[g - 1] = ld1<TT>(o2 + vo[g - 1]);
+                }
+                if (!(DBG & 1) && g < NU) p1_mfma(g, d);
+                if constexpr (!(DBG & 2)) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl8[g][mt], xh, acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh8[g][mt], xl, acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh8[g][mt], xh, acc[mt], 0, 0, 0);
+                }
+                if (g == 3) { c_n = decode(t + step); w1_n = window(tl); }
+                if (g == 4) { tl_n = decode(t + 3 * step); }
+                if (g == 5) { off2_n = origin(tl_n) - in; }
+                __builtin_amdgcn_sched_barrier(0);
+                xh = xhn; xl = xln;
+            }
+        }
+        using xfrag = typename std::conditional<H16, f16x4, f32x4>::type;
         xfrag xc = *reinterpret_cast<const xfrag*>(Rc + adr[0]), xn = xc;
         f32x4 wq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, wqn[2] = {wq[0], wq[1]};
         if constexpr (Q4) {
 #pragma unroll
             for (int cg = 0; cg < 2; ++cg) wq[cg] = wqn[cg] = *reinterpret_cast<const f32x4*>(WQ + (cg * 64 + lane) * 4);
         }
-        f32x4 d[2];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
+        for (int g = 0; g < (X3 ? 0 : NG); ++g) {
             if (g + 1 < NG) {
                 xn = *reinterpret_cast<const xfrag*>(Rc + adr[g + 1]);
                 if constexpr (Q4) {
@@ -292,15 +351,7 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
             }
             if (!(DBG & 1) && (g & 1) == 0 && g / 2 < NU) p1_mfma(g / 2, d);
             if constexpr (!(DBG & 2)) {
-                if constexpr (X3) {
-                    const f16x4 xh = __builtin_shufflevector(xc, xc, 0, 1, 2, 3), xl = __builtin_shufflevector(xc, xc, 4, 5, 6, 7);
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl[g][mt], xh, acc[mt], 0, 0, 0);
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[g][mt], xl, acc[mt], 0, 0, 0);
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[g][mt], xh, acc[mt], 0, 0, 0);
-                } else if constexpr (H16) {
+                if constexpr (H16) {
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[g][mt], xc, acc[mt], 0, 0, 0);
                 } else if constexpr (Q4) {
@@ -391,7 +442,19 @@ void k19_pack_weights(const float* w9, const float* w21, float* out, int wmode)
     const bool h16 = wmode != WM_F32, x3 = wmode == WM_F16X3;
     uint16_t* oh = reinterpret_cast<uint16_t*>(out);
     uint16_t* ol = reinterpret_cast<uint16_t*>(out + WX3_HALF);   // x3: the lo halves, same layout
-    for (int g = 0; g < NG; ++g)
+    if (x3) {   // K = 32 fragments: lane (cout, jj) holds k = 8 jj + e = chunk 2 (4 g + jj) + (e >> 2), channel e & 3
+        for (int g = 0; g < NG2; ++g)
+            for (int mt = 0; mt < 2; ++mt)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 8; ++e) {
+                        const int cout = 16 * mt + (l & 15), jj = l >> 4, fp = 4 * g + jj, fc = 2 * fp + (e >> 2);
+                        const int tap = fc / 6, c = (fc % 6) * 4 + (e & 3);
+                        const float v = (fp < NPAIR && cout < 24) ? w9[((size_t)tap * 24 + c) * 24 + cout] : 0.f;
+                        oh[((size_t)(g * 2 + mt) * 64 + l) * 8 + e] = f32_to_f16_bits(v);
+                        ol[((size_t)(g * 2 + mt) * 64 + l) * 8 + e] = f16_lo_bits(v);
+                    }
+    }
+    for (int g = 0; g < (x3 ? 0 : NG); ++g)
         for (int s = 0; s < 4; ++s)
             for (int mt = 0; mt < 2; ++mt)
                 for (int l = 0; l < 64; ++l) {
@@ -400,7 +463,6 @@ void k19_pack_weights(const float* w9, const float* w21, float* out, int wmode)
                     const float v = (fc < NCHUNK && cout < 24) ? w9[((size_t)tap * 24 + c) * 24 + cout] : 0.f;
                     if (h16) oh[((size_t)(g * 2 + mt) * 64 + l) * 4 + s] = f32_to_f16_bits(v);
                     else out[((g * 4 + s) * 2 + mt) * 64 + l] = v;
-                    if (x3) ol[((size_t)(g * 2 + mt) * 64 + l) * 4 + s] = f16_lo_bits(v);
                 }
     for (int mt = 0; mt < 2; ++mt)
         for (int r = 0; r < 4; ++r)
