@@ -1,0 +1,25 @@
+#!/bin/bash
+# Run HERE after `gpurun -- 'bash tools/refresh_profiles.sh r02'` has merged gpurun_out/: turns the raw rocprofv3 output into the tracked
+# summaries under profiles/ (kernel stats per run, PMC rows of the yf:: kernels, pmc_traffic.json stamped with the source hash).
+set -e
+cd "$(dirname "$0")/.."
+TAG=${1:-r02}
+python tools/pmc_traffic.py gpurun_out/ops.json gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv profiles/pmc_traffic.json gpurun_out/${TAG}_source_hash.txt 256 256 f32 | head -1
+for t in default lanes1 f16 f16x3 f16x3_512; do
+  f=$(ls gpurun_out/prof_$t/*_kernel_stats.csv)
+  case $t in f16) n=${TAG}_f16_640x512;; f16x3_512) n=${TAG}_f16x3_640x512;; *) n=${TAG}_$t;; esac
+  cp $f profiles/${n}_kernel_stats.csv
+done
+python - <<PY
+import csv
+for src, dst in (('gpurun_out/pmc_fetch/f_counter_collection.csv', 'profiles/${TAG}_pmc_fetch_size.csv'), ('gpurun_out/pmc_write/w_counter_collection.csv', 'profiles/${TAG}_pmc_write_size.csv')):
+    rows = list(csv.DictReader(open(src)))
+    keep = [r for r in rows if 'yf::' in r['Kernel_Name']]
+    cols = ['Dispatch_Id', 'Kernel_Name', 'Grid_Size', 'Workgroup_Size', 'LDS_Block_Size', 'VGPR_Count', 'SGPR_Count', 'Counter_Name', 'Counter_Value']
+    with open(dst, 'w', newline='') as fh:
+        w = csv.DictWriter(fh, fieldnames=cols); w.writeheader()
+        for r in keep:
+            r = dict(r); r['Kernel_Name'] = r['Kernel_Name'].replace('void yf::', '').split('(yf::')[0][:100]
+            w.writerow({c: r[c] for c in cols})
+PY
+echo "profiled build: $(cat gpurun_out/${TAG}_source_hash.txt)   this tree: $(python -c 'import bench; print(bench.source_hash())')"
