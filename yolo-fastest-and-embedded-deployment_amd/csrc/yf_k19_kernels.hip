@@ -38,8 +38,12 @@ constexpr int RS = 24;                     // record stride in elements
 // plane / row strides in elements: padded so that BOTH the phase-2 reads (b128 / b64 lane groups, 64 banks) and the phase-1
 // writes (8- / 16-lane groups, 32 banks) are conflict-free -- unpadded, the writes are 2.3-way conflicted and the LDS write
 // path, not the VALU, is what phase 1 costs (measured: 47 us of 210)
-constexpr int plane_stride(bool h16) { return 17 * RS + (h16 ? 20 : 4); }
-constexpr int row_stride(bool h16) { return 2 * plane_stride(h16) + (h16 ? 20 : 4); }
+#ifndef YF_K19_HPAD
+#define YF_K19_HPAD 8
+#endif
+// (fp16 storage: multiples of 8 halves, the 16-byte pair records of the K = 32 MFMA fragments must stay 16-byte aligned)
+constexpr int plane_stride(bool h16) { return 17 * RS + (h16 ? YF_K19_HPAD : 4); }
+constexpr int row_stride(bool h16) { return 2 * plane_stride(h16) + (h16 ? YF_K19_HPAD : 4); }
 constexpr int NG = 14;                     // k groups
 constexpr int NU = 5;                      // px-tiles of phase 1 per wave (36 over 8 waves)
 constexpr int NCHUNK = 54;                 // 9 taps x 6 chunks of 4 channels
@@ -90,8 +94,7 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
 
     // ---- weights: registers for the lifetime of the workgroup ----
     float wf[M16 ? 1 : NG][4][2];
-    f16x4 wh[H16 ? NG : 1][2];
-    f16x8 wh8[X3 ? NG2 : 1][2], wl8[X3 ? NG2 : 1][2];
+    f16x8 wh8[M16 ? NG2 : 1][2], wl8[X3 ? NG2 : 1][2];
     float w21f[2][4];
     f16x4 w21h[2], w21l[2];
     if constexpr (X3) {
@@ -107,11 +110,11 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
             w21l[mt] = reinterpret_cast<const f16x4*>(a.wp + WX3_HALF + W9_F16)[mt * 64 + lane];
         }
     } else if constexpr (H16) {
-        const f16x4* w = reinterpret_cast<const f16x4*>(a.wp);
+        const f16x8* w = reinterpret_cast<const f16x8*>(a.wp);
 #pragma unroll
-        for (int g = 0; g < NG; ++g)
+        for (int g = 0; g < NG2; ++g)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) wh[g][mt] = w[(g * 2 + mt) * 64 + lane];
+            for (int mt = 0; mt < 2; ++mt) wh8[g][mt] = w[(g * 2 + mt) * 64 + lane];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) w21h[mt] = reinterpret_cast<const f16x4*>(a.wp + W9_F16)[mt * 64 + lane];
     } else {
@@ -161,8 +164,8 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
         adr[g] = (2 * wave + ky) * RWS + (kx == 1 ? PS : 0) + (p + (kx >> 1)) * RS + c4 * 4;
     }
 
-    int adr2[X3 ? NG2 : 1];   // X3: the pair record (32 bytes: [hi8 | lo8]) lane group j reads in group g
-    if constexpr (X3) {
+    int adr2[M16 ? NG2 : 1];   // the pair record lane group j reads in group g -- X3: 32 bytes [hi8 | lo8]; fp16 storage: 8 halves
+    if constexpr (M16) {
 #pragma unroll
         for (int g = 0; g < NG2; ++g) {
             int fp = 4 * g + j;
@@ -302,16 +305,18 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         f32x4 accq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // Q4: channels 16 + 4 cg + i, this lane group's k-values only
         f32x4 d[2];
-        if constexpr (X3) {
-            // split-operand phase 2: 7 groups x (2 M-tiles x 3) v_mfma_f32_16x16x32_f16; phase 1 of the next tile rides along:
-            // px-tile u's two fp32 MFMAs in group u, its split + store in group u + 1
-            f16x8 xh = *reinterpret_cast<const f16x8*>(Rc + adr2[0]), xl = *reinterpret_cast<const f16x8*>(Rc + adr2[0] + 4);
+        if constexpr (M16) {
+            // fp16 matrix pipe: 7 groups of 32 k-values on v_mfma_f32_16x16x32_f16 -- 2 M-tiles x 3 MFMAs with split operands (X3),
+            // 2 x 1 with fp16 storage; phase 1 of the next tile rides along: px-tile u's two fp32 MFMAs in group u, its (split +)
+            // store in group u + 1
+            f16x8 xh = *reinterpret_cast<const f16x8*>(Rc + adr2[0]), xl = xh;
+            if constexpr (X3) xl = *reinterpret_cast<const f16x8*>(Rc + adr2[0] + 4);
 #pragma unroll
             for (int g = 0; g < NG2; ++g) {
                 f16x8 xhn = xh, xln = xl;
                 if (g + 1 < NG2) {
                     xhn = *reinterpret_cast<const f16x8*>(Rc + adr2[g + 1]);
-                    xln = *reinterpret_cast<const f16x8*>(Rc + adr2[g + 1] + 4);
+                    if constexpr (X3) xln = *reinterpret_cast<const f16x8*>(Rc + adr2[g + 1] + 4);
                 }
                 if (!(DBG & 1) && g >= 1 && g - 1 < NU) {
                     p1_store(g - 1, d, Rn, w1);
@@ -319,10 +324,12 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
                 }
                 if (!(DBG & 1) && g < NU) p1_mfma(g, d);
                 if constexpr (!(DBG & 2)) {
+                    if constexpr (X3) {
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl8[g][mt], xh, acc[mt], 0, 0, 0);
+                        for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl8[g][mt], xh, acc[mt], 0, 0, 0);
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh8[g][mt], xl, acc[mt], 0, 0, 0);
+                        for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh8[g][mt], xl, acc[mt], 0, 0, 0);
+                    }
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh8[g][mt], xh, acc[mt], 0, 0, 0);
                 }
@@ -333,15 +340,15 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
                 xh = xhn; xl = xln;
             }
         }
-        using xfrag = typename std::conditional<H16, f16x4, f32x4>::type;
-        xfrag xc = *reinterpret_cast<const xfrag*>(Rc + adr[0]), xn = xc;
+        using xfrag = f32x4;
+        xfrag xc = *reinterpret_cast<const xfrag*>(Rc + (M16 ? 0 : adr[0])), xn = xc;
         f32x4 wq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, wqn[2] = {wq[0], wq[1]};
         if constexpr (Q4) {
 #pragma unroll
             for (int cg = 0; cg < 2; ++cg) wq[cg] = wqn[cg] = *reinterpret_cast<const f32x4*>(WQ + (cg * 64 + lane) * 4);
         }
 #pragma unroll
-        for (int g = 0; g < (X3 ? 0 : NG); ++g) {
+        for (int g = 0; g < (M16 ? 0 : NG); ++g) {
             if (g + 1 < NG) {
                 xn = *reinterpret_cast<const xfrag*>(Rc + adr[g + 1]);
                 if constexpr (Q4) {
@@ -351,10 +358,7 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
             }
             if (!(DBG & 1) && (g & 1) == 0 && g / 2 < NU) p1_mfma(g / 2, d);
             if constexpr (!(DBG & 2)) {
-                if constexpr (H16) {
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[g][mt], xc, acc[mt], 0, 0, 0);
-                } else if constexpr (Q4) {
+                if constexpr (Q4) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][s][0], xc[s], acc[0], 0, 0, 0);
@@ -442,7 +446,7 @@ void k19_pack_weights(const float* w9, const float* w21, float* out, int wmode)
     const bool h16 = wmode != WM_F32, x3 = wmode == WM_F16X3;
     uint16_t* oh = reinterpret_cast<uint16_t*>(out);
     uint16_t* ol = reinterpret_cast<uint16_t*>(out + WX3_HALF);   // x3: the lo halves, same layout
-    if (x3) {   // K = 32 fragments: lane (cout, jj) holds k = 8 jj + e = chunk 2 (4 g + jj) + (e >> 2), channel e & 3
+    if (h16) {   // K = 32 fragments: lane (cout, jj) holds k = 8 jj + e = chunk 2 (4 g + jj) + (e >> 2), channel e & 3
         for (int g = 0; g < NG2; ++g)
             for (int mt = 0; mt < 2; ++mt)
                 for (int l = 0; l < 64; ++l)
@@ -451,18 +455,17 @@ void k19_pack_weights(const float* w9, const float* w21, float* out, int wmode)
                         const int tap = fc / 6, c = (fc % 6) * 4 + (e & 3);
                         const float v = (fp < NPAIR && cout < 24) ? w9[((size_t)tap * 24 + c) * 24 + cout] : 0.f;
                         oh[((size_t)(g * 2 + mt) * 64 + l) * 8 + e] = f32_to_f16_bits(v);
-                        ol[((size_t)(g * 2 + mt) * 64 + l) * 8 + e] = f16_lo_bits(v);
+                        if (x3) ol[((size_t)(g * 2 + mt) * 64 + l) * 8 + e] = f16_lo_bits(v);
                     }
     }
-    for (int g = 0; g < (x3 ? 0 : NG); ++g)
+    for (int g = 0; g < (h16 ? 0 : NG); ++g)
         for (int s = 0; s < 4; ++s)
             for (int mt = 0; mt < 2; ++mt)
                 for (int l = 0; l < 64; ++l) {
                     const int cout = 16 * mt + (l & 15), jj = l >> 4, fc = 4 * g + jj;
                     const int tap = fc / 6, c = (fc % 6) * 4 + s;
                     const float v = (fc < NCHUNK && cout < 24) ? w9[((size_t)tap * 24 + c) * 24 + cout] : 0.f;
-                    if (h16) oh[((size_t)(g * 2 + mt) * 64 + l) * 4 + s] = f32_to_f16_bits(v);
-                    else out[((g * 4 + s) * 2 + mt) * 64 + l] = v;
+                    out[((g * 4 + s) * 2 + mt) * 64 + l] = v;
                 }
     for (int mt = 0; mt < 2; ++mt)
         for (int r = 0; r < 4; ++r)
