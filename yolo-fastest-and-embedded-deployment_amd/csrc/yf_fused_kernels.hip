@@ -21,6 +21,22 @@
 #define YF_FB_DW_UNROLL 1
 #endif
 
+// Output pixels per thread (BH x BW) of the two stride-2 / stride-4 VALU blocks: these kernels are LATENCY-bound (47-55 % of their wave
+// time parked, profiles/r02_wave_time_breakdown.txt) and their residency is set by the E tile in LDS; 16x32-pixel tiles (1 x 2 per
+// thread, 20.7 KB, 7 workgroups per CU) beat 32x32 (2 x 2, 39 KB, 4 per CU) although the halo share of the expansion grows from 13
+// to 20 %: stem 70.9 -> 66.8 us, res2 blocks 58 -> 54 us (A/B, tools/ops_ab.sh).
+#ifndef YF_STEM_BH
+#define YF_STEM_BH 1
+#endif
+#ifndef YF_STEM_BW
+#define YF_STEM_BW 2
+#endif
+#ifndef YF_RES2_BH
+#define YF_RES2_BH 2   // res2: 32x16 tiles (2 x 1 per thread) are another 6 % faster than 16x32 (54 -> 50 us)
+#endif
+#ifndef YF_RES2_BW
+#define YF_RES2_BW 1
+#endif
 #ifndef YF_FB_PK
 #define YF_FB_PK 1   // expansion / projection / conv0 FMAs over output-channel PAIRS as v_pk_fma_f32 (scalar weight pair x broadcast value)
 #endif
@@ -457,9 +473,9 @@ static int launch_fb_t(FbArgs a, int N, hipStream_t s)
 //     cin cexp cout S  res    relu   pre    TYB TXB BH BW EC CG PE XL      (XL: stage the input tile in LDS -- measured
 //     slower at these shapes: it costs occupancy and LDS bandwidth, the L2-served loads were already hidden)
 #define YF_FB_SHAPES(FB)                                                                                                 \
-    FB(8, 8, 4, 1, false, false, true, 16, 16, 2, 2, 8, 8, 1, false)     /* conv0 + conv1_2/1_3/1_4      @ H/2  */          \
+    FB(8, 8, 4, 1, false, false, true, 16, 16, YF_STEM_BH, YF_STEM_BW, 8, 8, 1, false)     /* conv0 + conv1_2/1_3/1_4      @ H/2  */          \
     FB(4, 8, 4, 1, true, false, false, 16, 16, 1, 2, 8, 8, 1, false)     /* res1_1                        @ H/2  */          \
-    FB(8, 32, 8, 1, true, false, false, 16, 16, 2, 2, 8, 8, 1, false)    /* res2_1, res2_2                @ H/4  */          \
+    FB(8, 32, 8, 1, true, false, false, 16, 16, YF_RES2_BH, YF_RES2_BW, 8, 8, 1, false)    /* res2_1, res2_2                @ H/4  */          \
     FB(8, 32, 8, 2, false, false, false, 16, 20, 1, 1, 8, 8, 1, false)   /* conv2_2/2_3/3_1               H/4 -> H/8 */      \
     FB(8, 48, 8, 1, true, false, false, 16, 20, 1, 2, 8, 8, 2, false)    /* res3_1, res3_2                @ H/8  */          \
     FB(8, 48, 16, 1, false, false, false, 16, 20, 1, 2, 8, 8, 2, false)  /* conv3_2/3_3/3_4 (fallback)    @ H/8  */          \
