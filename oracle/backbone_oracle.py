@@ -14,7 +14,9 @@ directly from the 508-key state-dict the reference loads at src/detect.py:90-91.
 
 Parity pin: tests/test_oracle_golden.py checks this file against tests/golden/golden_{256,512}.npz,
 which tests/golden/make_golden.py produced by running the reference module itself on the
-shipped checkpoints (head logits and 25 per-layer probes).  The arithmetic below the
+shipped checkpoints (head logits and 25 per-layer probes); the train-mode graph (forward(train=True)) against
+tests/golden/golden_train_256.npz: the reference's own training iteration -- its heads, every parameter gradient, the
+BatchNorm running statistics.  The arithmetic below the
 torch.nn.functional calls is PyTorch's (the reference pins pytorch 1.2/1.4; un-vendored).
 """
 import torch
@@ -55,8 +57,12 @@ LAYERS = (
 _BY_NAME = {l[0]: l for l in LAYERS}
 
 
-def _unit(sd, name, x):
-    """One conv+BN(+ReLU) unit with the reference's un-folded arithmetic order."""
+BN_MOMENTUM = 0.1  # nn.BatchNorm2d default
+
+
+def _unit(sd, name, x, train=False):
+    """One conv+BN(+ReLU) unit with the reference's un-folded arithmetic order.  train: BatchNorm2d in train mode -- batch
+    statistics, and running_mean / running_var / num_batches_tracked of `sd` are updated in place like the module's buffers."""
     _, kind, cin, cout, k, s, relu = _BY_NAME[name]
     w = sd[name + ".0.weight"]
     if kind == "dc":
@@ -64,61 +70,83 @@ def _unit(sd, name, x):
     else:
         y = F.conv2d(x, w, None, stride=s, padding=(k - 1) // 2, groups=(cin if kind == "dw" else 1))
     y = F.batch_norm(y, sd[name + ".1.running_mean"], sd[name + ".1.running_var"], sd[name + ".1.weight"],
-                     sd[name + ".1.bias"], False, 0.0, BN_EPS)
+                     sd[name + ".1.bias"], train, BN_MOMENTUM if train else 0.0, BN_EPS)
+    if train and (name + ".1.num_batches_tracked") in sd:
+        sd[name + ".1.num_batches_tracked"] += 1
     return F.relu(y) if relu else y
 
 
-def _resblock(sd, name, x):
-    y = _unit(sd, name + ".conv1", x)
-    y = _unit(sd, name + ".conv2", y)
-    y = _unit(sd, name + ".conv3", y)
+def _resblock(sd, name, x, train=False):
+    y = _unit(sd, name + ".conv1", x, train)
+    y = _unit(sd, name + ".conv2", y, train)
+    y = _unit(sd, name + ".conv3", y, train)
     return y + x
 
 
-def forward(sd, x, probes=None):
+def forward(sd, x, probes=None, train=False):
     """yolo_fastest.py:150-218.  x: float32 [N,1,H,W].  Returns (head_large, head_small), NCHW.
-    If `probes` is a dict it is filled with named intermediate activations (NCHW)."""
+    If `probes` is a dict it is filled with named intermediate activations (NCHW).
+    train=True: the module in train mode (train.py:99, :114) -- BatchNorm on batch statistics, and the autograd graph is kept, so
+    `torch.autograd.grad(loss, [sd[k] for k in parameter_keys(sd)])` is what `loss.backward()` (train.py:131) leaves in .grad."""
     def rec(name, t):
         if probes is not None:
             probes[name] = t
         return t
 
-    with torch.no_grad():
+    with torch.enable_grad() if train else torch.no_grad():
         for n in ("conv0", "conv1_2", "conv1_3", "conv1_4"):
-            x = rec(n, _unit(sd, n, x))
-        x = rec("res1_1", _resblock(sd, "res1_1", x))
+            x = rec(n, _unit(sd, n, x, train))
+        x = rec("res1_1", _resblock(sd, "res1_1", x, train))
         for n in ("conv1_8", "conv1_9", "conv2_1"):
-            x = rec(n, _unit(sd, n, x))
+            x = rec(n, _unit(sd, n, x, train))
         for n in ("res2_1", "res2_2"):
-            x = rec(n, _resblock(sd, n, x))
+            x = rec(n, _resblock(sd, n, x, train))
         for n in ("conv2_2", "conv2_3", "conv3_1"):
-            x = rec(n, _unit(sd, n, x))
+            x = rec(n, _unit(sd, n, x, train))
         for n in ("res3_1", "res3_2"):
-            x = rec(n, _resblock(sd, n, x))
+            x = rec(n, _resblock(sd, n, x, train))
         for n in ("conv3_2", "conv3_3", "conv3_4"):
-            x = rec(n, _unit(sd, n, x))
+            x = rec(n, _unit(sd, n, x, train))
         for n in ("res3_3", "res3_4", "res3_5", "res3_6"):
-            x = rec(n, _resblock(sd, n, x))
+            x = rec(n, _resblock(sd, n, x, train))
         for n in ("conv3_5", "conv3_6", "conv4_1"):
-            x = rec(n, _unit(sd, n, x))
+            x = rec(n, _unit(sd, n, x, train))
         for n in ("res4_1", "res4_2", "res4_3", "res4_4"):
-            x = rec(n, _resblock(sd, n, x))
-        conv4_2 = rec("conv4_2", _unit(sd, "conv4_2", x))
-        x = rec("conv4_3", _unit(sd, "conv4_3", conv4_2))
-        x = rec("conv5_1", _unit(sd, "conv5_1", x))
+            x = rec(n, _resblock(sd, n, x, train))
+        conv4_2 = rec("conv4_2", _unit(sd, "conv4_2", x, train))
+        x = rec("conv4_3", _unit(sd, "conv4_3", conv4_2, train))
+        x = rec("conv5_1", _unit(sd, "conv5_1", x, train))
         for n in ("res5_1", "res5_2", "res5_3", "res5_4", "res5_5"):
-            x = rec(n, _resblock(sd, n, x))
-        conv5_2 = rec("conv5_2", _unit(sd, "conv5_2", x))
+            x = rec(n, _resblock(sd, n, x, train))
+        conv5_2 = rec("conv5_2", _unit(sd, "conv5_2", x, train))
         x = conv5_2
         for n in ("conv5_3", "conv5_4", "conv5_5", "conv5_6"):
-            x = rec(n, _unit(sd, n, x))
+            x = rec(n, _unit(sd, n, x, train))
         head_small = F.conv2d(x, sd["head_5.weight"], sd["head_5.bias"])
-        d = rec("deconv5_1", _unit(sd, "deconv5_1", conv5_2))
+        d = rec("deconv5_1", _unit(sd, "deconv5_1", conv5_2, train))
         x = torch.cat((conv4_2, d), 1)  # yolo_fastest.py:209
         for n in ("conv4_1_1", "conv4_1_2", "conv4_1_3", "conv4_1_4", "conv4_1_5"):
-            x = rec(n, _unit(sd, n, x))
+            x = rec(n, _unit(sd, n, x, train))
         head_large = F.conv2d(x, sd["head_4.weight"], sd["head_4.bias"])
     return head_large, head_small
+
+
+def parameter_keys(sd):
+    """The state-dict keys that are nn.Parameters, in `model.parameters()` order (what the optimizer of train.py:84 updates)."""
+    return [k for k in sd if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+
+
+def training_state(sd, dtype=torch.float32):
+    """A state-dict copy ready for forward(train=True): parameters as leaves that require grad, buffers as plain tensors."""
+    out = {}
+    for k, v in sd.items():
+        v = v.detach().clone()
+        if v.is_floating_point():
+            v = v.to(dtype)
+        out[k] = v
+    for k in parameter_keys(out):
+        out[k].requires_grad_(True)
+    return out
 
 
 def preprocess(u8):

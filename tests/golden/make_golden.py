@@ -377,6 +377,88 @@ def main_loss():
     np.savez_compressed(os.path.join(HERE, "golden_loss_256.npz"), **out)
 
 
+def main_train():
+    """Training-step goldens (second slice): the reference's own iteration of train.py:111-132 -- model.train(),
+    optimizer.zero_grad(), pred = model(imgs), the two YOLOLossV3 heads summed, loss.backward(), optim.Adam(lr0 = 0.001, betas
+    (0.9, 0.999), eps 1e-8).step() -- run twice on the reference's batch size (16: the first 16 bundled frames at 256x320, the targets
+    of main_loss) from the shipped checkpoint.  Stored: the train-mode heads, losses and every parameter's gradient of both iterations
+    (for the first one also, from a float64 run of the same reference code, which of them are zero in exact arithmetic), the
+    parameters and BatchNorm running statistics after the second."""
+    import types
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    sys.path.insert(0, os.path.join(REF, "src", "model_training"))
+    from loss.yolo_loss import YOLOLossV3            # the reference
+    g = np.load(os.path.join(HERE, "golden_256.npz"))
+    targets = np.load(os.path.join(HERE, "golden_loss_256.npz"))["targets"][:16].copy()
+    u8 = g["input_u8"][:16]
+    out = {"input_u8": u8, "targets": targets}
+    dev = torch.device("cpu")
+
+    def run(dtype, steps):
+        torch.manual_seed(0)
+        torch.set_default_dtype(dtype)               # the loss builds its masks with torch.zeros(...): default dtype
+        model, io = load_model(256)
+        model = model.to(dtype).train()
+        x = ((torch.from_numpy(u8.astype(np.float32))[:, None] - 128.0) / 255.0).to(dtype)
+        tt = torch.from_numpy(targets).to(dtype)
+        crit = [YOLOLossV3(io["anchors"][i], io["num_cls"], io["input_shape"], dev) for i in range(2)]
+        opt = torch.optim.Adam(model.parameters(), lr=config_params["train_params"]["lr0"], betas=(0.9, 0.999), eps=1e-08)
+        rec = []
+        for it in range(steps):
+            opt.zero_grad()
+            pred = model(x)
+            losses = [[] for _ in range(7)]
+            for i, item_pred in enumerate(pred):
+                for j, v in enumerate(crit[i](item_pred, tt)):
+                    losses[j].append(v)
+            losses = [sum(v) for v in losses]
+            for p in pred:
+                p.retain_grad()
+            losses[0].backward()
+            rec.append(dict(heads=[p.detach().float().numpy().copy() for p in pred], head_grads=[p.grad.detach().clone() for p in pred],
+                            losses=np.array([float(v) for v in losses], np.float64),
+                            grads=np.concatenate([p.grad.detach().float().numpy().ravel() for p in model.parameters()])))
+            opt.step()
+        return model, rec
+
+    model, rec = run(torch.float32, 2)
+    _, rec64 = run(torch.float64, 1)
+    torch.set_default_dtype(torch.float32)
+    out["head_large_1"], out["head_small_1"] = rec[0]["heads"]
+    out["head_large_2"], out["head_small_2"] = rec[1]["heads"]
+    out["losses_1"], out["losses_2"], out["losses_1_f64"] = rec[0]["losses"], rec[1]["losses"], rec64[0]["losses"]
+    out["grads_1"], out["grads_2"] = rec[0]["grads"], rec[1]["grads"]
+    out["params_2"] = np.concatenate([p.detach().numpy().ravel() for p in model.parameters()])
+    out["param_names"] = np.array([n for n, _ in model.named_parameters()])
+    out["param_sizes"] = np.array([p.numel() for p in model.parameters()], np.int64)
+    bufs = [(n, b) for n, b in model.named_buffers() if not n.endswith("num_batches_tracked")]
+    out["buffers_2"] = np.concatenate([b.detach().numpy().ravel() for _, b in bufs])
+    out["buffer_names"] = np.array([n for n, _ in bufs])
+    out["num_batches_tracked_2"] = np.array([int(b) for n, b in model.named_buffers() if n.endswith("num_batches_tracked")], np.int64)
+    # Per parameter tensor, max |gradient| of the float64 run.  It separates the parameters whose gradient is ZERO IN EXACT ARITHMETIC
+    # (a BatchNorm bias or conv bias that only feeds train-mode BatchNorms: 1e-16 in float64, 1e-6 of rounding noise in the
+    # reference's float32 -- which Adam then turns into +-lr steps of random sign) from the ones a parity test can compare.
+    # NOT an accuracy yardstick: in float64 the sigmoids no longer saturate to exactly 1.0, so BCELoss's -100 clamp stops firing and
+    # the class loss itself differs (losses_1_f64).
+    off = np.concatenate([[0], np.cumsum(out["param_sizes"])])
+    # The yardstick for the gradients: the SAME head gradients (the fp32 run's d loss / d heads) pushed back through the network in
+    # float64 -- what the layers' backward gives without rounding.  (The float64 loss itself is no yardstick, see above.)
+    torch.set_default_dtype(torch.float64)
+    m64, _ = load_model(256)
+    m64 = m64.double().train()
+    p64 = m64(((torch.from_numpy(u8.astype(np.float32))[:, None] - 128.0) / 255.0).double())
+    torch.autograd.backward(list(p64), [h.double() for h in rec[0]["head_grads"]])
+    torch.set_default_dtype(torch.float32)
+    out["grads_1_exact"] = np.concatenate([p.grad.detach().float().numpy().ravel() for p in m64.parameters()])
+    out["grad_absmax_f64"] = np.array([np.abs(rec64[0]["grads"][off[i]:off[i + 1]]).max() for i in range(len(off) - 1)], np.float64)
+    print("train: losses", out["losses_1"].tolist(), out["losses_2"].tolist(), "params", out["params_2"].size,
+          "| zero-gradient tensors:", int((out["grad_absmax_f64"] < 1e-9).sum()), "of", len(off) - 1,
+          "| reference fp32 gradients vs exact backward of the same head gradients: worst tensor",
+          max(float(np.abs(out["grads_1"][off[i]:off[i + 1]] - out["grads_1_exact"][off[i]:off[i + 1]]).max() /
+                    np.abs(out["grads_1_exact"][off[i]:off[i + 1]]).max()) for i in range(len(off) - 1) if out["grad_absmax_f64"][i] >= 1e-9))
+    np.savez_compressed(os.path.join(HERE, "golden_train_256.npz"), **out)
+
+
 def main_results():
     """Result-writer goldens (detect.py:176-192): what the reference's own detect.py run left under
     test_result/<size>/<laptop cpu (python)>_test_result/ -- DATA of the reference, not source:
@@ -422,9 +504,12 @@ if __name__ == "__main__":
         main_results()
     elif len(sys.argv) > 1 and sys.argv[1] == "loss":
         main_loss()
+    elif len(sys.argv) > 1 and sys.argv[1] == "train":
+        main_train()
     else:
         main()
         main_val()
         main_map()
         main_results()
         main_loss()
+        main_train()

@@ -116,8 +116,12 @@ def test_create_rejects_bad_arguments_before_touching_the_gpu(sd):
 def test_no_cpu_fallback(sd):
     m = yf.YoloFastest(yf.config_params["io_params"])
     m.load_state_dict(sd)
-    with pytest.raises(RuntimeError, match="eval"):
+    with pytest.raises(RuntimeError, match="no CPU path"):          # train mode (the default): training.py, GPU only as well
         m(torch.zeros(1, 1, 256, 320))
+    from yolo_fastest_amd import training
+    cpu_p = torch.nn.Parameter(torch.zeros(3)); cpu_p.grad = torch.ones(3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        training.Adam([cpu_p]).step()
     m.eval()
     with pytest.raises(RuntimeError, match="no CPU path"):
         m(torch.zeros(1, 1, 256, 320))

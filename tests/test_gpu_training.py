@@ -1,0 +1,440 @@
+"""GPU parity of the TRAINING step (second slice; `python -m pytest tests -m gpu`).
+
+  * every operator of csrc/yf_train_kernels.hip, through the C ABI (`yf_train_*`), against the same torch operator evaluated in
+    float64 on the CPU, on every layer geometry the network has (tolerances are fp32 rounding of sums of that length);
+  * the whole iteration of src/model_training/train.py:111-132 -- model.train(), forward on batch statistics, the two-head loss,
+    backward, Adam -- against the reference's own run of it (tests/golden/golden_train_256.npz, made by make_golden.py main_train):
+    heads, losses, all 256 parameter gradients, and after two iterations the parameters and the BatchNorm running statistics.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WEIGHTS = os.path.join(ROOT, "yolo-fastest-and-embedded-deployment_amd", "assets", "weights", "yolo_fastest_256x320_epoch28.pth")
+
+
+@pytest.fixture(scope="module")
+def yf():
+    import yolo_fastest_amd
+    return yolo_fastest_amd
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops(yf, dev):
+    from yolo_fastest_amd import training
+    return training._Ops(dev)
+
+
+def _g(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+
+def _close(got, want, rel, what):
+    got = got.cpu().numpy().astype(np.float64)
+    want = want.detach().numpy().astype(np.float64)
+    assert got.shape == want.shape, what
+    err = np.abs(got - want).max()
+    assert err <= rel * max(np.abs(want).max(), 1e-30), (what, err, np.abs(want).max())
+
+
+# (Cin, Cout, k, stride, depthwise, H, W): every conv geometry of yolo_fastest.py:78-146, on small maps (odd sizes too: the
+# reference's padding arithmetic, not only the even sizes the network sees)
+CONVS = [(1, 8, 3, 2, 0, 16, 12), (24, 24, 3, 2, 0, 10, 8), (8, 8, 3, 1, 1, 9, 7), (32, 32, 3, 2, 1, 12, 10), (136, 136, 3, 2, 1, 6, 8),
+         (96, 96, 5, 1, 1, 7, 9), (128, 128, 5, 1, 1, 4, 5), (4, 24, 1, 1, 0, 6, 5), (232, 96, 1, 1, 0, 4, 6), (224, 48, 1, 1, 0, 3, 4),
+         (24, 136, 1, 1, 0, 5, 5), (3, 5, 3, 2, 0, 7, 9)]
+
+
+@pytest.mark.parametrize("geom", CONVS)
+def test_conv_forward_backward_match_torch(ops, dev, geom):
+    Cin, Cout, k, stride, dw, H, W = geom
+    rng = np.random.default_rng(sum(geom))
+    N = 3
+    x = rng.normal(size=(N, Cin, H, W)).astype(np.float32)
+    w = rng.normal(size=(Cout, 1 if dw else Cin, k, k)).astype(np.float32)
+    b = rng.normal(size=(Cout,)).astype(np.float32)
+    xt = torch.from_numpy(x).double().requires_grad_(True)
+    wt = torch.from_numpy(w).double().requires_grad_(True)
+    bt = torch.from_numpy(b).double().requires_grad_(True)
+    yt = F.conv2d(xt, wt, bt, stride=stride, padding=(k - 1) // 2, groups=Cin if dw else 1)
+    gy = rng.normal(size=tuple(yt.shape)).astype(np.float32)
+    yt.backward(torch.from_numpy(gy).double())
+    xd, wd, bd, gyd = _g(x, dev), _g(w, dev), _g(b, dev), _g(gy, dev)
+    y = torch.empty(tuple(yt.shape), device=dev)
+    ops.call("yf_train_conv_forward", xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), N, Cin, H, W, Cout, k, stride, dw)
+    _close(y, yt, 2e-6, "forward")
+    y0 = torch.empty_like(y)
+    ops.call("yf_train_conv_forward", xd.data_ptr(), wd.data_ptr(), None, y0.data_ptr(), N, Cin, H, W, Cout, k, stride, dw)
+    _close(y0, yt - bt.detach()[None, :, None, None], 2e-6, "forward without bias")
+    gx = torch.full_like(xd, float("nan"))
+    ops.call("yf_train_conv_backward_data", gyd.data_ptr(), wd.data_ptr(), gx.data_ptr(), N, Cin, H, W, Cout, k, stride, dw)
+    _close(gx, xt.grad, 2e-6, "backward data")
+    gw = torch.full_like(wd, float("nan"))
+    ops.call("yf_train_conv_backward_weight", xd.data_ptr(), gyd.data_ptr(), gw.data_ptr(), N, Cin, H, W, Cout, k, stride, dw)
+    _close(gw, wt.grad, 5e-6, "backward weight")
+    gb = torch.full_like(bd, float("nan"))
+    ops.call("yf_train_channel_sum", gyd.data_ptr(), gb.data_ptr(), N, Cout, y.shape[2] * y.shape[3])
+    _close(gb, bt.grad, 2e-6, "bias gradient")
+
+
+def test_conv_backward_weight_long_reduction(ops, dev):
+    """The chunked reduction (several workgroups per weight element + atomics) at a reduction length of the real batch."""
+    rng = np.random.default_rng(5)
+    N, Cin, Cout, H, W = 16, 8, 32, 64, 80
+    x = rng.normal(size=(N, Cin, H, W)).astype(np.float32)
+    gy = rng.normal(size=(N, Cout, H, W)).astype(np.float32)
+    want = torch.einsum("nchw,nohw->oc", torch.from_numpy(x).double(), torch.from_numpy(gy).double())[:, :, None, None]
+    xd, gyd = _g(x, dev), _g(gy, dev)
+    gw = torch.full((Cout, Cin, 1, 1), float("nan"), device=dev)
+    ops.call("yf_train_conv_backward_weight", xd.data_ptr(), gyd.data_ptr(), gw.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0)
+    _close(gw, want, 2e-5, "backward weight, 81920-long sums")
+
+
+def test_deconv_forward_backward_match_torch(ops, dev):
+    rng = np.random.default_rng(9)
+    for N, Cin, Cout, H, W in ((2, 96, 96, 4, 5), (3, 5, 7, 3, 3)):
+        x = rng.normal(size=(N, Cin, H, W)).astype(np.float32)
+        w = rng.normal(size=(Cin, Cout, 2, 2)).astype(np.float32)
+        xt = torch.from_numpy(x).double().requires_grad_(True)
+        wt = torch.from_numpy(w).double().requires_grad_(True)
+        yt = F.conv_transpose2d(xt, wt, stride=2)
+        gy = rng.normal(size=tuple(yt.shape)).astype(np.float32)
+        yt.backward(torch.from_numpy(gy).double())
+        xd, wd, gyd = _g(x, dev), _g(w, dev), _g(gy, dev)
+        y = torch.empty(tuple(yt.shape), device=dev)
+        ops.call("yf_train_deconv_forward", xd.data_ptr(), wd.data_ptr(), y.data_ptr(), N, Cin, H, W, Cout)
+        _close(y, yt, 2e-6, "forward")
+        gx = torch.full_like(xd, float("nan"))
+        ops.call("yf_train_deconv_backward_data", gyd.data_ptr(), wd.data_ptr(), gx.data_ptr(), N, Cin, H, W, Cout)
+        _close(gx, xt.grad, 2e-6, "backward data")
+        gw = torch.full_like(wd, float("nan"))
+        ops.call("yf_train_deconv_backward_weight", xd.data_ptr(), gyd.data_ptr(), gw.data_ptr(), N, Cin, H, W, Cout)
+        _close(gw, wt.grad, 5e-6, "backward weight")
+
+
+@pytest.mark.parametrize("relu", [0, 1])
+def test_batchnorm_train_mode_matches_torch(ops, dev, relu):
+    rng = np.random.default_rng(11 + relu)
+    for N, C, H, W in ((4, 8, 9, 7), (16, 136, 4, 5), (2, 3, 1, 1)):
+        x = (rng.normal(size=(N, C, H, W)) * rng.uniform(0.5, 3, (1, C, 1, 1)) + rng.normal(size=(1, C, 1, 1))).astype(np.float32)
+        gamma, beta = rng.normal(1, 0.3, C).astype(np.float32), rng.normal(0, 0.5, C).astype(np.float32)
+        rm, rv = rng.normal(size=C).astype(np.float32), rng.uniform(0.5, 2, C).astype(np.float32)
+        bn = torch.nn.BatchNorm2d(C).double().train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.from_numpy(gamma)); bn.bias.copy_(torch.from_numpy(beta))
+            bn.running_mean.copy_(torch.from_numpy(rm)); bn.running_var.copy_(torch.from_numpy(rv))
+        xt = torch.from_numpy(x).double().requires_grad_(True)
+        yt = bn(xt)
+        if relu:
+            yt = F.relu(yt)
+        gy = rng.normal(size=x.shape).astype(np.float32)
+        yt.backward(torch.from_numpy(gy).double())
+        xd, gd, bd, rmd, rvd, gyd = _g(x, dev), _g(gamma, dev), _g(beta, dev), _g(rm, dev), _g(rv, dev), _g(gy, dev)
+        stats, y = torch.empty(2 * C, device=dev), torch.empty_like(xd)
+        ops.call("yf_train_bn_forward", xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), rmd.data_ptr(), rvd.data_ptr(), stats.data_ptr(),
+                 y.data_ptr(), N, C, H * W, relu)
+        _close(y, yt, 3e-6, "forward")
+        _close(rmd, bn.running_mean, 1e-6, "running_mean")
+        _close(rvd, bn.running_var, 1e-6, "running_var (unbiased)")
+        dg, db, gx = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.full_like(xd, float("nan"))
+        ops.call("yf_train_bn_backward", xd.data_ptr(), y.data_ptr(), gyd.data_ptr(), stats.data_ptr(), gd.data_ptr(), dg.data_ptr(),
+                 db.data_ptr(), gx.data_ptr(), N, C, H * W, relu)
+        _close(dg, bn.weight.grad, 5e-6, "dgamma")
+        _close(db, bn.bias.grad, 5e-6, "dbeta")
+        if N * H * W > 2:        # with two samples per channel xhat = +-1 and dx is a difference of nearly equal numbers
+            _close(gx, xt.grad, 2e-5, "dx")
+        # running statistics are optional
+        y2 = torch.empty_like(xd)
+        ops.call("yf_train_bn_forward", xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), None, None, stats.data_ptr(), y2.data_ptr(), N, C, H * W, relu)
+        assert torch.equal(y, y2)
+
+
+def test_add_slice_are_exact(ops, dev):
+    rng = np.random.default_rng(3)
+    a, b = _g(rng.normal(size=(3, 7, 5, 4)), dev), _g(rng.normal(size=(3, 7, 5, 4)), dev)
+    out = torch.empty_like(a)
+    ops.call("yf_train_add", a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel())
+    assert torch.equal(out, a + b)
+    a2 = a.clone()
+    ops.call("yf_train_add", a2.data_ptr(), b.data_ptr(), a2.data_ptr(), a.numel())            # in place
+    assert torch.equal(a2, a + b)
+    c = _g(rng.normal(size=(3, 4, 5, 4)), dev)
+    cat = torch.full((3, 11, 5, 4), float("nan"), device=dev)
+    ops.call("yf_train_channel_slice", a.data_ptr(), cat.data_ptr(), 3, 7, 20, 7, 0, 11, 0)
+    ops.call("yf_train_channel_slice", c.data_ptr(), cat.data_ptr(), 3, 4, 20, 4, 0, 11, 7)
+    assert torch.equal(cat, torch.cat((a, c), 1))
+    back = torch.empty_like(c)
+    ops.call("yf_train_channel_slice", cat.data_ptr(), back.data_ptr(), 3, 4, 20, 11, 7, 4, 0)
+    assert torch.equal(back, c)
+
+
+def test_adam_matches_torch(yf, dev):
+    """training.Adam against torch.optim.Adam (train.py:84's optimizer) on the CPU: five steps, a learning-rate edit in between
+    (train.py:106-109), gradients spanning 1e-9 .. 10 so that the eps term matters."""
+    from yolo_fastest_amd import training
+    rng = np.random.default_rng(2)
+    p0 = rng.normal(size=(37, 11)).astype(np.float32)
+    ref = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    our = torch.nn.Parameter(torch.from_numpy(p0.copy()).to(dev))
+    o_ref = torch.optim.Adam([ref], lr=0.001, betas=(0.9, 0.999), eps=1e-08)
+    o_our = training.Adam([our], lr=0.001, betas=(0.9, 0.999), eps=1e-08)
+    for it in range(5):
+        g = (rng.normal(size=p0.shape) * 10.0 ** rng.uniform(-9, 1, p0.shape)).astype(np.float32)
+        ref.grad = torch.from_numpy(g.copy())
+        our.grad = torch.from_numpy(g.copy()).to(dev)
+        if it == 3:
+            for grp in o_ref.param_groups + o_our.param_groups:
+                grp["lr"] = 0.00037
+        o_ref.step(); o_our.step()
+        assert np.abs(our.detach().cpu().numpy() - ref.detach().numpy()).max() <= 2e-7 * (it + 1), it
+    st = o_our.state[our]
+    assert st["step"] == 5
+    assert np.allclose(st["exp_avg"].cpu().numpy(), o_ref.state[ref]["exp_avg"].numpy(), rtol=1e-5, atol=1e-12)
+    assert np.allclose(st["exp_avg_sq"].cpu().numpy(), o_ref.state[ref]["exp_avg_sq"].numpy(), rtol=1e-5, atol=1e-20)
+    with pytest.raises(RuntimeError):
+        cpu = torch.nn.Parameter(torch.zeros(3)); cpu.grad = torch.ones(3)
+        training.Adam([cpu]).step()
+
+
+GRAD_RATIO = 1.5      # median and 90th percentile (over the parameter tensors) of our distance to the exact gradient, over the reference's
+GRAD_CAP = 8e-2        # no single tensor further than this from exact (relative to its largest element); the reference's worst: 1.2e-2
+
+
+def _split(flat, sizes):
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    return [flat[off[i]:off[i + 1]] for i in range(len(sizes))]
+
+
+def _setup_step(yf, golden, dev):
+    from yolo_fastest_amd import training, validation as val
+    gt = golden("golden_train_256")
+    io = yf.io_params_for(256)
+    m = yf.YoloFastest(io).to(dev)
+    m.load_state_dict(torch.load(WEIGHTS, map_location=dev))
+    m.train()
+    x = ((torch.from_numpy(gt["input_u8"].astype(np.float32))[:, None] - 128.0) / 255.0).to(dev)
+    targets = torch.from_numpy(gt["targets"]).to(dev)
+    crit = [val.YOLOLossV3(io["anchors"][i], io["num_cls"], io["input_shape"], dev, model=m) for i in range(2)]
+    opt = training.Adam(m.parameters(), lr=0.001, betas=(0.9, 0.999), eps=1e-08)          # train.py:84, _config.py:43
+    return gt, m, x, targets, crit, opt
+
+
+def _iteration(m, crit, x, targets):
+    """train.py:114-131 up to and including loss.backward()"""
+    pred = m(x)
+    losses = [[] for _ in range(7)]
+    for i, item_pred in enumerate(pred):
+        for j, v in enumerate(crit[i](item_pred, targets)):
+            losses[j].append(v)
+    losses = [sum(v) for v in losses]
+    losses[0].backward()
+    return pred, np.array([float(v.detach()) if torch.is_tensor(v) else float(v) for v in losses])
+
+
+def test_training_step_matches_the_reference(yf, golden, dev, capsys):
+    """Two iterations of train.py:111-132 at the reference's batch size (16 frames, 256x320) from the shipped checkpoint, against the
+    reference's own run.  Both sides are fp32 with different summation orders, so this is a tolerance test:
+      heads 1e-4 of the logit range, losses 1e-4 relative, in both iterations.
+      Gradients: measured against the EXACT backward (the fp32 head gradients pushed back through the network in float64,
+      grads_1_exact), the reference's own fp32 gradients are off by 1.4e-3 (median over the tensors, relative to each tensor's largest
+      element) up to 1.2e-2 -- not rounding of sums but ReLU decisions: of ~30 M pre-activations a few dozen lie within fp32 rounding of
+      zero and each flips one mask element on one side (tools/train_oracle_report.py shows one: a step of 1e-1 at the layer, 1e-2 in
+      everything upstream, in torch's fp32 as in ours).  Which ones flip is chance, so the test is on the distribution: our median and
+      90th percentile within 1.5x of the reference's, ours the closer one for at least 35 % of the tensors (measured: 47 %), no tensor
+      beyond 8e-2.  The flip-free check of the same backward is test_training_network_against_the_fp64_oracle and the per-operator tests.
+      23 BatchNorm biases have a gradient that is ZERO in exact arithmetic (their output only feeds convolutions followed by train-mode
+      BatchNorm; 1e-16 in the reference's float64 run): only the magnitude is checked (<= 1e-4; the reference's fp32: 1e-6).
+      Optimizer: Adam divides by the gradient's magnitude, so relative gradient noise IS step noise (and the 23 zero-gradient biases
+      take +-lr steps of random sign, in the reference too).  To compare the update itself, the reference's gradients are put in
+      p.grad before optimizer.step() ("teacher forcing"); then iteration 2 starts from the reference's parameters, its heads and
+      losses are tight again, and the parameters after two steps agree to 2e-7.  test_training_free_running_two_steps is the same
+      without forcing."""
+    gt, m, x, targets, crit, opt = _setup_step(yf, golden, dev)
+    names = [n for n, _ in m.named_parameters()]
+    assert names == [str(s) for s in gt["param_names"]]
+    sizes = gt["param_sizes"]
+    zero = gt["grad_absmax_f64"] < 1e-9
+    assert zero.sum() == 23
+    report = []
+    for it in (1, 2):
+        opt.zero_grad()
+        pred, got = _iteration(m, crit, x, targets)
+        for h, name in zip(pred, ("head_large", "head_small")):
+            want = gt["%s_%d" % (name, it)]
+            err = np.abs(h.detach().cpu().numpy() - want).max()
+            report.append("iteration %d %s: max |dlogit| %.2e of %.1f" % (it, name, err, np.abs(want).max()))
+            assert err <= 1e-4 * np.abs(want).max(), (it, name, err)
+        want = gt["losses_%d" % it]
+        report.append("iteration %d losses %s vs %s" % (it, np.round(got, 6).tolist(), np.round(want, 6).tolist()))
+        assert np.allclose(got, want, rtol=1e-4), (it, got, want)
+        ours, theirs, vs_ref = [], [], []
+        exacts = _split(gt["grads_1_exact"], sizes) if it == 1 else [None] * len(sizes)
+        for p, name, ref32, exact, z in zip(m.parameters(), names, _split(gt["grads_%d" % it], sizes), exacts, zero):
+            g = p.grad.detach().cpu().numpy().ravel()
+            assert np.isfinite(g).all(), name
+            if z:
+                assert np.abs(g).max() <= 1e-4, (name, np.abs(g).max())
+                continue
+            scale = np.abs(ref32).max()
+            vs_ref.append(np.abs(g - ref32).max() / scale)
+            assert vs_ref[-1] <= GRAD_CAP, (it, name, vs_ref[-1])
+            if exact is not None:
+                scale = np.abs(exact).max()
+                ours.append(np.abs(g - exact).max() / scale)
+                theirs.append(np.abs(ref32 - exact).max() / scale)
+                assert ours[-1] <= GRAD_CAP, (name, ours[-1], theirs[-1])
+        vs_ref = np.array(vs_ref)
+        report.append("iteration %d gradients vs the reference's, per tensor relative to its largest element: median %.2e / 90%% %.2e / max %.2e"
+                      % (it, np.median(vs_ref), np.quantile(vs_ref, 0.9), vs_ref.max()))
+        assert np.median(vs_ref) <= 5e-3 and np.quantile(vs_ref, 0.9) <= 1.5e-2
+        if it == 1:
+            ours, theirs = np.array(ours), np.array(theirs)
+            report.append("  vs the exact backward of the same head gradients: ours median %.2e / 90%% %.2e / max %.2e; the reference's fp32 median "
+                          "%.2e / 90%% %.2e / max %.2e; ours is the closer one in %d of %d"
+                          % (np.median(ours), np.quantile(ours, 0.9), ours.max(), np.median(theirs), np.quantile(theirs, 0.9), theirs.max(),
+                             (ours < theirs).sum(), ours.size))
+            assert np.median(ours) <= GRAD_RATIO * np.median(theirs) and np.quantile(ours, 0.9) <= GRAD_RATIO * np.quantile(theirs, 0.9)
+            assert (ours < theirs).sum() >= 0.35 * ours.size
+        with torch.no_grad():                                                  # teacher forcing: the reference's gradients
+            for p, ref32 in zip(m.parameters(), _split(gt["grads_%d" % it], sizes)):
+                p.grad.copy_(torch.from_numpy(ref32.reshape(tuple(p.shape))))
+        opt.step()
+
+    worst = 0.0
+    for p, name, want in zip(m.parameters(), names, _split(gt["params_2"], sizes)):
+        worst = max(worst, np.abs(p.detach().cpu().numpy().ravel() - want).max())
+    report.append("parameters after two Adam steps on the reference's gradients: max |d| %.2e (lr 1e-3)" % worst)
+    assert worst <= 2e-7
+    # BatchNorm running statistics after two train-mode forwards, num_batches_tracked
+    bufs = dict((n, b) for n, b in m.named_buffers())
+    off = 0
+    for n in [str(s) for s in gt["buffer_names"]]:
+        b = bufs[n].detach().cpu().numpy().ravel()
+        want = gt["buffers_2"][off:off + b.size]; off += b.size
+        assert np.abs(b - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-3), n
+    assert [int(b) for n, b in m.named_buffers() if n.endswith("num_batches_tracked")] == gt["num_batches_tracked_2"].tolist()
+    with capsys.disabled():
+        print("\n[training step vs reference] " + "\n[training step vs reference] ".join(report))
+
+    # back to inference: eval() re-packs the trained weights (BN fold of the updated parameters and running statistics)
+    m.eval()
+    from oracle import backbone_oracle as bo
+    with torch.no_grad():
+        hl, hs = m(x[:4])
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    wl, ws = bo.forward(sd, x[:4].cpu())
+    assert np.abs(hl.cpu().numpy() - wl.numpy()).max() <= 2e-3 and np.abs(hs.cpu().numpy() - ws.numpy()).max() <= 2e-3
+
+
+def test_training_free_running_two_steps(yf, golden, dev, capsys):
+    """The same two iterations with our own gradients in the optimizer (training.train_step = train.py:111-132 verbatim).  Adam's
+    first step is lr * g / (|g| + eps) = +-lr: only the SIGN of each gradient element matters, so the parameters after step 1 differ
+    from the reference's by 2 lr where a sign differs (gradient elements at the noise level) and by ~0 elsewhere; step 2 mixes the two
+    gradients.  Pinned: every element within the hard bound (2 steps of lr on either side); elements whose gradient is above 10 % of
+    the tensor's largest agree to a quarter of lr in >= 99 %; the second iteration's loss within 2e-3 (measured 2e-4)."""
+    from yolo_fastest_amd import training
+    gt, m, x, targets, crit, opt = _setup_step(yf, golden, dev)
+    sizes = gt["param_sizes"]
+    zero = gt["grad_absmax_f64"] < 1e-9
+    l1 = training.train_step(m, crit, opt, x, targets)
+    l2 = training.train_step(m, crit, opt, x, targets)
+    assert np.allclose(float(l1[0].detach()), gt["losses_1"][0], rtol=1e-4) and np.allclose(float(l2[0].detach()), gt["losses_2"][0], rtol=2e-3)
+    assert float(l2[0].detach()) < float(l1[0].detach())
+    lr = 0.001
+    tot = bad = 0
+    for p, want, g1, g2, z in zip(m.parameters(), _split(gt["params_2"], sizes), _split(gt["grads_1"], sizes), _split(gt["grads_2"], sizes), zero):
+        got = p.detach().cpu().numpy().ravel()
+        assert np.abs(got - want).max() <= 4.01 * lr
+        if z:
+            continue
+        ok = (np.abs(g1) > 0.1 * np.abs(g1).max()) & (np.abs(g2) > 0.1 * np.abs(g2).max())
+        tot += ok.sum(); bad += (np.abs(got - want)[ok] > 0.25 * lr).sum()
+    with capsys.disabled():
+        print("\n[free-running] losses %.5f -> %.5f (reference %.5f -> %.5f); %d of %d large-gradient elements differ by more than lr/4"
+              % (float(l1[0].detach()), float(l2[0].detach()), gt["losses_1"][0], gt["losses_2"][0], bad, tot))
+    assert tot > 1000 and bad <= 0.01 * tot, (bad, tot)
+
+
+@pytest.mark.parametrize("seed,tol", [(1, 1e-3), (2, 2e-2)])
+def test_training_network_against_the_fp64_oracle(yf, dev, seed, tol):
+    """The composition (residual adds, the conv4_2 / conv5_2 branch points, deconv, torch.cat, both heads, the loss) on random weights
+    and a small batch: our train-mode heads against oracle/backbone_oracle.py in float64, and our parameter gradients against the
+    oracle's backward of OUR head gradients.  Seed 1 is a case without a ReLU flip between our fp32 forward and the float64 one (the
+    forward kernels are deterministic, so it stays one): EVERY gradient tensor within 1e-3 of its largest element (measured 3.5e-4;
+    torch's own fp32 has a flip in this case and is off by 1e-1).  Seed 2 has one near-zero activation in conv4_1_4: 2e-2.
+    (tools/train_oracle_report.py prints the per-tensor table, ours and torch-fp32.)"""
+    from oracle import backbone_oracle as bo
+    from yolo_fastest_amd import validation as val
+    torch.manual_seed(seed)
+    io = yf.io_params_for(256)
+    m = yf.YoloFastest(io)
+    m.initialize_weights()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.bias.normal_(0, 0.2); mod.running_mean.normal_(0, 0.1); mod.running_var.uniform_(0.5, 1.5)
+        m.head_4.bias.normal_(0, 0.5); m.head_5.bias.normal_(0, 0.5)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(dev).train()
+    N, H, W = 3, 64, 96
+    x = torch.rand(N, 1, H, W) - 0.5
+    rng = np.random.default_rng(seed)
+    t = np.zeros((N, 8, 6), np.float32)
+    for b in range(N):
+        k = 2 + b % 5
+        t[b, :k, 0:2] = rng.uniform(0.05, 0.95, (k, 2)); t[b, :k, 2:4] = rng.uniform(0.05, 0.6, (k, 2))
+        t[b, :k, 4] = rng.integers(0, 3, k); t[b, :k, 5] = 255.0
+    shape = [H, W, 1]
+    pred = m(x.to(dev))
+    for p in pred:
+        p.retain_grad()
+    loss = sum(val.YOLOLossV3(io["anchors"][i], 3, shape, dev, model=m)(p, torch.from_numpy(t).to(dev))[0] for i, p in enumerate(pred))
+    loss.backward()
+    sd = bo.training_state(sd0, torch.float64)
+    keys = bo.parameter_keys(sd)
+    want = bo.forward(sd, x.double(), train=True)
+    for got, w in zip(pred, want):
+        assert np.abs(got.detach().cpu().numpy() - w.detach().numpy()).max() <= 2e-4 * max(1.0, float(w.detach().abs().max()))
+    g64 = torch.autograd.grad(list(want), [sd[k] for k in keys], [p.grad.cpu().double() for p in pred])
+    for (name, p), w in zip(m.named_parameters(), g64):
+        g, w = p.grad.cpu().numpy().astype(np.float64), w.numpy()
+        scale = np.abs(w).max()
+        if scale < 1e-9:                        # zero in exact arithmetic (see the step test)
+            assert np.abs(g).max() <= 1e-4, name
+            continue
+        assert np.abs(g - w).max() / scale <= tol, (name, np.abs(g - w).max() / scale)
+    # the running statistics moved like the module's buffers
+    for k in ("conv0.1.running_mean", "res5_5.conv2.1.running_var", "conv4_1_5.1.running_var", "deconv5_1.1.running_mean"):
+        assert np.allclose(m.state_dict()[k].cpu().numpy(), sd[k].numpy(), rtol=1e-5, atol=1e-7), k
+
+
+def test_training_forward_guards(yf, dev):
+    io = yf.io_params_for(256)
+    m = yf.YoloFastest(io).to(dev).train()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 1, 64, 64))                                 # CPU tensor
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 1, 60, 64, device=dev))
+    with torch.no_grad():                                            # no graph: plain heads, running statistics still move
+        before = m.conv0[1].running_mean.clone()
+        hl, hs = m(torch.rand(2, 1, 64, 64, device=dev))
+        assert not hl.requires_grad and hl.shape == (2, 24, 4, 4) and hs.shape == (2, 24, 2, 2)
+        assert not torch.equal(before, m.conv0[1].running_mean)
+    hl, hs = m(torch.rand(2, 1, 64, 64, device=dev))
+    assert hl.requires_grad
+    (hl.sum() + hs.sum()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    with pytest.raises(RuntimeError):
+        (hl.sum()).backward()                                        # the tape is freed by the first backward

@@ -194,3 +194,39 @@ def test_loss_oracle_matches_the_reference(golden):
         L, G = lo.loss_and_grad(torch.from_numpy(g[name].copy()), torch.from_numpy(gl["targets"]), io["anchors"][i], 3, io["input_shape"])
         assert np.array_equal(L, gl[name + "_losses"]), name
         assert np.array_equal(G.numpy(), gl[name + "_grad"]), name
+
+
+def test_train_mode_oracle_matches_the_reference(golden):
+    """oracle/backbone_oracle.forward(train=True) + oracle/loss_oracle.py = one iteration of train.py:111-131 (train-mode forward on
+    batch statistics, the two-head loss, backward) against the reference's own run (tests/golden/make_golden.py main_train): same
+    torch operators in the same order, so heads, losses, all 256 parameter gradients and the running statistics are identical; and
+    in float64, fed the fp32 run's head gradients, the backward reproduces the `grads_1_exact` yardstick."""
+    import yolo_fastest_amd as yf
+    from oracle import loss_oracle as lo
+    gt = golden("golden_train_256")
+    io = yf.io_params_for(256)
+    sd = bo.training_state(bo.load_state_dict(WEIGHTS[256]))
+    keys = bo.parameter_keys(sd)
+    assert keys == [str(s) for s in gt["param_names"]]
+    x = bo.preprocess(gt["input_u8"])
+    targets = torch.from_numpy(gt["targets"])
+    hl, hs = bo.forward(sd, x, train=True)
+    assert np.array_equal(hl.detach().numpy(), gt["head_large_1"]) and np.array_equal(hs.detach().numpy(), gt["head_small_1"])
+    outs = [lo.loss_head(h, targets, io["anchors"][i], 3, io["input_shape"]) for i, h in enumerate((hl, hs))]
+    hl.retain_grad(); hs.retain_grad()
+    total = outs[0][0] + outs[1][0]
+    got = np.array([float(total.detach())] + [outs[0][j] + outs[1][j] for j in range(1, 7)])
+    assert np.allclose(got, gt["losses_1"], rtol=1e-6), (got, gt["losses_1"])
+    grads = torch.autograd.grad(total, [sd[k] for k in keys] + [hl, hs])
+    head_grads = grads[-2:]
+    flat = np.concatenate([g.numpy().ravel() for g in grads[:-2]])
+    assert flat.shape == gt["grads_1"].shape
+    assert np.abs(flat - gt["grads_1"]).max() <= 1e-6 * np.abs(gt["grads_1"]).max()
+    # running statistics after ONE train-mode forward: momentum 0.1 towards the (unbiased) batch statistics
+    assert int(sd["conv0.1.num_batches_tracked"]) == int(bo.load_state_dict(WEIGHTS[256])["conv0.1.num_batches_tracked"]) + 1
+    # the float64 yardstick of the gradients
+    sd64 = bo.training_state(bo.load_state_dict(WEIGHTS[256]), torch.float64)
+    p64 = bo.forward(sd64, x.double(), train=True)
+    g64 = torch.autograd.grad(list(p64), [sd64[k] for k in keys], [h.double() for h in head_grads])
+    flat64 = np.concatenate([g.float().numpy().ravel() for g in g64])
+    assert np.abs(flat64 - gt["grads_1_exact"]).max() <= 1e-6 * np.abs(gt["grads_1_exact"]).max()

@@ -897,6 +897,80 @@ int yf_train_loss(yf_handle h, const float* d_head, int N, int fh, int fw, const
     return YF_OK;
 }
 
+// ---- training-step operators (second slice); NCHW fp32 device pointers, stream-ordered ----
+#define YF_TOP(cond, call)                                                          \
+    do {                                                                            \
+        if (!(cond)) return fail(YF_E_INVALID, "%s: bad argument", __func__);       \
+        HIP_OK(hipSetDevice(device));                                               \
+        call;                                                                       \
+        HIP_OK(hipGetLastError());                                                  \
+        return YF_OK;                                                               \
+    } while (0)
+
+int yf_train_conv_forward(int device, const float* d_x, const float* d_w, const float* d_bias, float* d_y, int N, int Cin, int H, int W, int Cout,
+                          int k, int stride, int depthwise, void* stream)
+{
+    YF_TOP(d_x && d_w && d_y && N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (k == 1 || k == 3 || k == 5) && (stride == 1 || stride == 2) &&
+               (!depthwise || Cin == Cout),
+           yf::launch_tconv_fwd(d_x, d_w, d_bias, d_y, N, Cin, H, W, Cout, k, stride, depthwise, (hipStream_t)stream));
+}
+int yf_train_conv_backward_data(int device, const float* d_dy, const float* d_w, float* d_dx, int N, int Cin, int H, int W, int Cout, int k,
+                                int stride, int depthwise, void* stream)
+{
+    YF_TOP(d_dy && d_w && d_dx && N > 0 && (k == 1 || k == 3 || k == 5) && (stride == 1 || stride == 2) && (!depthwise || Cin == Cout),
+           yf::launch_tconv_bwd_data(d_dy, d_w, d_dx, N, Cin, H, W, Cout, k, stride, depthwise, (hipStream_t)stream));
+}
+int yf_train_conv_backward_weight(int device, const float* d_x, const float* d_dy, float* d_dw, int N, int Cin, int H, int W, int Cout, int k,
+                                  int stride, int depthwise, void* stream)
+{
+    YF_TOP(d_x && d_dy && d_dw && N > 0 && (k == 1 || k == 3 || k == 5) && (stride == 1 || stride == 2) && (!depthwise || Cin == Cout),
+           yf::launch_tconv_bwd_weight(d_x, d_dy, d_dw, N, Cin, H, W, Cout, k, stride, depthwise, (hipStream_t)stream));
+}
+int yf_train_deconv_forward(int device, const float* d_x, const float* d_w, float* d_y, int N, int Cin, int H, int W, int Cout, void* stream)
+{
+    YF_TOP(d_x && d_w && d_y && N > 0, yf::launch_tdeconv_fwd(d_x, d_w, d_y, N, Cin, H, W, Cout, (hipStream_t)stream));
+}
+int yf_train_deconv_backward_data(int device, const float* d_dy, const float* d_w, float* d_dx, int N, int Cin, int H, int W, int Cout, void* stream)
+{
+    YF_TOP(d_dy && d_w && d_dx && N > 0, yf::launch_tdeconv_bwd_data(d_dy, d_w, d_dx, N, Cin, H, W, Cout, (hipStream_t)stream));
+}
+int yf_train_deconv_backward_weight(int device, const float* d_x, const float* d_dy, float* d_dw, int N, int Cin, int H, int W, int Cout, void* stream)
+{
+    YF_TOP(d_x && d_dy && d_dw && N > 0, yf::launch_tdeconv_bwd_weight(d_x, d_dy, d_dw, N, Cin, H, W, Cout, (hipStream_t)stream));
+}
+int yf_train_bn_forward(int device, const float* d_x, const float* d_gamma, const float* d_beta, float* d_running_mean, float* d_running_var,
+                        float* d_stats, float* d_y, int N, int C, long HW, int relu, void* stream)
+{
+    YF_TOP(d_x && d_gamma && d_beta && d_stats && d_y && N > 0 && C > 0 && HW > 0,
+           yf::launch_tbn_fwd(d_x, d_gamma, d_beta, d_running_mean, d_running_var, d_stats, d_y, N, C, HW, relu, (hipStream_t)stream));
+}
+int yf_train_bn_backward(int device, const float* d_x, const float* d_y, const float* d_dy, const float* d_stats, const float* d_gamma,
+                         float* d_dgamma, float* d_dbeta, float* d_dx, int N, int C, long HW, int relu, void* stream)
+{
+    YF_TOP(d_x && d_y && d_dy && d_stats && d_gamma && d_dgamma && d_dbeta && d_dx && N > 0 && C > 0 && HW > 0,
+           yf::launch_tbn_bwd(d_x, d_y, d_dy, d_stats, d_gamma, d_dgamma, d_dbeta, d_dx, N, C, HW, relu, (hipStream_t)stream));
+}
+int yf_train_channel_sum(int device, const float* d_dy, float* d_out, int N, int C, long HW, void* stream)
+{
+    YF_TOP(d_dy && d_out && N > 0 && C > 0 && HW > 0, yf::launch_tchan_sum(d_dy, d_out, N, C, HW, (hipStream_t)stream));
+}
+int yf_train_add(int device, const float* d_a, const float* d_b, float* d_out, long total, void* stream)
+{
+    YF_TOP(d_a && d_b && d_out && total > 0, yf::launch_tadd(d_a, d_b, d_out, total, (hipStream_t)stream));
+}
+int yf_train_channel_slice(int device, const float* d_src, float* d_dst, int N, int C, long HW, int Cs, int sc0, int Cd, int dc0, void* stream)
+{
+    YF_TOP(d_src && d_dst && N > 0 && C > 0 && sc0 >= 0 && dc0 >= 0 && sc0 + C <= Cs && dc0 + C <= Cd,
+           yf::launch_tslice(d_src, d_dst, N, C, HW, Cs, sc0, Cd, dc0, (hipStream_t)stream));
+}
+int yf_train_adam_step(int device, float* d_p, const float* d_g, float* d_m, float* d_v, long total, double lr, double beta1, double beta2,
+                       double eps, int step, void* stream)
+{
+    YF_TOP(d_p && d_g && d_m && d_v && total > 0 && step >= 1,
+           yf::launch_tadam(d_p, d_g, d_m, d_v, total, lr, beta1, beta2, eps, step, (hipStream_t)stream));
+}
+#undef YF_TOP
+
 int yf_detect(yf_handle h, const float* d_x, int N, double conf_thres, double nms_thres, const double* anchors, int origin_h,
               int origin_w, int K_max, int32_t* d_boxes, float* d_scores, int32_t* d_cls, int32_t* d_src, int32_t* d_counts,
               float* d_hl, float* d_hs, void* ws, size_t ws_bytes, void* stream)

@@ -228,6 +228,24 @@ int launch_val_nms(const float* pred, int N, int M, float conf_thres, float nms_
 size_t train_loss_workspace_bytes(int N, int fh, int fw);
 void launch_train_loss(const float* head, int N, int fh, int fw, const float* anc6, const float* targets, int T, float ignore_thres,
                        void* work, float* losses, float* grad, hipStream_t s);
+// training-step operators (yf_train_kernels.hip): NCHW fp32, correctness-first
+void launch_tconv_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W, int Cout, int k, int stride,
+                      int depthwise, hipStream_t s);
+void launch_tconv_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int k, int stride, int depthwise,
+                           hipStream_t s);
+void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int k, int stride, int depthwise,
+                             hipStream_t s);
+void launch_tdeconv_fwd(const float* x, const float* w, float* y, int N, int Cin, int H, int W, int Cout, hipStream_t s);
+void launch_tdeconv_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, hipStream_t s);
+void launch_tdeconv_bwd_weight(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, hipStream_t s);
+void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* stats, float* y, int N,
+                    int C, long HW, int relu, hipStream_t s);
+void launch_tbn_bwd(const float* x, const float* y, const float* dy, const float* stats, const float* gamma, float* dgamma, float* dbeta, float* dx,
+                    int N, int C, long HW, int relu, hipStream_t s);
+void launch_tchan_sum(const float* dy, float* out, int N, int C, long HW, hipStream_t s);
+void launch_tadd(const float* a, const float* b, float* out, long total, hipStream_t s);
+void launch_tslice(const float* src, float* dst, int N, int C, long HW, int Cs, int sc0, int Cd, int dc0, hipStream_t s);
+void launch_tadam(float* p, const float* g, float* m, float* v, long total, double lr, double b1, double b2, double eps, int step, hipStream_t s);
 void launch_nms_sorted(const int32_t* boxes, int n, double nms_thres, int32_t* suppressor, hipStream_t s);
 
 }  // namespace yf

@@ -8,8 +8,9 @@ Drop-in surface kept:
   * `model(x)`: x float32 [N,1,H,W] NCHW, H and W multiples of 32 -> `(head_large, head_small)` float32
     NCHW on the same device (:218).
 The torch.nn modules below are parameter CONTAINERS only (they give the state-dict its names and shapes);
-they are never called.  forward() packs them once (BN fold, packer.py) and runs hand-written HIP kernels.
-There is no CPU path: a non-GPU tensor, train mode, or a missing extension raises.
+they are never called.  In eval mode forward() packs them once (BN fold, packer.py) and runs the tuned HIP engine; in train mode it
+runs the training operators (training.py: batch-statistics BatchNorm, differentiable).  There is no CPU path: a non-GPU tensor or
+a missing extension raises.
 """
 import ctypes
 
@@ -213,7 +214,13 @@ class YoloFastest(nn.Module):
     # -- forward --------------------------------------------------------------------------------
     def forward(self, x, slot=0):
         if self.training:
-            raise RuntimeError("YoloFastest (HIP engine) is inference-only: call .eval() first (detect.py:89)")
+            # train.py:114 `pred = model(imgs)` after model.train(): batch-statistics BatchNorm, differentiable (training.py)
+            from . import training
+            self._weights_dirty = True           # the optimizer will move the parameters: re-pack at the next eval forward
+            return training.forward(self, x)
+        if getattr(self, "_weights_dirty", False):
+            self._invalidate()
+            self._weights_dirty = False
         if not x.is_cuda:
             raise RuntimeError("YoloFastest (HIP engine) has no CPU path: move the model and input to the GPU")
         if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] % 32 or x.shape[3] % 32:

@@ -1,0 +1,286 @@
+"""The reference's TRAINING step on the GPU (second slice): `src/model_training/train.py:98-132`
+
+    model.train()
+    optimizer.zero_grad()
+    pred = model(imgs)                                   # train-mode forward: BatchNorm on batch statistics, running stats updated
+    loss = sum(model_loss[i](pred[i], targets)[0] ...)   # validation.YOLOLossV3 (yf_train_loss)
+    loss.backward()                                      # backward of every layer -> param.grad
+    optimizer.step()                                     # training.Adam (yf_train_adam_step) -- or any torch optimizer
+
+`YoloFastest.forward` routes here when the module is in train mode.  Every operator is a HIP kernel behind the C ABI
+(`yf_train_*`, csrc/yf_train_kernels.hip): Conv2d / ConvTranspose2d forward, backward-data, backward-weight; BatchNorm2d in train
+mode with its backward (ReLU fused); channel slices for the torch.cat; Adam.  torch.autograd only carries the gradient across the
+boundary (one Function for the whole network whose inputs are the parameters) -- no torch operator computes anything.
+Correctness-first kernels: NCHW fp32 like the reference, one launch per layer, not the tuned inference engine (which folds
+BatchNorm into the weights and so cannot train).  No CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_SEQ1 = ["conv0", "conv1_2", "conv1_3", "conv1_4", "res1_1", "conv1_8", "conv1_9", "conv2_1", "res2_1", "res2_2", "conv2_2", "conv2_3",
+         "conv3_1", "res3_1", "res3_2", "conv3_2", "conv3_3", "conv3_4", "res3_3", "res3_4", "res3_5", "res3_6", "conv3_5", "conv3_6",
+         "conv4_1", "res4_1", "res4_2", "res4_3", "res4_4", "conv4_2"]                               # yolo_fastest.py:151-190
+_SEQ2 = ["conv4_3", "conv5_1", "res5_1", "res5_2", "res5_3", "res5_4", "res5_5", "conv5_2"]          # :191-200
+_SEQ3 = ["conv5_3", "conv5_4", "conv5_5", "conv5_6"]                                                 # :201-204
+_SEQ4 = ["conv4_1_1", "conv4_1_2", "conv4_1_3", "conv4_1_4", "conv4_1_5"]                            # :211-215
+
+
+class _Ops:
+    """ctypes front of the yf_train_* entry points for one device / stream."""
+
+    def __init__(self, device):
+        self.lib = _lib.lib()
+        self.device = device
+        self.dev = device.index if device.index is not None else torch.cuda.current_device()
+        self.stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+    def new(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    def call(self, name, *args):
+        _lib.check(getattr(self.lib, name)(self.dev, *args, self.stream))
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _conv_geom(conv, x):
+    k, stride = conv.kernel_size[0], conv.stride[0]
+    N, Cin, H, W = x.shape
+    Cout = conv.out_channels
+    dw = 1 if conv.groups > 1 else 0
+    if dw and not (conv.groups == Cin == Cout):
+        raise NotImplementedError("grouped convolution other than depthwise")
+    pad = (k - 1) // 2
+    return N, Cin, H, W, Cout, k, stride, dw, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+
+
+def _unit_forward(ops, mod, x, tape, name):
+    """conv_norm[_relu] / deconv_norm_relu (yolo_fastest.py:16-48) in train mode."""
+    conv, bn = mod[0], mod[1]
+    relu = 1 if len(mod) == 3 else 0
+    if isinstance(conv, torch.nn.ConvTranspose2d):
+        N, Cin, H, W = x.shape
+        Cout = conv.out_channels
+        z = ops.new(N, Cout, 2 * H, 2 * W)
+        ops.call("yf_train_deconv_forward", x.data_ptr(), conv.weight.data_ptr(), z.data_ptr(), N, Cin, H, W, Cout)
+    else:
+        N, Cin, H, W, Cout, k, stride, dw, Ho, Wo = _conv_geom(conv, x)
+        z = ops.new(N, Cout, Ho, Wo)
+        ops.call("yf_train_conv_forward", x.data_ptr(), conv.weight.data_ptr(), None, z.data_ptr(), N, Cin, H, W, Cout, k, stride, dw)
+    y = torch.empty_like(z)
+    stats = ops.new(2 * Cout)
+    HW = z.shape[2] * z.shape[3]
+    ops.call("yf_train_bn_forward", z.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), _ptr(bn.running_mean), _ptr(bn.running_var),
+             stats.data_ptr(), y.data_ptr(), N, Cout, HW, relu)
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    tape[name] = (x, z, y, stats, relu)
+    return y
+
+
+def _unit_backward(ops, mod, tape, name, gy, grads, need_dx=True):
+    conv, bn = mod[0], mod[1]
+    x, z, y, stats, relu = tape[name]
+    N, Cout = z.shape[0], z.shape[1]
+    HW = z.shape[2] * z.shape[3]
+    gz = torch.empty_like(z)
+    dgamma, dbeta = ops.new(Cout), ops.new(Cout)
+    ops.call("yf_train_bn_backward", z.data_ptr(), y.data_ptr(), gy.data_ptr(), stats.data_ptr(), bn.weight.data_ptr(), dgamma.data_ptr(),
+             dbeta.data_ptr(), gz.data_ptr(), N, Cout, HW, relu)
+    grads[bn.weight], grads[bn.bias] = dgamma, dbeta
+    dw_ = torch.empty_like(conv.weight)
+    gx = torch.empty_like(x) if need_dx else None
+    if isinstance(conv, torch.nn.ConvTranspose2d):
+        _, Cin, H, W = x.shape
+        ops.call("yf_train_deconv_backward_weight", x.data_ptr(), gz.data_ptr(), dw_.data_ptr(), N, Cin, H, W, Cout)
+        if need_dx:
+            ops.call("yf_train_deconv_backward_data", gz.data_ptr(), conv.weight.data_ptr(), gx.data_ptr(), N, Cin, H, W, Cout)
+    else:
+        _, Cin, H, W, _, k, stride, dw, _, _ = _conv_geom(conv, x)
+        ops.call("yf_train_conv_backward_weight", x.data_ptr(), gz.data_ptr(), dw_.data_ptr(), N, Cin, H, W, Cout, k, stride, dw)
+        if need_dx:
+            ops.call("yf_train_conv_backward_data", gz.data_ptr(), conv.weight.data_ptr(), gx.data_ptr(), N, Cin, H, W, Cout, k, stride, dw)
+    grads[conv.weight] = dw_
+    return gx
+
+
+def _res_forward(ops, blk, x, tape, name):          # BasicResBlock.forward, yolo_fastest.py:60-66
+    y = _unit_forward(ops, blk.conv1, x, tape, name + ".conv1")
+    y = _unit_forward(ops, blk.conv2, y, tape, name + ".conv2")
+    y = _unit_forward(ops, blk.conv3, y, tape, name + ".conv3")
+    ops.call("yf_train_add", y.data_ptr(), x.data_ptr(), y.data_ptr(), y.numel())     # out += residual (conv3 has no ReLU: its backward
+    return y                                                                            # does not read y)
+
+
+def _res_backward(ops, blk, tape, name, g, grads):
+    gx = _unit_backward(ops, blk.conv3, tape, name + ".conv3", g, grads)
+    gx = _unit_backward(ops, blk.conv2, tape, name + ".conv2", gx, grads)
+    gx = _unit_backward(ops, blk.conv1, tape, name + ".conv1", gx, grads)
+    ops.call("yf_train_add", gx.data_ptr(), g.data_ptr(), gx.data_ptr(), gx.numel())
+    return gx
+
+
+def _run(ops, model, names, x, tape):
+    for n in names:
+        m = getattr(model, n)
+        x = _res_forward(ops, m, x, tape, n) if n.startswith("res") else _unit_forward(ops, m, x, tape, n)
+    return x
+
+
+def _run_back(ops, model, names, g, tape, grads, first_needs_dx=True):
+    for i in range(len(names) - 1, -1, -1):
+        n = names[i]
+        m = getattr(model, n)
+        if n.startswith("res"):
+            g = _res_backward(ops, m, tape, n, g, grads)
+        else:
+            g = _unit_backward(ops, m, tape, n, g, grads, need_dx=(i > 0 or first_needs_dx))
+    return g
+
+
+def _head_forward(ops, conv, x, tape, name):        # nn.Conv2d(C, num_out, 1) with bias, yolo_fastest.py:136 / :146
+    N, Cin, H, W = x.shape
+    y = ops.new(N, conv.out_channels, H, W)
+    ops.call("yf_train_conv_forward", x.data_ptr(), conv.weight.data_ptr(), conv.bias.data_ptr(), y.data_ptr(), N, Cin, H, W, conv.out_channels,
+             1, 1, 0)
+    tape[name] = x
+    return y
+
+
+def _head_backward(ops, conv, tape, name, gy, grads):
+    x = tape[name]
+    N, Cin, H, W = x.shape
+    Cout = conv.out_channels
+    gy = gy.contiguous()
+    dw_, db, gx = torch.empty_like(conv.weight), ops.new(Cout), torch.empty_like(x)
+    ops.call("yf_train_conv_backward_weight", x.data_ptr(), gy.data_ptr(), dw_.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0)
+    ops.call("yf_train_channel_sum", gy.data_ptr(), db.data_ptr(), N, Cout, H * W)
+    ops.call("yf_train_conv_backward_data", gy.data_ptr(), conv.weight.data_ptr(), gx.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0)
+    grads[conv.weight], grads[conv.bias] = dw_, db
+    return gx
+
+
+def train_forward(model, x):
+    """YoloFastest.forward (yolo_fastest.py:150-218) in train mode -> (head_large, head_small, tape)."""
+    ops = _Ops(x.device)
+    tape = {}
+    a = _run(ops, model, _SEQ1, x, tape)                       # conv4_2
+    b = _run(ops, model, _SEQ2, a, tape)                       # conv5_2
+    c = _run(ops, model, _SEQ3, b, tape)
+    hs = _head_forward(ops, model.head_5, c, tape, "head_5")
+    d = _unit_forward(ops, model.deconv5_1, b, tape, "deconv5_1")
+    N, Ca, H, W = a.shape
+    Cd = d.shape[1]
+    cat = ops.new(N, Ca + Cd, H, W)                            # torch.cat((conv4_2, deconv5_1), 1)
+    ops.call("yf_train_channel_slice", a.data_ptr(), cat.data_ptr(), N, Ca, H * W, Ca, 0, Ca + Cd, 0)
+    ops.call("yf_train_channel_slice", d.data_ptr(), cat.data_ptr(), N, Cd, H * W, Cd, 0, Ca + Cd, Ca)
+    e = _run(ops, model, _SEQ4, cat, tape)
+    hl = _head_forward(ops, model.head_4, e, tape, "head_4")
+    tape["_cat"] = (Ca, Cd, H, W)
+    return hl, hs, tape
+
+
+def train_backward(model, tape, g_hl, g_hs):
+    """Backward of train_forward -> {parameter: gradient}."""
+    ops = _Ops(g_hl.device)
+    grads = {}
+    Ca, Cd, H, W = tape["_cat"]
+    N = g_hl.shape[0]
+    g = _head_backward(ops, model.head_4, tape, "head_4", g_hl.float(), grads)
+    g_cat = _run_back(ops, model, _SEQ4, g, tape, grads)
+    g_a2, g_d = ops.new(N, Ca, H, W), ops.new(N, Cd, H, W)
+    ops.call("yf_train_channel_slice", g_cat.data_ptr(), g_a2.data_ptr(), N, Ca, H * W, Ca + Cd, 0, Ca, 0)
+    ops.call("yf_train_channel_slice", g_cat.data_ptr(), g_d.data_ptr(), N, Cd, H * W, Ca + Cd, Ca, Cd, 0)
+    g_b2 = _unit_backward(ops, model.deconv5_1, tape, "deconv5_1", g_d, grads)
+    g = _head_backward(ops, model.head_5, tape, "head_5", g_hs.float(), grads)
+    g_b = _run_back(ops, model, _SEQ3, g, tape, grads)
+    ops.call("yf_train_add", g_b.data_ptr(), g_b2.data_ptr(), g_b.data_ptr(), g_b.numel())
+    g_a = _run_back(ops, model, _SEQ2, g_b, tape, grads)
+    ops.call("yf_train_add", g_a.data_ptr(), g_a2.data_ptr(), g_a.data_ptr(), g_a.numel())
+    _run_back(ops, model, _SEQ1, g_a, tape, grads, first_needs_dx=False)     # the images need no gradient
+    return grads
+
+
+class _TrainForwardFn(torch.autograd.Function):
+    """The whole network as one autograd node: inputs = the parameters, outputs = the two heads."""
+
+    @staticmethod
+    def forward(ctx, x, model, *params):
+        hl, hs, tape = train_forward(model, x)
+        ctx.model, ctx.tape, ctx.params = model, tape, params
+        return hl, hs
+
+    @staticmethod
+    def backward(ctx, g_hl, g_hs):
+        if ctx.tape is None:
+            raise RuntimeError("backward through the training forward a second time: its saved activations were freed")
+        grads = train_backward(ctx.model, ctx.tape, g_hl.contiguous(), g_hs.contiguous())
+        ctx.tape = None
+        return (None, None) + tuple(grads[p] for p in ctx.params)
+
+
+def forward(model, x):
+    """model(imgs) in train mode (train.py:114)."""
+    if not x.is_cuda:
+        raise RuntimeError("YoloFastest training (HIP) has no CPU path: move the model and input to the GPU")
+    if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] % 32 or x.shape[3] % 32:
+        raise ValueError("expected [N,1,H,W] with H and W multiples of 32, got %s" % (tuple(x.shape),))
+    params = list(model.parameters())
+    for p in params:
+        if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
+            raise RuntimeError("training runs on contiguous float32 GPU parameters")
+    x = x.contiguous().float()
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        return _TrainForwardFn.apply(x, model, *params)
+    hl, hs, _ = train_forward(model, x)
+    return hl, hs
+
+
+class Adam(torch.optim.Optimizer):
+    """`optim.Adam(model.parameters(), lr=lr0, betas=(0.9, 0.999), eps=1e-08)` (train.py:84) with the update done by yf_train_adam_step.
+    A torch.optim.Optimizer, so `param_groups[..]['lr']` edits (train.py:106-109) and `lr_scheduler.LambdaLR` (:89) work unchanged; the
+    state uses torch's names (step, exp_avg, exp_avg_sq)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closure")
+        lib = _lib.lib()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32:
+                    raise RuntimeError("training.Adam (HIP) has no CPU path: float32 GPU parameters only")
+                st = self.state[p]
+                if not st:
+                    st["step"], st["exp_avg"], st["exp_avg_sq"] = 0, torch.zeros_like(p), torch.zeros_like(p)
+                st["step"] += 1
+                g = p.grad.contiguous()
+                dev = p.device.index if p.device.index is not None else torch.cuda.current_device()
+                _lib.check(lib.yf_train_adam_step(dev, p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                                  p.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]),
+                                                  ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)))
+
+
+def train_step(model, model_loss, optimizer, imgs, targets):
+    """One iteration of train.py:111-132: returns the summed losses [total, x, y, w, h, conf, cls] (total a 0-dim tensor)."""
+    optimizer.zero_grad()
+    pred = model(imgs)
+    losses = [[] for _ in range(7)]
+    for i, item_pred in enumerate(pred):
+        for j, v in enumerate(model_loss[i](item_pred, targets)):
+            losses[j].append(v)
+    losses = [sum(v) for v in losses]
+    losses[0].backward()
+    optimizer.step()
+    return losses
