@@ -148,27 +148,36 @@ int yf_train_loss(yf_handle h, const float *d_head, int N, int fh, int fw, const
  *   deconv: ConvTranspose2d(k 2, stride 2, pad 0); d_w [Cin, Cout, 2, 2]; output 2H x 2W.
  *   bn: BatchNorm2d in train mode (eps 1e-5, momentum 0.1): d_stats float[2C] receives (mean, invstd) per channel for the backward;
  *       running_mean / running_var are updated in place (unbiased variance) unless NULL; relu = 1 fuses the following ReLU (the backward
- *       then masks by y > 0).  bn_backward: d_dgamma, d_dbeta [C], d_dx like x.
+ *       then masks by y > 0).  bn_backward: d_dgamma, d_dbeta [C], d_dx like x.  C <= 256.
+ *   d_scratch: yf_train_scratch_bytes() of device memory, one per stream, no initialisation needed: the per-channel reductions of bn
+ *       and the weight gradients are split over many workgroups that store partial results there, and a second pass adds them in a
+ *       fixed order (deterministic; device-scope float atomics are slow on a multi-XCD part).  conv_backward_weight accepts NULL / a
+ *       smaller buffer (scratch_bytes) and then splits less.
  *   adam_step: torch.optim.Adam(lr, betas, eps), no weight decay (train.py:84); step counts from 1. */
 int yf_train_conv_forward(int device, const float *d_x, const float *d_w, const float *d_bias, float *d_y, int N, int Cin, int H, int W, int Cout,
                           int k, int stride, int depthwise, void *stream);
 int yf_train_conv_backward_data(int device, const float *d_dy, const float *d_w, float *d_dx, int N, int Cin, int H, int W, int Cout, int k,
                                 int stride, int depthwise, void *stream);
 int yf_train_conv_backward_weight(int device, const float *d_x, const float *d_dy, float *d_dw, int N, int Cin, int H, int W, int Cout, int k,
-                                  int stride, int depthwise, void *stream);
+                                  int stride, int depthwise, void *d_scratch, size_t scratch_bytes, void *stream);
 int yf_train_deconv_forward(int device, const float *d_x, const float *d_w, float *d_y, int N, int Cin, int H, int W, int Cout, void *stream);
 int yf_train_deconv_backward_data(int device, const float *d_dy, const float *d_w, float *d_dx, int N, int Cin, int H, int W, int Cout, void *stream);
 int yf_train_deconv_backward_weight(int device, const float *d_x, const float *d_dy, float *d_dw, int N, int Cin, int H, int W, int Cout, void *stream);
+int yf_train_scratch_bytes(size_t *bytes);
 int yf_train_bn_forward(int device, const float *d_x, const float *d_gamma, const float *d_beta, float *d_running_mean, float *d_running_var,
-                        float *d_stats, float *d_y, int N, int C, long HW, int relu, void *stream);
+                        float *d_stats, float *d_y, int N, int C, long HW, int relu, void *d_scratch, void *stream);
 int yf_train_bn_backward(int device, const float *d_x, const float *d_y, const float *d_dy, const float *d_stats, const float *d_gamma,
-                         float *d_dgamma, float *d_dbeta, float *d_dx, int N, int C, long HW, int relu, void *stream);
+                         float *d_dgamma, float *d_dbeta, float *d_dx, int N, int C, long HW, int relu, void *d_scratch, void *stream);
 int yf_train_channel_sum(int device, const float *d_dy, float *d_out, int N, int C, long HW, void *stream);                 /* bias gradient */
 int yf_train_add(int device, const float *d_a, const float *d_b, float *d_out, long total, void *stream);                   /* residual / grad sum */
 int yf_train_channel_slice(int device, const float *d_src, float *d_dst, int N, int C, long HW, int Cs, int sc0, int Cd, int dc0,
                            void *stream);                                                                                    /* torch.cat and back */
 int yf_train_adam_step(int device, float *d_p, const float *d_g, float *d_m, float *d_v, long total, double lr, double beta1, double beta2,
                        double eps, int step, void *stream);
+/* the same update for `ntensors` tensors in one launch: HOST arrays of device pointers and sizes; d_table: >= 48 * ntensors bytes of
+ * device scratch (the pointer table is uploaded into it on `stream`). */
+int yf_train_adam_multi(int device, int ntensors, void *const *d_p, const void *const *d_g, void *const *d_m, void *const *d_v, const long *sizes,
+                        double lr, double beta1, double beta2, double eps, int step, void *d_table, size_t table_bytes, void *stream);
 
 /* yf_forward + yf_decode_nms back to back on one stream (heads also returned; may be NULL to use
  * workspace-internal buffers). */

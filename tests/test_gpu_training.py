@@ -82,8 +82,12 @@ def test_conv_forward_backward_match_torch(ops, dev, geom):
     ops.call("yf_train_conv_backward_data", gyd.data_ptr(), wd.data_ptr(), gx.data_ptr(), N, Cin, H, W, Cout, k, stride, dw)
     _close(gx, xt.grad, 2e-6, "backward data")
     gw = torch.full_like(wd, float("nan"))
-    ops.call("yf_train_conv_backward_weight", xd.data_ptr(), gyd.data_ptr(), gw.data_ptr(), N, Cin, H, W, Cout, k, stride, dw)
+    ops.call("yf_train_conv_backward_weight", xd.data_ptr(), gyd.data_ptr(), gw.data_ptr(), N, Cin, H, W, Cout, k, stride, dw, ops.scratch,
+             ops.scratch_bytes)
     _close(gw, wt.grad, 5e-6, "backward weight")
+    gw2 = torch.full_like(wd, float("nan"))                       # without scratch: no split (or the atomics fallback)
+    ops.call("yf_train_conv_backward_weight", xd.data_ptr(), gyd.data_ptr(), gw2.data_ptr(), N, Cin, H, W, Cout, k, stride, dw, None, 0)
+    _close(gw2, wt.grad, 5e-6, "backward weight, no scratch")
     gb = torch.full_like(bd, float("nan"))
     ops.call("yf_train_channel_sum", gyd.data_ptr(), gb.data_ptr(), N, Cout, y.shape[2] * y.shape[3])
     _close(gb, bt.grad, 2e-6, "bias gradient")
@@ -98,8 +102,19 @@ def test_conv_backward_weight_long_reduction(ops, dev):
     want = torch.einsum("nchw,nohw->oc", torch.from_numpy(x).double(), torch.from_numpy(gy).double())[:, :, None, None]
     xd, gyd = _g(x, dev), _g(gy, dev)
     gw = torch.full((Cout, Cin, 1, 1), float("nan"), device=dev)
-    ops.call("yf_train_conv_backward_weight", xd.data_ptr(), gyd.data_ptr(), gw.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0)
+    ops.call("yf_train_conv_backward_weight", xd.data_ptr(), gyd.data_ptr(), gw.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0, ops.scratch, ops.scratch_bytes)
     _close(gw, want, 2e-5, "backward weight, 81920-long sums")
+    gw2 = torch.empty_like(gw)
+    ops.call("yf_train_conv_backward_weight", xd.data_ptr(), gyd.data_ptr(), gw2.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0, ops.scratch, ops.scratch_bytes)
+    assert torch.equal(gw, gw2)                                   # fixed summation order: bit-reproducible
+    for k, dw, C2 in ((3, 1, 32), (5, 1, 32)):                    # depthwise, many chunks
+        w_ = torch.zeros(C2, 1, k, k, dtype=torch.float64, requires_grad=True)
+        xt = torch.from_numpy(rng.normal(size=(N, C2, H, W)).astype(np.float32))
+        gt_ = torch.from_numpy(rng.normal(size=(N, C2, H, W)).astype(np.float32))
+        F.conv2d(xt.double(), w_, None, padding=(k - 1) // 2, groups=C2).backward(gt_.double())
+        g, xg, gg = torch.empty(C2, 1, k, k, device=dev), xt.to(dev), gt_.to(dev)
+        ops.call("yf_train_conv_backward_weight", xg.data_ptr(), gg.data_ptr(), g.data_ptr(), N, C2, H, W, C2, k, 1, 1, ops.scratch, ops.scratch_bytes)
+        _close(g, w_.grad, 2e-5, "depthwise backward weight, long sums")
 
 
 def test_deconv_forward_backward_match_torch(ops, dev):
@@ -127,7 +142,7 @@ def test_deconv_forward_backward_match_torch(ops, dev):
 @pytest.mark.parametrize("relu", [0, 1])
 def test_batchnorm_train_mode_matches_torch(ops, dev, relu):
     rng = np.random.default_rng(11 + relu)
-    for N, C, H, W in ((4, 8, 9, 7), (16, 136, 4, 5), (2, 3, 1, 1)):
+    for N, C, H, W in ((4, 8, 9, 7), (16, 136, 4, 5), (2, 3, 1, 1), (16, 8, 64, 80), (3, 232, 20, 16)):
         x = (rng.normal(size=(N, C, H, W)) * rng.uniform(0.5, 3, (1, C, 1, 1)) + rng.normal(size=(1, C, 1, 1))).astype(np.float32)
         gamma, beta = rng.normal(1, 0.3, C).astype(np.float32), rng.normal(0, 0.5, C).astype(np.float32)
         rm, rv = rng.normal(size=C).astype(np.float32), rng.uniform(0.5, 2, C).astype(np.float32)
@@ -144,20 +159,21 @@ def test_batchnorm_train_mode_matches_torch(ops, dev, relu):
         xd, gd, bd, rmd, rvd, gyd = _g(x, dev), _g(gamma, dev), _g(beta, dev), _g(rm, dev), _g(rv, dev), _g(gy, dev)
         stats, y = torch.empty(2 * C, device=dev), torch.empty_like(xd)
         ops.call("yf_train_bn_forward", xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), rmd.data_ptr(), rvd.data_ptr(), stats.data_ptr(),
-                 y.data_ptr(), N, C, H * W, relu)
+                 y.data_ptr(), N, C, H * W, relu, ops.bn_scratch)
         _close(y, yt, 3e-6, "forward")
         _close(rmd, bn.running_mean, 1e-6, "running_mean")
         _close(rvd, bn.running_var, 1e-6, "running_var (unbiased)")
         dg, db, gx = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.full_like(xd, float("nan"))
         ops.call("yf_train_bn_backward", xd.data_ptr(), y.data_ptr(), gyd.data_ptr(), stats.data_ptr(), gd.data_ptr(), dg.data_ptr(),
-                 db.data_ptr(), gx.data_ptr(), N, C, H * W, relu)
+                 db.data_ptr(), gx.data_ptr(), N, C, H * W, relu, ops.bn_scratch)
         _close(dg, bn.weight.grad, 5e-6, "dgamma")
         _close(db, bn.bias.grad, 5e-6, "dbeta")
         if N * H * W > 2:        # with two samples per channel xhat = +-1 and dx is a difference of nearly equal numbers
             _close(gx, xt.grad, 2e-5, "dx")
         # running statistics are optional
         y2 = torch.empty_like(xd)
-        ops.call("yf_train_bn_forward", xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), None, None, stats.data_ptr(), y2.data_ptr(), N, C, H * W, relu)
+        ops.call("yf_train_bn_forward", xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), None, None, stats.data_ptr(), y2.data_ptr(), N, C, H * W, relu,
+                 ops.bn_scratch)
         assert torch.equal(y, y2)
 
 

@@ -10,6 +10,12 @@ for t in default lanes1 f16 f16x3 f16x3_512; do
   case $t in f16) n=${TAG}_f16_640x512;; f16x3_512) n=${TAG}_f16x3_640x512;; *) n=${TAG}_$t;; esac
   cp $f profiles/${n}_kernel_stats.csv
 done
+for t in train train256; do
+  f=$(ls gpurun_out/prof_$t/*_kernel_stats.csv)
+  case $t in train) n=${TAG}_train_step_batch16;; *) n=${TAG}_train_step_batch256;; esac
+  cp $f profiles/${n}_kernel_stats.csv
+  grep "^GPU" gpurun_out/prof_$t.log > profiles/${n}_bench_line.txt || true
+done
 python - <<PY
 import csv
 for src, dst in (('gpurun_out/pmc_fetch/f_counter_collection.csv', 'profiles/${TAG}_pmc_fetch_size.csv'), ('gpurun_out/pmc_write/w_counter_collection.csv', 'profiles/${TAG}_pmc_write_size.csv')):

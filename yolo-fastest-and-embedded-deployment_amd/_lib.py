@@ -44,12 +44,16 @@ _SIGS = {
                                  _c.c_double, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "yf_train_conv_forward": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 8 + [_c.c_void_p]),
     "yf_train_conv_backward_data": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 8 + [_c.c_void_p]),
-    "yf_train_conv_backward_weight": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 8 + [_c.c_void_p]),
+    "yf_train_conv_backward_weight": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 8 +
+                                      [_c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "yf_train_deconv_forward": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 5 + [_c.c_void_p]),
     "yf_train_deconv_backward_data": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 5 + [_c.c_void_p]),
     "yf_train_deconv_backward_weight": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 5 + [_c.c_void_p]),
-    "yf_train_bn_forward": (_c.c_int, [_c.c_int] + [_c.c_void_p] * 7 + [_c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_void_p]),
-    "yf_train_bn_backward": (_c.c_int, [_c.c_int] + [_c.c_void_p] * 8 + [_c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_void_p]),
+    "yf_train_scratch_bytes": (_c.c_int, [_c.POINTER(_c.c_size_t)]),
+    "yf_train_bn_forward": (_c.c_int, [_c.c_int] + [_c.c_void_p] * 7 + [_c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    "yf_train_bn_backward": (_c.c_int, [_c.c_int] + [_c.c_void_p] * 8 + [_c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    "yf_train_adam_multi": (_c.c_int, [_c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_double, _c.c_double,
+                                       _c.c_double, _c.c_double, _c.c_int, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "yf_train_channel_sum": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_long, _c.c_void_p]),
     "yf_train_add": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_long, _c.c_void_p]),
     "yf_train_channel_slice": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_int, _c.c_int, _c.c_int,

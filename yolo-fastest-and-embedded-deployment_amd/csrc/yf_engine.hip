@@ -921,10 +921,10 @@ int yf_train_conv_backward_data(int device, const float* d_dy, const float* d_w,
            yf::launch_tconv_bwd_data(d_dy, d_w, d_dx, N, Cin, H, W, Cout, k, stride, depthwise, (hipStream_t)stream));
 }
 int yf_train_conv_backward_weight(int device, const float* d_x, const float* d_dy, float* d_dw, int N, int Cin, int H, int W, int Cout, int k,
-                                  int stride, int depthwise, void* stream)
+                                  int stride, int depthwise, void* d_scratch, size_t scratch_bytes, void* stream)
 {
     YF_TOP(d_x && d_dy && d_dw && N > 0 && (k == 1 || k == 3 || k == 5) && (stride == 1 || stride == 2) && (!depthwise || Cin == Cout),
-           yf::launch_tconv_bwd_weight(d_x, d_dy, d_dw, N, Cin, H, W, Cout, k, stride, depthwise, (hipStream_t)stream));
+           yf::launch_tconv_bwd_weight(d_x, d_dy, d_dw, N, Cin, H, W, Cout, k, stride, depthwise, d_scratch, scratch_bytes, (hipStream_t)stream));
 }
 int yf_train_deconv_forward(int device, const float* d_x, const float* d_w, float* d_y, int N, int Cin, int H, int W, int Cout, void* stream)
 {
@@ -938,17 +938,23 @@ int yf_train_deconv_backward_weight(int device, const float* d_x, const float* d
 {
     YF_TOP(d_x && d_dy && d_dw && N > 0, yf::launch_tdeconv_bwd_weight(d_x, d_dy, d_dw, N, Cin, H, W, Cout, (hipStream_t)stream));
 }
-int yf_train_bn_forward(int device, const float* d_x, const float* d_gamma, const float* d_beta, float* d_running_mean, float* d_running_var,
-                        float* d_stats, float* d_y, int N, int C, long HW, int relu, void* stream)
+int yf_train_scratch_bytes(size_t* bytes)
 {
-    YF_TOP(d_x && d_gamma && d_beta && d_stats && d_y && N > 0 && C > 0 && HW > 0,
-           yf::launch_tbn_fwd(d_x, d_gamma, d_beta, d_running_mean, d_running_var, d_stats, d_y, N, C, HW, relu, (hipStream_t)stream));
+    if (!bytes) return fail(YF_E_INVALID, "yf_train_scratch_bytes: null argument");
+    *bytes = yf::train_scratch_bytes();
+    return YF_OK;
+}
+int yf_train_bn_forward(int device, const float* d_x, const float* d_gamma, const float* d_beta, float* d_running_mean, float* d_running_var,
+                        float* d_stats, float* d_y, int N, int C, long HW, int relu, void* d_scratch, void* stream)
+{
+    YF_TOP(d_x && d_gamma && d_beta && d_stats && d_y && d_scratch && N > 0 && N <= 65535 && C > 0 && C <= 256 && HW > 0,
+           yf::launch_tbn_fwd(d_x, d_gamma, d_beta, d_running_mean, d_running_var, d_stats, d_y, N, C, HW, relu, d_scratch, (hipStream_t)stream));
 }
 int yf_train_bn_backward(int device, const float* d_x, const float* d_y, const float* d_dy, const float* d_stats, const float* d_gamma,
-                         float* d_dgamma, float* d_dbeta, float* d_dx, int N, int C, long HW, int relu, void* stream)
+                         float* d_dgamma, float* d_dbeta, float* d_dx, int N, int C, long HW, int relu, void* d_scratch, void* stream)
 {
-    YF_TOP(d_x && d_y && d_dy && d_stats && d_gamma && d_dgamma && d_dbeta && d_dx && N > 0 && C > 0 && HW > 0,
-           yf::launch_tbn_bwd(d_x, d_y, d_dy, d_stats, d_gamma, d_dgamma, d_dbeta, d_dx, N, C, HW, relu, (hipStream_t)stream));
+    YF_TOP(d_x && d_y && d_dy && d_stats && d_gamma && d_dgamma && d_dbeta && d_dx && d_scratch && N > 0 && N <= 65535 && C > 0 && C <= 256 && HW > 0,
+           yf::launch_tbn_bwd(d_x, d_y, d_dy, d_stats, d_gamma, d_dgamma, d_dbeta, d_dx, N, C, HW, relu, d_scratch, (hipStream_t)stream));
 }
 int yf_train_channel_sum(int device, const float* d_dy, float* d_out, int N, int C, long HW, void* stream)
 {
@@ -968,6 +974,19 @@ int yf_train_adam_step(int device, float* d_p, const float* d_g, float* d_m, flo
 {
     YF_TOP(d_p && d_g && d_m && d_v && total > 0 && step >= 1,
            yf::launch_tadam(d_p, d_g, d_m, d_v, total, lr, beta1, beta2, eps, step, (hipStream_t)stream));
+}
+int yf_train_adam_multi(int device, int ntensors, void* const* d_p, const void* const* d_g, void* const* d_m, void* const* d_v, const long* sizes,
+                        double lr, double beta1, double beta2, double eps, int step, void* d_table, size_t table_bytes, void* stream)
+{
+    if (!d_p || !d_g || !d_m || !d_v || !sizes || !d_table || ntensors <= 0 || step < 1 || table_bytes < (size_t)ntensors * 48)
+        return fail(YF_E_INVALID, "yf_train_adam_multi: bad argument");
+    for (int t = 0; t < ntensors; ++t)
+        if (!d_p[t] || !d_g[t] || !d_m[t] || !d_v[t] || sizes[t] <= 0) return fail(YF_E_INVALID, "yf_train_adam_multi: tensor %d: null pointer or empty", t);
+    HIP_OK(hipSetDevice(device));
+    yf::launch_tadam_multi(ntensors, (float* const*)d_p, (const float* const*)d_g, (float* const*)d_m, (float* const*)d_v, sizes, lr, beta1, beta2, eps,
+                           step, d_table, (hipStream_t)stream);
+    HIP_OK(hipGetLastError());
+    return YF_OK;
 }
 #undef YF_TOP
 

@@ -234,14 +234,17 @@ void launch_tconv_fwd(const float* x, const float* w, const float* bias, float* 
 void launch_tconv_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int k, int stride, int depthwise,
                            hipStream_t s);
 void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int k, int stride, int depthwise,
-                             hipStream_t s);
+                             void* scratch, size_t scratch_bytes, hipStream_t s);
 void launch_tdeconv_fwd(const float* x, const float* w, float* y, int N, int Cin, int H, int W, int Cout, hipStream_t s);
 void launch_tdeconv_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, hipStream_t s);
 void launch_tdeconv_bwd_weight(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, hipStream_t s);
+size_t train_scratch_bytes();
 void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* stats, float* y, int N,
-                    int C, long HW, int relu, hipStream_t s);
+                    int C, long HW, int relu, void* scratch, hipStream_t s);
 void launch_tbn_bwd(const float* x, const float* y, const float* dy, const float* stats, const float* gamma, float* dgamma, float* dbeta, float* dx,
-                    int N, int C, long HW, int relu, hipStream_t s);
+                    int N, int C, long HW, int relu, void* scratch, hipStream_t s);
+void launch_tadam_multi(int nt, float* const* p, const float* const* g, float* const* m, float* const* v, const long* sizes, double lr, double b1,
+                        double b2, double eps, int step, void* d_table, hipStream_t s);
 void launch_tchan_sum(const float* dy, float* out, int N, int C, long HW, hipStream_t s);
 void launch_tadd(const float* a, const float* b, float* out, long total, hipStream_t s);
 void launch_tslice(const float* src, float* dst, int N, int C, long HW, int Cs, int sc0, int Cd, int dc0, hipStream_t s);

@@ -14,6 +14,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "yf_kernels.h"
 
 namespace yf {
@@ -43,6 +45,330 @@ __global__ void __launch_bounds__(256) tconv_fwd_kernel(const float* __restrict_
         }
     }
     y[idx] = s;
+}
+
+// ---- dense (groups == 1) convolution, CO_T output channels per thread: the input value is loaded once per CO_T outputs and the
+// weights are wave-uniform (scalar loads).  Also the pointwise backward-data: out = ci, in = co, weight strides swapped. ----
+template <int CO_T>
+__global__ void __launch_bounds__(256) tconv_mc_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                       float* __restrict__ y, int N, int Cin, int H, int W, int Cout, int Ho, int Wo, int k,
+                                                       int stride, long w_so, long w_si)
+{
+    const long q = (long)blockIdx.x * 256 + threadIdx.x, Q = (long)N * Ho * Wo;
+    const int co0 = blockIdx.y * CO_T;
+    if (q >= Q) return;
+    const int ox = (int)(q % Wo), oy = (int)((q / Wo) % Ho), n = (int)(q / ((long)Wo * Ho));
+    const int pad = (k - 1) / 2, kk = k * k;
+    float acc[CO_T];
+#pragma unroll
+    for (int j = 0; j < CO_T; ++j) acc[j] = (bias && co0 + j < Cout) ? bias[co0 + j] : 0.f;
+    const float* xn = x + (long)n * Cin * H * W;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float* xp = xn + (long)ci * H * W;
+        for (int ky = 0; ky < k; ++ky) {
+            const int iy = oy * stride - pad + ky;
+            for (int kx = 0; kx < k; ++kx) {
+                const int ix = ox * stride - pad + kx;
+                const float xv = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xp[(long)iy * W + ix] : 0.f;
+                const float* wp = w + (long)co0 * w_so + (long)ci * w_si + ky * k + kx;
+#pragma unroll
+                for (int j = 0; j < CO_T; ++j)
+                    if (co0 + j < Cout) acc[j] = fmaf(xv, wp[(long)j * w_so], acc[j]);
+            }
+        }
+    }
+    (void)kk;
+    float* yp = y + ((long)n * Cout + co0) * Ho * Wo + (long)oy * Wo + ox;
+#pragma unroll
+    for (int j = 0; j < CO_T; ++j)
+        if (co0 + j < Cout) yp[(long)j * Ho * Wo] = acc[j];
+}
+
+// ---- pointwise convolution as a GEMM on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32), operands straight from global memory:
+//   Y[m][q] = sum_k A[m][k] X[k][q],  q = pixel over the batch (frame n = q / HW), X and Y NCHW.
+// forward: A = weight [Cout][Cin] (sm = Cin, sk = 1); backward-data: A = weight^T (m = ci, k = co: sm = 1, sk = Cin), X = dY.
+// One wave = 16 output channels x 64 pixels (four 16x16 tiles sharing the A fragment); a workgroup = 4 waves on 4 channel tiles.
+// MFMA operand layout: A lane l = (row l % 16, k l / 16); B lane l = (k l / 16, col l % 16); D lane l = rows 4 (l / 16) + i, col l % 16.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <int NT>   // NT 16-pixel tiles per wave: 4 for large maps, 1 when there are few pixels (more waves in flight)
+__global__ void __launch_bounds__(256) tpw_mfma_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ bias,
+                                                       float* __restrict__ y, long Q, long HW, int M, int K, long sm, long sk)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
+    const int m0 = (blockIdx.y * 4 + wave) * 16;
+    if (m0 >= M) return;
+    const long q0 = (long)blockIdx.x * (16 * NT);
+    // no predication inside the k loop: out-of-range pixels and rows read a valid (clamped) address and are not stored; the k tail
+    // multiplies a clamped B element by an A element forced to zero
+    const float* xp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        long q = q0 + t * 16 + lr;
+        if (q > Q - 1) q = Q - 1;
+        const long n = q / HW, i = q - n * HW;
+        xp[t] = x + n * K * HW + i;                     // + k * HW
+    }
+    const int mr = m0 + lr < M ? m0 + lr : M - 1;
+    const float* ap = a + (long)mr * sm;
+    f32x4_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int K4 = K & ~3;
+#pragma unroll 4
+    for (int k0 = 0; k0 < K4; k0 += 4) {
+        const int k = k0 + lk;
+        const float av = ap[(long)k * sk];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xp[t][(long)k * HW], acc[t], 0, 0, 0);
+    }
+    if (K4 < K) {
+        const int k = K4 + lk, kc = k < K ? k : K - 1;
+        const float av = k < K ? ap[(long)kc * sk] : 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xp[t][(long)kc * HW], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const long q = q0 + t * 16 + lr;
+        if (q >= Q) continue;
+        const long n = q / HW, i = q - n * HW;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + lk * 4 + r;
+            if (m < M) y[(n * M + m) * HW + i] = acc[t][r] + (bias ? bias[m] : 0.f);
+        }
+    }
+}
+
+// dense conv forward for k > 1 (conv0, conv1_9) on the matrix pipe: the same GEMM with the B operand gathered (im2col on the fly):
+// k-index r = (ci, ky, kx); A = weight [Cout][Cin k k] as stored.  One wave = 16 output channels x 64 output pixels.
+template <int KS>
+__global__ void __launch_bounds__(256) tconv_im2col_mfma_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ bias,
+                                                                float* __restrict__ y, int N, int Cin, int H, int W, int Ho, int Wo, int M, int stride)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
+    const int m0 = (blockIdx.y * 4 + wave) * 16;
+    if (m0 >= M) return;
+    const long Q = (long)N * Ho * Wo, q0 = (long)blockIdx.x * 64;
+    constexpr int KK = KS * KS, PAD = (KS - 1) / 2;
+    const int K = Cin * KK;
+    const float* xn[4];
+    int iy0[4], ix0[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        long q = q0 + t * 16 + lr;
+        if (q > Q - 1) q = Q - 1;
+        const int ox = (int)(q % Wo), oy = (int)((q / Wo) % Ho), n = (int)(q / ((long)Wo * Ho));
+        xn[t] = x + (long)n * Cin * H * W;
+        iy0[t] = oy * stride - PAD;
+        ix0[t] = ox * stride - PAD;
+    }
+    const int mr = m0 + lr < M ? m0 + lr : M - 1;
+    const float* ap = a + (long)mr * K;
+    f32x4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int r = k0 + lk;
+        const bool kv = r < K;
+        const int rc = kv ? r : K - 1;
+        const int ci = rc / KK, tap = rc - ci * KK, ky = tap / KS, kx = tap - ky * KS;
+        const float av = kv ? ap[rc] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int iy = iy0[t] + ky, ix = ix0[t] + kx;
+            const float bv = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xn[t][((long)ci * H + iy) * W + ix] : 0.f;
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+        }
+    }
+    const long HWo = (long)Ho * Wo;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const long q = q0 + t * 16 + lr;
+        if (q >= Q) continue;
+        const long n = q / HWo, i = q - n * HWo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + lk * 4 + r;
+            if (m < M) y[(n * M + m) * HWo + i] = acc[t][r] + (bias ? bias[m] : 0.f);
+        }
+    }
+}
+
+// dense conv weight gradient on the matrix pipe: dW[co][r] = sum_q dY[co][q] Xcol[r][q], r = (ci, ky, kx), split over q.  One wave =
+// 16 co x 64 r and a slice of q; per step (16 output pixels) every lane loads float4 (4 consecutive pixels) of one dY row and the
+// four matching elements of four Xcol rows: MFMA e of the step takes element e, i.e. k-index l / 16 stands for pixel 4 (l / 16) + e
+// in both operands.  Needs Wo % 4 == 0 (the 4 pixels share a row).  KS == 1: the Xcol elements are one float4 as well.
+// Slice s writes its tile into dw + s * part_stride (a slab of the scratch; tsum_partials_kernel adds the slabs in order): device-scope
+// float atomics on this multi-XCD part are executed memory-side and serialise per address -- 100 slices on one tile cost more than the GEMM.
+template <int KS>
+__global__ void __launch_bounds__(64) tconv_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                                              int N, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride, long q_per,
+                                                              long part_stride)
+{
+    const int lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
+    const int c0 = blockIdx.y * 16, r0 = blockIdx.z * 64;
+    constexpr int KK = KS * KS, PAD = (KS - 1) / 2;
+    const int R = Cin * KK;
+    const long HWo = (long)Ho * Wo, Q = (long)N * HWo;
+    const long qb = (long)blockIdx.x * q_per, qe = qb + q_per < Q ? qb + q_per : Q;
+    const int cr = c0 + lr < Cout ? c0 + lr : Cout - 1;
+    const bool cv = c0 + lr < Cout;
+    int rci[4], rky[4], rkx[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int r = r0 + 16 * t + lr;
+        if (r > R - 1) r = R - 1;                     // clamped rows produce columns that are never stored
+        rci[t] = r / KK;
+        const int tap = r - rci[t] * KK;
+        rky[t] = tap / KS;
+        rkx[t] = tap - rky[t] * KS;
+    }
+    f32x4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (long q0 = qb; q0 < qe; q0 += 16) {
+        long q = q0 + 4 * lk;
+        const bool qv = q < qe;                                       // q_per, Q multiples of 4
+        if (!qv) q = qb;
+        const long n = q / HWo, i = q - n * HWo;
+        float4 av = *reinterpret_cast<const float4*>(dy + (n * Cout + cr) * HWo + i);
+        if (!(qv && cv)) av = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 bv[4];
+        if constexpr (KS == 1) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bv[t] = *reinterpret_cast<const float4*>(x + (n * Cin + rci[t]) * HWo + i);
+        } else {
+            const int oy = (int)(i / Wo), ox = (int)(i - (long)oy * Wo);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int iy = oy * stride - PAD + rky[t];
+                const float* xr = x + ((n * Cin + rci[t]) * H + iy) * W;
+                const bool yv = iy >= 0 && iy < H;
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ix = (ox + j) * stride - PAD + rkx[t];
+                    e[j] = (yv && ix >= 0 && ix < W) ? xr[ix] : 0.f;
+                }
+                bv[t] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&av)[e], ((const float*)&bv[t])[e], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = c0 + lk * 4 + r, rr = r0 + 16 * t + lr;
+            if (co < Cout && rr < R) dw[(long)blockIdx.x * part_stride + (long)co * R + rr] = acc[t][r];
+        }
+}
+
+// depthwise weight gradient: dW[c][ky][kx] = sum_q dY[c][q] X[c][q shifted].  grid (chunks, C): every thread walks its output pixels,
+// loads dY once and the KS x KS neighbourhood of X, keeps the KS*KS sums in registers; wave + workgroup reduction, one partial per tap
+// and chunk (slab blockIdx.x of the scratch).
+template <int KS>
+__global__ void __launch_bounds__(256) tdw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, int N,
+                                                        int C, int H, int W, int Ho, int Wo, int stride, long part_stride)
+{
+    constexpr int KK = KS * KS, PAD = (KS - 1) / 2;
+    __shared__ float red[4][KK];
+    const int c = blockIdx.y;
+    const long HWo = (long)Ho * Wo, Q = (long)N * HWo;
+    float acc[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[t] = 0.f;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < Q; q += (long)gridDim.x * 256) {
+        const long n = q / HWo, i = q - n * HWo;
+        const int oy = (int)(i / Wo), ox = (int)(i - (long)oy * Wo);
+        const float g = dy[(n * C + c) * HWo + i];
+        const float* xp = x + (n * C + c) * H * W;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            const int iy = oy * stride - PAD + ky;
+            const bool yv = iy >= 0 && iy < H;
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const int ix = ox * stride - PAD + kx;
+                const float xv = (yv && ix >= 0 && ix < W) ? xp[(long)iy * W + ix] : 0.f;
+                acc[ky * KS + kx] = fmaf(g, xv, acc[ky * KS + kx]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+        float v = acc[t];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < KK)
+        dw[(long)blockIdx.x * part_stride + (long)c * KK + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// dw[i] = sum over the slabs, in slab order (deterministic).  One wave per 64 / SPL outputs: SPL lanes share an output when there are many slabs.
+__global__ void __launch_bounds__(256) tsum_partials_kernel(const float* __restrict__ part, int nsplit, long nw, long part_stride,
+                                                            float* __restrict__ dw, int spl)
+{
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long i = t / spl;
+    const int j = (int)(t - i * spl);
+    float v = 0.f;
+    if (i < nw)
+        for (int sidx = j; sidx < nsplit; sidx += spl) v += part[(long)sidx * part_stride + i];
+    for (int o = spl >> 1; o > 0; o >>= 1) v += __shfl_down(v, o);       // spl is a power of two <= 64: the lanes of one output are adjacent
+    if (i < nw && j == 0) dw[i] = v;
+}
+
+// ---- backward-data of the dense 3x3 stride-2 pad-1 convolution (conv1_9): one thread = the 2x2 input block (2a.., 2b..) -- all four
+// parities, so every thread runs the same taps -- for CI_T input channels; the weights are wave-uniform.  H = 2 Ho, W = 2 Wo.
+//   dx[2a][2b]     = dy[a][b] w11
+//   dx[2a][2b+1]   = dy[a][b] w12 + dy[a][b+1] w10
+//   dx[2a+1][2b]   = dy[a][b] w21 + dy[a+1][b] w01
+//   dx[2a+1][2b+1] = dy[a][b] w22 + dy[a][b+1] w20 + dy[a+1][b] w02 + dy[a+1][b+1] w00
+template <int CI_T>
+__global__ void __launch_bounds__(256) tconv3s2_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                                                int N, int Cin, int Cout, int Ho, int Wo)
+{
+    const long q = (long)blockIdx.x * 256 + threadIdx.x, Q = (long)N * Ho * Wo;
+    const int ci0 = blockIdx.y * CI_T;
+    if (q >= Q) return;
+    const int b = (int)(q % Wo), a = (int)((q / Wo) % Ho), n = (int)(q / ((long)Wo * Ho));
+    const bool vb = b + 1 < Wo, va = a + 1 < Ho;
+    float acc[4][CI_T];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < CI_T; ++j) acc[e][j] = 0.f;
+    const float* dp = dy + (long)n * Cout * Ho * Wo + (long)a * Wo + b;
+    for (int co = 0; co < Cout; ++co) {
+        const float* d = dp + (long)co * Ho * Wo;
+        const float d00 = d[0], d01 = vb ? d[1] : 0.f, d10 = va ? d[Wo] : 0.f, d11 = (va && vb) ? d[Wo + 1] : 0.f;
+        const float* wp = w + ((long)co * Cin + ci0) * 9;
+#pragma unroll
+        for (int j = 0; j < CI_T; ++j) {
+            if (ci0 + j >= Cin) break;
+            const float* k = wp + j * 9;
+            acc[0][j] = fmaf(d00, k[4], acc[0][j]);
+            acc[1][j] = fmaf(d00, k[5], fmaf(d01, k[3], acc[1][j]));
+            acc[2][j] = fmaf(d00, k[7], fmaf(d10, k[1], acc[2][j]));
+            acc[3][j] = fmaf(d00, k[8], fmaf(d01, k[6], fmaf(d10, k[2], fmaf(d11, k[0], acc[3][j]))));
+        }
+    }
+    const int H = 2 * Ho, W = 2 * Wo;
+#pragma unroll
+    for (int j = 0; j < CI_T; ++j) {
+        if (ci0 + j >= Cin) break;
+        float* o = dx + (((long)n * Cin + ci0 + j) * H + 2 * a) * W + 2 * b;
+        *reinterpret_cast<float2*>(o) = make_float2(acc[0][j], acc[1][j]);
+        *reinterpret_cast<float2*>(o + W) = make_float2(acc[2][j], acc[3][j]);
+    }
 }
 
 // ---- Conv2d backward with respect to the input ----
@@ -102,6 +428,68 @@ __global__ void __launch_bounds__(256) tconv_bwd_weight_kernel(const float* __re
     if (threadIdx.x == 0) atomicAdd(&dw[widx], red[0] + red[1] + red[2] + red[3]);
 }
 
+// ---- dense conv weight gradient as a split-K GEMM: dW[co][r] = sum_p dy[co][p] * X[r][p], r = (ci, ky, kx) (im2col row), p = output
+// pixel over the batch.  One workgroup = a 64 x 64 tile of (co, r) and a slice of p; 32 pixels at a time are staged in LDS, each
+// thread accumulates 4 x 4 outputs and adds them to dW with atomics at the end.
+__global__ void __launch_bounds__(256) tconv_bwd_weight_gemm_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                                                    int N, int Cin, int H, int W, int Cout, int Ho, int Wo, int k, int stride,
+                                                                    long p_per)
+{
+    __shared__ float xs[64][33], ds[64][33];
+    const int tid = threadIdx.x, tc = tid & 15, tr = tid >> 4;
+    const int R = Cin * k * k, r0 = blockIdx.y * 64, c0 = blockIdx.z * 64, pad = (k - 1) / 2, kk = k * k;
+    const long P = (long)N * Ho * Wo, HWo = (long)Ho * Wo;
+    const long pb = (long)blockIdx.x * p_per, pe = pb + p_per < P ? pb + p_per : P;
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    const int px = tid & 31, row8 = tid >> 5;                     // loader: 8 rows x 32 pixels per pass, 8 passes
+    for (long p0 = pb; p0 < pe; p0 += 32) {
+        const long p = p0 + px;
+        const bool pv = p < pe;
+        int n = 0, oy = 0, ox = 0;
+        if (pv) { n = (int)(p / HWo); const long rem = p - (long)n * HWo; oy = (int)(rem / Wo); ox = (int)(rem - (long)oy * Wo); }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + row8;
+            float dv = 0.f, xv = 0.f;
+            if (pv) {
+                const int co = c0 + row;
+                if (co < Cout) dv = dy[((long)n * Cout + co) * HWo + (long)oy * Wo + ox];
+                const int r = r0 + row;
+                if (r < R) {
+                    const int ci = r / kk, t = r - ci * kk, ky = t / k, kx = t - ky * k;
+                    const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) xv = x[(((long)n * Cin + ci) * H + iy) * W + ix];
+                }
+            }
+            ds[row][px] = dv;
+            xs[row][px] = xv;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) {
+            float dv[4], xv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { dv[a] = ds[tr * 4 + a][q]; xv[a] = xs[tc * 4 + a][q]; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(dv[a], xv[b], acc[a][b]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int co = c0 + tr * 4 + a, r = r0 + tc * 4 + b;
+            if (co < Cout && r < R && acc[a][b] != 0.f) atomicAdd(&dw[(long)co * R + r], acc[a][b]);
+        }
+}
+
 // ---- ConvTranspose2d(k = 2, stride = 2, pad = 0), weight [Cin, Cout, 2, 2] ----
 __global__ void __launch_bounds__(256) tdeconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N,
                                                           int Cin, int H, int W, int Cout)
@@ -151,84 +539,125 @@ __global__ void __launch_bounds__(256) tdeconv_bwd_weight_kernel(const float* __
 }
 
 // ---- BatchNorm2d, training mode (torch.nn.BatchNorm2d: eps 1e-5, momentum 0.1; running_var takes the UNBIASED batch variance) ----
-// one workgroup per channel: mean and biased variance over N*H*W in double; stats[c] = {mean, invstd}
-__global__ void __launch_bounds__(256) tbn_stats_kernel(const float* __restrict__ x, int N, int C, long HW, float eps, float momentum,
-                                                        float* __restrict__ stats, float* __restrict__ running_mean, float* __restrict__ running_var)
+// Two launches each way, no cross-workgroup synchronisation inside a kernel (a device-scope fence costs an L2 write-back per XCD):
+//   1. partial sums over N*H*W per channel in double: grid (nchunk <= 64, C), every workgroup sums units of 256 contiguous elements
+//      and stores its pair into scratch[c][chunk];
+//   2. the elementwise kernel, grid (HW / 256, C, N): each workgroup first adds its channel's partial pairs (one per lane, fixed
+//      shuffle tree: deterministic), then transforms its 256 elements; the first workgroup of a channel also writes the per-channel
+//      results (stats + running statistics, or dgamma / dbeta).
+#define TBN_MAXCHUNK 64
+__device__ __forceinline__ void tbn_block_store(double s, double t, double* __restrict__ part)
 {
     __shared__ double r1[4], r2[4];
-    const int c = blockIdx.x;
-    const long P = (long)N * HW;
-    double s = 0, ss = 0;
-    for (long p = threadIdx.x; p < P; p += 256) {
-        const long n = p / HW, i = p - n * HW;
-        const double v = x[(n * C + c) * HW + i];
-        s += v; ss += v * v;
-    }
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o); ss += __shfl_down(ss, o); }
-    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s; r2[threadIdx.x >> 6] = ss; }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o); t += __shfl_down(t, o); }
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s; r2[threadIdx.x >> 6] = t; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double sum = r1[0] + r1[1] + r1[2] + r1[3], sq = r2[0] + r2[1] + r2[2] + r2[3];
-        const double mean = sum / (double)P;
-        double var = sq / (double)P - mean * mean;
-        if (var < 0) var = 0;
-        stats[2 * c] = (float)mean;
-        stats[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        part[2 * blockIdx.x] = r1[0] + r1[1] + r1[2] + r1[3];
+        part[2 * blockIdx.x + 1] = r2[0] + r2[1] + r2[2] + r2[3];
+    }
+}
+// the channel's two sums, in every thread of the workgroup
+__device__ __forceinline__ void tbn_block_total(const double* __restrict__ part, int nchunk, double& s, double& t)
+{
+    __shared__ double tot[2];
+    if (threadIdx.x < 64) {
+        double a = 0, b = 0;
+        if ((int)threadIdx.x < nchunk) { a = part[2 * threadIdx.x]; b = part[2 * threadIdx.x + 1]; }
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
+        if (threadIdx.x == 0) { tot[0] = a; tot[1] = b; }
+    }
+    __syncthreads();
+    s = tot[0]; t = tot[1];
+}
+
+__global__ void __launch_bounds__(256) tbn_stats_kernel(const float* __restrict__ x, int N, int C, long HW, double* __restrict__ scratch)
+{
+    const int c = blockIdx.y, nchunk = gridDim.x;
+    const long upn = (HW + 255) / 256, U = (long)N * upn;
+    double s = 0, ss = 0;
+    for (long u = blockIdx.x; u < U; u += nchunk) {
+        const long n = u / upn, i = (u - n * upn) * 256 + threadIdx.x;
+        if (i < HW) { const double v = x[(n * C + c) * HW + i]; s += v; ss += v * v; }
+    }
+    tbn_block_store(s, ss, scratch + (long)c * TBN_MAXCHUNK * 2);
+}
+
+// stats[c] = {mean, invstd}
+__global__ void __launch_bounds__(256) tbn_apply_kernel(const float* __restrict__ x, const double* __restrict__ scratch, int nchunk,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+                                                        int N, int C, long HW, int relu, float eps, float momentum, float* __restrict__ stats,
+                                                        float* __restrict__ running_mean, float* __restrict__ running_var)
+{
+    const int c = blockIdx.y;
+    double s, ss;
+    tbn_block_total(scratch + (long)c * TBN_MAXCHUNK * 2, nchunk, s, ss);
+    const double P = (double)N * (double)HW, mean = s / P;
+    double var = ss / P - mean * mean;
+    if (var < 0) var = 0;
+    const float fm = (float)mean, fi = (float)(1.0 / sqrt(var + (double)eps));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        stats[2 * c] = fm;
+        stats[2 * c + 1] = fi;
         if (running_mean) {
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * (double)P / (double)(P > 1 ? P - 1 : 1));
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * fm;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * P / (P > 1 ? P - 1 : 1));
         }
     }
+    const float g = gamma[c], b = beta[c];
+    const long upn = (HW + 255) / 256, U = (long)N * upn;
+    for (long u = blockIdx.x; u < U; u += gridDim.x) {
+        const long n = u / upn, i = (u - n * upn) * 256 + threadIdx.x;
+        if (i >= HW) continue;
+        const long idx = (n * C + c) * HW + i;
+        const float v = (x[idx] - fm) * fi * g + b;
+        y[idx] = relu ? fmaxf(v, 0.f) : v;
+    }
 }
 
-__global__ void __launch_bounds__(256) tbn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float* __restrict__ y, long total, int C, long HW, int relu)
-{
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int c = (int)((idx / HW) % C);
-    float v = (x[idx] - stats[2 * c]) * stats[2 * c + 1] * gamma[c] + beta[c];
-    y[idx] = relu ? fmaxf(v, 0.f) : v;
-}
-
-// backward: dy_eff = dy * (y > 0) with ReLU; sums[c] = {sum dy_eff, sum dy_eff * xhat}  (= dbeta, dgamma)
+// backward: dy_eff = dy * (y > 0) with ReLU; {sum dy_eff, sum dy_eff * xhat} = (dbeta, dgamma)
 __global__ void __launch_bounds__(256) tbn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
                                                              const float* __restrict__ stats, int N, int C, long HW, int relu,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta)
+                                                             double* __restrict__ scratch)
 {
-    __shared__ double r1[4], r2[4];
-    const int c = blockIdx.x;
-    const long P = (long)N * HW;
+    const int c = blockIdx.y, nchunk = gridDim.x;
+    const long upn = (HW + 255) / 256, U = (long)N * upn;
     const float mean = stats[2 * c], invstd = stats[2 * c + 1];
     double s = 0, sx = 0;
-    for (long p = threadIdx.x; p < P; p += 256) {
-        const long n = p / HW, i = p - n * HW, idx = (n * C + c) * HW + i;
-        float g = dy[idx];
-        if (relu && !(y[idx] > 0.f)) g = 0.f;
-        s += g; sx += (double)g * (double)((x[idx] - mean) * invstd);
+    for (long u = blockIdx.x; u < U; u += nchunk) {
+        const long n = u / upn, i = (u - n * upn) * 256 + threadIdx.x;
+        if (i < HW) {
+            const long idx = (n * C + c) * HW + i;
+            float g = dy[idx];
+            if (relu && !(y[idx] > 0.f)) g = 0.f;
+            s += g; sx += (double)g * (double)((x[idx] - mean) * invstd);
+        }
     }
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o); sx += __shfl_down(sx, o); }
-    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s; r2[threadIdx.x >> 6] = sx; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        dbeta[c] = (float)(r1[0] + r1[1] + r1[2] + r1[3]);
-        dgamma[c] = (float)(r2[0] + r2[1] + r2[2] + r2[3]);
-    }
+    tbn_block_store(s, sx, scratch + (long)c * TBN_MAXCHUNK * 2);
 }
 
 // dx = gamma * invstd * (dy_eff - (dbeta + xhat * dgamma) / P)
 __global__ void __launch_bounds__(256) tbn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta, float* __restrict__ dx,
-                                                            long total, int C, long HW, long P, int relu)
+                                                            const double* __restrict__ scratch, int nchunk, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ dx, int N, int C, long HW, int relu)
 {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int c = (int)((idx / HW) % C);
-    float g = dy[idx];
-    if (relu && !(y[idx] > 0.f)) g = 0.f;
-    const float xhat = (x[idx] - stats[2 * c]) * stats[2 * c + 1];
-    dx[idx] = gamma[c] * stats[2 * c + 1] * (g - (dbeta[c] + xhat * dgamma[c]) / (float)P);
+    const int c = blockIdx.y;
+    double s, sx;
+    tbn_block_total(scratch + (long)c * TBN_MAXCHUNK * 2, nchunk, s, sx);
+    const float db = (float)s, dg = (float)sx;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { dbeta[c] = db; dgamma[c] = dg; }
+    const float fm = stats[2 * c], fi = stats[2 * c + 1], gi = gamma[c] * fi, invP = 1.f / (float)((long)N * HW);
+    const long upn = (HW + 255) / 256, U = (long)N * upn;
+    for (long u = blockIdx.x; u < U; u += gridDim.x) {
+        const long n = u / upn, i = (u - n * upn) * 256 + threadIdx.x;
+        if (i >= HW) continue;
+        const long idx = (n * C + c) * HW + i;
+        float g = dy[idx];
+        if (relu && !(y[idx] > 0.f)) g = 0.f;
+        const float xhat = (x[idx] - fm) * fi;
+        dx[idx] = gi * (g - (db + xhat * dg) * invP);
+    }
 }
 
 // per-channel sum over N, H, W (bias gradient of the head convs)
@@ -236,11 +665,11 @@ __global__ void __launch_bounds__(256) tchan_sum_kernel(const float* __restrict_
 {
     __shared__ double r1[4];
     const int c = blockIdx.x;
-    const long P = (long)N * HW;
+    const long upn = (HW + 255) / 256, U = (long)N * upn;
     double s = 0;
-    for (long p = threadIdx.x; p < P; p += 256) {
-        const long n = p / HW, i = p - n * HW;
-        s += dy[(n * C + c) * HW + i];
+    for (long u = 0; u < U; ++u) {
+        const long n = u / upn, i = (u - n * upn) * 256 + threadIdx.x;
+        if (i < HW) s += dy[(n * C + c) * HW + i];
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
     if ((threadIdx.x & 63) == 0) r1[threadIdx.x >> 6] = s;
@@ -280,28 +709,131 @@ __global__ void __launch_bounds__(256) tadam_kernel(float* __restrict__ p, const
     p[idx] += -step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
 }
 
+// every parameter tensor in one launch: tab[t] = {p, g, m, v, first block, elements}
+struct TAdamEntry { float* p; const float* g; float* m; float* v; long block0; long n; };
+__global__ void __launch_bounds__(256) tadam_multi_kernel(const TAdamEntry* __restrict__ tab, int nt, float w1, float b2, float w2, float eps,
+                                                          float step_size, float bc2_sqrt)
+{
+    int lo = 0, hi = nt - 1;                                   // the tensor this workgroup belongs to
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab[mid].block0 <= (long)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const TAdamEntry e = tab[lo];
+    const long idx = ((long)blockIdx.x - e.block0) * 256 + threadIdx.x;
+    if (idx >= e.n) return;
+    const float gi = e.g[idx];
+    const float mi = e.m[idx] + w1 * (gi - e.m[idx]);
+    const float vi = e.v[idx] * b2 + (w2 * gi) * gi;
+    e.m[idx] = mi; e.v[idx] = vi;
+    e.p[idx] += -step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+}
+
 static inline unsigned nblk(long total) { return (unsigned)((total + 255) / 256); }
 
+static void launch_tpw_gemm(const float* x, const float* a, const float* bias, float* y, long Q, long HW, int M, int K, long sm, long sk, hipStream_t s)
+{
+    const unsigned my = (unsigned)((M + 63) / 64);
+    if (((Q + 63) / 64) * my >= 512)
+        hipLaunchKernelGGL(tpw_mfma_kernel<4>, dim3((unsigned)((Q + 63) / 64), my), dim3(256), 0, s, x, a, bias, y, Q, HW, M, K, sm, sk);
+    else
+        hipLaunchKernelGGL(tpw_mfma_kernel<1>, dim3((unsigned)((Q + 15) / 16), my), dim3(256), 0, s, x, a, bias, y, Q, HW, M, K, sm, sk);
+}
 void launch_tconv_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W, int Cout, int k, int stride,
                       int depthwise, hipStream_t s)
 {
     const int pad = (k - 1) / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    if (!depthwise && k == 1 && stride == 1) {
+        launch_tpw_gemm(x, w, bias, y, (long)N * H * W, (long)H * W, Cout, Cin, (long)Cin, 1L, s);
+        return;
+    }
+    if (!depthwise && k == 3) {
+        hipLaunchKernelGGL(tconv_im2col_mfma_kernel<3>, dim3((unsigned)(((long)N * Ho * Wo + 63) / 64), (Cout + 63) / 64), dim3(256), 0, s, x, w, bias, y,
+                           N, Cin, H, W, Ho, Wo, Cout, stride);
+        return;
+    }
+    if (!depthwise) {
+        const long Q = (long)N * Ho * Wo;
+        if (Cout > 8)
+            hipLaunchKernelGGL(tconv_mc_kernel<16>, dim3(nblk(Q), (Cout + 15) / 16), dim3(256), 0, s, x, w, bias, y, N, Cin, H, W, Cout, Ho, Wo, k,
+                               stride, (long)Cin * k * k, (long)k * k);
+        else
+            hipLaunchKernelGGL(tconv_mc_kernel<8>, dim3(nblk(Q), (Cout + 7) / 8), dim3(256), 0, s, x, w, bias, y, N, Cin, H, W, Cout, Ho, Wo, k, stride,
+                               (long)Cin * k * k, (long)k * k);
+        return;
+    }
     hipLaunchKernelGGL(tconv_fwd_kernel, dim3(nblk((long)N * Cout * Ho * Wo)), dim3(256), 0, s, x, w, bias, y, N, Cin, H, W, Cout, Ho, Wo, k, stride, depthwise);
 }
 void launch_tconv_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int k, int stride, int depthwise,
                            hipStream_t s)
 {
     const int pad = (k - 1) / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    if (!depthwise && k == 1 && stride == 1) {       // pointwise: dx[ci] = sum_co dy[co] w[co][ci] -- the same GEMM with the weight transposed
+        launch_tpw_gemm(dy, w, nullptr, dx, (long)N * H * W, (long)H * W, Cin, Cout, 1L, (long)Cin, s);
+        return;
+    }
+    if (!depthwise && k == 3 && stride == 2 && H == 2 * Ho && W == 2 * Wo) {
+        hipLaunchKernelGGL(tconv3s2_bwd_data_kernel<8>, dim3(nblk((long)N * Ho * Wo), (Cin + 7) / 8), dim3(256), 0, s, dy, w, dx, N, Cin, Cout, Ho, Wo);
+        return;
+    }
     hipLaunchKernelGGL(tconv_bwd_data_kernel, dim3(nblk((long)N * Cin * H * W)), dim3(256), 0, s, dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, k, stride, depthwise);
 }
+// the slabs of the split reductions: nsplit <= what fits into the scratch
+static inline void tsum_partials(const float* part, long nsplit, long nw, float* dw, hipStream_t s)
+{
+    int spl = 1;
+    while (spl < 64 && spl * 8 <= nsplit) spl *= 2;                 // >= 8 slabs per lane
+    hipLaunchKernelGGL(tsum_partials_kernel, dim3(nblk(nw * spl)), dim3(256), 0, s, part, (int)nsplit, nw, nw, dw, spl);
+}
 void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int k, int stride, int depthwise,
-                             hipStream_t s)
+                             void* scratch, size_t scratch_bytes, hipStream_t s)
 {
     const int pad = (k - 1) / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     const long nw = (long)Cout * (depthwise ? 1 : Cin) * k * k, P = (long)N * Ho * Wo;
+    const long fit = scratch ? (long)(scratch_bytes / ((size_t)nw * sizeof(float))) : 0;      // slabs that fit
+    // 4 consecutive output pixels per lane: in one row for k = 3 (Wo % 4), merely in one frame for a pointwise conv (Ho Wo % 4)
+    if (!depthwise && ((k == 3 && Wo % 4 == 0) || (k == 1 && stride == 1 && ((long)Ho * Wo) % 4 == 0))) {
+        const int R = Cin * k * k, tiles = ((Cout + 15) / 16) * ((R + 63) / 64);
+        long nsplit = (P + 127) / 128;                                  // >= 8 MFMA steps per wave ...
+        while (nsplit * tiles > 8192 && nsplit > 1) nsplit = (nsplit + 1) / 2;   // ... and a bounded grid
+        if (nsplit > 1024) nsplit = 1024;
+        if (nsplit > fit) nsplit = fit < 1 ? 1 : fit;
+        long q_per = (P + nsplit - 1) / nsplit;
+        q_per = (q_per + 15) / 16 * 16;
+        nsplit = (P + q_per - 1) / q_per;
+        float* out = nsplit > 1 ? (float*)scratch : dw;
+        const dim3 grid((unsigned)nsplit, (Cout + 15) / 16, (R + 63) / 64);
+        if (k == 1)
+            hipLaunchKernelGGL(tconv_wgrad_mfma_kernel<1>, grid, dim3(64), 0, s, x, dy, out, N, Cin, H, W, Cout, Ho, Wo, stride, q_per, nw);
+        else
+            hipLaunchKernelGGL(tconv_wgrad_mfma_kernel<3>, grid, dim3(64), 0, s, x, dy, out, N, Cin, H, W, Cout, Ho, Wo, stride, q_per, nw);
+        if (nsplit > 1) tsum_partials(out, nsplit, nw, dw, s);
+        return;
+    }
+    if (depthwise && (k == 3 || k == 5)) {
+        long chunks = (P + 2047) / 2048;                                // ~8 pixels per thread
+        while (chunks * Cout > 4096 && chunks > 1) chunks = (chunks + 1) / 2;
+        if (chunks > fit) chunks = fit < 1 ? 1 : fit;
+        float* out = chunks > 1 ? (float*)scratch : dw;
+        const dim3 grid((unsigned)chunks, Cout);
+        if (k == 3)
+            hipLaunchKernelGGL(tdw_wgrad_kernel<3>, grid, dim3(256), 0, s, x, dy, out, N, Cout, H, W, Ho, Wo, stride, nw);
+        else
+            hipLaunchKernelGGL(tdw_wgrad_kernel<5>, grid, dim3(256), 0, s, x, dy, out, N, Cout, H, W, Ho, Wo, stride, nw);
+        if (chunks > 1) tsum_partials(out, chunks, nw, dw, s);
+        return;
+    }
+    (void)hipMemsetAsync(dw, 0, (size_t)nw * sizeof(float), s);        // the fallbacks below accumulate with atomics
+    if (!depthwise) {
+        const int R = Cin * k * k, tiles = ((R + 63) / 64) * ((Cout + 63) / 64);
+        long nsplit = (P + 255) / 256;                                  // >= 8 staged tiles per workgroup ...
+        while (nsplit * tiles > 2048 && nsplit > 1) nsplit = (nsplit + 1) / 2;   // ... and a bounded grid
+        long p_per = (P + nsplit - 1) / nsplit;
+        p_per = (p_per + 31) / 32 * 32;
+        nsplit = (P + p_per - 1) / p_per;
+        hipLaunchKernelGGL(tconv_bwd_weight_gemm_kernel, dim3((unsigned)nsplit, (R + 63) / 64, (Cout + 63) / 64), dim3(256), 0, s, x, dy, dw, N, Cin, H,
+                           W, Cout, Ho, Wo, k, stride, p_per);
+        return;
+    }
     int nchunk = (int)((P + 4095) / 4096);                       // ~16 reduction elements per thread
     while ((long)nchunk * nw > 262144 && nchunk > 1) nchunk /= 2;   // bound the grid
-    (void)hipMemsetAsync(dw, 0, (size_t)nw * sizeof(float), s);
     hipLaunchKernelGGL(tconv_bwd_weight_kernel, dim3((unsigned)(nw * nchunk)), dim3(256), 0, s, x, dy, dw, N, Cin, H, W, Cout, Ho, Wo, k, stride,
                        depthwise, nchunk);
 }
@@ -321,18 +853,39 @@ void launch_tdeconv_bwd_weight(const float* x, const float* dy, float* dw, int N
     (void)hipMemsetAsync(dw, 0, (size_t)nw * sizeof(float), s);
     hipLaunchKernelGGL(tdeconv_bwd_weight_kernel, dim3((unsigned)(nw * nchunk)), dim3(256), 0, s, x, dy, dw, N, Cin, H, W, Cout, nchunk);
 }
-void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* stats, float* y, int N,
-                    int C, long HW, int relu, hipStream_t s)
+// one scratch for the split reductions of a stream: BatchNorm partial pairs (256 KB) or weight-gradient slabs (all of it)
+size_t train_scratch_bytes() { return (size_t)16 << 20; }
+static inline unsigned tbn_apply_blocks(int N, int C, long HW)
 {
-    hipLaunchKernelGGL(tbn_stats_kernel, dim3(C), dim3(256), 0, s, x, N, C, HW, 1e-5f, 0.1f, stats, running_mean, running_var);
-    hipLaunchKernelGGL(tbn_apply_kernel, dim3(nblk((long)N * C * HW)), dim3(256), 0, s, x, stats, gamma, beta, y, (long)N * C * HW, C, HW, relu);
+    const long U = (long)N * ((HW + 255) / 256);
+    long n = 4096 / C;
+    if (n > U) n = U;
+    return n < 1 ? 1u : (unsigned)n;
+}
+static inline int tbn_chunks(int N, int C, long HW)
+{
+    const long U = (long)N * ((HW + 255) / 256);
+    long n = 2048 / C;
+    if (n > TBN_MAXCHUNK) n = TBN_MAXCHUNK;
+    if (n > U) n = U;
+    return n < 1 ? 1 : (int)n;
+}
+// scratch: >= 256 KB of device memory (partial sums; needs no initialisation); C <= 256
+void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* stats, float* y, int N,
+                    int C, long HW, int relu, void* scratch, hipStream_t s)
+{
+    const int nchunk = tbn_chunks(N, C, HW);
+    hipLaunchKernelGGL(tbn_stats_kernel, dim3(nchunk, C), dim3(256), 0, s, x, N, C, HW, (double*)scratch);
+    hipLaunchKernelGGL(tbn_apply_kernel, dim3(tbn_apply_blocks(N, C, HW), C), dim3(256), 0, s, x, (const double*)scratch, nchunk, gamma, beta, y, N,
+                       C, HW, relu, 1e-5f, 0.1f, stats, running_mean, running_var);
 }
 void launch_tbn_bwd(const float* x, const float* y, const float* dy, const float* stats, const float* gamma, float* dgamma, float* dbeta, float* dx,
-                    int N, int C, long HW, int relu, hipStream_t s)
+                    int N, int C, long HW, int relu, void* scratch, hipStream_t s)
 {
-    hipLaunchKernelGGL(tbn_bwd_reduce_kernel, dim3(C), dim3(256), 0, s, x, y, dy, stats, N, C, HW, relu, dgamma, dbeta);
-    hipLaunchKernelGGL(tbn_bwd_apply_kernel, dim3(nblk((long)N * C * HW)), dim3(256), 0, s, x, y, dy, stats, gamma, dgamma, dbeta, dx,
-                       (long)N * C * HW, C, HW, (long)N * HW, relu);
+    const int nchunk = tbn_chunks(N, C, HW);
+    hipLaunchKernelGGL(tbn_bwd_reduce_kernel, dim3(nchunk, C), dim3(256), 0, s, x, y, dy, stats, N, C, HW, relu, (double*)scratch);
+    hipLaunchKernelGGL(tbn_bwd_apply_kernel, dim3(tbn_apply_blocks(N, C, HW), C), dim3(256), 0, s, x, y, dy, stats, gamma,
+                       (const double*)scratch, nchunk, dgamma, dbeta, dx, N, C, HW, relu);
 }
 void launch_tchan_sum(const float* dy, float* out, int N, int C, long HW, hipStream_t s)
 {
@@ -351,6 +904,23 @@ void launch_tadam(float* p, const float* g, float* m, float* v, long total, doub
     const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
     hipLaunchKernelGGL(tadam_kernel, dim3(nblk(total)), dim3(256), 0, s, p, g, m, v, total, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps,
                        (float)(lr / bc1), (float)sqrt(bc2));
+}
+
+// host arrays of device pointers -> one table upload + one launch.  d_table: at least nt * 48 bytes of device memory.
+void launch_tadam_multi(int nt, float* const* p, const float* const* g, float* const* m, float* const* v, const long* sizes, double lr, double b1,
+                        double b2, double eps, int step, void* d_table, hipStream_t s)
+{
+    static thread_local std::vector<TAdamEntry> tab;
+    tab.resize(nt);
+    long blocks = 0;
+    for (int t = 0; t < nt; ++t) {
+        tab[t] = TAdamEntry{p[t], g[t], m[t], v[t], blocks, sizes[t]};
+        blocks += (sizes[t] + 255) / 256;
+    }
+    (void)hipMemcpyAsync(d_table, tab.data(), (size_t)nt * sizeof(TAdamEntry), hipMemcpyHostToDevice, s);   // pageable source: staged before return
+    const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+    hipLaunchKernelGGL(tadam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const TAdamEntry*)d_table, nt, (float)(1.0 - b1), (float)b2,
+                       (float)(1.0 - b2), (float)eps, (float)(lr / bc1), (float)sqrt(bc2));
 }
 
 }  // namespace yf

@@ -36,12 +36,28 @@ class _Ops:
         self.device = device
         self.dev = device.index if device.index is not None else torch.cuda.current_device()
         self.stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        sc = _scratch(self.lib, device)
+        self.scratch, self.scratch_bytes = sc.data_ptr(), sc.numel()
+        self.bn_scratch = self.scratch
 
     def new(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
     def call(self, name, *args):
         _lib.check(getattr(self.lib, name)(self.dev, *args, self.stream))
+
+
+_SCRATCH = {}
+
+
+def _scratch(lib, device):
+    """The scratch of the split reductions (include/yolo_fastest_hip.h: yf_train_scratch_bytes), one per (device, stream)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    if key not in _SCRATCH:
+        n = ctypes.c_size_t()
+        _lib.check(lib.yf_train_scratch_bytes(ctypes.byref(n)))
+        _SCRATCH[key] = torch.empty(n.value, dtype=torch.uint8, device=device)
+    return _SCRATCH[key]
 
 
 def _ptr(t):
@@ -76,9 +92,9 @@ def _unit_forward(ops, mod, x, tape, name):
     stats = ops.new(2 * Cout)
     HW = z.shape[2] * z.shape[3]
     ops.call("yf_train_bn_forward", z.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), _ptr(bn.running_mean), _ptr(bn.running_var),
-             stats.data_ptr(), y.data_ptr(), N, Cout, HW, relu)
+             stats.data_ptr(), y.data_ptr(), N, Cout, HW, relu, ops.bn_scratch)
     if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+        tape.setdefault("_nbt", []).append(bn.num_batches_tracked)
     tape[name] = (x, z, y, stats, relu)
     return y
 
@@ -91,7 +107,7 @@ def _unit_backward(ops, mod, tape, name, gy, grads, need_dx=True):
     gz = torch.empty_like(z)
     dgamma, dbeta = ops.new(Cout), ops.new(Cout)
     ops.call("yf_train_bn_backward", z.data_ptr(), y.data_ptr(), gy.data_ptr(), stats.data_ptr(), bn.weight.data_ptr(), dgamma.data_ptr(),
-             dbeta.data_ptr(), gz.data_ptr(), N, Cout, HW, relu)
+             dbeta.data_ptr(), gz.data_ptr(), N, Cout, HW, relu, ops.bn_scratch)
     grads[bn.weight], grads[bn.bias] = dgamma, dbeta
     dw_ = torch.empty_like(conv.weight)
     gx = torch.empty_like(x) if need_dx else None
@@ -102,7 +118,8 @@ def _unit_backward(ops, mod, tape, name, gy, grads, need_dx=True):
             ops.call("yf_train_deconv_backward_data", gz.data_ptr(), conv.weight.data_ptr(), gx.data_ptr(), N, Cin, H, W, Cout)
     else:
         _, Cin, H, W, _, k, stride, dw, _, _ = _conv_geom(conv, x)
-        ops.call("yf_train_conv_backward_weight", x.data_ptr(), gz.data_ptr(), dw_.data_ptr(), N, Cin, H, W, Cout, k, stride, dw)
+        ops.call("yf_train_conv_backward_weight", x.data_ptr(), gz.data_ptr(), dw_.data_ptr(), N, Cin, H, W, Cout, k, stride, dw, ops.scratch,
+                 ops.scratch_bytes)
         if need_dx:
             ops.call("yf_train_conv_backward_data", gz.data_ptr(), conv.weight.data_ptr(), gx.data_ptr(), N, Cin, H, W, Cout, k, stride, dw)
     grads[conv.weight] = dw_
@@ -158,7 +175,7 @@ def _head_backward(ops, conv, tape, name, gy, grads):
     Cout = conv.out_channels
     gy = gy.contiguous()
     dw_, db, gx = torch.empty_like(conv.weight), ops.new(Cout), torch.empty_like(x)
-    ops.call("yf_train_conv_backward_weight", x.data_ptr(), gy.data_ptr(), dw_.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0)
+    ops.call("yf_train_conv_backward_weight", x.data_ptr(), gy.data_ptr(), dw_.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0, ops.scratch, ops.scratch_bytes)
     ops.call("yf_train_channel_sum", gy.data_ptr(), db.data_ptr(), N, Cout, H * W)
     ops.call("yf_train_conv_backward_data", gy.data_ptr(), conv.weight.data_ptr(), gx.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0)
     grads[conv.weight], grads[conv.bias] = dw_, db
@@ -182,6 +199,8 @@ def train_forward(model, x):
     e = _run(ops, model, _SEQ4, cat, tape)
     hl = _head_forward(ops, model.head_4, e, tape, "head_4")
     tape["_cat"] = (Ca, Cd, H, W)
+    if tape.get("_nbt"):
+        torch._foreach_add_(tape.pop("_nbt"), 1)               # the 84 num_batches_tracked counters
     return hl, hs, tape
 
 
@@ -256,20 +275,28 @@ class Adam(torch.optim.Optimizer):
         lib = _lib.lib()
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            todo = {}                                     # (device, step) -> tensors: one launch each (yf_train_adam_multi)
             for p in group["params"]:
                 if p.grad is None:
                     continue
-                if not p.is_cuda or p.dtype != torch.float32:
-                    raise RuntimeError("training.Adam (HIP) has no CPU path: float32 GPU parameters only")
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("training.Adam (HIP) has no CPU path: contiguous float32 GPU parameters only")
                 st = self.state[p]
                 if not st:
                     st["step"], st["exp_avg"], st["exp_avg_sq"] = 0, torch.zeros_like(p), torch.zeros_like(p)
                 st["step"] += 1
-                g = p.grad.contiguous()
-                dev = p.device.index if p.device.index is not None else torch.cuda.current_device()
-                _lib.check(lib.yf_train_adam_step(dev, p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                                  p.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]),
-                                                  ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)))
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                todo.setdefault((p.device, st["step"]), []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
+            for (device, step), items in todo.items():
+                n = len(items)
+                arr = lambda k: (ctypes.c_void_p * n)(*[it[k].data_ptr() for it in items])
+                sizes = (ctypes.c_long * n)(*[it[0].numel() for it in items])
+                table = torch.empty(48 * n, dtype=torch.uint8, device=device)
+                dev = device.index if device.index is not None else torch.cuda.current_device()
+                _lib.check(lib.yf_train_adam_multi(dev, n, arr(0), arr(1), arr(2), arr(3), sizes, float(group["lr"]), float(b1), float(b2),
+                                                   float(group["eps"]), int(step), table.data_ptr(), table.numel(),
+                                                   ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
+                self._keep = (items, table)          # alive until the next step: the launch is asynchronous
 
 
 def train_step(model, model_loss, optimizer, imgs, targets):
