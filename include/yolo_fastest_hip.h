@@ -168,6 +168,16 @@ int yf_train_bn_forward(int device, const float *d_x, const float *d_gamma, cons
                         float *d_stats, float *d_y, int N, int C, long HW, int relu, void *d_scratch, void *stream);
 int yf_train_bn_backward(int device, const float *d_x, const float *d_y, const float *d_dy, const float *d_stats, const float *d_gamma,
                          float *d_dgamma, float *d_dbeta, float *d_dx, int N, int C, long HW, int relu, void *d_scratch, void *stream);
+/* One block of the network each way -- conv_norm_relu / conv_norm / deconv_norm_relu (yolo_fastest.py:16-48): conv (deconv = 1:
+ * ConvTranspose2d) + BatchNorm (+ ReLU).  forward: d_z = conv output (kept for the backward), d_y = block output.  backward: d_gy =
+ * gradient of the block output -> d_dgamma, d_dbeta, d_dw, d_dx (NULL: not needed, the first layer); d_gz: work tensor like z. */
+int yf_train_unit_forward(int device, int deconv, const float *d_x, const float *d_w, const float *d_gamma, const float *d_beta,
+                          float *d_running_mean, float *d_running_var, float *d_stats, float *d_z, float *d_y, int N, int Cin, int H, int W, int Cout,
+                          int k, int stride, int depthwise, int relu, void *d_scratch, void *stream);
+int yf_train_unit_backward(int device, int deconv, const float *d_x, const float *d_z, const float *d_y, const float *d_gy, const float *d_stats,
+                           const float *d_w, const float *d_gamma, float *d_dgamma, float *d_dbeta, float *d_gz, float *d_dw, float *d_dx, int N,
+                           int Cin, int H, int W, int Cout, int k, int stride, int depthwise, int relu, void *d_scratch, size_t scratch_bytes,
+                           void *stream);
 int yf_train_channel_sum(int device, const float *d_dy, float *d_out, int N, int C, long HW, void *stream);                 /* bias gradient */
 int yf_train_add(int device, const float *d_a, const float *d_b, float *d_out, long total, void *stream);                   /* residual / grad sum */
 int yf_train_channel_slice(int device, const float *d_src, float *d_dst, int N, int C, long HW, int Cs, int sc0, int Cd, int dc0,

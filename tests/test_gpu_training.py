@@ -54,7 +54,8 @@ def _close(got, want, rel, what):
 # reference's padding arithmetic, not only the even sizes the network sees)
 CONVS = [(1, 8, 3, 2, 0, 16, 12), (24, 24, 3, 2, 0, 10, 8), (8, 8, 3, 1, 1, 9, 7), (32, 32, 3, 2, 1, 12, 10), (136, 136, 3, 2, 1, 6, 8),
          (96, 96, 5, 1, 1, 7, 9), (128, 128, 5, 1, 1, 4, 5), (4, 24, 1, 1, 0, 6, 5), (232, 96, 1, 1, 0, 4, 6), (224, 48, 1, 1, 0, 3, 4),
-         (24, 136, 1, 1, 0, 5, 5), (3, 5, 3, 2, 0, 7, 9)]
+         (24, 136, 1, 1, 0, 5, 5), (3, 5, 3, 2, 0, 7, 9), (48, 48, 3, 1, 1, 8, 12), (96, 96, 5, 1, 1, 8, 12), (32, 32, 3, 2, 1, 16, 16),
+         (16, 96, 1, 1, 0, 8, 10), (24, 24, 3, 2, 0, 16, 24)]
 
 
 @pytest.mark.parametrize("geom", CONVS)

@@ -975,6 +975,59 @@ int yf_train_adam_step(int device, float* d_p, const float* d_g, float* d_m, flo
     YF_TOP(d_p && d_g && d_m && d_v && total > 0 && step >= 1,
            yf::launch_tadam(d_p, d_g, d_m, d_v, total, lr, beta1, beta2, eps, step, (hipStream_t)stream));
 }
+// conv / deconv + BatchNorm (+ ReLU) as one call each way: what the reference's conv_norm_relu / conv_norm / deconv_norm_relu blocks do
+int yf_train_unit_forward(int device, int deconv, const float* d_x, const float* d_w, const float* d_gamma, const float* d_beta,
+                          float* d_running_mean, float* d_running_var, float* d_stats, float* d_z, float* d_y, int N, int Cin, int H, int W, int Cout,
+                          int k, int stride, int depthwise, int relu, void* d_scratch, void* stream)
+{
+    if (!d_x || !d_w || !d_gamma || !d_beta || !d_stats || !d_z || !d_y || !d_scratch || N <= 0 || Cin <= 0 || Cout <= 0 || Cout > 256 || H <= 0 ||
+        W <= 0 || (depthwise && Cin != Cout))
+        return fail(YF_E_INVALID, "yf_train_unit_forward: bad argument");
+    if (!deconv && !((k == 1 || k == 3 || k == 5) && (stride == 1 || stride == 2))) return fail(YF_E_INVALID, "yf_train_unit_forward: bad kernel / stride");
+    HIP_OK(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    long HWo;
+    if (deconv) {
+        yf::launch_tdeconv_fwd(d_x, d_w, d_z, N, Cin, H, W, Cout, s);
+        HWo = 4L * H * W;
+    } else {
+        yf::launch_tconv_fwd(d_x, d_w, nullptr, d_z, N, Cin, H, W, Cout, k, stride, depthwise, s);
+        const int pad = (k - 1) / 2;
+        HWo = (long)((H + 2 * pad - k) / stride + 1) * ((W + 2 * pad - k) / stride + 1);
+    }
+    yf::launch_tbn_fwd(d_z, d_gamma, d_beta, d_running_mean, d_running_var, d_stats, d_y, N, Cout, HWo, relu, d_scratch, s);
+    HIP_OK(hipGetLastError());
+    return YF_OK;
+}
+int yf_train_unit_backward(int device, int deconv, const float* d_x, const float* d_z, const float* d_y, const float* d_gy, const float* d_stats,
+                           const float* d_w, const float* d_gamma, float* d_dgamma, float* d_dbeta, float* d_gz, float* d_dw, float* d_dx, int N,
+                           int Cin, int H, int W, int Cout, int k, int stride, int depthwise, int relu, void* d_scratch, size_t scratch_bytes,
+                           void* stream)
+{
+    if (!d_x || !d_z || !d_y || !d_gy || !d_stats || !d_w || !d_gamma || !d_dgamma || !d_dbeta || !d_gz || !d_dw || !d_scratch || N <= 0 || Cin <= 0 ||
+        Cout <= 0 || Cout > 256 || (depthwise && Cin != Cout))
+        return fail(YF_E_INVALID, "yf_train_unit_backward: bad argument");
+    if (!deconv && !((k == 1 || k == 3 || k == 5) && (stride == 1 || stride == 2))) return fail(YF_E_INVALID, "yf_train_unit_backward: bad kernel / stride");
+    HIP_OK(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    long HWo;
+    if (deconv) {
+        HWo = 4L * H * W;
+    } else {
+        const int pad = (k - 1) / 2;
+        HWo = (long)((H + 2 * pad - k) / stride + 1) * ((W + 2 * pad - k) / stride + 1);
+    }
+    yf::launch_tbn_bwd(d_z, d_y, d_gy, d_stats, d_gamma, d_dgamma, d_dbeta, d_gz, N, Cout, HWo, relu, d_scratch, s);
+    if (deconv) {
+        yf::launch_tdeconv_bwd_weight(d_x, d_gz, d_dw, N, Cin, H, W, Cout, s);
+        if (d_dx) yf::launch_tdeconv_bwd_data(d_gz, d_w, d_dx, N, Cin, H, W, Cout, s);
+    } else {
+        yf::launch_tconv_bwd_weight(d_x, d_gz, d_dw, N, Cin, H, W, Cout, k, stride, depthwise, d_scratch, scratch_bytes, s);
+        if (d_dx) yf::launch_tconv_bwd_data(d_gz, d_w, d_dx, N, Cin, H, W, Cout, k, stride, depthwise, s);
+    }
+    HIP_OK(hipGetLastError());
+    return YF_OK;
+}
 int yf_train_adam_multi(int device, int ntensors, void* const* d_p, const void* const* d_g, void* const* d_m, void* const* d_v, const long* sizes,
                         double lr, double beta1, double beta2, double eps, int step, void* d_table, size_t table_bytes, void* stream)
 {

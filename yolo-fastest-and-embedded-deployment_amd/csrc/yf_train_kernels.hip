@@ -371,6 +371,65 @@ __global__ void __launch_bounds__(256) tconv3s2_bwd_data_kernel(const float* __r
     }
 }
 
+// ---- depthwise convolution, one (frame, channel) plane per blockIdx.y so that the KS*KS weights are wave-uniform; a thread computes 4
+// consecutive outputs of a row (Wo % 4 == 0) from the KS x (3 S + KS) input window.  FLIP: the weights reversed -- the backward-data
+// of a stride-1 depthwise conv is the same conv of dY with the flipped kernel. ----
+template <int KS, int S, bool FLIP>
+__global__ void tdw_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int C, int H, int W, int Ho, int Wo)
+{
+    constexpr int KK = KS * KS, PAD = (KS - 1) / 2, WIN = 3 * S + KS;
+    const int plane = blockIdx.y, c = plane % C;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, per_row = Wo / 4;
+    if (t >= Ho * per_row) return;
+    const int oy = t / per_row, ox0 = (t - oy * per_row) * 4;
+    const float* xp = x + (long)plane * H * W;
+    const float* wp = w + (long)c * KK;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+        const int iy = oy * S - PAD + ky;
+        if (iy < 0 || iy >= H) continue;
+        const float* xr = xp + (long)iy * W;
+        float win[WIN];
+#pragma unroll
+        for (int j = 0; j < WIN; ++j) {
+            const int ix = ox0 * S - PAD + j;
+            win[j] = (ix >= 0 && ix < W) ? xr[ix] : 0.f;
+        }
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            const float wv = FLIP ? wp[KK - 1 - (ky * KS + kx)] : wp[ky * KS + kx];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[o] = fmaf(win[o * S + kx], wv, acc[o]);
+        }
+    }
+    *reinterpret_cast<float4*>(y + ((long)plane * Ho + oy) * Wo + ox0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+// backward-data of the depthwise 3x3 stride-2 pad-1 convolution: one thread = the 2x2 input block (2a.., 2b..), see tconv3s2_bwd_data_kernel
+__global__ void tdw3s2_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int C, int Ho, int Wo)
+{
+    const int plane = blockIdx.y, c = plane % C;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Ho * Wo) return;
+    const int a = t / Wo, b = t - a * Wo;
+    const bool vb = b + 1 < Wo, va = a + 1 < Ho;
+    const float* d = dy + (long)plane * Ho * Wo + (long)a * Wo + b;
+    const float d00 = d[0], d01 = vb ? d[1] : 0.f, d10 = va ? d[Wo] : 0.f, d11 = (va && vb) ? d[Wo + 1] : 0.f;
+    const float* k = w + (long)c * 9;
+    const int W = 2 * Wo;
+    float* o = dx + ((long)plane * 2 * Ho + 2 * a) * W + 2 * b;
+    *reinterpret_cast<float2*>(o) = make_float2(d00 * k[4], fmaf(d00, k[5], d01 * k[3]));
+    *reinterpret_cast<float2*>(o + W) = make_float2(fmaf(d00, k[7], d10 * k[1]), fmaf(d00, k[8], fmaf(d01, k[6], fmaf(d10, k[2], d11 * k[0]))));
+}
+
+template <int KS, int S, bool FLIP>
+static void launch_tdw_conv(const float* x, const float* w, float* y, int N, int C, int H, int W, int Ho, int Wo, hipStream_t s)
+{
+    const int threads = Ho * (Wo / 4), bs = threads <= 64 ? 64 : 256;
+    hipLaunchKernelGGL((tdw_conv_kernel<KS, S, FLIP>), dim3((threads + bs - 1) / bs, N * C), dim3(bs), 0, s, x, w, y, C, H, W, Ho, Wo);
+}
+
 // ---- Conv2d backward with respect to the input ----
 __global__ void __launch_bounds__(256) tconv_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
                                                              int N, int Cin, int H, int W, int Cout, int Ho, int Wo, int k, int stride, int depthwise)
@@ -759,6 +818,11 @@ void launch_tconv_fwd(const float* x, const float* w, const float* bias, float* 
                                (long)Cin * k * k, (long)k * k);
         return;
     }
+    if (depthwise && !bias && Wo % 4 == 0 && (long)N * Cout <= 65535) {
+        if (k == 3 && stride == 1) return launch_tdw_conv<3, 1, false>(x, w, y, N, Cout, H, W, Ho, Wo, s);
+        if (k == 3 && stride == 2) return launch_tdw_conv<3, 2, false>(x, w, y, N, Cout, H, W, Ho, Wo, s);
+        if (k == 5 && stride == 1) return launch_tdw_conv<5, 1, false>(x, w, y, N, Cout, H, W, Ho, Wo, s);
+    }
     hipLaunchKernelGGL(tconv_fwd_kernel, dim3(nblk((long)N * Cout * Ho * Wo)), dim3(256), 0, s, x, w, bias, y, N, Cin, H, W, Cout, Ho, Wo, k, stride, depthwise);
 }
 void launch_tconv_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int k, int stride, int depthwise,
@@ -772,6 +836,15 @@ void launch_tconv_bwd_data(const float* dy, const float* w, float* dx, int N, in
     if (!depthwise && k == 3 && stride == 2 && H == 2 * Ho && W == 2 * Wo) {
         hipLaunchKernelGGL(tconv3s2_bwd_data_kernel<8>, dim3(nblk((long)N * Ho * Wo), (Cin + 7) / 8), dim3(256), 0, s, dy, w, dx, N, Cin, Cout, Ho, Wo);
         return;
+    }
+    if (depthwise && (long)N * Cin <= 65535) {
+        if (stride == 1 && W % 4 == 0 && k == 3) return launch_tdw_conv<3, 1, true>(dy, w, dx, N, Cin, H, W, H, W, s);
+        if (stride == 1 && W % 4 == 0 && k == 5) return launch_tdw_conv<5, 1, true>(dy, w, dx, N, Cin, H, W, H, W, s);
+        if (stride == 2 && k == 3 && H == 2 * Ho && W == 2 * Wo) {
+            const int threads = Ho * Wo, bs = threads <= 64 ? 64 : 256;
+            hipLaunchKernelGGL(tdw3s2_bwd_data_kernel, dim3((threads + bs - 1) / bs, N * Cin), dim3(bs), 0, s, dy, w, dx, Cin, Ho, Wo);
+            return;
+        }
     }
     hipLaunchKernelGGL(tconv_bwd_data_kernel, dim3(nblk((long)N * Cin * H * W)), dim3(256), 0, s, dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, k, stride, depthwise);
 }

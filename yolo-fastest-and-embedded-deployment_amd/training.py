@@ -44,7 +44,9 @@ class _Ops:
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
     def call(self, name, *args):
-        _lib.check(getattr(self.lib, name)(self.dev, *args, self.stream))
+        rc = getattr(self.lib, name)(self.dev, *args, self.stream)
+        if rc:
+            _lib.check(rc)
 
 
 _SCRATCH = {}
@@ -76,53 +78,40 @@ def _conv_geom(conv, x):
 
 
 def _unit_forward(ops, mod, x, tape, name):
-    """conv_norm[_relu] / deconv_norm_relu (yolo_fastest.py:16-48) in train mode."""
+    """conv_norm[_relu] / deconv_norm_relu (yolo_fastest.py:16-48) in train mode: one C call (yf_train_unit_forward)."""
     conv, bn = mod[0], mod[1]
     relu = 1 if len(mod) == 3 else 0
+    N, Cin, H, W = x.shape
+    Cout = conv.out_channels
     if isinstance(conv, torch.nn.ConvTranspose2d):
-        N, Cin, H, W = x.shape
-        Cout = conv.out_channels
-        z = ops.new(N, Cout, 2 * H, 2 * W)
-        ops.call("yf_train_deconv_forward", x.data_ptr(), conv.weight.data_ptr(), z.data_ptr(), N, Cin, H, W, Cout)
+        deconv, k, stride, dw, Ho, Wo = 1, 2, 2, 0, 2 * H, 2 * W
     else:
-        N, Cin, H, W, Cout, k, stride, dw, Ho, Wo = _conv_geom(conv, x)
-        z = ops.new(N, Cout, Ho, Wo)
-        ops.call("yf_train_conv_forward", x.data_ptr(), conv.weight.data_ptr(), None, z.data_ptr(), N, Cin, H, W, Cout, k, stride, dw)
-    y = torch.empty_like(z)
+        deconv = 0
+        _, _, _, _, _, k, stride, dw, Ho, Wo = _conv_geom(conv, x)
+    zy = ops.new(2, N, Cout, Ho, Wo)
+    z, y = zy[0], zy[1]
     stats = ops.new(2 * Cout)
-    HW = z.shape[2] * z.shape[3]
-    ops.call("yf_train_bn_forward", z.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), _ptr(bn.running_mean), _ptr(bn.running_var),
-             stats.data_ptr(), y.data_ptr(), N, Cout, HW, relu, ops.bn_scratch)
+    ops.call("yf_train_unit_forward", deconv, x.data_ptr(), conv.weight.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), _ptr(bn.running_mean),
+             _ptr(bn.running_var), stats.data_ptr(), z.data_ptr(), y.data_ptr(), N, Cin, H, W, Cout, k, stride, dw, relu, ops.scratch)
     if bn.num_batches_tracked is not None:
         tape.setdefault("_nbt", []).append(bn.num_batches_tracked)
-    tape[name] = (x, z, y, stats, relu)
+    tape[name] = (x, z, y, stats, relu, (deconv, k, stride, dw))
     return y
 
 
 def _unit_backward(ops, mod, tape, name, gy, grads, need_dx=True):
     conv, bn = mod[0], mod[1]
-    x, z, y, stats, relu = tape[name]
-    N, Cout = z.shape[0], z.shape[1]
-    HW = z.shape[2] * z.shape[3]
+    x, z, y, stats, relu, (deconv, k, stride, dw) = tape[name]
+    N, Cin, H, W = x.shape
+    Cout = z.shape[1]
     gz = torch.empty_like(z)
-    dgamma, dbeta = ops.new(Cout), ops.new(Cout)
-    ops.call("yf_train_bn_backward", z.data_ptr(), y.data_ptr(), gy.data_ptr(), stats.data_ptr(), bn.weight.data_ptr(), dgamma.data_ptr(),
-             dbeta.data_ptr(), gz.data_ptr(), N, Cout, HW, relu, ops.bn_scratch)
-    grads[bn.weight], grads[bn.bias] = dgamma, dbeta
+    dgb = ops.new(2, Cout)
     dw_ = torch.empty_like(conv.weight)
     gx = torch.empty_like(x) if need_dx else None
-    if isinstance(conv, torch.nn.ConvTranspose2d):
-        _, Cin, H, W = x.shape
-        ops.call("yf_train_deconv_backward_weight", x.data_ptr(), gz.data_ptr(), dw_.data_ptr(), N, Cin, H, W, Cout)
-        if need_dx:
-            ops.call("yf_train_deconv_backward_data", gz.data_ptr(), conv.weight.data_ptr(), gx.data_ptr(), N, Cin, H, W, Cout)
-    else:
-        _, Cin, H, W, _, k, stride, dw, _, _ = _conv_geom(conv, x)
-        ops.call("yf_train_conv_backward_weight", x.data_ptr(), gz.data_ptr(), dw_.data_ptr(), N, Cin, H, W, Cout, k, stride, dw, ops.scratch,
-                 ops.scratch_bytes)
-        if need_dx:
-            ops.call("yf_train_conv_backward_data", gz.data_ptr(), conv.weight.data_ptr(), gx.data_ptr(), N, Cin, H, W, Cout, k, stride, dw)
-    grads[conv.weight] = dw_
+    ops.call("yf_train_unit_backward", deconv, x.data_ptr(), z.data_ptr(), y.data_ptr(), gy.data_ptr(), stats.data_ptr(), conv.weight.data_ptr(),
+             bn.weight.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), gz.data_ptr(), dw_.data_ptr(), _ptr(gx), N, Cin, H, W, Cout, k, stride, dw,
+             relu, ops.scratch, ops.scratch_bytes)
+    grads[bn.weight], grads[bn.bias], grads[conv.weight] = dgb[0], dgb[1], dw_
     return gx
 
 
