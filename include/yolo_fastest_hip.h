@@ -142,8 +142,8 @@ int yf_train_loss(yf_handle h, const float *d_head, int N, int fh, int fw, const
 
 /* Operators of the reference's TRAINING step (second slice): every layer type of YoloFastest in train mode, forward
  * and backward, on NCHW float32 device tensors like the reference's (src/model_training/model/yolo_fastest.py:16-66, train.py:98-160).
- * Correctness-first kernels (one thread per output element, block reductions + atomics) -- not the tuned inference engine, which folds
- * BatchNorm and therefore cannot train.  `device` = HIP device index; everything is stream-ordered.
+ * Per-layer kernels (MFMA GEMMs for the pointwise / dense convs, split reductions added in a fixed order: DESIGN.md section 4) -- not the
+ * tuned inference engine, which folds BatchNorm and therefore cannot train.  `device` = HIP device index; everything is stream-ordered.
  *   conv: Conv2d(k in {1,3,5}, stride in {1,2}, pad (k-1)/2, groups 1 or C [depthwise = 1]); d_w [Cout, Cin/groups, k, k]; d_bias or NULL.
  *   deconv: ConvTranspose2d(k 2, stride 2, pad 0); d_w [Cin, Cout, 2, 2]; output 2H x 2W.
  *   bn: BatchNorm2d in train mode (eps 1e-5, momentum 0.1): d_stats float[2C] receives (mean, invstd) per channel for the backward;

@@ -7,9 +7,12 @@
 //   BasicResBlock              :52-66   three units + residual add
 //   heads                      :136,146 Conv2d 1x1 with bias
 //
-// CORRECTNESS-FIRST kernels: one thread per output element with coalesced innermost-x access, reductions by block + atomics.
-// They are NOT the tuned inference kernels (those fold BN, which training cannot: batch statistics) and are priced as such in
-// DESIGN.md.  Everything is stream-ordered; no allocation, no synchronisation.
+// Pointwise / dense convs are GEMMs on the fp32 matrix pipe read straight from global memory; depthwise convs keep their weights
+// wave-uniform; every reduction that spans workgroups (BatchNorm sums, weight gradients) stores partials into a scratch and a second
+// pass adds them in a fixed order -- no float atomics, no in-kernel fences (both measured slow on this multi-XCD part; DESIGN.md
+// section 4).  The generic one-thread-per-output kernels remain as the fallback for shapes the fast paths do not take (odd widths).
+// They are NOT the tuned inference kernels (those fold BN, which training cannot: batch statistics).  Everything is stream-ordered;
+// no allocation, no synchronisation.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>

@@ -5,14 +5,14 @@
     pred = model(imgs)                                   # train-mode forward: BatchNorm on batch statistics, running stats updated
     loss = sum(model_loss[i](pred[i], targets)[0] ...)   # validation.YOLOLossV3 (yf_train_loss)
     loss.backward()                                      # backward of every layer -> param.grad
-    optimizer.step()                                     # training.Adam (yf_train_adam_step) -- or any torch optimizer
+    optimizer.step()                                     # training.Adam (yf_train_adam_multi) -- or any torch optimizer
 
 `YoloFastest.forward` routes here when the module is in train mode.  Every operator is a HIP kernel behind the C ABI
 (`yf_train_*`, csrc/yf_train_kernels.hip): Conv2d / ConvTranspose2d forward, backward-data, backward-weight; BatchNorm2d in train
 mode with its backward (ReLU fused); channel slices for the torch.cat; Adam.  torch.autograd only carries the gradient across the
 boundary (one Function for the whole network whose inputs are the parameters) -- no torch operator computes anything.
-Correctness-first kernels: NCHW fp32 like the reference, one launch per layer, not the tuned inference engine (which folds
-BatchNorm into the weights and so cannot train).  No CPU path.
+NCHW fp32 like the reference, one C call per block (conv + BN [+ ReLU]) each way -- not the tuned inference engine (which folds
+BatchNorm into the weights and so cannot train); kernels and measurements: DESIGN.md section 4 "The training step".  No CPU path.
 """
 import ctypes
 
@@ -250,7 +250,7 @@ def forward(model, x):
 
 
 class Adam(torch.optim.Optimizer):
-    """`optim.Adam(model.parameters(), lr=lr0, betas=(0.9, 0.999), eps=1e-08)` (train.py:84) with the update done by yf_train_adam_step.
+    """`optim.Adam(model.parameters(), lr=lr0, betas=(0.9, 0.999), eps=1e-08)` (train.py:84) with the update done by yf_train_adam_multi (one launch for all tensors).
     A torch.optim.Optimizer, so `param_groups[..]['lr']` edits (train.py:106-109) and `lr_scheduler.LambdaLR` (:89) work unchanged; the
     state uses torch's names (step, exp_avg, exp_avg_sq)."""
 
