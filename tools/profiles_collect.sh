@@ -14,7 +14,7 @@ for t in train train256; do
   f=$(ls gpurun_out/prof_$t/*_kernel_stats.csv)
   case $t in train) n=${TAG}_train_step_batch16;; *) n=${TAG}_train_step_batch256;; esac
   cp $f profiles/${n}_kernel_stats.csv
-  grep "^GPU" gpurun_out/prof_$t.log > profiles/${n}_bench_line.txt || true
+  { echo "# tools/train_bench.py UNDER rocprofv3 --kernel-trace (tracing adds host time per launch; unprofiled numbers: DESIGN.md section 4)"; grep "^GPU" gpurun_out/prof_$t.log; } > profiles/${n}_bench_line.txt || true
 done
 python - <<PY
 import csv
