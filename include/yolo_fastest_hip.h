@@ -162,7 +162,8 @@ int yf_train_conv_backward_weight(int device, const float *d_x, const float *d_d
                                   int stride, int depthwise, void *d_scratch, size_t scratch_bytes, void *stream);
 int yf_train_deconv_forward(int device, const float *d_x, const float *d_w, float *d_y, int N, int Cin, int H, int W, int Cout, void *stream);
 int yf_train_deconv_backward_data(int device, const float *d_dy, const float *d_w, float *d_dx, int N, int Cin, int H, int W, int Cout, void *stream);
-int yf_train_deconv_backward_weight(int device, const float *d_x, const float *d_dy, float *d_dw, int N, int Cin, int H, int W, int Cout, void *stream);
+int yf_train_deconv_backward_weight(int device, const float *d_x, const float *d_dy, float *d_dw, int N, int Cin, int H, int W, int Cout,
+                                    void *d_scratch, size_t scratch_bytes, void *stream);
 int yf_train_scratch_bytes(size_t *bytes);
 int yf_train_bn_forward(int device, const float *d_x, const float *d_gamma, const float *d_beta, float *d_running_mean, float *d_running_var,
                         float *d_stats, float *d_y, int N, int C, long HW, int relu, void *d_scratch, void *stream);

@@ -120,7 +120,7 @@ def test_conv_backward_weight_long_reduction(ops, dev):
 
 def test_deconv_forward_backward_match_torch(ops, dev):
     rng = np.random.default_rng(9)
-    for N, Cin, Cout, H, W in ((2, 96, 96, 4, 5), (3, 5, 7, 3, 3)):
+    for N, Cin, Cout, H, W in ((2, 96, 96, 4, 5), (3, 5, 7, 3, 3), (16, 96, 96, 8, 10), (5, 20, 70, 6, 6)):
         x = rng.normal(size=(N, Cin, H, W)).astype(np.float32)
         w = rng.normal(size=(Cin, Cout, 2, 2)).astype(np.float32)
         xt = torch.from_numpy(x).double().requires_grad_(True)
@@ -136,7 +136,7 @@ def test_deconv_forward_backward_match_torch(ops, dev):
         ops.call("yf_train_deconv_backward_data", gyd.data_ptr(), wd.data_ptr(), gx.data_ptr(), N, Cin, H, W, Cout)
         _close(gx, xt.grad, 2e-6, "backward data")
         gw = torch.full_like(wd, float("nan"))
-        ops.call("yf_train_deconv_backward_weight", xd.data_ptr(), gyd.data_ptr(), gw.data_ptr(), N, Cin, H, W, Cout)
+        ops.call("yf_train_deconv_backward_weight", xd.data_ptr(), gyd.data_ptr(), gw.data_ptr(), N, Cin, H, W, Cout, ops.scratch, ops.scratch_bytes)
         _close(gw, wt.grad, 5e-6, "backward weight")
 
 

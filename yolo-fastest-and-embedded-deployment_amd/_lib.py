@@ -48,7 +48,8 @@ _SIGS = {
                                       [_c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "yf_train_deconv_forward": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 5 + [_c.c_void_p]),
     "yf_train_deconv_backward_data": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 5 + [_c.c_void_p]),
-    "yf_train_deconv_backward_weight": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 5 + [_c.c_void_p]),
+    "yf_train_deconv_backward_weight": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 5 +
+                                        [_c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "yf_train_unit_forward": (_c.c_int, [_c.c_int, _c.c_int] + [_c.c_void_p] * 9 + [_c.c_int] * 9 + [_c.c_void_p, _c.c_void_p]),
     "yf_train_unit_backward": (_c.c_int, [_c.c_int, _c.c_int] + [_c.c_void_p] * 12 + [_c.c_int] * 9 + [_c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "yf_train_scratch_bytes": (_c.c_int, [_c.POINTER(_c.c_size_t)]),

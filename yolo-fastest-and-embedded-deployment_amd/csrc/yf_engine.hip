@@ -934,9 +934,11 @@ int yf_train_deconv_backward_data(int device, const float* d_dy, const float* d_
 {
     YF_TOP(d_dy && d_w && d_dx && N > 0, yf::launch_tdeconv_bwd_data(d_dy, d_w, d_dx, N, Cin, H, W, Cout, (hipStream_t)stream));
 }
-int yf_train_deconv_backward_weight(int device, const float* d_x, const float* d_dy, float* d_dw, int N, int Cin, int H, int W, int Cout, void* stream)
+int yf_train_deconv_backward_weight(int device, const float* d_x, const float* d_dy, float* d_dw, int N, int Cin, int H, int W, int Cout,
+                                    void* d_scratch, size_t scratch_bytes, void* stream)
 {
-    YF_TOP(d_x && d_dy && d_dw && N > 0, yf::launch_tdeconv_bwd_weight(d_x, d_dy, d_dw, N, Cin, H, W, Cout, (hipStream_t)stream));
+    YF_TOP(d_x && d_dy && d_dw && N > 0,
+           yf::launch_tdeconv_bwd_weight(d_x, d_dy, d_dw, N, Cin, H, W, Cout, d_scratch, scratch_bytes, (hipStream_t)stream));
 }
 int yf_train_scratch_bytes(size_t* bytes)
 {
@@ -1019,7 +1021,7 @@ int yf_train_unit_backward(int device, int deconv, const float* d_x, const float
     }
     yf::launch_tbn_bwd(d_z, d_y, d_gy, d_stats, d_gamma, d_dgamma, d_dbeta, d_gz, N, Cout, HWo, relu, d_scratch, s);
     if (deconv) {
-        yf::launch_tdeconv_bwd_weight(d_x, d_gz, d_dw, N, Cin, H, W, Cout, s);
+        yf::launch_tdeconv_bwd_weight(d_x, d_gz, d_dw, N, Cin, H, W, Cout, d_scratch, scratch_bytes, s);
         if (d_dx) yf::launch_tdeconv_bwd_data(d_gz, d_w, d_dx, N, Cin, H, W, Cout, s);
     } else {
         yf::launch_tconv_bwd_weight(d_x, d_gz, d_dw, N, Cin, H, W, Cout, k, stride, depthwise, d_scratch, scratch_bytes, s);

@@ -237,7 +237,8 @@ void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, 
                              void* scratch, size_t scratch_bytes, hipStream_t s);
 void launch_tdeconv_fwd(const float* x, const float* w, float* y, int N, int Cin, int H, int W, int Cout, hipStream_t s);
 void launch_tdeconv_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, hipStream_t s);
-void launch_tdeconv_bwd_weight(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, hipStream_t s);
+void launch_tdeconv_bwd_weight(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, void* scratch, size_t scratch_bytes,
+                               hipStream_t s);
 size_t train_scratch_bytes();
 void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* stats, float* y, int N,
                     int C, long HW, int relu, void* scratch, hipStream_t s);

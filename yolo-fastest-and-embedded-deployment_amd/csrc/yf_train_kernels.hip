@@ -201,7 +201,9 @@ __global__ void __launch_bounds__(256) tconv_im2col_mfma_kernel(const float* __r
 // dense conv weight gradient on the matrix pipe: dW[co][r] = sum_q dY[co][q] Xcol[r][q], r = (ci, ky, kx), split over q.  One wave =
 // 16 co x 64 r and a slice of q; per step (16 output pixels) every lane loads float4 (4 consecutive pixels) of one dY row and the
 // four matching elements of four Xcol rows: MFMA e of the step takes element e, i.e. k-index l / 16 stands for pixel 4 (l / 16) + e
-// in both operands.  Needs Wo % 4 == 0 (the 4 pixels share a row).  KS == 1: the Xcol elements are one float4 as well.
+// in both operands.  Needs Ho Wo % 4 == 0 (the 4 pixels lie in one frame).  KS == 1: the Xcol elements are one float4 as well.
+// KS == 2 (pad 0, stride 2) with the operands swapped is the ConvTranspose2d(2, 2) weight gradient: dW[ci][(co, a, b)] = sum_p
+// X[ci][p] dY[co][2 iy + a][2 ix + b].
 // Slice s writes its tile into dw + s * part_stride (a slab of the scratch; tsum_partials_kernel adds the slabs in order): device-scope
 // float atomics on this multi-XCD part are executed memory-side and serialise per address -- 100 slices on one tile cost more than the GEMM.
 template <int KS>
@@ -243,17 +245,17 @@ __global__ void __launch_bounds__(64) tconv_wgrad_mfma_kernel(const float* __res
 #pragma unroll
             for (int t = 0; t < 4; ++t) bv[t] = *reinterpret_cast<const float4*>(x + (n * Cin + rci[t]) * HWo + i);
         } else {
-            const int oy = (int)(i / Wo), ox = (int)(i - (long)oy * Wo);
+            int oyj[4], oxj[4];                                     // the 4 pixels may straddle rows (Wo % 4 != 0)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { oyj[j] = (int)((i + j) / Wo); oxj[j] = (int)(i + j - (long)oyj[j] * Wo); }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int iy = oy * stride - PAD + rky[t];
-                const float* xr = x + ((n * Cin + rci[t]) * H + iy) * W;
-                const bool yv = iy >= 0 && iy < H;
+                const float* xc = x + (n * Cin + rci[t]) * H * W;
                 float e[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int ix = (ox + j) * stride - PAD + rkx[t];
-                    e[j] = (yv && ix >= 0 && ix < W) ? xr[ix] : 0.f;
+                    const int iy = oyj[j] * stride - PAD + rky[t], ix = oxj[j] * stride - PAD + rkx[t];
+                    e[j] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xc[(long)iy * W + ix] : 0.f;
                 }
                 bv[t] = make_float4(e[0], e[1], e[2], e[3]);
             }
@@ -602,12 +604,17 @@ __global__ void __launch_bounds__(256) tdeconv_bwd_weight_kernel(const float* __
 
 // ---- BatchNorm2d, training mode (torch.nn.BatchNorm2d: eps 1e-5, momentum 0.1; running_var takes the UNBIASED batch variance) ----
 // Two launches each way, no cross-workgroup synchronisation inside a kernel (a device-scope fence costs an L2 write-back per XCD):
-//   1. partial sums over N*H*W per channel in double: grid (nchunk <= 64, C), every workgroup sums units of 256 contiguous elements
-//      and stores its pair into scratch[c][chunk];
-//   2. the elementwise kernel, grid (HW / 256, C, N): each workgroup first adds its channel's partial pairs (one per lane, fixed
-//      shuffle tree: deterministic), then transforms its 256 elements; the first workgroup of a channel also writes the per-channel
-//      results (stats + running statistics, or dgamma / dbeta).
-#define TBN_MAXCHUNK 64
+//   1. partial sums over N*H*W per channel in double: grid (nchunk <= 256, C), every workgroup sums units of 256 V contiguous
+//      elements (V = 4: one float4 per thread, when H*W % 4 == 0) and stores its pair into scratch[c][chunk];
+//   2. the elementwise kernel, grid (blocks, C): each workgroup first adds its channel's partial pairs (lane l takes chunks l, l + 64,
+//      ..., then a fixed shuffle tree: deterministic), then transforms its units; the first workgroup of a channel also writes the
+//      per-channel results (stats + running statistics, or dgamma / dbeta).
+#define TBN_MAXCHUNK 256
+template <int V> struct tbn_vec;
+template <> struct tbn_vec<1> { typedef float type; };
+template <> struct tbn_vec<4> { typedef float4 type; };
+template <int V> __device__ __forceinline__ float tbn_at(const typename tbn_vec<V>::type& v, int j) { return ((const float*)&v)[j]; }
+
 __device__ __forceinline__ void tbn_block_store(double s, double t, double* __restrict__ part)
 {
     __shared__ double r1[4], r2[4];
@@ -625,7 +632,7 @@ __device__ __forceinline__ void tbn_block_total(const double* __restrict__ part,
     __shared__ double tot[2];
     if (threadIdx.x < 64) {
         double a = 0, b = 0;
-        if ((int)threadIdx.x < nchunk) { a = part[2 * threadIdx.x]; b = part[2 * threadIdx.x + 1]; }
+        for (int i = threadIdx.x; i < nchunk; i += 64) { a += part[2 * i]; b += part[2 * i + 1]; }
         for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
         if (threadIdx.x == 0) { tot[0] = a; tot[1] = b; }
     }
@@ -633,24 +640,32 @@ __device__ __forceinline__ void tbn_block_total(const double* __restrict__ part,
     s = tot[0]; t = tot[1];
 }
 
+template <int V>
 __global__ void __launch_bounds__(256) tbn_stats_kernel(const float* __restrict__ x, int N, int C, long HW, double* __restrict__ scratch)
 {
+    typedef typename tbn_vec<V>::type vec;
     const int c = blockIdx.y, nchunk = gridDim.x;
-    const long upn = (HW + 255) / 256, U = (long)N * upn;
+    const long upn = (HW + 256 * V - 1) / (256 * V), U = (long)N * upn;
     double s = 0, ss = 0;
     for (long u = blockIdx.x; u < U; u += nchunk) {
-        const long n = u / upn, i = (u - n * upn) * 256 + threadIdx.x;
-        if (i < HW) { const double v = x[(n * C + c) * HW + i]; s += v; ss += v * v; }
+        const long n = u / upn, i = ((u - n * upn) * 256 + threadIdx.x) * V;
+        if (i < HW) {
+            const vec v = *reinterpret_cast<const vec*>(x + (n * C + c) * HW + i);
+#pragma unroll
+            for (int j = 0; j < V; ++j) { const double e = tbn_at<V>(v, j); s += e; ss += e * e; }
+        }
     }
     tbn_block_store(s, ss, scratch + (long)c * TBN_MAXCHUNK * 2);
 }
 
 // stats[c] = {mean, invstd}
+template <int V>
 __global__ void __launch_bounds__(256) tbn_apply_kernel(const float* __restrict__ x, const double* __restrict__ scratch, int nchunk,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
                                                         int N, int C, long HW, int relu, float eps, float momentum, float* __restrict__ stats,
                                                         float* __restrict__ running_mean, float* __restrict__ running_var)
 {
+    typedef typename tbn_vec<V>::type vec;
     const int c = blockIdx.y;
     double s, ss;
     tbn_block_total(scratch + (long)c * TBN_MAXCHUNK * 2, nchunk, s, ss);
@@ -667,58 +682,82 @@ __global__ void __launch_bounds__(256) tbn_apply_kernel(const float* __restrict_
         }
     }
     const float g = gamma[c], b = beta[c];
-    const long upn = (HW + 255) / 256, U = (long)N * upn;
+    const long upn = (HW + 256 * V - 1) / (256 * V), U = (long)N * upn;
     for (long u = blockIdx.x; u < U; u += gridDim.x) {
-        const long n = u / upn, i = (u - n * upn) * 256 + threadIdx.x;
+        const long n = u / upn, i = ((u - n * upn) * 256 + threadIdx.x) * V;
         if (i >= HW) continue;
         const long idx = (n * C + c) * HW + i;
-        const float v = (x[idx] - fm) * fi * g + b;
-        y[idx] = relu ? fmaxf(v, 0.f) : v;
+        const vec xv = *reinterpret_cast<const vec*>(x + idx);
+        vec o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float v = (tbn_at<V>(xv, j) - fm) * fi * g + b;
+            ((float*)&o)[j] = relu ? fmaxf(v, 0.f) : v;
+        }
+        *reinterpret_cast<vec*>(y + idx) = o;
     }
 }
 
 // backward: dy_eff = dy * (y > 0) with ReLU; {sum dy_eff, sum dy_eff * xhat} = (dbeta, dgamma)
+template <int V>
 __global__ void __launch_bounds__(256) tbn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
                                                              const float* __restrict__ stats, int N, int C, long HW, int relu,
                                                              double* __restrict__ scratch)
 {
+    typedef typename tbn_vec<V>::type vec;
     const int c = blockIdx.y, nchunk = gridDim.x;
-    const long upn = (HW + 255) / 256, U = (long)N * upn;
+    const long upn = (HW + 256 * V - 1) / (256 * V), U = (long)N * upn;
     const float mean = stats[2 * c], invstd = stats[2 * c + 1];
     double s = 0, sx = 0;
     for (long u = blockIdx.x; u < U; u += nchunk) {
-        const long n = u / upn, i = (u - n * upn) * 256 + threadIdx.x;
+        const long n = u / upn, i = ((u - n * upn) * 256 + threadIdx.x) * V;
         if (i < HW) {
             const long idx = (n * C + c) * HW + i;
-            float g = dy[idx];
-            if (relu && !(y[idx] > 0.f)) g = 0.f;
-            s += g; sx += (double)g * (double)((x[idx] - mean) * invstd);
+            const vec gv = *reinterpret_cast<const vec*>(dy + idx), xv = *reinterpret_cast<const vec*>(x + idx);
+            vec yv = gv;
+            if (relu) yv = *reinterpret_cast<const vec*>(y + idx);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float g = tbn_at<V>(gv, j);
+                if (relu && !(tbn_at<V>(yv, j) > 0.f)) g = 0.f;
+                s += g; sx += (double)g * (double)((tbn_at<V>(xv, j) - mean) * invstd);
+            }
         }
     }
     tbn_block_store(s, sx, scratch + (long)c * TBN_MAXCHUNK * 2);
 }
 
 // dx = gamma * invstd * (dy_eff - (dbeta + xhat * dgamma) / P)
+template <int V>
 __global__ void __launch_bounds__(256) tbn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
                                                             const double* __restrict__ scratch, int nchunk, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, float* __restrict__ dx, int N, int C, long HW, int relu)
 {
+    typedef typename tbn_vec<V>::type vec;
     const int c = blockIdx.y;
     double s, sx;
     tbn_block_total(scratch + (long)c * TBN_MAXCHUNK * 2, nchunk, s, sx);
     const float db = (float)s, dg = (float)sx;
     if (blockIdx.x == 0 && threadIdx.x == 0) { dbeta[c] = db; dgamma[c] = dg; }
     const float fm = stats[2 * c], fi = stats[2 * c + 1], gi = gamma[c] * fi, invP = 1.f / (float)((long)N * HW);
-    const long upn = (HW + 255) / 256, U = (long)N * upn;
+    const long upn = (HW + 256 * V - 1) / (256 * V), U = (long)N * upn;
     for (long u = blockIdx.x; u < U; u += gridDim.x) {
-        const long n = u / upn, i = (u - n * upn) * 256 + threadIdx.x;
+        const long n = u / upn, i = ((u - n * upn) * 256 + threadIdx.x) * V;
         if (i >= HW) continue;
         const long idx = (n * C + c) * HW + i;
-        float g = dy[idx];
-        if (relu && !(y[idx] > 0.f)) g = 0.f;
-        const float xhat = (x[idx] - fm) * fi;
-        dx[idx] = gi * (g - (db + xhat * dg) * invP);
+        const vec gv = *reinterpret_cast<const vec*>(dy + idx), xv = *reinterpret_cast<const vec*>(x + idx);
+        vec yv = gv;
+        if (relu) yv = *reinterpret_cast<const vec*>(y + idx);
+        vec o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float g = tbn_at<V>(gv, j);
+            if (relu && !(tbn_at<V>(yv, j) > 0.f)) g = 0.f;
+            const float xhat = (tbn_at<V>(xv, j) - fm) * fi;
+            ((float*)&o)[j] = gi * (g - (db + xhat * dg) * invP);
+        }
+        *reinterpret_cast<vec*>(dx + idx) = o;
     }
 }
 
@@ -864,8 +903,8 @@ void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, 
     const int pad = (k - 1) / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     const long nw = (long)Cout * (depthwise ? 1 : Cin) * k * k, P = (long)N * Ho * Wo;
     const long fit = scratch ? (long)(scratch_bytes / ((size_t)nw * sizeof(float))) : 0;      // slabs that fit
-    // 4 consecutive output pixels per lane: in one row for k = 3 (Wo % 4), merely in one frame for a pointwise conv (Ho Wo % 4)
-    if (!depthwise && ((k == 3 && Wo % 4 == 0) || (k == 1 && stride == 1 && ((long)Ho * Wo) % 4 == 0))) {
+    // 4 consecutive output pixels per lane, in one frame
+    if (!depthwise && (k == 3 || (k == 1 && stride == 1)) && ((long)Ho * Wo) % 4 == 0) {
         const int R = Cin * k * k, tiles = ((Cout + 15) / 16) * ((R + 63) / 64);
         long nsplit = (P + 127) / 128;                                  // >= 8 MFMA steps per wave ...
         while (nsplit * tiles > 8192 && nsplit > 1) nsplit = (nsplit + 1) / 2;   // ... and a bounded grid
@@ -919,11 +958,31 @@ void launch_tdeconv_fwd(const float* x, const float* w, float* y, int N, int Cin
 }
 void launch_tdeconv_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, hipStream_t s)
 {
-    hipLaunchKernelGGL(tdeconv_bwd_data_kernel, dim3(nblk((long)N * Cin * H * W)), dim3(256), 0, s, dy, w, dx, N, Cin, H, W, Cout);
+    // dx[ci][p] = sum over (co, a, b) of dY[co][2 iy + a][2 ix + b] w[ci][co][a][b]: a 2x2 stride-2 pad-0 convolution of dY with the weight
+    // read as [Cin][(co, a, b)] -- the im2col GEMM
+    hipLaunchKernelGGL(tconv_im2col_mfma_kernel<2>, dim3((unsigned)(((long)N * H * W + 63) / 64), (Cin + 63) / 64), dim3(256), 0, s, dy, w,
+                       (const float*)nullptr, dx, N, Cout, 2 * H, 2 * W, H, W, Cin, 2);
 }
-void launch_tdeconv_bwd_weight(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, hipStream_t s)
+void launch_tdeconv_bwd_weight(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, void* scratch, size_t scratch_bytes,
+                               hipStream_t s)
 {
     const long nw = (long)Cin * Cout * 4, P = (long)N * H * W;
+    if (((long)H * W) % 4 == 0) {                 // the conv weight-gradient GEMM with the operands swapped (see tconv_wgrad_mfma_kernel)
+        const long fit = scratch ? (long)(scratch_bytes / ((size_t)nw * sizeof(float))) : 0;
+        const int R = Cout * 4, tiles = ((Cin + 15) / 16) * ((R + 63) / 64);
+        long nsplit = (P + 127) / 128;
+        while (nsplit * tiles > 8192 && nsplit > 1) nsplit = (nsplit + 1) / 2;
+        if (nsplit > 1024) nsplit = 1024;
+        if (nsplit > fit) nsplit = fit < 1 ? 1 : fit;
+        long q_per = (P + nsplit - 1) / nsplit;
+        q_per = (q_per + 15) / 16 * 16;
+        nsplit = (P + q_per - 1) / q_per;
+        float* out = nsplit > 1 ? (float*)scratch : dw;
+        hipLaunchKernelGGL(tconv_wgrad_mfma_kernel<2>, dim3((unsigned)nsplit, (Cin + 15) / 16, (R + 63) / 64), dim3(64), 0, s, dy, x, out, N, Cout, 2 * H,
+                           2 * W, Cin, H, W, 2, q_per, nw);
+        if (nsplit > 1) tsum_partials(out, nsplit, nw, dw, s);
+        return;
+    }
     int nchunk = (int)((P + 4095) / 4096);
     while ((long)nchunk * nw > 262144 && nchunk > 1) nchunk /= 2;
     (void)hipMemsetAsync(dw, 0, (size_t)nw * sizeof(float), s);
@@ -931,37 +990,51 @@ void launch_tdeconv_bwd_weight(const float* x, const float* dy, float* dw, int N
 }
 // one scratch for the split reductions of a stream: BatchNorm partial pairs (256 KB) or weight-gradient slabs (all of it)
 size_t train_scratch_bytes() { return (size_t)16 << 20; }
-static inline unsigned tbn_apply_blocks(int N, int C, long HW)
+static inline unsigned tbn_apply_blocks(int N, int C, long HW, int V)
 {
-    const long U = (long)N * ((HW + 255) / 256);
-    long n = 4096 / C;
+    const long U = (long)N * ((HW + 256 * V - 1) / (256 * V));
+    long n = 8192 / C;
     if (n > U) n = U;
     return n < 1 ? 1u : (unsigned)n;
 }
-static inline int tbn_chunks(int N, int C, long HW)
+static inline int tbn_chunks(int N, int C, long HW, int V)
 {
-    const long U = (long)N * ((HW + 255) / 256);
-    long n = 2048 / C;
+    const long U = (long)N * ((HW + 256 * V - 1) / (256 * V));
+    long n = 8192 / C;
     if (n > TBN_MAXCHUNK) n = TBN_MAXCHUNK;
     if (n > U) n = U;
     return n < 1 ? 1 : (int)n;
 }
-// scratch: >= 256 KB of device memory (partial sums; needs no initialisation); C <= 256
+// scratch: >= 1 MB of device memory (partial sums; needs no initialisation); C <= 256
 void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* stats, float* y, int N,
                     int C, long HW, int relu, void* scratch, hipStream_t s)
 {
-    const int nchunk = tbn_chunks(N, C, HW);
-    hipLaunchKernelGGL(tbn_stats_kernel, dim3(nchunk, C), dim3(256), 0, s, x, N, C, HW, (double*)scratch);
-    hipLaunchKernelGGL(tbn_apply_kernel, dim3(tbn_apply_blocks(N, C, HW), C), dim3(256), 0, s, x, (const double*)scratch, nchunk, gamma, beta, y, N,
-                       C, HW, relu, 1e-5f, 0.1f, stats, running_mean, running_var);
+    const int V = (HW % 4 == 0 && HW >= 1024) ? 4 : 1, nchunk = tbn_chunks(N, C, HW, V);
+    const dim3 g1(nchunk, C), g2(tbn_apply_blocks(N, C, HW, V), C);
+    if (V == 4) {
+        hipLaunchKernelGGL(tbn_stats_kernel<4>, g1, dim3(256), 0, s, x, N, C, HW, (double*)scratch);
+        hipLaunchKernelGGL(tbn_apply_kernel<4>, g2, dim3(256), 0, s, x, (const double*)scratch, nchunk, gamma, beta, y, N, C, HW, relu, 1e-5f, 0.1f,
+                           stats, running_mean, running_var);
+    } else {
+        hipLaunchKernelGGL(tbn_stats_kernel<1>, g1, dim3(256), 0, s, x, N, C, HW, (double*)scratch);
+        hipLaunchKernelGGL(tbn_apply_kernel<1>, g2, dim3(256), 0, s, x, (const double*)scratch, nchunk, gamma, beta, y, N, C, HW, relu, 1e-5f, 0.1f,
+                           stats, running_mean, running_var);
+    }
 }
 void launch_tbn_bwd(const float* x, const float* y, const float* dy, const float* stats, const float* gamma, float* dgamma, float* dbeta, float* dx,
                     int N, int C, long HW, int relu, void* scratch, hipStream_t s)
 {
-    const int nchunk = tbn_chunks(N, C, HW);
-    hipLaunchKernelGGL(tbn_bwd_reduce_kernel, dim3(nchunk, C), dim3(256), 0, s, x, y, dy, stats, N, C, HW, relu, (double*)scratch);
-    hipLaunchKernelGGL(tbn_bwd_apply_kernel, dim3(tbn_apply_blocks(N, C, HW), C), dim3(256), 0, s, x, y, dy, stats, gamma,
-                       (const double*)scratch, nchunk, dgamma, dbeta, dx, N, C, HW, relu);
+    const int V = (HW % 4 == 0 && HW >= 1024) ? 4 : 1, nchunk = tbn_chunks(N, C, HW, V);
+    const dim3 g1(nchunk, C), g2(tbn_apply_blocks(N, C, HW, V), C);
+    if (V == 4) {
+        hipLaunchKernelGGL(tbn_bwd_reduce_kernel<4>, g1, dim3(256), 0, s, x, y, dy, stats, N, C, HW, relu, (double*)scratch);
+        hipLaunchKernelGGL(tbn_bwd_apply_kernel<4>, g2, dim3(256), 0, s, x, y, dy, stats, gamma, (const double*)scratch, nchunk, dgamma, dbeta, dx, N,
+                           C, HW, relu);
+    } else {
+        hipLaunchKernelGGL(tbn_bwd_reduce_kernel<1>, g1, dim3(256), 0, s, x, y, dy, stats, N, C, HW, relu, (double*)scratch);
+        hipLaunchKernelGGL(tbn_bwd_apply_kernel<1>, g2, dim3(256), 0, s, x, y, dy, stats, gamma, (const double*)scratch, nchunk, dgamma, dbeta, dx, N,
+                           C, HW, relu);
+    }
 }
 void launch_tchan_sum(const float* dy, float* out, int N, int C, long HW, hipStream_t s)
 {
