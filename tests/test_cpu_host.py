@@ -145,6 +145,11 @@ def test_config_mirror():
     assert io["conf_thre"] == 0.5 and io["nms_thre"] == 0.2 and io["class_names"] == ["carrier", "defender", "destroyer"]
     io5 = yf.io_params_for(512)
     assert io5["input_shape"] == [512, 640, 1] and io5["anchors"][0] == [[150, 75], [100, 100], [75, 150]]
+    tp = yf.config_params["train_params"]                      # _config.py:38-50
+    assert (tp["total_epochs"], tp["batch_size"], tp["lr0"], tp["IOU_loss_thre"], tp["IOU_val_thre"]) == (30, 16, 0.001, 0.5, 0.5)
+    from yolo_fastest_amd import training                      # train.py:87-88
+    assert training.cosine_factor(0, 30) == 1.0 and abs(training.cosine_factor(30, 30) - 0.2) < 1e-12
+    assert abs(training.cosine_factor(15, 30) - 0.6) < 1e-12
 
 
 def test_ncnn_model_files_give_the_same_blob(sd):

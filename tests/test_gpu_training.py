@@ -455,3 +455,58 @@ def test_training_forward_guards(yf, dev):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
     with pytest.raises(RuntimeError):
         (hl.sum()).backward()                                        # the tape is freed by the first backward
+
+
+def test_train_loop_mirrors_train_py(yf, golden, dev, tmp_path):
+    """training.train(params, device, tbwriter, train_dataset, val_dataset) = the reference's train() (train.py:44-160): the warm-up /
+    cosine learning-rate sequence (checked against the formula of :87-88, :103-109 evaluated here), the log line of :143-147, one
+    checkpoint per epoch that a fresh model loads strictly (the reference's 508 keys), the mAP report after epoch 4, tensorboard
+    scalars -- on the 20 bundled frames with the synthetic targets of the mAP golden."""
+    import copy, logging, re
+    from yolo_fastest_amd import training
+    g, gm = golden("golden_256"), golden("golden_map_256")
+    items = [((g["input_u8"][i % 20].astype(np.float32) - 128.0)[..., None], gm["targets"][i % 20].astype(np.float32)) for i in range(40)]
+    params = copy.deepcopy(yf.config_params)
+    params["io_params"]["save_path"] = str(tmp_path / "models")
+    params["train_params"].update(total_epochs=6, batch_size=8, pretrained_pth=os.path.join(
+        ROOT, "yolo-fastest-and-embedded-deployment_amd", "assets", "weights", "yolo_fastest_256x320_epoch28.pth"))
+    lines = []
+
+    class H(logging.Handler):
+        def emit(self, rec):
+            lines.append(rec.getMessage())
+    logger = logging.getLogger("train_loop_test"); logger.setLevel(logging.INFO); logger.handlers = [H()]
+    scalars = []
+
+    class TB:
+        def add_scalar(self, name, value, step):
+            scalars.append((name, float(value), step))
+    torch.manual_seed(0)
+    model = training.train(params, dev, TB(), train_dataset=items, val_dataset=items[:20], logger=logger)
+    bpe, total = 5, 6                                                  # 40 items / batch 8, drop_last
+    logged = [l for l in lines if l.startswith("epoch [")]
+    assert len(logged) == 3                                            # iterations 10, 20, 30
+    num_warm = max(3 * bpe, 1000)
+    for l, step in zip(logged, (10, 20, 30)):
+        m = re.match(r"epoch \[(\d+)\]: current_batch = (\d+)/5, total_iter = (\d+), loss = (\d+\.\d{5}), example/sec = (\d+\.\d{3}), "
+                     r"lr = (\d\.\d{5}), remain = \d+:\d\d:\d\d$", l)
+        assert m, l
+        epoch, batch, it = int(m.group(1)), int(m.group(2)), int(m.group(3))
+        assert it == step and epoch == (step - 1) // bpe and batch == (step - 1) % bpe + 1
+        iteration = step - 1
+        lr = np.interp(iteration, [0, num_warm], [0.0, 0.001 * (((1 + np.cos(epoch * np.pi / total)) / 2) * 0.8 + 0.2)])
+        assert abs(float(m.group(6)) - lr) < 6e-6, (l, lr)
+        assert [s for s in scalars if s[0] == "lr" and s[2] == step][0][1] == pytest.approx(lr, rel=1e-9)
+    assert {s[0] for s in scalars} == {"lr", "example/sec", "total_loss", "x", "y", "w", "h", "conf", "cls"}
+    assert any("Load pretrained model" in l for l in lines) and any("epoch: 5 validation results" in l for l in lines)
+    assert sum("mean AP" in l for l in lines) == 1                     # only epoch 5 (> 4)
+    for e in range(total):
+        sd = torch.load(os.path.join(params["io_params"]["save_path"], "YOLO-Fastest_epoch_%d.pth" % e), map_location="cpu")
+        assert len(sd) == 508
+    fresh = yf.YoloFastest(params["io_params"])
+    assert str(fresh.load_state_dict(sd)) == "<All keys matched successfully>"
+    assert int(sd["conv0.1.num_batches_tracked"]) == int(torch.load(params["train_params"]["pretrained_pth"], map_location="cpu")[
+        "conv0.1.num_batches_tracked"]) + bpe * total
+    assert not model.training                                          # get_mAP left it in eval mode, like the reference
+    with pytest.raises(ValueError):
+        training.train(params, dev)

@@ -300,3 +300,96 @@ def train_step(model, model_loss, optimizer, imgs, targets):
     losses[0].backward()
     optimizer.step()
     return losses
+
+
+def cosine_factor(epoch, total_epochs):
+    """train.py:87-88 `lf`: the per-epoch learning-rate factor, 1.0 -> 0.2 over the run."""
+    import math
+    return ((1 + math.cos(epoch * math.pi / total_epochs)) / 2) * 0.8 + 0.2
+
+
+def train(params, device, tbwriter=None, train_dataset=None, val_dataset=None, logger=None):
+    """The reference's `train(params, device, tbwriter)` (train.py:44-160) with the iteration on the GPU kernels of this package.
+    Same control flow and arithmetic: one YOLOLossV3 per stride (:50-53), the model from `pretrained_pth` or initialize_weights()
+    (:58-65), DataLoader(batch_size, drop_last, shuffle) (:71-73), Adam(lr0, betas (0.9, 0.999), eps 1e-8) (:84), the cosine
+    LambdaLR stepped per epoch (:87-91), the linear warm-up of the first max(3 epochs, 1000 iterations) written into param_groups per
+    iteration (:103-109), the log line every 10 iterations (:134-150, same format), get_mAP after epoch 4 (:153-154) and one
+    `YOLO-Fastest_epoch_N.pth` state-dict per epoch (:155).  Differences: the datasets are passed in (the reference builds its
+    DetectDataset -- cv2 augmentation over files that are not shipped -- from paths in the config); items are DetectDataset's
+    ((h, w, c) uint8-range image, (64, 6) boxes), batched by validation.collate_fn (= DetectDataset.collate_fn).  tbwriter may be None.
+    Returns the trained model."""
+    import logging
+    import os
+    import time
+    import numpy as np
+    from torch.optim import lr_scheduler
+    from torch.utils.data import DataLoader
+    from . import validation
+    from .model import YoloFastest
+    if train_dataset is None:
+        raise ValueError("pass train_dataset (the reference's DetectDataset needs its un-shipped data and cv2)")
+    logger = logger or logging.getLogger(__name__)
+    io, tp = params["io_params"], params["train_params"]
+    save_path = io["save_path"]
+    os.makedirs(save_path, exist_ok=True)
+    total_epochs, batch_size = tp["total_epochs"], tp["batch_size"]
+    model = YoloFastest(io).to(device)
+    model_loss = [validation.YOLOLossV3(anchors=io["anchors"][i], num_classes=io["num_cls"], input_shape=io["input_shape"], device=device,
+                                        model=model) for i in range(len(io["strides"]))]
+    for ml in model_loss:
+        ml.ignore_threshold = tp.get("IOU_loss_thre", 0.5)
+    if tp.get("pretrained_pth") and os.path.exists(tp["pretrained_pth"]):
+        logger.info("Load pretrained model %s" % tp["pretrained_pth"])
+        model.load_state_dict(torch.load(tp["pretrained_pth"], map_location=device))
+    else:
+        logger.info("initialize model")
+        model.initialize_weights()
+    dataloader = DataLoader(train_dataset, batch_size=batch_size, num_workers=0, drop_last=True, pin_memory=True, shuffle=True,
+                            collate_fn=validation.collate_fn)
+    val = validation.Validation(params=params, logger=logger, dataset=val_dataset, device=device, model_loss=model_loss) \
+        if val_dataset is not None else None
+    batch_per_epoch = len(dataloader)
+    num_warm = max(3 * batch_per_epoch, 1000)
+    optimizer = Adam(model.parameters(), lr=tp["lr0"], betas=(0.9, 0.999), eps=1e-08)
+
+    def lf(epoch):
+        return cosine_factor(epoch, total_epochs)
+    scheduler = lr_scheduler.LambdaLR(optimizer, lr_lambda=lf)
+    start_epoch = 0
+    scheduler.last_epoch = start_epoch - 1
+    total_steps = (total_epochs - start_epoch) * batch_per_epoch
+    step_count = 0
+    logger.info("Start training.")
+    losses_name = ["total_loss", "x", "y", "w", "h", "conf", "cls"]
+    for epoch in range(start_epoch, total_epochs):
+        model.train()
+        for batch_id, (imgs, targets) in enumerate(dataloader):
+            start_time = time.time()
+            imgs = imgs.to(device).float()
+            targets = targets.to(device).float()
+            iteration = batch_id + batch_per_epoch * epoch
+            if iteration <= num_warm:
+                for x in optimizer.param_groups:
+                    x["lr"] = np.interp(iteration, [0, num_warm], [0.0, x["initial_lr"] * lf(epoch)])
+            losses = train_step(model, model_loss, optimizer, imgs, targets)
+            step_count += 1
+            if step_count > 0 and step_count % 10 == 0:
+                _loss = losses[0].item()
+                duration = float(time.time() - start_time)
+                example_per_second = batch_size / duration
+                _remain = (total_steps - step_count) * duration
+                _m, _s = divmod(_remain, 60)
+                _h, _m = divmod(_m, 60)
+                lr = optimizer.param_groups[0]["lr"]
+                logger.info("epoch [%d]: current_batch = %d/%d, total_iter = %d, loss = %.5f, example/sec = %.3f, lr = %.5f, remain = %d:%02d:%02d" %
+                            (epoch, batch_id + 1, batch_per_epoch, step_count, _loss, example_per_second, lr, _h, _m, _s))
+                if tbwriter is not None:
+                    tbwriter.add_scalar("lr", lr, step_count)
+                    tbwriter.add_scalar("example/sec", example_per_second, step_count)
+                    for i, name in enumerate(losses_name):
+                        tbwriter.add_scalar(name, _loss if i == 0 else losses[i], step_count)
+        scheduler.step()
+        if epoch > 4 and val is not None:
+            val.get_mAP(epoch=epoch, model=model)
+        torch.save(model.state_dict(), os.path.join(save_path, "YOLO-Fastest_epoch_{}.pth".format(str(epoch))))
+    return model
