@@ -20,6 +20,7 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--res", type=int, default=256)
 ap.add_argument("--cpu", action="store_true")
+ap.add_argument("--json", action="store_true", help="also print one JSON line (metric, value, ms per iteration, cpu baseline)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 io = yf.io_params_for(a.res)
@@ -49,6 +50,10 @@ for _ in range(a.steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 print("GPU  batch %d %dx%d: %.2f ms / iteration, %.0f examples/s, loss %.4f" % (a.batch, H, W, dt * 1e3, a.batch / dt, float(loss.detach())))
+line = {"metric": "training_examples_per_second", "value": round(a.batch / dt, 1), "unit": "examples/s", "ms_per_iteration": round(dt * 1e3, 3),
+        "steps": a.steps, "warmup": a.warmup, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "train.py:111-132 iteration (zero_grad, train-mode forward, two-head loss, backward, Adam)", "batch": a.batch,
+                   "input": [H, W]}, "cpu_baseline": None}
 if a.cpu:
     from oracle import backbone_oracle as bo, loss_oracle as lo
     sd = bo.training_state(sd0)
@@ -65,3 +70,8 @@ if a.cpu:
         copt.step()
     dc = (time.perf_counter() - t0) / n
     print("CPU oracle (torch, %d threads): %.1f ms / iteration, %.1f examples/s" % (torch.get_num_threads(), dc * 1e3, a.batch / dc))
+    line["cpu_baseline"] = {"value": round(a.batch / dc, 2), "unit": "examples/s", "cores": torch.get_num_threads(), "kind": "port",
+                            "sample": "%d iterations of the same batch through oracle/backbone_oracle.py + loss_oracle.py + torch.optim.Adam" % n}
+if a.json:
+    import json
+    print(json.dumps(line))
