@@ -510,3 +510,31 @@ def test_train_loop_mirrors_train_py(yf, golden, dev, tmp_path):
     assert not model.training                                          # get_mAP left it in eval mode, like the reference
     with pytest.raises(ValueError):
         training.train(params, dev)
+
+
+def test_training_forward_at_640x512(yf, dev):
+    """The other shipped input size, batch 2, random weights: train-mode heads against the float64 oracle; the gradients of the two
+    head convolutions (which no ReLU decision upstream can disturb beyond rounding) against the oracle's; everything else finite."""
+    from oracle import backbone_oracle as bo
+    torch.manual_seed(3)
+    io = yf.io_params_for(512)
+    m = yf.YoloFastest(io)
+    m.initialize_weights()
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(dev).train()
+    x = torch.rand(2, 1, 512, 640) - 0.5
+    hl, hs = m(x.to(dev))
+    assert hl.shape == (2, 24, 32, 40) and hs.shape == (2, 24, 16, 20)
+    ghl, ghs = torch.randn(hl.shape), torch.randn(hs.shape)
+    torch.autograd.backward([hl, hs], [ghl.to(dev), ghs.to(dev)])
+    sd = bo.training_state(sd0, torch.float64)
+    want = bo.forward(sd, x.double(), train=True)
+    for got, w in zip((hl, hs), want):
+        assert np.abs(got.detach().cpu().numpy() - w.detach().numpy()).max() <= 2e-4 * max(1.0, float(w.detach().abs().max()))
+    keys = ["head_4.weight", "head_4.bias", "head_5.weight", "head_5.bias"]
+    g64 = torch.autograd.grad(list(want), [sd[k] for k in keys], [ghl.double(), ghs.double()])
+    named = dict(m.named_parameters())
+    for k, w in zip(keys, g64):
+        g = named[k].grad.cpu().numpy()
+        assert np.abs(g - w.numpy()).max() <= 1e-4 * np.abs(w.numpy()).max(), k
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
