@@ -538,3 +538,79 @@ def test_training_forward_at_640x512(yf, dev):
         g = named[k].grad.cpu().numpy()
         assert np.abs(g - w.numpy()).max() <= 1e-4 * np.abs(w.numpy()).max(), k
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_training_operators_random_geometries(ops, dev):
+    """Fuzz of the conv / deconv / BatchNorm operators over random shapes (channel counts that are not multiples of the MFMA tiles,
+    1-pixel and odd maps, batch 1, strides, all kernel sizes): every fast path and every fallback against torch in float64."""
+    rng = np.random.default_rng(2024)
+    for trial in range(48):
+        dw = int(rng.integers(0, 3) == 0)
+        k = int(rng.choice([1, 3, 5])) if not dw else int(rng.choice([3, 5]))
+        stride = int(rng.integers(1, 3)) if k != 5 else 1
+        N = int(rng.integers(1, 6))
+        Cin = int(rng.integers(1, 70))
+        Cout = Cin if dw else int(rng.integers(1, 70))
+        H, W = int(rng.integers(1, 21)), int(rng.integers(1, 25))
+        if trial % 3 == 0:
+            H, W = 2 * ((H + 1) // 2), 4 * ((W + 3) // 4)            # the shapes the fast paths take
+        x = rng.normal(size=(N, Cin, H, W)).astype(np.float32)
+        w = rng.normal(size=(Cout, 1 if dw else Cin, k, k)).astype(np.float32)
+        xt = torch.from_numpy(x).double().requires_grad_(True)
+        wt = torch.from_numpy(w).double().requires_grad_(True)
+        yt = F.conv2d(xt, wt, None, stride=stride, padding=(k - 1) // 2, groups=Cin if dw else 1)
+        gy = rng.normal(size=tuple(yt.shape)).astype(np.float32)
+        yt.backward(torch.from_numpy(gy).double())
+        xd, wd, gyd = _g(x, dev), _g(w, dev), _g(gy, dev)
+        tag = "trial %d: N %d Cin %d Cout %d k %d s %d dw %d %dx%d" % (trial, N, Cin, Cout, k, stride, dw, H, W)
+        y = torch.full(tuple(yt.shape), float("nan"), device=dev)
+        ops.call("yf_train_conv_forward", xd.data_ptr(), wd.data_ptr(), None, y.data_ptr(), N, Cin, H, W, Cout, k, stride, dw)
+        _close(y, yt, 3e-6, tag + " forward")
+        gx = torch.full_like(xd, float("nan"))
+        ops.call("yf_train_conv_backward_data", gyd.data_ptr(), wd.data_ptr(), gx.data_ptr(), N, Cin, H, W, Cout, k, stride, dw)
+        _close(gx, xt.grad, 3e-6, tag + " backward data")
+        gw = torch.full_like(wd, float("nan"))
+        ops.call("yf_train_conv_backward_weight", xd.data_ptr(), gyd.data_ptr(), gw.data_ptr(), N, Cin, H, W, Cout, k, stride, dw, ops.scratch,
+                 ops.scratch_bytes)
+        _close(gw, wt.grad, 1e-5, tag + " backward weight")
+        # BatchNorm on the conv output
+        C, HW = Cout, yt.shape[2] * yt.shape[3]
+        if N * HW > 2:
+            bn = torch.nn.BatchNorm2d(C).double().train()
+            zt = yt.detach().clone().requires_grad_(True)
+            relu = trial & 1
+            ot = F.relu(bn(zt)) if relu else bn(zt)
+            ot.backward(torch.from_numpy(gy).double())
+            gam, bet = _g(np.ones(C), dev), _g(np.zeros(C), dev)
+            stats, yy = torch.empty(2 * C, device=dev), torch.empty_like(y)
+            zd = _g(yt.detach().numpy(), dev)
+            ops.call("yf_train_bn_forward", zd.data_ptr(), gam.data_ptr(), bet.data_ptr(), None, None, stats.data_ptr(), yy.data_ptr(), N, C, HW, relu,
+                     ops.scratch)
+            assert np.abs(yy.cpu().numpy() - ot.detach().numpy()).max() <= 2e-5 * max(1.0, float(ot.detach().abs().max())), tag + " bn forward"
+            dg, db, gz = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.full_like(zd, float("nan"))
+            ops.call("yf_train_bn_backward", zd.data_ptr(), yy.data_ptr(), gyd.data_ptr(), stats.data_ptr(), gam.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                     gz.data_ptr(), N, C, HW, relu, ops.scratch)
+            assert torch.isfinite(gz).all(), tag
+            if N * HW >= 16:                                           # a handful of samples per channel: dx is ill-conditioned, skip
+                _close(db, bn.bias.grad, 2e-5, tag + " dbeta")
+    for trial in range(12):
+        N, Cin, Cout, H, W = (int(rng.integers(1, 5)), int(rng.integers(1, 40)), int(rng.integers(1, 40)), int(rng.integers(1, 9)),
+                              int(rng.integers(1, 11)))
+        x = rng.normal(size=(N, Cin, H, W)).astype(np.float32)
+        w = rng.normal(size=(Cin, Cout, 2, 2)).astype(np.float32)
+        xt = torch.from_numpy(x).double().requires_grad_(True)
+        wt = torch.from_numpy(w).double().requires_grad_(True)
+        yt = F.conv_transpose2d(xt, wt, stride=2)
+        gy = rng.normal(size=tuple(yt.shape)).astype(np.float32)
+        yt.backward(torch.from_numpy(gy).double())
+        xd, wd, gyd = _g(x, dev), _g(w, dev), _g(gy, dev)
+        tag = "deconv trial %d: N %d Cin %d Cout %d %dx%d" % (trial, N, Cin, Cout, H, W)
+        y = torch.empty(tuple(yt.shape), device=dev)
+        ops.call("yf_train_deconv_forward", xd.data_ptr(), wd.data_ptr(), y.data_ptr(), N, Cin, H, W, Cout)
+        _close(y, yt, 3e-6, tag + " forward")
+        gx = torch.full_like(xd, float("nan"))
+        ops.call("yf_train_deconv_backward_data", gyd.data_ptr(), wd.data_ptr(), gx.data_ptr(), N, Cin, H, W, Cout)
+        _close(gx, xt.grad, 3e-6, tag + " backward data")
+        gw = torch.full_like(wd, float("nan"))
+        ops.call("yf_train_deconv_backward_weight", xd.data_ptr(), gyd.data_ptr(), gw.data_ptr(), N, Cin, H, W, Cout, ops.scratch, ops.scratch_bytes)
+        _close(gw, wt.grad, 1e-5, tag + " backward weight")
