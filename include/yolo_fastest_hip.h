@@ -148,7 +148,8 @@ int yf_train_loss(yf_handle h, const float *d_head, int N, int fh, int fw, const
  *   deconv: ConvTranspose2d(k 2, stride 2, pad 0); d_w [Cin, Cout, 2, 2]; output 2H x 2W.
  *   bn: BatchNorm2d in train mode (eps 1e-5, momentum 0.1): d_stats float[2C] receives (mean, invstd) per channel for the backward;
  *       running_mean / running_var are updated in place (unbiased variance) unless NULL; relu = 1 fuses the following ReLU (the backward
- *       then masks by y > 0).  bn_backward: d_dgamma, d_dbeta [C], d_dx like x.  C <= 256.
+ *       then masks by y > 0, with y recomputed from x bit for bit -- it does not read the forward's output).  bn_backward: d_x = the
+ *       forward's input, d_dgamma, d_dbeta [C], d_dx like x.  C <= 256.
  *   d_scratch: yf_train_scratch_bytes() of device memory, one per stream, no initialisation needed: the per-channel reductions of bn
  *       and the weight gradients are split over many workgroups that store partial results there, and a second pass adds them in a
  *       fixed order (deterministic; device-scope float atomics are slow on a multi-XCD part).  conv_backward_weight accepts NULL / a
@@ -167,7 +168,7 @@ int yf_train_deconv_backward_weight(int device, const float *d_x, const float *d
 int yf_train_scratch_bytes(size_t *bytes);
 int yf_train_bn_forward(int device, const float *d_x, const float *d_gamma, const float *d_beta, float *d_running_mean, float *d_running_var,
                         float *d_stats, float *d_y, int N, int C, long HW, int relu, void *d_scratch, void *stream);
-int yf_train_bn_backward(int device, const float *d_x, const float *d_y, const float *d_dy, const float *d_stats, const float *d_gamma,
+int yf_train_bn_backward(int device, const float *d_x, const float *d_dy, const float *d_stats, const float *d_gamma, const float *d_beta,
                          float *d_dgamma, float *d_dbeta, float *d_dx, int N, int C, long HW, int relu, void *d_scratch, void *stream);
 /* One block of the network each way -- conv_norm_relu / conv_norm / deconv_norm_relu (yolo_fastest.py:16-48): conv (deconv = 1:
  * ConvTranspose2d) + BatchNorm (+ ReLU).  forward: d_z = conv output (kept for the backward), d_y = block output.  backward: d_gy =
@@ -175,8 +176,8 @@ int yf_train_bn_backward(int device, const float *d_x, const float *d_y, const f
 int yf_train_unit_forward(int device, int deconv, const float *d_x, const float *d_w, const float *d_gamma, const float *d_beta,
                           float *d_running_mean, float *d_running_var, float *d_stats, float *d_z, float *d_y, int N, int Cin, int H, int W, int Cout,
                           int k, int stride, int depthwise, int relu, void *d_scratch, void *stream);
-int yf_train_unit_backward(int device, int deconv, const float *d_x, const float *d_z, const float *d_y, const float *d_gy, const float *d_stats,
-                           const float *d_w, const float *d_gamma, float *d_dgamma, float *d_dbeta, float *d_gz, float *d_dw, float *d_dx, int N,
+int yf_train_unit_backward(int device, int deconv, const float *d_x, const float *d_z, const float *d_gy, const float *d_stats, const float *d_w,
+                           const float *d_gamma, const float *d_beta, float *d_dgamma, float *d_dbeta, float *d_gz, float *d_dw, float *d_dx, int N,
                            int Cin, int H, int W, int Cout, int k, int stride, int depthwise, int relu, void *d_scratch, size_t scratch_bytes,
                            void *stream);
 int yf_train_channel_sum(int device, const float *d_dy, float *d_out, int N, int C, long HW, void *stream);                 /* bias gradient */

@@ -51,7 +51,7 @@ _SIGS = {
     "yf_train_deconv_backward_weight": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 5 +
                                         [_c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "yf_train_unit_forward": (_c.c_int, [_c.c_int, _c.c_int] + [_c.c_void_p] * 9 + [_c.c_int] * 9 + [_c.c_void_p, _c.c_void_p]),
-    "yf_train_unit_backward": (_c.c_int, [_c.c_int, _c.c_int] + [_c.c_void_p] * 12 + [_c.c_int] * 9 + [_c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "yf_train_unit_backward": (_c.c_int, [_c.c_int, _c.c_int] + [_c.c_void_p] * 12 + [_c.c_int] * 9 + [_c.c_void_p, _c.c_size_t, _c.c_void_p]),  # x z gy stats w gamma beta dgamma dbeta gz dw dx
     "yf_train_scratch_bytes": (_c.c_int, [_c.POINTER(_c.c_size_t)]),
     "yf_train_bn_forward": (_c.c_int, [_c.c_int] + [_c.c_void_p] * 7 + [_c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "yf_train_bn_backward": (_c.c_int, [_c.c_int] + [_c.c_void_p] * 8 + [_c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_void_p, _c.c_void_p]),

@@ -952,11 +952,11 @@ int yf_train_bn_forward(int device, const float* d_x, const float* d_gamma, cons
     YF_TOP(d_x && d_gamma && d_beta && d_stats && d_y && d_scratch && N > 0 && N <= 65535 && C > 0 && C <= 256 && HW > 0,
            yf::launch_tbn_fwd(d_x, d_gamma, d_beta, d_running_mean, d_running_var, d_stats, d_y, N, C, HW, relu, d_scratch, (hipStream_t)stream));
 }
-int yf_train_bn_backward(int device, const float* d_x, const float* d_y, const float* d_dy, const float* d_stats, const float* d_gamma,
+int yf_train_bn_backward(int device, const float* d_x, const float* d_dy, const float* d_stats, const float* d_gamma, const float* d_beta,
                          float* d_dgamma, float* d_dbeta, float* d_dx, int N, int C, long HW, int relu, void* d_scratch, void* stream)
 {
-    YF_TOP(d_x && d_y && d_dy && d_stats && d_gamma && d_dgamma && d_dbeta && d_dx && d_scratch && N > 0 && N <= 65535 && C > 0 && C <= 256 && HW > 0,
-           yf::launch_tbn_bwd(d_x, d_y, d_dy, d_stats, d_gamma, d_dgamma, d_dbeta, d_dx, N, C, HW, relu, d_scratch, (hipStream_t)stream));
+    YF_TOP(d_x && d_dy && d_stats && d_gamma && d_beta && d_dgamma && d_dbeta && d_dx && d_scratch && N > 0 && C > 0 && C <= 256 && HW > 0,
+           yf::launch_tbn_bwd(d_x, d_dy, d_stats, d_gamma, d_beta, d_dgamma, d_dbeta, d_dx, N, C, HW, relu, d_scratch, (hipStream_t)stream));
 }
 int yf_train_channel_sum(int device, const float* d_dy, float* d_out, int N, int C, long HW, void* stream)
 {
@@ -1001,12 +1001,12 @@ int yf_train_unit_forward(int device, int deconv, const float* d_x, const float*
     HIP_OK(hipGetLastError());
     return YF_OK;
 }
-int yf_train_unit_backward(int device, int deconv, const float* d_x, const float* d_z, const float* d_y, const float* d_gy, const float* d_stats,
-                           const float* d_w, const float* d_gamma, float* d_dgamma, float* d_dbeta, float* d_gz, float* d_dw, float* d_dx, int N,
+int yf_train_unit_backward(int device, int deconv, const float* d_x, const float* d_z, const float* d_gy, const float* d_stats, const float* d_w,
+                           const float* d_gamma, const float* d_beta, float* d_dgamma, float* d_dbeta, float* d_gz, float* d_dw, float* d_dx, int N,
                            int Cin, int H, int W, int Cout, int k, int stride, int depthwise, int relu, void* d_scratch, size_t scratch_bytes,
                            void* stream)
 {
-    if (!d_x || !d_z || !d_y || !d_gy || !d_stats || !d_w || !d_gamma || !d_dgamma || !d_dbeta || !d_gz || !d_dw || !d_scratch || N <= 0 || Cin <= 0 ||
+    if (!d_x || !d_z || !d_gy || !d_stats || !d_w || !d_gamma || !d_beta || !d_dgamma || !d_dbeta || !d_gz || !d_dw || !d_scratch || N <= 0 || Cin <= 0 ||
         Cout <= 0 || Cout > 256 || (depthwise && Cin != Cout))
         return fail(YF_E_INVALID, "yf_train_unit_backward: bad argument");
     if (!deconv && !((k == 1 || k == 3 || k == 5) && (stride == 1 || stride == 2))) return fail(YF_E_INVALID, "yf_train_unit_backward: bad kernel / stride");
@@ -1019,7 +1019,7 @@ int yf_train_unit_backward(int device, int deconv, const float* d_x, const float
         const int pad = (k - 1) / 2;
         HWo = (long)((H + 2 * pad - k) / stride + 1) * ((W + 2 * pad - k) / stride + 1);
     }
-    yf::launch_tbn_bwd(d_z, d_y, d_gy, d_stats, d_gamma, d_dgamma, d_dbeta, d_gz, N, Cout, HWo, relu, d_scratch, s);
+    yf::launch_tbn_bwd(d_z, d_gy, d_stats, d_gamma, d_beta, d_dgamma, d_dbeta, d_gz, N, Cout, HWo, relu, d_scratch, s);
     if (deconv) {
         yf::launch_tdeconv_bwd_weight(d_x, d_gz, d_dw, N, Cin, H, W, Cout, d_scratch, scratch_bytes, s);
         if (d_dx) yf::launch_tdeconv_bwd_data(d_gz, d_w, d_dx, N, Cin, H, W, Cout, s);

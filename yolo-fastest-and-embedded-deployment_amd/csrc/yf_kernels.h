@@ -242,7 +242,7 @@ void launch_tdeconv_bwd_weight(const float* x, const float* dy, float* dw, int N
 size_t train_scratch_bytes();
 void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* stats, float* y, int N,
                     int C, long HW, int relu, void* scratch, hipStream_t s);
-void launch_tbn_bwd(const float* x, const float* y, const float* dy, const float* stats, const float* gamma, float* dgamma, float* dbeta, float* dx,
+void launch_tbn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, float* dgamma, float* dbeta, float* dx,
                     int N, int C, long HW, int relu, void* scratch, hipStream_t s);
 void launch_tadam_multi(int nt, float* const* p, const float* const* g, float* const* m, float* const* v, const long* sizes, double lr, double b1,
                         double b2, double eps, int step, void* d_table, hipStream_t s);

@@ -615,6 +615,11 @@ template <> struct tbn_vec<1> { typedef float type; };
 template <> struct tbn_vec<4> { typedef float4 type; };
 template <int V> __device__ __forceinline__ float tbn_at(const typename tbn_vec<V>::type& v, int j) { return ((const float*)&v)[j]; }
 
+// y before the ReLU, in ONE fixed operation order: the backward recomputes it from z to get the ReLU mask (y > 0) without reading y
+__device__ __forceinline__ float tbn_affine(float x, float mean, float invstd, float gamma, float beta)
+{
+    return __fmaf_rn(__fmul_rn(__fsub_rn(x, mean), invstd), gamma, beta);
+}
 __device__ __forceinline__ void tbn_block_store(double s, double t, double* __restrict__ part)
 {
     __shared__ double r1[4], r2[4];
@@ -691,36 +696,36 @@ __global__ void __launch_bounds__(256) tbn_apply_kernel(const float* __restrict_
         vec o;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            const float v = (tbn_at<V>(xv, j) - fm) * fi * g + b;
+            const float v = tbn_affine(tbn_at<V>(xv, j), fm, fi, g, b);
             ((float*)&o)[j] = relu ? fmaxf(v, 0.f) : v;
         }
         *reinterpret_cast<vec*>(y + idx) = o;
     }
 }
 
-// backward: dy_eff = dy * (y > 0) with ReLU; {sum dy_eff, sum dy_eff * xhat} = (dbeta, dgamma)
+// backward: dy_eff = dy * (y > 0) with ReLU; {sum dy_eff, sum dy_eff * xhat} = (dbeta, dgamma).  The mask is recomputed from z
+// (tbn_affine, bit-identical to the forward's value): one tensor less to read in each of the two backward passes.
 template <int V>
-__global__ void __launch_bounds__(256) tbn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
-                                                             const float* __restrict__ stats, int N, int C, long HW, int relu,
-                                                             double* __restrict__ scratch)
+__global__ void __launch_bounds__(256) tbn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stats,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int N, int C, long HW,
+                                                             int relu, double* __restrict__ scratch)
 {
     typedef typename tbn_vec<V>::type vec;
     const int c = blockIdx.y, nchunk = gridDim.x;
     const long upn = (HW + 256 * V - 1) / (256 * V), U = (long)N * upn;
-    const float mean = stats[2 * c], invstd = stats[2 * c + 1];
+    const float mean = stats[2 * c], invstd = stats[2 * c + 1], gm = gamma[c], bt = beta[c];
     double s = 0, sx = 0;
     for (long u = blockIdx.x; u < U; u += nchunk) {
         const long n = u / upn, i = ((u - n * upn) * 256 + threadIdx.x) * V;
         if (i < HW) {
             const long idx = (n * C + c) * HW + i;
             const vec gv = *reinterpret_cast<const vec*>(dy + idx), xv = *reinterpret_cast<const vec*>(x + idx);
-            vec yv = gv;
-            if (relu) yv = *reinterpret_cast<const vec*>(y + idx);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 float g = tbn_at<V>(gv, j);
-                if (relu && !(tbn_at<V>(yv, j) > 0.f)) g = 0.f;
-                s += g; sx += (double)g * (double)((tbn_at<V>(xv, j) - mean) * invstd);
+                const float xe = tbn_at<V>(xv, j);
+                if (relu && !(tbn_affine(xe, mean, invstd, gm, bt) > 0.f)) g = 0.f;
+                s += g; sx += (double)g * (double)((xe - mean) * invstd);
             }
         }
     }
@@ -729,8 +734,8 @@ __global__ void __launch_bounds__(256) tbn_bwd_reduce_kernel(const float* __rest
 
 // dx = gamma * invstd * (dy_eff - (dbeta + xhat * dgamma) / P)
 template <int V>
-__global__ void __launch_bounds__(256) tbn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
-                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(256) tbn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const double* __restrict__ scratch, int nchunk, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, float* __restrict__ dx, int N, int C, long HW, int relu)
 {
@@ -740,21 +745,20 @@ __global__ void __launch_bounds__(256) tbn_bwd_apply_kernel(const float* __restr
     tbn_block_total(scratch + (long)c * TBN_MAXCHUNK * 2, nchunk, s, sx);
     const float db = (float)s, dg = (float)sx;
     if (blockIdx.x == 0 && threadIdx.x == 0) { dbeta[c] = db; dgamma[c] = dg; }
-    const float fm = stats[2 * c], fi = stats[2 * c + 1], gi = gamma[c] * fi, invP = 1.f / (float)((long)N * HW);
+    const float fm = stats[2 * c], fi = stats[2 * c + 1], gm = gamma[c], bt = beta[c], gi = gm * fi, invP = 1.f / (float)((long)N * HW);
     const long upn = (HW + 256 * V - 1) / (256 * V), U = (long)N * upn;
     for (long u = blockIdx.x; u < U; u += gridDim.x) {
         const long n = u / upn, i = ((u - n * upn) * 256 + threadIdx.x) * V;
         if (i >= HW) continue;
         const long idx = (n * C + c) * HW + i;
         const vec gv = *reinterpret_cast<const vec*>(dy + idx), xv = *reinterpret_cast<const vec*>(x + idx);
-        vec yv = gv;
-        if (relu) yv = *reinterpret_cast<const vec*>(y + idx);
         vec o;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             float g = tbn_at<V>(gv, j);
-            if (relu && !(tbn_at<V>(yv, j) > 0.f)) g = 0.f;
-            const float xhat = (tbn_at<V>(xv, j) - fm) * fi;
+            const float xe = tbn_at<V>(xv, j);
+            if (relu && !(tbn_affine(xe, fm, fi, gm, bt) > 0.f)) g = 0.f;
+            const float xhat = (xe - fm) * fi;
             ((float*)&o)[j] = gi * (g - (db + xhat * dg) * invP);
         }
         *reinterpret_cast<vec*>(dx + idx) = o;
@@ -1021,18 +1025,18 @@ void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float
                            stats, running_mean, running_var);
     }
 }
-void launch_tbn_bwd(const float* x, const float* y, const float* dy, const float* stats, const float* gamma, float* dgamma, float* dbeta, float* dx,
+void launch_tbn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, float* dgamma, float* dbeta, float* dx,
                     int N, int C, long HW, int relu, void* scratch, hipStream_t s)
 {
     const int V = (HW % 4 == 0 && HW >= 1024) ? 4 : 1, nchunk = tbn_chunks(N, C, HW, V);
     const dim3 g1(nchunk, C), g2(tbn_apply_blocks(N, C, HW, V), C);
     if (V == 4) {
-        hipLaunchKernelGGL(tbn_bwd_reduce_kernel<4>, g1, dim3(256), 0, s, x, y, dy, stats, N, C, HW, relu, (double*)scratch);
-        hipLaunchKernelGGL(tbn_bwd_apply_kernel<4>, g2, dim3(256), 0, s, x, y, dy, stats, gamma, (const double*)scratch, nchunk, dgamma, dbeta, dx, N,
+        hipLaunchKernelGGL(tbn_bwd_reduce_kernel<4>, g1, dim3(256), 0, s, x, dy, stats, gamma, beta, N, C, HW, relu, (double*)scratch);
+        hipLaunchKernelGGL(tbn_bwd_apply_kernel<4>, g2, dim3(256), 0, s, x, dy, stats, gamma, beta, (const double*)scratch, nchunk, dgamma, dbeta, dx, N,
                            C, HW, relu);
     } else {
-        hipLaunchKernelGGL(tbn_bwd_reduce_kernel<1>, g1, dim3(256), 0, s, x, y, dy, stats, N, C, HW, relu, (double*)scratch);
-        hipLaunchKernelGGL(tbn_bwd_apply_kernel<1>, g2, dim3(256), 0, s, x, y, dy, stats, gamma, (const double*)scratch, nchunk, dgamma, dbeta, dx, N,
+        hipLaunchKernelGGL(tbn_bwd_reduce_kernel<1>, g1, dim3(256), 0, s, x, dy, stats, gamma, beta, N, C, HW, relu, (double*)scratch);
+        hipLaunchKernelGGL(tbn_bwd_apply_kernel<1>, g2, dim3(256), 0, s, x, dy, stats, gamma, beta, (const double*)scratch, nchunk, dgamma, dbeta, dx, N,
                            C, HW, relu);
     }
 }

@@ -108,9 +108,9 @@ def _unit_backward(ops, mod, tape, name, gy, grads, need_dx=True):
     dgb = ops.new(2, Cout)
     dw_ = torch.empty_like(conv.weight)
     gx = torch.empty_like(x) if need_dx else None
-    ops.call("yf_train_unit_backward", deconv, x.data_ptr(), z.data_ptr(), y.data_ptr(), gy.data_ptr(), stats.data_ptr(), conv.weight.data_ptr(),
-             bn.weight.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), gz.data_ptr(), dw_.data_ptr(), _ptr(gx), N, Cin, H, W, Cout, k, stride, dw,
-             relu, ops.scratch, ops.scratch_bytes)
+    ops.call("yf_train_unit_backward", deconv, x.data_ptr(), z.data_ptr(), gy.data_ptr(), stats.data_ptr(), conv.weight.data_ptr(),
+             bn.weight.data_ptr(), bn.bias.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), gz.data_ptr(), dw_.data_ptr(), _ptr(gx), N, Cin, H, W, Cout,
+             k, stride, dw, relu, ops.scratch, ops.scratch_bytes)
     grads[bn.weight], grads[bn.bias], grads[conv.weight] = dgb[0], dgb[1], dw_
     return gx
 
