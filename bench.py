@@ -52,11 +52,13 @@ F16_MFMA_PEAK_TF = 2500.0      # dense fp16/bf16 MFMA
 
 
 def source_hash():
-    """sha256 over the kernel sources: identifies the build a profile under profiles/ belongs to."""
+    """sha256 over the sources of the inference kernels and the engine: identifies the build a profile under profiles/ belongs to.
+    (The training-step kernels, yf_train_* / yf_loss_*, are not launched by this benchmark and are left out, so that work on them does
+    not orphan the PMC traffic figures.)"""
     h = hashlib.sha256()
     d = os.path.join(PKG, "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
+        if f.endswith((".hip", ".h")) and not f.startswith(("yf_train_", "yf_loss_")):
             with open(os.path.join(d, f), "rb") as fh:
                 h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
