@@ -191,6 +191,24 @@ int yf_train_adam_step(int device, float *d_p, const float *d_g, float *d_m, flo
 int yf_train_adam_multi(int device, int ntensors, void *const *d_p, const void *const *d_g, void *const *d_m, void *const *d_v, const long *sizes,
                         double lr, double beta1, double beta2, double eps, int step, void *d_table, size_t table_bytes, void *stream);
 
+/* The same training forward / backward as ONE call each: the whole graph of yolo_fastest.py:150-218 in train mode (what
+ * `pred = model(imgs)` and `loss.backward()` run, train.py:114, :131), launched from C++ into a caller-owned workspace.
+ *   d_params / d_grads: HOST arrays of yf_trainer_num_params() device pointers in `model.parameters()` order (per conv block: conv
+ *     weight, BN weight, BN bias; per head: weight, bias); d_grads are written, not accumulated.
+ *   d_bn_buffers: HOST array of 2 * n_bn device pointers (running_mean, running_var per BatchNorm in module order) or NULL.
+ *   d_ws: yf_trainer_workspace_bytes(t, N) bytes; forward leaves the activations there and backward reads them: the same buffer,
+ *     untouched in between.  backward also needs the images again (d_x: the first conv's weight gradient).
+ * Stream-ordered, no allocation, no synchronisation. */
+typedef struct yf_trainer_s *yf_trainer;
+int yf_trainer_create(int H, int W, int device, yf_trainer *out);
+void yf_trainer_destroy(yf_trainer t);
+int yf_trainer_num_params(yf_trainer t, int *n_params, int *n_bn);
+int yf_trainer_workspace_bytes(yf_trainer t, int N, size_t *bytes);
+int yf_trainer_forward(yf_trainer t, const float *d_x, int N, const void *const *d_params, void *const *d_bn_buffers, float *d_head_large,
+                       float *d_head_small, void *d_ws, size_t ws_bytes, void *stream);
+int yf_trainer_backward(yf_trainer t, const float *d_x, const float *d_grad_head_large, const float *d_grad_head_small, int N,
+                        const void *const *d_params, void *const *d_grads, void *d_ws, size_t ws_bytes, void *stream);
+
 /* yf_forward + yf_decode_nms back to back on one stream (heads also returned; may be NULL to use
  * workspace-internal buffers). */
 int yf_detect(yf_handle h, const float *d_x, int N, double conf_thres, double nms_thres, const double *anchors,

@@ -616,3 +616,44 @@ def test_training_operators_random_geometries(ops, dev):
         gw = torch.full_like(wd, float("nan"))
         ops.call("yf_train_deconv_backward_weight", xd.data_ptr(), gyd.data_ptr(), gw.data_ptr(), N, Cin, H, W, Cout, ops.scratch, ops.scratch_bytes)
         _close(gw, wt.grad, 1e-5, tag + " backward weight")
+
+
+def test_trainer_is_identical_to_the_per_block_path(yf, golden, dev):
+    """yf_trainer_forward / yf_trainer_backward (the graph walked in C++) against the same kernels orchestrated from Python one block at
+    a time (model.train_impl = "ops"): the launches are the same, so heads, every gradient and the running statistics are bit-identical."""
+    gt = golden("golden_train_256")
+    x = ((torch.from_numpy(gt["input_u8"][:6].astype(np.float32))[:, None] - 128.0) / 255.0).to(dev)
+    out = {}
+    for impl in ("trainer", "ops"):
+        m = yf.YoloFastest(yf.io_params_for(256)).to(dev)
+        m.load_state_dict(torch.load(WEIGHTS, map_location=dev))
+        m.train()
+        m.train_impl = impl
+        hl, hs = m(x)
+        torch.manual_seed(1)
+        ghl, ghs = torch.randn(hl.shape, device=dev), torch.randn(hs.shape, device=dev)
+        torch.autograd.backward([hl, hs], [ghl, ghs])
+        out[impl] = (hl.detach(), hs.detach(), [p.grad.clone() for p in m.parameters()], [b.clone() for b in m.buffers()])
+    a, b = out["trainer"], out["ops"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for (n, _), ga, gb in zip(yf.YoloFastest(yf.io_params_for(256)).named_parameters(), a[2], b[2]):
+        assert torch.equal(ga, gb), n
+    for ba, bb in zip(a[3], b[3]):
+        assert torch.equal(ba, bb)
+    # two forwards before the first backward: each pass owns its tape
+    m = yf.YoloFastest(yf.io_params_for(256)).to(dev)
+    m.load_state_dict(torch.load(WEIGHTS, map_location=dev))
+    m.train()
+    h1 = m(x[:2])
+    h2 = m(x[2:6])
+    (h1[0].sum() + h1[1].sum()).backward()
+    g1 = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad()
+    (h2[0].sum() + h2[1].sum()).backward()
+    m2 = yf.YoloFastest(yf.io_params_for(256)).to(dev)
+    m2.load_state_dict(torch.load(WEIGHTS, map_location=dev))
+    m2.train()
+    h1b = m2(x[:2])
+    (h1b[0].sum() + h1b[1].sum()).backward()
+    for p, g in zip(m2.parameters(), g1):
+        assert torch.equal(p.grad, g)

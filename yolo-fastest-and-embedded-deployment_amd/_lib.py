@@ -52,6 +52,14 @@ _SIGS = {
                                         [_c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "yf_train_unit_forward": (_c.c_int, [_c.c_int, _c.c_int] + [_c.c_void_p] * 9 + [_c.c_int] * 9 + [_c.c_void_p, _c.c_void_p]),
     "yf_train_unit_backward": (_c.c_int, [_c.c_int, _c.c_int] + [_c.c_void_p] * 12 + [_c.c_int] * 9 + [_c.c_void_p, _c.c_size_t, _c.c_void_p]),  # x z gy stats w gamma beta dgamma dbeta gz dw dx
+    "yf_trainer_create": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_void_p)]),
+    "yf_trainer_destroy": (None, [_c.c_void_p]),
+    "yf_trainer_num_params": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
+    "yf_trainer_workspace_bytes": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_size_t)]),
+    "yf_trainer_forward": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                      _c.c_size_t, _c.c_void_p]),
+    "yf_trainer_backward": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                       _c.c_size_t, _c.c_void_p]),
     "yf_train_scratch_bytes": (_c.c_int, [_c.POINTER(_c.c_size_t)]),
     "yf_train_bn_forward": (_c.c_int, [_c.c_int] + [_c.c_void_p] * 7 + [_c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "yf_train_bn_backward": (_c.c_int, [_c.c_int] + [_c.c_void_p] * 8 + [_c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_void_p, _c.c_void_p]),

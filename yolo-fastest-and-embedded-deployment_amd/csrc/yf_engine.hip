@@ -571,6 +571,101 @@ float logit_threshold(double thres)
 
 }  // namespace
 
+// ---- the training iteration's forward and backward as ONE call each (yf_trainer_*): the graph of yolo_fastest.py:150-218 over
+// NCHW fp32 tensors in a caller-owned workspace.  kLayers is in module-definition order, which is also the forward order; a layer's
+// input is the previous layer's output except where noted in trainer_build(). ----
+struct TLayer {
+    int in;                 // layer whose y is this layer's input: -1 = the images, -2 = the concat buffer
+    int Cin, Hin, Win, Cout, Ho, Wo;
+    int res_from;           // conv3 of a BasicResBlock: layer whose INPUT is added to this layer's output (the block's conv1), else -1
+    size_t z, y, st;        // float offsets PER FRAME of z and y, absolute float offset of stats (2 * Cout)
+    int p0;                 // index of the layer's first parameter in parameters() order
+};
+struct yf_trainer_s {
+    int device, H, W;
+    TLayer L[kNumLayers];
+    size_t act_floats;      // per frame: all z / y, the concat buffer
+    size_t cat;             // per-frame offset of the concat buffer
+    size_t stats_floats;    // total, independent of N
+    size_t gmax;            // per frame: the largest activation
+    size_t ga2, gb2, gd;    // per-frame sizes of the branch-point gradient buffers (conv4_2, conv5_2, deconv5_1 outputs)
+    int n_params;
+    int i_conv4_2, i_conv4_3, i_conv5_2, i_conv5_3, i_conv5_6, i_head5, i_deconv, i_c411, i_c415, i_head4;
+};
+
+namespace {
+
+int trainer_build(yf_trainer_s* t, int H, int W)
+{
+    t->H = H; t->W = W;
+    t->i_conv4_2 = find_layer("conv4_2"); t->i_conv4_3 = find_layer("conv4_3"); t->i_conv5_2 = find_layer("conv5_2");
+    t->i_conv5_3 = find_layer("conv5_3"); t->i_conv5_6 = find_layer("conv5_6"); t->i_head5 = find_layer("head_5");
+    t->i_deconv = find_layer("deconv5_1"); t->i_c411 = find_layer("conv4_1_1"); t->i_c415 = find_layer("conv4_1_5");
+    t->i_head4 = find_layer("head_4");
+    size_t off = 0, st = 0;
+    int p = 0;
+    t->gmax = 0;
+    for (int i = 0; i < kNumLayers; ++i) {
+        const LayerSpec& S = kLayers[i];
+        TLayer& L = t->L[i];
+        L.in = i - 1;
+        if (i == t->i_deconv) L.in = t->i_conv5_2;              // deconv5_1(conv5_2)              yolo_fastest.py:208
+        if (i == t->i_c411) L.in = -2;                          // conv4_1_1(cat(conv4_2, deconv5_1))       :209-211
+        if (L.in >= 0) { L.Cin = t->L[L.in].Cout; L.Hin = t->L[L.in].Ho; L.Win = t->L[L.in].Wo; }
+        else if (L.in == -1) { L.Cin = 1; L.Hin = H; L.Win = W; }
+        else { L.Cin = t->L[t->i_conv4_2].Cout + t->L[t->i_deconv].Cout; L.Hin = t->L[t->i_conv4_2].Ho; L.Win = t->L[t->i_conv4_2].Wo; }
+        if (L.Cin != S.cin) return -1;
+        L.Cout = S.cout;
+        if (S.kind == K_DECONV) { L.Ho = 2 * L.Hin; L.Wo = 2 * L.Win; }
+        else { const int pad = (S.k - 1) / 2; L.Ho = (L.Hin + 2 * pad - S.k) / S.stride + 1; L.Wo = (L.Win + 2 * pad - S.k) / S.stride + 1; }
+        const size_t a = (size_t)L.Cout * L.Ho * L.Wo;
+        L.res_from = -1;
+        const size_t n = strlen(S.name);
+        if (n > 6 && !strcmp(S.name + n - 6, ".conv3")) L.res_from = i - 2;
+        if (S.kind == K_HEAD) { L.z = L.y = 0; L.st = 0; L.p0 = p; p += 2; continue; }     // the heads write into the caller's tensors
+        L.z = off; off += a;
+        L.y = off; off += a;
+        L.st = st; st += 2 * (size_t)L.Cout;
+        L.p0 = p; p += 3;
+        if (a > t->gmax) t->gmax = a;
+    }
+    t->cat = off;
+    off += (size_t)t->L[t->i_c411].Cin * t->L[t->i_c411].Hin * t->L[t->i_c411].Win;
+    if ((size_t)t->L[t->i_c411].Cin * t->L[t->i_c411].Hin * t->L[t->i_c411].Win > t->gmax)
+        t->gmax = (size_t)t->L[t->i_c411].Cin * t->L[t->i_c411].Hin * t->L[t->i_c411].Win;
+    if ((size_t)H * W > t->gmax) t->gmax = (size_t)H * W;
+    t->act_floats = off;
+    t->stats_floats = st;
+    t->n_params = p;
+    t->ga2 = (size_t)t->L[t->i_conv4_2].Cout * t->L[t->i_conv4_2].Ho * t->L[t->i_conv4_2].Wo;
+    t->gb2 = (size_t)t->L[t->i_conv5_2].Cout * t->L[t->i_conv5_2].Ho * t->L[t->i_conv5_2].Wo;
+    t->gd = (size_t)t->L[t->i_deconv].Cout * t->L[t->i_deconv].Ho * t->L[t->i_deconv].Wo;
+    return 0;
+}
+
+// workspace: [scratch | stats | activations x N | 4 gradient buffers x N x gmax | ga2, gb2, gd x N]
+struct TWs {
+    char* scratch; float* stats; float* act; float* g[4]; float* ga2; float* gb2; float* gd;
+    size_t bytes;
+};
+TWs trainer_ws(const yf_trainer_s* t, int N, void* base)
+{
+    TWs w;
+    char* p = static_cast<char*>(base);
+    auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+    w.scratch = take(yf::train_scratch_bytes());
+    w.stats = reinterpret_cast<float*>(take(t->stats_floats * 4));
+    w.act = reinterpret_cast<float*>(take(t->act_floats * N * 4));
+    for (int i = 0; i < 4; ++i) w.g[i] = reinterpret_cast<float*>(take(t->gmax * N * 4));
+    w.ga2 = reinterpret_cast<float*>(take(t->ga2 * N * 4));
+    w.gb2 = reinterpret_cast<float*>(take(t->gb2 * N * 4));
+    w.gd = reinterpret_cast<float*>(take(t->gd * N * 4));
+    w.bytes = (size_t)(p - static_cast<char*>(base));
+    return w;
+}
+
+}  // namespace
+
 extern "C" {
 
 int yf_abi_version(void) { return YF_ABI_VERSION; }
@@ -1040,6 +1135,154 @@ int yf_train_adam_multi(int device, int ntensors, void* const* d_p, const void* 
     HIP_OK(hipSetDevice(device));
     yf::launch_tadam_multi(ntensors, (float* const*)d_p, (const float* const*)d_g, (float* const*)d_m, (float* const*)d_v, sizes, lr, beta1, beta2, eps,
                            step, d_table, (hipStream_t)stream);
+    HIP_OK(hipGetLastError());
+    return YF_OK;
+}
+// ---- the trainer: forward and backward of the whole network as one call each ----
+int yf_trainer_create(int H, int W, int device, yf_trainer* out)
+{
+    if (!out || H <= 0 || W <= 0 || H % 32 || W % 32) return fail(YF_E_INVALID, "yf_trainer_create: H and W must be positive multiples of 32");
+    yf_trainer_s* t = new yf_trainer_s();
+    t->device = device;
+    if (trainer_build(t, H, W)) { delete t; return fail(YF_E_INVALID, "yf_trainer_create: layer table inconsistent"); }
+    *out = t;
+    return YF_OK;
+}
+void yf_trainer_destroy(yf_trainer t) { delete t; }
+int yf_trainer_num_params(yf_trainer t, int* n_params, int* n_bn)
+{
+    if (!t || !n_params || !n_bn) return fail(YF_E_INVALID, "yf_trainer_num_params: null argument");
+    *n_params = t->n_params;
+    *n_bn = kNumLayers - 2;
+    return YF_OK;
+}
+int yf_trainer_workspace_bytes(yf_trainer t, int N, size_t* bytes)
+{
+    if (!t || !bytes || N <= 0) return fail(YF_E_INVALID, "yf_trainer_workspace_bytes: bad argument");
+    *bytes = trainer_ws(t, N, nullptr).bytes;
+    return YF_OK;
+}
+int yf_trainer_forward(yf_trainer t, const float* d_x, int N, const void* const* d_params, void* const* d_bn_buffers, float* d_head_large,
+                       float* d_head_small, void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!t || !d_x || !d_params || !d_head_large || !d_head_small || !d_ws || N <= 0) return fail(YF_E_INVALID, "yf_trainer_forward: bad argument");
+    const TWs w = trainer_ws(t, N, d_ws);
+    if (ws_bytes < w.bytes) return fail(YF_E_WORKSPACE, "yf_trainer_forward: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
+    for (int i = 0; i < t->n_params; ++i)
+        if (!d_params[i]) return fail(YF_E_INVALID, "yf_trainer_forward: parameter %d is null", i);
+    HIP_OK(hipSetDevice(t->device));
+    hipStream_t s = (hipStream_t)stream;
+    auto P = [&](int i) { return static_cast<const float*>(d_params[i]); };
+    int bn = 0;
+    for (int i = 0; i < kNumLayers; ++i) {
+        const LayerSpec& S = kLayers[i];
+        const TLayer& L = t->L[i];
+        const float* x = L.in == -1 ? d_x : L.in == -2 ? w.act + t->cat * N : w.act + t->L[L.in].y * N;
+        if (S.kind == K_HEAD) {
+            yf::launch_tconv_fwd(x, P(L.p0), P(L.p0 + 1), i == t->i_head4 ? d_head_large : d_head_small, N, L.Cin, L.Hin, L.Win, L.Cout, 1, 1, 0, s);
+            continue;
+        }
+        float* z = w.act + L.z * N;
+        float* y = w.act + L.y * N;
+        if (S.kind == K_DECONV) yf::launch_tdeconv_fwd(x, P(L.p0), z, N, L.Cin, L.Hin, L.Win, L.Cout, s);
+        else yf::launch_tconv_fwd(x, P(L.p0), nullptr, z, N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, s);
+        float* rm = d_bn_buffers ? static_cast<float*>(d_bn_buffers[2 * bn]) : nullptr;
+        float* rv = d_bn_buffers ? static_cast<float*>(d_bn_buffers[2 * bn + 1]) : nullptr;
+        ++bn;
+        yf::launch_tbn_fwd(z, P(L.p0 + 1), P(L.p0 + 2), rm, rv, w.stats + L.st, y, N, L.Cout, (long)L.Ho * L.Wo, S.relu, w.scratch, s);
+        if (L.res_from >= 0) {                                                  // out += residual                    yolo_fastest.py:65
+            const TLayer& R = t->L[L.res_from];
+            const float* r = R.in == -1 ? d_x : w.act + t->L[R.in].y * N;
+            yf::launch_tadd(y, r, y, (long)N * L.Cout * L.Ho * L.Wo, s);
+        }
+        if (i == t->i_deconv) {                                                 // torch.cat((conv4_2, deconv5_1), 1)        :209
+            const TLayer& A = t->L[t->i_conv4_2];
+            float* cat = w.act + t->cat * N;
+            const long HW = (long)A.Ho * A.Wo;
+            yf::launch_tslice(w.act + A.y * N, cat, N, A.Cout, HW, A.Cout, 0, A.Cout + L.Cout, 0, s);
+            yf::launch_tslice(y, cat, N, L.Cout, HW, L.Cout, 0, A.Cout + L.Cout, A.Cout, s);
+        }
+    }
+    HIP_OK(hipGetLastError());
+    return YF_OK;
+}
+int yf_trainer_backward(yf_trainer t, const float* d_x, const float* d_grad_head_large, const float* d_grad_head_small, int N,
+                        const void* const* d_params, void* const* d_grads, void* d_ws, size_t ws_bytes, void* stream)
+{
+    if (!t || !d_x || !d_grad_head_large || !d_grad_head_small || !d_params || !d_grads || !d_ws || N <= 0)
+        return fail(YF_E_INVALID, "yf_trainer_backward: bad argument");
+    const TWs w = trainer_ws(t, N, d_ws);
+    if (ws_bytes < w.bytes) return fail(YF_E_WORKSPACE, "yf_trainer_backward: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
+    for (int i = 0; i < t->n_params; ++i)
+        if (!d_params[i] || !d_grads[i]) return fail(YF_E_INVALID, "yf_trainer_backward: parameter / gradient %d is null", i);
+    HIP_OK(hipSetDevice(t->device));
+    hipStream_t s = (hipStream_t)stream;
+    auto P = [&](int i) { return static_cast<const float*>(d_params[i]); };
+    auto G = [&](int i) { return static_cast<float*>(d_grads[i]); };
+    const size_t sb = yf::train_scratch_bytes();
+    auto xin = [&](const TLayer& L) { return L.in == -1 ? d_x : L.in == -2 ? (const float*)(w.act + t->cat * N) : (const float*)(w.act + t->L[L.in].y * N); };
+    // gradient buffers: `cur` holds the gradient flowing backwards, `skip` a block's output gradient until the block's input is reached
+    int cur = 0, skip = -1;
+    auto other = [&](int a, int b, int c) { for (int i = 0; i < 4; ++i) if (i != a && i != b && i != c) return i; return -1; };
+    // backward of one conv + BN (+ ReLU) unit: gradient of its output in gy -> parameter gradients, gradient of its input in w.g[ret]
+    auto unit = [&](int i, const float* gy, bool need_dx) {
+        const LayerSpec& S = kLayers[i];
+        const TLayer& L = t->L[i];
+        const int iz = other(cur, skip, -1), ix = other(cur, skip, iz);
+        float* gz = w.g[iz];
+        yf::launch_tbn_bwd(w.act + L.z * N, gy, w.stats + L.st, P(L.p0 + 1), P(L.p0 + 2), G(L.p0 + 1), G(L.p0 + 2), gz, N, L.Cout, (long)L.Ho * L.Wo,
+                           S.relu, w.scratch, s);
+        if (S.kind == K_DECONV) {
+            yf::launch_tdeconv_bwd_weight(xin(L), gz, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, w.scratch, sb, s);
+            if (need_dx) yf::launch_tdeconv_bwd_data(gz, P(L.p0), w.g[ix], N, L.Cin, L.Hin, L.Win, L.Cout, s);
+        } else {
+            yf::launch_tconv_bwd_weight(xin(L), gz, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, w.scratch, sb, s);
+            if (need_dx) yf::launch_tconv_bwd_data(gz, P(L.p0), w.g[ix], N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, s);
+        }
+        return ix;
+    };
+    auto head = [&](int i, const float* gy) {                                  // nn.Conv2d(C, 24, 1) with bias
+        const TLayer& L = t->L[i];
+        const int ix = other(cur, skip, -1);
+        yf::launch_tconv_bwd_weight(xin(L), gy, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, 1, 1, 0, w.scratch, sb, s);
+        yf::launch_tchan_sum(gy, G(L.p0 + 1), N, L.Cout, (long)L.Hin * L.Win, s);
+        yf::launch_tconv_bwd_data(gy, P(L.p0), w.g[ix], N, L.Cin, L.Hin, L.Win, L.Cout, 1, 1, 0, s);
+        return ix;
+    };
+    // a run of layers hi .. lo (inclusive), backwards; the gradient of layer hi's output is in w.g[cur] on entry, the gradient of layer
+    // lo's input is in w.g[cur] on exit
+    auto run_back = [&](int hi, int lo, bool first_needs_dx) {
+        for (int i = hi; i >= lo; --i) {
+            const TLayer& L = t->L[i];
+            if (L.res_from >= 0) skip = cur;                                    // conv3 of a block: its output gradient also goes to the skip
+            const int nx = unit(i, w.g[cur], i > lo || first_needs_dx);
+            const bool block_input = skip >= 0 && i + 2 < kNumLayers && t->L[i + 2].res_from == i;       // conv1 of that block
+            cur = nx;
+            if (block_input) {
+                yf::launch_tadd(w.g[cur], w.g[skip], w.g[cur], (long)N * L.Cin * L.Hin * L.Win, s);
+                skip = -1;
+            }
+        }
+    };
+    const TLayer& A = t->L[t->i_conv4_2];
+    const TLayer& D = t->L[t->i_deconv];
+    const long HWa = (long)A.Ho * A.Wo;
+    // head_large branch: head_4, conv4_1_5 .. conv4_1_1, the concat                                   yolo_fastest.py:209-216
+    cur = head(t->i_head4, d_grad_head_large);
+    run_back(t->i_c415, t->i_c411, true);
+    yf::launch_tslice(w.g[cur], w.ga2, N, A.Cout, HWa, A.Cout + D.Cout, 0, A.Cout, 0, s);
+    yf::launch_tslice(w.g[cur], w.gd, N, D.Cout, HWa, A.Cout + D.Cout, A.Cout, D.Cout, 0, s);
+    {   // deconv5_1: gradient of conv5_2's output, first part
+        const int nx = unit(t->i_deconv, w.gd, true);
+        HIP_OK(hipMemcpyAsync(w.gb2, w.g[nx], t->gb2 * N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    // head_small branch: head_5, conv5_6 .. conv5_3                                                     :201-206
+    cur = head(t->i_head5, d_grad_head_small);
+    run_back(t->i_conv5_6, t->i_conv5_3, true);
+    yf::launch_tadd(w.g[cur], w.gb2, w.g[cur], (long)N * t->gb2, s);
+    run_back(t->i_conv5_2, t->i_conv4_3, true);                                  // conv5_2 .. conv4_3             :191-200
+    yf::launch_tadd(w.g[cur], w.ga2, w.g[cur], (long)N * t->ga2, s);
+    run_back(t->i_conv4_2, 0, false);                                            // conv4_2 .. conv0; the images need no gradient
     HIP_OK(hipGetLastError());
     return YF_OK;
 }

@@ -117,8 +117,7 @@ __global__ void __launch_bounds__(256) tpw_mfma_kernel(const float* __restrict__
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int K4 = K & ~3;
-#pragma unroll 4
-    for (int k0 = 0; k0 < K4; k0 += 4) {
+    for (int k0 = 0; k0 < K4; k0 += 4) {      // (four k-steps per trip with all loads up front was measured slower: 51 vs 44 us at batch 256)
         const int k = k0 + lk;
         const float av = ap[(long)k * sk];
 #pragma unroll
@@ -232,15 +231,13 @@ __global__ void __launch_bounds__(64) tconv_wgrad_mfma_kernel(const float* __res
     f32x4_t acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (long q0 = qb; q0 < qe; q0 += 16) {
+    auto load = [&](long q0, float4& av, float4* bv) {
         long q = q0 + 4 * lk;
         const bool qv = q < qe;                                       // q_per, Q multiples of 4
         if (!qv) q = qb;
         const long n = q / HWo, i = q - n * HWo;
-        float4 av = *reinterpret_cast<const float4*>(dy + (n * Cout + cr) * HWo + i);
+        av = *reinterpret_cast<const float4*>(dy + (n * Cout + cr) * HWo + i);
         if (!(qv && cv)) av = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 bv[4];
         if constexpr (KS == 1) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) bv[t] = *reinterpret_cast<const float4*>(x + (n * Cin + rci[t]) * HWo + i);
@@ -260,11 +257,26 @@ __global__ void __launch_bounds__(64) tconv_wgrad_mfma_kernel(const float* __res
                 bv[t] = make_float4(e[0], e[1], e[2], e[3]);
             }
         }
+    };
+    auto mac = [&](const float4& av, const float4* bv) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&av)[e], ((const float*)&bv[t])[e], acc[t], 0, 0, 0);
+    };
+    long q0 = qb;
+    for (; q0 + 16 < qe; q0 += 32) {                                  // two steps per trip: ten float4 loads in flight per lane
+        float4 a0, a1, b0[4], b1[4];
+        load(q0, a0, b0);
+        load(q0 + 16, a1, b1);
+        mac(a0, b0);
+        mac(a1, b1);
+    }
+    if (q0 < qe) {
+        float4 a0, b0[4];
+        load(q0, a0, b0);
+        mac(a0, b0);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -566,20 +578,6 @@ __global__ void __launch_bounds__(256) tdeconv_fwd_kernel(const float* __restric
     float s = 0.f;
     for (int ci = 0; ci < Cin; ++ci) s = fmaf(x[(((long)n * Cin + ci) * H + iy) * W + ix], w[(((long)ci * Cout + co) * 2 + dy_) * 2 + dx_], s);
     y[idx] = s;
-}
-
-__global__ void __launch_bounds__(256) tdeconv_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
-                                                               int N, int Cin, int H, int W, int Cout)
-{
-    const int Ho = 2 * H, Wo = 2 * W;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x, total = (long)N * Cin * H * W;
-    if (idx >= total) return;
-    const int ix = (int)(idx % W), iy = (int)((idx / W) % H), ci = (int)((idx / ((long)W * H)) % Cin), n = (int)(idx / ((long)W * H * Cin));
-    float s = 0.f;
-    for (int co = 0; co < Cout; ++co)
-        for (int q = 0; q < 4; ++q)
-            s = fmaf(dy[(((long)n * Cout + co) * Ho + 2 * iy + (q >> 1)) * Wo + 2 * ix + (q & 1)], w[((long)ci * Cout + co) * 4 + q], s);
-    dx[idx] = s;
 }
 
 __global__ void __launch_bounds__(256) tdeconv_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,

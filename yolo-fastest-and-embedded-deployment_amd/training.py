@@ -7,8 +7,10 @@
     loss.backward()                                      # backward of every layer -> param.grad
     optimizer.step()                                     # training.Adam (yf_train_adam_multi) -- or any torch optimizer
 
-`YoloFastest.forward` routes here when the module is in train mode.  Every operator is a HIP kernel behind the C ABI
-(`yf_train_*`, csrc/yf_train_kernels.hip): Conv2d / ConvTranspose2d forward, backward-data, backward-weight; BatchNorm2d in train
+`YoloFastest.forward` routes here when the module is in train mode.  Forward and backward of the whole network are ONE C call each
+(`yf_trainer_forward` / `yf_trainer_backward`: the graph walked in C++ over a workspace that is the pass's tape); `model.train_impl =
+"ops"` selects the same computation orchestrated from Python, one C call per block (bring-up, probing).  Every operator is a HIP
+kernel behind the C ABI (`yf_train_*`, csrc/yf_train_kernels.hip): Conv2d / ConvTranspose2d forward, backward-data, backward-weight; BatchNorm2d in train
 mode with its backward (ReLU fused); channel slices for the torch.cat; Adam.  torch.autograd only carries the gradient across the
 boundary (one Function for the whole network whose inputs are the parameters) -- no torch operator computes anything.
 NCHW fp32 like the reference, one C call per block (conv + BN [+ ReLU]) each way -- not the tuned inference engine (which folds
@@ -214,22 +216,100 @@ def train_backward(model, tape, g_hl, g_hs):
     return grads
 
 
+class _Trainer:
+    """yf_trainer handle for one (H, W, device): the whole forward / backward as one C call each (include/yolo_fastest_hip.h)."""
+
+    def __init__(self, H, W, device):
+        self.lib = _lib.lib()
+        self.dev = device.index if device.index is not None else torch.cuda.current_device()
+        self.handle = ctypes.c_void_p()
+        _lib.check(self.lib.yf_trainer_create(H, W, self.dev, ctypes.byref(self.handle)))
+        n, nb = ctypes.c_int(), ctypes.c_int()
+        _lib.check(self.lib.yf_trainer_num_params(self.handle, ctypes.byref(n), ctypes.byref(nb)))
+        self.n_params, self.n_bn = n.value, nb.value
+        self._bytes = {}
+
+    def workspace(self, N, device):
+        if N not in self._bytes:
+            need = ctypes.c_size_t()
+            _lib.check(self.lib.yf_trainer_workspace_bytes(self.handle, N, ctypes.byref(need)))
+            self._bytes[N] = need.value
+        return torch.empty(self._bytes[N], dtype=torch.uint8, device=device)     # one per forward: it is that pass's tape
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.yf_trainer_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def _trainer(model, H, W, device):
+    key = (H, W, device.index if device.index is not None else torch.cuda.current_device())
+    cache = model.__dict__.setdefault("_trainers", {})
+    if key not in cache:
+        cache[key] = _Trainer(H, W, device)
+    return cache[key]
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
 class _TrainForwardFn(torch.autograd.Function):
     """The whole network as one autograd node: inputs = the parameters, outputs = the two heads."""
 
     @staticmethod
     def forward(ctx, x, model, *params):
-        hl, hs, tape = train_forward(model, x)
-        ctx.model, ctx.tape, ctx.params = model, tape, params
+        if getattr(model, "train_impl", "trainer") == "ops":          # one C call per block, orchestrated here (kept for bring-up / probing)
+            hl, hs, tape = train_forward(model, x)
+            ctx.model, ctx.tape, ctx.params, ctx.tr = model, tape, params, None
+            return hl, hs
+        hl, hs, tr, ws = _trainer_forward(model, x, params)
+        ctx.model, ctx.tape, ctx.params, ctx.tr = model, (x, ws), params, tr
         return hl, hs
 
     @staticmethod
     def backward(ctx, g_hl, g_hs):
         if ctx.tape is None:
             raise RuntimeError("backward through the training forward a second time: its saved activations were freed")
-        grads = train_backward(ctx.model, ctx.tape, g_hl.contiguous(), g_hs.contiguous())
+        if ctx.tr is None:
+            grads = train_backward(ctx.model, ctx.tape, g_hl.contiguous(), g_hs.contiguous())
+            ctx.tape = None
+            return (None, None) + tuple(grads[p] for p in ctx.params)
+        x, ws = ctx.tape
+        tr, params = ctx.tr, ctx.params
+        g_hl, g_hs = g_hl.contiguous().float(), g_hs.contiguous().float()
+        sizes = [p.numel() for p in params]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=x.device)
+        grads = [g.view_as(p) for g, p in zip(flat.split(sizes), params)]
+        _lib.check(tr.lib.yf_trainer_backward(tr.handle, x.data_ptr(), g_hl.data_ptr(), g_hs.data_ptr(), x.shape[0], _ptr_array(params),
+                                              _ptr_array(grads), ws.data_ptr(), ws.numel(),
+                                              ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
         ctx.tape = None
-        return (None, None) + tuple(grads[p] for p in ctx.params)
+        return (None, None) + tuple(grads)
+
+
+def _trainer_forward(model, x, params):
+    N, _, H, W = x.shape
+    tr = _trainer(model, H, W, x.device)
+    if len(params) != tr.n_params:
+        raise RuntimeError("the model has %d parameters, the trainer expects %d" % (len(params), tr.n_params))
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    if len(bns) != tr.n_bn:
+        raise RuntimeError("the model has %d BatchNorm layers, the trainer expects %d" % (len(bns), tr.n_bn))
+    bufs = None
+    if all(b.running_mean is not None for b in bns):
+        bufs = (ctypes.c_void_p * (2 * len(bns)))(*[t.data_ptr() for b in bns for t in (b.running_mean, b.running_var)])
+    hl = torch.empty((N, model.num_out, H // 16, W // 16), dtype=torch.float32, device=x.device)
+    hs = torch.empty((N, model.num_out, H // 32, W // 32), dtype=torch.float32, device=x.device)
+    ws = tr.workspace(N, x.device)
+    _lib.check(tr.lib.yf_trainer_forward(tr.handle, x.data_ptr(), N, _ptr_array(params), bufs, hl.data_ptr(), hs.data_ptr(), ws.data_ptr(),
+                                         ws.numel(), ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+    nbt = [b.num_batches_tracked for b in bns if b.num_batches_tracked is not None]
+    if nbt:
+        torch._foreach_add_(nbt, 1)
+    return hl, hs, tr, ws
 
 
 def forward(model, x):
@@ -245,7 +325,10 @@ def forward(model, x):
     x = x.contiguous().float()
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         return _TrainForwardFn.apply(x, model, *params)
-    hl, hs, _ = train_forward(model, x)
+    if getattr(model, "train_impl", "trainer") == "ops":
+        hl, hs, _ = train_forward(model, x)
+    else:
+        hl, hs, _, _ = _trainer_forward(model, x, tuple(params))
     return hl, hs
 
 
