@@ -120,7 +120,7 @@ def test_conv_backward_weight_long_reduction(ops, dev):
 
 def test_deconv_forward_backward_match_torch(ops, dev):
     rng = np.random.default_rng(9)
-    for N, Cin, Cout, H, W in ((2, 96, 96, 4, 5), (3, 5, 7, 3, 3), (16, 96, 96, 8, 10), (5, 20, 70, 6, 6)):
+    for N, Cin, Cout, H, W in ((2, 96, 96, 4, 5), (3, 5, 7, 3, 3), (16, 96, 96, 8, 10), (5, 20, 70, 6, 6), (64, 12, 20, 12, 12), (120, 96, 96, 8, 10)):
         x = rng.normal(size=(N, Cin, H, W)).astype(np.float32)
         w = rng.normal(size=(Cin, Cout, 2, 2)).astype(np.float32)
         xt = torch.from_numpy(x).double().requires_grad_(True)
@@ -143,7 +143,7 @@ def test_deconv_forward_backward_match_torch(ops, dev):
 @pytest.mark.parametrize("relu", [0, 1])
 def test_batchnorm_train_mode_matches_torch(ops, dev, relu):
     rng = np.random.default_rng(11 + relu)
-    for N, C, H, W in ((4, 8, 9, 7), (16, 136, 4, 5), (2, 3, 1, 1), (16, 8, 64, 80), (3, 232, 20, 16)):
+    for N, C, H, W in ((4, 8, 9, 7), (16, 136, 4, 5), (2, 3, 1, 1), (16, 8, 64, 80), (3, 232, 20, 16), (40, 5, 30, 30), (16, 24, 40, 32)):
         x = (rng.normal(size=(N, C, H, W)) * rng.uniform(0.5, 3, (1, C, 1, 1)) + rng.normal(size=(1, C, 1, 1))).astype(np.float32)
         gamma, beta = rng.normal(1, 0.3, C).astype(np.float32), rng.normal(0, 0.5, C).astype(np.float32)
         rm, rv = rng.normal(size=C).astype(np.float32), rng.uniform(0.5, 2, C).astype(np.float32)
