@@ -74,3 +74,37 @@ def test_all_gather_two_ranks_equals_unsharded():
         for p in ps:
             p.join(60)
         assert res == [(0, True), (1, True)]
+
+
+def _worker_grad(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(7)
+    both = torch.randn((world, 1000), generator=g)                 # every rank can compute what the others hold
+    flat = both[rank].clone()
+    views = flat.split([300, 700])                                  # parameter gradients are views of the flat buffer
+    yfd.all_reduce_mean_(flat)
+    ok = torch.allclose(flat, both.mean(0), atol=1e-7) and torch.allclose(torch.cat(views), both.mean(0), atol=1e-7)
+    lin = torch.nn.Linear(3, 2)
+    with torch.no_grad():
+        lin.weight.fill_(float(rank + 1))
+    yfd.broadcast_model_(lin)
+    ok = ok and bool((lin.weight == 1.0).all())
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_training_gradient_exchange_two_ranks():
+    """training.data_parallel's exchange step on gloo, world size 2: one all-reduce of the flat gradient buffer leaves the mean in every
+    parameter's view on both ranks; parameters start from rank 0's."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker_grad, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+    assert res == [(0, True), (1, True)]

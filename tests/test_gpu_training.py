@@ -657,3 +657,34 @@ def test_trainer_is_identical_to_the_per_block_path(yf, golden, dev):
     (h1b[0].sum() + h1b[1].sum()).backward()
     for p, g in zip(m2.parameters(), g1):
         assert torch.equal(p.grad, g)
+
+
+def test_data_parallel_training_single_rank_rccl(yf, golden, dev):
+    """training.data_parallel on the real backend: a 1-rank RCCL group (the box has one GPU) runs the broadcast and the all-reduce of the
+    flat gradient buffer; with one rank the gradients are unchanged.  The 2-rank arithmetic is covered on gloo (tests/test_dist_gloo.py)."""
+    import torch.distributed as dist
+    from yolo_fastest_amd import training
+    gt = golden("golden_train_256")
+    x = ((torch.from_numpy(gt["input_u8"][:4].astype(np.float32))[:, None] - 128.0) / 255.0).to(dev)
+
+    def grads(dp):
+        m = yf.YoloFastest(yf.io_params_for(256)).to(dev)
+        m.load_state_dict(torch.load(WEIGHTS, map_location=dev))
+        m.train()
+        if dp:
+            training.data_parallel(m)
+        hl, hs = m(x)
+        (hl.sum() + hs.sum()).backward()
+        return [p.grad.clone() for p in m.parameters()]
+    want = grads(False)
+    with pytest.raises(RuntimeError):
+        training.data_parallel(yf.YoloFastest(yf.io_params_for(256)).to(dev))      # no process group yet
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1, device_id=dev)
+    try:
+        got = grads(True)
+        torch.cuda.synchronize(dev)
+    finally:
+        dist.destroy_process_group()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)

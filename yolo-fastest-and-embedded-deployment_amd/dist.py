@@ -75,3 +75,22 @@ def all_gather_detections_async(raw, n_total, group=None):
 def all_gather_detections(raw, n_total, group=None):
     """Every rank contributes its shard's records; every rank gets all n_total frames in frame order."""
     return all_gather_detections_async(raw, n_total, group).wait()
+
+
+def all_reduce_mean_(flat, group=None):
+    """Data-parallel TRAINING's one exchange step: the gradients of all parameters live in one flat buffer (training.py allocates them
+    so), so a step needs ONE all-reduce (RCCL: ring over xGMI; 1.3 MB for this network -- latency-bound) and a scale by 1 / world.
+    In place; returns `flat`."""
+    world = dist.get_world_size(group)
+    if world > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.mul_(1.0 / world)
+    return flat
+
+
+def broadcast_model_(model, src=0, group=None):
+    """Every rank starts from rank `src`'s parameters and buffers (what torch's DistributedDataParallel does at construction)."""
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t, src=src, group=group)
+    return model

@@ -287,6 +287,10 @@ class _TrainForwardFn(torch.autograd.Function):
                                               _ptr_array(grads), ws.data_ptr(), ws.numel(),
                                               ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
         ctx.tape = None
+        sync = getattr(ctx.model, "_grad_sync", None)
+        if sync is not None:                                     # data_parallel(): one all-reduce of the flat gradient buffer
+            from . import dist as yfd
+            yfd.all_reduce_mean_(flat, sync[0])
         return (None, None) + tuple(grads)
 
 
@@ -330,6 +334,22 @@ def forward(model, x):
     else:
         hl, hs, _, _ = _trainer_forward(model, x, tuple(params))
     return hl, hs
+
+
+def data_parallel(model, process_group=None, broadcast=True):
+    """One process per GPU (torch.distributed, backend "nccl" = RCCL): every rank trains on its shard of the batch; after this call
+    `loss.backward()` averages the gradients over the ranks with ONE all-reduce of the flat gradient buffer before they reach
+    `param.grad` (the semantics of torch's DistributedDataParallel: BatchNorm statistics stay per rank), and the parameters and
+    buffers are broadcast from rank 0 once.  The reference has no distributed training; with one rank this changes nothing."""
+    import torch.distributed as tdist
+    if not tdist.is_initialized():
+        raise RuntimeError("initialise torch.distributed first (one process per GPU)")
+    from . import dist as yfd
+    if broadcast:
+        yfd.broadcast_model_(model, 0, process_group)
+    model._grad_sync = (process_group,)
+    model.train_impl = "trainer"
+    return model
 
 
 class Adam(torch.optim.Optimizer):
