@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
     __shared__ __attribute__((aligned(16))) float E[EC * PLANE];
     __shared__ __attribute__((aligned(16))) float X[XFLOATS];
 
-    const int b = blockIdx.x;
+    const int b = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = b % a.tiles_x, ty = (b / a.tiles_x) % a.tiles_y, n = b / (a.tiles_x * a.tiles_y);
     const int oy0 = ty * TH, ox0 = tx * TW, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
     const int wave = wave_id(), lane = threadIdx.x & 63;
@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(256) k19_kernel(K19Args a)
     constexpr int NE = RH * RWE, NO = RH * RWO, NR = NE + NO;    // records (pixels) in the even / odd plane
     __shared__ __attribute__((aligned(16))) float A[NR * CH];
 
-    const int b = blockIdx.x;
+    const int b = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = b % a.tiles_x, ty = (b / a.tiles_x) % a.tiles_y, n = b / (a.tiles_x * a.tiles_y);
     const int oy0 = ty * T, ox0 = tx * T;
     const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;  // region origin in stride-2 coordinates

@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
         }
     };
 
-    int t = blockIdx.x;  // grid <= total
+    int t = xcd_tile(blockIdx.x, gridDim.x);  // grid <= total; XCD x walks the contiguous runs [x * grid / 8, (x + 1) * grid / 8) + k * grid
     const int step = gridDim.x;
     // ---- prologue: region of the first tile -> buffer 0; input elements of the second tile on their way ----
     {

@@ -61,6 +61,25 @@ __device__ __forceinline__ void split_f16x4(float a0, float a1, float a2, float 
 }
 #endif
 
+// Workgroups are dealt round-robin to the 8 XCDs of the chip (block i -> XCD i % 8), each with its own L2.  xcd_tile() gives XCD x the
+// CONTIGUOUS range [x * per, (x + 1) * per) of logical tiles, so that neighbouring tiles of a frame -- which share halo rows and
+// columns -- are fetched through one L2 instead of up to eight.  The ragged tail (grid % 8) keeps its index.  -DYF_XCD_SWIZZLE=0: off.
+#ifndef YF_XCD_SWIZZLE
+#define YF_XCD_SWIZZLE 1
+#endif
+#ifdef __HIPCC__
+__device__ __forceinline__ int xcd_tile(unsigned b, unsigned nb)
+{
+#if YF_XCD_SWIZZLE
+    const unsigned per = nb >> 3, main = per << 3;
+    return b < main ? (int)((b & 7) * per + (b >> 3)) : (int)b;
+#else
+    (void)nb;
+    return (int)b;
+#endif
+}
+#endif
+
 // hipFuncSetAttribute (dynamic LDS above 64 KiB) and the CU count belong to (kernel, DEVICE), not to the process: launchers keep
 // their "done once" state per device so that a second GPU in the same process gets the attribute too.
 enum { YF_MAX_DEVICES = 64 };

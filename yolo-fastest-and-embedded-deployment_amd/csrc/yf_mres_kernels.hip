@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
     float* WL = E + 16 * EPL;             // the block's whole weight stream (NCH chunks + b2), staged once
     constexpr int WFLOATS = (NCH * CHUNK + COUT + 3) & ~3;
 
-    const int b = blockIdx.x;
+    const int b = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = b % a.tiles_x, ty = (b / a.tiles_x) % a.tiles_y, n = b / (a.tiles_x * a.tiles_y);
     const int oy0 = ty * TH, ox0 = tx * TW;   // output coordinates
     const int Ho = a.H / S, Wo = a.W / S;
@@ -456,7 +456,7 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
     float* WL = E + 2 * 16 * EPL;          // weight stream
     constexpr int WFLOATS = (NCH * CHUNK + COUT + 3) & ~3;
 
-    const int b = blockIdx.x;
+    const int b = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = b % a.tiles_x, ty = (b / a.tiles_x) % a.tiles_y, n = b / (a.tiles_x * a.tiles_y);
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
