@@ -13,8 +13,9 @@
 kernel behind the C ABI (`yf_train_*`, csrc/yf_train_kernels.hip): Conv2d / ConvTranspose2d forward, backward-data, backward-weight; BatchNorm2d in train
 mode with its backward (ReLU fused); channel slices for the torch.cat; Adam.  torch.autograd only carries the gradient across the
 boundary (one Function for the whole network whose inputs are the parameters) -- no torch operator computes anything.
-NCHW fp32 like the reference, one C call per block (conv + BN [+ ReLU]) each way -- not the tuned inference engine (which folds
-BatchNorm into the weights and so cannot train); kernels and measurements: DESIGN.md section 4 "The training step".  No CPU path.
+NCHW fp32 like the reference -- not the tuned inference engine (which folds BatchNorm into the weights and so cannot train); kernels
+and measurements: DESIGN.md section 4 "The training step".  `train()` is the reference's epoch loop around the iteration,
+`data_parallel()` the one-all-reduce gradient exchange for one process per GPU.  No CPU path.
 """
 import ctypes
 
