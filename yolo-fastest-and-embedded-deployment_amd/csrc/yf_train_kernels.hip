@@ -98,9 +98,12 @@ __global__ void __launch_bounds__(256) tpw_mfma_kernel(const float* __restrict__
                                                        float* __restrict__ y, long Q, long HW, int M, int K, long sm, long sk)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
-    const int m0 = (blockIdx.y * 4 + wave) * 16;
+    // 1-D grid in XCD-contiguous order with the channel tile fastest: the workgroups that read the same 16 NT pixels (all channel
+    // tiles of that pixel tile) run on one XCD and share its L2
+    const unsigned my = (unsigned)((M + 63) / 64), lb = (unsigned)xcd_tile(blockIdx.x, gridDim.x);
+    const int m0 = (int)((lb % my) * 4 + wave) * 16;
     if (m0 >= M) return;
-    const long q0 = (long)blockIdx.x * (16 * NT);
+    const long q0 = (long)(lb / my) * (16 * NT);
     // no predication inside the k loop: out-of-range pixels and rows read a valid (clamped) address and are not stored; the k tail
     // multiplies a clamped B element by an A element forced to zero
     const float* xp[NT];
@@ -211,11 +214,14 @@ __global__ void __launch_bounds__(64) tconv_wgrad_mfma_kernel(const float* __res
                                                               long part_stride)
 {
     const int lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
-    const int c0 = blockIdx.y * 16, r0 = blockIdx.z * 64;
     constexpr int KK = KS * KS, PAD = (KS - 1) / 2;
     const int R = Cin * KK;
+    // 1-D grid in XCD-contiguous order, tiles fastest: the waves of one pixel slice (they all read the same rows of dY and X) share an L2
+    const unsigned nct = (unsigned)((Cout + 15) / 16), nrt = (unsigned)((R + 63) / 64), lb = (unsigned)xcd_tile(blockIdx.x, gridDim.x);
+    const unsigned slice = lb / (nct * nrt), tile = lb - slice * (nct * nrt);
+    const int c0 = (int)(tile % nct) * 16, r0 = (int)(tile / nct) * 64;
     const long HWo = (long)Ho * Wo, Q = (long)N * HWo;
-    const long qb = (long)blockIdx.x * q_per, qe = qb + q_per < Q ? qb + q_per : Q;
+    const long qb = (long)slice * q_per, qe = qb + q_per < Q ? qb + q_per : Q;
     const int cr = c0 + lr < Cout ? c0 + lr : Cout - 1;
     const bool cv = c0 + lr < Cout;
     int rci[4], rky[4], rkx[4];
@@ -283,7 +289,7 @@ __global__ void __launch_bounds__(64) tconv_wgrad_mfma_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = c0 + lk * 4 + r, rr = r0 + 16 * t + lr;
-            if (co < Cout && rr < R) dw[(long)blockIdx.x * part_stride + (long)co * R + rr] = acc[t][r];
+            if (co < Cout && rr < R) dw[(long)slice * part_stride + (long)co * R + rr] = acc[t][r];
         }
 }
 
@@ -929,9 +935,9 @@ static void launch_tpw_gemm(const float* x, const float* a, const float* bias, f
 {
     const unsigned my = (unsigned)((M + 63) / 64);
     if (((Q + 63) / 64) * my >= 512)
-        hipLaunchKernelGGL(tpw_mfma_kernel<4>, dim3((unsigned)((Q + 63) / 64), my), dim3(256), 0, s, x, a, bias, y, Q, HW, M, K, sm, sk);
+        hipLaunchKernelGGL(tpw_mfma_kernel<4>, dim3((unsigned)((Q + 63) / 64) * my), dim3(256), 0, s, x, a, bias, y, Q, HW, M, K, sm, sk);
     else
-        hipLaunchKernelGGL(tpw_mfma_kernel<1>, dim3((unsigned)((Q + 15) / 16), my), dim3(256), 0, s, x, a, bias, y, Q, HW, M, K, sm, sk);
+        hipLaunchKernelGGL(tpw_mfma_kernel<1>, dim3((unsigned)((Q + 15) / 16) * my), dim3(256), 0, s, x, a, bias, y, Q, HW, M, K, sm, sk);
 }
 void launch_tconv_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W, int Cout, int k, int stride,
                       int depthwise, hipStream_t s)
@@ -1010,7 +1016,7 @@ void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, 
         q_per = (q_per + 15) / 16 * 16;
         nsplit = (P + q_per - 1) / q_per;
         float* out = nsplit > 1 ? (float*)scratch : dw;
-        const dim3 grid((unsigned)nsplit, (Cout + 15) / 16, (R + 63) / 64);
+        const dim3 grid((unsigned)(nsplit * tiles));
         if (k == 1)
             hipLaunchKernelGGL(tconv_wgrad_mfma_kernel<1>, grid, dim3(64), 0, s, x, dy, out, N, Cin, H, W, Cout, Ho, Wo, stride, q_per, nw);
         else
@@ -1078,7 +1084,7 @@ void launch_tdeconv_bwd_weight(const float* x, const float* dy, float* dw, int N
         q_per = (q_per + 15) / 16 * 16;
         nsplit = (P + q_per - 1) / q_per;
         float* out = nsplit > 1 ? (float*)scratch : dw;
-        hipLaunchKernelGGL(tconv_wgrad_mfma_kernel<2>, dim3((unsigned)nsplit, (Cin + 15) / 16, (R + 63) / 64), dim3(64), 0, s, dy, x, out, N, Cout, 2 * H,
+        hipLaunchKernelGGL(tconv_wgrad_mfma_kernel<2>, dim3((unsigned)(nsplit * tiles)), dim3(64), 0, s, dy, x, out, N, Cout, 2 * H,
                            2 * W, Cin, H, W, 2, q_per, nw);
         if (nsplit > 1) tsum_partials(out, nsplit, nw, dw, s);
         return;
