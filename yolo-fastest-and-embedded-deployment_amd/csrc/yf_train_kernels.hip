@@ -237,6 +237,8 @@ __global__ void __launch_bounds__(64) tconv_wgrad_mfma_kernel(const float* __res
     f32x4_t acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int ntu = (R - r0 + 15) / 16;            // 16-row tiles of Xcol this wave really has (wave-uniform): the layers with the most pixels
+                                                   // have the fewest channels, and loading / multiplying three tiles of clamped rows is what they cost
     auto load = [&](long q0, float4& av, float4* bv) {
         long q = q0 + 4 * lk;
         const bool qv = q < qe;                                       // q_per, Q multiples of 4
@@ -246,13 +248,15 @@ __global__ void __launch_bounds__(64) tconv_wgrad_mfma_kernel(const float* __res
         if (!(qv && cv)) av = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (KS == 1) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bv[t] = *reinterpret_cast<const float4*>(x + (n * Cin + rci[t]) * HWo + i);
+            for (int t = 0; t < 4; ++t)
+                if (t < ntu) bv[t] = *reinterpret_cast<const float4*>(x + (n * Cin + rci[t]) * HWo + i);
         } else {
             int oyj[4], oxj[4];                                     // the 4 pixels may straddle rows (Wo % 4 != 0)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { oyj[j] = (int)((i + j) / Wo); oxj[j] = (int)(i + j - (long)oyj[j] * Wo); }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+                if (t >= ntu) continue;
                 const float* xc = x + (n * Cin + rci[t]) * H * W;
                 float e[4];
 #pragma unroll
@@ -269,7 +273,7 @@ __global__ void __launch_bounds__(64) tconv_wgrad_mfma_kernel(const float* __res
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&av)[e], ((const float*)&bv[t])[e], acc[t], 0, 0, 0);
+                if (t < ntu) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&av)[e], ((const float*)&bv[t])[e], acc[t], 0, 0, 0);
     };
     long q0 = qb;
     for (; q0 + 16 < qe; q0 += 32) {                                  // two steps per trip: ten float4 loads in flight per lane
