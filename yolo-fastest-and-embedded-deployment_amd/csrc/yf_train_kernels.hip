@@ -93,6 +93,7 @@ __global__ void __launch_bounds__(256) tconv_mc_kernel(const float* __restrict__
 // One wave = 16 output channels x 64 pixels (four 16x16 tiles sharing the A fragment); a workgroup = 4 waves on 4 channel tiles.
 // MFMA operand layout: A lane l = (row l % 16, k l / 16); B lane l = (k l / 16, col l % 16); D lane l = rows 4 (l / 16) + i, col l % 16.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__host__ __device__ inline int tpw_waves_m(int M) { return M > 32 ? 4 : M > 16 ? 2 : 1; }
 template <int NT>   // NT 16-pixel tiles per wave: 4 for large maps, 1 when there are few pixels (more waves in flight)
 __global__ void __launch_bounds__(256) tpw_mfma_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ bias,
                                                        float* __restrict__ y, long Q, long HW, int M, int K, long sm, long sk)
@@ -100,10 +101,12 @@ __global__ void __launch_bounds__(256) tpw_mfma_kernel(const float* __restrict__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
     // 1-D grid in XCD-contiguous order with the channel tile fastest: the workgroups that read the same 16 NT pixels (all channel
     // tiles of that pixel tile) run on one XCD and share its L2
-    const unsigned my = (unsigned)((M + 63) / 64), lb = (unsigned)xcd_tile(blockIdx.x, gridDim.x);
-    const int m0 = (int)((lb % my) * 4 + wave) * 16;
+    // the 4 waves of a workgroup: wm of them along the channels, 4 / wm along the pixels (few channels: all four on pixels, no idle wave)
+    const int wm = tpw_waves_m(M), wq = 4 / wm;
+    const unsigned my = (unsigned)((M + 16 * wm - 1) / (16 * wm)), lb = (unsigned)xcd_tile(blockIdx.x, gridDim.x);
+    const int m0 = (int)((lb % my) * wm + (wave % wm)) * 16;
     if (m0 >= M) return;
-    const long q0 = (long)(lb / my) * (16 * NT);
+    const long q0 = ((long)(lb / my) * wq + wave / wm) * (16 * NT);
     // no predication inside the k loop: out-of-range pixels and rows read a valid (clamped) address and are not stored; the k tail
     // multiplies a clamped B element by an A element forced to zero
     const float* xp[NT];
@@ -937,11 +940,13 @@ static inline unsigned nblk(long total) { return (unsigned)((total + 255) / 256)
 
 static void launch_tpw_gemm(const float* x, const float* a, const float* bias, float* y, long Q, long HW, int M, int K, long sm, long sk, hipStream_t s)
 {
-    const unsigned my = (unsigned)((M + 63) / 64);
-    if (((Q + 63) / 64) * my >= 512)
-        hipLaunchKernelGGL(tpw_mfma_kernel<4>, dim3((unsigned)((Q + 63) / 64) * my), dim3(256), 0, s, x, a, bias, y, Q, HW, M, K, sm, sk);
+    const int wm = tpw_waves_m(M), wq = 4 / wm;
+    const unsigned my = (unsigned)((M + 16 * wm - 1) / (16 * wm));
+    const long b4 = (Q + 64L * wq - 1) / (64L * wq), b1 = (Q + 16L * wq - 1) / (16L * wq);     // workgroups along the pixels, NT = 4 / 1
+    if (b4 * my >= 512)
+        hipLaunchKernelGGL(tpw_mfma_kernel<4>, dim3((unsigned)(b4 * my)), dim3(256), 0, s, x, a, bias, y, Q, HW, M, K, sm, sk);
     else
-        hipLaunchKernelGGL(tpw_mfma_kernel<1>, dim3((unsigned)((Q + 15) / 16) * my), dim3(256), 0, s, x, a, bias, y, Q, HW, M, K, sm, sk);
+        hipLaunchKernelGGL(tpw_mfma_kernel<1>, dim3((unsigned)(b1 * my)), dim3(256), 0, s, x, a, bias, y, Q, HW, M, K, sm, sk);
 }
 void launch_tconv_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W, int Cout, int k, int stride,
                       int depthwise, hipStream_t s)
