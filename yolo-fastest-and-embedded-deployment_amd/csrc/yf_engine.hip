@@ -1044,7 +1044,7 @@ int yf_train_scratch_bytes(size_t* bytes)
 int yf_train_bn_forward(int device, const float* d_x, const float* d_gamma, const float* d_beta, float* d_running_mean, float* d_running_var,
                         float* d_stats, float* d_y, int N, int C, long HW, int relu, void* d_scratch, void* stream)
 {
-    YF_TOP(d_x && d_gamma && d_beta && d_stats && d_y && d_scratch && N > 0 && N <= 65535 && C > 0 && C <= 256 && HW > 0,
+    YF_TOP(d_x && d_gamma && d_beta && d_stats && d_y && d_scratch && N > 0 && C > 0 && C <= 256 && HW > 0,
            yf::launch_tbn_fwd(d_x, d_gamma, d_beta, d_running_mean, d_running_var, d_stats, d_y, N, C, HW, relu, d_scratch, (hipStream_t)stream));
 }
 int yf_train_bn_backward(int device, const float* d_x, const float* d_dy, const float* d_stats, const float* d_gamma, const float* d_beta,

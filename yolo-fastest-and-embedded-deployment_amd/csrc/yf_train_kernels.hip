@@ -401,15 +401,15 @@ __global__ void __launch_bounds__(256) tconv3s2_bwd_data_kernel(const float* __r
     }
 }
 
-// ---- depthwise convolution, one (frame, channel) plane per blockIdx.y so that the KS*KS weights are wave-uniform; a thread computes 4
+// ---- depthwise convolution, one (frame, channel) plane per blockIdx.x so that the KS*KS weights are wave-uniform; a thread computes 4
 // consecutive outputs of a row (Wo % 4 == 0) from the KS x (3 S + KS) input window.  FLIP: the weights reversed -- the backward-data
 // of a stride-1 depthwise conv is the same conv of dY with the flipped kernel. ----
 template <int KS, int S, bool FLIP>
 __global__ void tdw_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int C, int H, int W, int Ho, int Wo)
 {
     constexpr int KK = KS * KS, PAD = (KS - 1) / 2, WIN = 3 * S + KS;
-    const int plane = blockIdx.y, c = plane % C;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x, per_row = Wo / 4;
+    const int plane = blockIdx.x, c = plane % C;                    // planes in x (N * C may exceed 65535), the plane's thread chunks in y
+    const int t = blockIdx.y * blockDim.x + threadIdx.x, per_row = Wo / 4;
     if (t >= Ho * per_row) return;
     const int oy = t / per_row, ox0 = (t - oy * per_row) * 4;
     const float* xp = x + (long)plane * H * W;
@@ -439,8 +439,8 @@ __global__ void tdw_conv_kernel(const float* __restrict__ x, const float* __rest
 // backward-data of the depthwise 3x3 stride-2 pad-1 convolution: one thread = the 2x2 input block (2a.., 2b..), see tconv3s2_bwd_data_kernel
 __global__ void tdw3s2_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int C, int Ho, int Wo)
 {
-    const int plane = blockIdx.y, c = plane % C;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int plane = blockIdx.x, c = plane % C;
+    const int t = blockIdx.y * blockDim.x + threadIdx.x;
     if (t >= Ho * Wo) return;
     const int a = t / Wo, b = t - a * Wo;
     const bool vb = b + 1 < Wo, va = a + 1 < Ho;
@@ -457,7 +457,7 @@ template <int KS, int S, bool FLIP>
 static void launch_tdw_conv(const float* x, const float* w, float* y, int N, int C, int H, int W, int Ho, int Wo, hipStream_t s)
 {
     const int threads = Ho * (Wo / 4), bs = threads <= 64 ? 64 : 256;
-    hipLaunchKernelGGL((tdw_conv_kernel<KS, S, FLIP>), dim3((threads + bs - 1) / bs, N * C), dim3(bs), 0, s, x, w, y, C, H, W, Ho, Wo);
+    hipLaunchKernelGGL((tdw_conv_kernel<KS, S, FLIP>), dim3(N * C, (threads + bs - 1) / bs), dim3(bs), 0, s, x, w, y, C, H, W, Ho, Wo);
 }
 
 // ---- Conv2d backward with respect to the input ----
@@ -971,7 +971,7 @@ void launch_tconv_fwd(const float* x, const float* w, const float* bias, float* 
                                (long)Cin * k * k, (long)k * k);
         return;
     }
-    if (depthwise && !bias && Wo % 4 == 0 && (long)N * Cout <= 65535) {
+    if (depthwise && !bias && Wo % 4 == 0) {
         if (k == 3 && stride == 1) return launch_tdw_conv<3, 1, false>(x, w, y, N, Cout, H, W, Ho, Wo, s);
         if (k == 3 && stride == 2) return launch_tdw_conv<3, 2, false>(x, w, y, N, Cout, H, W, Ho, Wo, s);
         if (k == 5 && stride == 1) return launch_tdw_conv<5, 1, false>(x, w, y, N, Cout, H, W, Ho, Wo, s);
@@ -990,12 +990,12 @@ void launch_tconv_bwd_data(const float* dy, const float* w, float* dx, int N, in
         hipLaunchKernelGGL(tconv3s2_bwd_data_kernel<8>, dim3(nblk((long)N * Ho * Wo), (Cin + 7) / 8), dim3(256), 0, s, dy, w, dx, N, Cin, Cout, Ho, Wo);
         return;
     }
-    if (depthwise && (long)N * Cin <= 65535) {
+    if (depthwise) {
         if (stride == 1 && W % 4 == 0 && k == 3) return launch_tdw_conv<3, 1, true>(dy, w, dx, N, Cin, H, W, H, W, s);
         if (stride == 1 && W % 4 == 0 && k == 5) return launch_tdw_conv<5, 1, true>(dy, w, dx, N, Cin, H, W, H, W, s);
         if (stride == 2 && k == 3 && H == 2 * Ho && W == 2 * Wo) {
             const int threads = Ho * Wo, bs = threads <= 64 ? 64 : 256;
-            hipLaunchKernelGGL(tdw3s2_bwd_data_kernel, dim3((threads + bs - 1) / bs, N * Cin), dim3(bs), 0, s, dy, w, dx, Cin, Ho, Wo);
+            hipLaunchKernelGGL(tdw3s2_bwd_data_kernel, dim3(N * Cin, (threads + bs - 1) / bs), dim3(bs), 0, s, dy, w, dx, Cin, Ho, Wo);
             return;
         }
     }
