@@ -1189,12 +1189,12 @@ int yf_trainer_forward(yf_trainer t, const float* d_x, int N, const void* const*
         float* rm = d_bn_buffers ? static_cast<float*>(d_bn_buffers[2 * bn]) : nullptr;
         float* rv = d_bn_buffers ? static_cast<float*>(d_bn_buffers[2 * bn + 1]) : nullptr;
         ++bn;
-        yf::launch_tbn_fwd(z, P(L.p0 + 1), P(L.p0 + 2), rm, rv, w.stats + L.st, y, N, L.Cout, (long)L.Ho * L.Wo, S.relu, w.scratch, s);
-        if (L.res_from >= 0) {                                                  // out += residual                    yolo_fastest.py:65
+        const float* residual = nullptr;                                        // out += residual, fused into the BatchNorm pass   yolo_fastest.py:65
+        if (L.res_from >= 0) {
             const TLayer& R = t->L[L.res_from];
-            const float* r = R.in == -1 ? d_x : w.act + t->L[R.in].y * N;
-            yf::launch_tadd(y, r, y, (long)N * L.Cout * L.Ho * L.Wo, s);
+            residual = R.in == -1 ? d_x : w.act + t->L[R.in].y * N;
         }
+        yf::launch_tbn_fwd(z, P(L.p0 + 1), P(L.p0 + 2), rm, rv, w.stats + L.st, y, N, L.Cout, (long)L.Ho * L.Wo, S.relu, w.scratch, s, residual);
         if (i == t->i_deconv) {                                                 // torch.cat((conv4_2, deconv5_1), 1)        :209
             const TLayer& A = t->L[t->i_conv4_2];
             float* cat = w.act + t->cat * N;
@@ -1225,7 +1225,7 @@ int yf_trainer_backward(yf_trainer t, const float* d_x, const float* d_grad_head
     int cur = 0, skip = -1;
     auto other = [&](int a, int b, int c) { for (int i = 0; i < 4; ++i) if (i != a && i != b && i != c) return i; return -1; };
     // backward of one conv + BN (+ ReLU) unit: gradient of its output in gy -> parameter gradients, gradient of its input in w.g[ret]
-    auto unit = [&](int i, const float* gy, bool need_dx) {
+    auto unit = [&](int i, const float* gy, bool need_dx, const float* addend = nullptr) {
         const LayerSpec& S = kLayers[i];
         const TLayer& L = t->L[i];
         const int iz = other(cur, skip, -1), ix = other(cur, skip, iz);
@@ -1237,7 +1237,7 @@ int yf_trainer_backward(yf_trainer t, const float* d_x, const float* d_grad_head
             if (need_dx) yf::launch_tdeconv_bwd_data(gz, P(L.p0), w.g[ix], N, L.Cin, L.Hin, L.Win, L.Cout, s);
         } else {
             yf::launch_tconv_bwd_weight(xin(L), gz, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, w.scratch, sb, s);
-            if (need_dx) yf::launch_tconv_bwd_data(gz, P(L.p0), w.g[ix], N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, s);
+            if (need_dx) yf::launch_tconv_bwd_data(gz, P(L.p0), w.g[ix], N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, s, addend);
         }
         return ix;
     };
@@ -1255,13 +1255,10 @@ int yf_trainer_backward(yf_trainer t, const float* d_x, const float* d_grad_head
         for (int i = hi; i >= lo; --i) {
             const TLayer& L = t->L[i];
             if (L.res_from >= 0) skip = cur;                                    // conv3 of a block: its output gradient also goes to the skip
-            const int nx = unit(i, w.g[cur], i > lo || first_needs_dx);
-            const bool block_input = skip >= 0 && i + 2 < kNumLayers && t->L[i + 2].res_from == i;       // conv1 of that block
+            const bool block_input = skip >= 0 && i + 2 < kNumLayers && t->L[i + 2].res_from == i;       // conv1 of that block:
+            const int nx = unit(i, w.g[cur], i > lo || first_needs_dx, block_input ? w.g[skip] : nullptr);   // + the skip gradient, fused
             cur = nx;
-            if (block_input) {
-                yf::launch_tadd(w.g[cur], w.g[skip], w.g[cur], (long)N * L.Cin * L.Hin * L.Win, s);
-                skip = -1;
-            }
+            if (block_input) skip = -1;
         }
     };
     const TLayer& A = t->L[t->i_conv4_2];

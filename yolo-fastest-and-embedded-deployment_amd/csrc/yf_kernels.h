@@ -251,7 +251,7 @@ void launch_train_loss(const float* head, int N, int fh, int fw, const float* an
 void launch_tconv_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W, int Cout, int k, int stride,
                       int depthwise, hipStream_t s);
 void launch_tconv_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int k, int stride, int depthwise,
-                           hipStream_t s);
+                           hipStream_t s, const float* addend = nullptr);
 void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int k, int stride, int depthwise,
                              void* scratch, size_t scratch_bytes, hipStream_t s);
 void launch_tdeconv_fwd(const float* x, const float* w, float* y, int N, int Cin, int H, int W, int Cout, hipStream_t s);
@@ -260,7 +260,7 @@ void launch_tdeconv_bwd_weight(const float* x, const float* dy, float* dw, int N
                                hipStream_t s);
 size_t train_scratch_bytes();
 void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* stats, float* y, int N,
-                    int C, long HW, int relu, void* scratch, hipStream_t s);
+                    int C, long HW, int relu, void* scratch, hipStream_t s, const float* residual = nullptr);
 void launch_tbn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, float* dgamma, float* dbeta, float* dx,
                     int N, int C, long HW, int relu, void* scratch, hipStream_t s);
 void launch_tadam_multi(int nt, float* const* p, const float* const* g, float* const* m, float* const* v, const long* sizes, double lr, double b1,

@@ -96,7 +96,8 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __host__ __device__ inline int tpw_waves_m(int M) { return M > 32 ? 4 : M > 16 ? 2 : 1; }
 template <int NT>   // NT 16-pixel tiles per wave: 4 for large maps, 1 when there are few pixels (more waves in flight)
 __global__ void __launch_bounds__(256) tpw_mfma_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ bias,
-                                                       float* __restrict__ y, long Q, long HW, int M, int K, long sm, long sk)
+                                                       const float* __restrict__ addend, float* __restrict__ y, long Q, long HW, int M, int K,
+                                                       long sm, long sk)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
     // 1-D grid in XCD-contiguous order with the channel tile fastest: the workgroups that read the same 16 NT pixels (all channel
@@ -143,7 +144,11 @@ __global__ void __launch_bounds__(256) tpw_mfma_kernel(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + lk * 4 + r;
-            if (m < M) y[(n * M + m) * HW + i] = acc[t][r] + (bias ? bias[m] : 0.f);
+            if (m < M) {
+                const long o = (n * M + m) * HW + i;
+                const float v = acc[t][r] + (bias ? bias[m] : 0.f);
+                y[o] = addend ? v + addend[o] : v;                  // addend: the skip gradient of a residual block (saves an add pass)
+            }
         }
     }
 }
@@ -694,7 +699,8 @@ template <int V>
 __global__ void __launch_bounds__(256) tbn_apply_kernel(const float* __restrict__ x, const double* __restrict__ scratch, int nchunk,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
                                                         int N, int C, long HW, int relu, float eps, float momentum, float* __restrict__ stats,
-                                                        float* __restrict__ running_mean, float* __restrict__ running_var)
+                                                        float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                        const float* __restrict__ res)
 {
     typedef typename tbn_vec<V>::type vec;
     const int c = blockIdx.y;
@@ -719,11 +725,13 @@ __global__ void __launch_bounds__(256) tbn_apply_kernel(const float* __restrict_
         if (i >= HW) continue;
         const long idx = (n * C + c) * HW + i;
         const vec xv = *reinterpret_cast<const vec*>(x + idx);
-        vec o;
+        vec o, rv = xv;
+        if (res) rv = *reinterpret_cast<const vec*>(res + idx);   // out += residual (BasicResBlock), fused
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            const float v = tbn_affine(tbn_at<V>(xv, j), fm, fi, g, b);
-            ((float*)&o)[j] = relu ? fmaxf(v, 0.f) : v;
+            float v = tbn_affine(tbn_at<V>(xv, j), fm, fi, g, b);
+            if (relu) v = fmaxf(v, 0.f);
+            ((float*)&o)[j] = res ? v + tbn_at<V>(rv, j) : v;
         }
         *reinterpret_cast<vec*>(y + idx) = o;
     }
@@ -811,7 +819,7 @@ __device__ __forceinline__ void tbn_block_total1024(double& s, double& t)
 __global__ void __launch_bounds__(1024) tbn_fwd_small_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ y, int N, int C, int HW, int relu, float eps, float momentum,
                                                              float* __restrict__ stats, float* __restrict__ running_mean,
-                                                             float* __restrict__ running_var)
+                                                             float* __restrict__ running_var, const float* __restrict__ res)
 {
     const int c = blockIdx.x, P = N * HW;
     double s = 0, ss = 0;
@@ -837,8 +845,9 @@ __global__ void __launch_bounds__(1024) tbn_fwd_small_kernel(const float* __rest
     for (int p = threadIdx.x; p < P; p += 1024) {
         const int n = p / HW, i = p - n * HW;
         const long idx = ((long)n * C + c) * HW + i;
-        const float v = tbn_affine(x[idx], fm, fi, g, b);
-        y[idx] = relu ? fmaxf(v, 0.f) : v;
+        float v = tbn_affine(x[idx], fm, fi, g, b);
+        if (relu) v = fmaxf(v, 0.f);
+        y[idx] = res ? v + res[idx] : v;
     }
 }
 __global__ void __launch_bounds__(1024) tbn_bwd_small_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stats,
@@ -938,22 +947,23 @@ __global__ void __launch_bounds__(256) tadam_multi_kernel(const TAdamEntry* __re
 
 static inline unsigned nblk(long total) { return (unsigned)((total + 255) / 256); }
 
-static void launch_tpw_gemm(const float* x, const float* a, const float* bias, float* y, long Q, long HW, int M, int K, long sm, long sk, hipStream_t s)
+static void launch_tpw_gemm(const float* x, const float* a, const float* bias, const float* addend, float* y, long Q, long HW, int M, int K, long sm,
+                            long sk, hipStream_t s)
 {
     const int wm = tpw_waves_m(M), wq = 4 / wm;
     const unsigned my = (unsigned)((M + 16 * wm - 1) / (16 * wm));
     const long b4 = (Q + 64L * wq - 1) / (64L * wq), b1 = (Q + 16L * wq - 1) / (16L * wq);     // workgroups along the pixels, NT = 4 / 1
     if (b4 * my >= 512)
-        hipLaunchKernelGGL(tpw_mfma_kernel<4>, dim3((unsigned)(b4 * my)), dim3(256), 0, s, x, a, bias, y, Q, HW, M, K, sm, sk);
+        hipLaunchKernelGGL(tpw_mfma_kernel<4>, dim3((unsigned)(b4 * my)), dim3(256), 0, s, x, a, bias, addend, y, Q, HW, M, K, sm, sk);
     else
-        hipLaunchKernelGGL(tpw_mfma_kernel<1>, dim3((unsigned)(b1 * my)), dim3(256), 0, s, x, a, bias, y, Q, HW, M, K, sm, sk);
+        hipLaunchKernelGGL(tpw_mfma_kernel<1>, dim3((unsigned)(b1 * my)), dim3(256), 0, s, x, a, bias, addend, y, Q, HW, M, K, sm, sk);
 }
 void launch_tconv_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W, int Cout, int k, int stride,
                       int depthwise, hipStream_t s)
 {
     const int pad = (k - 1) / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     if (!depthwise && k == 1 && stride == 1) {
-        launch_tpw_gemm(x, w, bias, y, (long)N * H * W, (long)H * W, Cout, Cin, (long)Cin, 1L, s);
+        launch_tpw_gemm(x, w, bias, nullptr, y, (long)N * H * W, (long)H * W, Cout, Cin, (long)Cin, 1L, s);
         return;
     }
     if (!depthwise && k == 3) {
@@ -978,12 +988,18 @@ void launch_tconv_fwd(const float* x, const float* w, const float* bias, float* 
     }
     hipLaunchKernelGGL(tconv_fwd_kernel, dim3(nblk((long)N * Cout * Ho * Wo)), dim3(256), 0, s, x, w, bias, y, N, Cin, H, W, Cout, Ho, Wo, k, stride, depthwise);
 }
+// addend (optional, like dx): added to the result -- fused for the pointwise GEMM, a separate pass otherwise
 void launch_tconv_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int k, int stride, int depthwise,
-                           hipStream_t s)
+                           hipStream_t s, const float* addend)
 {
+    if (addend && !(!depthwise && k == 1 && stride == 1)) {
+        launch_tconv_bwd_data(dy, w, dx, N, Cin, H, W, Cout, k, stride, depthwise, s, nullptr);
+        launch_tadd(dx, addend, dx, (long)N * Cin * H * W, s);
+        return;
+    }
     const int pad = (k - 1) / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     if (!depthwise && k == 1 && stride == 1) {       // pointwise: dx[ci] = sum_co dy[co] w[co][ci] -- the same GEMM with the weight transposed
-        launch_tpw_gemm(dy, w, nullptr, dx, (long)N * H * W, (long)H * W, Cin, Cout, 1L, (long)Cin, s);
+        launch_tpw_gemm(dy, w, nullptr, addend, dx, (long)N * H * W, (long)H * W, Cin, Cout, 1L, (long)Cin, s);
         return;
     }
     if (!depthwise && k == 3 && stride == 2 && H == 2 * Ho && W == 2 * Wo) {
@@ -1121,12 +1137,13 @@ static inline int tbn_chunks(int N, int C, long HW, int V)
     return n < 1 ? 1 : (int)n;
 }
 // scratch: >= 1 MB of device memory (partial sums; needs no initialisation); C <= 256
+// residual (optional, like y): y = bn(x) [relu] + residual
 void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* stats, float* y, int N,
-                    int C, long HW, int relu, void* scratch, hipStream_t s)
+                    int C, long HW, int relu, void* scratch, hipStream_t s, const float* residual)
 {
     if ((long)N * HW <= TBN_SMALL) {
         hipLaunchKernelGGL(tbn_fwd_small_kernel, dim3(C), dim3(1024), 0, s, x, gamma, beta, y, N, C, (int)HW, relu, 1e-5f, 0.1f, stats, running_mean,
-                           running_var);
+                           running_var, residual);
         return;
     }
     const int V = (HW % 4 == 0 && HW >= 1024) ? 4 : 1, nchunk = tbn_chunks(N, C, HW, V);
@@ -1134,11 +1151,11 @@ void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float
     if (V == 4) {
         hipLaunchKernelGGL(tbn_stats_kernel<4>, g1, dim3(256), 0, s, x, N, C, HW, (double*)scratch);
         hipLaunchKernelGGL(tbn_apply_kernel<4>, g2, dim3(256), 0, s, x, (const double*)scratch, nchunk, gamma, beta, y, N, C, HW, relu, 1e-5f, 0.1f,
-                           stats, running_mean, running_var);
+                           stats, running_mean, running_var, residual);
     } else {
         hipLaunchKernelGGL(tbn_stats_kernel<1>, g1, dim3(256), 0, s, x, N, C, HW, (double*)scratch);
         hipLaunchKernelGGL(tbn_apply_kernel<1>, g2, dim3(256), 0, s, x, (const double*)scratch, nchunk, gamma, beta, y, N, C, HW, relu, 1e-5f, 0.1f,
-                           stats, running_mean, running_var);
+                           stats, running_mean, running_var, residual);
     }
 }
 void launch_tbn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, float* dgamma, float* dbeta, float* dx,
