@@ -16,6 +16,9 @@
 
 #include "../../include/yolo_fastest_hip.h"
 #include "yf_kernels.h"
+#include "yf_layers.h"
+
+using namespace yf_layers;
 
 namespace {
 
@@ -28,13 +31,23 @@ int fail(int code, const char* fmt, ...)
     va_end(ap);
     return code;
 }
+}  // namespace
+// the same error slot for the other translation units of the library (yf_train_engine.hip)
+namespace yf {
+int set_error(int code, const char* msg)
+{
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+}  // namespace yf
+namespace {
 #define HIP_OK(expr)                                                                                     \
     do {                                                                                                 \
         hipError_t e_ = (expr);                                                                          \
         if (e_ != hipSuccess) return fail(YF_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
     } while (0)
 
-enum Kind { K_PW = 0, K_DW = 1, K_DENSE = 2, K_DECONV = 3, K_HEAD = 4 };
+
 
 struct BlobHeader {
     char magic[8];
@@ -48,34 +61,7 @@ struct BlobLayer {
 };
 static_assert(sizeof(BlobHeader) == 64 && sizeof(BlobLayer) == 64, "blob layout");
 
-// The YoloFastest layer table, module-definition order (yolo_fastest.py:78-148). The blob must match it.
-struct LayerSpec {
-    const char* name;
-    int kind, cin, cout, k, stride, relu;
-};
-#define RES(n, c, e) {n ".conv1", K_PW, c, e, 1, 1, 1}, {n ".conv2", K_DW, e, e, 3, 1, 1}, {n ".conv3", K_PW, e, c, 1, 1, 0}
-const LayerSpec kLayers[] = {
-    {"conv0", K_DENSE, 1, 8, 3, 2, 1}, {"conv1_2", K_PW, 8, 8, 1, 1, 1}, {"conv1_3", K_DW, 8, 8, 3, 1, 1},
-    {"conv1_4", K_PW, 8, 4, 1, 1, 0}, RES("res1_1", 4, 8),
-    {"conv1_8", K_PW, 4, 24, 1, 1, 1}, {"conv1_9", K_DENSE, 24, 24, 3, 2, 1}, {"conv2_1", K_PW, 24, 8, 1, 1, 0},
-    RES("res2_1", 8, 32), RES("res2_2", 8, 32),
-    {"conv2_2", K_PW, 8, 32, 1, 1, 1}, {"conv2_3", K_DW, 32, 32, 3, 2, 1}, {"conv3_1", K_PW, 32, 8, 1, 1, 0},
-    RES("res3_1", 8, 48), RES("res3_2", 8, 48),
-    {"conv3_2", K_PW, 8, 48, 1, 1, 1}, {"conv3_3", K_DW, 48, 48, 3, 1, 1}, {"conv3_4", K_PW, 48, 16, 1, 1, 0},
-    RES("res3_3", 16, 96), RES("res3_4", 16, 96), RES("res3_5", 16, 96), RES("res3_6", 16, 96),
-    {"conv3_5", K_PW, 16, 96, 1, 1, 1}, {"conv3_6", K_DW, 96, 96, 3, 2, 1}, {"conv4_1", K_PW, 96, 24, 1, 1, 0},
-    RES("res4_1", 24, 136), RES("res4_2", 24, 136), RES("res4_3", 24, 136), RES("res4_4", 24, 136),
-    {"conv4_2", K_PW, 24, 136, 1, 1, 1}, {"conv4_3", K_DW, 136, 136, 3, 2, 1}, {"conv5_1", K_PW, 136, 48, 1, 1, 1},
-    RES("res5_1", 48, 224), RES("res5_2", 48, 224), RES("res5_3", 48, 224), RES("res5_4", 48, 224),
-    RES("res5_5", 48, 224),
-    {"conv5_2", K_PW, 48, 96, 1, 1, 1}, {"conv5_3", K_DW, 96, 96, 5, 1, 1}, {"conv5_4", K_PW, 96, 128, 1, 1, 0},
-    {"conv5_5", K_DW, 128, 128, 5, 1, 1}, {"conv5_6", K_PW, 128, 128, 1, 1, 0}, {"head_5", K_HEAD, 128, 24, 1, 1, 0},
-    {"deconv5_1", K_DECONV, 96, 96, 2, 2, 1},
-    {"conv4_1_1", K_PW, 232, 96, 1, 1, 1}, {"conv4_1_2", K_DW, 96, 96, 5, 1, 1}, {"conv4_1_3", K_PW, 96, 96, 1, 1, 0},
-    {"conv4_1_4", K_DW, 96, 96, 5, 1, 1}, {"conv4_1_5", K_PW, 96, 96, 1, 1, 0}, {"head_4", K_HEAD, 96, 24, 1, 1, 0},
-};
-constexpr int kNumLayers = sizeof(kLayers) / sizeof(kLayers[0]);
-static_assert(kNumLayers == 86, "84 conv+BN units + 2 heads");
+
 
 enum { BUF_INPUT = -1, BUF_HEAD_LARGE = -2, BUF_HEAD_SMALL = -3 };
 
@@ -143,12 +129,6 @@ struct yf_engine {
 
 namespace {
 
-int find_layer(const char* name)
-{
-    for (int i = 0; i < kNumLayers; ++i)
-        if (!strcmp(kLayers[i].name, name)) return i;
-    return -1;
-}
 
 struct Builder {
     Plan* e;
@@ -571,101 +551,6 @@ float logit_threshold(double thres)
 
 }  // namespace
 
-// ---- the training iteration's forward and backward as ONE call each (yf_trainer_*): the graph of yolo_fastest.py:150-218 over
-// NCHW fp32 tensors in a caller-owned workspace.  kLayers is in module-definition order, which is also the forward order; a layer's
-// input is the previous layer's output except where noted in trainer_build(). ----
-struct TLayer {
-    int in;                 // layer whose y is this layer's input: -1 = the images, -2 = the concat buffer
-    int Cin, Hin, Win, Cout, Ho, Wo;
-    int res_from;           // conv3 of a BasicResBlock: layer whose INPUT is added to this layer's output (the block's conv1), else -1
-    size_t z, y, st;        // float offsets PER FRAME of z and y, absolute float offset of stats (2 * Cout)
-    int p0;                 // index of the layer's first parameter in parameters() order
-};
-struct yf_trainer_s {
-    int device, H, W;
-    TLayer L[kNumLayers];
-    size_t act_floats;      // per frame: all z / y, the concat buffer
-    size_t cat;             // per-frame offset of the concat buffer
-    size_t stats_floats;    // total, independent of N
-    size_t gmax;            // per frame: the largest activation
-    size_t ga2, gb2, gd;    // per-frame sizes of the branch-point gradient buffers (conv4_2, conv5_2, deconv5_1 outputs)
-    int n_params;
-    int i_conv4_2, i_conv4_3, i_conv5_2, i_conv5_3, i_conv5_6, i_head5, i_deconv, i_c411, i_c415, i_head4;
-};
-
-namespace {
-
-int trainer_build(yf_trainer_s* t, int H, int W)
-{
-    t->H = H; t->W = W;
-    t->i_conv4_2 = find_layer("conv4_2"); t->i_conv4_3 = find_layer("conv4_3"); t->i_conv5_2 = find_layer("conv5_2");
-    t->i_conv5_3 = find_layer("conv5_3"); t->i_conv5_6 = find_layer("conv5_6"); t->i_head5 = find_layer("head_5");
-    t->i_deconv = find_layer("deconv5_1"); t->i_c411 = find_layer("conv4_1_1"); t->i_c415 = find_layer("conv4_1_5");
-    t->i_head4 = find_layer("head_4");
-    size_t off = 0, st = 0;
-    int p = 0;
-    t->gmax = 0;
-    for (int i = 0; i < kNumLayers; ++i) {
-        const LayerSpec& S = kLayers[i];
-        TLayer& L = t->L[i];
-        L.in = i - 1;
-        if (i == t->i_deconv) L.in = t->i_conv5_2;              // deconv5_1(conv5_2)              yolo_fastest.py:208
-        if (i == t->i_c411) L.in = -2;                          // conv4_1_1(cat(conv4_2, deconv5_1))       :209-211
-        if (L.in >= 0) { L.Cin = t->L[L.in].Cout; L.Hin = t->L[L.in].Ho; L.Win = t->L[L.in].Wo; }
-        else if (L.in == -1) { L.Cin = 1; L.Hin = H; L.Win = W; }
-        else { L.Cin = t->L[t->i_conv4_2].Cout + t->L[t->i_deconv].Cout; L.Hin = t->L[t->i_conv4_2].Ho; L.Win = t->L[t->i_conv4_2].Wo; }
-        if (L.Cin != S.cin) return -1;
-        L.Cout = S.cout;
-        if (S.kind == K_DECONV) { L.Ho = 2 * L.Hin; L.Wo = 2 * L.Win; }
-        else { const int pad = (S.k - 1) / 2; L.Ho = (L.Hin + 2 * pad - S.k) / S.stride + 1; L.Wo = (L.Win + 2 * pad - S.k) / S.stride + 1; }
-        const size_t a = (size_t)L.Cout * L.Ho * L.Wo;
-        L.res_from = -1;
-        const size_t n = strlen(S.name);
-        if (n > 6 && !strcmp(S.name + n - 6, ".conv3")) L.res_from = i - 2;
-        if (S.kind == K_HEAD) { L.z = L.y = 0; L.st = 0; L.p0 = p; p += 2; continue; }     // the heads write into the caller's tensors
-        L.z = off; off += a;
-        L.y = off; off += a;
-        L.st = st; st += 2 * (size_t)L.Cout;
-        L.p0 = p; p += 3;
-        if (a > t->gmax) t->gmax = a;
-    }
-    t->cat = off;
-    off += (size_t)t->L[t->i_c411].Cin * t->L[t->i_c411].Hin * t->L[t->i_c411].Win;
-    if ((size_t)t->L[t->i_c411].Cin * t->L[t->i_c411].Hin * t->L[t->i_c411].Win > t->gmax)
-        t->gmax = (size_t)t->L[t->i_c411].Cin * t->L[t->i_c411].Hin * t->L[t->i_c411].Win;
-    if ((size_t)H * W > t->gmax) t->gmax = (size_t)H * W;
-    t->act_floats = off;
-    t->stats_floats = st;
-    t->n_params = p;
-    t->ga2 = (size_t)t->L[t->i_conv4_2].Cout * t->L[t->i_conv4_2].Ho * t->L[t->i_conv4_2].Wo;
-    t->gb2 = (size_t)t->L[t->i_conv5_2].Cout * t->L[t->i_conv5_2].Ho * t->L[t->i_conv5_2].Wo;
-    t->gd = (size_t)t->L[t->i_deconv].Cout * t->L[t->i_deconv].Ho * t->L[t->i_deconv].Wo;
-    return 0;
-}
-
-// workspace: [scratch | stats | activations x N | 4 gradient buffers x N x gmax | ga2, gb2, gd x N]
-struct TWs {
-    char* scratch; float* stats; float* act; float* g[4]; float* ga2; float* gb2; float* gd;
-    size_t bytes;
-};
-TWs trainer_ws(const yf_trainer_s* t, int N, void* base)
-{
-    TWs w;
-    char* p = static_cast<char*>(base);
-    auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
-    w.scratch = take(yf::train_scratch_bytes());
-    w.stats = reinterpret_cast<float*>(take(t->stats_floats * 4));
-    w.act = reinterpret_cast<float*>(take(t->act_floats * N * 4));
-    for (int i = 0; i < 4; ++i) w.g[i] = reinterpret_cast<float*>(take(t->gmax * N * 4));
-    w.ga2 = reinterpret_cast<float*>(take(t->ga2 * N * 4));
-    w.gb2 = reinterpret_cast<float*>(take(t->gb2 * N * 4));
-    w.gd = reinterpret_cast<float*>(take(t->gd * N * 4));
-    w.bytes = (size_t)(p - static_cast<char*>(base));
-    return w;
-}
-
-}  // namespace
-
 extern "C" {
 
 int yf_abi_version(void) { return YF_ABI_VERSION; }
@@ -992,298 +877,6 @@ int yf_train_loss(yf_handle h, const float* d_head, int N, int fh, int fw, const
     return YF_OK;
 }
 
-// ---- training-step operators (second slice); NCHW fp32 device pointers, stream-ordered ----
-#define YF_TOP(cond, call)                                                          \
-    do {                                                                            \
-        if (!(cond)) return fail(YF_E_INVALID, "%s: bad argument", __func__);       \
-        HIP_OK(hipSetDevice(device));                                               \
-        call;                                                                       \
-        HIP_OK(hipGetLastError());                                                  \
-        return YF_OK;                                                               \
-    } while (0)
-
-int yf_train_conv_forward(int device, const float* d_x, const float* d_w, const float* d_bias, float* d_y, int N, int Cin, int H, int W, int Cout,
-                          int k, int stride, int depthwise, void* stream)
-{
-    YF_TOP(d_x && d_w && d_y && N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (k == 1 || k == 3 || k == 5) && (stride == 1 || stride == 2) &&
-               (!depthwise || Cin == Cout),
-           yf::launch_tconv_fwd(d_x, d_w, d_bias, d_y, N, Cin, H, W, Cout, k, stride, depthwise, (hipStream_t)stream));
-}
-int yf_train_conv_backward_data(int device, const float* d_dy, const float* d_w, float* d_dx, int N, int Cin, int H, int W, int Cout, int k,
-                                int stride, int depthwise, void* stream)
-{
-    YF_TOP(d_dy && d_w && d_dx && N > 0 && (k == 1 || k == 3 || k == 5) && (stride == 1 || stride == 2) && (!depthwise || Cin == Cout),
-           yf::launch_tconv_bwd_data(d_dy, d_w, d_dx, N, Cin, H, W, Cout, k, stride, depthwise, (hipStream_t)stream));
-}
-int yf_train_conv_backward_weight(int device, const float* d_x, const float* d_dy, float* d_dw, int N, int Cin, int H, int W, int Cout, int k,
-                                  int stride, int depthwise, void* d_scratch, size_t scratch_bytes, void* stream)
-{
-    YF_TOP(d_x && d_dy && d_dw && N > 0 && (k == 1 || k == 3 || k == 5) && (stride == 1 || stride == 2) && (!depthwise || Cin == Cout),
-           yf::launch_tconv_bwd_weight(d_x, d_dy, d_dw, N, Cin, H, W, Cout, k, stride, depthwise, d_scratch, scratch_bytes, (hipStream_t)stream));
-}
-int yf_train_deconv_forward(int device, const float* d_x, const float* d_w, float* d_y, int N, int Cin, int H, int W, int Cout, void* stream)
-{
-    YF_TOP(d_x && d_w && d_y && N > 0, yf::launch_tdeconv_fwd(d_x, d_w, d_y, N, Cin, H, W, Cout, (hipStream_t)stream));
-}
-int yf_train_deconv_backward_data(int device, const float* d_dy, const float* d_w, float* d_dx, int N, int Cin, int H, int W, int Cout, void* stream)
-{
-    YF_TOP(d_dy && d_w && d_dx && N > 0, yf::launch_tdeconv_bwd_data(d_dy, d_w, d_dx, N, Cin, H, W, Cout, (hipStream_t)stream));
-}
-int yf_train_deconv_backward_weight(int device, const float* d_x, const float* d_dy, float* d_dw, int N, int Cin, int H, int W, int Cout,
-                                    void* d_scratch, size_t scratch_bytes, void* stream)
-{
-    YF_TOP(d_x && d_dy && d_dw && N > 0,
-           yf::launch_tdeconv_bwd_weight(d_x, d_dy, d_dw, N, Cin, H, W, Cout, d_scratch, scratch_bytes, (hipStream_t)stream));
-}
-int yf_train_scratch_bytes(size_t* bytes)
-{
-    if (!bytes) return fail(YF_E_INVALID, "yf_train_scratch_bytes: null argument");
-    *bytes = yf::train_scratch_bytes();
-    return YF_OK;
-}
-int yf_train_bn_forward(int device, const float* d_x, const float* d_gamma, const float* d_beta, float* d_running_mean, float* d_running_var,
-                        float* d_stats, float* d_y, int N, int C, long HW, int relu, void* d_scratch, void* stream)
-{
-    YF_TOP(d_x && d_gamma && d_beta && d_stats && d_y && d_scratch && N > 0 && C > 0 && C <= 256 && HW > 0,
-           yf::launch_tbn_fwd(d_x, d_gamma, d_beta, d_running_mean, d_running_var, d_stats, d_y, N, C, HW, relu, d_scratch, (hipStream_t)stream));
-}
-int yf_train_bn_backward(int device, const float* d_x, const float* d_dy, const float* d_stats, const float* d_gamma, const float* d_beta,
-                         float* d_dgamma, float* d_dbeta, float* d_dx, int N, int C, long HW, int relu, void* d_scratch, void* stream)
-{
-    YF_TOP(d_x && d_dy && d_stats && d_gamma && d_beta && d_dgamma && d_dbeta && d_dx && d_scratch && N > 0 && C > 0 && C <= 256 && HW > 0,
-           yf::launch_tbn_bwd(d_x, d_dy, d_stats, d_gamma, d_beta, d_dgamma, d_dbeta, d_dx, N, C, HW, relu, d_scratch, (hipStream_t)stream));
-}
-int yf_train_channel_sum(int device, const float* d_dy, float* d_out, int N, int C, long HW, void* stream)
-{
-    YF_TOP(d_dy && d_out && N > 0 && C > 0 && HW > 0, yf::launch_tchan_sum(d_dy, d_out, N, C, HW, (hipStream_t)stream));
-}
-int yf_train_add(int device, const float* d_a, const float* d_b, float* d_out, long total, void* stream)
-{
-    YF_TOP(d_a && d_b && d_out && total > 0, yf::launch_tadd(d_a, d_b, d_out, total, (hipStream_t)stream));
-}
-int yf_train_channel_slice(int device, const float* d_src, float* d_dst, int N, int C, long HW, int Cs, int sc0, int Cd, int dc0, void* stream)
-{
-    YF_TOP(d_src && d_dst && N > 0 && C > 0 && sc0 >= 0 && dc0 >= 0 && sc0 + C <= Cs && dc0 + C <= Cd,
-           yf::launch_tslice(d_src, d_dst, N, C, HW, Cs, sc0, Cd, dc0, (hipStream_t)stream));
-}
-int yf_train_adam_step(int device, float* d_p, const float* d_g, float* d_m, float* d_v, long total, double lr, double beta1, double beta2,
-                       double eps, int step, void* stream)
-{
-    YF_TOP(d_p && d_g && d_m && d_v && total > 0 && step >= 1,
-           yf::launch_tadam(d_p, d_g, d_m, d_v, total, lr, beta1, beta2, eps, step, (hipStream_t)stream));
-}
-// conv / deconv + BatchNorm (+ ReLU) as one call each way: what the reference's conv_norm_relu / conv_norm / deconv_norm_relu blocks do
-int yf_train_unit_forward(int device, int deconv, const float* d_x, const float* d_w, const float* d_gamma, const float* d_beta,
-                          float* d_running_mean, float* d_running_var, float* d_stats, float* d_z, float* d_y, int N, int Cin, int H, int W, int Cout,
-                          int k, int stride, int depthwise, int relu, void* d_scratch, void* stream)
-{
-    if (!d_x || !d_w || !d_gamma || !d_beta || !d_stats || !d_z || !d_y || !d_scratch || N <= 0 || Cin <= 0 || Cout <= 0 || Cout > 256 || H <= 0 ||
-        W <= 0 || (depthwise && Cin != Cout))
-        return fail(YF_E_INVALID, "yf_train_unit_forward: bad argument");
-    if (!deconv && !((k == 1 || k == 3 || k == 5) && (stride == 1 || stride == 2))) return fail(YF_E_INVALID, "yf_train_unit_forward: bad kernel / stride");
-    HIP_OK(hipSetDevice(device));
-    hipStream_t s = (hipStream_t)stream;
-    long HWo;
-    if (deconv) {
-        yf::launch_tdeconv_fwd(d_x, d_w, d_z, N, Cin, H, W, Cout, s);
-        HWo = 4L * H * W;
-    } else {
-        yf::launch_tconv_fwd(d_x, d_w, nullptr, d_z, N, Cin, H, W, Cout, k, stride, depthwise, s);
-        const int pad = (k - 1) / 2;
-        HWo = (long)((H + 2 * pad - k) / stride + 1) * ((W + 2 * pad - k) / stride + 1);
-    }
-    yf::launch_tbn_fwd(d_z, d_gamma, d_beta, d_running_mean, d_running_var, d_stats, d_y, N, Cout, HWo, relu, d_scratch, s);
-    HIP_OK(hipGetLastError());
-    return YF_OK;
-}
-int yf_train_unit_backward(int device, int deconv, const float* d_x, const float* d_z, const float* d_gy, const float* d_stats, const float* d_w,
-                           const float* d_gamma, const float* d_beta, float* d_dgamma, float* d_dbeta, float* d_gz, float* d_dw, float* d_dx, int N,
-                           int Cin, int H, int W, int Cout, int k, int stride, int depthwise, int relu, void* d_scratch, size_t scratch_bytes,
-                           void* stream)
-{
-    if (!d_x || !d_z || !d_gy || !d_stats || !d_w || !d_gamma || !d_beta || !d_dgamma || !d_dbeta || !d_gz || !d_dw || !d_scratch || N <= 0 || Cin <= 0 ||
-        Cout <= 0 || Cout > 256 || (depthwise && Cin != Cout))
-        return fail(YF_E_INVALID, "yf_train_unit_backward: bad argument");
-    if (!deconv && !((k == 1 || k == 3 || k == 5) && (stride == 1 || stride == 2))) return fail(YF_E_INVALID, "yf_train_unit_backward: bad kernel / stride");
-    HIP_OK(hipSetDevice(device));
-    hipStream_t s = (hipStream_t)stream;
-    long HWo;
-    if (deconv) {
-        HWo = 4L * H * W;
-    } else {
-        const int pad = (k - 1) / 2;
-        HWo = (long)((H + 2 * pad - k) / stride + 1) * ((W + 2 * pad - k) / stride + 1);
-    }
-    yf::launch_tbn_bwd(d_z, d_gy, d_stats, d_gamma, d_beta, d_dgamma, d_dbeta, d_gz, N, Cout, HWo, relu, d_scratch, s);
-    if (deconv) {
-        yf::launch_tdeconv_bwd_weight(d_x, d_gz, d_dw, N, Cin, H, W, Cout, d_scratch, scratch_bytes, s);
-        if (d_dx) yf::launch_tdeconv_bwd_data(d_gz, d_w, d_dx, N, Cin, H, W, Cout, s);
-    } else {
-        yf::launch_tconv_bwd_weight(d_x, d_gz, d_dw, N, Cin, H, W, Cout, k, stride, depthwise, d_scratch, scratch_bytes, s);
-        if (d_dx) yf::launch_tconv_bwd_data(d_gz, d_w, d_dx, N, Cin, H, W, Cout, k, stride, depthwise, s);
-    }
-    HIP_OK(hipGetLastError());
-    return YF_OK;
-}
-int yf_train_adam_multi(int device, int ntensors, void* const* d_p, const void* const* d_g, void* const* d_m, void* const* d_v, const long* sizes,
-                        double lr, double beta1, double beta2, double eps, int step, void* d_table, size_t table_bytes, void* stream)
-{
-    if (!d_p || !d_g || !d_m || !d_v || !sizes || !d_table || ntensors <= 0 || step < 1 || table_bytes < (size_t)ntensors * 48)
-        return fail(YF_E_INVALID, "yf_train_adam_multi: bad argument");
-    for (int t = 0; t < ntensors; ++t)
-        if (!d_p[t] || !d_g[t] || !d_m[t] || !d_v[t] || sizes[t] <= 0) return fail(YF_E_INVALID, "yf_train_adam_multi: tensor %d: null pointer or empty", t);
-    HIP_OK(hipSetDevice(device));
-    yf::launch_tadam_multi(ntensors, (float* const*)d_p, (const float* const*)d_g, (float* const*)d_m, (float* const*)d_v, sizes, lr, beta1, beta2, eps,
-                           step, d_table, (hipStream_t)stream);
-    HIP_OK(hipGetLastError());
-    return YF_OK;
-}
-// ---- the trainer: forward and backward of the whole network as one call each ----
-int yf_trainer_create(int H, int W, int device, yf_trainer* out)
-{
-    if (!out || H <= 0 || W <= 0 || H % 32 || W % 32) return fail(YF_E_INVALID, "yf_trainer_create: H and W must be positive multiples of 32");
-    yf_trainer_s* t = new yf_trainer_s();
-    t->device = device;
-    if (trainer_build(t, H, W)) { delete t; return fail(YF_E_INVALID, "yf_trainer_create: layer table inconsistent"); }
-    *out = t;
-    return YF_OK;
-}
-void yf_trainer_destroy(yf_trainer t) { delete t; }
-int yf_trainer_num_params(yf_trainer t, int* n_params, int* n_bn)
-{
-    if (!t || !n_params || !n_bn) return fail(YF_E_INVALID, "yf_trainer_num_params: null argument");
-    *n_params = t->n_params;
-    *n_bn = kNumLayers - 2;
-    return YF_OK;
-}
-int yf_trainer_workspace_bytes(yf_trainer t, int N, size_t* bytes)
-{
-    if (!t || !bytes || N <= 0) return fail(YF_E_INVALID, "yf_trainer_workspace_bytes: bad argument");
-    *bytes = trainer_ws(t, N, nullptr).bytes;
-    return YF_OK;
-}
-int yf_trainer_forward(yf_trainer t, const float* d_x, int N, const void* const* d_params, void* const* d_bn_buffers, float* d_head_large,
-                       float* d_head_small, void* d_ws, size_t ws_bytes, void* stream)
-{
-    if (!t || !d_x || !d_params || !d_head_large || !d_head_small || !d_ws || N <= 0) return fail(YF_E_INVALID, "yf_trainer_forward: bad argument");
-    const TWs w = trainer_ws(t, N, d_ws);
-    if (ws_bytes < w.bytes) return fail(YF_E_WORKSPACE, "yf_trainer_forward: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
-    for (int i = 0; i < t->n_params; ++i)
-        if (!d_params[i]) return fail(YF_E_INVALID, "yf_trainer_forward: parameter %d is null", i);
-    HIP_OK(hipSetDevice(t->device));
-    hipStream_t s = (hipStream_t)stream;
-    auto P = [&](int i) { return static_cast<const float*>(d_params[i]); };
-    int bn = 0;
-    for (int i = 0; i < kNumLayers; ++i) {
-        const LayerSpec& S = kLayers[i];
-        const TLayer& L = t->L[i];
-        const float* x = L.in == -1 ? d_x : L.in == -2 ? w.act + t->cat * N : w.act + t->L[L.in].y * N;
-        if (S.kind == K_HEAD) {
-            yf::launch_tconv_fwd(x, P(L.p0), P(L.p0 + 1), i == t->i_head4 ? d_head_large : d_head_small, N, L.Cin, L.Hin, L.Win, L.Cout, 1, 1, 0, s);
-            continue;
-        }
-        float* z = w.act + L.z * N;
-        float* y = w.act + L.y * N;
-        if (S.kind == K_DECONV) yf::launch_tdeconv_fwd(x, P(L.p0), z, N, L.Cin, L.Hin, L.Win, L.Cout, s);
-        else yf::launch_tconv_fwd(x, P(L.p0), nullptr, z, N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, s);
-        float* rm = d_bn_buffers ? static_cast<float*>(d_bn_buffers[2 * bn]) : nullptr;
-        float* rv = d_bn_buffers ? static_cast<float*>(d_bn_buffers[2 * bn + 1]) : nullptr;
-        ++bn;
-        const float* residual = nullptr;                                        // out += residual, fused into the BatchNorm pass   yolo_fastest.py:65
-        if (L.res_from >= 0) {
-            const TLayer& R = t->L[L.res_from];
-            residual = R.in == -1 ? d_x : w.act + t->L[R.in].y * N;
-        }
-        yf::launch_tbn_fwd(z, P(L.p0 + 1), P(L.p0 + 2), rm, rv, w.stats + L.st, y, N, L.Cout, (long)L.Ho * L.Wo, S.relu, w.scratch, s, residual);
-        if (i == t->i_deconv) {                                                 // torch.cat((conv4_2, deconv5_1), 1)        :209
-            const TLayer& A = t->L[t->i_conv4_2];
-            float* cat = w.act + t->cat * N;
-            const long HW = (long)A.Ho * A.Wo;
-            yf::launch_tslice(w.act + A.y * N, cat, N, A.Cout, HW, A.Cout, 0, A.Cout + L.Cout, 0, s);
-            yf::launch_tslice(y, cat, N, L.Cout, HW, L.Cout, 0, A.Cout + L.Cout, A.Cout, s);
-        }
-    }
-    HIP_OK(hipGetLastError());
-    return YF_OK;
-}
-int yf_trainer_backward(yf_trainer t, const float* d_x, const float* d_grad_head_large, const float* d_grad_head_small, int N,
-                        const void* const* d_params, void* const* d_grads, void* d_ws, size_t ws_bytes, void* stream)
-{
-    if (!t || !d_x || !d_grad_head_large || !d_grad_head_small || !d_params || !d_grads || !d_ws || N <= 0)
-        return fail(YF_E_INVALID, "yf_trainer_backward: bad argument");
-    const TWs w = trainer_ws(t, N, d_ws);
-    if (ws_bytes < w.bytes) return fail(YF_E_WORKSPACE, "yf_trainer_backward: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
-    for (int i = 0; i < t->n_params; ++i)
-        if (!d_params[i] || !d_grads[i]) return fail(YF_E_INVALID, "yf_trainer_backward: parameter / gradient %d is null", i);
-    HIP_OK(hipSetDevice(t->device));
-    hipStream_t s = (hipStream_t)stream;
-    auto P = [&](int i) { return static_cast<const float*>(d_params[i]); };
-    auto G = [&](int i) { return static_cast<float*>(d_grads[i]); };
-    const size_t sb = yf::train_scratch_bytes();
-    auto xin = [&](const TLayer& L) { return L.in == -1 ? d_x : L.in == -2 ? (const float*)(w.act + t->cat * N) : (const float*)(w.act + t->L[L.in].y * N); };
-    // gradient buffers: `cur` holds the gradient flowing backwards, `skip` a block's output gradient until the block's input is reached
-    int cur = 0, skip = -1;
-    auto other = [&](int a, int b, int c) { for (int i = 0; i < 4; ++i) if (i != a && i != b && i != c) return i; return -1; };
-    // backward of one conv + BN (+ ReLU) unit: gradient of its output in gy -> parameter gradients, gradient of its input in w.g[ret]
-    auto unit = [&](int i, const float* gy, bool need_dx, const float* addend = nullptr) {
-        const LayerSpec& S = kLayers[i];
-        const TLayer& L = t->L[i];
-        const int iz = other(cur, skip, -1), ix = other(cur, skip, iz);
-        float* gz = w.g[iz];
-        yf::launch_tbn_bwd(w.act + L.z * N, gy, w.stats + L.st, P(L.p0 + 1), P(L.p0 + 2), G(L.p0 + 1), G(L.p0 + 2), gz, N, L.Cout, (long)L.Ho * L.Wo,
-                           S.relu, w.scratch, s);
-        if (S.kind == K_DECONV) {
-            yf::launch_tdeconv_bwd_weight(xin(L), gz, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, w.scratch, sb, s);
-            if (need_dx) yf::launch_tdeconv_bwd_data(gz, P(L.p0), w.g[ix], N, L.Cin, L.Hin, L.Win, L.Cout, s);
-        } else {
-            yf::launch_tconv_bwd_weight(xin(L), gz, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, w.scratch, sb, s);
-            if (need_dx) yf::launch_tconv_bwd_data(gz, P(L.p0), w.g[ix], N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, s, addend);
-        }
-        return ix;
-    };
-    auto head = [&](int i, const float* gy) {                                  // nn.Conv2d(C, 24, 1) with bias
-        const TLayer& L = t->L[i];
-        const int ix = other(cur, skip, -1);
-        yf::launch_tconv_bwd_weight(xin(L), gy, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, 1, 1, 0, w.scratch, sb, s);
-        yf::launch_tchan_sum(gy, G(L.p0 + 1), N, L.Cout, (long)L.Hin * L.Win, s);
-        yf::launch_tconv_bwd_data(gy, P(L.p0), w.g[ix], N, L.Cin, L.Hin, L.Win, L.Cout, 1, 1, 0, s);
-        return ix;
-    };
-    // a run of layers hi .. lo (inclusive), backwards; the gradient of layer hi's output is in w.g[cur] on entry, the gradient of layer
-    // lo's input is in w.g[cur] on exit
-    auto run_back = [&](int hi, int lo, bool first_needs_dx) {
-        for (int i = hi; i >= lo; --i) {
-            const TLayer& L = t->L[i];
-            if (L.res_from >= 0) skip = cur;                                    // conv3 of a block: its output gradient also goes to the skip
-            const bool block_input = skip >= 0 && i + 2 < kNumLayers && t->L[i + 2].res_from == i;       // conv1 of that block:
-            const int nx = unit(i, w.g[cur], i > lo || first_needs_dx, block_input ? w.g[skip] : nullptr);   // + the skip gradient, fused
-            cur = nx;
-            if (block_input) skip = -1;
-        }
-    };
-    const TLayer& A = t->L[t->i_conv4_2];
-    const TLayer& D = t->L[t->i_deconv];
-    const long HWa = (long)A.Ho * A.Wo;
-    // head_large branch: head_4, conv4_1_5 .. conv4_1_1, the concat                                   yolo_fastest.py:209-216
-    cur = head(t->i_head4, d_grad_head_large);
-    run_back(t->i_c415, t->i_c411, true);
-    yf::launch_tslice(w.g[cur], w.ga2, N, A.Cout, HWa, A.Cout + D.Cout, 0, A.Cout, 0, s);
-    yf::launch_tslice(w.g[cur], w.gd, N, D.Cout, HWa, A.Cout + D.Cout, A.Cout, D.Cout, 0, s);
-    {   // deconv5_1: gradient of conv5_2's output, first part
-        const int nx = unit(t->i_deconv, w.gd, true);
-        HIP_OK(hipMemcpyAsync(w.gb2, w.g[nx], t->gb2 * N * sizeof(float), hipMemcpyDeviceToDevice, s));
-    }
-    // head_small branch: head_5, conv5_6 .. conv5_3                                                     :201-206
-    cur = head(t->i_head5, d_grad_head_small);
-    run_back(t->i_conv5_6, t->i_conv5_3, true);
-    yf::launch_tadd(w.g[cur], w.gb2, w.g[cur], (long)N * t->gb2, s);
-    run_back(t->i_conv5_2, t->i_conv4_3, true);                                  // conv5_2 .. conv4_3             :191-200
-    yf::launch_tadd(w.g[cur], w.ga2, w.g[cur], (long)N * t->ga2, s);
-    run_back(t->i_conv4_2, 0, false);                                            // conv4_2 .. conv0; the images need no gradient
-    HIP_OK(hipGetLastError());
-    return YF_OK;
-}
-#undef YF_TOP
 
 int yf_detect(yf_handle h, const float* d_x, int N, double conf_thres, double nms_thres, const double* anchors, int origin_h,
               int origin_w, int K_max, int32_t* d_boxes, float* d_scores, int32_t* d_cls, int32_t* d_src, int32_t* d_counts,
