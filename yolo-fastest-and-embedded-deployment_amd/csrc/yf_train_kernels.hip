@@ -319,6 +319,34 @@ __global__ void __launch_bounds__(256) tdw_wgrad_kernel(const float* __restrict_
     float acc[KK];
 #pragma unroll
     for (int t = 0; t < KK; ++t) acc[t] = 0.f;
+    if (stride == 1 && (Wo & 3) == 0) {
+        // stride 1, widths multiple of 4: four output pixels per trip -- dY and each window row as aligned float4 loads (see tdw_conv_kernel)
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (long q4 = (long)blockIdx.x * 256 + threadIdx.x; q4 < Q / 4; q4 += (long)gridDim.x * 256) {
+            const long q = q4 * 4, n = q / HWo, i = q - n * HWo;
+            const int oy = (int)(i / Wo), ox0 = (int)(i - (long)oy * Wo);
+            const float4 g4 = *reinterpret_cast<const float4*>(dy + (n * C + c) * HWo + i);
+            const float* xp = x + (n * C + c) * H * W;
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                const int iy = oy - PAD + ky;
+                if (iy < 0 || iy >= H) continue;
+                const float* xr = xp + (long)iy * W;
+                const float4 c4 = *reinterpret_cast<const float4*>(xr + ox0);
+                const float4 l4 = ox0 >= 4 ? *reinterpret_cast<const float4*>(xr + ox0 - 4) : z4;
+                const float4 r4 = ox0 + 4 < W ? *reinterpret_cast<const float4*>(xr + ox0 + 4) : z4;
+                float win[4 + 2 * PAD];
+#pragma unroll
+                for (int j = 0; j < PAD; ++j) { win[j] = ((const float*)&l4)[4 - PAD + j]; win[PAD + 4 + j] = ((const float*)&r4)[j]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) win[PAD + j] = ((const float*)&c4)[j];
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[ky * KS + kx] = fmaf(((const float*)&g4)[j], win[j + kx], acc[ky * KS + kx]);
+            }
+        }
+    } else
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < Q; q += (long)gridDim.x * 256) {
         const long n = q / HWo, i = q - n * HWo;
         const int oy = (int)(i / Wo), ox = (int)(i - (long)oy * Wo);
@@ -426,10 +454,23 @@ __global__ void tdw_conv_kernel(const float* __restrict__ x, const float* __rest
         if (iy < 0 || iy >= H) continue;
         const float* xr = xp + (long)iy * W;
         float win[WIN];
+        if constexpr (S == 1) {
+            // stride 1: the window is [ox0 - PAD, ox0 + 3 + PAD]; ox0 and W are multiples of 4, so it is three ALIGNED float4 loads -- the
+            // 4 centre inputs, the quad before (its last PAD elements) and the quad after (its first PAD) -- instead of 4 + 2 PAD scalar ones
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 c4 = *reinterpret_cast<const float4*>(xr + ox0);
+            const float4 l4 = ox0 >= 4 ? *reinterpret_cast<const float4*>(xr + ox0 - 4) : z4;
+            const float4 r4 = ox0 + 4 < W ? *reinterpret_cast<const float4*>(xr + ox0 + 4) : z4;
 #pragma unroll
-        for (int j = 0; j < WIN; ++j) {
-            const int ix = ox0 * S - PAD + j;
-            win[j] = (ix >= 0 && ix < W) ? xr[ix] : 0.f;
+            for (int j = 0; j < PAD; ++j) { win[j] = ((const float*)&l4)[4 - PAD + j]; win[PAD + 4 + j] = ((const float*)&r4)[j]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) win[PAD + j] = ((const float*)&c4)[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < WIN; ++j) {
+                const int ix = ox0 * S - PAD + j;
+                win[j] = (ix >= 0 && ix < W) ? xr[ix] : 0.f;
+            }
         }
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
