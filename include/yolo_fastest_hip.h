@@ -139,6 +139,10 @@ int yf_val_nms(yf_handle h, const float *d_pred, int N, int M, double conf_thres
 int yf_train_loss_workspace_bytes(yf_handle h, int N, int fh, int fw, size_t *out);
 int yf_train_loss(yf_handle h, const float *d_head, int N, int fh, int fw, const double *anchors, const float *d_targets, int T,
                   double ignore_thres, void *d_work, size_t work_bytes, float *d_losses, float *d_grad_head, void *stream);
+/* The same without an engine: H x W = the net input (only the head's stride is taken from it), like the other yf_train_* entries. */
+int yf_train_head_loss_workspace_bytes(int N, int fh, int fw, size_t *out);
+int yf_train_head_loss(int device, int H, int W, const float *d_head, int N, int fh, int fw, const double *anchors, const float *d_targets,
+                       int T, double ignore_thres, void *d_work, size_t work_bytes, float *d_losses, float *d_grad_head, void *stream);
 
 /* Operators of the reference's TRAINING step (second slice): every layer type of YoloFastest in train mode, forward
  * and backward, on NCHW float32 device tensors like the reference's (src/model_training/model/yolo_fastest.py:16-66, train.py:98-160).
@@ -190,6 +194,12 @@ int yf_train_adam_step(int device, float *d_p, const float *d_g, float *d_m, flo
  * device scratch (the pointer table is uploaded into it on `stream`). */
 int yf_train_adam_multi(int device, int ntensors, void *const *d_p, const void *const *d_g, void *const *d_m, void *const *d_v, const long *sizes,
                         double lr, double beta1, double beta2, double eps, int step, void *d_table, size_t table_bytes, void *stream);
+/* ... with a caller-owned PINNED host copy of the table (>= 48 * ntensors bytes, one per optimizer): the table is written there and
+ * uploaded asynchronously, and only when `upload` != 0 -- set it when the pointer set changed; before the NEXT call with upload != 0 the
+ * previous upload must have executed (wait on an event recorded behind this call).  h_table_pinned NULL = yf_train_adam_multi. */
+int yf_train_adam_multi_pinned(int device, int ntensors, void *const *d_p, const void *const *d_g, void *const *d_m, void *const *d_v,
+                               const long *sizes, double lr, double beta1, double beta2, double eps, int step, void *d_table, size_t table_bytes,
+                               void *h_table_pinned, int upload, void *stream);
 
 /* The same training forward / backward as ONE call each: the whole graph of yolo_fastest.py:150-218 in train mode (what
  * `pred = model(imgs)` and `loss.backward()` run, train.py:114, :131), launched from C++ into a caller-owned workspace.

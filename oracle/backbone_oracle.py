@@ -60,30 +60,35 @@ _BY_NAME = {l[0]: l for l in LAYERS}
 BN_MOMENTUM = 0.1  # nn.BatchNorm2d default
 
 
-def _unit(sd, name, x, train=False):
+def _unit(sd, name, x, train=False, pre=None):
     """One conv+BN(+ReLU) unit with the reference's un-folded arithmetic order.  train: BatchNorm2d in train mode -- batch
-    statistics, and running_mean / running_var / num_batches_tracked of `sd` are updated in place like the module's buffers."""
+    statistics, and running_mean / running_var / num_batches_tracked of `sd` are updated in place like the module's buffers.
+    pre: optional dict; for units WITH a ReLU it receives name -> {z: the pre-activation (BatchNorm output), mu / sigma / absmax: per
+    channel batch statistics of the conv output} (tests use it to find the ReLU decisions that lie within fp32 rounding of zero)."""
     _, kind, cin, cout, k, s, relu = _BY_NAME[name]
     w = sd[name + ".0.weight"]
     if kind == "dc":
-        y = F.conv_transpose2d(x, w, None, stride=2, padding=0)
+        c = F.conv_transpose2d(x, w, None, stride=2, padding=0)
     else:
-        y = F.conv2d(x, w, None, stride=s, padding=(k - 1) // 2, groups=(cin if kind == "dw" else 1))
-    y = F.batch_norm(y, sd[name + ".1.running_mean"], sd[name + ".1.running_var"], sd[name + ".1.weight"],
+        c = F.conv2d(x, w, None, stride=s, padding=(k - 1) // 2, groups=(cin if kind == "dw" else 1))
+    y = F.batch_norm(c, sd[name + ".1.running_mean"], sd[name + ".1.running_var"], sd[name + ".1.weight"],
                      sd[name + ".1.bias"], train, BN_MOMENTUM if train else 0.0, BN_EPS)
     if train and (name + ".1.num_batches_tracked") in sd:
         sd[name + ".1.num_batches_tracked"] += 1
+    if pre is not None and relu:
+        pre[name] = dict(z=y.detach(), mu=c.detach().mean((0, 2, 3)), sigma=c.detach().var((0, 2, 3), unbiased=False).sqrt(),
+                         absmax=c.detach().abs().amax((0, 2, 3)))
     return F.relu(y) if relu else y
 
 
-def _resblock(sd, name, x, train=False):
-    y = _unit(sd, name + ".conv1", x, train)
-    y = _unit(sd, name + ".conv2", y, train)
-    y = _unit(sd, name + ".conv3", y, train)
+def _resblock(sd, name, x, train=False, pre=None):
+    y = _unit(sd, name + ".conv1", x, train, pre)
+    y = _unit(sd, name + ".conv2", y, train, pre)
+    y = _unit(sd, name + ".conv3", y, train, pre)
     return y + x
 
 
-def forward(sd, x, probes=None, train=False):
+def forward(sd, x, probes=None, train=False, pre=None):
     """yolo_fastest.py:150-218.  x: float32 [N,1,H,W].  Returns (head_large, head_small), NCHW.
     If `probes` is a dict it is filled with named intermediate activations (NCHW).
     train=True: the module in train mode (train.py:99, :114) -- BatchNorm on batch statistics, and the autograd graph is kept, so
@@ -95,38 +100,38 @@ def forward(sd, x, probes=None, train=False):
 
     with torch.enable_grad() if train else torch.no_grad():
         for n in ("conv0", "conv1_2", "conv1_3", "conv1_4"):
-            x = rec(n, _unit(sd, n, x, train))
-        x = rec("res1_1", _resblock(sd, "res1_1", x, train))
+            x = rec(n, _unit(sd, n, x, train, pre))
+        x = rec("res1_1", _resblock(sd, "res1_1", x, train, pre))
         for n in ("conv1_8", "conv1_9", "conv2_1"):
-            x = rec(n, _unit(sd, n, x, train))
+            x = rec(n, _unit(sd, n, x, train, pre))
         for n in ("res2_1", "res2_2"):
-            x = rec(n, _resblock(sd, n, x, train))
+            x = rec(n, _resblock(sd, n, x, train, pre))
         for n in ("conv2_2", "conv2_3", "conv3_1"):
-            x = rec(n, _unit(sd, n, x, train))
+            x = rec(n, _unit(sd, n, x, train, pre))
         for n in ("res3_1", "res3_2"):
-            x = rec(n, _resblock(sd, n, x, train))
+            x = rec(n, _resblock(sd, n, x, train, pre))
         for n in ("conv3_2", "conv3_3", "conv3_4"):
-            x = rec(n, _unit(sd, n, x, train))
+            x = rec(n, _unit(sd, n, x, train, pre))
         for n in ("res3_3", "res3_4", "res3_5", "res3_6"):
-            x = rec(n, _resblock(sd, n, x, train))
+            x = rec(n, _resblock(sd, n, x, train, pre))
         for n in ("conv3_5", "conv3_6", "conv4_1"):
-            x = rec(n, _unit(sd, n, x, train))
+            x = rec(n, _unit(sd, n, x, train, pre))
         for n in ("res4_1", "res4_2", "res4_3", "res4_4"):
-            x = rec(n, _resblock(sd, n, x, train))
-        conv4_2 = rec("conv4_2", _unit(sd, "conv4_2", x, train))
-        x = rec("conv4_3", _unit(sd, "conv4_3", conv4_2, train))
-        x = rec("conv5_1", _unit(sd, "conv5_1", x, train))
+            x = rec(n, _resblock(sd, n, x, train, pre))
+        conv4_2 = rec("conv4_2", _unit(sd, "conv4_2", x, train, pre))
+        x = rec("conv4_3", _unit(sd, "conv4_3", conv4_2, train, pre))
+        x = rec("conv5_1", _unit(sd, "conv5_1", x, train, pre))
         for n in ("res5_1", "res5_2", "res5_3", "res5_4", "res5_5"):
-            x = rec(n, _resblock(sd, n, x, train))
-        conv5_2 = rec("conv5_2", _unit(sd, "conv5_2", x, train))
+            x = rec(n, _resblock(sd, n, x, train, pre))
+        conv5_2 = rec("conv5_2", _unit(sd, "conv5_2", x, train, pre))
         x = conv5_2
         for n in ("conv5_3", "conv5_4", "conv5_5", "conv5_6"):
-            x = rec(n, _unit(sd, n, x, train))
+            x = rec(n, _unit(sd, n, x, train, pre))
         head_small = F.conv2d(x, sd["head_5.weight"], sd["head_5.bias"])
-        d = rec("deconv5_1", _unit(sd, "deconv5_1", conv5_2, train))
+        d = rec("deconv5_1", _unit(sd, "deconv5_1", conv5_2, train, pre))
         x = torch.cat((conv4_2, d), 1)  # yolo_fastest.py:209
         for n in ("conv4_1_1", "conv4_1_2", "conv4_1_3", "conv4_1_4", "conv4_1_5"):
-            x = rec(n, _unit(sd, n, x, train))
+            x = rec(n, _unit(sd, n, x, train, pre))
         head_large = F.conv2d(x, sd["head_4.weight"], sd["head_4.bias"])
     return head_large, head_small
 

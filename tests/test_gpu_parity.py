@@ -121,10 +121,10 @@ def test_heads_match_reference_goldens(models, golden, dev, res):
     _check_heads(hl, hs, g["syn_head_large"], g["syn_head_small"], t[0], t[1], res == 256)
 
 
-@pytest.mark.parametrize("fusion", [0, 1])
+@pytest.mark.parametrize("fusion", [0, 1, 2])
 def test_layer_probes_match_reference(yf, models, golden, dev, fusion):
     """25 intermediate activations recorded from the reference module by forward hooks.  fusion=0: one launch
-    per layer, all 25 exist; fusion=1 (the product default): tensors kept on chip by a fused kernel report
+    per layer, all 25 exist; fusion=1 / 2 (2 = the product default): tensors kept on chip by a fused kernel report
     YF_E_NOPROBE, every other one must match."""
     m, _, _ = models[256]
     g = golden("golden_256")
@@ -138,7 +138,7 @@ def test_layer_probes_match_reference(yf, models, golden, dev, fusion):
             try:
                 got = m.probe(x, k[6:]).cpu().numpy()[0]
             except yf._lib.YFError as e:
-                assert "error -5" in str(e) and fusion == 1, str(e)
+                assert "error -5" in str(e) and fusion >= 1, str(e)
                 fused_away.append(k[6:])
                 continue
             seen += 1
@@ -147,23 +147,53 @@ def test_layer_probes_match_reference(yf, models, golden, dev, fusion):
             if not err < 2e-5 * max(1.0, np.abs(v).max()):  # relative to the tensor's range
                 bad.append((k, float(err)))
     finally:
-        m.fusion = 1
+        m.fusion = yf.model.DEFAULT_FUSION
     assert not bad, bad
     assert seen == (25 if fusion == 0 else 25 - len(fused_away)) and seen >= 12, (seen, fused_away)
 
 
-def test_fused_and_per_layer_plans_agree(models, golden, dev):
+def test_fused_and_per_layer_plans_agree(yf, models, golden, dev):
     m, _, _ = models[256]
     x = _x(golden("golden_256")["input_u8"][:6], dev)
     with torch.no_grad():
         a = m(x)
-        m.fusion = 0
         try:
+            m.fusion = 0
             b = m(x)
-        finally:
             m.fusion = 1
+            c = m(x)
+        finally:
+            m.fusion = yf.model.DEFAULT_FUSION
     # same math, different summation order inside the fused kernels
     assert (a[0] - b[0]).abs().max().item() < 2e-4 and (a[1] - b[1]).abs().max().item() < 2e-4
+    # fusion 2 only removes launch boundaries from fusion 1's plan (conv5_2 in the res5 launch, ...): the same MFMAs in the same order,
+    # hence the same BITS
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+
+
+@pytest.mark.parametrize("res,batch", [(256, 256), (512, 24), (96, 5)])
+def test_deep_stage_fusion_is_bitwise_neutral(yf, dev, res, batch):
+    """yf_set_fusion 2 (default) against 1 on noise frames: bitwise equal heads at the metric's size and batch, at 640x512 (where the
+    stride-32 tile is a quarter frame, so the chains fall apart into single blocks) and at a ragged size (partial tiles), and fewer
+    launches."""
+    import ctypes
+    H, W = (res, res * 5 // 4) if res != 96 else (96, 160)
+    io = dict(yf.io_params_for(256 if res != 512 else 512)); io["input_shape"] = [H, W, 1]
+    m = yf.YoloFastest(io).to(dev).eval()
+    m.load_state_dict(torch.load(WEIGHTS[512 if res == 512 else 256], map_location=dev))
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = ((torch.randint(0, 256, (batch, 1, H, W), generator=g).float() - 128.0) / 255.0).to(dev)
+    outs, launches = {}, {}
+    for lvl in (2, 1):
+        m.fusion = lvl
+        with torch.no_grad():
+            outs[lvl] = m(x)
+        n = ctypes.c_int()
+        e = m.engine(H, W, batch, dev)
+        yf._lib.check(e.lib.yf_num_launches(e.handle, ctypes.byref(n)))
+        launches[lvl] = n.value
+    assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
+    assert launches[2] < launches[1], launches
 
 
 @pytest.mark.parametrize("name", ["golden_256", "golden_512", "golden_dense_256", "golden_dense_512"])
@@ -351,6 +381,68 @@ def test_post_edge_cases(models, dev):
         post.to_lists(raw)
 
 
+def test_conf_ties_above_logit_22_follow_the_reference(models, dev):
+    """The reference sorts a class by the fp64 conf = 1 / (1 + exp(-t)), stable (detect.py:23-25, :167): two DIFFERENT fp32 logits
+    share one conf above t ~ 22 (and every logit above 36.7 gives conf == 1.0), and such ties keep decode order.  Sorting by the logit
+    would put the later, larger logit first and NMS would keep the other box; the sort key is built from the conf's own fp64 value
+    there (conf_order(), yf_post_kernels.hip).  Checked against the oracle's Python doubles: survivors and their order."""
+    import math
+    from oracle import post_oracle as po
+    m, post, io = models[256]
+    m(_x(np.zeros((1, 256, 320), np.uint8), dev))
+    hl = np.full((2, 24, 16, 20), -5.0, np.float32)
+    hs = np.full((2, 24, 8, 10), -5.0, np.float32)
+    for a in range(3):
+        hl[:, 8 * a:8 * a + 4] = 0.0; hs[:, 8 * a:8 * a + 4] = 0.0      # box = cell centre, anchor size (no zero-area boxes)
+    hl[:, 2:4] = 1.2                                                    # large head, anchor 0: 3.3 x the anchor -> neighbours overlap
+    up = lambda v, n=1: np.nextafter(np.float32(v), np.float32(100.0)) if n == 1 else up(up(v), n - 1)   # noqa: E731
+    # frame 0, class 0 (channel 5 is the largest class logit everywhere: all -5, first maximum wins)
+    t24, t24b = np.float32(24.0), up(24.0)
+    assert t24b > t24 and 1 / (1 + math.exp(-float(t24))) == 1 / (1 + math.exp(-float(t24b)))       # the tie exists in the reference
+    hl[0, 4, 5, 5], hl[0, 4, 5, 6] = t24, t24b                 # overlapping neighbours: the reference keeps (5,5), a logit sort (5,6)
+    hl[0, 4, 9, 3], hl[0, 4, 9, 4] = 23.0, 25.0                # distinct confs: the later one leads
+    hl[0, 4, 12, 10], hl[0, 4, 12, 11] = 40.0, 50.0            # both conf == 1.0 exactly: decode order
+    hl[0, 4, 2, 15], hl[0, 4, 2, 16] = up(30.0, 3), 30.0       # a tie the other way round (already in decode order)
+    # frame 1: the same on the small head and another anchor, class 2
+    hs[1, 8 + 7] = 3.0
+    hs[1, 8 + 4, 3, 3], hs[1, 8 + 4, 3, 4] = np.float32(26.5), up(26.5)
+    hs[1, 8 + 4, 6, 7], hs[1, 8 + 4, 6, 8] = 37.0, 88.0
+    got = post.detect((torch.from_numpy(hl).to(dev), torch.from_numpy(hs).to(dev)), with_src=True)
+    for f in range(2):
+        want = po.post_process((hl[f], hs[f]), io["anchors"], io["input_shape"][:2])
+        assert [e[:4] + [e[6], e[7]] for e in got[f]] == [list(e[:4]) + [e[6], e[7]] for e in want], (f, got[f], want)
+        assert len(want) >= 2
+    src0 = [e[7] for e in got[0]]
+    assert src0[0] == 12 * 20 + 10 and 12 * 20 + 11 not in src0      # conf == 1.0 twice: the first in decode order leads and suppresses the other
+    assert 5 * 20 + 5 in src0 and 5 * 20 + 6 not in src0              # equal conf at 24.0 / 24.0 + 1 ulp: (5, 5) survives, not the larger logit
+
+
+def test_int32_saturation_of_box_corners(models, dev):
+    """A box whose exp(t_w) * anchor leaves int32: the reference's corners are unbounded Python ints (round() of a double, detect.py:65),
+    the device stores int32 and SATURATES.  Pinned: the saturated box equals the reference's clamped to int32, and nothing else in the
+    frame changes (needs |t_w| > ~16; never seen on real frames)."""
+    from oracle import post_oracle as po
+    m, post, io = models[256]
+    m(_x(np.zeros((1, 256, 320), np.uint8), dev))
+    hl = np.full((1, 24, 16, 20), -5.0, np.float32)
+    hs = np.full((1, 24, 8, 10), -5.0, np.float32)
+    for a in range(3):
+        hl[:, 8 * a:8 * a + 4] = 0.0
+    hl[0, 4, 4, 4] = 2.0; hl[0, 2, 4, 4] = 25.0; hl[0, 3, 4, 4] = 0.5; hl[0, 6, 4, 4] = 1.0     # class 1: w = e^25 * anchor_w ~ 1e12 px
+    hl[0, 8 + 4, 7, 7] = 3.0; hl[0, 8 + 3, 7, 7] = 30.0; hl[0, 8 + 7, 7, 7] = 1.0             # class 2: h overflows
+    hl[0, 4, 10, 10] = 1.0; hl[0, 4, 10, 12] = 0.5                                           # class 0: ordinary boxes
+    got = post.detect((torch.from_numpy(hl).to(dev), torch.from_numpy(hs).to(dev)), with_src=True)[0]
+    want = po.post_process((hl[0], hs[0]), io["anchors"], io["input_shape"][:2])
+    lo, hi = -2 ** 31, 2 ** 31 - 1
+    clamp = lambda v: max(lo, min(hi, v))   # noqa: E731
+    assert len(want) == len(got) == 4
+    assert any(abs(v) > 2 ** 31 for e in want for v in e[:4])          # the reference really leaves int32 here
+    for g_, w_ in zip(got, want):
+        assert g_[:4] == [clamp(v) for v in w_[:4]] and g_[6] == w_[6] and g_[7] == w_[7], (g_, w_)
+    differ = [i for i, (g_, w_) in enumerate(zip(got, want)) if g_[:4] != list(w_[:4])]
+    assert len(differ) == 2 and all(want[i][6] in (1, 2) for i in differ)
+
+
 def test_weights_from_ncnn_files(yf, golden, dev):
     """The engine fed from the reference's ncnn .param/.bin instead of the .pth: same heads as the reference."""
     io = yf.io_params_for(256)
@@ -422,30 +514,47 @@ def test_forward_u8_fused_preprocess_is_bit_identical(yf, models, golden, dev):
         assert [e[:4] for e in L] == g["adj_box"][f, :n].tolist() and [e[6] for e in L] == g["adj_cls"][f, :n].tolist()
 
 
-@pytest.mark.parametrize("lanes", [1, 2])
-def test_forward_is_hip_graph_capturable(yf, golden, dev, lanes):
-    """yf_forward issues launches (and, with 2 lanes, event fork/join on the engine's side stream) only: it can be
-    captured into a HIP graph and replayed bit-identically."""
+@pytest.mark.parametrize("lanes,detect", [(1, False), (2, False), (2, True), (3, True)])
+def test_forward_is_hip_graph_capturable(yf, golden, dev, lanes, detect):
+    """yf_forward / yf_detect issue launches and event fork/join on the engine's side streams only: a pass can be captured into a HIP
+    graph and replayed bit-identically -- with several lanes AND the small head's branch stream on (the default), forward only and
+    with each chunk's decode + NMS behind it.  The engine issues the same stream topology eager and captured; it is one that the HIP
+    runtime bundled with PyTorch can capture (a branch never joins back into a forked lane: tools/cap_repro.hip)."""
     io = yf.io_params_for(256)
     m = yf.YoloFastest(io).to(dev).eval()
     m.lanes = lanes
-    m.chunk = 32 if lanes == 2 else 0   # two chunks -> both lanes (the automatic split starts at larger passes)
+    assert m.branches == 1
+    m.chunk = (64 + lanes - 1) // lanes if lanes > 1 else 0   # one chunk per lane (the automatic split starts at larger passes)
     m.load_state_dict(torch.load(WEIGHTS[256], map_location=dev))
+    post = yf.YOLO_post_process(io["conf_thre"], io["nms_thre"], io["num_anchors"], io["num_cls"], io["anchors"], io["input_shape"]).bind(m)
     x = _x(np.tile(golden("golden_256")["input_u8"], (4, 1, 1))[:64], dev)
+
+    def run():
+        if detect:
+            r = post.detect_raw_from_input(x, kmax=16)
+            return [r["head_large"], r["head_small"], r["counts"], r["boxes"], r["cls"], r["src"]]
+        return list(m(x))
+
     with torch.no_grad():
-        ref = m(x)
+        ref = [t.clone() for t in run()]
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s), torch.no_grad():
-        m(x)
+        run()
     torch.cuda.current_stream().wait_stream(s)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g), torch.no_grad():
-        out = m(x)
-    out[0].zero_(); out[1].zero_()
+        out = run()
+    for t in out:
+        t.zero_()
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+    if detect:
+        assert torch.equal(out[2], ref[2]) and int(ref[2].sum()) > 64
+        valid = torch.arange(16, device=dev)[None, :] < ref[2][:, None]
+        for a, b in zip(out[3:], ref[3:]):
+            assert torch.equal(a[valid], b[valid])
 
 
 def test_yf_detect_single_call_equals_two_calls(models, golden, dev):
@@ -1017,6 +1126,36 @@ def test_bench_line_and_multi_gpu_rehearsal(dev):
             assert j["config"]["in_flight"] == 2 and j["one_batch_in_flight"]["detections_identical"]
             assert j["variants"][0]["dtype"] == "f16x3" and j["variants"][0]["detections_identical_to_f32_on_this_batch"]
             assert j["variants"][0]["max_abs_logit_diff_vs_f32_on_this_batch"] < 1e-3
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs: runs the day a multi-GPU node is leased")
+def test_two_gpu_bench_gathers_the_single_gpu_records(tmp_path):
+    """SURVEY.md 8(e) parity on REAL RCCL with N = 2: `bench.py --gpus 2 --frames fixtures` (one rank per GPU, 20 bundled frames each, the
+    ranks' record blocks all-gathered over xGMI) must hand rank 0 exactly the records a single GPU computes for the same 40 frames,
+    in frame order; the line says world_size 2."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    common = ["--steps", "3", "--warmup", "1", "--frames", "fixtures", "--no-cpu-baseline", "--no-variants", "--no-configs"]
+    two, one = str(tmp_path / "two.npz"), str(tmp_path / "one.npz")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "20", "--dump-records", two] + common,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["n_gpus"] == 2 and j["config"]["world_size"] == 2 and j["config"]["global_batch"] == 40
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "40", "--dump-records", one] + common,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = np.load(two), np.load(one)
+    assert int(a["world_size"]) == 2 and int(b["world_size"]) == 1
+    assert np.array_equal(a["counts"], b["counts"]) and a["counts"].shape == (40,) and a["counts"].sum() > 40
+    valid = np.arange(a["cls"].shape[1])[None, :] < a["counts"][:, None]
+    for k in ("boxes", "scores", "cls", "src"):
+        assert np.array_equal(a[k][valid], b[k][valid]), k
 
 
 def test_training_loss_matches_the_reference(yf, models, golden, dev):

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Runs the standalone capture reproducer over the topologies of interest, against BOTH HIP runtimes of the image: /opt/rocm's (ROCm 7.2,
+# what a plain hipcc program links) and the one PyTorch bundles and loads first in any Python process (torch/lib/libamdhip64.so, ROCm
+# 7.0) -- the engine runs on the latter.  One line per case (rc 139 = the runtime crashed).
+cd "$(dirname "$0")"
+T=/usr/local/lib/python3.10/dist-packages/torch/lib
+for rt in rocm torch; do
+for args in "1 1" "2 0" "2 1" "2 1 fresh" "2 1 lanemajor" "2 1 thread" "1 1 nopost" "2 0 nopost" "2 1 nopost" "2 1 nopost fresh" "2 1 nopost lanemajor" "2 1 nopost joinorigin" "3 1 nopost" "3 1 nopost joinorigin" "3 1" "2 1 postonbranch" "3 1 postonbranch" "1 1 postonbranch" "2 0 postonbranch"; do
+    if [ $rt = torch ]; then
+        LD_LIBRARY_PATH=$T LD_PRELOAD=$T/libamdhip64.so timeout -k 5 60 ./cap_repro.bin $args > /tmp/cap_repro.out 2>&1
+    else
+        timeout -k 5 60 ./cap_repro.bin $args > /tmp/cap_repro.out 2>&1
+    fi
+    rc=$?
+    echo "== [$rt runtime] cap_repro $args -> rc=$rc : $(tail -1 /tmp/cap_repro.out)"
+done
+done
+exit 0

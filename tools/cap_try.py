@@ -1,6 +1,7 @@
-import os, sys, faulthandler, numpy as np, torch
-faulthandler.enable()
-ROOT = "/root/repo"; sys.path.insert(0, ROOT)
+import os, sys, numpy as np, torch
+if not os.environ.get('YF_SEGV_TRACE'):
+    import faulthandler; faulthandler.enable()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import yolo_fastest_amd as yf
 dev = torch.device("cuda:0")
 io = yf.io_params_for(256)
@@ -15,6 +16,9 @@ s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(s), torch.no_grad(): m(x)
 torch.cuda.current_stream().wait_stream(s); torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
+if os.environ.get("YF_SEGV_TRACE"):
+    import ctypes
+    ctypes.CDLL(os.path.join(ROOT, "tools", "libsegv_trace.so")).segv_trace_install()
 print("capturing", lanes, branches, flush=True)
 with torch.cuda.graph(g), torch.no_grad():
     out = m(x)

@@ -42,6 +42,9 @@ _SIGS = {
     "yf_train_loss_workspace_bytes": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_size_t)]),
     "yf_train_loss": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.c_void_p, _c.c_int,
                                  _c.c_double, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "yf_train_head_loss_workspace_bytes": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_size_t)]),
+    "yf_train_head_loss": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_double),
+                                      _c.c_void_p, _c.c_int, _c.c_double, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "yf_train_conv_forward": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 8 + [_c.c_void_p]),
     "yf_train_conv_backward_data": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 8 + [_c.c_void_p]),
     "yf_train_conv_backward_weight": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 8 +
@@ -65,6 +68,9 @@ _SIGS = {
     "yf_train_bn_backward": (_c.c_int, [_c.c_int] + [_c.c_void_p] * 8 + [_c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "yf_train_adam_multi": (_c.c_int, [_c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_double, _c.c_double,
                                        _c.c_double, _c.c_double, _c.c_int, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "yf_train_adam_multi_pinned": (_c.c_int, [_c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_double,
+                                              _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_int,
+                                              _c.c_void_p]),
     "yf_train_channel_sum": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_long, _c.c_void_p]),
     "yf_train_add": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_long, _c.c_void_p]),
     "yf_train_channel_slice": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_int, _c.c_int, _c.c_int,

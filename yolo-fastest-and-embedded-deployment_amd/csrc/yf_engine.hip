@@ -72,7 +72,7 @@ struct Tensor {
     int last_use;  // index of the last op reading it
     size_t elems() const { return (size_t)C * H * W; }
 };
-enum OpType { OP_LAYER = 0, OP_FUSED_BLOCK = 1, OP_K19 = 2, OP_MRES = 3, OP_MDW = 4 };
+enum OpType { OP_LAYER = 0, OP_FUSED_BLOCK = 1, OP_K19 = 2, OP_MRES = 3, OP_MDW = 4, OP_MDW2 = 5, OP_DCAT = 6 };
 struct Op {
     int layer;         // index into kLayers (fused ops: the first of their layers)
     int in1, in2, res; // tensor ids (-1 = none)
@@ -81,6 +81,10 @@ struct Op {
     int type = OP_LAYER;
     int l_pre = -1, l_exp = -1, l_dw = -1, l_proj = -1;  // fused block: conv0 (optional), expand, depthwise, project
     int l_head = -1;     // OP_MDW: fused head conv (or -1)
+    int l_post = -1;     // OP_MRES, fusion level 2: a trailing 1x1 conv + ReLU applied on chip (conv5_2 after res5_5); `out` is ITS tensor
+    long post_off = -1;  //          offset of its packed fragments + bias in d_wmfma
+    int l_dw2 = -1, l_proj2 = -1;  // OP_MDW2 (fusion level 2): the small head's second pair (conv5_5, conv5_6) chained behind l_dw / l_proj
+    long mfma_off2 = -1;           //          offset of the second pair's weight stream
     int out2 = -1;       // OP_MRES conv4_2 + conv4_3 + conv5_1: the expanded tensor (conv4_2) is a second output
     int nblk = 1;        // OP_MRES: > 1 = a chain of residual blocks in one launch; block k's layers are l_exp/l_dw/l_proj + 3k
     long wstride = 0;    //          floats between the packed weight streams of consecutive chained blocks
@@ -111,8 +115,10 @@ struct yf_engine {
     float* d_wmfma = nullptr;         // MFMA B fragments of the GEMM-worthy pointwise layers (fused plan)
     size_t n_floats = 0;
     uint32_t w_off[kNumLayers], b_off[kNumLayers];
-    Plan plans[2];                    // [0] one launch per layer (bring-up / probes), [1] block-fused (default)
-    int fusion = 1;
+    // [0] one launch per layer (bring-up / probes), [1] block-fused, [2] (default) block-fused + the per-frame deep stage's launch
+    // boundaries removed: conv5_2 rides in the res5 launch, ...
+    Plan plans[3];
+    int fusion = 2;
     // Chunks of the batch can run on `lanes` concurrent streams (fork/join with events around the caller's stream):
     // at the deep stages one workgroup owns a CU and is latency-bound; a second chunk in flight fills the bubbles.
     int lanes = 2;
@@ -122,9 +128,15 @@ struct yf_engine {
     int branches = 1;                 // 0: issue the small head's launches in line (yf_set_branches)
     hipStream_t bside[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_bfork[4] = {nullptr, nullptr, nullptr, nullptr}, ev_bjoin[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_l2b[4] = {nullptr, nullptr, nullptr, nullptr};   // lane -> branch, in front of a chunk's post-process on the branch stream
     size_t head_l_elems = 0, head_s_elems = 0;
     const Plan& plan() const { return plans[fusion]; }
-    size_t frame_floats_max() const { return plans[0].frame_floats > plans[1].frame_floats ? plans[0].frame_floats : plans[1].frame_floats; }
+    size_t frame_floats_max() const
+    {
+        size_t m = 0;
+        for (const Plan& p : plans) m = p.frame_floats > m ? p.frame_floats : m;
+        return m;
+    }
 };
 
 namespace {
@@ -209,6 +221,20 @@ struct Builder {
         e->ops.push_back(o);
         return o.out;
     }
+    // the small head as ONE launch: dw5x5 -> 1x1 -> dw5x5 -> 1x1 -> head conv (yf_mdw_kernels.hip, mdw2_kernel); frames that fit one tile
+    int dwpw2(const char* dw1, const char* pw1, const char* dw2, const char* pw2, const char* head, int in, const char* out_name, int ext)
+    {
+        const LayerSpec &LD = kLayers[find_layer(dw1)], &LP = kLayers[find_layer(pw1)], &LQ = kLayers[find_layer(pw2)];
+        const Tensor& ti = e->tensors[in];
+        if (!yf::mdw2_can_chain(LD.cin, LP.cout, LQ.cout, 24, ti.H, ti.W)) return -1;
+        Op o{};
+        o.type = OP_MDW2;
+        o.l_dw = find_layer(dw1); o.l_proj = find_layer(pw1); o.l_dw2 = find_layer(dw2); o.l_proj2 = find_layer(pw2); o.l_head = find_layer(head);
+        o.layer = o.l_dw; o.in1 = in; o.in2 = -1; o.res = -1; o.omode = 1;
+        o.out = add_tensor(out_name, 24, ti.H, ti.W, ext);
+        e->ops.push_back(o);
+        return o.out;
+    }
     // conv4_2 (a skip tensor: the large head concatenates it) -> conv4_3 -> conv5_1 as one launch that also writes conv4_2
     int triple_keep_expansion(const char* a, const char* b, const char* c, int x, int* expanded)
     {
@@ -233,8 +259,9 @@ struct Builder {
     int dtype = yf::DT_F32;   // the engine's: some blocks are planned on a different kernel per dtype (mres_has_kernel)
 };
 
-void build_plan(Plan* e, bool fused, int dtype)
+void build_plan(Plan* e, int level, int dtype)
 {
+    const bool fused = level >= 1, deep = level >= 2;
     Builder b{e};
     b.fused = fused;
     b.dtype = dtype;
@@ -267,17 +294,42 @@ void build_plan(Plan* e, bool fused, int dtype)
     int conv4_2 = -1;
     x = b.triple_keep_expansion("conv4_2", "conv4_3", "conv5_1", x, &conv4_2);
     x = b.reschain({"res5_1", "res5_2", "res5_3", "res5_4", "res5_5"}, x);
+    int conv5_2 = -1;
+    {   // level 2: conv5_2 (48 -> 96, ReLU) runs on the last res5 launch's result while it is in LDS; res5_5 itself is not stored
+        Op& last = e->ops.back();
+        const LayerSpec& L52 = kLayers[find_layer("conv5_2")];
+        if (deep && last.type == OP_MRES && last.out == x &&
+            yf::mres_has_post(kLayers[last.l_exp].cin, kLayers[last.l_exp].cout, kLayers[last.l_proj].cout, L52.cout)) {
+            last.l_post = find_layer("conv5_2");
+            e->tensors[x].name.clear();   // never materialised: not probe-able
+            conv5_2 = b.add_tensor("conv5_2", L52.cout, e->tensors[x].H, e->tensors[x].W);
+            last.out = conv5_2;
+        }
+    }
     b.fused = false;
-    int conv5_2 = b.unit("conv5_2", x);
+    if (conv5_2 < 0) conv5_2 = b.unit("conv5_2", x);
     b.fused = fused_deep;
     const size_t br0 = e->ops.size();
-    x = b.dwpw("conv5_3", "conv5_4", nullptr, conv5_2, nullptr, 0);
-    b.dwpw("conv5_5", "conv5_6", "head_5", x, "head_small", BUF_HEAD_SMALL);
+    if (!deep || b.dwpw2("conv5_3", "conv5_4", "conv5_5", "conv5_6", "head_5", conv5_2, "head_small", BUF_HEAD_SMALL) < 0) {
+        x = b.dwpw("conv5_3", "conv5_4", nullptr, conv5_2, nullptr, 0);
+        b.dwpw("conv5_5", "conv5_6", "head_5", x, "head_small", BUF_HEAD_SMALL);
+    }
     if (fused)
         for (size_t i = br0; i < e->ops.size(); ++i) e->ops[i].branch = 1;
     b.fused = false;
-    int d = b.unit("deconv5_1", conv5_2);
-    x = b.unit("conv4_1_1", conv4_2, nullptr, d);  // torch.cat((conv4_2, deconv5_1), 1), yolo_fastest.py:209
+    if (deep && dtype == yf::DT_F32 && yf::dcat_has_kernel(e->tensors[conv5_2].C, e->tensors[conv4_2].C, kLayers[find_layer("conv4_1_1")].cout)) {
+        // level 2, fp32: deconv5_1 + conv4_1_1 in one launch, the deconv result stays in registers (yf_dcat_kernels.hip)
+        Op o{};
+        o.type = OP_DCAT;
+        o.layer = find_layer("deconv5_1"); o.l_proj = find_layer("conv4_1_1");
+        o.in1 = conv5_2; o.in2 = conv4_2; o.res = -1; o.omode = 0;
+        o.out = b.add_tensor("conv4_1_1", kLayers[o.l_proj].cout, e->tensors[conv4_2].H, e->tensors[conv4_2].W);
+        e->ops.push_back(o);
+        x = o.out;
+    } else {
+        int d = b.unit("deconv5_1", conv5_2);
+        x = b.unit("conv4_1_1", conv4_2, nullptr, d);  // torch.cat((conv4_2, deconv5_1), 1), yolo_fastest.py:209
+    }
     b.fused = fused_deep;
     x = b.dwpw("conv4_1_2", "conv4_1_3", nullptr, x, nullptr, 0);
     b.dwpw("conv4_1_4", "conv4_1_5", "head_4", x, "head_large", BUF_HEAD_LARGE);
@@ -364,8 +416,8 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                 const uint8_t* d_u8 = nullptr, int u8_down2 = 0, const yf::PostArgs* post = nullptr)
 {
     if (!e || (!d_x && !d_u8) || !d_hl || !d_hs || N <= 0) return fail(YF_E_INVALID, "yf_forward: null pointer or N <= 0");
-    if (d_u8 && e->fusion != 1) return fail(YF_E_INVALID, "u8 input needs the fused plan (yf_set_fusion 1)");
-    if (e->dtype == yf::DT_F16 && e->fusion != 1) return fail(YF_E_INVALID, "fp16 storage needs the fused plan (yf_set_fusion 1)");
+    if (d_u8 && e->fusion < 1) return fail(YF_E_INVALID, "u8 input needs a fused plan (yf_set_fusion 1 or 2)");
+    if (e->dtype == yf::DT_F16 && e->fusion < 1) return fail(YF_E_INVALID, "fp16 storage needs a fused plan (yf_set_fusion 1 or 2)");
     const size_t esz = e->esz();
     if (N > e->max_batch) return fail(YF_E_INVALID, "yf_forward: N=%d exceeds max_batch=%d", N, e->max_batch);
     const Plan& P = e->plan();
@@ -375,10 +427,6 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
     size_t need = P.frame_floats * (size_t)cf * esz * lanes;
     if (!ws || ws_bytes < need) return fail(YF_E_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, need);
     HIP_OK(hipSetDevice(e->device));
-    if (lanes > 1) {  // fork: side streams wait for everything already queued on the caller's stream
-        HIP_OK(hipEventRecord(e->ev_fork, s));
-        for (int l = 1; l < lanes; ++l) HIP_OK(hipStreamWaitEvent(e->side[l - 1], e->ev_fork, 0));
-    }
     const hipStream_t s_main = s;
     int probe_t = -1;
     if (probe) {
@@ -394,18 +442,22 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
     // are issued OP-MAJOR (op k of every lane, then op k + 1): issued lane-major, the second lane's first kernel was queued
     // only after the first lane's 33 launches had gone through the host (~0.15 ms of a 1.3 ms step), and the lanes overlapped
     // for little more than half of the step (rocprofv3 kernel trace, profiles/).
-    // The small head's launches (Op::branch) go to a side stream of the lane, forked after conv5_2 and joined before the lane's
-    // post-process: two under-filled launch chains (80 and 320 pixels per frame) run beside each other instead of in sequence.
-    // Not while profiling / probing (one stream, one launch at a time).
-    bool use_branch = e->branches && !prof && !probe && e->fusion == 1;
-    if (use_branch && lanes > 1) {
-        // Under stream capture a branch forked from a lane's side stream is a fork nested in a fork; hipStreamEndCapture of ROCm 7.2
-        // crashes on that topology (tools/cap_try.py 2 1), so a captured multi-lane pass issues the small head in line.
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s_main, &st) != hipSuccess || st != hipStreamCaptureStatusNone) use_branch = false;
-    }
+    // The small head's launches (Op::branch) go to a side stream of the lane, forked after conv5_2: two under-filled launch chains (80
+    // and 320 pixels per frame) run beside each other instead of in sequence.  Not while profiling / probing (one stream, one launch
+    // at a time).  A branch never joins back INTO a forked lane: it joins the caller's stream, and with a post-process (yf_detect) the
+    // lane joins its branch and the chunk's decode + NMS runs there.  The same dependencies, but a topology that the HIP runtime
+    // PyTorch bundles (ROCm 7.0's libamdhip64 in torch/lib) can capture: its hipStreamEndCapture recurses without bound when a stream
+    // forked from a forked stream joins that stream again (tools/cap_repro.hip reproduces it with empty kernels on that runtime;
+    // /opt/rocm's 7.2 runtime is fine).  So eager and captured passes issue the SAME thing; there is no capture special case.
+    const bool use_branch = e->branches && !prof && !probe && e->fusion >= 1;
     for (int g0 = 0; g0 < nchunks; g0 += lanes) {
       const int gcount = (nchunks - g0) < lanes ? (nchunks - g0) : lanes;
+      // fork: the side lanes wait for everything already queued on the caller's stream -- which, from the second group of chunks on,
+      // includes the previous group's lanes AND branches (they all joined it below), whose workspace regions this group reuses
+      if (gcount > 1) {
+          HIP_OK(hipEventRecord(e->ev_fork, s_main));
+          for (int l = 1; l < gcount; ++l) HIP_OK(hipStreamWaitEvent(e->side[l - 1], e->ev_fork, 0));
+      }
       size_t op_idx = 0;
       bool forked[4] = {false, false, false, false};
       if (prof) HIP_OK(hipEventRecord(prof->ev[0], s_main));
@@ -437,13 +489,18 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
             const Tensor& to = P.tensors[o.out];
             int rc = 0;
             struct AtExit { ProfileEvents* p; size_t* i; hipStream_t st; ~AtExit() { if (p) { ++*i; (void)hipEventRecord(p->ev[*i], st); } } } at_exit{prof, &op_idx, s};
-            if (o.type == OP_MDW) {
+            if (o.type == OP_DCAT) {
+                rc = yf::launch_dcat(ptr(o.in1), ptr(o.in2), e->d_wmfma + o.mfma_off, e->d_wmfma + o.mfma_off2, ptr(o.out), ti.H, ti.W, n, s);
+            } else if (o.type == OP_MDW2) {
+                rc = yf::launch_mdw2(ptr(o.in1), e->d_wmfma + o.mfma_off, e->d_wmfma + o.mfma_off2, ptr(o.out), ti.H, ti.W, n, s, o.kdt);
+            } else if (o.type == OP_MDW) {
                 yf::MdwArgs a{ptr(o.in1), e->d_wmfma + o.mfma_off, ptr(o.out), ti.H, ti.W, 0, 0};
                 rc = yf::launch_mdw(ti.C, kLayers[o.l_proj].cout, o.l_head >= 0 ? 24 : 0, a, n, s, o.kdt);
             } else if (o.type == OP_MRES) {
                 const LayerSpec &LE = kLayers[o.l_exp], &LP = kLayers[o.l_proj];
                 yf::MresArgs a{ptr(o.in1), e->d_wmfma + o.mfma_off, ptr(o.out), ti.H, ti.W, 0, 0, o.out2 >= 0 ? ptr(o.out2) : nullptr,
-                               o.nblk, o.wstride};
+                               o.nblk, o.wstride, nullptr, nullptr};
+                if (o.l_post >= 0) { a.post_w = e->d_wmfma + o.post_off; a.post_out = ptr(o.out); a.out = nullptr; }
                 rc = yf::launch_mres(LE.cin, LE.cout, LP.cout, o.res >= 0, kLayers[o.l_dw].stride, a, n, s, o.kdt);
             } else if (o.type == OP_FUSED_BLOCK) {
                 const bool pre = o.l_pre >= 0;
@@ -500,32 +557,36 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
         }
        }
       }
-      for (int lane_id = 0; lane_id < gcount; ++lane_id)   // join the small-head branch back into its lane
-        if (forked[lane_id]) {
-            hipStream_t sl = lane_id == 0 ? s_main : e->side[lane_id - 1];
-            HIP_OK(hipEventRecord(e->ev_bjoin[lane_id], e->bside[lane_id]));
-            HIP_OK(hipStreamWaitEvent(sl, e->ev_bjoin[lane_id], 0));
-        }
-      // decode + NMS of each chunk on ITS lane (yf_detect): frames are independent, so a lane's post-process overlaps the other
-      // lane's tail instead of running after the join
+      // decode + NMS of each chunk (yf_detect) on ITS lane -- frames are independent, so a lane's post-process overlaps the other
+      // lane's tail instead of running after the join -- or, where the lane forked a branch, on the BRANCH stream once the lane has
+      // joined it (see above)
       if (post)
         for (int lane_id = 0; lane_id < gcount; ++lane_id) {
             const int f0 = (g0 + lane_id) * cf;
             const int n = (N - f0) < cf ? (N - f0) : cf;
+            hipStream_t sl = lane_id == 0 ? s_main : e->side[lane_id - 1];
+            if (forked[lane_id]) {
+                HIP_OK(hipEventRecord(e->ev_l2b[lane_id], sl));
+                HIP_OK(hipStreamWaitEvent(e->bside[lane_id], e->ev_l2b[lane_id], 0));
+                sl = e->bside[lane_id];
+            }
             yf::PostArgs a = *post;
             a.head_large += (size_t)f0 * e->head_l_elems; a.head_small += (size_t)f0 * e->head_s_elems;
             a.boxes += (size_t)f0 * a.kmax * 4; a.scores += (size_t)f0 * a.kmax * 2;
             a.cls += (size_t)f0 * a.kmax; a.src += (size_t)f0 * a.kmax; a.counts += f0;
-            const int rc = yf::launch_post(a, n, lane_id == 0 ? s_main : e->side[lane_id - 1]);
+            const int rc = yf::launch_post(a, n, sl);
             if (rc == -1) return fail(YF_E_INVALID, "frame of %dx%d has too many cells for the on-chip NMS (limit 8191 cells / 160 KiB LDS)", e->H, e->W);
             if (rc) return fail(YF_E_HIP, "hipFuncSetAttribute(post_kernel) failed");
         }
-    }
-    if (lanes > 1) {  // join: the caller's stream continues only after every side stream has drained
-        for (int l = 1; l < lanes; ++l) {
-            HIP_OK(hipEventRecord(e->ev_join[l - 1], e->side[l - 1]));
-            HIP_OK(hipStreamWaitEvent(s_main, e->ev_join[l - 1], 0));
+      for (int lane_id = 0; lane_id < gcount; ++lane_id)   // every branch joins the caller's stream
+        if (forked[lane_id]) {
+            HIP_OK(hipEventRecord(e->ev_bjoin[lane_id], e->bside[lane_id]));
+            HIP_OK(hipStreamWaitEvent(s_main, e->ev_bjoin[lane_id], 0));
         }
+      for (int l = 1; l < gcount; ++l) {  // join: the caller's stream continues only after every side lane has drained
+          HIP_OK(hipEventRecord(e->ev_join[l - 1], e->side[l - 1]));
+          HIP_OK(hipStreamWaitEvent(s_main, e->ev_join[l - 1], 0));
+      }
     }
     HIP_OK(hipGetLastError());
     return YF_OK;
@@ -606,9 +667,9 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
         (void)hipFree(e->d_weights); delete e;
         return fail(YF_E_HIP, "hipMemcpy(weights) failed");
     }
-    for (int f = 0; f < 2; ++f) {
+    for (int f = 0; f < 3; ++f) {
         e->plans[f].H = H; e->plans[f].W = W;
-        build_plan(&e->plans[f], f == 1, dtype);
+        build_plan(&e->plans[f], f, dtype);
     }
     e->head_l_elems = 24u * (H / 16) * (W / 16);
     e->head_s_elems = 24u * (H / 32) * (W / 32);
@@ -618,7 +679,9 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
         const bool x3 = e->dtype == yf::DT_F16X3;
         std::vector<float> packed;
         for (Op& o : e->plans[0].ops) o.kdt = e->sdt();
-        for (Op& o : e->plans[1].ops) {
+      for (int lvl = 1; lvl <= 2; ++lvl) {
+        const Plan& P = e->plans[lvl];
+        for (Op& o : e->plans[lvl].ops) {
             o.kdt = e->sdt();
             if (o.type == OP_MRES) {
                 const LayerSpec &LE = kLayers[o.l_exp], &LP = kLayers[o.l_proj];
@@ -631,6 +694,13 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
                     yf::mres_pack_weights(hw + e->w_off[o.l_exp + 3 * k], hw + e->b_off[o.l_exp + 3 * k], hw + e->w_off[o.l_dw + 3 * k],
                                           hw + e->b_off[o.l_dw + 3 * k], hw + e->w_off[o.l_proj + 3 * k], hw + e->b_off[o.l_proj + 3 * k],
                                           LE.cin, LE.cout, LP.cout, packed.data() + o.mfma_off + (size_t)o.wstride * k, wm);
+                if (o.l_post >= 0) {   // trailing 1x1 conv: the pw GEMM's fp32 fragments, then its bias (exact fp32 in every engine dtype)
+                    const LayerSpec& LQ = kLayers[o.l_post];
+                    o.post_off = (long)packed.size();
+                    packed.resize(packed.size() + ((yf::mres_post_packed_floats(LQ.cin, LQ.cout) + 63) & ~(size_t)63));
+                    yf::mfma_pack_weights(hw + e->w_off[o.l_post], LQ.cin, 0, LQ.cout, packed.data() + o.post_off);
+                    memcpy(packed.data() + o.post_off + yf::mfma_packed_floats(LQ.cin, 0, LQ.cout), hw + e->b_off[o.l_post], LQ.cout * sizeof(float));
+                }
                 continue;
             }
             if (o.type == OP_K19) {
@@ -662,10 +732,37 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
                                      LP.cout, headn, packed.data() + o.mfma_off, o.kdt);
                 continue;
             }
+            if (o.type == OP_DCAT) {   // deconv: the pw GEMM's fragments per quadrant; conv4_1_1: the LDS stream + both biases
+                const LayerSpec &LD = kLayers[o.layer], &LC = kLayers[o.l_proj];
+                o.kdt = yf::DT_F32;
+                const size_t per = yf::mfma_packed_floats(LD.cin, 0, LD.cout);
+                o.mfma_off = (long)packed.size();
+                packed.resize(packed.size() + ((4 * per + 63) & ~(size_t)63));
+                for (int qd = 0; qd < 4; ++qd)
+                    yf::mfma_pack_weights(hw + e->w_off[o.layer] + (size_t)qd * LD.cin * LD.cout, LD.cin, 0, LD.cout, packed.data() + o.mfma_off + per * qd);
+                o.mfma_off2 = (long)packed.size();
+                packed.resize(packed.size() + ((yf::dcat_packed_floats() + 63) & ~(size_t)63));
+                yf::dcat_pack_weights(hw + e->w_off[o.l_proj], hw + e->b_off[o.layer], hw + e->b_off[o.l_proj], packed.data() + o.mfma_off2);
+                (void)LC;
+                continue;
+            }
+            if (o.type == OP_MDW2) {   // two mdw weight streams, one after the other
+                if (x3) o.kdt = yf::DT_F16X3;
+                for (int st = 0; st < 2; ++st) {
+                    const int ld = st ? o.l_dw2 : o.l_dw, lp = st ? o.l_proj2 : o.l_proj, headn = st ? 24 : 0;
+                    const LayerSpec &LD = kLayers[ld], &LP = kLayers[lp];
+                    const long off = (long)packed.size();
+                    (st ? o.mfma_off2 : o.mfma_off) = off;
+                    packed.resize(packed.size() + ((yf::mdw_packed_floats(LD.cin, LP.cout, headn, o.kdt) + 63) & ~(size_t)63));
+                    yf::mdw_pack_weights(hw + e->w_off[ld], hw + e->b_off[ld], hw + e->w_off[lp], hw + e->b_off[lp],
+                                         headn ? hw + e->w_off[o.l_head] : nullptr, headn ? hw + e->b_off[o.l_head] : nullptr, LD.cin, LP.cout,
+                                         headn, packed.data() + off, o.kdt);
+                }
+                continue;
+            }
             if (o.type != OP_LAYER) continue;
             const LayerSpec& L = kLayers[o.layer];
             if (L.kind != K_PW && L.kind != K_HEAD && L.kind != K_DECONV) continue;
-            const Plan& P = e->plans[1];
             int c1 = P.tensors[o.in1].C, c2 = o.in2 >= 0 ? P.tensors[o.in2].C : 0;
             if (!yf::mfma_has_kernel(c1, c2, L.cout, L.relu != 0, o.res >= 0, o.omode)) continue;
             const int nq = L.kind == K_DECONV ? 4 : 1;
@@ -684,6 +781,7 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
                                            packed.data() + o.mfma_off + per * qd);
             }
         }
+      }
         if (!packed.empty()) {
             if (hipMalloc(&e->d_wmfma, packed.size() * 4) != hipSuccess ||
                 hipMemcpy(e->d_wmfma, packed.data(), packed.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
@@ -706,7 +804,8 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
     for (int l = 0; l < 4; ++l) {
         if (hipStreamCreateWithFlags(&e->bside[l], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_bfork[l], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&e->ev_bjoin[l], hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&e->ev_bjoin[l], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_l2b[l], hipEventDisableTiming) != hipSuccess) {
             (void)yf_destroy(e);
             return fail(YF_E_HIP, "hipStreamCreate/hipEventCreate (branch) failed");
         }
@@ -728,6 +827,7 @@ int yf_destroy(yf_handle h)
         if (h->bside[l]) (void)hipStreamDestroy(h->bside[l]);
         if (h->ev_bfork[l]) (void)hipEventDestroy(h->ev_bfork[l]);
         if (h->ev_bjoin[l]) (void)hipEventDestroy(h->ev_bjoin[l]);
+        if (h->ev_l2b[l]) (void)hipEventDestroy(h->ev_l2b[l]);
     }
     (void)hipFree(h->d_weights);
     (void)hipFree(h->d_wmfma);
@@ -855,7 +955,13 @@ int yf_val_nms(yf_handle h, const float* d_pred, int N, int M, double conf_thres
 // Training-time loss of ONE head (first slice).  anchors: HOST double[3][2] of this head, net-input pixels.
 int yf_train_loss_workspace_bytes(yf_handle h, int N, int fh, int fw, size_t* out)
 {
-    if (!h || !out || N <= 0 || fh <= 0 || fw <= 0) return fail(YF_E_INVALID, "yf_train_loss_workspace_bytes: bad argument");
+    if (!h) return fail(YF_E_INVALID, "yf_train_loss_workspace_bytes: null handle");
+    return yf_train_head_loss_workspace_bytes(N, fh, fw, out);
+}
+
+int yf_train_head_loss_workspace_bytes(int N, int fh, int fw, size_t* out)
+{
+    if (!out || N <= 0 || fh <= 0 || fw <= 0) return fail(YF_E_INVALID, "yf_train_head_loss_workspace_bytes: bad argument");
     *out = yf::train_loss_workspace_bytes(N, fh, fw);
     return YF_OK;
 }
@@ -863,13 +969,22 @@ int yf_train_loss_workspace_bytes(yf_handle h, int N, int fh, int fw, size_t* ou
 int yf_train_loss(yf_handle h, const float* d_head, int N, int fh, int fw, const double* anchors, const float* d_targets, int T,
                   double ignore_thres, void* d_work, size_t work_bytes, float* d_losses, float* d_grad_head, void* stream)
 {
-    if (!h || !d_head || !anchors || !d_targets || !d_work || !d_losses || N <= 0 || fh <= 0 || fw <= 0 || T <= 0)
-        return fail(YF_E_INVALID, "yf_train_loss: bad argument");
-    if (work_bytes < yf::train_loss_workspace_bytes(N, fh, fw)) return fail(YF_E_WORKSPACE, "yf_train_loss: workspace too small");
-    if (reinterpret_cast<uintptr_t>(d_work) & 7) return fail(YF_E_INVALID, "yf_train_loss: workspace must be 8-byte aligned");
-    HIP_OK(hipSetDevice(h->device));
+    if (!h) return fail(YF_E_INVALID, "yf_train_loss: null handle");
+    return yf_train_head_loss(h->device, h->H, h->W, d_head, N, fh, fw, anchors, d_targets, T, ignore_thres, d_work, work_bytes, d_losses,
+                              d_grad_head, stream);
+}
+
+// The same without an engine handle (the loss needs the net-input size only for the head's stride), like the other yf_train_* entries.
+int yf_train_head_loss(int device, int H, int W, const float* d_head, int N, int fh, int fw, const double* anchors, const float* d_targets,
+                       int T, double ignore_thres, void* d_work, size_t work_bytes, float* d_losses, float* d_grad_head, void* stream)
+{
+    if (!d_head || !anchors || !d_targets || !d_work || !d_losses || N <= 0 || fh <= 0 || fw <= 0 || T <= 0 || H <= 0 || W <= 0)
+        return fail(YF_E_INVALID, "yf_train_head_loss: bad argument");
+    if (work_bytes < yf::train_loss_workspace_bytes(N, fh, fw)) return fail(YF_E_WORKSPACE, "yf_train_head_loss: workspace too small");
+    if (reinterpret_cast<uintptr_t>(d_work) & 7) return fail(YF_E_INVALID, "yf_train_head_loss: workspace must be 8-byte aligned");
+    HIP_OK(hipSetDevice(device));
     // yolo_loss.py:52-56: strides and feature-map-scaled anchors are Python doubles; torch uses them as float32
-    const double stride_h = (double)h->H / fh, stride_w = (double)h->W / fw;
+    const double stride_h = (double)H / fh, stride_w = (double)W / fw;
     float anc6[6];
     for (int a = 0; a < 3; ++a) { anc6[2 * a] = (float)(anchors[2 * a] / stride_w); anc6[2 * a + 1] = (float)(anchors[2 * a + 1] / stride_h); }
     yf::launch_train_loss(d_head, N, fh, fw, anc6, d_targets, T, (float)ignore_thres, d_work, d_losses, d_grad_head, (hipStream_t)stream);
@@ -940,7 +1055,7 @@ int yf_op_info_ex(yf_handle h, int op, char* name, int name_len, double* algorit
     double elems = 0, macs_mfma = 0, macs_valu = 0;
     // which pipe a layer's MACs run on in THIS plan: depthwise convs and everything inside the VALU block kernels are vector
     // FMAs; the pointwise / dense / deconv layers of the k19m, mres, mdw and pw_mfma / pw_ws kernels are MFMAs
-    const bool op_mfma = o.type == OP_K19 || o.type == OP_MRES || o.type == OP_MDW || (o.type == OP_LAYER && o.mfma_off >= 0);
+    const bool op_mfma = o.type == OP_K19 || o.type == OP_MRES || o.type == OP_MDW || o.type == OP_MDW2 || o.type == OP_DCAT || (o.type == OP_LAYER && o.mfma_off >= 0);
     auto add = [&](int li, size_t in_px, size_t out_px, bool res) {
         if (li < 0) return;
         const LayerSpec& L = kLayers[li];
@@ -958,8 +1073,14 @@ int yf_op_info_ex(yf_handle h, int op, char* name, int name_len, double* algorit
         for (int k = 0; k < o.nblk; ++k) {
             add(o.l_exp + 3 * k, epx, epx, false); add(o.l_dw + 3 * k, epx, opx, false); add(o.l_proj + 3 * k, opx, opx, o.res >= 0);
         }
+        add(o.l_post, opx, opx, false);
     } else if (o.type == OP_K19) {
         add(o.l_exp, ipx, ipx, false); add(o.l_dw, ipx, opx, false); add(o.l_proj, opx, opx, false);
+    } else if (o.type == OP_DCAT) {
+        add(o.layer, ipx, opx, false); add(o.l_proj, opx, opx, false);
+    } else if (o.type == OP_MDW2) {
+        add(o.l_dw, ipx, ipx, false); add(o.l_proj, ipx, ipx, false); add(o.l_dw2, ipx, ipx, false); add(o.l_proj2, ipx, ipx, false);
+        add(o.l_head, ipx, ipx, false);
     } else if (o.type == OP_MDW) {
         add(o.l_dw, ipx, ipx, false); add(o.l_proj, ipx, ipx, false); add(o.l_head, ipx, ipx, false);
     } else {
@@ -1017,7 +1138,7 @@ int yf_set_branches(yf_handle h, int on)
 
 int yf_set_fusion(yf_handle h, int level)
 {
-    if (!h || level < 0 || level > 1) return fail(YF_E_INVALID, "fusion level must be 0 or 1");
+    if (!h || level < 0 || level > 2) return fail(YF_E_INVALID, "fusion level must be 0, 1 or 2");
     h->fusion = level;
     return YF_OK;
 }

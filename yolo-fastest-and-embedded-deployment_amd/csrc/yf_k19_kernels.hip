@@ -131,8 +131,7 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
     }
     float w21q[2] = {0.f, 0.f}, biasq[2] = {0.f, 0.f};
     if constexpr (Q4) {
-        for (int i = threadIdx.x; i < WQ_F32 / 4; i += 512)
-            reinterpret_cast<float4*>(WQ)[i] = reinterpret_cast<const float4*>(a.wp + W9_F32 + W21_F32)[i];   // visible after the prologue's barrier
+        stage_to_lds<WQ_F32, 512>(WQ, a.wp + W9_F32 + W21_F32);   // all loads in flight at once; visible after the prologue's barrier
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             w21q[t] = a.wp[W9_F32 + W21_F32 + WQ_F32 + t * 64 + lane];

@@ -61,6 +61,42 @@ __device__ __forceinline__ void split_f16x4(float a0, float a1, float a2, float 
 }
 #endif
 
+#ifdef __HIPCC__
+// Copy NFLOATS (a multiple of 4) floats from global memory to LDS with ALL of a thread's 16-byte loads in flight before its first LDS
+// write.  Written as the obvious rolled loop (load, store, next) the compiler waits for every load before its store: one L2 round
+// trip per iteration, up to 22 in a row at the top of a kernel (measured: the "10-13 us floor" of the per-frame head kernels).
+template <int NFLOATS, int NTHR>
+struct LdsStage {   // issue() the loads early, commit() the LDS writes when convenient (other loads may be requested in between)
+    typedef float stage_f32x4 __attribute__((ext_vector_type(4)));
+    static_assert(NFLOATS % 4 == 0, "16-byte pieces");
+    static constexpr int N4 = NFLOATS / 4, NI = (N4 + NTHR - 1) / NTHR;
+    stage_f32x4 v[NI];
+    __device__ __forceinline__ void issue(const float* __restrict__ src)
+    {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int idx = threadIdx.x + i * NTHR;
+            v[i] = *reinterpret_cast<const stage_f32x4*>(src + 4 * (idx < N4 ? idx : N4 - 1));
+        }
+    }
+    __device__ __forceinline__ void commit(float* __restrict__ dst) const
+    {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int idx = threadIdx.x + i * NTHR;
+            if (idx < N4) *reinterpret_cast<stage_f32x4*>(dst + 4 * idx) = v[i];
+        }
+    }
+};
+template <int NFLOATS, int NTHR>
+__device__ __forceinline__ void stage_to_lds(float* __restrict__ dst, const float* __restrict__ src)
+{
+    LdsStage<NFLOATS, NTHR> st;
+    st.issue(src);
+    st.commit(dst);
+}
+#endif
+
 // Workgroups are dealt round-robin to the 8 XCDs of the chip (block i -> XCD i % 8), each with its own L2.  xcd_tile() gives XCD x the
 // CONTIGUOUS range [x * per, (x + 1) * per) of logical tiles, so that neighbouring tiles of a frame -- which share halo rows and
 // columns -- are fetched through one L2 instead of up to eight.  The ragged tail (grid % 8) keeps its index.  -DYF_XCD_SWIZZLE=0: off.
@@ -183,10 +219,15 @@ struct MresArgs {
     float* out_exp;    // optional: the EXPANDED tensor (after ReLU) is also written, NHWC [N,H,W,CEXP] -- conv4_2 is a skip tensor
     int nblk;          // > 1: a chain of that many residual blocks of this shape in one launch (tile == frame only)
     long wstride;      // floats between the packed weight streams of consecutive chained blocks
+    const float* post_w;  // optional (mres_has_post shapes): a 1x1 conv + ReLU applied to the last block's result on chip --
+                          // mfma_pack_weights fragments followed by the bias; the block's own result is then NOT stored
+    float* post_out;      // NHWC [N,H,W,POSTN]
 };
 int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArgs& a, int N, hipStream_t s, int dtype = DT_F32);
 bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride = 1, bool relu_out = false, int dtype = DT_F32);
 bool mres_can_chain(int cin, int cexp, int cout, int H, int W);  // relu_out: ReLU after the projection
+bool mres_has_post(int cin, int cexp, int cout, int postn);      // a trailing 1x1 conv (+ReLU) of postn channels can ride in the launch
+size_t mres_post_packed_floats(int cout, int postn);
 size_t mres_packed_floats(int cin, int cexp, int cout, int wmode = WM_F32);
 void mres_pack_weights(const float* w1, const float* b1, const float* wd, const float* bd, const float* w2, const float* b2,
                        int cin, int cexp, int cout, float* out, int wmode = WM_F32);
@@ -200,9 +241,19 @@ struct MdwArgs {
 };
 int launch_mdw(int c, int n, int headn, const MdwArgs& a, int Nf, hipStream_t s, int dtype = DT_F32);
 bool mdw_has_kernel(int c, int n, int headn);
+// the small head's two pairs as ONE launch (frames that fit one tile): stage 1 (c1 -> n1, no head) feeds stage 2 (n1 -> n2 -> head) in LDS
+bool mdw2_can_chain(int c1, int n1, int n2, int headn, int H, int W);
+int launch_mdw2(const float* in, const float* wp1, const float* wp2, float* out_nchw, int H, int W, int Nf, hipStream_t s, int dtype = DT_F32);
 size_t mdw_packed_floats(int c, int n, int headn, int wmode = WM_F32);
 void mdw_pack_weights(const float* wd, const float* bd, const float* w, const float* b, const float* hw, const float* hb, int c,
                       int n, int headn, float* out, int wmode = WM_F32);
+
+// deconv5_1 + conv4_1_1 over cat(conv4_2, deconv5_1) as one launch (yf_dcat_kernels.hip); fp32 storage
+bool dcat_has_kernel(int cin, int cskip, int cout);
+size_t dcat_packed_floats();
+void dcat_pack_weights(const float* w_cat /*[136 + 96][96]*/, const float* b_deconv, const float* b_conv, float* out);
+int launch_dcat(const float* x /*conv5_2*/, const float* skip /*conv4_2*/, const float* w_deconv /*4 x mfma_pack_weights*/, const float* w_conv, float* out,
+                int h, int w, int Nf, hipStream_t s);
 
 struct K19Args {
     const float* in;              // NHWC [N,H,W,4] (res1_1 output, stride-2 resolution)
@@ -263,8 +314,8 @@ void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float
                     int C, long HW, int relu, void* scratch, hipStream_t s, const float* residual = nullptr);
 void launch_tbn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, float* dgamma, float* dbeta, float* dx,
                     int N, int C, long HW, int relu, void* scratch, hipStream_t s);
-void launch_tadam_multi(int nt, float* const* p, const float* const* g, float* const* m, float* const* v, const long* sizes, double lr, double b1,
-                        double b2, double eps, int step, void* d_table, hipStream_t s);
+int launch_tadam_multi(int nt, float* const* p, const float* const* g, float* const* m, float* const* v, const long* sizes, double lr, double b1,
+                       double b2, double eps, int step, void* d_table, void* h_table, int upload, hipStream_t s);
 void launch_tchan_sum(const float* dy, float* out, int N, int C, long HW, hipStream_t s);
 void launch_tadd(const float* a, const float* b, float* out, long total, hipStream_t s);
 void launch_tslice(const float* src, float* dst, int N, int C, long HW, int Cs, int sc0, int Cd, int dc0, hipStream_t s);

@@ -101,8 +101,12 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
     const TT* __restrict__ src = reinterpret_cast<const TT*>(a.in) + (long)n * a.H * a.W * C;
 
     MDW_STAMP_DECL
+#ifndef YF_MDW_ROLLED_STAGING
+    stage_to_lds<WFLOATS, NTHR>(WL, a.wp);
+#else   // round 2's staging loop (A/B builds only): one exposed L2 round trip per iteration
     for (int i = threadIdx.x * 4; i < WFLOATS; i += NTHR * 4)
         *reinterpret_cast<float4*>(&WL[i]) = *reinterpret_cast<const float4*>(a.wp + i);
+#endif
 
     // chunk-invariant addressing of this thread's NLD fill items: item id -> (region pixel, channel quad)
     int goff[NLD];  // frame-relative pixel index, -1 = outside the image (zero fill), -2 = no item
@@ -317,6 +321,297 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
     }
     MDW_STAMP(6)   // epilogue
     MDW_STAMP_FLUSH
+}
+
+// ------------------------------------------------------------------------------------------------
+// mdw2_kernel: the SMALL head's two pairs in one launch (fusion level 2)
+//     conv5_3 (dw5x5+ReLU) -> conv5_4 (1x1)   ->   conv5_5 (dw5x5+ReLU) -> conv5_6 (1x1) -> head_5     yolo_fastest.py:200-206
+// for frames that fit ONE tile (the stride-32 frame of the 320x256 net is 8 x 10 pixels), so that stage 2's 5x5 windows need no
+// pixels of another workgroup.  Stage 1 is mdw_kernel's chunk loop; its result (+ bias, zero outside the image = stage 2's zero
+// padding) goes to LDS as Y[16-ch chunk][4-ch group][pixel][4] instead of HBM.  Stage 2 is the same chunk loop with the E fill taken
+// from Y (one 16-byte LDS copy per thread and chunk; E's halo ring is zero from stage 1's last fill) and the head conv chained in
+// registers.  What the single launch removes: the second launch's fill/drain, the conv5_4 tensor's HBM round trip, and stage 2's
+// exposed weight staging -- the first SPLIT chunks of stage 2's weight stream are staged beside stage 1's at kernel start, the rest
+// is requested into registers before stage 1's epilogue and lands in stage 1's (then dead) weight region behind one barrier.
+// Arithmetic and its order are mdw_kernel's: the heads are bitwise those of the two-launch plan.
+// ------------------------------------------------------------------------------------------------
+struct Mdw2Args {
+    const float* in;    // NHWC [N,H,W,C1]
+    const float* wp1;   // stage 1 stream: mdw_pack_weights(C1, N1, no head)
+    const float* wp2;   // stage 2 stream: mdw_pack_weights(N1, N2, HEADN)
+    float* out;         // NCHW [N,HEADN,H,W]
+    int H, W;
+};
+
+__host__ __device__ constexpr int mdw2_split(int c1, int n1, int n2, int headn, int wmode)
+{
+    // chunks of stage 2's stream staged at kernel start: the fewest that let the REST fit into stage 1's weight region
+    int s = 0;
+    while (mdw_stream_floats(n1, n2, headn, wmode) - s * mdw_chunk_floats(n2, wmode) > mdw_stream_floats(c1, n1, 0, wmode)) ++s;
+    return s;
+}
+__host__ __device__ constexpr size_t mdw2_lds_floats(int c1, int n1, int n2, int headn, int th, int tw, int nwave, int wmode)
+{
+    return (size_t)16 * mdw_epl(th, tw, nwave) + (size_t)n1 * th * tw + mdw_stream_floats(c1, n1, 0, wmode) +
+           (size_t)mdw2_split(c1, n1, n2, headn, wmode) * mdw_chunk_floats(n2, wmode);
+}
+
+// depthwise 5x5 of channels 4q..4q+3 at this lane's pixel + the 1x1 conv's MFMAs of one 16-channel chunk (one M-tile per wave)
+template <int N, int RW, typename TT>
+__device__ __forceinline__ void mdw_chunk_1tile(const float* E, int epl, const float* wc, int lane, int rp0, f32x4 (&acc)[N / 16])
+{
+    constexpr bool X3 = is_x3<TT>::value;
+    constexpr bool H16 = sizeof(TT) == 2 || X3;
+    constexpr int NT = N / 16, OFF_BD = 400, OFF_W = 416;
+    const int q = lane >> 4;
+    const float4 bd = *reinterpret_cast<const float4*>(wc + OFF_BD + 4 * q);
+    mdw_f32x2 d2[2] = {mdw_f32x2{bd.x, bd.y}, mdw_f32x2{bd.z, bd.w}};
+    const float4* e4 = reinterpret_cast<const float4*>(E) + q * epl;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+        float4 vc[5], wr[5];
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) wr[kx] = *reinterpret_cast<const float4*>(wc + (ky * 5 + kx) * 16 + 4 * q);
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) vc[kx] = e4[rp0 + (ky - 2) * RW + (kx - 2)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+            const float4 v = vc[kx];
+            d2[0] = __builtin_elementwise_fma(mdw_f32x2{v.x, v.y}, mdw_f32x2{wr[kx].x, wr[kx].y}, d2[0]);
+            d2[1] = __builtin_elementwise_fma(mdw_f32x2{v.z, v.w}, mdw_f32x2{wr[kx].z, wr[kx].w}, d2[1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (X3) {
+        f16x4 dh, dl;
+        split_f16x4(fmaxf(d2[0][0], 0.f), fmaxf(d2[0][1], 0.f), fmaxf(d2[1][0], 0.f), fmaxf(d2[1][1], 0.f), dh, dl);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(reinterpret_cast<const f16x4*>(wc + OFF_W)[(NT + nt) * 64 + lane], dh, acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(reinterpret_cast<const f16x4*>(wc + OFF_W)[nt * 64 + lane], dl, acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(reinterpret_cast<const f16x4*>(wc + OFF_W)[nt * 64 + lane], dh, acc[nt], 0, 0, 0);
+    } else if constexpr (H16) {
+        const f16x4 dh = f16x4{(half_t)fmaxf(d2[0][0], 0.f), (half_t)fmaxf(d2[0][1], 0.f), (half_t)fmaxf(d2[1][0], 0.f), (half_t)fmaxf(d2[1][1], 0.f)};
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(reinterpret_cast<const f16x4*>(wc + OFF_W)[nt * 64 + lane], dh, acc[nt], 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float w2f[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) w2f[nt] = wc[OFF_W + (j * NT + nt) * 64 + lane];
+            const float dj = __int_as_float(max(__float_as_int(d2[j >> 1][j & 1]), 0));   // ReLU of a non-NaN as one v_max_i32
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[nt], dj, acc[nt], 0, 0, 0);
+        }
+    }
+}
+
+template <int C1, int N1, int N2, int HEADN, int TH, int TW, int NWAVE, typename TT>
+__global__ void __launch_bounds__(NWAVE * 64) mdw2_kernel(Mdw2Args a)
+{
+    constexpr bool X3 = is_x3<TT>::value;
+    constexpr bool H16 = sizeof(TT) == 2 || X3;
+    constexpr int WMODE = wmode_of<TT>(), WM = X3 ? 2 : 1;
+    constexpr int NTHR = NWAVE * 64;
+    constexpr int RH = TH + 4, RW = TW + 4, NRP = RH * RW, NPX = TH * TW;
+    constexpr int MTO = NPX / 16;
+    static_assert(MTO == NWAVE && NPX % 16 == 0, "one M-tile per wave");
+    constexpr int EPL = mdw_epl(TH, TW, NWAVE);
+    constexpr int NT1 = N1 / 16, NCH1 = C1 / 16, NT2 = N2 / 16, NCH2 = N1 / 16;
+    constexpr int CHUNK1 = mdw_chunk_floats(N1, WMODE), CHUNK2 = mdw_chunk_floats(N2, WMODE);
+    constexpr int WF1 = mdw_stream_floats(C1, N1, 0, WMODE), WF2 = mdw_stream_floats(N1, N2, HEADN, WMODE);
+    constexpr int SPLIT = mdw2_split(C1, N1, N2, HEADN, WMODE), PART_A = SPLIT * CHUNK2, PART_B = WF2 - PART_A;
+    static_assert(PART_B <= WF1 && SPLIT <= NCH2 && PART_A % 4 == 0 && PART_B % 4 == 0, "stage 2's stream must fit");
+    constexpr int OFF_BPW1 = NCH1 * CHUNK1;
+    // stage 2's stream, as addressed from its chunk SPLIT on (region A): [chunks SPLIT.. | b_pw | head fragments | head bias]
+    constexpr int OFF_BPW2 = (NCH2 - SPLIT) * CHUNK2, OFF_HW = OFF_BPW2 + N2, KSH = N2 / 4, NTH = 2;
+    constexpr int OFF_HB = OFF_HW + (H16 ? WM * (N2 / 16) * NTH * 128 : KSH * NTH * 64);
+    constexpr int NLD = (NRP * 4 + NTHR - 1) / NTHR;
+    constexpr int NB4 = (PART_B / 4 + NTHR - 1) / NTHR;
+    static_assert(HEADN > 0 && HEADN <= 32, "head width");
+    extern __shared__ __attribute__((aligned(16))) float mdw_smem[];
+    float* E = mdw_smem;                 // [4][EPL][4]
+    float* Y = E + 16 * EPL;             // [NCH2][4][NPX][4]: stage 1's result
+    float* WA = Y + N1 * NPX;            // stage 1's stream, later the rest of stage 2's
+    float* WB = WA + WF1;                // the first SPLIT chunks of stage 2's stream
+
+    const int n = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const TT* __restrict__ src = reinterpret_cast<const TT*>(a.in) + (long)n * a.H * a.W * C1;
+
+    {   // both weight regions in one batch of loads
+        LdsStage<WF1, NTHR> sa;
+        LdsStage<PART_A, NTHR> sb;
+        sa.issue(a.wp1);
+        sb.issue(a.wp2);
+        sa.commit(WA);
+        sb.commit(WB);
+    }
+
+    int goff[NLD];  // frame-relative pixel index, -1 = outside the image (zero fill), -2 = no item
+#pragma unroll
+    for (int m = 0; m < NLD; ++m) {
+        const int id = threadIdx.x + m * NTHR;
+        const int px = id >> 2;
+        const int ry = px / RW, rx = px - ry * RW;
+        const int iy = ry - 2, ix = rx - 2;
+        goff[m] = px >= NRP ? -2 : (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? iy * a.W + ix : -1;
+    }
+    float4 pf[NLD];
+    auto prefetch = [&](int c) {
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) {
+            const int id = threadIdx.x + m * NTHR;
+            pf[m] = goff[m] >= 0 ? ld4<TT>(src + (long)goff[m] * C1 + c * 16 + 4 * (id & 3)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    prefetch(0);
+
+    const int op = wave * 16 + r, oy = op / TW, ox = op - oy * TW;   // this lane's output pixel (both stages)
+    const int rp0 = (oy + 2) * RW + ox + 2;
+    const bool inside = oy < a.H && ox < a.W;
+
+    // ================= stage 1: dw5x5 (C1) -> 1x1 (N1) =================
+    f32x4 acc1[NT1];
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) acc1[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int c = 0; c < NCH1; ++c) {
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) {
+            const int id = threadIdx.x + m * NTHR;
+            if (goff[m] != -2) *reinterpret_cast<float4*>(&E[((id & 3) * EPL + (id >> 2)) * 4]) = pf[m];
+        }
+        __syncthreads();
+        if (c + 1 < NCH1) prefetch(c + 1);
+        mdw_chunk_1tile<N1, RW, TT>(E, EPL, WA + c * CHUNK1, lane, rp0, acc1);
+        __syncthreads();
+    }
+    // the rest of stage 2's stream: requested now, written over stage 1's stream once every wave is past its epilogue
+    f32x4 wv[NB4];
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+        const int idx = threadIdx.x + i * NTHR;
+        wv[i] = *reinterpret_cast<const f32x4*>(a.wp2 + PART_A + 4 * (idx < PART_B / 4 ? idx : PART_B / 4 - 1));
+    }
+    // stage 1's epilogue: + bias -> Y (lane (r, q) holds channels nt*16 + 4q .. +3 of its pixel = one record of stage 2's chunk nt);
+    // pixels outside the image are stage 2's zero padding
+    {
+        const float* bpw = WA + OFF_BPW1;
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) {
+            const float4 bias = *reinterpret_cast<const float4*>(bpw + nt * 16 + 4 * q);
+            const float4 v = inside ? make_float4(acc1[nt][0] + bias.x, acc1[nt][1] + bias.y, acc1[nt][2] + bias.z, acc1[nt][3] + bias.w)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&Y[((nt * 4 + q) * NPX + op) * 4]) = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+        const int idx = threadIdx.x + i * NTHR;
+        if (idx < PART_B / 4) *reinterpret_cast<f32x4*>(&WA[4 * idx]) = wv[i];
+    }
+    // E fill of a stage-2 chunk: interior pixels from Y (the halo ring of E is zero since stage 1's last fill: tile == frame)
+    auto fill2 = [&](int c) {
+        for (int idx = threadIdx.x; idx < 4 * NPX; idx += NTHR) {
+            const int qq = idx / NPX, p = idx - qq * NPX;
+            const int py = p / TW, px = p - py * TW;
+            *reinterpret_cast<float4*>(&E[(qq * EPL + (py + 2) * RW + px + 2) * 4]) = *reinterpret_cast<const float4*>(&Y[((c * 4 + qq) * NPX + p) * 4]);
+        }
+    };
+    fill2(0);
+    __syncthreads();
+
+    // ================= stage 2: dw5x5 (N1) -> 1x1 (N2) -> head =================
+    f32x4 acc2[NT2];
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int c = 0; c < NCH2; ++c) {
+        const float* wc = c < SPLIT ? WB + c * CHUNK2 : WA + (c - SPLIT) * CHUNK2;
+        mdw_chunk_1tile<N2, RW, TT>(E, EPL, wc, lane, rp0, acc2);
+        __syncthreads();
+        if (c + 1 < NCH2) {
+            fill2(c + 1);
+            __syncthreads();
+        }
+    }
+    // head conv chained in registers (mdw_kernel's epilogue): logits NCHW
+    {
+        const float* bpw = WA + OFF_BPW2;
+        const float* hw = WA + OFF_HW;
+        const float* hb = WA + OFF_HB;
+        f32x4 h[NTH] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+            const float4 bias = *reinterpret_cast<const float4*>(bpw + nt * 16 + 4 * q);
+            const float hv[4] = {acc2[nt][0] + bias.x, acc2[nt][1] + bias.y, acc2[nt][2] + bias.z, acc2[nt][3] + bias.w};
+            if constexpr (X3) {
+                f16x4 bh, bl;
+                split_f16x4(hv[0], hv[1], hv[2], hv[3], bh, bl);
+                const f16x4* hwh = reinterpret_cast<const f16x4*>(hw);
+                const f16x4* hwl = hwh + (N2 / 16) * NTH * 64;
+#pragma unroll
+                for (int nth = 0; nth < NTH; ++nth) {
+                    h[nth] = __builtin_amdgcn_mfma_f32_16x16x16f16(hwl[(nt * NTH + nth) * 64 + lane], bh, h[nth], 0, 0, 0);
+                    h[nth] = __builtin_amdgcn_mfma_f32_16x16x16f16(hwh[(nt * NTH + nth) * 64 + lane], bl, h[nth], 0, 0, 0);
+                    h[nth] = __builtin_amdgcn_mfma_f32_16x16x16f16(hwh[(nt * NTH + nth) * 64 + lane], bh, h[nth], 0, 0, 0);
+                }
+            } else if constexpr (H16) {
+                const f16x4 bh = f16x4{(half_t)hv[0], (half_t)hv[1], (half_t)hv[2], (half_t)hv[3]};
+#pragma unroll
+                for (int nth = 0; nth < NTH; ++nth)
+                    h[nth] = __builtin_amdgcn_mfma_f32_16x16x16f16(reinterpret_cast<const f16x4*>(hw)[(nt * NTH + nth) * 64 + lane], bh, h[nth], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int nth = 0; nth < NTH; ++nth)
+                        h[nth] = __builtin_amdgcn_mfma_f32_16x16x4f32(hw[((nt * 4 + j) * NTH + nth) * 64 + lane], hv[j], h[nth], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int nth = 0; nth < NTH; ++nth)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int hc = nth * 16 + 4 * q + reg;
+                if (hc < HEADN && inside) a.out[(((long)n * HEADN + hc) * a.H + oy) * a.W + ox] = h[nth][reg] + hb[hc];  // NCHW
+            }
+    }
+}
+
+template <int C1, int N1, int N2, int HEADN, int TH, int TW, int NWAVE, typename T>
+static int launch_mdw2_t(const Mdw2Args& a, int Nf, hipStream_t s)
+{
+    if (a.H > TH || a.W > TW) return -4;   // the chain needs tile == frame
+    constexpr size_t lds = mdw2_lds_floats(C1, N1, N2, HEADN, TH, TW, NWAVE, wmode_of<T>()) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "LDS");
+    static bool attr_done[YF_MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (dev < 0) return -2;
+    if (lds > 64 * 1024 && !attr_done[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mdw2_kernel<C1, N1, N2, HEADN, TH, TW, NWAVE, T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -2;
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL((mdw2_kernel<C1, N1, N2, HEADN, TH, TW, NWAVE, T>), dim3((unsigned)Nf), dim3(NWAVE * 64), lds, s, a);
+    return 0;
+}
+
+// conv5_3 -> conv5_4 -> conv5_5 -> conv5_6 -> head_5 on H x W frames in one launch?
+bool mdw2_can_chain(int c1, int n1, int n2, int headn, int H, int W) { return c1 == 96 && n1 == 128 && n2 == 128 && headn == 24 && H <= 8 && W <= 10; }
+
+int launch_mdw2(const float* in, const float* wp1, const float* wp2, float* out, int H, int W, int Nf, hipStream_t s, int dtype)
+{
+    const Mdw2Args a{in, wp1, wp2, out, H, W};
+    return dtype == DT_F16 ? launch_mdw2_t<96, 128, 128, 24, 8, 10, 5, half_t>(a, Nf, s)
+         : dtype == DT_F16X3 ? launch_mdw2_t<96, 128, 128, 24, 8, 10, 5, x3_t>(a, Nf, s) : launch_mdw2_t<96, 128, 128, 24, 8, 10, 5, float>(a, Nf, s);
 }
 
 template <int C, int N, int HEADN, int TH, int TW, int NWAVE, typename T>

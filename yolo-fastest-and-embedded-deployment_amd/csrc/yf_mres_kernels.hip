@@ -418,6 +418,56 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
     MRES_STAMP_FLUSH(NWAVE)
 }
 
+
+// ---- POSTN: a 1x1 conv + ReLU on the LAST block's result while it is still in LDS (conv5_2 after res5_5, yolo_fastest.py:197-198).
+// The chain's last block leaves its result in X instead of HBM; after one barrier every wave owns one n-tile of the conv and walks
+// over M-tiles of the tile's pixels: B operand = the pixel's channels from X (the same 16-byte fragment reads as the expansion),
+// A operand = the conv's weight fragments in the pw GEMM's own packing (mfma_pack_weights: [k-step][n-tile][lane], then the bias),
+// read straight from L2 (12 coalesced 256-byte loads per wave, requested BEFORE the barrier).  acc = 0, k-steps in order, + bias,
+// ReLU: the arithmetic -- and the bits -- of pw_ws_kernel, which this replaces as a launch.  Always exact fp32 MFMAs on the fp32
+// tile (also in the fp16 / split-operand engines: 360 MFMAs per frame).
+template <int K, int NOUT>
+struct MresPostFrag { float w[mres_ksteps(K)]; float4 bias; };
+
+template <int K, int NOUT, int NWAVE>
+__device__ __forceinline__ void mres_post_fetch(const float* __restrict__ pw, int wave, int lane, MresPostFrag<K, NOUT>& f)
+{
+    constexpr int KS = mres_ksteps(K), NT = NOUT / 16;
+    static_assert(K % 16 == 0 && NOUT % 16 == 0 && NWAVE >= NT, "post conv shape");
+    const int nt = wave % NT;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) f.w[s] = pw[(s * NT + nt) * 64 + lane];
+    f.bias = *reinterpret_cast<const float4*>(pw + KS * NT * 64 + nt * 16 + 4 * (lane >> 4));
+}
+
+template <int K, int NOUT, int TH, int TW, int RW, int XP, int NWAVE, typename T>
+__device__ __forceinline__ void mres_post_conv(const float* X, const MresPostFrag<K, NOUT>& f, T* __restrict__ out, int wave, int lane,
+                                               int n, int oy0, int ox0, int H, int W)
+{
+    constexpr int NB = K / 16, NT = NOUT / 16, MTO = (TH * TW) / 16, NG = NWAVE / NT;
+    const int r = lane & 15, q = lane >> 4;
+    const int nt = wave % NT, g = wave / NT;
+    if (g >= NG) return;   // wave-uniform: the waves beyond NG full groups have no n-tile
+#pragma unroll 1
+    for (int mt = g; mt < MTO; mt += NG) {
+        const int p = mt * 16 + r, oy = p / TW, ox = p - oy * TW;
+        const float* xr = X + ((oy + 1) * RW + ox + 1) * XP + 4 * q;
+        float4 av[NB];
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) av[kb] = *reinterpret_cast<const float4*>(xr + kb * 16);
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[kb * 4 + j], ((const float*)&av[kb])[j], acc, 0, 0, 0);
+        const int gy = oy0 + oy, gx = ox0 + ox;
+        if (gy >= H || gx >= W) continue;
+        const float4 v = make_float4(fmaxf(acc[0] + f.bias.x, 0.f), fmaxf(acc[1] + f.bias.y, 0.f), fmaxf(acc[2] + f.bias.z, 0.f),
+                                     fmaxf(acc[3] + f.bias.w, 0.f));
+        st4<T>(out + (((long)n * H + gy) * W + gx) * NOUT + nt * 16 + 4 * q, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // mres_pc_kernel: the same block with the workgroup's waves split into NWP *producers* (expansion MFMAs of chunk c+1
 // into one of two E buffers) and NWC *consumers* (depthwise + projection of chunk c from the other buffer): the matrix
@@ -430,7 +480,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
 // requested into registers before the epilogue and lands in LDS behind two barriers.  Saves, per chained block, a launch's
 // fill/drain, the input staging and the output round trip.
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NWC, typename T>
+template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NWC, typename T, int POSTN = 0>
 __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
 {
     constexpr int NWAVE = NWP + NWC;
@@ -579,6 +629,12 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
             __syncthreads();
         }
       }
+      if constexpr (POSTN > 0) {   // the last block's result is in X once the consumers pass this barrier
+          MresPostFrag<COUT, POSTN> pf;
+          mres_post_fetch<COUT, POSTN, NWAVE>(a.post_w, wave, lane, pf);
+          __syncthreads();
+          mres_post_conv<COUT, POSTN, TH, TW, RW, XP, NWAVE, T>(X, pf, reinterpret_cast<T*>(a.post_out), wave, lane, n, oy0, ox0, a.H, a.W);
+      }
     } else {
         // ================= consumer: depthwise + projection of chunk s - 1 from E[(s - 1) & 1] =================
         const int cw = wave - NWP;
@@ -698,8 +754,8 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
                     const float4 x = *reinterpret_cast<const float4*>(xr);
                     v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
                 }
-                if (last) st4<T>(reinterpret_cast<T*>(a.out) + (((long)n * a.H + gy) * a.W + gx) * COUT + col, v);
-                else *reinterpret_cast<float4*>(xr) = v;   // the next block's input (CIN == COUT), in place
+                if (last && POSTN == 0) st4<T>(reinterpret_cast<T*>(a.out) + (((long)n * a.H + gy) * a.W + gx) * COUT + col, v);
+                else *reinterpret_cast<float4*>(xr) = v;   // the next block's (or the post conv's) input (CIN == COUT), in place
             }
         }
         if (!last) {
@@ -707,10 +763,16 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
             __syncthreads();
         }
       }
+      if constexpr (POSTN > 0) {
+          MresPostFrag<COUT, POSTN> pf;
+          mres_post_fetch<COUT, POSTN, NWAVE>(a.post_w, wave, lane, pf);
+          __syncthreads();
+          mres_post_conv<COUT, POSTN, TH, TW, RW, XP, NWAVE, T>(X, pf, reinterpret_cast<T*>(a.post_out), wave, lane, n, oy0, ox0, a.H, a.W);
+      }
     }
 }
 
-template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NWC, typename T>
+template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NWC, typename T, int POSTN = 0>
 static int launch_mres_pc_t(MresArgs a, int N, hipStream_t s)
 {
     a.tiles_y = (a.H + TH - 1) / TH;
@@ -723,13 +785,14 @@ static int launch_mres_pc_t(MresArgs a, int N, hipStream_t s)
     const int dev = current_device();
     if (dev < 0) return -2;
     if (lds > 64 * 1024 && !attr_done[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, T>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, T, POSTN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
         attr_done[dev] = true;
     }
     if (a.nblk > 1 && (a.tiles_y != 1 || a.tiles_x != 1 || !RES)) return -4;  // a chain needs tile == frame
-    hipLaunchKernelGGL((mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, T>), dim3((unsigned)(N * a.tiles_y * a.tiles_x)),
+    if ((POSTN > 0) != (a.post_w != nullptr) || (POSTN > 0 && !a.post_out)) return -5;
+    hipLaunchKernelGGL((mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, T, POSTN>), dim3((unsigned)(N * a.tiles_y * a.tiles_x)),
                        dim3((NWP + NWC) * 64), lds, s, a);
     return 0;
 }
@@ -780,8 +843,18 @@ static int launch_mres_any(const MresArgs& a, int N, hipStream_t s)
     else { static_assert(S == 1, "producer/consumer kernel: stride 1 only"); return launch_mres_pc_t<CIN, CEXP, COUT, RES, TH, TW, NWP, NW, T>(a, N, s); }
 }
 
+// the one block shape with a fused trailing 1x1 conv: res5_x + conv5_2 (48 -> 96, ReLU)
+bool mres_has_post(int cin, int cexp, int cout, int postn) { return cin == 48 && cexp == 224 && cout == 48 && postn == 96; }
+size_t mres_post_packed_floats(int cout, int postn) { return (size_t)mres_ksteps(cout) * (postn / 16) * 64 + postn; }
+
 int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArgs& a, int N, hipStream_t s, int dtype)
 {
+    if (a.post_w) {
+        if (!(cin == 48 && cexp == 224 && cout == 48 && res && stride == 1)) return -5;
+        return dtype == DT_F16 ? launch_mres_pc_t<48, 224, 48, true, 8, 10, 8, 5, half_t, 96>(a, N, s)
+             : dtype == DT_F16X3 ? launch_mres_pc_t<48, 224, 48, true, 8, 10, 8, 5, x3_t, 96>(a, N, s)
+                                 : launch_mres_pc_t<48, 224, 48, true, 8, 10, 8, 5, float, 96>(a, N, s);
+    }
 #define MR(ci, ce, co, rs, st, th, tw, np, nw)                                                                    \
     if (cin == ci && cexp == ce && cout == co && res == rs && stride == st)                                       \
         return dtype == DT_F16 ? launch_mres_any<ci, ce, co, rs, st, th, tw, np, nw, half_t>(a, N, s)              \

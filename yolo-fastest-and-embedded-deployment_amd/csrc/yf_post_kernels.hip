@@ -10,10 +10,10 @@
 //   * threshold: the host finds, with this machine's libm, the smallest fp32 logit t for which the
 //     reference's  1/(1+exp(-t)) > conf_thres  holds (sigmoid is monotone), so the device compares raw
 //     fp32 logits -- bit-exact for every conf_thres;
-//   * order: candidates are sorted ONCE on a unique 64-bit key (class asc | conf logit desc | cell asc):
+//   * order: candidates are sorted ONCE on a unique 64-bit key (class asc | conf desc -- conf_order() -- | cell asc):
 //     class-major output, conf descending, ties in decode order == the reference's bucket + stable sort
 //     (sigmoid is monotone in the logit; two different logits share one double conf only above
-//     logit ~ 22, conf > 1-3e-10);
+//     logit ~ 22, conf > 1-3e-10, and there the key is built from the conf's own fp64 value: conf_order());
 //   * boxes: fp64 arithmetic and rint() (round-half-even == Python round());
 //   * IoU test: int64 areas, fp64 IEEE division, strict '>'.
 #include <hip/hip_runtime.h>
@@ -33,6 +33,20 @@ __device__ inline uint32_t orderable(float f)
     return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
 }
 __device__ inline double sigmoid_d(double x) { return 1. / (1. + exp(-x)); }
+// 32-bit sort field of a conf logit: ascending field == descending conf, and EQUAL fields exactly where the reference's fp64
+// conf = 1 / (1 + exp(-t)) (detect.py:23-25, :58) is equal, so that its stable sort's ties (decode order, :167) are ties here too.
+//   * t <= 20: distinct fp32 logits give distinct fp64 confs (an fp32 step moves conf by >= 17 ulp there) -> the logit's own order;
+//   * t > 20: 1 + exp(-t) rounds to 1 + k 2^-52 with k = RN(exp(-t) 2^52) < 2^24, and 1 / (1 + k 2^-52) rounds to 1 - k 2^-52 exactly
+//     (the next term, k^2 2^-104 < 5e-18, is below a quarter of the spacing of doubles under 1): conf is a function of k alone.
+//     Different logits share one conf above t ~ 22 (all of them above 36.7, where conf == 1.0); the field is k.  A device exp() that is
+//     one ulp off the host's changes k only if exp(-t) 2^52 lies within k 2^-52 (relative) of a half-integer: < 2e-9 per candidate.
+// The two ranges join monotonically: k(20+) = 9.28e6 < ~orderable(20.0f) = 0x3e5fffff.
+// (Not covered: logits within 4e-9 of zero also share conf == 0.5 +- 1 ulp in fp64; they only pass thresholds below 0.5.)
+__device__ inline uint32_t conf_order(float t)
+{
+    if (t > 20.f) return (uint32_t)rint(exp(-(double)t) * 4503599627370496.0);
+    return ~orderable(t);
+}
 __device__ inline int32_t clamp_i32(double v)
 {
     if (v >= 2147483647.0) return 2147483647;
@@ -97,7 +111,7 @@ __global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncel
                     float v = logit_at(r, 5 + k);
                     if (v > best) { best = v; cls = k; }  // np.argmax: first maximum wins
                 }
-                key = ((uint64_t)cls << 45) | ((uint64_t)(~orderable(t4)) << 13) | (uint64_t)cell;
+                key = ((uint64_t)cls << 45) | ((uint64_t)conf_order(t4) << 13) | (uint64_t)cell;
             }
         }
         unsigned long long m = __ballot(pass);

@@ -269,13 +269,21 @@ int yf_train_unit_backward(int device, int deconv, const float* d_x, const float
 int yf_train_adam_multi(int device, int ntensors, void* const* d_p, const void* const* d_g, void* const* d_m, void* const* d_v, const long* sizes,
                         double lr, double beta1, double beta2, double eps, int step, void* d_table, size_t table_bytes, void* stream)
 {
+    return yf_train_adam_multi_pinned(device, ntensors, d_p, d_g, d_m, d_v, sizes, lr, beta1, beta2, eps, step, d_table, table_bytes, nullptr, 1, stream);
+}
+
+int yf_train_adam_multi_pinned(int device, int ntensors, void* const* d_p, const void* const* d_g, void* const* d_m, void* const* d_v,
+                               const long* sizes, double lr, double beta1, double beta2, double eps, int step, void* d_table, size_t table_bytes,
+                               void* h_table_pinned, int upload, void* stream)
+{
     if (!d_p || !d_g || !d_m || !d_v || !sizes || !d_table || ntensors <= 0 || step < 1 || table_bytes < (size_t)ntensors * 48)
         return fail(YF_E_INVALID, "yf_train_adam_multi: bad argument");
     for (int t = 0; t < ntensors; ++t)
         if (!d_p[t] || !d_g[t] || !d_m[t] || !d_v[t] || sizes[t] <= 0) return fail(YF_E_INVALID, "yf_train_adam_multi: tensor %d: null pointer or empty", t);
     HIP_OK(hipSetDevice(device));
-    yf::launch_tadam_multi(ntensors, (float* const*)d_p, (const float* const*)d_g, (float* const*)d_m, (float* const*)d_v, sizes, lr, beta1, beta2, eps,
-                           step, d_table, (hipStream_t)stream);
+    if (yf::launch_tadam_multi(ntensors, (float* const*)d_p, (const float* const*)d_g, (float* const*)d_m, (float* const*)d_v, sizes, lr, beta1, beta2,
+                               eps, step, d_table, h_table_pinned, upload, (hipStream_t)stream))
+        return fail(YF_E_HIP, "yf_train_adam_multi: the upload of the pointer table failed");
     HIP_OK(hipGetLastError());
     return YF_OK;
 }

@@ -1237,21 +1237,28 @@ void launch_tadam(float* p, const float* g, float* m, float* v, long total, doub
                        (float)(lr / bc1), (float)sqrt(bc2));
 }
 
-// host arrays of device pointers -> one table upload + one launch.  d_table: at least nt * 48 bytes of device memory.
-void launch_tadam_multi(int nt, float* const* p, const float* const* g, float* const* m, float* const* v, const long* sizes, double lr, double b1,
-                        double b2, double eps, int step, void* d_table, hipStream_t s)
+// host arrays of device pointers -> (one table upload +) one launch.  d_table: at least nt * 48 bytes of device memory.
+// h_table: nt * 48 bytes of PINNED host memory owned by the caller (one per optimizer), or null.  With it the table is written there and
+// uploaded with a truly asynchronous copy, and only when `upload` is set -- the caller sets it when the pointer set changed (p, m, v are
+// stable; g is too when the flat gradient buffer is reused) and must not call again with upload = 1 before the previous upload has
+// executed (training.Adam waits on an event).  Without it (null) the table is staged from pageable memory on every call, which the
+// runtime completes before returning -- correct, but it can hold the host until the stream has drained.
+int launch_tadam_multi(int nt, float* const* p, const float* const* g, float* const* m, float* const* v, const long* sizes, double lr, double b1,
+                       double b2, double eps, int step, void* d_table, void* h_table, int upload, hipStream_t s)
 {
     static thread_local std::vector<TAdamEntry> tab;
-    tab.resize(nt);
+    TAdamEntry* host = static_cast<TAdamEntry*>(h_table);
+    if (!host) { tab.resize(nt); host = tab.data(); upload = 1; }
     long blocks = 0;
     for (int t = 0; t < nt; ++t) {
-        tab[t] = TAdamEntry{p[t], g[t], m[t], v[t], blocks, sizes[t]};
+        if (upload) host[t] = TAdamEntry{p[t], g[t], m[t], v[t], blocks, sizes[t]};
         blocks += (sizes[t] + 255) / 256;
     }
-    (void)hipMemcpyAsync(d_table, tab.data(), (size_t)nt * sizeof(TAdamEntry), hipMemcpyHostToDevice, s);   // pageable source: staged before return
+    if (upload && hipMemcpyAsync(d_table, host, (size_t)nt * sizeof(TAdamEntry), hipMemcpyHostToDevice, s) != hipSuccess) return -1;
     const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
     hipLaunchKernelGGL(tadam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const TAdamEntry*)d_table, nt, (float)(1.0 - b1), (float)b2,
                        (float)(1.0 - b2), (float)eps, (float)(lr / bc1), (float)sqrt(bc2));
+    return 0;
 }
 
 }  // namespace yf

@@ -20,6 +20,10 @@ import torch.nn as nn
 from . import _lib, packer
 
 
+DEFAULT_FUSION = 2   # yf_set_fusion: 0 = one launch per layer (bring-up, every probe); 1 = block-fused kernels (round 2's plan);
+                     # 2 = + the per-frame deep stage's launch boundaries removed (conv5_2 in the res5 launch, ...)
+
+
 def _container(kind, cin, cout, k, stride, relu):
     if kind == packer.KIND_HEAD:
         return nn.Conv2d(cin, cout, kernel_size=1, stride=1)
@@ -109,7 +113,7 @@ class YoloFastest(nn.Module):
         self._engines = {}
         self._blob = None
         self.chunk = 0  # frames per pass of the layer chain (0 = whole batch); see yf_set_chunk
-        self.fusion = 1  # 1 = block-fused kernels (default); 0 = one launch per layer (bring-up, all probes)
+        self.fusion = DEFAULT_FUSION
         self.lanes = 2   # concurrent streams over chunks of the batch (chunk 0 = one chunk per lane); see yf_set_lanes
         self.branches = 1  # 1: the small head's launches run on a side stream beside the large head's; see yf_set_branches
         # activation storage / pointwise-GEMM operand type: torch.float32, or torch.float16 (BASELINE configs[2]: fp16 in HBM,
@@ -182,6 +186,9 @@ class YoloFastest(nn.Module):
         """The engine (yf_handle + workspace + its side streams) for this input size on this device.  `slot` > 0: a further engine
         of the same kind, so that several batches can be in flight on different streams (pipeline.BatchPipeline): one engine serves
         one stream at a time."""
+        if getattr(self, "_weights_dirty", False):        # a training forward has run since the last pack: fold the CURRENT parameters
+            self._invalidate()
+            self._weights_dirty = False
         key = (H, W, device.index if device.index is not None else torch.cuda.current_device(), self._dtype_code(), slot)
         e = self._engines.get(key)
         if e is None or e.max_batch < N:
@@ -218,9 +225,6 @@ class YoloFastest(nn.Module):
             from . import training
             self._weights_dirty = True           # the optimizer will move the parameters: re-pack at the next eval forward
             return training.forward(self, x)
-        if getattr(self, "_weights_dirty", False):
-            self._invalidate()
-            self._weights_dirty = False
         if not x.is_cuda:
             raise RuntimeError("YoloFastest (HIP engine) has no CPU path: move the model and input to the GPU")
         if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] % 32 or x.shape[3] % 32:

@@ -328,6 +328,13 @@ def forward(model, x):
         if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
             raise RuntimeError("training runs on contiguous float32 GPU parameters")
     x = x.contiguous().float()
+    for name, b in model.named_modules():
+        # the BatchNorm kernels (and the backward's bit-exact recomputation of the ReLU mask) are built for nn.BatchNorm2d's defaults,
+        # which is what the reference uses (yolo_fastest.py:12-13): anything else would train silently wrong
+        if isinstance(b, torch.nn.BatchNorm2d) and (b.eps != 1e-5 or b.momentum != 0.1 or not b.affine or not b.track_running_stats):
+            raise NotImplementedError("%s: the training kernels implement BatchNorm2d(eps=1e-5, momentum=0.1, affine=True, "
+                                      "track_running_stats=True) only (got eps=%r, momentum=%r, affine=%r, track_running_stats=%r)"
+                                      % (name, b.eps, b.momentum, b.affine, b.track_running_stats))
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         return _TrainForwardFn.apply(x, model, *params)
     if getattr(model, "train_impl", "trainer") == "ops":
@@ -340,8 +347,12 @@ def forward(model, x):
 def data_parallel(model, process_group=None, broadcast=True):
     """One process per GPU (torch.distributed, backend "nccl" = RCCL): every rank trains on its shard of the batch; after this call
     `loss.backward()` averages the gradients over the ranks with ONE all-reduce of the flat gradient buffer before they reach
-    `param.grad` (the semantics of torch's DistributedDataParallel: BatchNorm statistics stay per rank), and the parameters and
-    buffers are broadcast from rank 0 once.  The reference has no distributed training; with one rank this changes nothing."""
+    `param.grad`, and the parameters and buffers are broadcast from rank 0 once.  BatchNorm uses each rank's own batch statistics
+    (like torch's DistributedDataParallel without SyncBatchNorm), and -- UNLIKE DistributedDataParallel, which re-broadcasts rank 0's
+    buffers before every forward -- the running_mean / running_var buffers then drift apart between the ranks: call
+    `sync_buffers(model)` before validating or saving so that every rank holds rank 0's.  `train()` below does that, shards the
+    data with a DistributedSampler and writes checkpoints on rank 0 only when torch.distributed is initialised.
+    The reference has no distributed training; with one rank this changes nothing."""
     import torch.distributed as tdist
     if not tdist.is_initialized():
         raise RuntimeError("initialise torch.distributed first (one process per GPU)")
@@ -350,6 +361,17 @@ def data_parallel(model, process_group=None, broadcast=True):
         yfd.broadcast_model_(model, 0, process_group)
     model._grad_sync = (process_group,)
     model.train_impl = "trainer"
+    return model
+
+
+def sync_buffers(model, process_group=None):
+    """Every rank takes rank 0's BatchNorm running statistics (what DistributedDataParallel's per-forward buffer broadcast amounts to
+    at the points where the buffers are used: validation and checkpoints)."""
+    import torch.distributed as tdist
+    if tdist.is_initialized() and tdist.get_world_size(process_group) > 1:
+        with torch.no_grad():
+            for b in model.buffers():
+                tdist.broadcast(b, src=0, group=process_group)
     return model
 
 
@@ -377,19 +399,35 @@ class Adam(torch.optim.Optimizer):
                 st = self.state[p]
                 if not st:
                     st["step"], st["exp_avg"], st["exp_avg_sq"] = 0, torch.zeros_like(p), torch.zeros_like(p)
-                st["step"] += 1
+                st["step"] = int(st["step"]) + 1         # (a loaded torch.optim.Adam state carries `step` as a tensor)
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 todo.setdefault((p.device, st["step"]), []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
             for (device, step), items in todo.items():
                 n = len(items)
-                arr = lambda k: (ctypes.c_void_p * n)(*[it[k].data_ptr() for it in items])
+                ptrs = tuple(tuple(it[k].data_ptr() for it in items) for k in range(4))
+                # The pointer table lives on the device, with a pinned host copy, per (device, tensor count); it is re-uploaded only when
+                # a pointer changed (p, exp_avg, exp_avg_sq never do; the gradients are views of the trainer's flat buffer, which the
+                # caching allocator hands back every iteration) -- so a step is normally ONE asynchronous launch and the host runs ahead.
+                cache = self.__dict__.setdefault("_tables", {})
+                ent = cache.get((device, n))
+                if ent is None:
+                    ent = cache[(device, n)] = dict(dev=torch.empty(48 * n, dtype=torch.uint8, device=device),
+                                                    host=torch.empty(48 * n, dtype=torch.uint8).pin_memory(), key=None, event=None)
+                upload = ent["key"] != ptrs
+                if upload and ent["event"] is not None:
+                    ent["event"].synchronize()           # the previous upload has left the pinned buffer
+                arr = lambda k: (ctypes.c_void_p * n)(*ptrs[k])
                 sizes = (ctypes.c_long * n)(*[it[0].numel() for it in items])
-                table = torch.empty(48 * n, dtype=torch.uint8, device=device)
                 dev = device.index if device.index is not None else torch.cuda.current_device()
-                _lib.check(lib.yf_train_adam_multi(dev, n, arr(0), arr(1), arr(2), arr(3), sizes, float(group["lr"]), float(b1), float(b2),
-                                                   float(group["eps"]), int(step), table.data_ptr(), table.numel(),
-                                                   ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
-                self._keep = (items, table)          # alive until the next step: the launch is asynchronous
+                stream = torch.cuda.current_stream(device)
+                _lib.check(lib.yf_train_adam_multi_pinned(dev, n, arr(0), arr(1), arr(2), arr(3), sizes, float(group["lr"]), float(b1), float(b2),
+                                                          float(group["eps"]), int(step), ent["dev"].data_ptr(), ent["dev"].numel(),
+                                                          ent["host"].data_ptr(), int(upload), ctypes.c_void_p(stream.cuda_stream)))
+                if upload:
+                    ent["key"] = ptrs
+                    ent["event"] = torch.cuda.Event()
+                    ent["event"].record(stream)
+                self._keep = items                   # alive until the next step: the launch is asynchronous
 
 
 def train_step(model, model_loss, optimizer, imgs, targets):
@@ -448,8 +486,16 @@ def train(params, device, tbwriter=None, train_dataset=None, val_dataset=None, l
     else:
         logger.info("initialize model")
         model.initialize_weights()
-    dataloader = DataLoader(train_dataset, batch_size=batch_size, num_workers=0, drop_last=True, pin_memory=True, shuffle=True,
-                            collate_fn=validation.collate_fn)
+    import torch.distributed as tdist
+    world = tdist.get_world_size() if tdist.is_initialized() else 1
+    rank = tdist.get_rank() if tdist.is_initialized() else 0
+    sampler = None
+    if world > 1:            # one process per GPU: every rank its own shard of each epoch, gradients averaged by data_parallel()
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = DistributedSampler(train_dataset, num_replicas=world, rank=rank, shuffle=True, drop_last=True)
+        data_parallel(model)
+    dataloader = DataLoader(train_dataset, batch_size=batch_size, num_workers=0, drop_last=True, pin_memory=True, shuffle=sampler is None,
+                            sampler=sampler, collate_fn=validation.collate_fn)
     val = validation.Validation(params=params, logger=logger, dataset=val_dataset, device=device, model_loss=model_loss) \
         if val_dataset is not None else None
     batch_per_epoch = len(dataloader)
@@ -467,6 +513,8 @@ def train(params, device, tbwriter=None, train_dataset=None, val_dataset=None, l
     losses_name = ["total_loss", "x", "y", "w", "h", "conf", "cls"]
     for epoch in range(start_epoch, total_epochs):
         model.train()
+        if sampler is not None:
+            sampler.set_epoch(epoch)
         for batch_id, (imgs, targets) in enumerate(dataloader):
             start_time = time.time()
             imgs = imgs.to(device).float()
@@ -493,7 +541,10 @@ def train(params, device, tbwriter=None, train_dataset=None, val_dataset=None, l
                     for i, name in enumerate(losses_name):
                         tbwriter.add_scalar(name, _loss if i == 0 else losses[i], step_count)
         scheduler.step()
+        if world > 1:
+            sync_buffers(model)                      # validation and the checkpoint see rank 0's running statistics on every rank
         if epoch > 4 and val is not None:
             val.get_mAP(epoch=epoch, model=model)
-        torch.save(model.state_dict(), os.path.join(save_path, "YOLO-Fastest_epoch_{}.pth".format(str(epoch))))
+        if rank == 0:
+            torch.save(model.state_dict(), os.path.join(save_path, "YOLO-Fastest_epoch_{}.pth".format(str(epoch))))
     return model

@@ -35,7 +35,9 @@ def _engine(t, H, W, model=None):
 class YOLOLossV3(torch.nn.Module):
     def __init__(self, anchors, num_classes, input_shape, device, model=None):
         super().__init__()
-        self.model = model          # the YoloFastest whose heads this decodes (None: validation.bind's default)
+        # the YoloFastest whose heads this decodes (None: validation.bind's default).  NOT registered as a submodule: the loss object's
+        # .train() / .eval() / .to() / state_dict() must not reach into the network (the reference's YOLOLossV3 does not hold the model)
+        object.__setattr__(self, "model", model)
         self.anchors = anchors
         self.num_anchors = len(anchors)
         self.num_classes = num_classes
@@ -70,17 +72,18 @@ class _TrainLossFn(torch.autograd.Function):
     def forward(ctx, x, targets, loss_mod):
         bs, _, fh, fw = x.shape
         H, W = int(loss_mod.input_shape[0]), int(loss_mod.input_shape[1])
-        e = _engine(x, H, W, loss_mod.model)
+        lib = _lib.lib()                                     # no inference engine needed: the loss takes (device, H, W)
+        dev_index = x.device.index if x.device.index is not None else torch.cuda.current_device()
         need = ctypes.c_size_t()
-        _lib.check(e.lib.yf_train_loss_workspace_bytes(e.handle, bs, fh, fw, ctypes.byref(need)))
+        _lib.check(lib.yf_train_head_loss_workspace_bytes(bs, fh, fw, ctypes.byref(need)))
         work = torch.empty((need.value + 7) // 8, dtype=torch.float64, device=x.device)     # 8-byte aligned scratch
         losses = torch.empty(8, dtype=torch.float32, device=x.device)
         grad = torch.empty_like(x)
         anc = (ctypes.c_double * 6)(*[float(v) for a in loss_mod.anchors for v in a])
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        _lib.check(e.lib.yf_train_loss(e.handle, x.data_ptr(), bs, fh, fw, anc, targets.data_ptr(), targets.shape[1],
-                                       float(loss_mod.ignore_threshold), work.data_ptr(), work.numel() * 8, losses.data_ptr(),
-                                       grad.data_ptr(), ctypes.c_void_p(stream)))
+        _lib.check(lib.yf_train_head_loss(dev_index, H, W, x.data_ptr(), bs, fh, fw, anc, targets.data_ptr(), targets.shape[1],
+                                          float(loss_mod.ignore_threshold), work.data_ptr(), work.numel() * 8, losses.data_ptr(),
+                                          grad.data_ptr(), ctypes.c_void_p(stream)))
         ctx.save_for_backward(grad)
         ctx.mark_non_differentiable(losses)
         return losses[0].clone(), losses
@@ -224,7 +227,7 @@ class Validation:
         self.clear()
         model.eval()
         for loss in self.model_loss:
-            loss.model = model
+            object.__setattr__(loss, "model", model)      # (not a registered submodule, see YOLOLossV3.__init__)
         with torch.no_grad():
             for imgs, targets in self.dataloader:
                 targets = self._recover_targets(targets.float())                      # host: the bookkeeping stays on the CPU
