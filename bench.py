@@ -9,11 +9,12 @@ as a child BEFORE it touches the GPU, relays rank 0's JSON line and exits with t
 GPUs -> non-zero exit and a message.  Launched by torch.distributed.run from outside (the driver), WORLD_SIZE must equal --gpus.
 
 A "step" = one pass of the hot path (model forward -> decode -> per-class NMS [-> all-gather of the decoded
-boxes when N > 1]) over one batch of synthetic frames that is already resident in HBM.  By default TWO batches are in flight
+boxes when N > 1]) over one batch of synthetic frames that is already resident in HBM.  Runs of >= 50 steps keep TWO batches in flight
 (--in-flight 2, yolo_fastest_amd.BatchPipeline): consecutive steps are issued round-robin on two HIP streams, each with its own
-engine, so a batch's late per-frame stages run beside the next batch's early machine-filling ones; all K steps (and exchanges)
-complete inside the timed region, `ms_per_step` is elapsed / K.  The one-step-at-a-time figure is reported beside it
-(`one_batch_in_flight`), as are the per-pass model / post-process times (`forward_chain.forward_ms`, `post_ms`).
+engine, so a batch's late per-frame stages run beside the next batch's early machine-filling ones; shorter runs (the driver's 20 steps)
+issue one step at a time on two half-batch lanes, because the pipeline's fill and drain cost a short run more than the overlap brings.
+All K steps (and exchanges) complete inside the timed region, `ms_per_step` is elapsed / K.  The other mode's figure is reported beside
+it (`two_batches_in_flight` / `one_batch_in_flight`), as are the per-pass model / post-process times (`forward_chain.forward_ms`, `post_ms`).
 Workload at N = 1: BASELINE.json configs[1], "YOLO-Fastest 320x256 batch=256 fp32, synthetic frames"
 (u8 ~ Uniform{0..255} i.i.d., x = (u8-128)/255, seed = rank).  N > 1: the same per GPU (weak
 scaling, frames are independent units; one RCCL all-gather of the fixed-capacity box records).
@@ -102,6 +103,151 @@ def cpu_baseline(seconds=12.0):
                       + f"; host has {os.cpu_count()} logical CPUs"}
 
 
+def live_traffic(args):
+    """HBM bytes per launch, measured IN THIS RUN: two child runs of this script's single-lane pass under `rocprofv3 --pmc` (FETCH_SIZE and
+    WRITE_SIZE in separate passes, counters with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes), started before this
+    process touches the GPU.  Units and corrections of that guide: both counters are KiB of 64-byte fabric requests; on gfx950 FETCH_SIZE
+    reports half of the bytes of wide (16 B / lane) coalesced streaming reads, so it is doubled; WRITE_SIZE is exact for 16-byte-per-lane
+    streaming stores.  Launches are matched to the plan's ops by order (one lane, one batch in flight: deterministic).
+    Returns ({op name: bytes per launch}, note): ({}, why) when the profiler is not usable here."""
+    import csv
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return {}, "rocprofv3 not found"
+    work = tempfile.mkdtemp(prefix="yf_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, counter)
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-variants", "--no-configs",
+                   "--no-live-traffic", "--no-train", "--in-flight", "1", "--lanes", "1", "--res", str(args.res), "--batch", str(args.batch), "--dtype", args.dtype,
+                   "--frames", args.frames, "--kmax", str(args.kmax), "--dump-ops", os.path.join(work, "ops.json")]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            path = os.path.join(d, "p_counter_collection.csv")
+            if r.returncode != 0 or not os.path.exists(path):
+                return {}, "rocprofv3 --pmc %s child failed (rc %d): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-300:].replace("\n", " | "))
+            with open(os.path.join(work, "ops.json")) as f:
+                ops = json.load(f)
+            with open(path) as f:
+                rows = [x for x in csv.DictReader(f) if x["Counter_Name"] == counter and "yf::" in x["Kernel_Name"]
+                        and "post_kernel" not in x["Kernel_Name"] and "nms_sorted" not in x["Kernel_Name"]]
+            rows.sort(key=lambda x: int(x["Dispatch_Id"]))
+            n = len(ops)
+            if n == 0 or len(rows) < n or len(rows) % n:
+                return {}, "PMC rows (%d) do not divide into forward passes of %d launches" % (len(rows), n)
+            passes = len(rows) // n
+            vals[counter] = [sum(float(rows[q * n + i]["Counter_Value"]) for q in range(passes)) / passes for i in range(n)]
+        out = {}
+        for i, o in enumerate(ops):
+            out[o["name"]] = out.get(o["name"], 0.0) + vals["FETCH_SIZE"][i] * 1024 * 2 + vals["WRITE_SIZE"][i] * 1024
+        return {k: int(round(v)) for k, v in out.items()}, None
+    except Exception as e:   # the profiler is evidence, not product: never fail the benchmark over it
+        return {}, "live PMC pass failed: %r" % (e,)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+TRAIN_FLOPS_PER_EXAMPLE = {256: 2 * (3 * 118_221_440 - 1_474_560)}   # forward + backward-data (conv0 needs none) + weight-gradient MACs x 2
+
+
+def live_train_traffic(batch, iters=3):
+    """HBM bytes of ONE training iteration at this batch size, by the counters, in this run: tools/train_bench.py under `rocprofv3 --pmc`
+    (FETCH_SIZE and WRITE_SIZE passes, the units and the gfx950 doubling of FETCH_SIZE as in live_traffic) summed over every kernel of
+    the process -- ours and torch's -- and divided by the iterations.  Also returns the kernel that holds the largest share of the
+    kernel time of that (counter-slowed) run.  -> (bytes per iteration or None, dominant kernel or None, its share, note)"""
+    import csv
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, None, None, "rocprofv3 not found"
+    work = tempfile.mkdtemp(prefix="yf_pmct_", dir="/tmp")
+    total, times = 0.0, {}
+    try:
+        for counter, scale in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
+            d = os.path.join(work, counter)
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
+                   os.path.join(ROOT, "tools", "train_bench.py"), "--batch", str(batch), "--steps", str(iters), "--warmup", "0"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=900)
+            path = os.path.join(d, "p_counter_collection.csv")
+            if r.returncode != 0 or not os.path.exists(path):
+                return None, None, None, "rocprofv3 --pmc %s child failed (rc %d): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-300:].replace("\n", " | "))
+            with open(path) as f:
+                for x in csv.DictReader(f):
+                    if x["Counter_Name"] != counter:
+                        continue
+                    total += float(x["Counter_Value"]) * scale
+                    if counter == "FETCH_SIZE":
+                        k = x["Kernel_Name"].split("(")[0]
+                        times[k] = times.get(k, 0.0) + (int(x["End_Timestamp"]) - int(x["Start_Timestamp"]))
+        dom = max(times, key=times.get) if times else None
+        return total / iters, dom, (times[dom] / sum(times.values()) if dom else None), None
+    except Exception as e:
+        return None, None, None, "live PMC pass failed: %r" % (e,)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def train_records(dev, pmc):
+    """The training iteration (train.py:111-132: zero_grad, train-mode forward, two-head loss, backward, Adam) on synthetic frames at the
+    reference's batch size (16, _config.py:41) and at 256: examples/s, and the physical roofs of the iteration -- flops over the fp32
+    issue peak, counter-measured HBM bytes over 8 TB/s."""
+    import numpy as np
+    import torch
+    import yolo_fastest_amd as yf
+    from yolo_fastest_amd import training, validation as val
+    io = yf.io_params_for(256)
+    H, W = io["input_shape"][:2]
+    out = []
+    for batch, steps in ((16, 30), (256, 6)):
+        torch.manual_seed(0)
+        m = yf.YoloFastest(io)
+        m.initialize_weights()
+        m = m.to(dev).train()
+        x = (torch.rand(batch, 1, H, W) - 0.5).to(dev)
+        rng = np.random.default_rng(0)
+        t = np.zeros((batch, 64, 6), np.float32)
+        for b in range(batch):
+            k = 1 + b % 6
+            t[b, :k, 0:2] = rng.uniform(0.05, 0.95, (k, 2)); t[b, :k, 2:4] = rng.uniform(0.03, 0.4, (k, 2))
+            t[b, :k, 4] = rng.integers(0, 3, k); t[b, :k, 5] = 255.0
+        td = torch.from_numpy(t).to(dev)
+        crit = [val.YOLOLossV3(io["anchors"][i], 3, io["input_shape"], dev, model=m) for i in range(2)]
+        opt = training.Adam(m.parameters(), lr=0.001)
+        for _ in range(3):
+            training.train_step(m, crit, opt, x, td)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = training.train_step(m, crit, opt, x, td)[0]
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        flops = TRAIN_FLOPS_PER_EXAMPLE[256] * batch
+        rec = {"workload": "train.py:111-132 iteration (zero_grad, train-mode forward, two-head loss, backward, Adam), 320x256, synthetic frames and targets",
+               "batch": batch, "steps": steps, "warmup": 3, "dtype": "f32", "value": round(batch / dt, 1), "unit": "examples/s",
+               "ms_per_iteration": round(1e3 * dt, 3), "loss_finite": bool(torch.isfinite(loss.detach()).item()),
+               "roofline": {"flops_per_iteration": flops, "compute": {"achieved": round(flops / dt / 1e12, 2), "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
+                                                                     "frac": round(flops / dt / 1e12 / FP32_PEAK_TF, 4)},
+                            "hbm": None, "bound": None, "dominant_kernel": None}}
+        tb, dom, share, note = pmc.get(batch, (None, None, None, "not measured at this batch size (launch-bound: ~650 launches per iteration)"))
+        if tb is not None:
+            gbs = tb / dt / 1e9
+            rec["roofline"]["hbm"] = {"traffic": int(tb), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                      "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/train_bench.py, all kernels"}
+            rec["roofline"]["bound"] = "hbm" if gbs / HBM_PEAK_GBS > rec["roofline"]["compute"]["frac"] else "fp32 issue"
+            rec["roofline"]["dominant_kernel"] = {"name": dom[:100], "share_of_kernel_time_in_the_counter_pass": round(share, 3)}
+        elif note:
+            rec["roofline"]["note"] = note
+        out.append(rec)
+        del m, opt, crit, x, td
+        torch.cuda.empty_cache()
+    return out
+
+
 def self_launch(n_gpus):
     """--gpus N > 1 without a launcher: start the N ranks as a CHILD process tree (never exec: this process must not have
     touched the GPU, and it has not -- device_count() does not initialise it) and relay its output."""
@@ -157,8 +303,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="frames per pass of the layer chain (0 = whole batch)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="batches in flight: consecutive steps are issued round-robin on this many streams, each with its own engine "
-                         "(yolo_fastest_amd.BatchPipeline); 1 = one step at a time; 0 (default) = 2 at 320x256, 1 at 640x512 (whose "
-                         "launches fill the machine by themselves: measured 83.7 k vs 84.9 k frames/s f16x3)")
+                         "(yolo_fastest_amd.BatchPipeline); 1 = one step at a time; 0 (default) = 2 at 320x256 for runs of >= 50 steps, else "
+                         "1 (a short run pays the pipeline's fill and drain; 640x512 launches fill the machine by themselves: measured "
+                         "83.7 k vs 84.9 k frames/s f16x3)")
     ap.add_argument("--lanes", type=int, default=0, help="concurrent streams over the chunks of ONE batch (1..4); 0 = 1 with several "
                                                         "batches in flight, else 2")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f16x3"],
@@ -171,12 +318,16 @@ def main():
                     help="SURVEY.md 8(d) config 5: synthetic dense head logits (~1200 candidates, ~260 survivors per 640x512 frame) are "
                          "added to the heads of the noise frames, to stress decode + sort + NMS; use with --res 512 --batch 64 --kmax 1024")
     ap.add_argument("--branches", type=int, default=-1, choices=[-1, 0, 1],
-                    help="1: the small head's launches on a side stream of their lane; -1 = 0 with several batches in flight, else 1")
+                    help="1: the small head's launches on a side stream of their lane; -1 (default) = 0")
     ap.add_argument("--kmax", type=int, default=64)
     ap.add_argument("--exchange-at-1", action="store_true",
                     help="rehearsal of the N > 1 code path on one GPU: a 1-rank RCCL group and the all-gather of every step's records")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra f16x3 measurement of the same workload")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure the HBM bytes per launch in this run (two rocprofv3 --pmc child passes before the benchmark); "
+                         "roofline.traffic then comes from profiles/pmc_traffic.json if it was taken at this build, else null")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-iteration records (the `training` array)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other single-GPU BASELINE.json configurations (the `configs` array)")
     ap.add_argument("--dump-ops", default=None, help="write the launch names of one forward pass to this JSON file")
     ap.add_argument("--dump-records", default=None,
@@ -192,6 +343,15 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; "
                          f"use --nproc-per-node == --gpus (or run plain `python bench.py --gpus N`, which launches the ranks itself)")
+
+    # HBM traffic of every launch, by the counters, in THIS run (children; this process has not touched the GPU yet)
+    live, live_note = ({}, "not requested")
+    if world == 1 and not args.no_live_traffic and not args.dense and not args.exchange_at_1:
+        live, live_note = live_traffic(args)
+
+    train_pmc = {}
+    if world == 1 and not args.no_train and not args.no_live_traffic and args.res == 256 and args.dtype == "f32" and not args.dense:
+        train_pmc[256] = live_train_traffic(256)
 
     import numpy as np
     import torch
@@ -248,11 +408,15 @@ def main():
     wname = WNAME[args.res]
     H, W = io["input_shape"][:2]
     n_total = args.batch * world
-    in_flight = args.in_flight if args.in_flight > 0 else (2 if args.res == 256 else 1)
+    # batches in flight, automatic: two pay in steady state (100 steps: 291 k vs 280 k frames/s at 320x256) but their fill and drain cost a
+    # short run more than the overlap brings (20 steps: 271 k vs 280 k), and at 640x512 the launches fill the machine by themselves
+    in_flight = args.in_flight if args.in_flight > 0 else (2 if args.res == 256 and args.steps >= 50 else 1)
     if syn is not None:
         in_flight = 1    # the dense field is spliced in between model and post-process: one at a time
     lanes = args.lanes if args.lanes else (1 if in_flight > 1 else 2)
-    branches = args.branches if args.branches >= 0 else (0 if in_flight > 1 else 1)
+    # the small head in line: since it is ONE launch (fusion level 2) the side stream no longer pays at this batch size
+    # (tools/fusion_ab.py, one batch at a time on two lanes: 280 k frames/s in line, 273 k on the side stream)
+    branches = args.branches if args.branches >= 0 else 0
     cur = {"x": x, "syn": syn, "kmax": args.kmax, "n_total": n_total}   # the workload timed() / forward() run on
 
     def make(dtype, lanes_, branches_, io_=None, res_=None):
@@ -333,7 +497,7 @@ def main():
 
     # model / post-process split and the one-batch-at-a-time figure (two half-batch lanes, the small head on its side stream): measured
     # after the headline's timed region, same process
-    m1, p1 = (model, post) if in_flight == 1 else make(args.dtype, 2, 1)
+    m1, p1 = (model, post) if in_flight == 1 else make(args.dtype, 2, 0)
     es = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     fwd_ms = post_ms = 0.0
     for _ in range(10):
@@ -343,11 +507,17 @@ def main():
         es[0].record(); pred = forward(m1); es[1].record(); raw1 = p1.detect_raw(pred, kmax=args.kmax); es[2].record()
         torch.cuda.synchronize(dev)
         fwd_ms += es[0].elapsed_time(es[1]) / 10; post_ms += es[1].elapsed_time(es[2]) / 10
-    single = None
+    single = other = None    # the other scheduling mode of the same workload, same loop, same run
     if in_flight > 1 and world == 1:
         e1, r1 = timed(m1, p1, 1, args.steps, args.warmup, False)
-        single = {"in_flight": 1, "lanes": 2, "branches": 1, "value": round(args.batch * args.steps / e1, 1), "unit": "frames/s",
+        single = {"in_flight": 1, "lanes": 2, "branches": 0, "value": round(args.batch * args.steps / e1, 1), "unit": "frames/s",
                   "ms_per_step": round(1e3 * e1 / args.steps, 4), "detections_identical": bool(same_detections(raw, r1))}
+    elif world == 1 and args.res == 256 and syn is None and args.in_flight == 0:
+        m2f, p2f = make(args.dtype, 1, 0)
+        e1, r1 = timed(m2f, p2f, 2, args.steps, args.warmup, False)
+        other = {"in_flight": 2, "lanes": 1, "branches": 0, "value": round(args.batch * args.steps / e1, 1), "unit": "frames/s",
+                 "ms_per_step": round(1e3 * e1 / args.steps, 4), "detections_identical": bool(same_detections(raw, r1))}
+        del m2f, p2f
 
     # The same workload on the split-operand fp16-MFMA variant (fp32 storage, fp32-class accuracy), measured in the SAME
     # run with the same loop: an extra object of the JSON line, never the headline `value` (which is the dtype named by --dtype).
@@ -446,10 +616,13 @@ def main():
                             "valu_flops": o["valu_flops"]} for o in ops], f)
         chain_ms = sum(o["ms"] for o in ops)
         # measured HBM bytes per launch (PMC passes of tools/refresh_profiles.sh), valid for this build and this workload only
-        traffic, traffic_note = {}, None
+        traffic, traffic_note, traffic_source = {}, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         wl = {"res": args.res, "batch": args.batch, "dtype": args.dtype}
-        if os.path.exists(tpath):
+        if live:
+            traffic = live
+            traffic_source = "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes (bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024)"
+        elif os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
             if tj.get("source_hash") != source_hash():
@@ -458,8 +631,11 @@ def main():
                 traffic_note = f"profiles/pmc_traffic.json is for {tj.get('workload')}, this run is {wl}"
             else:
                 traffic = {k: v.get("hbm_bytes_per_launch") for k, v in tj.get("kernels", {}).items()}
+                traffic_source = "profiles/pmc_traffic.json (same source hash and workload)"
+            if live_note and live_note != "not requested":
+                traffic_note = (traffic_note + "; " if traffic_note else "") + "live PMC: " + live_note
         else:
-            traffic_note = "profiles/pmc_traffic.json not found"
+            traffic_note = "profiles/pmc_traffic.json not found" + ("; live PMC: " + live_note if live_note else "")
         for o in ops:
             o["roof"] = launch_roofline(o, args.dtype, traffic.get(o["name"]))
         dom = max(ops, key=lambda o: o["ms"])
@@ -488,6 +664,8 @@ def main():
             roofline.update(achieved=roofline["compute"]["achieved"], peak=dr["peak_tf"], unit="TFLOP/s", frac=roofline["compute"]["frac"])
         if traffic_note:
             roofline["traffic_note"] = traffic_note
+        if traffic_source:
+            roofline["traffic_source"] = traffic_source
         out = {
             "metric": "frames/sec end-to-end (model forward + decode + per-class NMS), 320x256 batch=256 per GPU"
                       if args.res == 256 else "frames/sec end-to-end, 640x512",
@@ -523,10 +701,16 @@ def main():
         }
         if single is not None:
             out["one_batch_in_flight"] = single
+        if other is not None:
+            out["two_batches_in_flight"] = other
         if variant is not None:
             out["variants"] = [variant]
         if extra_configs is not None:
             out["configs"] = extra_configs
+        if world == 1 and not args.no_train and args.res == 256 and args.dtype == "f32" and not args.dense and args.frames == "noise":
+            del model, post
+            torch.cuda.empty_cache()
+            out["training"] = train_records(dev, train_pmc)        # never `value`
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

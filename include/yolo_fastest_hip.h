@@ -258,8 +258,10 @@ int yf_set_lanes(yf_handle h, int lanes);          /* 1..4: chunks of the batch 
                                                      streams, forked from / joined to the caller's stream by events    */
 int yf_set_branches(yf_handle h, int on);         /* 1 (default): the small head's launches (conv5_3 .. head_5) run on a side stream of
                                                      their lane, beside the large head's (deconv5_1 .. head_4); 0 = in line */
-int yf_set_fusion(yf_handle h, int level);        /* 1 (default) = block-fused kernels; 0 = one launch per layer, every
-                                                     named tensor probe-able (bring-up / layer-wise parity tests)    */
+int yf_set_fusion(yf_handle h, int level);        /* 2 (default) = block-fused kernels + the per-frame deep stage's launch boundaries
+                                                     removed (conv5_2 in the res5 launch, the small head one launch, deconv5_1 +
+                                                     conv4_1_1 one launch); 1 = block-fused kernels (bitwise the same heads);
+                                                     0 = one launch per layer, every named tensor probe-able (bring-up / parity) */
 
 #ifdef __cplusplus
 }

@@ -1112,7 +1112,8 @@ def test_bench_line_and_multi_gpu_rehearsal(dev):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--batch", "64"]
-    for extra in ([], ["--exchange-at-1", "--no-variants"], ["--exchange-at-1", "--no-variants", "--in-flight", "1"]):
+    for extra in ([], ["--exchange-at-1", "--no-variants", "--no-configs", "--no-train"],
+                  ["--exchange-at-1", "--no-variants", "--no-configs", "--no-train", "--in-flight", "2"]):
         r = subprocess.run(base + extra, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         j = json.loads(r.stdout.strip().splitlines()[-1])
@@ -1123,7 +1124,14 @@ def test_bench_line_and_multi_gpu_rehearsal(dev):
         assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
         assert 0 < j["roofline"]["frac"] < 1
         if not extra:
-            assert j["config"]["in_flight"] == 2 and j["one_batch_in_flight"]["detections_identical"]
+            # the default line: HBM bytes of the dominant launch measured by the counters in THIS run, the other BASELINE configs
+            assert j["roofline"]["traffic"] and "measured in this run" in j["roofline"]["traffic_source"], j["roofline"]
+            assert [c["dtype"] for c in j["configs"]] == ["f16x3", "f16", "f16x3", "f32"]
+            assert j["configs"][0]["detections_identical_to_f32_on_this_batch"] and j["configs"][0]["max_abs_logit_diff_vs_f32_on_this_batch"] < 2e-2
+            assert j["configs"][2]["survivors_per_frame"] >= 200 and j["configs"][2]["detections_identical_on_re_evaluation"]
+            assert [t["batch"] for t in j["training"]] == [16, 256] and all(t["value"] > 100 and t["loss_finite"] for t in j["training"])
+            assert j["training"][1]["roofline"]["hbm"]["traffic"] > 1e9 and j["training"][1]["roofline"]["dominant_kernel"]["name"]
+            assert j["config"]["in_flight"] == 1 and j["two_batches_in_flight"]["detections_identical"]      # a short run: one step at a time
             assert j["variants"][0]["dtype"] == "f16x3" and j["variants"][0]["detections_identical_to_f32_on_this_batch"]
             assert j["variants"][0]["max_abs_logit_diff_vs_f32_on_this_batch"] < 1e-3
 
@@ -1140,7 +1148,7 @@ def test_two_gpu_bench_gathers_the_single_gpu_records(tmp_path):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    common = ["--steps", "3", "--warmup", "1", "--frames", "fixtures", "--no-cpu-baseline", "--no-variants", "--no-configs"]
+    common = ["--steps", "3", "--warmup", "1", "--frames", "fixtures", "--no-cpu-baseline", "--no-variants", "--no-configs", "--no-train"]
     two, one = str(tmp_path / "two.npz"), str(tmp_path / "one.npz")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "20", "--dump-records", two] + common,
                        env=env, capture_output=True, text=True, timeout=900)

@@ -357,6 +357,76 @@ def test_training_step_matches_the_reference(yf, golden, dev, capsys):
     assert np.abs(hl.cpu().numpy() - wl.numpy()).max() <= 2e-3 and np.abs(hs.cpu().numpy() - ws.numpy()).max() <= 2e-3
 
 
+CLEAN_TOL = 1e-4      # gradient elements that no flipped ReLU decision can reach: relative to the tensor's largest element (measured: ~1e-5)
+
+
+def test_gradient_error_is_confined_to_flipped_relu_decisions(yf, golden, dev, capsys):
+    """The first iteration's parameter gradients against the exact backward, ELEMENT-wise flip-aware.
+    The excess over rounding in test_training_step_matches_the_reference (worst tensor 3.45e-2) is attributed to ReLU decisions that
+    fall on the other side of zero than in exact arithmetic.  Here that is checked instead of narrated:
+      1. the ReLU masks of OUR train-mode forward (y > 0 of every conv+BN+ReLU unit, read from the per-block path's tape, which is
+         bit-identical to the trainer's) are compared with the masks of the oracle's float64 forward: the mismatches ARE the flips;
+      2. tests/flip_reach.py propagates them to the parameter-gradient elements they can reach (with train-mode BatchNorm: channel c of
+         the flipped layer's own parameters and every parameter upstream of it);
+      3. every element they can NOT reach must agree with the exact backward to CLEAN_TOL = 1e-4 of its tensor's largest element
+         (50x tighter than the 5e-3 the review asked for); elements they can reach keep the cap GRAD_CAP.
+    Flips also occur in the last ReLU layers of both heads, so most of the network is reachable and the clean set is the parameters
+    downstream of / beside the flips -- but there the agreement is at rounding level, which is what the claim predicts.  The test prints
+    the flips, the clean set's size and worst error, and which tensor carries the overall worst error."""
+    from oracle import backbone_oracle as bo
+    from yolo_fastest_amd import training
+    import flip_reach as fr
+    gt, m, x, targets, crit, opt = _setup_step(yf, golden, dev)
+    names = [n for n, _ in m.named_parameters()]
+    sizes = gt["param_sizes"]
+    zero = gt["grad_absmax_f64"] < 1e-9
+    # 1. our masks (a forward that leaves the BatchNorm buffers as they were) and the float64 masks
+    saved = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}
+    with torch.no_grad():
+        _, _, tape = training.train_forward(m, x)
+    m.load_state_dict(saved, strict=False)
+    m.train()
+    sd64 = bo.training_state(bo.load_state_dict(WEIGHTS), torch.float64)
+    pre = {}
+    bo.forward(sd64, x.detach().cpu().double(), train=True, pre=pre)
+    flips, n_flips, n_relu = {}, 0, 0
+    for name, d in pre.items():
+        ours = (tape[name][2] > 0).cpu()             # tape: (x, conv output, y = relu(BatchNorm(conv output)), ...): y > 0 <=> pre-activation > 0
+        diff = ours != (d["z"] > 0)
+        n_relu += diff.numel()
+        if diff.any():
+            flips[name] = torch.nonzero(diff.any(0).any(-1).any(-1)).ravel().tolist()
+            n_flips += int(diff.sum())
+    assert 0 < n_flips < 500, n_flips            # a few dozen of ~30 M decisions (measured: see the printed line)
+    # 2. what they reach
+    masks = fr.reach_masks(flips, names, [tuple(p.shape) for p in m.parameters()])
+    # 3. our gradients against the exact backward
+    opt.zero_grad()
+    _iteration(m, crit, x, targets)
+    worst_clean, worst_reach, n_clean_elems, n_clean_tensors = ("", 0.0), ("", 0.0), 0, 0
+    for p, name, exact, mask, z in zip(m.parameters(), names, _split(gt["grads_1_exact"], sizes), masks, zero):
+        if z:
+            continue
+        g = p.grad.detach().cpu().numpy().ravel()
+        err = np.abs(g - exact) / np.abs(exact).max()
+        if (~mask).any():
+            e = float(err[~mask].max())
+            n_clean_elems += int((~mask).sum()); n_clean_tensors += 1
+            assert e <= CLEAN_TOL, (name, e, "an element no flipped ReLU decision can reach is off by more than rounding")
+            if e > worst_clean[1]:
+                worst_clean = (name, e)
+        if mask.any():
+            e = float(err[mask].max())
+            assert e <= GRAD_CAP, (name, e)
+            if e > worst_reach[1]:
+                worst_reach = (name, e)
+    assert n_clean_tensors >= 8 and n_clean_elems >= 20000, (n_clean_tensors, n_clean_elems)
+    with capsys.disabled():
+        print("\n[flip-aware gradients] %d of %d ReLU decisions differ from the float64 forward, in %s" % (n_flips, n_relu, {k: len(v) for k, v in flips.items()}))
+        print("[flip-aware gradients] unreachable from any flip: %d elements in %d tensors, worst %.2e (%s); reachable: worst %.2e (%s)"
+              % (n_clean_elems, n_clean_tensors, worst_clean[1], worst_clean[0], worst_reach[1], worst_reach[0]))
+
+
 def test_training_free_running_two_steps(yf, golden, dev, capsys):
     """The same two iterations with our own gradients in the optimizer (training.train_step = train.py:111-132 verbatim).  Adam's
     first step is lr * g / (|g| + eps) = +-lr: only the SIGN of each gradient element matters, so the parameters after step 1 differ

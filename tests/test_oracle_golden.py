@@ -230,3 +230,43 @@ def test_train_mode_oracle_matches_the_reference(golden):
     g64 = torch.autograd.grad(list(p64), [sd64[k] for k in keys], [h.double() for h in head_grads])
     flat64 = np.concatenate([g.float().numpy().ravel() for g in g64])
     assert np.abs(flat64 - gt["grads_1_exact"]).max() <= 1e-6 * np.abs(gt["grads_1_exact"]).max()
+
+
+def test_relu_flips_confine_the_fp32_gradient_error(golden):
+    """The claim behind the gradient tolerances of tests/test_gpu_training.py, checked on the CPU with torch's own fp32 against float64
+    (no GPU involved): an fp32 backward differs from the exact one by more than rounding ONLY in gradient elements that a ReLU decision
+    which came out differently in fp32 can reach (tests/flip_reach.py).  The reference's own fp32 run (`grads_1`) against the exact
+    backward of the same head gradients (`grads_1_exact`): elements no flip reaches agree to 2e-5 of their tensor's largest element
+    (measured 5e-6), reachable ones are off by up to 1.2e-2."""
+    import flip_reach as fr
+    gt = golden("golden_train_256")
+    x = bo.preprocess(gt["input_u8"])
+    names = [str(s) for s in gt["param_names"]]
+    sd32 = bo.training_state(bo.load_state_dict(WEIGHTS[256]))
+    sd64 = bo.training_state(bo.load_state_dict(WEIGHTS[256]), torch.float64)
+    pre32, pre64 = {}, {}
+    bo.forward(sd32, x, train=True, pre=pre32)
+    bo.forward(sd64, x.double(), train=True, pre=pre64)
+    flips, n = {}, 0
+    for name in pre64:
+        diff = (pre32[name]["z"] > 0) != (pre64[name]["z"] > 0)
+        if diff.any():
+            flips[name] = torch.nonzero(diff.any(0).any(-1).any(-1)).ravel().tolist()
+            n += int(diff.sum())
+    assert 5 <= n <= 200, n                      # a few dozen of ~30 M decisions
+    masks = fr.reach_masks(flips, names, [tuple(sd32[k].shape) for k in names])
+    off = np.concatenate([[0], np.cumsum(gt["param_sizes"])])
+    clean_worst, reach_worst, clean_elems = 0.0, 0.0, 0
+    for i, m in enumerate(masks):
+        exact, g32 = gt["grads_1_exact"][off[i]:off[i + 1]], gt["grads_1"][off[i]:off[i + 1]]
+        if gt["grad_absmax_f64"][i] < 1e-9:
+            continue
+        err = np.abs(g32 - exact) / np.abs(exact).max()
+        if (~m).any():
+            clean_worst = max(clean_worst, float(err[~m].max())); clean_elems += int((~m).sum())
+        if m.any():
+            reach_worst = max(reach_worst, float(err[m].max()))
+    assert clean_elems >= 20000 and clean_worst <= 2e-5, (clean_elems, clean_worst)
+    assert 1e-3 <= reach_worst <= 5e-2, reach_worst
+    # upstream(): the two heads' private layers are not upstream of each other, the trunk is upstream of both
+    assert "conv5_3" not in fr.upstream("conv4_1_2") and "conv5_2" in fr.upstream("conv4_1_2") and "deconv5_1" not in fr.upstream("conv5_5")

@@ -4,7 +4,7 @@
 #   100-step default-bench runs; prints every value and the median per lib.  With no libs: the in-tree build only.
 N=${1:-5}; shift
 LIB=yolo-fastest-and-embedded-deployment_amd/libyolo_fastest_hip.so
-run() { python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-variants --no-configs 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['value'])"; }
+run() { python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-variants --no-configs --no-train --no-live-traffic 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['value'])"; }
 if [ $# -eq 0 ]; then for i in $(seq $N); do run; done | sort -n | awk '{v[NR]=$1; printf "%s ", $1} END {print " median", v[int((NR+1)/2)]}'; exit 0; fi
 cp $LIB /tmp/orig.so
 for i in $(seq $N); do for L in "$@"; do cp $L $LIB; echo "$L $(run)"; done; done > /tmp/ab.txt

@@ -3,7 +3,7 @@
 DT=$1; shift
 LIB=yolo-fastest-and-embedded-deployment_amd/libyolo_fastest_hip.so
 cp $LIB /tmp/orig.so
-for L in "$@"; do cp $L $LIB; python bench.py --dtype $DT --no-cpu-baseline --no-variants --no-configs --in-flight 1 --dump-ops /tmp/ops.json 2>/dev/null | python -c "
+for L in "$@"; do cp $L $LIB; python bench.py --dtype $DT --no-cpu-baseline --no-variants --no-configs --no-train --no-live-traffic --in-flight 1 --dump-ops /tmp/ops.json 2>/dev/null | python -c "
 import sys, json
 j = json.loads(sys.stdin.read()); o = json.load(open('/tmp/ops.json'))
 print('$L', j['value'], 'k19m %.1f us' % (1e3 * o[2]['ms']), 'sum %.1f us' % (1e3 * sum(x['ms'] for x in o)))"; done

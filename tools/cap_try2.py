@@ -1,6 +1,6 @@
 """The engine's forward pass captured with the HIP runtime's own calls (no torch.cuda.graph): hipStreamBeginCapture on a fresh stream,
 yf_forward, hipStreamEndCapture, hipGraphInstantiate, one replay.  Separates torch's capture machinery from the runtime's.
-   python tools/cap_try2.py LANES BRANCHES   (env YF_CAPTURE_BRANCH, YF_SEGV_TRACE as in cap_try.py)"""
+   python tools/cap_try2.py LANES BRANCHES   (env YF_SEGV_TRACE=1: native backtrace on SIGSEGV through tools/libsegv_trace.so)"""
 import ctypes, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import yolo_fastest_amd as yf

@@ -3,7 +3,7 @@
 #   tools/ops_ab.sh a.so b.so
 LIB=yolo-fastest-and-embedded-deployment_amd/libyolo_fastest_hip.so
 cp $LIB /tmp/orig.so
-for i in 1 2; do L=${!i}; cp $L $LIB; python bench.py --in-flight 1 --lanes 1 --no-cpu-baseline --no-variants --no-configs --steps 20 --dump-ops gpurun_out/ops_$i.json > /dev/null 2>&1; done
+for i in 1 2; do L=${!i}; cp $L $LIB; python bench.py --in-flight 1 --lanes 1 --no-cpu-baseline --no-variants --no-configs --no-train --no-live-traffic --steps 20 --dump-ops gpurun_out/ops_$i.json > /dev/null 2>&1; done
 cp /tmp/orig.so $LIB
 python - <<'PY'
 import json

@@ -63,6 +63,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef YF_K19_Q4
 #define YF_K19_Q4 1
 #endif
+#ifndef YF_K19_PF
+#define YF_K19_PF 1   // how many k groups ahead phase 2's LDS operands are requested
+#endif
 // Q4 (fp32): output channels 16..23 of conv1_9 do not ride in a second 16-row M-tile (half of whose rows are padding: 25 % of all
 // MFMA cycles) but in 4x4 blocks: v_mfma_f32_4x4x1_16B_f32 is 16 independent 4x4 outer products, block b = lanes 4b..4b+3, and
 // with lane = (pixel p, chunk j) block (j, p >> 2) multiplies 4 channels x the 4 pixels of its lanes at the k-value THAT lane
@@ -340,19 +343,27 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
             }
         }
         using xfrag = f32x4;
-        xfrag xc = *reinterpret_cast<const xfrag*>(Rc + (M16 ? 0 : adr[0])), xn = xc;
-        f32x4 wq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, wqn[2] = {wq[0], wq[1]};
-        if constexpr (Q4) {
+        // LDS operands of group g are requested YF_K19_PF groups ahead (1: 188-190 us; 2: A/B in DESIGN.md)
+        constexpr int PF = YF_K19_PF;
+        xfrag xq[PF + 1];
+        f32x4 wqq[PF + 1][2];
 #pragma unroll
-            for (int cg = 0; cg < 2; ++cg) wq[cg] = wqn[cg] = *reinterpret_cast<const f32x4*>(WQ + (cg * 64 + lane) * 4);
+        for (int d = 0; d < PF; ++d) {
+            xq[d] = *reinterpret_cast<const xfrag*>(Rc + (M16 ? 0 : adr[d < NG ? d : 0]));
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg)
+                wqq[d][cg] = Q4 ? *reinterpret_cast<const f32x4*>(WQ + ((d * 2 + cg) * 64 + lane) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        xq[PF] = xq[0]; wqq[PF][0] = wqq[0][0]; wqq[PF][1] = wqq[0][1];
+        xfrag xc = xq[0];
+        f32x4 wq[2] = {wqq[0][0], wqq[0][1]};
 #pragma unroll
         for (int g = 0; g < (M16 ? 0 : NG); ++g) {
-            if (g + 1 < NG) {
-                xn = *reinterpret_cast<const xfrag*>(Rc + adr[g + 1]);
+            if (g + PF < NG) {
+                xq[PF] = *reinterpret_cast<const xfrag*>(Rc + adr[g + PF]);
                 if constexpr (Q4) {
 #pragma unroll
-                    for (int cg = 0; cg < 2; ++cg) wqn[cg] = *reinterpret_cast<const f32x4*>(WQ + (((g + 1) * 2 + cg) * 64 + lane) * 4);
+                    for (int cg = 0; cg < 2; ++cg) wqq[PF][cg] = *reinterpret_cast<const f32x4*>(WQ + (((g + PF) * 2 + cg) * 64 + lane) * 4);
                 }
             }
             if (!(DBG & 1) && (g & 1) == 0 && g / 2 < NU) p1_mfma(g / 2, d);
@@ -379,9 +390,11 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
             if (g == 10) { c_n = decode(t + step); w1_n = window(tl); }
             if (g == 11) { tl_n = decode(t + 3 * step); }
             if (g == 12) { off2_n = origin(tl_n) - in; }
-            __builtin_amdgcn_sched_barrier(0);  // keeps the one-group-ahead LDS read where it is (hoisting all 14 costs 56 VGPRs)
-            xc = xn;
-            if constexpr (Q4) { wq[0] = wqn[0]; wq[1] = wqn[1]; }
+            __builtin_amdgcn_sched_barrier(0);  // keeps the PF-groups-ahead LDS reads where they are (hoisting all 14 costs 56 VGPRs)
+#pragma unroll
+            for (int d = 0; d < PF; ++d) { xq[d] = xq[d + 1]; wqq[d][0] = wqq[d + 1][0]; wqq[d][1] = wqq[d + 1][1]; }
+            xc = xq[0];
+            if constexpr (Q4) { wq[0] = wqq[0][0]; wq[1] = wqq[0][1]; }
         }
 
         // ---- epilogue: bias + ReLU, conv2_1 (24 -> 8) chained in registers, store ----
