@@ -345,6 +345,12 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
         using xfrag = f32x4;
         // LDS operands of group g are requested YF_K19_PF groups ahead (1: 188-190 us; 2: A/B in DESIGN.md)
         constexpr int PF = YF_K19_PF;
+        // The 4x4x1 weight table lies behind the two region buffers, > 64 KiB into the LDS allocation: past the 16-bit offset field of a
+        // DS instruction, so the compiler paid one v_add_u32 per read (28 per tile).  An opaque per-lane base keeps the per-group
+        // part (<= 27 KiB) in the immediate.
+        int wq_lane = (int)((size_t)2 * BUF * sizeof(TT) / sizeof(float)) + lane * 4;
+        asm volatile("" : "+v"(wq_lane));
+        const float* const wq_base = reinterpret_cast<const float*>(k19_smem) + wq_lane;
         xfrag xq[PF + 1];
         f32x4 wqq[PF + 1][2];
 #pragma unroll
@@ -352,7 +358,7 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
             xq[d] = *reinterpret_cast<const xfrag*>(Rc + (M16 ? 0 : adr[d < NG ? d : 0]));
 #pragma unroll
             for (int cg = 0; cg < 2; ++cg)
-                wqq[d][cg] = Q4 ? *reinterpret_cast<const f32x4*>(WQ + ((d * 2 + cg) * 64 + lane) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                wqq[d][cg] = Q4 ? *reinterpret_cast<const f32x4*>(wq_base + (d * 2 + cg) * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         xq[PF] = xq[0]; wqq[PF][0] = wqq[0][0]; wqq[PF][1] = wqq[0][1];
         xfrag xc = xq[0];
@@ -363,7 +369,7 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
                 xq[PF] = *reinterpret_cast<const xfrag*>(Rc + adr[g + PF]);
                 if constexpr (Q4) {
 #pragma unroll
-                    for (int cg = 0; cg < 2; ++cg) wqq[PF][cg] = *reinterpret_cast<const f32x4*>(WQ + (((g + PF) * 2 + cg) * 64 + lane) * 4);
+                    for (int cg = 0; cg < 2; ++cg) wqq[PF][cg] = *reinterpret_cast<const f32x4*>(wq_base + ((g + PF) * 2 + cg) * 256);
                 }
             }
             if (!(DBG & 1) && (g & 1) == 0 && g / 2 < NU) p1_mfma(g / 2, d);

@@ -57,6 +57,9 @@ __device__ __forceinline__ unsigned long long mres_clock()
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef YF_MRES_FRAME
+#define YF_MRES_FRAME 1   // frame-sized tiles of the producer/consumer kernel expand the interior pixels only (0: round 2's behaviour, for A/B builds)
+#endif
 #ifndef YF_MRES_PK
 #define YF_MRES_PK 1   // depthwise taps as v_pk_fma_f32 (two channels per instruction; same fused multiply-add per element)
 #endif
@@ -480,13 +483,18 @@ __device__ __forceinline__ void mres_post_conv(const float* X, const MresPostFra
 // requested into registers before the epilogue and lands in LDS behind two barriers.  Saves, per chained block, a launch's
 // fill/drain, the input staging and the output round trip.
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NWC, typename T, int POSTN = 0>
+// FRAME: the tile is the whole frame (what the chains need anyway), so every halo pixel lies outside the image and its expansion is zero
+// by definition: the producers expand the TH x TW interior pixels only (MTO M-tiles instead of MTR: 5 instead of 8 at stride 32, 20
+// instead of 25 at stride 16 -- 37 % / 20 % of the expansion MFMAs were spent on zeros) and the halo ring of both E buffers is zeroed
+// once.  The interior pixels' values, and the order they are summed in, do not change.
+template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NWC, typename T, int POSTN = 0, bool FRAME = false>
 __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
 {
     constexpr int NWAVE = NWP + NWC;
     constexpr int RH = TH + 2, RW = TW + 2, NRP = RH * RW;
     constexpr int MTR = (NRP + 15) / 16, MTO = (TH * TW) / 16;
-    constexpr int MTRW = (MTR + NWP - 1) / NWP, MTOW = (MTO + NWC - 1) / NWC;
+    constexpr int MTP = FRAME ? MTO : MTR;      // M-tiles of the expansion
+    constexpr int MTRW = (MTP + NWP - 1) / NWP, MTOW = (MTO + NWC - 1) / NWC;
     constexpr int XP = CIN + 4;
     constexpr int EPL = mres_epl(MTR);
     constexpr bool X3 = is_x3<T>::value;  // fp32 storage, split-operand fp16 MFMAs (see mres_kernel)
@@ -513,6 +521,9 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
 
     mres_stage<CIN, 1, RW, NRP, MTR, XP, WFLOATS, NWAVE * 64, T>(a, n, oy0, ox0, X, WL);
+    if constexpr (FRAME) {   // the producers never write the halo ring: zero both E buffers once
+        for (int i = threadIdx.x; i < 2 * 16 * EPL / 4; i += NWAVE * 64) reinterpret_cast<float4*>(E)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     __syncthreads();
 
     // next block's weight stream, moved by the PRODUCER waves (idle while the consumers finish the last chunk and the epilogue, and
@@ -524,21 +535,23 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
     if (wave < NWP) {
         // ================= producer: expansion of chunk s into E[s & 1] =================
         unsigned long long inmask = 0;
+        int prow[MTRW];   // region pixel (= row of X, record of E) of this lane's pixel of the wave's i-th expansion tile
 #pragma unroll
         for (int i = 0; i < MTRW; ++i) {
             const int mt = wave + i * NWP;
-            const int rp = mt * 16 + r;
+            int rp = (mt < MTP ? mt : 0) * 16 + r;
+            if constexpr (FRAME) { const int py = rp / TW, px = rp - py * TW; rp = (py + 1) * RW + px + 1; }
+            prow[i] = rp;
             const int ry = rp / RW, rx = rp - ry * RW;
             const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
-            if (mt < MTR && rp < NRP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) inmask |= 1ull << i;
+            if (mt < MTP && rp < NRP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) inmask |= 1ull << i;
         }
 #pragma unroll 1
       for (int blk = 0; blk < nblk; ++blk) {
         float a1[MTRW][KS1];
 #pragma unroll
         for (int i = 0; i < MTRW; ++i) {
-            const int mt = wave + i * NWP;
-            const int row = (mt < MTR ? mt : 0) * 16 + r;
+            const int row = prow[i];
 #pragma unroll
             for (int kb = 0; kb < NB1; ++kb) {
                 const float4 t = *reinterpret_cast<const float4*>(&X[row * XP + kb * 16 + 4 * q]);
@@ -580,7 +593,7 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
 #pragma unroll
                 for (int i = 0; i < MTRW; ++i) {
                     const int mt = wave + i * NWP;
-                    if (i < MTRW - 1 || mt < MTR) {
+                    if (i < MTRW - 1 || mt < MTP) {
                         f32x4 cf = f32x4{b1.x, b1.y, b1.z, b1.w};   // bias as the C operand
                         if constexpr (X3) {
 #pragma unroll
@@ -603,7 +616,7 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
                             for (int k = 0; k < KS1; ++k) cf = __builtin_amdgcn_mfma_f32_16x16x4f32(w1f[k], a1[i][k], cf, 0, 0, 0);
                         }
                         const float lim = (inmask >> i) & 1 ? __builtin_inff() : 0.f;   // median(x, 0, lim): ReLU + outside-the-image zero
-                        *reinterpret_cast<float4*>(Eb + (q * EPL + mt * 16 + r) * 4) =
+                        *reinterpret_cast<float4*>(Eb + (q * EPL + prow[i]) * 4) =
                             make_float4(__builtin_amdgcn_fmed3f(cf[0], 0.f, lim), __builtin_amdgcn_fmed3f(cf[1], 0.f, lim),
                                         __builtin_amdgcn_fmed3f(cf[2], 0.f, lim), __builtin_amdgcn_fmed3f(cf[3], 0.f, lim));
                     }
@@ -772,11 +785,16 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
     }
 }
 
-template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NWC, typename T, int POSTN = 0>
+template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NWC, typename T, int POSTN = 0, bool FRAME = false>
 static int launch_mres_pc_t(MresArgs a, int N, hipStream_t s)
 {
     a.tiles_y = (a.H + TH - 1) / TH;
     a.tiles_x = (a.W + TW - 1) / TW;
+#if YF_MRES_FRAME
+    if constexpr (!FRAME) {   // tile == frame: the interior-only expansion
+        if (a.tiles_y == 1 && a.tiles_x == 1) return launch_mres_pc_t<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, T, POSTN, true>(a, N, s);
+    }
+#endif
     constexpr int MTR = ((TH + 2) * (TW + 2) + 15) / 16;
     constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 2 * 16 * mres_epl(MTR) +
                             ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT, wmode_of<T>()) + COUT + 3) & ~3)) * sizeof(float);
@@ -785,14 +803,14 @@ static int launch_mres_pc_t(MresArgs a, int N, hipStream_t s)
     const int dev = current_device();
     if (dev < 0) return -2;
     if (lds > 64 * 1024 && !attr_done[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, T, POSTN>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, T, POSTN, FRAME>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
         attr_done[dev] = true;
     }
     if (a.nblk > 1 && (a.tiles_y != 1 || a.tiles_x != 1 || !RES)) return -4;  // a chain needs tile == frame
     if ((POSTN > 0) != (a.post_w != nullptr) || (POSTN > 0 && !a.post_out)) return -5;
-    hipLaunchKernelGGL((mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, T, POSTN>), dim3((unsigned)(N * a.tiles_y * a.tiles_x)),
+    hipLaunchKernelGGL((mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, T, POSTN, FRAME>), dim3((unsigned)(N * a.tiles_y * a.tiles_x)),
                        dim3((NWP + NWC) * 64), lds, s, a);
     return 0;
 }
@@ -822,6 +840,22 @@ static int launch_mres_t(MresArgs a, int N, hipStream_t s)
     return 0;
 }
 
+// producer / consumer wave counts of the two chained shapes (A/B builds: -DYF_RES5_NWP=.. etc.).  Measured with the interior-only
+// expansion (tools/ops_abn.sh, us per launch at batch 256): res5 chain (8,5) 82.5 -- the three idle producers still sit in every
+// barrier --, (5,5) 71.9, (5,7) 71.3, (3,5) 69.3 [8 waves = 2 per SIMD], (5,3) / (5,4) 80, 9 or 13 waves with 3 producers > 100
+// (a third wave on one SIMD caps the registers at 168: spills); res4 chain (8,8) 76.7, (4,8) 75.7, (6,8) 79.3, (5,10) 79.7.
+#ifndef YF_RES4_NWP
+#define YF_RES4_NWP 4
+#endif
+#ifndef YF_RES4_NWC
+#define YF_RES4_NWC 8
+#endif
+#ifndef YF_RES5_NWP
+#define YF_RES5_NWP 3
+#endif
+#ifndef YF_RES5_NWC
+#define YF_RES5_NWC 5
+#endif
 //      (cin, cexp, cout, residual, stride, TH, TW, producer waves (0 = two-barrier kernel), waves / consumer waves)
 // Producer/consumer pays where one workgroup owns the CU anyway (strides 16, 32); at stride 8 its second E buffer
 // halves the workgroups per CU and it is slower (tools/kbench.hip mrespc).
@@ -833,8 +867,8 @@ static int launch_mres_t(MresArgs a, int N, hipStream_t s)
     MR(8, 32, 8, false, 2, 8, 10, 0, 8)     /* conv2_2/2_3/3_1          H/4 -> H/8  */    \
     MR(8, 32, 8, true, 1, 16, 20, 0, 8)     /* res2_1, res2_2 @ H/4: planned for DT_F16X3 only (fp32: the VALU block is as fast) */ \
     MR(24, 136, 48, false, 2, 8, 10, 0, 8)  /* conv4_2/4_3/5_1 (+ conv4_2 written) H/16 -> H/32 */ \
-    MR(24, 136, 24, true, 1, 16, 20, 8, 8)  /* res4_1 .. res4_4         @ H/16 */         \
-    MR(48, 224, 48, true, 1, 8, 10, 8, 5)   /* res5_1 .. res5_5         @ H/32 */
+    MR(24, 136, 24, true, 1, 16, 20, YF_RES4_NWP, YF_RES4_NWC)  /* res4_1 .. res4_4         @ H/16 */         \
+    MR(48, 224, 48, true, 1, 8, 10, YF_RES5_NWP, YF_RES5_NWC)   /* res5_1 .. res5_5         @ H/32 */
 
 template <int CIN, int CEXP, int COUT, bool RES, int S, int TH, int TW, int NWP, int NW, typename T>
 static int launch_mres_any(const MresArgs& a, int N, hipStream_t s)
@@ -851,9 +885,9 @@ int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArg
 {
     if (a.post_w) {
         if (!(cin == 48 && cexp == 224 && cout == 48 && res && stride == 1)) return -5;
-        return dtype == DT_F16 ? launch_mres_pc_t<48, 224, 48, true, 8, 10, 8, 5, half_t, 96>(a, N, s)
-             : dtype == DT_F16X3 ? launch_mres_pc_t<48, 224, 48, true, 8, 10, 8, 5, x3_t, 96>(a, N, s)
-                                 : launch_mres_pc_t<48, 224, 48, true, 8, 10, 8, 5, float, 96>(a, N, s);
+        return dtype == DT_F16 ? launch_mres_pc_t<48, 224, 48, true, 8, 10, YF_RES5_NWP, YF_RES5_NWC, half_t, 96>(a, N, s)
+             : dtype == DT_F16X3 ? launch_mres_pc_t<48, 224, 48, true, 8, 10, YF_RES5_NWP, YF_RES5_NWC, x3_t, 96>(a, N, s)
+                                 : launch_mres_pc_t<48, 224, 48, true, 8, 10, YF_RES5_NWP, YF_RES5_NWC, float, 96>(a, N, s);
     }
 #define MR(ci, ce, co, rs, st, th, tw, np, nw)                                                                    \
     if (cin == ci && cexp == ce && cout == co && res == rs && stride == st)                                       \
