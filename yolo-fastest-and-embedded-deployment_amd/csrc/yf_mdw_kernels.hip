@@ -636,12 +636,15 @@ static int launch_mdw_t(MdwArgs a, int Nf, hipStream_t s)
     return 0;
 }
 
+#ifndef YF_MDW_LARGE_NW
+#define YF_MDW_LARGE_NW 10
+#endif
 //      (c, n, head, TH, TW, waves)
 #define YF_MDW_SHAPES(MD)                                            \
     MD(96, 128, 0, 8, 10, 5)    /* conv5_3 -> conv5_4            @ H/32 */ \
     MD(128, 128, 24, 8, 10, 5)  /* conv5_5 -> conv5_6 -> head_5  @ H/32 */ \
-    MD(96, 96, 0, 16, 20, 10)   /* conv4_1_2 -> conv4_1_3        @ H/16 */ \
-    MD(96, 96, 24, 16, 20, 10)  /* conv4_1_4 -> conv4_1_5 -> head_4      */
+    MD(96, 96, 0, 16, 20, YF_MDW_LARGE_NW)   /* conv4_1_2 -> conv4_1_3        @ H/16 */ \
+    MD(96, 96, 24, 16, 20, YF_MDW_LARGE_NW)  /* conv4_1_4 -> conv4_1_5 -> head_4      */
 
 int launch_mdw(int c, int n, int headn, const MdwArgs& a, int Nf, hipStream_t s, int dtype)
 {
