@@ -57,6 +57,12 @@ __device__ __forceinline__ unsigned long long mres_clock()
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef YF_MRES_WAVES_ATTR
+#define YF_MRES_WAVES_ATTR   // A/B builds: e.g. -DYF_MRES_WAVES_ATTR='__attribute__((amdgpu_waves_per_eu(6,6)))'
+#endif
+#ifndef YF_MRES_BATCH9_MIN
+#define YF_MRES_BATCH9_MIN 32   // blocks with more expanded channels than this issue the nine depthwise window reads of a pixel together
+#endif
 #ifndef YF_MRES_FRAME
 #define YF_MRES_FRAME 1   // frame-sized tiles of the producer/consumer kernel expand the interior pixels only (0: round 2's behaviour, for A/B builds)
 #endif
@@ -156,7 +162,7 @@ __device__ __forceinline__ void mres_out_px(int mo, int r, int& oy, int& ox)
 // S = 2: the stride-2 triples (pw-expand -> dw3x3 stride 2 -> pw-project, no residual): a.H / a.W are the INPUT dims, the tile
 // is TH x TW OUTPUT pixels and the region (TH - 1) S + 3 rows.
 template <int CIN, int CEXP, int COUT, bool RES, int S, int TH, int TW, int NWAVE, typename T>
-__global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
+__global__ void __launch_bounds__(NWAVE * 64) YF_MRES_WAVES_ATTR mres_kernel(MresArgs a)
 {
     constexpr int RH = (TH - 1) * S + 3, RW = (TW - 1) * S + 3, NRP = RH * RW;
     constexpr int MTR = (NRP + 15) / 16, MTO = (TH * TW) / 16;
@@ -332,7 +338,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mres_kernel(MresArgs a)
                 // All nine window reads go out together (left to the scheduler they were split 3 + 1 + 5 with a wait each) ... except in
                 // the smallest block (8/32 stride-2 triple), where three workgroups fit a CU's LDS and the +24 VGPRs of the batch take it
                 // from 74 to 98 registers = from three resident workgroups to two (measured 35 -> 42 us).
-                constexpr bool BATCH9 = CEXP > 32;
+                constexpr bool BATCH9 = CEXP > YF_MRES_BATCH9_MIN;
                 float4 v9[9];
                 if constexpr (BATCH9) {
 #pragma unroll
