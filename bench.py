@@ -103,6 +103,24 @@ def cpu_baseline(seconds=12.0):
                       + f"; host has {os.cpu_count()} logical CPUs"}
 
 
+def _run_child(cmd, timeout):
+    """subprocess.run for the profiler passes, with the WHOLE process group ended on a timeout (the profiler's child is the python
+    process that holds the GPU).  -> (returncode, combined output tail)"""
+    import signal
+    p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                         start_new_session=True)
+    try:
+        out, _ = p.communicate(timeout=timeout)
+        return p.returncode, out[-300:]
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        p.communicate()
+        return -9, "timed out after %d s" % timeout
+
+
 def live_traffic(args):
     """HBM bytes per launch, measured IN THIS RUN: two child runs of this script's single-lane pass under `rocprofv3 --pmc` (FETCH_SIZE and
     WRITE_SIZE in separate passes, counters with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes), started before this
@@ -117,7 +135,6 @@ def live_traffic(args):
     if not os.path.exists(prof):
         return {}, "rocprofv3 not found"
     work = tempfile.mkdtemp(prefix="yf_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
     vals = {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -126,10 +143,10 @@ def live_traffic(args):
                    os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-variants", "--no-configs",
                    "--no-live-traffic", "--no-train", "--in-flight", "1", "--lanes", "1", "--res", str(args.res), "--batch", str(args.batch), "--dtype", args.dtype,
                    "--frames", args.frames, "--kmax", str(args.kmax), "--dump-ops", os.path.join(work, "ops.json")]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            rc, tail = _run_child(cmd, 180)
             path = os.path.join(d, "p_counter_collection.csv")
-            if r.returncode != 0 or not os.path.exists(path):
-                return {}, "rocprofv3 --pmc %s child failed (rc %d): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-300:].replace("\n", " | "))
+            if rc != 0 or not os.path.exists(path):
+                return {}, "rocprofv3 --pmc %s child failed (rc %d): %s" % (counter, rc, tail.replace("\n", " | "))
             with open(os.path.join(work, "ops.json")) as f:
                 ops = json.load(f)
             with open(path) as f:
@@ -172,10 +189,10 @@ def live_train_traffic(batch, iters=3):
             d = os.path.join(work, counter)
             cmd = [prof, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
                    os.path.join(ROOT, "tools", "train_bench.py"), "--batch", str(batch), "--steps", str(iters), "--warmup", "0"]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=900)
+            rc, tail = _run_child(cmd, 240)
             path = os.path.join(d, "p_counter_collection.csv")
-            if r.returncode != 0 or not os.path.exists(path):
-                return None, None, None, "rocprofv3 --pmc %s child failed (rc %d): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-300:].replace("\n", " | "))
+            if rc != 0 or not os.path.exists(path):
+                return None, None, None, "rocprofv3 --pmc %s child failed (rc %d): %s" % (counter, rc, tail.replace("\n", " | "))
             with open(path) as f:
                 for x in csv.DictReader(f):
                     if x["Counter_Name"] != counter:
