@@ -9,12 +9,13 @@ as a child BEFORE it touches the GPU, relays rank 0's JSON line and exits with t
 GPUs -> non-zero exit and a message.  Launched by torch.distributed.run from outside (the driver), WORLD_SIZE must equal --gpus.
 
 A "step" = one pass of the hot path (model forward -> decode -> per-class NMS [-> all-gather of the decoded
-boxes when N > 1]) over one batch of synthetic frames that is already resident in HBM.  Runs of >= 50 steps keep TWO batches in flight
+boxes when N > 1]) over one batch of synthetic frames that is already resident in HBM.  By default TWO batches are in flight
 (--in-flight 2, yolo_fastest_amd.BatchPipeline): consecutive steps are issued round-robin on two HIP streams, each with its own
-engine, so a batch's late per-frame stages run beside the next batch's early machine-filling ones; shorter runs (the driver's 20 steps)
-issue one step at a time on two half-batch lanes, because the pipeline's fill and drain cost a short run more than the overlap brings.
-All K steps (and exchanges) complete inside the timed region, `ms_per_step` is elapsed / K.  The other mode's figure is reported beside
-it (`two_batches_in_flight` / `one_batch_in_flight`), as are the per-pass model / post-process times (`forward_chain.forward_ms`, `post_ms`).
+engine, so a batch's late per-frame stages run beside the next batch's early machine-filling ones.  Which two streams is decided by
+an untimed measurement before the warm-up (BatchPipeline.tune_streams: the overlap of two streams depends on the hardware queues the
+runtime happened to give them -- 253-261 k frames/s on an unlucky pair, 291-295 k on the others).
+All K steps (and exchanges) complete inside the timed region, `ms_per_step` is elapsed / K.  The one-step-at-a-time figure (two half-batch
+lanes) is reported beside it (`one_batch_in_flight`), as are the per-pass model / post-process times (`forward_chain.forward_ms`, `post_ms`).
 Workload at N = 1: BASELINE.json configs[1], "YOLO-Fastest 320x256 batch=256 fp32, synthetic frames"
 (u8 ~ Uniform{0..255} i.i.d., x = (u8-128)/255, seed = rank).  N > 1: the same per GPU (weak
 scaling, frames are independent units; one RCCL all-gather of the fixed-capacity box records).
@@ -320,9 +321,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="frames per pass of the layer chain (0 = whole batch)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="batches in flight: consecutive steps are issued round-robin on this many streams, each with its own engine "
-                         "(yolo_fastest_amd.BatchPipeline); 1 = one step at a time; 0 (default) = 2 at 320x256 for runs of >= 50 steps, else "
-                         "1 (a short run pays the pipeline's fill and drain; 640x512 launches fill the machine by themselves: measured "
-                         "83.7 k vs 84.9 k frames/s f16x3)")
+                         "(yolo_fastest_amd.BatchPipeline); 1 = one step at a time; 0 (default) = 2 at 320x256, 1 at 640x512 (whose "
+                         "launches fill the machine by themselves: measured 83.7 k vs 84.9 k frames/s f16x3)")
     ap.add_argument("--lanes", type=int, default=0, help="concurrent streams over the chunks of ONE batch (1..4); 0 = 1 with several "
                                                         "batches in flight, else 2")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f16x3"],
@@ -425,9 +425,10 @@ def main():
     wname = WNAME[args.res]
     H, W = io["input_shape"][:2]
     n_total = args.batch * world
-    # batches in flight, automatic: two pay in steady state (100 steps: 291 k vs 280 k frames/s at 320x256) but their fill and drain cost a
-    # short run more than the overlap brings (20 steps: 271 k vs 280 k), and at 640x512 the launches fill the machine by themselves
-    in_flight = args.in_flight if args.in_flight > 0 else (2 if args.res == 256 and args.steps >= 50 else 1)
+    # batches in flight, automatic: two at 320x256 (on streams chosen by measurement, BatchPipeline.tune_streams: 20 steps 290-294 k
+    # frames/s against 281-283 k one at a time; on an unlucky stream pair 253-261 k), one at 640x512, whose launches fill the machine by
+    # themselves
+    in_flight = args.in_flight if args.in_flight > 0 else (2 if args.res == 256 else 1)
     if syn is not None:
         in_flight = 1    # the dense field is spliced in between model and post-process: one at a time
     lanes = args.lanes if args.lanes else (1 if in_flight > 1 else 2)
@@ -460,6 +461,8 @@ def main():
         per-frame stages run beside the next batch's early, machine-filling ones.  Every step -- and every exchange -- completes
         inside the timed region (device synchronisation + barrier on both sides).  Returns (seconds, last step's records)."""
         pipe = yf.BatchPipeline(m, p, depth=depth, kmax=cur["kmax"], lanes=m.lanes, branches=m.branches) if depth > 1 else None
+        if pipe is not None:
+            pipe.tune_streams(cur["x"])      # untimed: which streams the batches overlap best on (pipeline.BatchPipeline.tune_streams)
         gather = (lambda out: yfd.all_gather_detections_async({k: out[k] for k in REC}, cur["n_total"])) if exchange else None
 
         def run(n):

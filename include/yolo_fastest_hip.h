@@ -252,6 +252,12 @@ int yf_op_dtype(yf_handle h, int op, int *kernel_dtype);
  * the pass is done and returns each launch's duration in ms in op_ms[yf_num_launches]. */
 int yf_profile_forward(yf_handle h, const float *d_x, int N, void *d_workspace, size_t workspace_bytes, void *stream,
                        float *op_ms, int n_ops);
+int yf_streams_overlap(yf_handle h, void *stream_a, void *stream_b, int *overlap);
+                                                   /* do two HIP streams run concurrently?  The runtime multiplexes streams onto a few
+                                                      hardware queues; two on one queue execute strictly in issue order (measured: -30 %
+                                                      for two lanes, no gain from two batches in flight).  Host-blocking probe (~0.2 ms:
+                                                      a 100 us spin kernel on each); the engine uses it to pick its lane / branch streams
+                                                      per caller stream, BatchPipeline to pick the streams of the batches in flight */
 int yf_num_launches(yf_handle h, int *out);       /* kernel launches one yf_forward issues            */
 int yf_set_chunk(yf_handle h, int frames);        /* frames per pass of the layer chain (0 = whole batch) */
 int yf_set_lanes(yf_handle h, int lanes);          /* 1..4: chunks of the batch (yf_set_chunk) run on this many concurrent

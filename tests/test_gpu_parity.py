@@ -1059,6 +1059,38 @@ def test_small_head_branch_stream_is_identical(yf, golden, dev):
                 assert torch.equal(raw["head_large"], hl) and torch.equal(raw["head_small"], hs)
 
 
+def test_stream_overlap_probe_and_lane_assignment(yf, golden, dev):
+    """yf_streams_overlap: the probe the engine (lane / branch streams per caller stream) and BatchPipeline.tune_streams use to stay off
+    stream pairs that share a hardware queue.  It answers for pool streams, rejects a stream paired with itself, finds an overlapping
+    partner among a handful of pool streams (there are at least two hardware queues), and a two-lane pass gives the same bits whatever
+    stream it is called on (the assignment is made per caller stream and cached)."""
+    import ctypes
+    io = yf.io_params_for(256)
+    m = yf.YoloFastest(io).to(dev).eval()
+    m.lanes, m.chunk = 2, 10
+    m.load_state_dict(torch.load(WEIGHTS[256], map_location=dev))
+    x = _x(golden("golden_256")["input_u8"], dev)
+    with torch.no_grad():
+        ref = m(x)
+    e = m.engine(256, 320, 20, dev)
+    streams = [torch.cuda.Stream(dev) for _ in range(6)]
+    ov = ctypes.c_int(-1)
+    found = 0
+    for s in streams[1:]:
+        yf._lib.check(e.lib.yf_streams_overlap(e.handle, ctypes.c_void_p(streams[0].cuda_stream), ctypes.c_void_p(s.cuda_stream), ctypes.byref(ov)))
+        assert ov.value in (0, 1)
+        found += ov.value
+    assert found >= 1
+    with pytest.raises(yf._lib.YFError):
+        yf._lib.check(e.lib.yf_streams_overlap(e.handle, ctypes.c_void_p(streams[0].cuda_stream), ctypes.c_void_p(streams[0].cuda_stream), ctypes.byref(ov)))
+    for s in streams[:3] + streams[:2]:        # new caller streams are probed, known ones come from the cache
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.no_grad():
+            out = m(x)
+        s.synchronize()
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+
+
 @pytest.mark.parametrize("depth", [2, 3])
 def test_batch_pipeline_is_identical(yf, golden, dev, depth):
     """yolo_fastest_amd.BatchPipeline (several batches in flight on separate streams, each with its own engine): every batch's heads
@@ -1082,6 +1114,8 @@ def test_batch_pipeline_is_identical(yf, golden, dev, depth):
             want.append((pred, post.detect_raw(pred, kmax=16)))
     torch.cuda.synchronize()
     pipe = yf.BatchPipeline(m, post, depth=depth, kmax=16)
+    replaced = pipe.tune_streams()     # streams that share a hardware queue are replaced (probe: yf_streams_overlap); results must not care
+    assert 0 <= replaced <= 8 * (depth - 1) and len(pipe.streams) == depth
     tickets = [pipe.submit(x) for x in batches]
     for (pred, raw), t in zip(want, tickets):
         out = t.result()
@@ -1113,7 +1147,7 @@ def test_bench_line_and_multi_gpu_rehearsal(dev):
         env.pop(k, None)
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--batch", "64"]
     for extra in ([], ["--exchange-at-1", "--no-variants", "--no-configs", "--no-train"],
-                  ["--exchange-at-1", "--no-variants", "--no-configs", "--no-train", "--in-flight", "2"]):
+                  ["--exchange-at-1", "--no-variants", "--no-configs", "--no-train", "--in-flight", "1"]):
         r = subprocess.run(base + extra, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         j = json.loads(r.stdout.strip().splitlines()[-1])
@@ -1131,7 +1165,7 @@ def test_bench_line_and_multi_gpu_rehearsal(dev):
             assert j["configs"][2]["survivors_per_frame"] >= 200 and j["configs"][2]["detections_identical_on_re_evaluation"]
             assert [t["batch"] for t in j["training"]] == [16, 256] and all(t["value"] > 100 and t["loss_finite"] for t in j["training"])
             assert j["training"][1]["roofline"]["hbm"]["traffic"] > 1e9 and j["training"][1]["roofline"]["dominant_kernel"]["name"]
-            assert j["config"]["in_flight"] == 1 and j["two_batches_in_flight"]["detections_identical"]      # a short run: one step at a time
+            assert j["config"]["in_flight"] == 2 and j["one_batch_in_flight"]["detections_identical"]
             assert j["variants"][0]["dtype"] == "f16x3" and j["variants"][0]["detections_identical_to_f32_on_this_batch"]
             assert j["variants"][0]["max_abs_logit_diff_vs_f32_on_this_batch"] < 1e-3
 

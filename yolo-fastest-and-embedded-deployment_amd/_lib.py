@@ -86,6 +86,7 @@ _SIGS = {
                                       _c.POINTER(_c.c_float), _c.c_int]),
     "yf_set_chunk": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "yf_set_fusion": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "yf_streams_overlap": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_int)]),
     "yf_set_branches": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "yf_set_lanes": (_c.c_int, [_c.c_void_p, _c.c_int]),
 }

@@ -129,6 +129,13 @@ struct yf_engine {
     hipStream_t bside[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_bfork[4] = {nullptr, nullptr, nullptr, nullptr}, ev_bjoin[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_l2b[4] = {nullptr, nullptr, nullptr, nullptr};   // lane -> branch, in front of a chunk's post-process on the branch stream
+    // Which of the engine's seven streams serve as lanes / branches is decided per CALLER stream, by probing (assign_streams): the
+    // runtime multiplexes HIP streams onto a few hardware queues, and two streams that share one run strictly one after the other
+    hipStream_t assigned_for = nullptr;
+    bool assigned = false;
+    struct Assignment { hipStream_t caller, side[3], bside[4]; } seen[4];   // what was found for the last few caller streams
+    int n_seen = 0;
+    hipEvent_t ev_probe[3] = {nullptr, nullptr, nullptr};
     size_t head_l_elems = 0, head_s_elems = 0;
     const Plan& plan() const { return plans[fusion]; }
     size_t frame_floats_max() const
@@ -406,6 +413,85 @@ int chunk_frames(const yf_engine* e, int N)
     return c < N ? c : N;
 }
 
+// ---- do two streams run concurrently?  HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) in
+// first-use order; two streams on one queue execute strictly in issue order, and nothing in the API tells.  Measured on MI355X with two
+// half-batch lanes, one batch at a time: 272-284 k frames/s when the caller's stream and the lane's stream sit on different queues, 192
+// k (even 142 k) when they share one -- decided by which torch pool stream the caller happened to be on (tools/lane_try.sh).  The probe:
+// a one-wave kernel that spins 100 us on each stream, the second ordered behind the first's START; together they take ~0.115 ms when the
+// streams overlap and ~0.215 ms when they are serialised.
+__global__ void yf_spin_kernel(long ticks)
+{
+    const long t0 = wall_clock64();
+    for (int i = 0; i < (1 << 20) && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(16);   // bounded: always exits
+}
+
+int streams_overlap(yf_engine* e, hipStream_t a, hipStream_t b, bool* overlap)
+{
+    int khz = 100000;   // s_memrealtime: 100 MHz on this part
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->device);
+    const long ticks = (long)khz * 100 / 1000;   // 100 us: well above the ~15 us of launch and event overhead around the two kernels
+    HIP_OK(hipEventRecord(e->ev_probe[0], a));
+    HIP_OK(hipStreamWaitEvent(b, e->ev_probe[0], 0));
+    hipLaunchKernelGGL(yf_spin_kernel, dim3(1), dim3(64), 0, a, ticks);
+    hipLaunchKernelGGL(yf_spin_kernel, dim3(1), dim3(64), 0, b, ticks);
+    HIP_OK(hipEventRecord(e->ev_probe[1], b));
+    HIP_OK(hipStreamWaitEvent(a, e->ev_probe[1], 0));
+    HIP_OK(hipEventRecord(e->ev_probe[2], a));
+    HIP_OK(hipEventSynchronize(e->ev_probe[2]));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, e->ev_probe[0], e->ev_probe[2]));
+    *overlap = ms < 0.150f;   // ~0.115 ms when the two spins overlap, ~0.215 ms when they are serialised
+    return YF_OK;
+}
+
+// Choose, for caller stream s, which of the engine's streams are lane 1 and the branches of lanes 0 and 1 (the three that matter:
+// with the caller's stream that is one stream per hardware queue of the default four) so that they overlap with s and with each
+// other; the rest keep their order.  Host-blocking (a few probes of ~0.2 ms), once per caller stream; never while capturing.
+int assign_streams(yf_engine* e, hipStream_t s)
+{
+    for (int i = 0; i < e->n_seen; ++i)
+        if (e->seen[i].caller == s) {   // probed before: a caller that alternates between streams does not pay again
+            for (int l = 0; l < 3; ++l) e->side[l] = e->seen[i].side[l];
+            for (int l = 0; l < 4; ++l) e->bside[l] = e->seen[i].bside[l];
+            e->assigned_for = s;
+            return YF_OK;
+        }
+    hipStream_t pool[7] = {e->side[0], e->bside[0], e->bside[1], e->side[1], e->side[2], e->bside[2], e->bside[3]};
+    bool used[7] = {false, false, false, false, false, false, false};
+    hipStream_t chosen[4] = {s, nullptr, nullptr, nullptr};
+    int nchosen = 1;
+    hipStream_t out[7];
+    for (int need = 0; need < 7; ++need) {
+        int pick = -1;
+        if (need < 3) {
+            for (int c = 0; c < 7 && pick < 0; ++c) {
+                if (used[c]) continue;
+                bool ok = true;
+                for (int k = 0; k < nchosen && ok; ++k) {
+                    bool ov = false;
+                    if (int rc = streams_overlap(e, chosen[k], pool[c], &ov)) return rc;
+                    ok = ov;
+                }
+                if (ok) pick = c;
+            }
+        }
+        if (pick < 0)
+            for (int c = 0; c < 7 && pick < 0; ++c)
+                if (!used[c]) pick = c;
+        used[pick] = true;
+        out[need] = pool[pick];
+        if (need < 3) chosen[nchosen++] = pool[pick];
+    }
+    e->side[0] = out[0]; e->bside[0] = out[1]; e->bside[1] = out[2]; e->side[1] = out[3]; e->side[2] = out[4]; e->bside[2] = out[5]; e->bside[3] = out[6];
+    e->assigned_for = s;
+    e->assigned = true;
+    yf_engine::Assignment& a = e->seen[e->n_seen < 4 ? e->n_seen++ : 3];
+    a.caller = s;
+    for (int l = 0; l < 3; ++l) a.side[l] = e->side[l];
+    for (int l = 0; l < 4; ++l) a.bside[l] = e->bside[l];
+    return YF_OK;
+}
+
 // per-op profiling state (yf_profile_forward): events recorded around every launch of a single-lane pass
 struct ProfileEvents {
     std::vector<hipEvent_t> ev;  // ops.size() + 1
@@ -450,6 +536,13 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
     // forked from a forked stream joins that stream again (tools/cap_repro.hip reproduces it with empty kernels on that runtime;
     // /opt/rocm's 7.2 runtime is fine).  So eager and captured passes issue the SAME thing; there is no capture special case.
     const bool use_branch = e->branches && !prof && !probe && e->fusion >= 1;
+    if ((lanes > 1 || use_branch) && (!e->assigned || e->assigned_for != s_main)) {
+        // first pass on this caller stream: which of the engine's streams overlap with it (see streams_overlap).  The probe waits on
+        // the host, which a stream capture does not allow: a captured pass keeps the current assignment.
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s_main, &st) == hipSuccess && st == hipStreamCaptureStatusNone)
+            if (int rc = assign_streams(e, s_main)) return rc;
+    }
     for (int g0 = 0; g0 < nchunks; g0 += lanes) {
       const int gcount = (nchunks - g0) < lanes ? (nchunks - g0) : lanes;
       // fork: the side lanes wait for everything already queued on the caller's stream -- which, from the second group of chunks on,
@@ -801,6 +894,11 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
         (void)yf_destroy(e);
         return fail(YF_E_HIP, "hipEventCreate failed");
     }
+    for (int l = 0; l < 3; ++l)
+        if (hipEventCreate(&e->ev_probe[l]) != hipSuccess) {
+            (void)yf_destroy(e);
+            return fail(YF_E_HIP, "hipEventCreate (probe) failed");
+        }
     for (int l = 0; l < 4; ++l) {
         if (hipStreamCreateWithFlags(&e->bside[l], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_bfork[l], hipEventDisableTiming) != hipSuccess ||
@@ -823,6 +921,8 @@ int yf_destroy(yf_handle h)
         if (h->ev_join[l]) (void)hipEventDestroy(h->ev_join[l]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (int l = 0; l < 3; ++l)
+        if (h->ev_probe[l]) (void)hipEventDestroy(h->ev_probe[l]);
     for (int l = 0; l < 4; ++l) {
         if (h->bside[l]) (void)hipStreamDestroy(h->bside[l]);
         if (h->ev_bfork[l]) (void)hipEventDestroy(h->ev_bfork[l]);
@@ -1023,6 +1123,16 @@ int yf_preprocess_u8(yf_handle h, const uint8_t* d_u8, int N, int src_h, int src
     HIP_OK(hipSetDevice(h->device));
     yf::launch_preprocess(d_u8, d_x, N, h->H, h->W, down2, (hipStream_t)stream);
     HIP_OK(hipGetLastError());
+    return YF_OK;
+}
+
+int yf_streams_overlap(yf_handle h, void* stream_a, void* stream_b, int* overlap)
+{
+    if (!h || !overlap || stream_a == stream_b) return fail(YF_E_INVALID, "yf_streams_overlap: bad argument");
+    HIP_OK(hipSetDevice(h->device));
+    bool ov = false;
+    if (int rc = streams_overlap(h, (hipStream_t)stream_a, (hipStream_t)stream_b, &ov)) return rc;
+    *overlap = ov ? 1 : 0;
     return YF_OK;
 }
 

@@ -70,3 +70,34 @@ class BatchPipeline:
     def drain(self):
         for s in self.streams:
             s.synchronize()
+
+    def tune_streams(self, x=None, candidates=8):
+        """Make sure the batches in flight run on streams that really overlap.  The HIP runtime multiplexes streams onto a few hardware
+        queues (GPU_MAX_HW_QUEUES, default 4) in first-use order, and two streams that share a queue execute strictly in issue order:
+        two batches "in flight" on such a pair run one after the other -- measured on MI355X, same engines, same process, 20 steps:
+        253-261 k frames/s on the first pair of pool streams created after another engine had run, 291-295 k on each of the next nine
+        pairs (tools/queue_try2.py).  Nothing in the HIP API tells the pairs apart, so the engine probes (yf_streams_overlap: a 100 us
+        spin kernel on each stream, ~0.2 ms per pair): stream k is replaced by fresh pool streams until it overlaps with streams
+        0 .. k - 1, at most `candidates` tries.  Call once, before the first batch.  Returns how many streams were replaced.
+        (x: unused, kept for the call sites that pass the batch.)"""
+        if self.depth < 2:
+            return 0
+        import ctypes
+        from . import _lib
+        p = next(self.model.parameters())
+        dev = p.device
+        e = self.model.engine_on(dev)
+        replaced = 0
+        for k in range(1, self.depth):
+            for _ in range(candidates):
+                ok = True
+                for j in range(k):
+                    ov = ctypes.c_int()
+                    _lib.check(e.lib.yf_streams_overlap(e.handle, ctypes.c_void_p(self.streams[j].cuda_stream),
+                                                        ctypes.c_void_p(self.streams[k].cuda_stream), ctypes.byref(ov)))
+                    ok = ok and bool(ov.value)
+                if ok:
+                    break
+                self.streams[k] = torch.cuda.Stream(self.device)
+                replaced += 1
+        return replaced
