@@ -1114,8 +1114,10 @@ def test_batch_pipeline_is_identical(yf, golden, dev, depth):
             want.append((pred, post.detect_raw(pred, kmax=16)))
     torch.cuda.synchronize()
     pipe = yf.BatchPipeline(m, post, depth=depth, kmax=16)
-    replaced = pipe.tune_streams()     # streams that share a hardware queue are replaced (probe: yf_streams_overlap); results must not care
-    assert 0 <= replaced <= 8 * (depth - 1) and len(pipe.streams) == depth
+    # streams that share a hardware queue are replaced (probe: yf_streams_overlap), then candidate sets are timed; results must not care
+    assert pipe.tune_streams() == [] and len(pipe.streams) == depth
+    rates = pipe.tune_streams(batches[0], candidates=2, batches=3)
+    assert len(rates) == 2 and all(r > 0 for r in rates) and len(pipe.streams) == depth
     tickets = [pipe.submit(x) for x in batches]
     for (pred, raw), t in zip(want, tickets):
         out = t.result()

@@ -49,6 +49,9 @@ if order == "one-first":
 for i in range(P):
     pipe = yf.BatchPipeline(m, p, depth=2, kmax=64, lanes=1, branches=0)
     a = two(pipe)
-    rep = pipe.tune_streams()          # replaces streams that share a hardware queue (yf_streams_overlap)
+    rep = pipe._fix_collisions()       # replaces streams that share a hardware queue (yf_streams_overlap)
     b = two(pipe)
-    print(f"pipeline {i}: as created {a:.1f}, after tune_streams ({rep} replaced) {b:.1f} k frames/s   (one at a time again: {one():.1f})", flush=True)
+    rates = pipe.tune_streams(x)       # ... and times candidate sets on real batches
+    c = two(pipe)
+    print(f"pipeline {i}: as created {a:.1f}, collisions fixed ({rep} replaced) {b:.1f}, tuned {c:.1f} k frames/s (candidates: "
+          + " ".join("%.0f" % (r / 1e3) for r in rates) + f")   (one at a time again: {one():.1f})", flush=True)

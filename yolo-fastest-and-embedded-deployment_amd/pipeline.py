@@ -71,25 +71,14 @@ class BatchPipeline:
         for s in self.streams:
             s.synchronize()
 
-    def tune_streams(self, x=None, candidates=8):
-        """Make sure the batches in flight run on streams that really overlap.  The HIP runtime multiplexes streams onto a few hardware
-        queues (GPU_MAX_HW_QUEUES, default 4) in first-use order, and two streams that share a queue execute strictly in issue order:
-        two batches "in flight" on such a pair run one after the other -- measured on MI355X, same engines, same process, 20 steps:
-        253-261 k frames/s on the first pair of pool streams created after another engine had run, 291-295 k on each of the next nine
-        pairs (tools/queue_try2.py).  Nothing in the HIP API tells the pairs apart, so the engine probes (yf_streams_overlap: a 100 us
-        spin kernel on each stream, ~0.2 ms per pair): stream k is replaced by fresh pool streams until it overlaps with streams
-        0 .. k - 1, at most `candidates` tries.  Call once, before the first batch.  Returns how many streams were replaced.
-        (x: unused, kept for the call sites that pass the batch.)"""
-        if self.depth < 2:
-            return 0
+    def _fix_collisions(self, tries=8):
+        """Replace stream k by fresh pool streams until it overlaps with streams 0 .. k - 1 (yf_streams_overlap)."""
         import ctypes
         from . import _lib
-        p = next(self.model.parameters())
-        dev = p.device
-        e = self.model.engine_on(dev)
+        e = self.model.engine_on(next(self.model.parameters()).device)
         replaced = 0
         for k in range(1, self.depth):
-            for _ in range(candidates):
+            for _ in range(tries):
                 ok = True
                 for j in range(k):
                     ov = ctypes.c_int()
@@ -101,3 +90,42 @@ class BatchPipeline:
                 self.streams[k] = torch.cuda.Stream(self.device)
                 replaced += 1
         return replaced
+
+    def tune_streams(self, x=None, candidates=3, batches=6):
+        """Make sure the batches in flight run on streams that really overlap.  The HIP runtime multiplexes streams onto a few hardware
+        queues (GPU_MAX_HW_QUEUES, default 4) in first-use order, and HOW WELL two batches overlap is a property of the pair of streams
+        they are issued on -- measured on MI355X, same engines, same process, 20 steps of batch 256 (tools/queue_try2.py): 253-261 k
+        frames/s on a pair that shares a hardware queue (the two batches simply run one after the other), ~274 k on pairs that overlap
+        but share some dispatch resource, 291-295 k on the others.  Nothing in the HIP API tells them apart, so:
+          1. streams that do not overlap at all with the ones before them are replaced (yf_streams_overlap: a 100 us spin kernel on
+             each stream, ~0.2 ms per pair) -- this alone removes the worst case and needs no input;
+          2. with a batch `x`: `candidates` such sets of streams are timed on `batches` real submissions each and the fastest is kept
+             (a few milliseconds per candidate).
+        Call once, before the first real batch.  Returns the measured frames/s per candidate (empty without x)."""
+        if self.depth < 2:
+            return []
+        self._fix_collisions()
+        if x is None:
+            return []
+        rates, sets = [], []
+        for c in range(candidates):
+            if c > 0:
+                self.streams = [torch.cuda.Stream(self.device) for _ in range(self.depth)]
+                self._fix_collisions()
+            self._n = 0
+            for _ in range(2 * self.depth):
+                self.submit(x)
+            self.drain()
+            t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(self.device)
+            t0.record()
+            for _ in range(batches):
+                self.submit(x)
+            self.drain()
+            t1.record()
+            torch.cuda.synchronize(self.device)
+            rates.append(1e3 * batches * x.shape[0] / t0.elapsed_time(t1))
+            sets.append(self.streams)
+        self.streams = sets[max(range(len(rates)), key=rates.__getitem__)]
+        self._n = 0
+        return rates
