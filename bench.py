@@ -321,8 +321,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="frames per pass of the layer chain (0 = whole batch)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="batches in flight: consecutive steps are issued round-robin on this many streams, each with its own engine "
-                         "(yolo_fastest_amd.BatchPipeline); 1 = one step at a time; 0 (default) = 2 at 320x256, 1 at 640x512 (whose "
-                         "launches fill the machine by themselves: measured 83.7 k vs 84.9 k frames/s f16x3)")
+                         "(yolo_fastest_amd.BatchPipeline); 1 = one step at a time; 0 (default) = 2")
     ap.add_argument("--lanes", type=int, default=0, help="concurrent streams over the chunks of ONE batch (1..4); 0 = 1 with several "
                                                         "batches in flight, else 2")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f16x3"],
@@ -425,10 +424,10 @@ def main():
     wname = WNAME[args.res]
     H, W = io["input_shape"][:2]
     n_total = args.batch * world
-    # batches in flight, automatic: two at 320x256 (on streams chosen by measurement, BatchPipeline.tune_streams: 20 steps 290-294 k
-    # frames/s against 281-283 k one at a time; on an unlucky stream pair 253-261 k), one at 640x512, whose launches fill the machine by
-    # themselves
-    in_flight = args.in_flight if args.in_flight > 0 else (2 if args.res == 256 else 1)
+    # batches in flight, automatic: two, on streams chosen by measurement (BatchPipeline.tune_streams): 320x256, 20 steps: 290-294 k
+    # frames/s against 281-283 k one at a time (on an unlucky stream pair 253-261 k); 640x512 batch 128: 72.6 k against 69.7 k fp32,
+    # 91.4 k against 85.4 k f16x3 (round 2's "no gain at 640x512" was such an unlucky pair)
+    in_flight = args.in_flight if args.in_flight > 0 else 2
     if syn is not None:
         in_flight = 1    # the dense field is spliced in between model and post-process: one at a time
     lanes = args.lanes if args.lanes else (1 if in_flight > 1 else 2)
@@ -532,7 +531,7 @@ def main():
         e1, r1 = timed(m1, p1, 1, args.steps, args.warmup, False)
         single = {"in_flight": 1, "lanes": 2, "branches": 0, "value": round(args.batch * args.steps / e1, 1), "unit": "frames/s",
                   "ms_per_step": round(1e3 * e1 / args.steps, 4), "detections_identical": bool(same_detections(raw, r1))}
-    elif world == 1 and args.res == 256 and syn is None and args.in_flight == 0:
+    elif world == 1 and syn is None and args.in_flight == 0:
         m2f, p2f = make(args.dtype, 1, 0)
         e1, r1 = timed(m2f, p2f, 2, args.steps, args.warmup, False)
         other = {"in_flight": 2, "lanes": 1, "branches": 0, "value": round(args.batch * args.steps / e1, 1), "unit": "frames/s",
@@ -580,8 +579,8 @@ def main():
             ref_heads = ref_m(x5)
             ref_raw = ref_p.detect_raw(ref_heads, kmax=64)
         for dt in ("f16x3", "f16"):
-            mc, pc = make(dt, 2, 1, io5, 512)
-            ec, rawc = timed(mc, pc, 1, args.steps, args.warmup, False)
+            mc, pc = make(dt, 1, 0, io5, 512)
+            ec, rawc = timed(mc, pc, 2, args.steps, args.warmup, False)
             with torch.no_grad():
                 hc = mc(x5)
             extra_configs.append({
@@ -589,7 +588,7 @@ def main():
                           (" (f16x3: fp32 storage, split fp16 operands -- the variant that meets 2e-2 on logits)" if dt == "f16x3" else
                            " (f16: fp16 storage, single fp16 operands -- throughput mode, does not meet 2e-2)"),
                 "dtype": dt, "value": round(128 * args.steps / ec, 1), "unit": "frames/s", "ms_per_step": round(1e3 * ec / args.steps, 4),
-                "steps": args.steps, "warmup": args.warmup, "in_flight": 1, "lanes": 2,
+                "steps": args.steps, "warmup": args.warmup, "in_flight": 2, "lanes": 1,
                 "max_abs_logit_diff_vs_f32_on_this_batch": round(max(float((ref_heads[0] - hc[0]).abs().max()), float((ref_heads[1] - hc[1]).abs().max())), 6),
                 "detections_identical_to_f32_on_this_batch": bool(same_detections(ref_raw, rawc)),
                 "roofline": dominant(mc)})
