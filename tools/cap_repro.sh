@@ -3,6 +3,7 @@
 # what a plain hipcc program links) and the one PyTorch bundles and loads first in any Python process (torch/lib/libamdhip64.so, ROCm
 # 7.0) -- the engine runs on the latter.  One line per case (rc 139 = the runtime crashed).
 cd "$(dirname "$0")"
+[ -x ./cap_repro.bin ] || /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 cap_repro.hip -o cap_repro.bin || exit 1
 T=/usr/local/lib/python3.10/dist-packages/torch/lib
 for rt in rocm torch; do
 for args in "1 1" "2 0" "2 1" "2 1 fresh" "2 1 lanemajor" "2 1 thread" "1 1 nopost" "2 0 nopost" "2 1 nopost" "2 1 nopost fresh" "2 1 nopost lanemajor" "2 1 nopost joinorigin" "3 1 nopost" "3 1 nopost joinorigin" "3 1" "2 1 postonbranch" "3 1 postonbranch" "1 1 postonbranch" "2 0 postonbranch"; do
