@@ -57,6 +57,9 @@ __device__ __forceinline__ unsigned long long mres_clock()
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef YF_RES5_CPP
+#define YF_RES5_CPP 1   // chunks per barrier phase of the stride-32 chain (A/B: 2)
+#endif
 #ifndef YF_MRES_WAVES_ATTR
 #define YF_MRES_WAVES_ATTR   // A/B builds: e.g. -DYF_MRES_WAVES_ATTR='__attribute__((amdgpu_waves_per_eu(6,6)))'
 #endif
@@ -493,7 +496,9 @@ __device__ __forceinline__ void mres_post_conv(const float* X, const MresPostFra
 // by definition: the producers expand the TH x TW interior pixels only (MTO M-tiles instead of MTR: 5 instead of 8 at stride 32, 20
 // instead of 25 at stride 16 -- 37 % / 20 % of the expansion MFMAs were spent on zeros) and the halo ring of both E buffers is zeroed
 // once.  The interior pixels' values, and the order they are summed in, do not change.
-template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NWC, typename T, int POSTN = 0, bool FRAME = false>
+// CPP chunks per barrier phase (2 x CPP E buffers): the producers expand chunks t CPP .. t CPP + CPP - 1 while the consumers work on the
+// previous CPP -- half the barriers per block for CPP = 2, where the LDS has room for the extra buffers (the stride-32 chain).
+template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NWC, typename T, int POSTN = 0, bool FRAME = false, int CPP = 1>
 __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
 {
     constexpr int NWAVE = NWP + NWC;
@@ -516,8 +521,10 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
     static_assert(MTRW * 4 <= 64, "in-image mask bits");
     extern __shared__ __attribute__((aligned(16))) float mres_smem[];
     float* X = mres_smem;                  // [MTR*16][XP]
-    float* E = mres_smem + MTR * 16 * XP;  // [2][4][EPL][4]
-    float* WL = E + 2 * 16 * EPL;          // weight stream
+    float* E = mres_smem + MTR * 16 * XP;  // [2 * CPP][4][EPL][4]
+    float* WL = E + 2 * CPP * 16 * EPL;    // weight stream
+    constexpr int NPH = ((CEXP + 15) / 16) / CPP;   // barrier phases per block
+    static_assert(((CEXP + 15) / 16) % CPP == 0, "chunks per phase must divide the chunk count");
     constexpr int WFLOATS = (NCH * CHUNK + COUT + 3) & ~3;
 
     const int b = xcd_tile(blockIdx.x, gridDim.x);
@@ -528,7 +535,7 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
 
     mres_stage<CIN, 1, RW, NRP, MTR, XP, WFLOATS, NWAVE * 64, T>(a, n, oy0, ox0, X, WL);
     if constexpr (FRAME) {   // the producers never write the halo ring: zero both E buffers once
-        for (int i = threadIdx.x; i < 2 * 16 * EPL / 4; i += NWAVE * 64) reinterpret_cast<float4*>(E)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = threadIdx.x; i < 2 * CPP * 16 * EPL / 4; i += NWAVE * 64) reinterpret_cast<float4*>(E)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
 
@@ -578,10 +585,13 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
                                 4 * k + 3 < KS1 ? a1[i][(4 * k + 3) % KS1] : 0.f, a1h[i][k], a1l[i][k]);
         }
 #pragma unroll 1
-        for (int s = 0; s <= NCH; ++s) {
-            if (s < NCH) {
+        for (int ph = 0; ph <= NPH; ++ph) {
+#pragma unroll
+            for (int u = 0; u < CPP; ++u)
+            if (ph < NPH) {
+                const int s = ph * CPP + u;
                 const float* wc = WL + s * CHUNK;
-                float* Eb = E + (s & 1) * 16 * EPL;
+                float* Eb = E + ((ph & 1) * CPP + u) * 16 * EPL;
                 float w1f[KS1];
                 f16x4 w1h[NK1], w1l[X3 ? NK1 : 1];
                 if constexpr (H16) {
@@ -673,10 +683,13 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
 #pragma unroll
             for (int nt = 0; nt < NT2; ++nt) acc[i][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-        for (int s = 0; s <= NCH; ++s) {
-            if (s >= 1) {
-                const float* wc = WL + (s - 1) * CHUNK;
-                const float* Eb = E + ((s - 1) & 1) * 16 * EPL;
+        for (int ph = 0; ph <= NPH; ++ph) {
+#pragma unroll
+            for (int u = 0; u < CPP; ++u)
+            if (ph >= 1) {
+                const int s1 = (ph - 1) * CPP + u;
+                const float* wc = WL + s1 * CHUNK;
+                const float* Eb = E + (((ph - 1) & 1) * CPP + u) * 16 * EPL;
                 float4 wd[9];
 #pragma unroll
                 for (int t = 0; t < 9; ++t) wd[t] = *reinterpret_cast<const float4*>(wc + OFF_WD + t * 16 + 4 * q);
@@ -794,6 +807,7 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
 template <int CIN, int CEXP, int COUT, bool RES, int TH, int TW, int NWP, int NWC, typename T, int POSTN = 0, bool FRAME = false>
 static int launch_mres_pc_t(MresArgs a, int N, hipStream_t s)
 {
+    constexpr int CPP = (CIN == 48 && CEXP == 224) ? YF_RES5_CPP : 1;   // the stride-32 chain has the LDS for 2 x 2 E buffers
     a.tiles_y = (a.H + TH - 1) / TH;
     a.tiles_x = (a.W + TW - 1) / TW;
 #if YF_MRES_FRAME
@@ -802,21 +816,21 @@ static int launch_mres_pc_t(MresArgs a, int N, hipStream_t s)
     }
 #endif
     constexpr int MTR = ((TH + 2) * (TW + 2) + 15) / 16;
-    constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 2 * 16 * mres_epl(MTR) +
+    constexpr size_t lds = ((size_t)MTR * 16 * (CIN + 4) + 2 * CPP * 16 * mres_epl(MTR) +
                             ((((CEXP + 15) / 16) * mres_chunk_floats(CIN, COUT, wmode_of<T>()) + COUT + 3) & ~3)) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done[YF_MAX_DEVICES] = {};
     const int dev = current_device();
     if (dev < 0) return -2;
     if (lds > 64 * 1024 && !attr_done[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, T, POSTN, FRAME>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, T, POSTN, FRAME, CPP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
         attr_done[dev] = true;
     }
     if (a.nblk > 1 && (a.tiles_y != 1 || a.tiles_x != 1 || !RES)) return -4;  // a chain needs tile == frame
     if ((POSTN > 0) != (a.post_w != nullptr) || (POSTN > 0 && !a.post_out)) return -5;
-    hipLaunchKernelGGL((mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, T, POSTN, FRAME>), dim3((unsigned)(N * a.tiles_y * a.tiles_x)),
+    hipLaunchKernelGGL((mres_pc_kernel<CIN, CEXP, COUT, RES, TH, TW, NWP, NWC, T, POSTN, FRAME, CPP>), dim3((unsigned)(N * a.tiles_y * a.tiles_x)),
                        dim3((NWP + NWC) * 64), lds, s, a);
     return 0;
 }
