@@ -362,6 +362,12 @@ def main():
 
     # HBM traffic of every launch, by the counters, in THIS run (children; this process has not touched the GPU yet)
     live, live_note = ({}, "not requested")
+    # (not when this process itself runs under a profiler: its preloaded tool library has initialised the GPU already, and a process
+    # that has must not start other programs on this pool)
+    profiled = any(k.startswith(("ROCPROFILER_", "ROCP_", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if profiled:
+        args.no_live_traffic = True
+        live_note = "this process runs under a profiler: no nested counter passes"
     if world == 1 and not args.no_live_traffic and not args.dense and not args.exchange_at_1:
         live, live_note = live_traffic(args)
 
