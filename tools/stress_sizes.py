@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Developer stress (GPU box): fused plan vs one-launch-per-layer plan on random frame sizes and batch sizes (fp32), and
-fp16 storage vs fp32 on the same inputs.  Prints the worst deviations; exits non-zero on a suspicious one."""
+"""Developer stress (GPU box): fused plan (fusion level 2, and level 1 bitwise beside it) vs one-launch-per-layer plan on random frame
+sizes and batch sizes (fp32, f16x3), and fp16 storage vs fp32 on the same inputs.  Prints the worst deviations; exits non-zero on a suspicious one."""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,8 +16,13 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
     H = 32 * int(rng.integers(1, 17)); W = 32 * int(rng.integers(1, 21)); N = int(rng.integers(1, 6))
     x = torch.from_numpy(((rng.integers(0, 256, (N, 1, H, W)).astype(np.float32) - 128.0) / 255.0)).to(dev)
     outs = {}
-    for tag, fusion, dt in (("per-layer", 0, torch.float32), ("fused", 1, torch.float32), ("fused f16", 1, torch.float16)):
-        m = yf.YoloFastest(io).to(dev).eval(); m.load_state_dict(sd); m.fusion = fusion; m.storage_dtype = dt
+    for tag, fusion, dt in (("per-layer", 0, torch.float32), ("fused", 2, torch.float32), ("fused 1", 1, torch.float32), ("fused f16", 2, torch.float16),
+                            ("fused f16x3", 2, "f16x3")):
+        m = yf.YoloFastest(io).to(dev).eval(); m.load_state_dict(sd); m.fusion = fusion
+        if dt == "f16x3":
+            m.precision = "f16x3"
+        else:
+            m.storage_dtype = dt
         m.lanes = int(rng.integers(1, 3)); m.chunk = int(rng.integers(0, 3))
         with torch.no_grad():
             outs[tag] = [t.float().cpu().numpy() for t in m(x)]
@@ -25,7 +30,9 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
     rngv = max(np.abs(outs["per-layer"][0]).max(), np.abs(outs["per-layer"][1]).max(), 1.0)
     d32 = max(np.abs(a - b).max() for a, b in zip(outs["per-layer"], outs["fused"]))
     d16 = max(np.abs(a - b).max() for a, b in zip(outs["per-layer"], outs["fused f16"]))
-    flag = "" if (d32 <= 2e-5 * rngv + 2e-5 and d16 <= 6e-3 * rngv + 2e-2) else "  <-- CHECK"
+    dx3 = max(np.abs(a - b).max() for a, b in zip(outs["per-layer"], outs["fused f16x3"]))
+    same = all(np.array_equal(a, b) for a, b in zip(outs["fused"], outs["fused 1"]))      # fusion level 2 == level 1, bitwise
+    flag = "" if (d32 <= 2e-5 * rngv + 2e-5 and d16 <= 6e-3 * rngv + 2e-2 and dx3 <= 2e-5 * rngv + 2e-5 and same) else "  <-- CHECK"
     bad += bool(flag)
-    print(f"{H:4d}x{W:<4d} N={N}  range {rngv:7.2f}  fused-vs-per-layer {d32:.2e}   f16-vs-f32 {d16:.2e}{flag}", flush=True)
+    print(f"{H:4d}x{W:<4d} N={N}  range {rngv:7.2f}  fused-vs-per-layer {d32:.2e}   f16x3 {dx3:.2e}   f16-vs-f32 {d16:.2e}   level 2 == level 1: {same}{flag}", flush=True)
 sys.exit(1 if bad else 0)
