@@ -18,7 +18,7 @@
 //     the grid is persistent over the items.  Operand fragments of the next M-tile are requested while the current one is computed
 //     (the "A ring" of pw_ws_kernel).  No barrier after the weight staging.
 // Arithmetic and its order are those of the two launches this replaces (pw_ws_kernel, OMODE 2 and the two-source GEMM): acc = 0,
-// k-steps in order, + bias, ReLU -- bitwise the same conv4_1_1 tensor.  fp32 storage only.
+// k-steps in order, + bias, ReLU -- bitwise the same conv4_1_1 tensor.  fp32 storage only (DT_F32; DT_F16X3: dcat_x3_kernel below).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -189,6 +189,172 @@ __global__ void __launch_bounds__(256) dcat_kernel(DcatArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// dcat_x3_kernel: the same launch for DT_F16X3 engines (fp32 storage, split-operand fp16 MFMAs; yf_kernels.h): every operand a = hi + lo
+// (two fp16 halves, lo = rne(a - hi)), a k-block of 16 channels issues w_lo a_hi + w_hi a_lo + w_hi a_hi on v_mfma_f32_16x16x16_f16 -- the
+// order of pw_ws_x3_kernel, whose two launches this replaces bit for bit.  A wave keeps its quadrant's deconv weights as hi and lo
+// fragments (the same 144 registers as the fp32 fragments); conv4_1_1's stream in LDS holds, per (16-channel block, n-tile, lane), the
+// 16-byte record [hi4 | lo4], so one ds_read_b128 still feeds a whole k-block; activations are split where they are consumed (the
+// conv4_2 fragments once per M-tile, the deconv result once, in registers).
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int DX_NG = DC_KB_S + 1 + DC_KB_D;                 // 15 k-blocks of conv4_1_1: 8 skip, the 8-channel tail, 6 deconv
+constexpr int DX_OFF_BD = DX_NG * DC_NT * 64 * 4;            // floats: [block][nt][lane][hi4 | lo4] = 4 floats per lane
+constexpr int DX_OFF_BC = DX_OFF_BD + DC_N;
+constexpr int DX_WFLOATS = DX_OFF_BC + DC_N;                 // 23232 floats = 92928 B
+}  // namespace
+
+__global__ void __launch_bounds__(256) dcat_x3_kernel(DcatArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float dc_smem[];
+    float* WL = dc_smem;
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int qd = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), dy = qd >> 1, dx = qd & 1;
+
+    LdsStage<DX_WFLOATS, 256> stage;
+    stage.issue(a.wc);
+    // this wave's deconv weights (mfma_pack_weights_x3 per quadrant: [hi: k-block][n-tile][lane] f16x4, then lo the same)
+    f16x4 dh[DC_NT][DC_KB_D], dl[DC_NT][DC_KB_D];
+    {
+        const f16x4* w = reinterpret_cast<const f16x4*>(a.wd) + (size_t)qd * 2 * DC_KB_D * DC_NT * 64 + lane;
+#pragma unroll
+        for (int kb = 0; kb < DC_KB_D; ++kb)
+#pragma unroll
+            for (int nt = 0; nt < DC_NT; ++nt) {
+                dh[nt][kb] = w[(kb * DC_NT + nt) * 64];
+                dl[nt][kb] = w[((DC_KB_D + kb) * DC_NT + nt) * 64];
+            }
+    }
+    stage.commit(WL);
+    __syncthreads();
+    const float4* WL4 = reinterpret_cast<const float4*>(WL);
+
+    const int npx = a.h * a.w, ow = 2 * a.w;
+    const long ntile = (long)((a.nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * DC_MT;
+    struct Tile { const float* sp; const float* cp; long o; bool ok; };
+    auto tile = [&](long t) {
+        const long it = (long)blockIdx.x + (t / DC_MT) * gridDim.x;
+        const int n = (int)(it / a.items_per_frame), chunk = (int)(it - (long)n * a.items_per_frame);
+        const int p = chunk * (DC_MT * 16) + (int)(t % DC_MT) * 16 + r;
+        Tile T;
+        T.ok = p < npx;
+        const int pc = T.ok ? p : npx - 1;
+        const int y = pc / a.w, x = pc - y * a.w;
+        const long opix = (long)n * 4 * npx + (long)(2 * y + dy) * ow + 2 * x + dx;
+        T.sp = a.x + ((long)n * npx + pc) * DC_CIN + 4 * q;
+        T.cp = a.skip + opix * DC_SKIP;
+        T.o = opix * DC_N + 4 * q;
+        return T;
+    };
+    if (ntile <= 0) return;
+    float4 sf[DC_KB_D], cf[DC_KB_S];
+    float2 ct;
+    Tile cur = tile(0);
+#pragma unroll
+    for (int kb = 0; kb < DC_KB_D; ++kb) sf[kb] = *reinterpret_cast<const float4*>(cur.sp + kb * 16);
+#pragma unroll
+    for (int kb = 0; kb < DC_KB_S; ++kb) cf[kb] = *reinterpret_cast<const float4*>(cur.cp + kb * 16 + 4 * q);
+    ct = *reinterpret_cast<const float2*>(cur.cp + DC_KB_S * 16 + 2 * q);
+
+    // w_lo a_hi, w_hi a_lo, w_hi a_hi for all six n-tiles of one k-block (pw_ws_x3_kernel's mac)
+    auto mac6 = [&](f32x4 (&acc)[DC_NT], const f16x4 (&wh)[DC_NT], const f16x4 (&wl)[DC_NT], float x0, float x1, float x2, float x3) {
+        f16x4 ah, al;
+        split_f16x4(x0, x1, x2, x3, ah, al);
+#pragma unroll
+        for (int nt = 0; nt < DC_NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl[nt], ah, acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < DC_NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[nt], al, acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < DC_NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[nt], ah, acc[nt], 0, 0, 0);
+    };
+
+#pragma unroll 1
+    for (long t = 0; t < ntile; ++t) {
+        const Tile nxt = tile(t + 1 < ntile ? t + 1 : t);
+        f32x4 dacc[DC_NT];
+#pragma unroll
+        for (int nt = 0; nt < DC_NT; ++nt) dacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < DC_KB_D; ++kb) {
+            f16x4 wh[DC_NT], wl[DC_NT];
+#pragma unroll
+            for (int nt = 0; nt < DC_NT; ++nt) { wh[nt] = dh[nt][kb]; wl[nt] = dl[nt][kb]; }
+            mac6(dacc, wh, wl, sf[kb].x, sf[kb].y, sf[kb].z, sf[kb].w);
+            sf[kb] = *reinterpret_cast<const float4*>(nxt.sp + kb * 16);
+        }
+        float dv[DC_NT][4];
+#pragma unroll
+        for (int nt = 0; nt < DC_NT; ++nt) {
+            const float4 b = *reinterpret_cast<const float4*>(WL + DX_OFF_BD + nt * 16 + 4 * q);
+            dv[nt][0] = fmaxf(dacc[nt][0] + b.x, 0.f); dv[nt][1] = fmaxf(dacc[nt][1] + b.y, 0.f);
+            dv[nt][2] = fmaxf(dacc[nt][2] + b.z, 0.f); dv[nt][3] = fmaxf(dacc[nt][3] + b.w, 0.f);
+        }
+        f32x4 cacc[DC_NT];
+#pragma unroll
+        for (int nt = 0; nt < DC_NT; ++nt) cacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float4 wbuf[2][DC_NT];
+#pragma unroll
+        for (int nt = 0; nt < DC_NT; ++nt) wbuf[0][nt] = WL4[nt * 64 + lane];
+#pragma unroll
+        for (int g = 0; g < DX_NG; ++g) {
+            if (g + 1 < DX_NG) {
+#pragma unroll
+                for (int nt = 0; nt < DC_NT; ++nt) wbuf[(g + 1) & 1][nt] = WL4[((g + 1) * DC_NT + nt) * 64 + lane];
+            }
+            f16x4 wh[DC_NT], wl[DC_NT];
+#pragma unroll
+            for (int nt = 0; nt < DC_NT; ++nt) {
+                const float4 w = wbuf[g & 1][nt];
+                wh[nt] = __builtin_bit_cast(f16x4, make_float2(w.x, w.y));
+                wl[nt] = __builtin_bit_cast(f16x4, make_float2(w.z, w.w));
+            }
+            if (g < DC_KB_S) {
+                mac6(cacc, wh, wl, cf[g].x, cf[g].y, cf[g].z, cf[g].w);
+                cf[g] = *reinterpret_cast<const float4*>(nxt.cp + g * 16 + 4 * q);
+            } else if (g == DC_KB_S) {
+                mac6(cacc, wh, wl, ct.x, ct.y, 0.f, 0.f);
+                ct = *reinterpret_cast<const float2*>(nxt.cp + DC_KB_S * 16 + 2 * q);
+            } else {
+                const int kb = g - DC_KB_S - 1;
+                mac6(cacc, wh, wl, dv[kb][0], dv[kb][1], dv[kb][2], dv[kb][3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (cur.ok) {
+#pragma unroll
+            for (int nt = 0; nt < DC_NT; ++nt) {
+                const float4 b = *reinterpret_cast<const float4*>(WL + DX_OFF_BC + nt * 16 + 4 * q);
+                *reinterpret_cast<float4*>(a.out + cur.o + nt * 16) =
+                    make_float4(fmaxf(cacc[nt][0] + b.x, 0.f), fmaxf(cacc[nt][1] + b.y, 0.f), fmaxf(cacc[nt][2] + b.z, 0.f), fmaxf(cacc[nt][3] + b.w, 0.f));
+            }
+        }
+        cur = nxt;
+    }
+}
+
+size_t dcat_packed_floats_x3() { return (size_t)DX_WFLOATS; }
+
+void dcat_pack_weights_x3(const float* w, const float* bd, const float* bc, float* out)
+{
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(out);
+    for (int g = 0; g < DX_NG; ++g)
+        for (int nt = 0; nt < DC_NT; ++nt)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int q = lane >> 4, c = nt * 16 + (lane & 15);
+                for (int j = 0; j < 4; ++j) {
+                    int k = -1;   // row of w, or none (a zero k-slot)
+                    if (g < DC_KB_S) k = g * 16 + 4 * q + j;
+                    else if (g == DC_KB_S) k = j < 2 ? DC_KB_S * 16 + 2 * q + j : -1;
+                    else k = DC_SKIP + (g - DC_KB_S - 1) * 16 + 4 * q + j;
+                    const float v = k >= 0 ? w[(size_t)k * DC_N + c] : 0.f;
+                    const size_t rec = ((size_t)(g * DC_NT + nt) * 64 + lane) * 8;   // 8 halves: hi4 | lo4
+                    o16[rec + j] = f32_to_f16_bits(v);
+                    o16[rec + 4 + j] = f16_lo_bits(v);
+                }
+            }
+    for (int i = 0; i < DC_N; ++i) { out[DX_OFF_BD + i] = bd[i]; out[DX_OFF_BC + i] = bc[i]; }
+}
+
 size_t dcat_packed_floats() { return (size_t)DC_WFLOATS; }
 
 // w: conv4_1_1's folded weights [232][96] (rows 0..135 = conv4_2 channels, 136..231 = deconv5_1 channels), bd / bc: the two biases
@@ -211,24 +377,29 @@ void dcat_pack_weights(const float* w, const float* bd, const float* bc, float* 
 
 bool dcat_has_kernel(int cin, int cskip, int cout) { return cin == DC_CIN && cskip == DC_SKIP && cout == DC_N; }
 
-int launch_dcat(const float* x, const float* skip, const float* wd, const float* wc, float* out, int h, int w, int Nf, hipStream_t s)
+int launch_dcat(const float* x, const float* skip, const float* wd, const float* wc, float* out, int h, int w, int Nf, hipStream_t s, int dtype)
 {
-    static bool attr_done[YF_MAX_DEVICES] = {};
+    static bool attr_done[2][YF_MAX_DEVICES] = {};
     const int dev = current_device();
     const int n_cu = device_cu_count(dev);
     if (dev < 0 || n_cu <= 0) return -2;
-    constexpr size_t lds = (size_t)DC_WFLOATS * sizeof(float);
-    static_assert(lds <= 160 * 1024, "LDS");
-    if (!attr_done[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dcat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
-        attr_done[dev] = true;
+    if (dtype != DT_F32 && dtype != DT_F16X3) return -1;   // fp32 storage only
+    const bool x3 = dtype == DT_F16X3;
+    const size_t lds = (size_t)(x3 ? DX_WFLOATS : DC_WFLOATS) * sizeof(float);
+    static_assert((size_t)DX_WFLOATS * sizeof(float) <= 160 * 1024 && (size_t)DC_WFLOATS * sizeof(float) <= 160 * 1024, "LDS");
+    if (!attr_done[x3][dev]) {
+        if (hipFuncSetAttribute(x3 ? reinterpret_cast<const void*>(dcat_x3_kernel) : reinterpret_cast<const void*>(dcat_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -2;
+        attr_done[x3][dev] = true;
     }
     DcatArgs a{x, skip, wd, wc, out, h, w, 0, 0};
     a.items_per_frame = (h * w + DC_MT * 16 - 1) / (DC_MT * 16);
     a.nitems = Nf * a.items_per_frame;
     // persistent grid, every workgroup the same number of items
     const int rounds = (a.nitems + n_cu - 1) / n_cu, grid = (a.nitems + rounds - 1) / rounds;
-    hipLaunchKernelGGL(dcat_kernel, dim3((unsigned)grid), dim3(256), lds, s, a);
+    if (x3) hipLaunchKernelGGL(dcat_x3_kernel, dim3((unsigned)grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(dcat_kernel, dim3((unsigned)grid), dim3(256), lds, s, a);
     return 0;
 }
 

@@ -298,6 +298,9 @@ void build_plan(Plan* e, int level, int dtype)
     x = b.triple("conv3_5", "conv3_6", "conv4_1", x);
     x = b.reschain({"res4_1", "res4_2", "res4_3", "res4_4"}, x);
     const bool fused_deep = fused;
+    // developer switch (tests, A/B): YF_DEEP_MASK bit 0 = conv5_2 in the res5 launch, bit 1 = the chained small head, bit 2 = deconv5_1 + conv4_1_1
+    const char* dm_env = getenv("YF_DEEP_MASK");
+    const int dmask = dm_env ? atoi(dm_env) : 7;
     int conv4_2 = -1;
     x = b.triple_keep_expansion("conv4_2", "conv4_3", "conv5_1", x, &conv4_2);
     x = b.reschain({"res5_1", "res5_2", "res5_3", "res5_4", "res5_5"}, x);
@@ -305,7 +308,7 @@ void build_plan(Plan* e, int level, int dtype)
     {   // level 2: conv5_2 (48 -> 96, ReLU) runs on the last res5 launch's result while it is in LDS; res5_5 itself is not stored
         Op& last = e->ops.back();
         const LayerSpec& L52 = kLayers[find_layer("conv5_2")];
-        if (deep && last.type == OP_MRES && last.out == x &&
+        if (deep && (dmask & 1) && last.type == OP_MRES && last.out == x &&
             yf::mres_has_post(kLayers[last.l_exp].cin, kLayers[last.l_exp].cout, kLayers[last.l_proj].cout, L52.cout)) {
             last.l_post = find_layer("conv5_2");
             e->tensors[x].name.clear();   // never materialised: not probe-able
@@ -317,15 +320,15 @@ void build_plan(Plan* e, int level, int dtype)
     if (conv5_2 < 0) conv5_2 = b.unit("conv5_2", x);
     b.fused = fused_deep;
     const size_t br0 = e->ops.size();
-    if (!deep || b.dwpw2("conv5_3", "conv5_4", "conv5_5", "conv5_6", "head_5", conv5_2, "head_small", BUF_HEAD_SMALL) < 0) {
+    if (!deep || !(dmask & 2) || b.dwpw2("conv5_3", "conv5_4", "conv5_5", "conv5_6", "head_5", conv5_2, "head_small", BUF_HEAD_SMALL) < 0) {
         x = b.dwpw("conv5_3", "conv5_4", nullptr, conv5_2, nullptr, 0);
         b.dwpw("conv5_5", "conv5_6", "head_5", x, "head_small", BUF_HEAD_SMALL);
     }
     if (fused)
         for (size_t i = br0; i < e->ops.size(); ++i) e->ops[i].branch = 1;
     b.fused = false;
-    if (deep && dtype == yf::DT_F32 && yf::dcat_has_kernel(e->tensors[conv5_2].C, e->tensors[conv4_2].C, kLayers[find_layer("conv4_1_1")].cout)) {
-        // level 2, fp32: deconv5_1 + conv4_1_1 in one launch, the deconv result stays in registers (yf_dcat_kernels.hip)
+    if (deep && (dmask & 4) && dtype != yf::DT_F16 && yf::dcat_has_kernel(e->tensors[conv5_2].C, e->tensors[conv4_2].C, kLayers[find_layer("conv4_1_1")].cout)) {
+        // level 2, fp32 storage: deconv5_1 + conv4_1_1 in one launch, the deconv result stays in registers (yf_dcat_kernels.hip)
         Op o{};
         o.type = OP_DCAT;
         o.layer = find_layer("deconv5_1"); o.l_proj = find_layer("conv4_1_1");
@@ -583,7 +586,7 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
             int rc = 0;
             struct AtExit { ProfileEvents* p; size_t* i; hipStream_t st; ~AtExit() { if (p) { ++*i; (void)hipEventRecord(p->ev[*i], st); } } } at_exit{prof, &op_idx, s};
             if (o.type == OP_DCAT) {
-                rc = yf::launch_dcat(ptr(o.in1), ptr(o.in2), e->d_wmfma + o.mfma_off, e->d_wmfma + o.mfma_off2, ptr(o.out), ti.H, ti.W, n, s);
+                rc = yf::launch_dcat(ptr(o.in1), ptr(o.in2), e->d_wmfma + o.mfma_off, e->d_wmfma + o.mfma_off2, ptr(o.out), ti.H, ti.W, n, s, o.kdt);
             } else if (o.type == OP_MDW2) {
                 rc = yf::launch_mdw2(ptr(o.in1), e->d_wmfma + o.mfma_off, e->d_wmfma + o.mfma_off2, ptr(o.out), ti.H, ti.W, n, s, o.kdt);
             } else if (o.type == OP_MDW) {
@@ -826,17 +829,20 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
                 continue;
             }
             if (o.type == OP_DCAT) {   // deconv: the pw GEMM's fragments per quadrant; conv4_1_1: the LDS stream + both biases
-                const LayerSpec &LD = kLayers[o.layer], &LC = kLayers[o.l_proj];
-                o.kdt = yf::DT_F32;
-                const size_t per = yf::mfma_packed_floats(LD.cin, 0, LD.cout);
+                const LayerSpec& LD = kLayers[o.layer];
+                o.kdt = x3 ? yf::DT_F16X3 : yf::DT_F32;
+                const size_t per = x3 ? yf::mfma_packed_floats_x3(LD.cin, 0, LD.cout) : yf::mfma_packed_floats(LD.cin, 0, LD.cout);
                 o.mfma_off = (long)packed.size();
                 packed.resize(packed.size() + ((4 * per + 63) & ~(size_t)63));
-                for (int qd = 0; qd < 4; ++qd)
-                    yf::mfma_pack_weights(hw + e->w_off[o.layer] + (size_t)qd * LD.cin * LD.cout, LD.cin, 0, LD.cout, packed.data() + o.mfma_off + per * qd);
+                for (int qd = 0; qd < 4; ++qd) {
+                    const float* wq = hw + e->w_off[o.layer] + (size_t)qd * LD.cin * LD.cout;
+                    if (x3) yf::mfma_pack_weights_x3(wq, LD.cin, 0, LD.cout, packed.data() + o.mfma_off + per * qd);
+                    else yf::mfma_pack_weights(wq, LD.cin, 0, LD.cout, packed.data() + o.mfma_off + per * qd);
+                }
                 o.mfma_off2 = (long)packed.size();
-                packed.resize(packed.size() + ((yf::dcat_packed_floats() + 63) & ~(size_t)63));
-                yf::dcat_pack_weights(hw + e->w_off[o.l_proj], hw + e->b_off[o.layer], hw + e->b_off[o.l_proj], packed.data() + o.mfma_off2);
-                (void)LC;
+                packed.resize(packed.size() + (((x3 ? yf::dcat_packed_floats_x3() : yf::dcat_packed_floats()) + 63) & ~(size_t)63));
+                if (x3) yf::dcat_pack_weights_x3(hw + e->w_off[o.l_proj], hw + e->b_off[o.layer], hw + e->b_off[o.l_proj], packed.data() + o.mfma_off2);
+                else yf::dcat_pack_weights(hw + e->w_off[o.l_proj], hw + e->b_off[o.layer], hw + e->b_off[o.l_proj], packed.data() + o.mfma_off2);
                 continue;
             }
             if (o.type == OP_MDW2) {   // two mdw weight streams, one after the other

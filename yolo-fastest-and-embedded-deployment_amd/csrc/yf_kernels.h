@@ -252,8 +252,10 @@ void mdw_pack_weights(const float* wd, const float* bd, const float* w, const fl
 bool dcat_has_kernel(int cin, int cskip, int cout);
 size_t dcat_packed_floats();
 void dcat_pack_weights(const float* w_cat /*[136 + 96][96]*/, const float* b_deconv, const float* b_conv, float* out);
-int launch_dcat(const float* x /*conv5_2*/, const float* skip /*conv4_2*/, const float* w_deconv /*4 x mfma_pack_weights*/, const float* w_conv, float* out,
-                int h, int w, int Nf, hipStream_t s);
+int launch_dcat(const float* x /*conv5_2*/, const float* skip /*conv4_2*/, const float* w_deconv /*4 x mfma_pack_weights[_x3]*/, const float* w_conv,
+                float* out, int h, int w, int Nf, hipStream_t s, int dtype = DT_F32);
+size_t dcat_packed_floats_x3();   // DT_F16X3: the split-operand stream
+void dcat_pack_weights_x3(const float* w_cat, const float* b_deconv, const float* b_conv, float* out);
 
 struct K19Args {
     const float* in;              // NHWC [N,H,W,4] (res1_1 output, stride-2 resolution)
