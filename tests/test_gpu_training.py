@@ -94,6 +94,40 @@ def test_conv_forward_backward_match_torch(ops, dev, geom):
     _close(gb, bt.grad, 2e-6, "bias gradient")
 
 
+# the bandwidth kernels of the large maps (float4 pointwise GEMM, multi-wave weight gradient, row-block depthwise kernels) only take
+# over above a size the small geometries above never reach: (N, Cin, Cout, k, stride, depthwise, H, W)
+BIG = [(64, 8, 32, 1, 1, 0, 64, 80), (40, 48, 8, 1, 1, 0, 64, 80), (24, 16, 96, 1, 1, 0, 32, 80), (6, 8, 8, 3, 1, 1, 64, 160), (5, 16, 16, 5, 1, 1, 32, 80),
+       (3, 8, 8, 3, 1, 1, 36, 72), (12, 24, 24, 3, 2, 0, 64, 80), (32, 1, 8, 3, 2, 0, 64, 160)]
+
+
+@pytest.mark.parametrize("geom", BIG)
+def test_large_map_kernels_match_torch(ops, dev, geom):
+    N, Cin, Cout, k, stride, dw, H, W = geom
+    rng = np.random.default_rng(sum(geom))
+    x = rng.normal(size=(N, Cin, H, W)).astype(np.float32)
+    w = rng.normal(size=(Cout, 1 if dw else Cin, k, k)).astype(np.float32)
+    xt = torch.from_numpy(x).double().requires_grad_(True)
+    wt = torch.from_numpy(w).double().requires_grad_(True)
+    yt = F.conv2d(xt, wt, None, stride=stride, padding=(k - 1) // 2, groups=Cin if dw else 1)
+    gy = rng.normal(size=tuple(yt.shape)).astype(np.float32)
+    yt.backward(torch.from_numpy(gy).double())
+    xd, wd, gyd = _g(x, dev), _g(w, dev), _g(gy, dev)
+    y = torch.full(tuple(yt.shape), float("nan"), device=dev)
+    ops.call("yf_train_conv_forward", xd.data_ptr(), wd.data_ptr(), None, y.data_ptr(), N, Cin, H, W, Cout, k, stride, dw)
+    _close(y, yt, 3e-6, "forward")
+    gx = torch.full_like(xd, float("nan"))
+    ops.call("yf_train_conv_backward_data", gyd.data_ptr(), wd.data_ptr(), gx.data_ptr(), N, Cin, H, W, Cout, k, stride, dw)
+    _close(gx, xt.grad, 3e-6, "backward data")
+    gw = torch.full_like(wd, float("nan"))
+    ops.call("yf_train_conv_backward_weight", xd.data_ptr(), gyd.data_ptr(), gw.data_ptr(), N, Cin, H, W, Cout, k, stride, dw, ops.scratch,
+             ops.scratch_bytes)
+    _close(gw, wt.grad, 3e-5, "backward weight")
+    gw2 = torch.empty_like(gw)
+    ops.call("yf_train_conv_backward_weight", xd.data_ptr(), gyd.data_ptr(), gw2.data_ptr(), N, Cin, H, W, Cout, k, stride, dw, ops.scratch,
+             ops.scratch_bytes)
+    assert torch.equal(gw, gw2)                                   # fixed summation order
+
+
 def test_conv_backward_weight_long_reduction(ops, dev):
     """The chunked reduction (several workgroups per weight element + atomics) at a reduction length of the real batch."""
     rng = np.random.default_rng(5)

@@ -7,7 +7,11 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <string>
+#include <vector>
 
 #include "../../include/yolo_fastest_hip.h"
 #include "yf_kernels.h"
@@ -128,6 +132,35 @@ TWs trainer_ws(const yf_trainer_s* t, int N, void* base)
     w.bytes = (size_t)(p - static_cast<char*>(base));
     return w;
 }
+
+// developer timing (YF_TRAIN_TIMING=1): an event after every layer of a pass, the table printed to stderr when the pass has drained
+struct PassTimer {
+    bool on;
+    hipStream_t s;
+    std::vector<hipEvent_t> ev;
+    std::vector<std::string> label;
+    PassTimer(hipStream_t s_) : on(getenv("YF_TRAIN_TIMING") != nullptr), s(s_) { tick("start"); }
+    void tick(const char* what, const char* layer = "")
+    {
+        if (!on) return;
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(e, s);
+        ev.push_back(e);
+        label.push_back(std::string(what) + " " + layer);
+    }
+    void report(const char* pass)
+    {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        for (size_t i = 1; i < ev.size(); ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[i - 1], ev[i]);
+            fprintf(stderr, "[yf_train_timing] %s %-28s %9.1f us\n", pass, label[i].c_str(), ms * 1e3f);
+        }
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    }
+};
 
 }  // namespace
 
@@ -323,18 +356,21 @@ int yf_trainer_forward(yf_trainer t, const float* d_x, int N, const void* const*
     hipStream_t s = (hipStream_t)stream;
     auto P = [&](int i) { return static_cast<const float*>(d_params[i]); };
     int bn = 0;
+    PassTimer tm(s);
     for (int i = 0; i < kNumLayers; ++i) {
         const LayerSpec& S = kLayers[i];
         const TLayer& L = t->L[i];
         const float* x = L.in == -1 ? d_x : L.in == -2 ? w.act + t->cat * N : w.act + t->L[L.in].y * N;
         if (S.kind == K_HEAD) {
             yf::launch_tconv_fwd(x, P(L.p0), P(L.p0 + 1), i == t->i_head4 ? d_head_large : d_head_small, N, L.Cin, L.Hin, L.Win, L.Cout, 1, 1, 0, s);
+            tm.tick("conv", S.name);
             continue;
         }
         float* z = w.act + L.z * N;
         float* y = w.act + L.y * N;
         if (S.kind == K_DECONV) yf::launch_tdeconv_fwd(x, P(L.p0), z, N, L.Cin, L.Hin, L.Win, L.Cout, s);
         else yf::launch_tconv_fwd(x, P(L.p0), nullptr, z, N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, s);
+        tm.tick("conv", S.name);
         float* rm = d_bn_buffers ? static_cast<float*>(d_bn_buffers[2 * bn]) : nullptr;
         float* rv = d_bn_buffers ? static_cast<float*>(d_bn_buffers[2 * bn + 1]) : nullptr;
         ++bn;
@@ -344,14 +380,17 @@ int yf_trainer_forward(yf_trainer t, const float* d_x, int N, const void* const*
             residual = R.in == -1 ? d_x : w.act + t->L[R.in].y * N;
         }
         yf::launch_tbn_fwd(z, P(L.p0 + 1), P(L.p0 + 2), rm, rv, w.stats + L.st, y, N, L.Cout, (long)L.Ho * L.Wo, S.relu, w.scratch, s, residual);
+        tm.tick("bn", S.name);
         if (i == t->i_deconv) {                                                 // torch.cat((conv4_2, deconv5_1), 1)        :209
             const TLayer& A = t->L[t->i_conv4_2];
             float* cat = w.act + t->cat * N;
             const long HW = (long)A.Ho * A.Wo;
             yf::launch_tslice(w.act + A.y * N, cat, N, A.Cout, HW, A.Cout, 0, A.Cout + L.Cout, 0, s);
             yf::launch_tslice(y, cat, N, L.Cout, HW, L.Cout, 0, A.Cout + L.Cout, A.Cout, s);
+            tm.tick("cat", S.name);
         }
     }
+    tm.report("fwd");
     HIP_OK(hipGetLastError());
     return YF_OK;
 }
@@ -372,6 +411,7 @@ int yf_trainer_backward(yf_trainer t, const float* d_x, const float* d_grad_head
     auto xin = [&](const TLayer& L) { return L.in == -1 ? d_x : L.in == -2 ? (const float*)(w.act + t->cat * N) : (const float*)(w.act + t->L[L.in].y * N); };
     // gradient buffers: `cur` holds the gradient flowing backwards, `skip` a block's output gradient until the block's input is reached
     int cur = 0, skip = -1;
+    PassTimer tm(s);
     auto other = [&](int a, int b, int c) { for (int i = 0; i < 4; ++i) if (i != a && i != b && i != c) return i; return -1; };
     // backward of one conv + BN (+ ReLU) unit: gradient of its output in gy -> parameter gradients, gradient of its input in w.g[ret]
     auto unit = [&](int i, const float* gy, bool need_dx, const float* addend = nullptr) {
@@ -381,13 +421,17 @@ int yf_trainer_backward(yf_trainer t, const float* d_x, const float* d_grad_head
         float* gz = w.g[iz];
         yf::launch_tbn_bwd(w.act + L.z * N, gy, w.stats + L.st, P(L.p0 + 1), P(L.p0 + 2), G(L.p0 + 1), G(L.p0 + 2), gz, N, L.Cout, (long)L.Ho * L.Wo,
                            S.relu, w.scratch, s);
+        tm.tick("bn", S.name);
         if (S.kind == K_DECONV) {
             yf::launch_tdeconv_bwd_weight(xin(L), gz, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, w.scratch, sb, s);
+            tm.tick("wgrad", S.name);
             if (need_dx) yf::launch_tdeconv_bwd_data(gz, P(L.p0), w.g[ix], N, L.Cin, L.Hin, L.Win, L.Cout, s);
         } else {
             yf::launch_tconv_bwd_weight(xin(L), gz, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, w.scratch, sb, s);
+            tm.tick("wgrad", S.name);
             if (need_dx) yf::launch_tconv_bwd_data(gz, P(L.p0), w.g[ix], N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, s, addend);
         }
+        tm.tick("dgrad", S.name);
         return ix;
     };
     auto head = [&](int i, const float* gy) {                                  // nn.Conv2d(C, 24, 1) with bias
@@ -396,6 +440,7 @@ int yf_trainer_backward(yf_trainer t, const float* d_x, const float* d_grad_head
         yf::launch_tconv_bwd_weight(xin(L), gy, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, 1, 1, 0, w.scratch, sb, s);
         yf::launch_tchan_sum(gy, G(L.p0 + 1), N, L.Cout, (long)L.Hin * L.Win, s);
         yf::launch_tconv_bwd_data(gy, P(L.p0), w.g[ix], N, L.Cin, L.Hin, L.Win, L.Cout, 1, 1, 0, s);
+        tm.tick("head", kLayers[i].name);
         return ix;
     };
     // a run of layers hi .. lo (inclusive), backwards; the gradient of layer hi's output is in w.g[cur] on entry, the gradient of layer
@@ -429,6 +474,7 @@ int yf_trainer_backward(yf_trainer t, const float* d_x, const float* d_grad_head
     run_back(t->i_conv5_2, t->i_conv4_3, true);                                  // conv5_2 .. conv4_3             :191-200
     yf::launch_tadd(w.g[cur], w.ga2, w.g[cur], (long)N * t->ga2, s);
     run_back(t->i_conv4_2, 0, false);                                            // conv4_2 .. conv0; the images need no gradient
+    tm.report("bwd");
     HIP_OK(hipGetLastError());
     return YF_OK;
 }

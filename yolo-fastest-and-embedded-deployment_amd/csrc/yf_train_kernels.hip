@@ -153,6 +153,82 @@ __global__ void __launch_bounds__(256) tpw_mfma_kernel(const float* __restrict__
     }
 }
 
+// The same GEMM for maps with many pixels, built for bandwidth: every lane loads float4 = 4 consecutive pixels of ONE k-row (a wave's
+// load instruction covers 4 rows x 256 B), and MFMA e of a k-step takes element e -- column lr of accumulator e is pixel 4 lr + e, so
+// the lane ends up with 4 consecutive pixels of each of its 4 output rows and stores float4 too.  One wave = MT 16-channel tiles x 64
+// pixels (the B fragments are loaded once for all MT tiles); the 4 waves of a workgroup sit on 4 consecutive pixel tiles; m-groups of
+// one pixel block are neighbours in the XCD-contiguous order.  Needs HW % 4 == 0 and K % 4 == 0 (every layer of this network).
+// Two k-steps per trip with the loads up front.
+template <int MT>
+__global__ void __launch_bounds__(256) tpw4_mfma_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ bias,
+                                                        const float* __restrict__ addend, float* __restrict__ y, long Q, long HW, int M, int K,
+                                                        long sm, long sk, int mgroups)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
+    const unsigned lb = (unsigned)xcd_tile(blockIdx.x, gridDim.x);
+    const int m0 = (int)(lb % (unsigned)mgroups) * (16 * MT);
+    const long q0 = ((long)(lb / (unsigned)mgroups) * 4 + wave) * 64;
+    if (q0 >= Q) return;
+    long q = q0 + 4 * lr;
+    const bool qv = q < Q;
+    if (!qv) q = Q - 4;
+    const long n = q / HW, i = q - n * HW;
+    const float* xp = x + (n * K + lk) * HW + i;          // + k0 * HW
+    const float* ap[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = m0 + 16 * t + lr;
+        ap[t] = a + (long)(m < M ? m : M - 1) * sm + (long)lk * sk;
+    }
+    f32x4_t acc[MT][4];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto step = [&](const float4& b, const float (&av)[MT]) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], b.x, acc[t][0], 0, 0, 0);
+            acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], b.y, acc[t][1], 0, 0, 0);
+            acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], b.z, acc[t][2], 0, 0, 0);
+            acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], b.w, acc[t][3], 0, 0, 0);
+        }
+    };
+    int k0 = 0;
+    for (; k0 + 8 <= K; k0 += 8) {
+        const float4 b0 = *reinterpret_cast<const float4*>(xp + (long)k0 * HW);
+        const float4 b1 = *reinterpret_cast<const float4*>(xp + (long)(k0 + 4) * HW);
+        float a0[MT], a1[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) { a0[t] = ap[t][(long)k0 * sk]; a1[t] = ap[t][(long)(k0 + 4) * sk]; }
+        step(b0, a0);
+        step(b1, a1);
+    }
+    if (k0 < K) {
+        const float4 b0 = *reinterpret_cast<const float4*>(xp + (long)k0 * HW);
+        float a0[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a0[t] = ap[t][(long)k0 * sk];
+        step(b0, a0);
+    }
+    if (!qv) return;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * t + 4 * lk + r;
+            if (m >= M) continue;
+            const long o = (n * M + m) * HW + i;
+            const float bv = bias ? bias[m] : 0.f;
+            float4 v = make_float4(acc[t][0][r] + bv, acc[t][1][r] + bv, acc[t][2][r] + bv, acc[t][3][r] + bv);
+            if (addend) {                                           // the skip gradient of a residual block (saves an add pass)
+                const float4 ad = *reinterpret_cast<const float4*>(addend + o);
+                v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+            }
+            *reinterpret_cast<float4*>(y + o) = v;
+        }
+}
+
 // dense conv forward for k > 1 (conv0, conv1_9) on the matrix pipe: the same GEMM with the B operand gathered (im2col on the fly):
 // k-index r = (ci, ky, kx); A = weight [Cout][Cin k k] as stored.  One wave = 16 output channels x 64 output pixels.
 template <int KS>
@@ -216,12 +292,15 @@ __global__ void __launch_bounds__(256) tconv_im2col_mfma_kernel(const float* __r
 // X[ci][p] dY[co][2 iy + a][2 ix + b].
 // Slice s writes its tile into dw + s * part_stride (a slab of the scratch; tsum_partials_kernel adds the slabs in order): device-scope
 // float atomics on this multi-XCD part are executed memory-side and serialise per address -- 100 slices on one tile cost more than the GEMM.
-template <int KS>
-__global__ void __launch_bounds__(64) tconv_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
-                                                              int N, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride, long q_per,
-                                                              long part_stride)
+// NW waves per workgroup share a slice (32-pixel trips dealt round-robin) and add their tiles through LDS in wave order: the layers with
+// the most pixels have ONE tile, and 1024 single-wave workgroups (the slab limit) leave a CU with 4 waves = 8 KB of loads in flight.
+template <int KS, int NW>
+__global__ void __launch_bounds__(64 * NW) tconv_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                                                   int N, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride, long q_per,
+                                                                   long part_stride)
 {
-    const int lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
+    const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+    const int wv = NW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     constexpr int KK = KS * KS, PAD = (KS - 1) / 2;
     const int R = Cin * KK;
     // 1-D grid in XCD-contiguous order, tiles fastest: the waves of one pixel slice (they all read the same rows of dY and X) share an L2
@@ -283,8 +362,8 @@ __global__ void __launch_bounds__(64) tconv_wgrad_mfma_kernel(const float* __res
             for (int t = 0; t < 4; ++t)
                 if (t < ntu) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&av)[e], ((const float*)&bv[t])[e], acc[t], 0, 0, 0);
     };
-    long q0 = qb;
-    for (; q0 + 16 < qe; q0 += 32) {                                  // two steps per trip: ten float4 loads in flight per lane
+    long q0 = qb + 32L * wv;
+    for (; q0 + 16 < qe; q0 += 32L * NW) {                            // two steps per trip: ten float4 loads in flight per lane
         float4 a0, a1, b0[4], b1[4];
         load(q0, a0, b0);
         load(q0 + 16, a1, b1);
@@ -295,6 +374,19 @@ __global__ void __launch_bounds__(64) tconv_wgrad_mfma_kernel(const float* __res
         float4 a0, b0[4];
         load(q0, a0, b0);
         mac(a0, b0);
+    }
+    if constexpr (NW > 1) {
+        __shared__ f32x4_t red[NW - 1][4][64];
+        if (wv > 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) red[wv - 1][t][lane] = acc[t];
+        }
+        __syncthreads();
+        if (wv > 0) return;
+#pragma unroll
+        for (int w = 0; w < NW - 1; ++w)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] += red[w][t][lane];
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -482,6 +574,124 @@ __global__ void tdw_conv_kernel(const float* __restrict__ x, const float* __rest
     *reinterpret_cast<float4*>(y + ((long)plane * Ho + oy) * Wo + ox0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
+// ---- stride-1 depthwise convolution for the large maps, built for bandwidth: a thread owns 4 columns x R rows of the output and walks
+// the R + KS - 1 input rows once, ONE aligned float4 per row; the PAD columns either side come from the neighbouring lanes (the quads
+// ox0 -+ 4 of the same row are lanes -+ 1: a wave is a run of consecutive quads), by global loads only at the wave's two ends.
+// (tdw_conv_kernel: 3 float4 loads per input row and output row, 9 per output quad -- the texture path, not HBM, was its limit.)
+// No lane leaves before the last cross-lane exchange; threads past the plane compute on clamped addresses and store nothing. ----
+template <int PAD>
+__device__ __forceinline__ void tdw_row_window(const float* __restrict__ xr, bool row_ok, int ox0, int W, int lane, float (&win)[4 + 2 * PAD])
+{
+    float4 c4 = *reinterpret_cast<const float4*>(xr + ox0);
+    if (!row_ok) c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    win[PAD] = c4.x; win[PAD + 1] = c4.y; win[PAD + 2] = c4.z; win[PAD + 3] = c4.w;
+#pragma unroll
+    for (int j = 0; j < PAD; ++j) {
+        // element ox0 - PAD + j = component 4 - PAD + j of the quad before; element ox0 + 4 + j = component j of the quad after
+        float l = __shfl_up(win[PAD + 4 - PAD + j], 1), r = __shfl_down(win[PAD + j], 1);
+        if (lane == 0) l = (row_ok && ox0 > 0) ? xr[ox0 - PAD + j] : 0.f;
+        if (lane == 63) r = (row_ok && ox0 + 4 < W) ? xr[ox0 + 4 + j] : 0.f;
+        win[j] = ox0 > 0 ? l : 0.f;
+        win[PAD + 4 + j] = ox0 + 4 < W ? r : 0.f;
+    }
+}
+
+template <int KS, bool FLIP, int R>
+__global__ void __launch_bounds__(256) tdw_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int C, int H, int W)
+{
+    constexpr int KK = KS * KS, PAD = (KS - 1) / 2;
+    const int plane = blockIdx.x, c = plane % C, lane = threadIdx.x & 63;
+    const int per_row = W / 4, count = (H / R) * per_row;
+    const int t = blockIdx.y * 256 + threadIdx.x, tc = t < count ? t : count - 1;
+    const int rb = tc / per_row, ox0 = (tc - rb * per_row) * 4, oy0 = rb * R;
+    const float* xp = x + (long)plane * H * W;
+    float wk[KK];
+#pragma unroll
+    for (int i = 0; i < KK; ++i) wk[i] = w[(long)c * KK + (FLIP ? KK - 1 - i : i)];
+    float acc[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[r][o] = 0.f;
+#pragma unroll
+    for (int j = 0; j < R + 2 * PAD; ++j) {
+        const int iy = oy0 - PAD + j;
+        const bool ok = iy >= 0 && iy < H;
+        float win[4 + 2 * PAD];
+        tdw_row_window<PAD>(xp + (long)(ok ? iy : 0) * W, ok, ox0, W, lane, win);
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            const int r = j - ky;                                   // input row j is tap row ky of output row j - ky
+            if (r < 0 || r >= R) continue;
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[r][o] = fmaf(win[o + kx], wk[ky * KS + kx], acc[r][o]);
+        }
+    }
+    if (t >= count) return;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        *reinterpret_cast<float4*>(y + ((long)plane * H + oy0 + r) * W + ox0) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+}
+
+// the weight gradient of the same convolutions, same access pattern: per trip a thread takes 4 columns x R rows of dY (R float4) and the
+// R + KS - 1 input rows (one float4 each + the lane exchange), KS*KS sums in registers; grid (chunks, C), a workgroup's trips stride over
+// the (frame, row block, quad) list with a wave-uniform trip count.
+template <int KS, int R>
+__global__ void __launch_bounds__(256) tdw_wgrad_rows_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, int N,
+                                                             int C, int H, int W, long part_stride)
+{
+    constexpr int KK = KS * KS, PAD = (KS - 1) / 2;
+    __shared__ float red[4][KK];
+    const int c = blockIdx.y, lane = threadIdx.x & 63;
+    const int per_row = W / 4, per_plane = (H / R) * per_row;
+    const long total = (long)N * per_plane;
+    float acc[KK];
+#pragma unroll
+    for (int i = 0; i < KK; ++i) acc[i] = 0.f;
+    for (long base = (long)blockIdx.x * 256; base < total; base += (long)gridDim.x * 256) {
+        const long g = base + threadIdx.x;
+        const bool gv = g < total;
+        const long gc = gv ? g : total - 1;
+        const long n = gc / per_plane;
+        const int t = (int)(gc - n * per_plane), rb = t / per_row, ox0 = (t - rb * per_row) * 4, oy0 = rb * R;
+        const float* xp = x + (n * C + c) * (long)H * W;
+        const float* gp = dy + (n * C + c) * (long)H * W + (long)oy0 * W + ox0;
+        float4 g4[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            g4[r] = *reinterpret_cast<const float4*>(gp + (long)r * W);
+            if (!gv) g4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < R + 2 * PAD; ++j) {
+            const int iy = oy0 - PAD + j;
+            const bool ok = iy >= 0 && iy < H;
+            float win[4 + 2 * PAD];
+            tdw_row_window<PAD>(xp + (long)(ok ? iy : 0) * W, ok, ox0, W, lane, win);
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                const int r = j - ky;
+                if (r < 0 || r >= R) continue;
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) acc[ky * KS + kx] = fmaf(((const float*)&g4[r])[o], win[o + kx], acc[ky * KS + kx]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < KK; ++i) {
+        float v = acc[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if (lane == 0) red[threadIdx.x >> 6][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < KK)
+        dw[(long)blockIdx.x * part_stride + (long)c * KK + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 // backward-data of the depthwise 3x3 stride-2 pad-1 convolution: one thread = the 2x2 input block (2a.., 2b..), see tconv3s2_bwd_data_kernel
 __global__ void tdw3s2_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int C, int Ho, int Wo)
 {
@@ -499,9 +709,18 @@ __global__ void tdw3s2_bwd_data_kernel(const float* __restrict__ dy, const float
     *reinterpret_cast<float2*>(o + W) = make_float2(fmaf(d00, k[7], d10 * k[1]), fmaf(d00, k[8], fmaf(d01, k[6], fmaf(d10, k[2], d11 * k[0]))));
 }
 
+static const bool tdw_rows_off = getenv("YF_TDW_ROWS_OFF") != nullptr;
 template <int KS, int S, bool FLIP>
 static void launch_tdw_conv(const float* x, const float* w, float* y, int N, int C, int H, int W, int Ho, int Wo, hipStream_t s)
 {
+    if constexpr (S == 1) {
+        // large maps: 4 rows per thread (see tdw_rows_kernel); the plane must still give a workgroup something to do
+        if (!tdw_rows_off && H % 4 == 0 && (H / 4) * (W / 4) >= 64) {
+            const int count = (H / 4) * (W / 4);
+            hipLaunchKernelGGL((tdw_rows_kernel<KS, FLIP, 4>), dim3(N * C, (count + 255) / 256), dim3(256), 0, s, x, w, y, C, H, W);
+            return;
+        }
+    }
     const int threads = Ho * (Wo / 4), bs = threads <= 64 ? 64 : 256;
     hipLaunchKernelGGL((tdw_conv_kernel<KS, S, FLIP>), dim3(N * C, (threads + bs - 1) / bs), dim3(bs), 0, s, x, w, y, C, H, W, Ho, Wo);
 }
@@ -994,6 +1213,15 @@ static void launch_tpw_gemm(const float* x, const float* a, const float* bias, c
     const int wm = tpw_waves_m(M), wq = 4 / wm;
     const unsigned my = (unsigned)((M + 16 * wm - 1) / (16 * wm));
     const long b4 = (Q + 64L * wq - 1) / (64L * wq), b1 = (Q + 16L * wq - 1) / (16L * wq);     // workgroups along the pixels, NT = 4 / 1
+    static const bool old_only = getenv("YF_TPW_OLD") != nullptr;
+    const int tiles = (M + 15) / 16, mgroups = (tiles + 3) / 4, mt = (tiles + mgroups - 1) / mgroups;
+    const long wg = (Q + 255) / 256 * mgroups;
+    if (!old_only && wg >= 512 && HW % 4 == 0 && K % 4 == 0 && Q % 4 == 0) {
+#define YF_PW4(MT_) hipLaunchKernelGGL(tpw4_mfma_kernel<MT_>, dim3((unsigned)wg), dim3(256), 0, s, x, a, bias, addend, y, Q, HW, M, K, sm, sk, mgroups)
+        if (mt == 1) YF_PW4(1); else if (mt == 2) YF_PW4(2); else if (mt == 3) YF_PW4(3); else YF_PW4(4);
+#undef YF_PW4
+        return;
+    }
     if (b4 * my >= 512)
         hipLaunchKernelGGL(tpw_mfma_kernel<4>, dim3((unsigned)(b4 * my)), dim3(256), 0, s, x, a, bias, addend, y, Q, HW, M, K, sm, sk);
     else
@@ -1058,6 +1286,16 @@ void launch_tconv_bwd_data(const float* dy, const float* w, float* dx, int N, in
     }
     hipLaunchKernelGGL(tconv_bwd_data_kernel, dim3(nblk((long)N * Cin * H * W)), dim3(256), 0, s, dy, w, dx, N, Cin, H, W, Cout, Ho, Wo, k, stride, depthwise);
 }
+// waves per workgroup of the weight-gradient GEMM: fill the chip (>= 16 waves per CU) when the slab limit keeps the grid small and a
+// slice is long enough to deal out
+static inline int twgrad_waves(long workgroups, long q_per)
+{
+    static const int forced = getenv("YF_WGRAD_NW") ? atoi(getenv("YF_WGRAD_NW")) : 0;
+    if (forced == 1 || forced == 4 || forced == 8) return forced;
+    if (workgroups * 8 <= 8192 && q_per >= 8 * 64) return 8;
+    if (workgroups * 4 <= 8192 && q_per >= 4 * 64) return 4;
+    return 1;
+}
 // the slabs of the split reductions: nsplit <= what fits into the scratch
 static inline void tsum_partials(const float* part, long nsplit, long nw, float* dw, hipStream_t s)
 {
@@ -1083,10 +1321,11 @@ void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, 
         nsplit = (P + q_per - 1) / q_per;
         float* out = nsplit > 1 ? (float*)scratch : dw;
         const dim3 grid((unsigned)(nsplit * tiles));
-        if (k == 1)
-            hipLaunchKernelGGL(tconv_wgrad_mfma_kernel<1>, grid, dim3(64), 0, s, x, dy, out, N, Cin, H, W, Cout, Ho, Wo, stride, q_per, nw);
-        else
-            hipLaunchKernelGGL(tconv_wgrad_mfma_kernel<3>, grid, dim3(64), 0, s, x, dy, out, N, Cin, H, W, Cout, Ho, Wo, stride, q_per, nw);
+        const int nwv = twgrad_waves(nsplit * tiles, q_per);
+#define YF_WG(KS_, NW_) hipLaunchKernelGGL((tconv_wgrad_mfma_kernel<KS_, NW_>), grid, dim3(64 * NW_), 0, s, x, dy, out, N, Cin, H, W, Cout, Ho, Wo, stride, q_per, nw)
+        if (k == 1) { if (nwv == 8) YF_WG(1, 8); else if (nwv == 4) YF_WG(1, 4); else YF_WG(1, 1); }
+        else { if (nwv == 8) YF_WG(3, 8); else if (nwv == 4) YF_WG(3, 4); else YF_WG(3, 1); }
+#undef YF_WG
         if (nsplit > 1) tsum_partials(out, nsplit, nw, dw, s);
         return;
     }
@@ -1096,6 +1335,12 @@ void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, 
         if (chunks > fit) chunks = fit < 1 ? 1 : fit;
         float* out = chunks > 1 ? (float*)scratch : dw;
         const dim3 grid((unsigned)chunks, Cout);
+        if (!tdw_rows_off && stride == 1 && W % 4 == 0 && H % 4 == 0 && (long)N * (H / 4) * (W / 4) >= 256 * chunks) {
+            if (k == 3) hipLaunchKernelGGL((tdw_wgrad_rows_kernel<3, 4>), grid, dim3(256), 0, s, x, dy, out, N, Cout, H, W, nw);
+            else hipLaunchKernelGGL((tdw_wgrad_rows_kernel<5, 4>), grid, dim3(256), 0, s, x, dy, out, N, Cout, H, W, nw);
+            if (chunks > 1) tsum_partials(out, chunks, nw, dw, s);
+            return;
+        }
         if (k == 3)
             hipLaunchKernelGGL(tdw_wgrad_kernel<3>, grid, dim3(256), 0, s, x, dy, out, N, Cout, H, W, Ho, Wo, stride, nw);
         else
@@ -1150,8 +1395,11 @@ void launch_tdeconv_bwd_weight(const float* x, const float* dy, float* dw, int N
         q_per = (q_per + 15) / 16 * 16;
         nsplit = (P + q_per - 1) / q_per;
         float* out = nsplit > 1 ? (float*)scratch : dw;
-        hipLaunchKernelGGL(tconv_wgrad_mfma_kernel<2>, dim3((unsigned)(nsplit * tiles)), dim3(64), 0, s, dy, x, out, N, Cout, 2 * H,
-                           2 * W, Cin, H, W, 2, q_per, nw);
+        const int nwv = twgrad_waves(nsplit * tiles, q_per);
+        const dim3 grid((unsigned)(nsplit * tiles));
+        if (nwv == 8) hipLaunchKernelGGL((tconv_wgrad_mfma_kernel<2, 8>), grid, dim3(512), 0, s, dy, x, out, N, Cout, 2 * H, 2 * W, Cin, H, W, 2, q_per, nw);
+        else if (nwv == 4) hipLaunchKernelGGL((tconv_wgrad_mfma_kernel<2, 4>), grid, dim3(256), 0, s, dy, x, out, N, Cout, 2 * H, 2 * W, Cin, H, W, 2, q_per, nw);
+        else hipLaunchKernelGGL((tconv_wgrad_mfma_kernel<2, 1>), grid, dim3(64), 0, s, dy, x, out, N, Cout, 2 * H, 2 * W, Cin, H, W, 2, q_per, nw);
         if (nsplit > 1) tsum_partials(out, nsplit, nw, dw, s);
         return;
     }
