@@ -185,6 +185,8 @@ int yf_train_unit_backward(int device, int deconv, const float *d_x, const float
                            int Cin, int H, int W, int Cout, int k, int stride, int depthwise, int relu, void *d_scratch, size_t scratch_bytes,
                            void *stream);
 int yf_train_channel_sum(int device, const float *d_dy, float *d_out, int N, int C, long HW, void *stream);                 /* bias gradient */
+/* the same sum spread over the chip for large N HW (partial sums in d_scratch, yf_train_scratch_bytes(); a second launch adds them in order) */
+int yf_train_channel_sum_split(int device, const float *d_dy, float *d_out, int N, int C, long HW, void *d_scratch, void *stream);
 int yf_train_add(int device, const float *d_a, const float *d_b, float *d_out, long total, void *stream);                   /* residual / grad sum */
 int yf_train_channel_slice(int device, const float *d_src, float *d_dst, int N, int C, long HW, int Cs, int sc0, int Cd, int dc0,
                            void *stream);                                                                                    /* torch.cat and back */

@@ -126,6 +126,10 @@ def test_large_map_kernels_match_torch(ops, dev, geom):
     ops.call("yf_train_conv_backward_weight", xd.data_ptr(), gyd.data_ptr(), gw2.data_ptr(), N, Cin, H, W, Cout, k, stride, dw, ops.scratch,
              ops.scratch_bytes)
     assert torch.equal(gw, gw2)                                   # fixed summation order
+    if not dw and k == 1:                                         # the split bias-gradient sum of the heads, at a size where it splits
+        gb = torch.full((Cout,), float("nan"), device=dev)
+        ops.call("yf_train_channel_sum_split", gyd.data_ptr(), gb.data_ptr(), N, Cout, H * W, ops.scratch)
+        _close(gb, torch.from_numpy(gy).double().sum((0, 2, 3)), 2e-6, "bias gradient, split")
 
 
 def test_conv_backward_weight_long_reduction(ops, dev):
@@ -494,9 +498,10 @@ def test_training_free_running_two_steps(yf, golden, dev, capsys):
 def test_training_network_against_the_fp64_oracle(yf, dev, seed, tol):
     """The composition (residual adds, the conv4_2 / conv5_2 branch points, deconv, torch.cat, both heads, the loss) on random weights
     and a small batch: our train-mode heads against oracle/backbone_oracle.py in float64, and our parameter gradients against the
-    oracle's backward of OUR head gradients.  Seed 1 is a case without a ReLU flip between our fp32 forward and the float64 one (the
-    forward kernels are deterministic, so it stays one): EVERY gradient tensor within 1e-3 of its largest element (measured 3.5e-4;
-    torch's own fp32 has a flip in this case and is off by 1e-1).  Seed 2 has one near-zero activation in conv4_1_4: 2e-2.
+    oracle's backward of OUR head gradients.  Every gradient element that no flipped ReLU decision of our fp32 forward can reach is
+    within 1e-3 of its tensor's largest element for seed 1 (measured 3.5e-4 when the forward has no flip at all -- round 2's kernels; a
+    forward with another summation order flips one decision in res5_5.conv2, and the tensors upstream of it then carry 3e-2 .. 2e-1, as
+    torch's own fp32 does: 1e-2 .. 1e-1).  Seed 2 has a near-zero activation in conv4_1_4: 2e-2.
     (tools/train_oracle_report.py prints the per-tensor table, ours and torch-fp32.)"""
     from oracle import backbone_oracle as bo
     from yolo_fastest_amd import validation as val
@@ -527,17 +532,41 @@ def test_training_network_against_the_fp64_oracle(yf, dev, seed, tol):
     loss.backward()
     sd = bo.training_state(sd0, torch.float64)
     keys = bo.parameter_keys(sd)
-    want = bo.forward(sd, x.double(), train=True)
+    pre = {}
+    want = bo.forward(sd, x.double(), train=True, pre=pre)
     for got, w in zip(pred, want):
         assert np.abs(got.detach().cpu().numpy() - w.detach().numpy()).max() <= 2e-4 * max(1.0, float(w.detach().abs().max()))
     g64 = torch.autograd.grad(list(want), [sd[k] for k in keys], [p.grad.cpu().double() for p in pred])
-    for (name, p), w in zip(m.named_parameters(), g64):
-        g, w = p.grad.cpu().numpy().astype(np.float64), w.numpy()
+    # ReLU decisions of OUR forward that differ from the float64 one (none for these seeds with some kernel generations, one with
+    # others: which side of zero a pre-activation at rounding level lands on depends on the summation order of the forward kernels).
+    # What a flip can reach (tests/flip_reach.py) only keeps the flip-level cap; everything else keeps `tol`.
+    import flip_reach as fr
+    from yolo_fastest_amd import training
+    saved = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}
+    with torch.no_grad():
+        _, _, tape = training.train_forward(m, x.to(dev))
+    m.load_state_dict(saved, strict=False)
+    flips = {}
+    for name, d in pre.items():
+        diff = (tape[name][2] > 0).cpu() != (d["z"] > 0)
+        if diff.any():
+            flips[name] = torch.nonzero(diff.any(0).any(-1).any(-1)).ravel().tolist()
+    names = [n for n, _ in m.named_parameters()]
+    masks = fr.reach_masks(flips, names, [tuple(p.shape) for p in m.parameters()])
+    n_clean = 0
+    for (name, p), w, mask in zip(m.named_parameters(), g64, masks):
+        g, w = p.grad.cpu().numpy().astype(np.float64).ravel(), w.numpy().ravel()
         scale = np.abs(w).max()
         if scale < 1e-9:                        # zero in exact arithmetic (see the step test)
             assert np.abs(g).max() <= 1e-4, name
             continue
-        assert np.abs(g - w).max() / scale <= tol, (name, np.abs(g - w).max() / scale)
+        err = np.abs(g - w) / scale
+        if (~mask).any():
+            n_clean += 1
+            assert err[~mask].max() <= tol, (name, err[~mask].max(), flips)
+        if mask.any():
+            assert err[mask].max() <= 2.0, (name, err[mask].max(), flips)      # a flipped channel's own gamma moves by O(1)
+    assert n_clean >= 10, (n_clean, flips)      # the flips (if any) leave at least the large head's private layers untouched
     # the running statistics moved like the module's buffers
     for k in ("conv0.1.running_mean", "res5_5.conv2.1.running_var", "conv4_1_5.1.running_var", "deconv5_1.1.running_mean"):
         assert np.allclose(m.state_dict()[k].cpu().numpy(), sd[k].numpy(), rtol=1e-5, atol=1e-7), k

@@ -72,6 +72,7 @@ _SIGS = {
                                               _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_int,
                                               _c.c_void_p]),
     "yf_train_channel_sum": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_long, _c.c_void_p]),
+    "yf_train_channel_sum_split": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_long, _c.c_void_p, _c.c_void_p]),
     "yf_train_add": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_long, _c.c_void_p]),
     "yf_train_channel_slice": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                           _c.c_void_p]),

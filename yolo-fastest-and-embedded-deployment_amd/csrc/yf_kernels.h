@@ -318,7 +318,7 @@ void launch_tbn_bwd(const float* x, const float* dy, const float* stats, const f
                     int N, int C, long HW, int relu, void* scratch, hipStream_t s);
 int launch_tadam_multi(int nt, float* const* p, const float* const* g, float* const* m, float* const* v, const long* sizes, double lr, double b1,
                        double b2, double eps, int step, void* d_table, void* h_table, int upload, hipStream_t s);
-void launch_tchan_sum(const float* dy, float* out, int N, int C, long HW, hipStream_t s);
+void launch_tchan_sum(const float* dy, float* out, int N, int C, long HW, hipStream_t s, void* scratch = nullptr /* >= 64 C doubles */);
 void launch_tadd(const float* a, const float* b, float* out, long total, hipStream_t s);
 void launch_tslice(const float* src, float* dst, int N, int C, long HW, int Cs, int sc0, int Cd, int dc0, hipStream_t s);
 void launch_tadam(float* p, const float* g, float* m, float* v, long total, double lr, double b1, double b2, double eps, int step, hipStream_t s);

@@ -231,6 +231,10 @@ int yf_train_channel_sum(int device, const float* d_dy, float* d_out, int N, int
 {
     YF_TOP(d_dy && d_out && N > 0 && C > 0 && HW > 0, yf::launch_tchan_sum(d_dy, d_out, N, C, HW, (hipStream_t)stream));
 }
+int yf_train_channel_sum_split(int device, const float* d_dy, float* d_out, int N, int C, long HW, void* d_scratch, void* stream)
+{
+    YF_TOP(d_dy && d_out && d_scratch && N > 0 && C > 0 && C <= 4096 && HW > 0, yf::launch_tchan_sum(d_dy, d_out, N, C, HW, (hipStream_t)stream, d_scratch));
+}
 int yf_train_add(int device, const float* d_a, const float* d_b, float* d_out, long total, void* stream)
 {
     YF_TOP(d_a && d_b && d_out && total > 0, yf::launch_tadd(d_a, d_b, d_out, total, (hipStream_t)stream));
@@ -438,7 +442,7 @@ int yf_trainer_backward(yf_trainer t, const float* d_x, const float* d_grad_head
         const TLayer& L = t->L[i];
         const int ix = other(cur, skip, -1);
         yf::launch_tconv_bwd_weight(xin(L), gy, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, 1, 1, 0, w.scratch, sb, s);
-        yf::launch_tchan_sum(gy, G(L.p0 + 1), N, L.Cout, (long)L.Hin * L.Win, s);
+        yf::launch_tchan_sum(gy, G(L.p0 + 1), N, L.Cout, (long)L.Hin * L.Win, s, w.scratch);
         yf::launch_tconv_bwd_data(gy, P(L.p0), w.g[ix], N, L.Cin, L.Hin, L.Win, L.Cout, 1, 1, 0, s);
         tm.tick("head", kLayers[i].name);
         return ix;

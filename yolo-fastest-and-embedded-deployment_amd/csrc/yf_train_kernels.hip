@@ -159,10 +159,12 @@ __global__ void __launch_bounds__(256) tpw_mfma_kernel(const float* __restrict__
 // pixels (the B fragments are loaded once for all MT tiles); the 4 waves of a workgroup sit on 4 consecutive pixel tiles; m-groups of
 // one pixel block are neighbours in the XCD-contiguous order.  Needs HW % 4 == 0 and K % 4 == 0 (every layer of this network).
 // Two k-steps per trip with the loads up front.
-template <int MT>
+// DECONV: the ConvTranspose2d(2, 2) forward is this GEMM with M = (co, a, b) rows (A = the weight [Cin][Cout 2 2] read by columns) and a
+// scattering epilogue: the lane's 4 rows are the 2x2 output block of ONE channel, for each of its 4 input pixels (Wd = input width).
+template <int MT, bool DECONV = false>
 __global__ void __launch_bounds__(256) tpw4_mfma_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ bias,
                                                         const float* __restrict__ addend, float* __restrict__ y, long Q, long HW, int M, int K,
-                                                        long sm, long sk, int mgroups)
+                                                        long sm, long sk, int mgroups, int Wd = 0)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
     const unsigned lb = (unsigned)xcd_tile(blockIdx.x, gridDim.x);
@@ -212,6 +214,23 @@ __global__ void __launch_bounds__(256) tpw4_mfma_kernel(const float* __restrict_
         step(b0, a0);
     }
     if (!qv) return;
+    if constexpr (DECONV) {
+        const int Cout = M / 4;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int m = m0 + 16 * t + 4 * lk;                     // rows m .. m + 3 = channel m / 4, (a, b) = 0 .. 3
+            if (m >= M) continue;
+            float* yc = y + (n * Cout + m / 4) * 4 * HW;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int iy = (int)((i + e) / Wd), ix = (int)(i + e - (long)iy * Wd);
+                float* o = yc + (long)(2 * iy) * (2 * Wd) + 2 * ix;
+                *reinterpret_cast<float2*>(o) = make_float2(acc[t][e][0], acc[t][e][1]);
+                *reinterpret_cast<float2*>(o + 2 * Wd) = make_float2(acc[t][e][2], acc[t][e][3]);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -227,6 +246,65 @@ __global__ void __launch_bounds__(256) tpw4_mfma_kernel(const float* __restrict_
             }
             *reinterpret_cast<float4*>(y + o) = v;
         }
+}
+
+// backward-data of the ConvTranspose2d(2, 2): dx[ci][p] = sum over k = (co, a, b) of w[ci][k] dY[co][2 iy + a][2 ix + b] -- the pointwise
+// GEMM again, lane (lk, lr) = tap (a, b) = lk of pixel lr, so a k-step is one channel of dY and the lane's operand address only
+// advances by a plane.  One wave = MT 16-channel tiles x 4 pixel tiles of 16 (the old gather kernel recomputed indices per element).
+template <int MT>
+__global__ void __launch_bounds__(256) tdeconv_bwd_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                                               long Q, int H, int W, int Cin, int Cout, int mgroups)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
+    const unsigned lb = (unsigned)xcd_tile(blockIdx.x, gridDim.x);
+    const int m0 = (int)(lb % (unsigned)mgroups) * (16 * MT);
+    const long q0 = ((long)(lb / (unsigned)mgroups) * 4 + wave) * 64, HW = (long)H * W;
+    if (q0 >= Q) return;
+    const float* bp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        long q = q0 + 16 * t + lr;
+        if (q > Q - 1) q = Q - 1;
+        const long n = q / HW, i = q - n * HW;
+        const int iy = (int)(i / W), ix = (int)(i - (long)iy * W);
+        bp[t] = dy + n * Cout * 4 * HW + (long)(2 * iy + (lk >> 1)) * (2 * W) + 2 * ix + (lk & 1);     // + co * 4 HW
+    }
+    const float* ap[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = m0 + 16 * t + lr;
+        ap[t] = w + (long)(m < Cin ? m : Cin - 1) * 4 * Cout + lk;                                  // + co * 4
+    }
+    f32x4_t acc[MT][4];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int co = 0; co < Cout; ++co) {
+        float b[4], av[MT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b[u] = bp[u][(long)co * 4 * HW];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) av[t] = ap[t][co * 4];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], b[u], acc[t][u], 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long q = q0 + 16 * u + lr;
+        if (q >= Q) continue;
+        const long n = q / HW, i = q - n * HW;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 16 * t + 4 * lk + r;
+                if (m < Cin) dx[(n * Cin + m) * HW + i] = acc[t][u][r];
+            }
+    }
 }
 
 // dense conv forward for k > 1 (conv0, conv1_9) on the matrix pipe: the same GEMM with the B operand gathered (im2col on the fly):
@@ -282,6 +360,110 @@ __global__ void __launch_bounds__(256) tconv_im2col_mfma_kernel(const float* __r
             if (m < M) y[(n * M + m) * HWo + i] = acc[t][r] + (bias ? bias[m] : 0.f);
         }
     }
+}
+
+// dense 3x3 stride-2 pad-1 convolution (conv1_9: 24 -> 24 on the 128x160 map, the most expensive layer of the iteration) on the matrix
+// pipe without a gather: k-index = (tap, 4 input channels), lane (lk, lr) = input channel ci0 + lk and a GROUP of 4 consecutive output
+// pixels; per (ci0, ky) the lane loads the 9 input columns 8 ox4 - 1 .. 8 ox4 + 7 of its row as two aligned float4 and one scalar, and
+// MFMA (kx, e) takes column 2 e + kx - 1 -- column lr of accumulator e is output pixel 4 lr + e, stored as float4 (cf. tpw4_mfma_kernel).
+// Needs Cin % 4 == 0, H even, W % 8 == 0.  One wave = MT 16-channel tiles x 64 output pixels.
+template <int MT>
+__global__ void __launch_bounds__(256) tconv3s2_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ y, int N, int Cin, int H, int W, int M)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
+    const int Ho = H / 2, Wo = W / 2, per_row = Wo / 4;
+    const long G = (long)N * Ho * per_row;                              // groups of 4 output pixels
+    const long g0 = ((long)blockIdx.x * 4 + wave) * 16;
+    if (g0 >= G) return;
+    long g = g0 + lr;
+    const bool gv = g < G;
+    if (!gv) g = G - 1;
+    const int ox4 = (int)(g % per_row), oy = (int)((g / per_row) % Ho), n = (int)(g / ((long)per_row * Ho));
+    const float* xp = x + ((long)n * Cin + lk) * H * W + 8 * ox4;          // + ci0 H W + iy W
+    const float* wp[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = 16 * t + lr;
+        wp[t] = w + ((long)(m < M ? m : M - 1) * Cin + lk) * 9;          // + ci0 * 9 + ky * 3 + kx
+    }
+    f32x4_t acc[MT][4];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int ci0 = 0; ci0 < Cin; ci0 += 4) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy + ky - 1;
+            const bool ok = iy >= 0;
+            const float* xr = xp + ((long)ci0 * H + (ok ? iy : 0)) * W;
+            float4 lo = *reinterpret_cast<const float4*>(xr), hi = *reinterpret_cast<const float4*>(xr + 4);
+            float m1 = xr[ox4 > 0 ? -1 : 0];
+            if (!ok) { lo = make_float4(0.f, 0.f, 0.f, 0.f); hi = lo; }
+            if (!ok || ox4 == 0) m1 = 0.f;
+            const float v[9] = {m1, lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};     // v[c + 1] = column 8 ox4 + c
+            float av[MT][3];
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) av[t][kx] = wp[t][ci0 * 9 + ky * 3 + kx];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) acc[t][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][kx], v[2 * e + kx], acc[t][e], 0, 0, 0);
+        }
+    }
+    if (!gv) return;
+    const long HWo = (long)Ho * Wo;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 16 * t + 4 * lk + r;
+            if (m >= M) continue;
+            const float bv = bias ? bias[m] : 0.f;
+            *reinterpret_cast<float4*>(y + ((long)n * M + m) * HWo + (long)oy * Wo + 4 * ox4) =
+                make_float4(acc[t][0][r] + bv, acc[t][1][r] + bv, acc[t][2][r] + bv, acc[t][3][r] + bv);
+        }
+}
+
+// conv0 (1 -> 8, 3x3 stride 2): nothing to multiply, 190 MB to move.  A thread = 4 consecutive output pixels x all CO channels from the
+// 3 x 9 input window (two aligned float4 + one scalar per row), CO float4 stores.
+template <int CO>
+__global__ void __launch_bounds__(256) tconv3s2_c1_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ y, int N, int H, int W, int M)
+{
+    const int Ho = H / 2, Wo = W / 2, per_row = Wo / 4;
+    const long G = (long)N * Ho * per_row, g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= G) return;
+    const int ox4 = (int)(g % per_row), oy = (int)((g / per_row) % Ho), n = (int)(g / ((long)per_row * Ho));
+    float acc[CO][4];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) { const float bv = (bias && c < M) ? bias[c] : 0.f; acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = bv; }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * oy + ky - 1;
+        if (iy < 0) continue;
+        const float* xr = x + ((long)n * H + iy) * W + 8 * ox4;
+        const float4 lo = *reinterpret_cast<const float4*>(xr), hi = *reinterpret_cast<const float4*>(xr + 4);
+        const float m1 = ox4 > 0 ? xr[-1] : 0.f;
+        const float v[9] = {m1, lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int c = 0; c < CO; ++c)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float wv = w[(c < M ? c : M - 1) * 9 + ky * 3 + kx];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[c][e] = fmaf(v[2 * e + kx], wv, acc[c][e]);
+            }
+    }
+    const long HWo = (long)Ho * Wo;
+#pragma unroll
+    for (int c = 0; c < CO; ++c)
+        if (c < M) *reinterpret_cast<float4*>(y + ((long)n * M + c) * HWo + (long)oy * Wo + 4 * ox4) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
 }
 
 // dense conv weight gradient on the matrix pipe: dW[co][r] = sum_q dY[co][q] Xcol[r][q], r = (ci, ky, kx), split over q.  One wave =
@@ -395,6 +577,130 @@ __global__ void __launch_bounds__(64 * NW) tconv_wgrad_mfma_kernel(const float* 
             const int co = c0 + lk * 4 + r, rr = r0 + 16 * t + lr;
             if (co < Cout && rr < R) dw[(long)slice * part_stride + (long)co * R + rr] = acc[t][r];
         }
+}
+
+// Weight gradient of the dense 3x3 stride-2 pad-1 convolution (conv1_9) as NINE GEMMs that share their operands, no gather:
+//   dW[co][ci][ky][kx] = sum over pixels of dY[co][p] X[ci][2 oy + ky - 1][2 ox + kx - 1]:   M = co, N = ci, K = pixels, one accumulator per tap.
+// Lane (lk, lr) of the A operand = channel co = lr, pixel GROUP lk (4 consecutive output pixels: one float4 of dY); of the B operand =
+// channel ci = lr, the same group: per tap row ky the 9 input columns 8 ox4 - 1 .. 8 ox4 + 7 (two aligned float4 + one scalar), of which
+// MFMA (ky, kx, e) takes column 2 e + kx - 1 against element e of dY (cf. tconv3s2_mfma_kernel).  A workgroup = 4 waves = the (co tile,
+// ci tile) pairs of a slice of the pixel groups (they read the same operands: L1 serves the second reader); a step = 4 groups = 36
+// MFMAs per wave for 10 loads, the next step's operands requested before the current step's MFMAs.  Cout, Cin <= 32; H even, W % 8 == 0.
+// Slice s writes its tiles into dw + s * part_stride.
+__global__ void __launch_bounds__(256) tconv3s2_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                                                  int N, int Cin, int H, int W, int Cout, long g_per, long part_stride)
+{
+    const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), c0 = (wv & 1) * 16, i0 = (wv >> 1) * 16;
+    if (c0 >= Cout || i0 >= Cin) return;
+    const int Ho = H / 2, Wo = W / 2, per_row = Wo / 4;
+    const long G = (long)N * Ho * per_row, gb = (long)blockIdx.x * g_per, ge = gb + g_per < G ? gb + g_per : G;
+    const int co = c0 + lr, ci = i0 + lr;
+    const bool cov = co < Cout, civ = ci < Cin;
+    const float* dyc = dy + (long)(cov ? co : Cout - 1) * Ho * Wo;
+    const float* xc = x + (long)(civ ? ci : Cin - 1) * H * W;
+    struct Frag { float4 a, lo[3], hi[3]; float m1[3]; };
+    auto load = [&](long g0, Frag& f) {
+        long g = g0 + lk;
+        const bool gv = g < ge;
+        if (!gv) g = gb;
+        const int ox4 = (int)(g % per_row), oy = (int)((g / per_row) % Ho);
+        const long n = g / ((long)per_row * Ho);
+        f.a = *reinterpret_cast<const float4*>(dyc + n * Cout * Ho * Wo + (long)oy * Wo + 4 * ox4);
+        if (!(gv && cov)) f.a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* xn = xc + n * Cin * H * W + 8 * ox4;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy + ky - 1;
+            const bool ok = iy >= 0;
+            const float* xr = xn + (long)(ok ? iy : 0) * W;
+            f.lo[ky] = *reinterpret_cast<const float4*>(xr);
+            f.hi[ky] = *reinterpret_cast<const float4*>(xr + 4);
+            f.m1[ky] = xr[ox4 > 0 ? -1 : 0];
+            if (!ok) { f.lo[ky] = make_float4(0.f, 0.f, 0.f, 0.f); f.hi[ky] = f.lo[ky]; }
+            if (!ok || ox4 == 0) f.m1[ky] = 0.f;
+        }
+    };
+    f32x4_t acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto mac = [&](const Frag& f) {
+        const float av[4] = {f.a.x, f.a.y, f.a.z, f.a.w};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float v[9] = {f.m1[ky], f.lo[ky].x, f.lo[ky].y, f.lo[ky].z, f.lo[ky].w, f.hi[ky].x, f.hi[ky].y, f.hi[ky].z, f.hi[ky].w};
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], v[2 * e + kx], acc[ky * 3 + kx], 0, 0, 0);
+        }
+    };
+    Frag cur, nxt;
+    load(gb, cur);
+    for (long g0 = gb; g0 < ge; g0 += 4) {
+        load(g0 + 4 < ge ? g0 + 4 : g0, nxt);
+        mac(cur);
+        cur = nxt;
+    }
+    // acc[tap][r] = dW[c0 + 4 lk + r][i0 + lr][tap]
+    if (!civ) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = c0 + 4 * lk + r;
+        if (m >= Cout) continue;
+        float* o = dw + (long)blockIdx.x * part_stride + ((long)m * Cin + ci) * 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) o[t] = acc[t][r];
+    }
+}
+
+// conv0's weight gradient (1 -> CO channels, 3x3 stride 2): 72 numbers out of 190 MB.  A thread walks groups of 4 output pixels: CO float4
+// of dY and the 3 x 9 input window per group, CO x 9 sums in registers; wave shuffle + LDS reduction, one slab per workgroup.
+template <int CO>
+__global__ void __launch_bounds__(256) tconv3s2_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                                                int N, int H, int W, int M, long part_stride)
+{
+    __shared__ float red[4][CO * 9];
+    const int Ho = H / 2, Wo = W / 2, per_row = Wo / 4;
+    const long G = (long)N * Ho * per_row, HWo = (long)Ho * Wo;
+    float acc[CO][9];
+#pragma unroll
+    for (int c = 0; c < CO; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < G; g += (long)gridDim.x * 256) {
+        const int ox4 = (int)(g % per_row), oy = (int)((g / per_row) % Ho);
+        const long n = g / ((long)per_row * Ho);
+        float4 d[CO];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) d[c] = c < M ? *reinterpret_cast<const float4*>(dy + (n * M + c) * HWo + (long)oy * Wo + 4 * ox4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy + ky - 1;
+            if (iy < 0) continue;
+            const float* xr = x + (n * H + iy) * W + 8 * ox4;
+            const float4 lo = *reinterpret_cast<const float4*>(xr), hi = *reinterpret_cast<const float4*>(xr + 4);
+            const float m1 = ox4 > 0 ? xr[-1] : 0.f;
+            const float v[9] = {m1, lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int c = 0; c < CO; ++c)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[c][ky * 3 + kx] = fmaf(((const float*)&d[c])[e], v[2 * e + kx], acc[c][ky * 3 + kx]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CO; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float v = acc[c][t];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c * 9 + t] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < M * 9)
+        dw[(long)blockIdx.x * part_stride + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 // depthwise weight gradient: dW[c][ky][kx] = sum_q dY[c][q] X[c][q shifted].  grid (chunks, C): every thread walks its output pixels,
@@ -906,6 +1212,27 @@ template <> struct tbn_vec<1> { typedef float type; };
 template <> struct tbn_vec<4> { typedef float4 type; };
 template <int V> __device__ __forceinline__ float tbn_at(const typename tbn_vec<V>::type& v, int j) { return ((const float*)&v)[j]; }
 
+// unit -> element mapping of the four kernels.  Per-frame units (256 V elements of ONE frame, the tail of a plane idle) suit the large
+// maps; FLAT (V = 4) numbers the float4 of a channel across the frames, so a 16x20 or 8x10 plane does not leave 40-70 % of a workgroup idle.
+template <int V, bool FLAT>
+struct TbnMap {
+    long per, total;                                                    // FLAT: float4 per plane, float4 per channel; else units per frame, -
+    __device__ TbnMap(int N, long HW) : per(FLAT ? HW / V : (HW + 256 * V - 1) / (256 * V)), total(FLAT ? (long)N * (HW / V) : 0) {}
+    __device__ long units(int N) const { return FLAT ? (total + 255) / 256 : (long)N * per; }
+    __device__ bool at(long u, long HW, long& n, long& i) const
+    {
+        if constexpr (FLAT) {
+            const long f = u * 256 + threadIdx.x;
+            n = f / per; i = (f - n * per) * V;
+            return f < total;
+        } else {
+            n = u / per; i = ((u - n * per) * 256 + threadIdx.x) * V;
+            return i < HW;
+        }
+    }
+};
+static inline long tbn_units(int N, long HW, int V, bool flat) { return flat ? ((long)N * (HW / V) + 255) / 256 : (long)N * ((HW + 256 * V - 1) / (256 * V)); }
+
 // y before the ReLU, in ONE fixed operation order: the backward recomputes it from z to get the ReLU mask (y > 0) without reading y
 __device__ __forceinline__ float tbn_affine(float x, float mean, float invstd, float gamma, float beta)
 {
@@ -936,16 +1263,17 @@ __device__ __forceinline__ void tbn_block_total(const double* __restrict__ part,
     s = tot[0]; t = tot[1];
 }
 
-template <int V>
+template <int V, bool FLAT = false>
 __global__ void __launch_bounds__(256) tbn_stats_kernel(const float* __restrict__ x, int N, int C, long HW, double* __restrict__ scratch)
 {
     typedef typename tbn_vec<V>::type vec;
     const int c = blockIdx.y, nchunk = gridDim.x;
-    const long upn = (HW + 256 * V - 1) / (256 * V), U = (long)N * upn;
+    const TbnMap<V, FLAT> map(N, HW);
+    const long U = map.units(N);
     double s = 0, ss = 0;
     for (long u = blockIdx.x; u < U; u += nchunk) {
-        const long n = u / upn, i = ((u - n * upn) * 256 + threadIdx.x) * V;
-        if (i < HW) {
+        long n, i;
+        if (map.at(u, HW, n, i)) {
             const vec v = *reinterpret_cast<const vec*>(x + (n * C + c) * HW + i);
 #pragma unroll
             for (int j = 0; j < V; ++j) { const double e = tbn_at<V>(v, j); s += e; ss += e * e; }
@@ -955,7 +1283,7 @@ __global__ void __launch_bounds__(256) tbn_stats_kernel(const float* __restrict_
 }
 
 // stats[c] = {mean, invstd}
-template <int V>
+template <int V, bool FLAT = false>
 __global__ void __launch_bounds__(256) tbn_apply_kernel(const float* __restrict__ x, const double* __restrict__ scratch, int nchunk,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
                                                         int N, int C, long HW, int relu, float eps, float momentum, float* __restrict__ stats,
@@ -979,10 +1307,11 @@ __global__ void __launch_bounds__(256) tbn_apply_kernel(const float* __restrict_
         }
     }
     const float g = gamma[c], b = beta[c];
-    const long upn = (HW + 256 * V - 1) / (256 * V), U = (long)N * upn;
+    const TbnMap<V, FLAT> map(N, HW);
+    const long U = map.units(N);
     for (long u = blockIdx.x; u < U; u += gridDim.x) {
-        const long n = u / upn, i = ((u - n * upn) * 256 + threadIdx.x) * V;
-        if (i >= HW) continue;
+        long n, i;
+        if (!map.at(u, HW, n, i)) continue;
         const long idx = (n * C + c) * HW + i;
         const vec xv = *reinterpret_cast<const vec*>(x + idx);
         vec o, rv = xv;
@@ -999,19 +1328,20 @@ __global__ void __launch_bounds__(256) tbn_apply_kernel(const float* __restrict_
 
 // backward: dy_eff = dy * (y > 0) with ReLU; {sum dy_eff, sum dy_eff * xhat} = (dbeta, dgamma).  The mask is recomputed from z
 // (tbn_affine, bit-identical to the forward's value): one tensor less to read in each of the two backward passes.
-template <int V>
+template <int V, bool FLAT = false>
 __global__ void __launch_bounds__(256) tbn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stats,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta, int N, int C, long HW,
                                                              int relu, double* __restrict__ scratch)
 {
     typedef typename tbn_vec<V>::type vec;
     const int c = blockIdx.y, nchunk = gridDim.x;
-    const long upn = (HW + 256 * V - 1) / (256 * V), U = (long)N * upn;
+    const TbnMap<V, FLAT> map(N, HW);
+    const long U = map.units(N);
     const float mean = stats[2 * c], invstd = stats[2 * c + 1], gm = gamma[c], bt = beta[c];
     double s = 0, sx = 0;
     for (long u = blockIdx.x; u < U; u += nchunk) {
-        const long n = u / upn, i = ((u - n * upn) * 256 + threadIdx.x) * V;
-        if (i < HW) {
+        long n, i;
+        if (map.at(u, HW, n, i)) {
             const long idx = (n * C + c) * HW + i;
             const vec gv = *reinterpret_cast<const vec*>(dy + idx), xv = *reinterpret_cast<const vec*>(x + idx);
 #pragma unroll
@@ -1027,7 +1357,7 @@ __global__ void __launch_bounds__(256) tbn_bwd_reduce_kernel(const float* __rest
 }
 
 // dx = gamma * invstd * (dy_eff - (dbeta + xhat * dgamma) / P)
-template <int V>
+template <int V, bool FLAT = false>
 __global__ void __launch_bounds__(256) tbn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stats,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const double* __restrict__ scratch, int nchunk, float* __restrict__ dgamma,
@@ -1040,10 +1370,11 @@ __global__ void __launch_bounds__(256) tbn_bwd_apply_kernel(const float* __restr
     const float db = (float)s, dg = (float)sx;
     if (blockIdx.x == 0 && threadIdx.x == 0) { dbeta[c] = db; dgamma[c] = dg; }
     const float fm = stats[2 * c], fi = stats[2 * c + 1], gm = gamma[c], bt = beta[c], gi = gm * fi, invP = 1.f / (float)((long)N * HW);
-    const long upn = (HW + 256 * V - 1) / (256 * V), U = (long)N * upn;
+    const TbnMap<V, FLAT> map(N, HW);
+    const long U = map.units(N);
     for (long u = blockIdx.x; u < U; u += gridDim.x) {
-        const long n = u / upn, i = ((u - n * upn) * 256 + threadIdx.x) * V;
-        if (i >= HW) continue;
+        long n, i;
+        if (!map.at(u, HW, n, i)) continue;
         const long idx = (n * C + c) * HW + i;
         const vec gv = *reinterpret_cast<const vec*>(dy + idx), xv = *reinterpret_cast<const vec*>(x + idx);
         vec o;
@@ -1156,6 +1487,32 @@ __global__ void __launch_bounds__(256) tchan_sum_kernel(const float* __restrict_
     if (threadIdx.x == 0) out[c] = (float)(r1[0] + r1[1] + r1[2] + r1[3]);
 }
 
+// the same sum split over chunks of the (frame, pixel) list: partial sums in double to the scratch, added in chunk order by a second launch
+__global__ void __launch_bounds__(256) tchan_sum_part_kernel(const float* __restrict__ dy, int N, int C, long HW, double* __restrict__ part)
+{
+    __shared__ double r1[4];
+    const int c = blockIdx.y, nchunk = gridDim.x;
+    const long hw4 = HW / 4, U = (long)N * hw4;                       // float4 units (HW % 4 == 0)
+    double s = 0;
+    for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < U; u += (long)nchunk * 256) {
+        const long n = u / hw4, i = (u - n * hw4) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(dy + (n * C + c) * HW + i);
+        s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) r1[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(long)c * nchunk + blockIdx.x] = r1[0] + r1[1] + r1[2] + r1[3];
+}
+__global__ void tchan_sum_final_kernel(const double* __restrict__ part, int nchunk, int C, float* __restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0;
+    for (int k = 0; k < nchunk; ++k) s += part[(long)c * nchunk + k];
+    out[c] = (float)s;
+}
+
 // out = a + b (residual add, gradient accumulation); out may alias a
 __global__ void __launch_bounds__(256) tadd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long total)
 {
@@ -1235,6 +1592,20 @@ void launch_tconv_fwd(const float* x, const float* w, const float* bias, float* 
         launch_tpw_gemm(x, w, bias, nullptr, y, (long)N * H * W, (long)H * W, Cout, Cin, (long)Cin, 1L, s);
         return;
     }
+    static const bool s2_off = getenv("YF_TCONV3S2_OFF") != nullptr;
+    if (!depthwise && k == 3 && stride == 2 && !s2_off && H % 2 == 0 && W % 8 == 0) {
+        const long G = (long)N * Ho * (Wo / 4);
+        if (Cin == 1 && Cout <= 8) {
+            hipLaunchKernelGGL(tconv3s2_c1_kernel<8>, dim3(nblk(G)), dim3(256), 0, s, x, w, bias, y, N, H, W, Cout);
+            return;
+        }
+        if (Cin % 4 == 0 && Cout <= 32) {
+            const dim3 grid((unsigned)((G + 63) / 64));
+            if (Cout <= 16) hipLaunchKernelGGL(tconv3s2_mfma_kernel<1>, grid, dim3(256), 0, s, x, w, bias, y, N, Cin, H, W, Cout);
+            else hipLaunchKernelGGL(tconv3s2_mfma_kernel<2>, grid, dim3(256), 0, s, x, w, bias, y, N, Cin, H, W, Cout);
+            return;
+        }
+    }
     if (!depthwise && k == 3) {
         hipLaunchKernelGGL(tconv_im2col_mfma_kernel<3>, dim3((unsigned)(((long)N * Ho * Wo + 63) / 64), (Cout + 63) / 64), dim3(256), 0, s, x, w, bias, y,
                            N, Cin, H, W, Ho, Wo, Cout, stride);
@@ -1309,6 +1680,31 @@ void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, 
     const int pad = (k - 1) / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     const long nw = (long)Cout * (depthwise ? 1 : Cin) * k * k, P = (long)N * Ho * Wo;
     const long fit = scratch ? (long)(scratch_bytes / ((size_t)nw * sizeof(float))) : 0;      // slabs that fit
+    static const bool s2_off = getenv("YF_TCONV3S2_OFF") != nullptr;
+    if (!depthwise && k == 3 && stride == 2 && !s2_off && H % 2 == 0 && W % 8 == 0 && fit >= 1) {
+        const long G = (long)N * Ho * (Wo / 4);
+        if (Cin == 1 && Cout <= 8 && G >= 4096) {
+            long chunks = G / 2048;                                     // >= 8 groups per thread
+            if (chunks > 1024) chunks = 1024;
+            if (chunks > fit) chunks = fit;
+            float* out = chunks > 1 ? (float*)scratch : dw;
+            hipLaunchKernelGGL(tconv3s2_c1_wgrad_kernel<8>, dim3((unsigned)chunks), dim3(256), 0, s, x, dy, out, N, H, W, Cout, nw);
+            if (chunks > 1) tsum_partials(out, chunks, nw, dw, s);
+            return;
+        }
+        if (Cin % 4 == 0 && Cin <= 32 && Cout <= 32 && G >= 2048) {
+            long nsplit = G / 32;                                       // >= 8 steps per wave
+            if (nsplit > 1024) nsplit = 1024;
+            if (nsplit > fit) nsplit = fit;
+            long g_per = (G + nsplit - 1) / nsplit;
+            g_per = (g_per + 3) / 4 * 4;
+            nsplit = (G + g_per - 1) / g_per;
+            float* out = nsplit > 1 ? (float*)scratch : dw;
+            hipLaunchKernelGGL(tconv3s2_wgrad_mfma_kernel, dim3((unsigned)nsplit), dim3(256), 0, s, x, dy, out, N, Cin, H, W, Cout, g_per, nw);
+            if (nsplit > 1) tsum_partials(out, nsplit, nw, dw, s);
+            return;
+        }
+    }
     // 4 consecutive output pixels per lane, in one frame
     if (!depthwise && (k == 3 || (k == 1 && stride == 1)) && ((long)Ho * Wo) % 4 == 0) {
         const int R = Cin * k * k, tiles = ((Cout + 15) / 16) * ((R + 63) / 64);
@@ -1367,12 +1763,32 @@ void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, 
 }
 void launch_tdeconv_fwd(const float* x, const float* w, float* y, int N, int Cin, int H, int W, int Cout, hipStream_t s)
 {
+    static const bool off = getenv("YF_TDECONV_OLD") != nullptr;
+    const long Q = (long)N * H * W, HW = (long)H * W;
+    if (!off && Q >= 4096 && HW % 4 == 0 && Cin % 4 == 0) {            // the GEMM form (tpw4_mfma_kernel<.., DECONV>): M = 4 Cout rows
+        const int M = 4 * Cout, tiles = (M + 15) / 16, mgroups = (tiles + 3) / 4, mt = (tiles + mgroups - 1) / mgroups;
+        const dim3 grid((unsigned)((Q + 255) / 256 * mgroups));
+#define YF_DC4(MT_) hipLaunchKernelGGL((tpw4_mfma_kernel<MT_, true>), grid, dim3(256), 0, s, x, w, (const float*)nullptr, (const float*)nullptr, y, Q, HW, M, Cin, 1L, (long)M, mgroups, W)
+        if (mt == 1) YF_DC4(1); else if (mt == 2) YF_DC4(2); else if (mt == 3) YF_DC4(3); else YF_DC4(4);
+#undef YF_DC4
+        return;
+    }
     hipLaunchKernelGGL(tdeconv_fwd_kernel, dim3(nblk((long)N * Cout * 4 * H * W)), dim3(256), 0, s, x, w, y, N, Cin, H, W, Cout);
 }
 void launch_tdeconv_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, hipStream_t s)
 {
     if ((long)N * H * W < 8192) {      // measured at 16 x 8 x 10 pixels: 25 us against 134 us for the GEMM form
         hipLaunchKernelGGL(tdeconv_bwd_data_kernel, dim3(nblk((long)N * Cin * H * W)), dim3(256), 0, s, dy, w, dx, N, Cin, H, W, Cout);
+        return;
+    }
+    static const bool off = getenv("YF_TDECONV_OLD") != nullptr;
+    if (!off) {
+        const long Q = (long)N * H * W;
+        const int tiles = (Cin + 15) / 16, mgroups = (tiles + 2) / 3, mt = (tiles + mgroups - 1) / mgroups;
+        const dim3 grid((unsigned)((Q + 255) / 256 * mgroups));
+#define YF_DB(MT_) hipLaunchKernelGGL(tdeconv_bwd_mfma_kernel<MT_>, grid, dim3(256), 0, s, dy, w, dx, Q, H, W, Cin, Cout, mgroups)
+        if (mt == 1) YF_DB(1); else if (mt == 2) YF_DB(2); else YF_DB(3);
+#undef YF_DB
         return;
     }
     // dx[ci][p] = sum over (co, a, b) of dY[co][2 iy + a][2 ix + b] w[ci][co][a][b]: a 2x2 stride-2 pad-0 convolution of dY with the weight
@@ -1410,16 +1826,16 @@ void launch_tdeconv_bwd_weight(const float* x, const float* dy, float* dw, int N
 }
 // one scratch for the split reductions of a stream: BatchNorm partial pairs (256 KB) or weight-gradient slabs (all of it)
 size_t train_scratch_bytes() { return (size_t)16 << 20; }
-static inline unsigned tbn_apply_blocks(int N, int C, long HW, int V)
+static inline unsigned tbn_apply_blocks(int N, int C, long HW, int V, bool flat)
 {
-    const long U = (long)N * ((HW + 256 * V - 1) / (256 * V));
+    const long U = tbn_units(N, HW, V, flat);
     long n = 8192 / C;
     if (n > U) n = U;
     return n < 1 ? 1u : (unsigned)n;
 }
-static inline int tbn_chunks(int N, int C, long HW, int V)
+static inline int tbn_chunks(int N, int C, long HW, int V, bool flat)
 {
-    const long U = (long)N * ((HW + 256 * V - 1) / (256 * V));
+    const long U = tbn_units(N, HW, V, flat);
     long n = 8192 / C;
     if (n > TBN_MAXCHUNK) n = TBN_MAXCHUNK;
     if (n > U) n = U;
@@ -1435,9 +1851,15 @@ void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float
                            running_var, residual);
         return;
     }
-    const int V = (HW % 4 == 0 && HW >= 1024) ? 4 : 1, nchunk = tbn_chunks(N, C, HW, V);
-    const dim3 g1(nchunk, C), g2(tbn_apply_blocks(N, C, HW, V), C);
-    if (V == 4) {
+    static const bool flat_off = getenv("YF_TBN_FLAT_OFF") != nullptr;
+    const bool flat = !flat_off && HW % 4 == 0 && HW % 1024 != 0;      // float4 numbered across the frames (small / ragged planes)
+    const int V = (flat || (HW % 4 == 0 && HW >= 1024)) ? 4 : 1, nchunk = tbn_chunks(N, C, HW, V, flat);
+    const dim3 g1(nchunk, C), g2(tbn_apply_blocks(N, C, HW, V, flat), C);
+    if (flat) {
+        hipLaunchKernelGGL((tbn_stats_kernel<4, true>), g1, dim3(256), 0, s, x, N, C, HW, (double*)scratch);
+        hipLaunchKernelGGL((tbn_apply_kernel<4, true>), g2, dim3(256), 0, s, x, (const double*)scratch, nchunk, gamma, beta, y, N, C, HW, relu, 1e-5f, 0.1f,
+                           stats, running_mean, running_var, residual);
+    } else if (V == 4) {
         hipLaunchKernelGGL(tbn_stats_kernel<4>, g1, dim3(256), 0, s, x, N, C, HW, (double*)scratch);
         hipLaunchKernelGGL(tbn_apply_kernel<4>, g2, dim3(256), 0, s, x, (const double*)scratch, nchunk, gamma, beta, y, N, C, HW, relu, 1e-5f, 0.1f,
                            stats, running_mean, running_var, residual);
@@ -1454,9 +1876,15 @@ void launch_tbn_bwd(const float* x, const float* dy, const float* stats, const f
         hipLaunchKernelGGL(tbn_bwd_small_kernel, dim3(C), dim3(1024), 0, s, x, dy, stats, gamma, beta, dgamma, dbeta, dx, N, C, (int)HW, relu);
         return;
     }
-    const int V = (HW % 4 == 0 && HW >= 1024) ? 4 : 1, nchunk = tbn_chunks(N, C, HW, V);
-    const dim3 g1(nchunk, C), g2(tbn_apply_blocks(N, C, HW, V), C);
-    if (V == 4) {
+    static const bool flat_off = getenv("YF_TBN_FLAT_OFF") != nullptr;
+    const bool flat = !flat_off && HW % 4 == 0 && HW % 1024 != 0;
+    const int V = (flat || (HW % 4 == 0 && HW >= 1024)) ? 4 : 1, nchunk = tbn_chunks(N, C, HW, V, flat);
+    const dim3 g1(nchunk, C), g2(tbn_apply_blocks(N, C, HW, V, flat), C);
+    if (flat) {
+        hipLaunchKernelGGL((tbn_bwd_reduce_kernel<4, true>), g1, dim3(256), 0, s, x, dy, stats, gamma, beta, N, C, HW, relu, (double*)scratch);
+        hipLaunchKernelGGL((tbn_bwd_apply_kernel<4, true>), g2, dim3(256), 0, s, x, dy, stats, gamma, beta, (const double*)scratch, nchunk, dgamma, dbeta,
+                           dx, N, C, HW, relu);
+    } else if (V == 4) {
         hipLaunchKernelGGL(tbn_bwd_reduce_kernel<4>, g1, dim3(256), 0, s, x, dy, stats, gamma, beta, N, C, HW, relu, (double*)scratch);
         hipLaunchKernelGGL(tbn_bwd_apply_kernel<4>, g2, dim3(256), 0, s, x, dy, stats, gamma, beta, (const double*)scratch, nchunk, dgamma, dbeta, dx, N,
                            C, HW, relu);
@@ -1466,8 +1894,16 @@ void launch_tbn_bwd(const float* x, const float* dy, const float* stats, const f
                            C, HW, relu);
     }
 }
-void launch_tchan_sum(const float* dy, float* out, int N, int C, long HW, hipStream_t s)
+void launch_tchan_sum(const float* dy, float* out, int N, int C, long HW, hipStream_t s, void* scratch)
 {
+    const long U = (long)N * HW / 4;
+    if (scratch && HW % 4 == 0 && U >= 16384) {                        // enough to spread over the chip: <= 64 chunks of >= 8 trips
+        int nchunk = (int)(U / 2048);
+        if (nchunk > 64) nchunk = 64;
+        hipLaunchKernelGGL(tchan_sum_part_kernel, dim3(nchunk, C), dim3(256), 0, s, dy, N, C, HW, (double*)scratch);
+        hipLaunchKernelGGL(tchan_sum_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, (const double*)scratch, nchunk, C, out);
+        return;
+    }
     hipLaunchKernelGGL(tchan_sum_kernel, dim3(C), dim3(256), 0, s, dy, N, C, HW, out);
 }
 void launch_tadd(const float* a, const float* b, float* out, long total, hipStream_t s)

@@ -168,7 +168,7 @@ def _head_backward(ops, conv, tape, name, gy, grads):
     gy = gy.contiguous()
     dw_, db, gx = torch.empty_like(conv.weight), ops.new(Cout), torch.empty_like(x)
     ops.call("yf_train_conv_backward_weight", x.data_ptr(), gy.data_ptr(), dw_.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0, ops.scratch, ops.scratch_bytes)
-    ops.call("yf_train_channel_sum", gy.data_ptr(), db.data_ptr(), N, Cout, H * W)
+    ops.call("yf_train_channel_sum_split", gy.data_ptr(), db.data_ptr(), N, Cout, H * W, ops.scratch)
     ops.call("yf_train_conv_backward_data", gy.data_ptr(), conv.weight.data_ptr(), gx.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0)
     grads[conv.weight], grads[conv.bias] = dw_, db
     return gx
