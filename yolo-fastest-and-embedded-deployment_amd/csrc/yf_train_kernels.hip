@@ -196,22 +196,24 @@ __global__ void __launch_bounds__(256) tpw4_mfma_kernel(const float* __restrict_
             acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], b.w, acc[t][3], 0, 0, 0);
         }
     };
-    int k0 = 0;
-    for (; k0 + 8 <= K; k0 += 8) {
-        const float4 b0 = *reinterpret_cast<const float4*>(xp + (long)k0 * HW);
-        const float4 b1 = *reinterpret_cast<const float4*>(xp + (long)(k0 + 4) * HW);
-        float a0[MT], a1[MT];
+    // UK k-steps per trip, all of a trip's loads requested before its first MFMA: a wave's time is (trips) x (one memory latency), and
+    // the small maps have too few waves per CU to hide it any other way (K = 224: 7 trips instead of 56 dependent ones)
+    constexpr int UK = MT <= 2 ? 8 : 6;
+    for (int k0 = 0; k0 < K; k0 += 4 * UK) {
+        float4 b[UK];
+        float av[UK][MT];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) { a0[t] = ap[t][(long)k0 * sk]; a1[t] = ap[t][(long)(k0 + 4) * sk]; }
-        step(b0, a0);
-        step(b1, a1);
-    }
-    if (k0 < K) {
-        const float4 b0 = *reinterpret_cast<const float4*>(xp + (long)k0 * HW);
-        float a0[MT];
+        for (int j = 0; j < UK; ++j) {
+            if (k0 + 4 * j >= K) break;                                  // wave-uniform
+            b[j] = *reinterpret_cast<const float4*>(xp + (long)(k0 + 4 * j) * HW);
 #pragma unroll
-        for (int t = 0; t < MT; ++t) a0[t] = ap[t][(long)k0 * sk];
-        step(b0, a0);
+            for (int t = 0; t < MT; ++t) av[j][t] = ap[t][(long)(k0 + 4 * j) * sk];
+        }
+#pragma unroll
+        for (int j = 0; j < UK; ++j) {
+            if (k0 + 4 * j >= K) break;
+            step(b[j], av[j]);
+        }
     }
     if (!qv) return;
     if constexpr (DECONV) {
@@ -1470,6 +1472,99 @@ __global__ void __launch_bounds__(1024) tbn_bwd_small_kernel(const float* __rest
     }
 }
 
+// The same for H*W % 4 == 0 and up to 4096 UPT elements per channel: a thread keeps its UPT float4 in registers between the statistics
+// and the elementwise pass, so z (and dy) are read ONCE -- at the reference's batch 16 this also takes the stride-8 layers (20480
+// elements per channel) from two launches each way to one.
+template <int UPT>
+__global__ void __launch_bounds__(1024) tbn_fwd_small4_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ y, int N, int C, int HW, int relu, float eps, float momentum,
+                                                              float* __restrict__ stats, float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var, const float* __restrict__ res)
+{
+    const int c = blockIdx.x, hw4 = HW / 4, P4 = N * hw4;
+    float4 v[UPT];
+    long idx[UPT];
+    double s = 0, ss = 0;
+#pragma unroll
+    for (int j = 0; j < UPT; ++j) {
+        const int f = threadIdx.x + j * 1024;
+        const int fc = f < P4 ? f : P4 - 1, n = fc / hw4;
+        idx[j] = ((long)n * C + c) * HW + (long)(fc - n * hw4) * 4;
+        v[j] = *reinterpret_cast<const float4*>(x + idx[j]);
+        if (f < P4) {
+            const double a = v[j].x, b = v[j].y, d = v[j].z, e = v[j].w;
+            s += (a + b) + (d + e); ss += (a * a + b * b) + (d * d + e * e);
+        }
+    }
+    tbn_block_total1024(s, ss);
+    const double Pd = (double)N * (double)HW, mean = s / Pd;
+    double var = ss / Pd - mean * mean;
+    if (var < 0) var = 0;
+    const float fm = (float)mean, fi = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) {
+        stats[2 * c] = fm;
+        stats[2 * c + 1] = fi;
+        if (running_mean) {
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * fm;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * Pd / (Pd > 1 ? Pd - 1 : 1));
+        }
+    }
+    const float g = gamma[c], b = beta[c];
+#pragma unroll
+    for (int j = 0; j < UPT; ++j) {
+        if (threadIdx.x + j * 1024 >= P4) continue;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = tbn_affine(((const float*)&v[j])[e], fm, fi, g, b);
+            if (relu) o[e] = fmaxf(o[e], 0.f);
+        }
+        if (res) {
+            const float4 r = *reinterpret_cast<const float4*>(res + idx[j]);
+            o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+        }
+        *reinterpret_cast<float4*>(y + idx[j]) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+template <int UPT>
+__global__ void __launch_bounds__(1024) tbn_bwd_small4_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stats,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dx, int N,
+                                                              int C, int HW, int relu)
+{
+    const int c = blockIdx.x, hw4 = HW / 4, P4 = N * hw4;
+    const float fm = stats[2 * c], fi = stats[2 * c + 1], gm = gamma[c], bt = beta[c];
+    float4 xv[UPT], gv[UPT];
+    long idx[UPT];
+    double s = 0, sx = 0;
+#pragma unroll
+    for (int j = 0; j < UPT; ++j) {
+        const int f = threadIdx.x + j * 1024;
+        const int fc = f < P4 ? f : P4 - 1, n = fc / hw4;
+        idx[j] = ((long)n * C + c) * HW + (long)(fc - n * hw4) * 4;
+        xv[j] = *reinterpret_cast<const float4*>(x + idx[j]);
+        gv[j] = *reinterpret_cast<const float4*>(dy + idx[j]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float& g = ((float*)&gv[j])[e];
+            const float xe = ((const float*)&xv[j])[e];
+            if (relu && !(tbn_affine(xe, fm, fi, gm, bt) > 0.f)) g = 0.f;
+            if (f < P4) { s += g; sx += (double)g * (double)((xe - fm) * fi); }
+        }
+    }
+    tbn_block_total1024(s, sx);
+    const float db = (float)s, dg = (float)sx, gi = gm * fi, invP = 1.f / (float)((long)N * HW);
+    if (threadIdx.x == 0) { dbeta[c] = db; dgamma[c] = dg; }
+#pragma unroll
+    for (int j = 0; j < UPT; ++j) {
+        if (threadIdx.x + j * 1024 >= P4) continue;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = gi * (((const float*)&gv[j])[e] - (db + (((const float*)&xv[j])[e] - fm) * fi * dg) * invP);
+        *reinterpret_cast<float4*>(dx + idx[j]) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // per-channel sum over N, H, W (bias gradient of the head convs)
 __global__ void __launch_bounds__(256) tchan_sum_kernel(const float* __restrict__ dy, int N, int C, long HW, float* __restrict__ out)
 {
@@ -1571,9 +1666,14 @@ static void launch_tpw_gemm(const float* x, const float* a, const float* bias, c
     const unsigned my = (unsigned)((M + 16 * wm - 1) / (16 * wm));
     const long b4 = (Q + 64L * wq - 1) / (64L * wq), b1 = (Q + 16L * wq - 1) / (16L * wq);     // workgroups along the pixels, NT = 4 / 1
     static const bool old_only = getenv("YF_TPW_OLD") != nullptr;
-    const int tiles = (M + 15) / 16, mgroups = (tiles + 3) / 4, mt = (tiles + mgroups - 1) / mgroups;
+    const int tiles = (M + 15) / 16;
+    int mgroups = (tiles + 3) / 4, mt = (tiles + mgroups - 1) / mgroups;
+    while (mt > 1 && (Q + 63) / 64 * mgroups < 512) {                  // few pixels: channel tiles on separate waves (the B re-reads hit L2)
+        mt = (mt + 1) / 2;
+        mgroups = (tiles + mt - 1) / mt;
+    }
     const long wg = (Q + 255) / 256 * mgroups;
-    if (!old_only && wg >= 512 && HW % 4 == 0 && K % 4 == 0 && Q % 4 == 0) {
+    if (!old_only && HW % 4 == 0 && K % 4 == 0 && Q % 4 == 0) {
 #define YF_PW4(MT_) hipLaunchKernelGGL(tpw4_mfma_kernel<MT_>, dim3((unsigned)wg), dim3(256), 0, s, x, a, bias, addend, y, Q, HW, M, K, sm, sk, mgroups)
         if (mt == 1) YF_PW4(1); else if (mt == 2) YF_PW4(2); else if (mt == 3) YF_PW4(3); else YF_PW4(4);
 #undef YF_PW4
@@ -1765,8 +1865,10 @@ void launch_tdeconv_fwd(const float* x, const float* w, float* y, int N, int Cin
 {
     static const bool off = getenv("YF_TDECONV_OLD") != nullptr;
     const long Q = (long)N * H * W, HW = (long)H * W;
-    if (!off && Q >= 4096 && HW % 4 == 0 && Cin % 4 == 0) {            // the GEMM form (tpw4_mfma_kernel<.., DECONV>): M = 4 Cout rows
-        const int M = 4 * Cout, tiles = (M + 15) / 16, mgroups = (tiles + 3) / 4, mt = (tiles + mgroups - 1) / mgroups;
+    if (!off && Q >= 256 && HW % 4 == 0 && Cin % 4 == 0) {             // the GEMM form (tpw4_mfma_kernel<.., DECONV>): M = 4 Cout rows
+        const int M = 4 * Cout, tiles = (M + 15) / 16;
+        int mgroups = (tiles + 3) / 4, mt = (tiles + mgroups - 1) / mgroups;
+        while (mt > 1 && (Q + 63) / 64 * mgroups < 512) { mt = (mt + 1) / 2; mgroups = (tiles + mt - 1) / mt; }
         const dim3 grid((unsigned)((Q + 255) / 256 * mgroups));
 #define YF_DC4(MT_) hipLaunchKernelGGL((tpw4_mfma_kernel<MT_, true>), grid, dim3(256), 0, s, x, w, (const float*)nullptr, (const float*)nullptr, y, Q, HW, M, Cin, 1L, (long)M, mgroups, W)
         if (mt == 1) YF_DC4(1); else if (mt == 2) YF_DC4(2); else if (mt == 3) YF_DC4(3); else YF_DC4(4);
@@ -1777,14 +1879,16 @@ void launch_tdeconv_fwd(const float* x, const float* w, float* y, int N, int Cin
 }
 void launch_tdeconv_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, hipStream_t s)
 {
-    if ((long)N * H * W < 8192) {      // measured at 16 x 8 x 10 pixels: 25 us against 134 us for the GEMM form
+    static const bool off = getenv("YF_TDECONV_OLD") != nullptr;
+    if ((long)N * H * W < (off ? 8192 : 256)) {      // (the old gather GEMM at 16 x 8 x 10 pixels: 134 us against 25 us for this one)
         hipLaunchKernelGGL(tdeconv_bwd_data_kernel, dim3(nblk((long)N * Cin * H * W)), dim3(256), 0, s, dy, w, dx, N, Cin, H, W, Cout);
         return;
     }
-    static const bool off = getenv("YF_TDECONV_OLD") != nullptr;
     if (!off) {
         const long Q = (long)N * H * W;
-        const int tiles = (Cin + 15) / 16, mgroups = (tiles + 2) / 3, mt = (tiles + mgroups - 1) / mgroups;
+        const int tiles = (Cin + 15) / 16;
+        int mgroups = (tiles + 2) / 3, mt = (tiles + mgroups - 1) / mgroups;
+        while (mt > 1 && (Q + 63) / 64 * mgroups < 512) { mt = (mt + 1) / 2; mgroups = (tiles + mt - 1) / mt; }
         const dim3 grid((unsigned)((Q + 255) / 256 * mgroups));
 #define YF_DB(MT_) hipLaunchKernelGGL(tdeconv_bwd_mfma_kernel<MT_>, grid, dim3(256), 0, s, dy, w, dx, Q, H, W, Cin, Cout, mgroups)
         if (mt == 1) YF_DB(1); else if (mt == 2) YF_DB(2); else YF_DB(3);
@@ -1846,6 +1950,14 @@ static inline int tbn_chunks(int N, int C, long HW, int V, bool flat)
 void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* stats, float* y, int N,
                     int C, long HW, int relu, void* scratch, hipStream_t s, const float* residual)
 {
+    static const bool small4_off = getenv("YF_TBN_SMALL4_OFF") != nullptr;
+    if (!small4_off && HW % 4 == 0 && (long)N * HW <= 4096 * 8) {
+        const long P4 = (long)N * HW / 4;
+#define YF_BNF(U_) hipLaunchKernelGGL(tbn_fwd_small4_kernel<U_>, dim3(C), dim3(1024), 0, s, x, gamma, beta, y, N, C, (int)HW, relu, 1e-5f, 0.1f, stats, running_mean, running_var, residual)
+        if (P4 <= 1024) YF_BNF(1); else if (P4 <= 2048) YF_BNF(2); else if (P4 <= 4096) YF_BNF(4); else YF_BNF(8);
+#undef YF_BNF
+        return;
+    }
     if ((long)N * HW <= TBN_SMALL) {
         hipLaunchKernelGGL(tbn_fwd_small_kernel, dim3(C), dim3(1024), 0, s, x, gamma, beta, y, N, C, (int)HW, relu, 1e-5f, 0.1f, stats, running_mean,
                            running_var, residual);
@@ -1872,6 +1984,14 @@ void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float
 void launch_tbn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, float* dgamma, float* dbeta, float* dx,
                     int N, int C, long HW, int relu, void* scratch, hipStream_t s)
 {
+    static const bool small4_off = getenv("YF_TBN_SMALL4_OFF") != nullptr;
+    if (!small4_off && HW % 4 == 0 && (long)N * HW <= 4096 * 8) {
+        const long P4 = (long)N * HW / 4;
+#define YF_BNB(U_) hipLaunchKernelGGL(tbn_bwd_small4_kernel<U_>, dim3(C), dim3(1024), 0, s, x, dy, stats, gamma, beta, dgamma, dbeta, dx, N, C, (int)HW, relu)
+        if (P4 <= 1024) YF_BNB(1); else if (P4 <= 2048) YF_BNB(2); else if (P4 <= 4096) YF_BNB(4); else YF_BNB(8);
+#undef YF_BNB
+        return;
+    }
     if ((long)N * HW <= TBN_SMALL) {
         hipLaunchKernelGGL(tbn_bwd_small_kernel, dim3(C), dim3(1024), 0, s, x, dy, stats, gamma, beta, dgamma, dbeta, dx, N, C, (int)HW, relu);
         return;
