@@ -1,5 +1,6 @@
 // yf_kernels.h -- internal launch interface between the engine (yf_engine.hip) and the kernel files.
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -305,12 +306,22 @@ void launch_tconv_fwd(const float* x, const float* w, const float* bias, float* 
                       int depthwise, hipStream_t s);
 void launch_tconv_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int k, int stride, int depthwise,
                            hipStream_t s, const float* addend = nullptr);
+// split weight-gradient reductions, summed once per pass: a layer's launcher puts its slabs into `slab` and records an entry instead of
+// launching its own sum; launch_tsum_multi adds them all (offsets relative to slab / dst_base, so the table is the same every iteration)
+struct TSumEntry { long part_off, dst_off, nw, blk0; int nsplit, spl; };
+struct TSumDefer {
+    float* slab; size_t cap_floats, used; float* dst_base; long nblocks;
+    std::vector<TSumEntry> entries;
+    float* take(long floats);
+    void push(const float* part, long nsplit, long nw, float* dw);
+};
+void launch_tsum_multi(const TSumEntry* d_tab, int n, long nblocks, const float* slab, float* dst, hipStream_t s);
 void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int k, int stride, int depthwise,
-                             void* scratch, size_t scratch_bytes, hipStream_t s);
+                             void* scratch, size_t scratch_bytes, hipStream_t s, TSumDefer* defer = nullptr);
 void launch_tdeconv_fwd(const float* x, const float* w, float* y, int N, int Cin, int H, int W, int Cout, hipStream_t s);
 void launch_tdeconv_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, hipStream_t s);
 void launch_tdeconv_bwd_weight(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, void* scratch, size_t scratch_bytes,
-                               hipStream_t s);
+                               hipStream_t s, TSumDefer* defer = nullptr);
 size_t train_scratch_bytes();
 void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* stats, float* y, int N,
                     int C, long HW, int relu, void* scratch, hipStream_t s, const float* residual = nullptr);

@@ -59,6 +59,10 @@ struct yf_trainer_s {
     size_t gmax;            // per frame: the largest activation
     size_t ga2, gb2, gd;    // per-frame sizes of the branch-point gradient buffers (conv4_2, conv5_2, deconv5_1 outputs)
     int n_params;
+    size_t param_off[3 * kNumLayers];   // float offset of every parameter in a flat parameters()-order buffer, [n_params] = the total
+    // the table of the pass's one multi-tensor sum of the split weight gradients (offsets only: the same every iteration of a batch size)
+    std::vector<yf::TSumEntry> sum_tab;
+    yf::TSumEntry* d_sum_tab = nullptr;
     int i_conv4_2, i_conv4_3, i_conv5_2, i_conv5_3, i_conv5_6, i_head5, i_deconv, i_c411, i_c415, i_head4;
 };
 
@@ -74,6 +78,7 @@ int trainer_build(yf_trainer_s* t, int H, int W)
     size_t off = 0, st = 0;
     int p = 0;
     t->gmax = 0;
+    t->param_off[0] = 0;
     for (int i = 0; i < kNumLayers; ++i) {
         const LayerSpec& S = kLayers[i];
         TLayer& L = t->L[i];
@@ -91,6 +96,12 @@ int trainer_build(yf_trainer_s* t, int H, int W)
         L.res_from = -1;
         const size_t n = strlen(S.name);
         if (n > 6 && !strcmp(S.name + n - 6, ".conv3")) L.res_from = i - 2;
+        {   // parameters() order: conv weight, then BatchNorm gamma, beta -- or the head's weight, bias
+            const size_t wn = (size_t)S.cout * (S.kind == K_DW ? 1 : S.cin) * S.k * S.k;      // ConvTranspose2d: [Cin][Cout][2][2], the same count
+            t->param_off[p + 1] = t->param_off[p] + wn;
+            t->param_off[p + 2] = t->param_off[p + 1] + S.cout;
+            if (S.kind != K_HEAD) t->param_off[p + 3] = t->param_off[p + 2] + S.cout;
+        }
         if (S.kind == K_HEAD) { L.z = L.y = 0; L.st = 0; L.p0 = p; p += 2; continue; }     // the heads write into the caller's tensors
         L.z = off; off += a;
         L.y = off; off += a;
@@ -114,9 +125,26 @@ int trainer_build(yf_trainer_s* t, int H, int W)
 
 // workspace: [scratch | stats | activations x N | 4 gradient buffers x N x gmax | ga2, gb2, gd x N]
 struct TWs {
-    char* scratch; float* stats; float* act; float* g[4]; float* ga2; float* gb2; float* gd;
-    size_t bytes;
+    char* scratch; float* stats; float* act; float* g[4]; float* ga2; float* gb2; float* gd; float* slabs;
+    size_t bytes, slab_floats;
 };
+// room for every layer's weight-gradient slabs at once: a layer splits into at most min(1024, pixels / 128) slices, and never needs
+// more than the shared scratch holds
+size_t trainer_slab_floats(const yf_trainer_s* t, int N)
+{
+    size_t total = 0;
+    for (int i = 0; i < kNumLayers; ++i) {
+        const LayerSpec& S = kLayers[i];
+        const TLayer& L = t->L[i];
+        const size_t nw = (size_t)S.cout * (S.kind == K_DW ? 1 : S.cin) * S.k * S.k;
+        size_t P = (size_t)N * (S.kind == K_DECONV ? (size_t)L.Hin * L.Win : (size_t)L.Ho * L.Wo), ns = (P + 127) / 128;
+        if (ns > 1024) ns = 1024;
+        size_t f = ns * nw;
+        if (f > yf::train_scratch_bytes() / 4) f = yf::train_scratch_bytes() / 4;
+        total += (f + 63) & ~(size_t)63;
+    }
+    return total;
+}
 TWs trainer_ws(const yf_trainer_s* t, int N, void* base)
 {
     TWs w;
@@ -129,6 +157,8 @@ TWs trainer_ws(const yf_trainer_s* t, int N, void* base)
     w.ga2 = reinterpret_cast<float*>(take(t->ga2 * N * 4));
     w.gb2 = reinterpret_cast<float*>(take(t->gb2 * N * 4));
     w.gd = reinterpret_cast<float*>(take(t->gd * N * 4));
+    w.slab_floats = trainer_slab_floats(t, N);
+    w.slabs = reinterpret_cast<float*>(take(w.slab_floats * 4));
     w.bytes = (size_t)(p - static_cast<char*>(base));
     return w;
 }
@@ -334,7 +364,11 @@ int yf_trainer_create(int H, int W, int device, yf_trainer* out)
     *out = t;
     return YF_OK;
 }
-void yf_trainer_destroy(yf_trainer t) { delete t; }
+void yf_trainer_destroy(yf_trainer t)
+{
+    if (t && t->d_sum_tab) (void)hipFree(t->d_sum_tab);
+    delete t;
+}
 int yf_trainer_num_params(yf_trainer t, int* n_params, int* n_bn)
 {
     if (!t || !n_params || !n_bn) return fail(YF_E_INVALID, "yf_trainer_num_params: null argument");
@@ -416,6 +450,12 @@ int yf_trainer_backward(yf_trainer t, const float* d_x, const float* d_grad_head
     // gradient buffers: `cur` holds the gradient flowing backwards, `skip` a block's output gradient until the block's input is reached
     int cur = 0, skip = -1;
     PassTimer tm(s);
+    // the gradients of a flat parameters()-order buffer (what training.py passes): the split weight-gradient sums of all layers become one
+    // launch at the end of the pass.  Pointers that are not laid out that way: every layer sums its own slabs as before.
+    bool flat = getenv("YF_TRAIN_SUM_EACH") == nullptr;
+    for (int i = 1; i < t->n_params && flat; ++i) flat = (const float*)d_grads[i] == (const float*)d_grads[0] + t->param_off[i];
+    yf::TSumDefer defer{w.slabs, w.slab_floats, 0, static_cast<float*>(d_grads[0]), 0, {}};
+    yf::TSumDefer* dfr = flat ? &defer : nullptr;
     auto other = [&](int a, int b, int c) { for (int i = 0; i < 4; ++i) if (i != a && i != b && i != c) return i; return -1; };
     // backward of one conv + BN (+ ReLU) unit: gradient of its output in gy -> parameter gradients, gradient of its input in w.g[ret]
     auto unit = [&](int i, const float* gy, bool need_dx, const float* addend = nullptr) {
@@ -427,11 +467,11 @@ int yf_trainer_backward(yf_trainer t, const float* d_x, const float* d_grad_head
                            S.relu, w.scratch, s);
         tm.tick("bn", S.name);
         if (S.kind == K_DECONV) {
-            yf::launch_tdeconv_bwd_weight(xin(L), gz, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, w.scratch, sb, s);
+            yf::launch_tdeconv_bwd_weight(xin(L), gz, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, w.scratch, sb, s, dfr);
             tm.tick("wgrad", S.name);
             if (need_dx) yf::launch_tdeconv_bwd_data(gz, P(L.p0), w.g[ix], N, L.Cin, L.Hin, L.Win, L.Cout, s);
         } else {
-            yf::launch_tconv_bwd_weight(xin(L), gz, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, w.scratch, sb, s);
+            yf::launch_tconv_bwd_weight(xin(L), gz, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, w.scratch, sb, s, dfr);
             tm.tick("wgrad", S.name);
             if (need_dx) yf::launch_tconv_bwd_data(gz, P(L.p0), w.g[ix], N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, s, addend);
         }
@@ -441,7 +481,7 @@ int yf_trainer_backward(yf_trainer t, const float* d_x, const float* d_grad_head
     auto head = [&](int i, const float* gy) {                                  // nn.Conv2d(C, 24, 1) with bias
         const TLayer& L = t->L[i];
         const int ix = other(cur, skip, -1);
-        yf::launch_tconv_bwd_weight(xin(L), gy, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, 1, 1, 0, w.scratch, sb, s);
+        yf::launch_tconv_bwd_weight(xin(L), gy, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, 1, 1, 0, w.scratch, sb, s, dfr);
         yf::launch_tchan_sum(gy, G(L.p0 + 1), N, L.Cout, (long)L.Hin * L.Win, s, w.scratch);
         yf::launch_tconv_bwd_data(gy, P(L.p0), w.g[ix], N, L.Cin, L.Hin, L.Win, L.Cout, 1, 1, 0, s);
         tm.tick("head", kLayers[i].name);
@@ -478,6 +518,20 @@ int yf_trainer_backward(yf_trainer t, const float* d_x, const float* d_grad_head
     run_back(t->i_conv5_2, t->i_conv4_3, true);                                  // conv5_2 .. conv4_3             :191-200
     yf::launch_tadd(w.g[cur], w.ga2, w.g[cur], (long)N * t->ga2, s);
     run_back(t->i_conv4_2, 0, false);                                            // conv4_2 .. conv0; the images need no gradient
+    if (dfr && !defer.entries.empty()) {
+        const size_t nb = defer.entries.size() * sizeof(yf::TSumEntry);
+        if (t->sum_tab.size() != defer.entries.size() || memcmp(t->sum_tab.data(), defer.entries.data(), nb)) {
+            // first pass at this batch size: the table goes to the device once (nothing of this trainer may still be reading the old one)
+            HIP_OK(hipStreamSynchronize(s));
+            if (t->d_sum_tab) (void)hipFree(t->d_sum_tab);
+            t->d_sum_tab = nullptr;
+            HIP_OK(hipMalloc(&t->d_sum_tab, nb));
+            HIP_OK(hipMemcpy(t->d_sum_tab, defer.entries.data(), nb, hipMemcpyHostToDevice));
+            t->sum_tab = defer.entries;
+        }
+        yf::launch_tsum_multi(t->d_sum_tab, (int)defer.entries.size(), defer.nblocks, w.slabs, defer.dst_base, s);
+        tm.tick("wsum", "all");
+    }
     tm.report("bwd");
     HIP_OK(hipGetLastError());
     return YF_OK;

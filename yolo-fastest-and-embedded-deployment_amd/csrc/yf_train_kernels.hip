@@ -1774,8 +1774,64 @@ static inline void tsum_partials(const float* part, long nsplit, long nw, float*
     while (spl < 64 && spl * 8 <= nsplit) spl *= 2;                 // >= 8 slabs per lane
     hipLaunchKernelGGL(tsum_partials_kernel, dim3(nblk(nw * spl)), dim3(256), 0, s, part, (int)nsplit, nw, nw, dw, spl);
 }
+// the multi-tensor form: every layer's slabs stay alive in the defer region until ONE launch at the end of the pass adds them all
+// (tsum_multi_kernel: the same lanes, order and arithmetic per output as tsum_partials_kernel -- bitwise the same sums)
+__global__ void __launch_bounds__(256) tsum_multi_kernel(const TSumEntry* __restrict__ tab, int n, const float* __restrict__ slab, float* __restrict__ dst)
+{
+    // this block's entry = the last one that starts at or before it: one parallel probe of the (<= 256) entries, not a dependent scan
+    const int e = __syncthreads_count((int)threadIdx.x < n && tab[threadIdx.x].blk0 <= (long)blockIdx.x) - 1;
+    const TSumEntry E = tab[e];
+    const float* part = slab + E.part_off;
+    const long t = ((long)blockIdx.x - E.blk0) * 256 + threadIdx.x;
+    const long i = t / E.spl;
+    const int j = (int)(t - i * E.spl);
+    float v = 0.f;
+    if (i < E.nw)
+        for (int sidx = j; sidx < E.nsplit; sidx += E.spl) v += part[(long)sidx * E.nw + i];
+    for (int o = E.spl >> 1; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if (i < E.nw && j == 0) dst[E.dst_off + i] = v;
+}
+float* TSumDefer::take(long floats)
+{
+    const size_t need = ((size_t)floats + 63) & ~(size_t)63;
+    if (!slab || used + need > cap_floats) return nullptr;
+    float* p = slab + used;
+    used += need;
+    return p;
+}
+void TSumDefer::push(const float* part, long nsplit, long nw, float* dw)
+{
+    TSumEntry E;
+    E.part_off = part - slab; E.dst_off = dw - dst_base; E.nw = nw; E.nsplit = (int)nsplit;
+    int spl = 1;
+    while (spl < 64 && spl * 8 <= nsplit) spl *= 2;
+    E.spl = spl;
+    E.blk0 = nblocks;
+    nblocks += (nw * spl + 255) / 256;
+    entries.push_back(E);
+}
+void launch_tsum_multi(const TSumEntry* d_tab, int n, long nblocks, const float* slab, float* dst, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(tsum_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, d_tab, n, slab, dst);
+}
+// where a split reduction writes: the gradient itself without a split, a slab of the defer region, or the shared scratch
+static inline float* tsum_out(void* scratch, long nsplit, long nw, float* dw, TSumDefer* d)
+{
+    if (nsplit <= 1) return dw;
+    if (d) {
+        float* p = d->take(nsplit * nw);
+        if (p) return p;
+    }
+    return (float*)scratch;
+}
+static inline void tsum_finish(const float* out, void* scratch, long nsplit, long nw, float* dw, hipStream_t s, TSumDefer* d)
+{
+    if (nsplit <= 1) return;
+    if (d && out != (const float*)scratch) d->push(out, nsplit, nw, dw);
+    else tsum_partials(out, nsplit, nw, dw, s);
+}
 void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int k, int stride, int depthwise,
-                             void* scratch, size_t scratch_bytes, hipStream_t s)
+                             void* scratch, size_t scratch_bytes, hipStream_t s, TSumDefer* defer)
 {
     const int pad = (k - 1) / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     const long nw = (long)Cout * (depthwise ? 1 : Cin) * k * k, P = (long)N * Ho * Wo;
@@ -1787,9 +1843,9 @@ void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, 
             long chunks = G / 2048;                                     // >= 8 groups per thread
             if (chunks > 1024) chunks = 1024;
             if (chunks > fit) chunks = fit;
-            float* out = chunks > 1 ? (float*)scratch : dw;
+            float* out = tsum_out(scratch, chunks, nw, dw, defer);
             hipLaunchKernelGGL(tconv3s2_c1_wgrad_kernel<8>, dim3((unsigned)chunks), dim3(256), 0, s, x, dy, out, N, H, W, Cout, nw);
-            if (chunks > 1) tsum_partials(out, chunks, nw, dw, s);
+            tsum_finish(out, scratch, chunks, nw, dw, s, defer);
             return;
         }
         if (Cin % 4 == 0 && Cin <= 32 && Cout <= 32 && G >= 2048) {
@@ -1799,9 +1855,9 @@ void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, 
             long g_per = (G + nsplit - 1) / nsplit;
             g_per = (g_per + 3) / 4 * 4;
             nsplit = (G + g_per - 1) / g_per;
-            float* out = nsplit > 1 ? (float*)scratch : dw;
+            float* out = tsum_out(scratch, nsplit, nw, dw, defer);
             hipLaunchKernelGGL(tconv3s2_wgrad_mfma_kernel, dim3((unsigned)nsplit), dim3(256), 0, s, x, dy, out, N, Cin, H, W, Cout, g_per, nw);
-            if (nsplit > 1) tsum_partials(out, nsplit, nw, dw, s);
+            tsum_finish(out, scratch, nsplit, nw, dw, s, defer);
             return;
         }
     }
@@ -1815,33 +1871,33 @@ void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, 
         long q_per = (P + nsplit - 1) / nsplit;
         q_per = (q_per + 15) / 16 * 16;
         nsplit = (P + q_per - 1) / q_per;
-        float* out = nsplit > 1 ? (float*)scratch : dw;
+        float* out = tsum_out(scratch, nsplit, nw, dw, defer);
         const dim3 grid((unsigned)(nsplit * tiles));
         const int nwv = twgrad_waves(nsplit * tiles, q_per);
 #define YF_WG(KS_, NW_) hipLaunchKernelGGL((tconv_wgrad_mfma_kernel<KS_, NW_>), grid, dim3(64 * NW_), 0, s, x, dy, out, N, Cin, H, W, Cout, Ho, Wo, stride, q_per, nw)
         if (k == 1) { if (nwv == 8) YF_WG(1, 8); else if (nwv == 4) YF_WG(1, 4); else YF_WG(1, 1); }
         else { if (nwv == 8) YF_WG(3, 8); else if (nwv == 4) YF_WG(3, 4); else YF_WG(3, 1); }
 #undef YF_WG
-        if (nsplit > 1) tsum_partials(out, nsplit, nw, dw, s);
+        tsum_finish(out, scratch, nsplit, nw, dw, s, defer);
         return;
     }
     if (depthwise && (k == 3 || k == 5)) {
         long chunks = (P + 2047) / 2048;                                // ~8 pixels per thread
         while (chunks * Cout > 4096 && chunks > 1) chunks = (chunks + 1) / 2;
         if (chunks > fit) chunks = fit < 1 ? 1 : fit;
-        float* out = chunks > 1 ? (float*)scratch : dw;
+        float* out = tsum_out(scratch, chunks, nw, dw, defer);
         const dim3 grid((unsigned)chunks, Cout);
         if (!tdw_rows_off && stride == 1 && W % 4 == 0 && H % 4 == 0 && (long)N * (H / 4) * (W / 4) >= 256 * chunks) {
             if (k == 3) hipLaunchKernelGGL((tdw_wgrad_rows_kernel<3, 4>), grid, dim3(256), 0, s, x, dy, out, N, Cout, H, W, nw);
             else hipLaunchKernelGGL((tdw_wgrad_rows_kernel<5, 4>), grid, dim3(256), 0, s, x, dy, out, N, Cout, H, W, nw);
-            if (chunks > 1) tsum_partials(out, chunks, nw, dw, s);
+            tsum_finish(out, scratch, chunks, nw, dw, s, defer);
             return;
         }
         if (k == 3)
             hipLaunchKernelGGL(tdw_wgrad_kernel<3>, grid, dim3(256), 0, s, x, dy, out, N, Cout, H, W, Ho, Wo, stride, nw);
         else
             hipLaunchKernelGGL(tdw_wgrad_kernel<5>, grid, dim3(256), 0, s, x, dy, out, N, Cout, H, W, Ho, Wo, stride, nw);
-        if (chunks > 1) tsum_partials(out, chunks, nw, dw, s);
+        tsum_finish(out, scratch, chunks, nw, dw, s, defer);
         return;
     }
     (void)hipMemsetAsync(dw, 0, (size_t)nw * sizeof(float), s);        // the fallbacks below accumulate with atomics
@@ -1901,7 +1957,7 @@ void launch_tdeconv_bwd_data(const float* dy, const float* w, float* dx, int N, 
                        (const float*)nullptr, dx, N, Cout, 2 * H, 2 * W, H, W, Cin, 2);
 }
 void launch_tdeconv_bwd_weight(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, void* scratch, size_t scratch_bytes,
-                               hipStream_t s)
+                               hipStream_t s, TSumDefer* defer)
 {
     const long nw = (long)Cin * Cout * 4, P = (long)N * H * W;
     if (((long)H * W) % 4 == 0) {                 // the conv weight-gradient GEMM with the operands swapped (see tconv_wgrad_mfma_kernel)
@@ -1914,13 +1970,13 @@ void launch_tdeconv_bwd_weight(const float* x, const float* dy, float* dw, int N
         long q_per = (P + nsplit - 1) / nsplit;
         q_per = (q_per + 15) / 16 * 16;
         nsplit = (P + q_per - 1) / q_per;
-        float* out = nsplit > 1 ? (float*)scratch : dw;
+        float* out = tsum_out(scratch, nsplit, nw, dw, defer);
         const int nwv = twgrad_waves(nsplit * tiles, q_per);
         const dim3 grid((unsigned)(nsplit * tiles));
         if (nwv == 8) hipLaunchKernelGGL((tconv_wgrad_mfma_kernel<2, 8>), grid, dim3(512), 0, s, dy, x, out, N, Cout, 2 * H, 2 * W, Cin, H, W, 2, q_per, nw);
         else if (nwv == 4) hipLaunchKernelGGL((tconv_wgrad_mfma_kernel<2, 4>), grid, dim3(256), 0, s, dy, x, out, N, Cout, 2 * H, 2 * W, Cin, H, W, 2, q_per, nw);
         else hipLaunchKernelGGL((tconv_wgrad_mfma_kernel<2, 1>), grid, dim3(64), 0, s, dy, x, out, N, Cout, 2 * H, 2 * W, Cin, H, W, 2, q_per, nw);
-        if (nsplit > 1) tsum_partials(out, nsplit, nw, dw, s);
+        tsum_finish(out, scratch, nsplit, nw, dw, s, defer);
         return;
     }
     int nchunk = (int)((P + 4095) / 4096);
