@@ -1000,6 +1000,87 @@ __global__ void __launch_bounds__(256) tdw_wgrad_rows_kernel(const float* __rest
         dw[(long)blockIdx.x * part_stride + (long)c * KK + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// ---- stride-1 depthwise convolution on planes whose width is not a multiple of 4 (the 8x10 maps of stride 32 at 256x320: the float4
+// kernels above do not apply, and the one-thread-per-element fallback spent 57 us on an 18 MB tensor): a thread = one output ROW of one
+// plane (W <= 16), the KS input rows in registers.  Same for the weight gradient, grid (chunks, C). ----
+template <int KS, bool FLIP>
+__global__ void __launch_bounds__(256) tdw_plane_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int C, int H,
+                                                        int W, long nrows)
+{
+    constexpr int KK = KS * KS, PAD = (KS - 1) / 2, MW = 16;
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrows) return;
+    const long plane = r / H;
+    const int oy = (int)(r - plane * H), c = (int)(plane % C);
+    const float* xp = x + plane * H * W;
+    float wk[KK];
+#pragma unroll
+    for (int i = 0; i < KK; ++i) wk[i] = w[(long)c * KK + (FLIP ? KK - 1 - i : i)];
+    float acc[MW];
+#pragma unroll
+    for (int j = 0; j < MW; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+        const int iy = oy - PAD + ky;
+        if (iy < 0 || iy >= H) continue;
+        const float* xr = xp + (long)iy * W;
+        float row[MW + 2 * PAD];
+#pragma unroll
+        for (int j = 0; j < MW + 2 * PAD; ++j) row[j] = (j >= PAD && j - PAD < W) ? xr[j - PAD] : 0.f;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+            for (int j = 0; j < MW; ++j) acc[j] = fmaf(row[j + kx], wk[ky * KS + kx], acc[j]);
+    }
+    float* yr = y + r * W;
+#pragma unroll
+    for (int j = 0; j < MW; ++j)
+        if (j < W) yr[j] = acc[j];
+}
+template <int KS>
+__global__ void __launch_bounds__(256) tdw_plane_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, int N,
+                                                              int C, int H, int W, long part_stride)
+{
+    constexpr int KK = KS * KS, PAD = (KS - 1) / 2, MW = 16;
+    __shared__ float red[4][KK];
+    const int c = blockIdx.y;
+    const long rows = (long)N * H;
+    float acc[KK];
+#pragma unroll
+    for (int i = 0; i < KK; ++i) acc[i] = 0.f;
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+        const long n = r / H;
+        const int oy = (int)(r - n * H);
+        const float* xp = x + (n * C + c) * (long)H * W;
+        const float* gr = dy + ((n * C + c) * (long)H + oy) * W;
+        float g[MW];
+#pragma unroll
+        for (int j = 0; j < MW; ++j) g[j] = j < W ? gr[j] : 0.f;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            const int iy = oy - PAD + ky;
+            if (iy < 0 || iy >= H) continue;
+            const float* xr = xp + (long)iy * W;
+            float row[MW + 2 * PAD];
+#pragma unroll
+            for (int j = 0; j < MW + 2 * PAD; ++j) row[j] = (j >= PAD && j - PAD < W) ? xr[j - PAD] : 0.f;
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+                for (int j = 0; j < MW; ++j) acc[ky * KS + kx] = fmaf(g[j], row[j + kx], acc[ky * KS + kx]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < KK; ++i) {
+        float v = acc[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < KK)
+        dw[(long)blockIdx.x * part_stride + (long)c * KK + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 // backward-data of the depthwise 3x3 stride-2 pad-1 convolution: one thread = the 2x2 input block (2a.., 2b..), see tconv3s2_bwd_data_kernel
 __global__ void tdw3s2_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int C, int Ho, int Wo)
 {
@@ -1721,6 +1802,12 @@ void launch_tconv_fwd(const float* x, const float* w, const float* bias, float* 
                                (long)Cin * k * k, (long)k * k);
         return;
     }
+    if (depthwise && !bias && stride == 1 && W % 4 != 0 && W <= 16 && (k == 3 || k == 5)) {
+        const long nrows = (long)N * Cout * H;
+        if (k == 3) hipLaunchKernelGGL((tdw_plane_kernel<3, false>), dim3(nblk(nrows)), dim3(256), 0, s, x, w, y, Cout, H, W, nrows);
+        else hipLaunchKernelGGL((tdw_plane_kernel<5, false>), dim3(nblk(nrows)), dim3(256), 0, s, x, w, y, Cout, H, W, nrows);
+        return;
+    }
     if (depthwise && !bias && Wo % 4 == 0) {
         if (k == 3 && stride == 1) return launch_tdw_conv<3, 1, false>(x, w, y, N, Cout, H, W, Ho, Wo, s);
         if (k == 3 && stride == 2) return launch_tdw_conv<3, 2, false>(x, w, y, N, Cout, H, W, Ho, Wo, s);
@@ -1747,6 +1834,12 @@ void launch_tconv_bwd_data(const float* dy, const float* w, float* dx, int N, in
         return;
     }
     if (depthwise) {
+        if (stride == 1 && W % 4 != 0 && W <= 16 && (k == 3 || k == 5)) {
+            const long nrows = (long)N * Cin * H;
+            if (k == 3) hipLaunchKernelGGL((tdw_plane_kernel<3, true>), dim3(nblk(nrows)), dim3(256), 0, s, dy, w, dx, Cin, H, W, nrows);
+            else hipLaunchKernelGGL((tdw_plane_kernel<5, true>), dim3(nblk(nrows)), dim3(256), 0, s, dy, w, dx, Cin, H, W, nrows);
+            return;
+        }
         if (stride == 1 && W % 4 == 0 && k == 3) return launch_tdw_conv<3, 1, true>(dy, w, dx, N, Cin, H, W, H, W, s);
         if (stride == 1 && W % 4 == 0 && k == 5) return launch_tdw_conv<5, 1, true>(dy, w, dx, N, Cin, H, W, H, W, s);
         if (stride == 2 && k == 3 && H == 2 * Ho && W == 2 * Wo) {
@@ -1864,8 +1957,12 @@ void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, 
     // 4 consecutive output pixels per lane, in one frame
     if (!depthwise && (k == 3 || (k == 1 && stride == 1)) && ((long)Ho * Wo) % 4 == 0) {
         const int R = Cin * k * k, tiles = ((Cout + 15) / 16) * ((R + 63) / 64);
-        long nsplit = (P + 127) / 128;                                  // >= 8 MFMA steps per wave ...
-        while (nsplit * tiles > 8192 && nsplit > 1) nsplit = (nsplit + 1) / 2;   // ... and a bounded grid
+        // many pixels: 4 waves per workgroup share a slice (added through LDS) rather than 4 slices -- the same waves in flight, a
+        // quarter of the slabs to write and to add up afterwards
+        static const bool forced_nw = getenv("YF_WGRAD_NW") != nullptr;
+        const long pw = (!forced_nw && P >= 65536) ? 4 : 1;
+        long nsplit = (P + 128 * pw - 1) / (128 * pw);                  // >= 8 MFMA steps per wave ...
+        while (nsplit * tiles * pw > 8192 && nsplit > 1) nsplit = (nsplit + 1) / 2;   // ... and a bounded grid
         if (nsplit > 1024) nsplit = 1024;
         if (nsplit > fit) nsplit = fit < 1 ? 1 : fit;
         long q_per = (P + nsplit - 1) / nsplit;
@@ -1873,7 +1970,8 @@ void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, 
         nsplit = (P + q_per - 1) / q_per;
         float* out = tsum_out(scratch, nsplit, nw, dw, defer);
         const dim3 grid((unsigned)(nsplit * tiles));
-        const int nwv = twgrad_waves(nsplit * tiles, q_per);
+        int nwv = twgrad_waves(nsplit * tiles, q_per);
+        if (pw == 4 && nwv < 4 && q_per >= 4 * 64) nwv = 4;
 #define YF_WG(KS_, NW_) hipLaunchKernelGGL((tconv_wgrad_mfma_kernel<KS_, NW_>), grid, dim3(64 * NW_), 0, s, x, dy, out, N, Cin, H, W, Cout, Ho, Wo, stride, q_per, nw)
         if (k == 1) { if (nwv == 8) YF_WG(1, 8); else if (nwv == 4) YF_WG(1, 4); else YF_WG(1, 1); }
         else { if (nwv == 8) YF_WG(3, 8); else if (nwv == 4) YF_WG(3, 4); else YF_WG(3, 1); }
@@ -1890,6 +1988,12 @@ void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, 
         if (!tdw_rows_off && stride == 1 && W % 4 == 0 && H % 4 == 0 && (long)N * (H / 4) * (W / 4) >= 256 * chunks) {
             if (k == 3) hipLaunchKernelGGL((tdw_wgrad_rows_kernel<3, 4>), grid, dim3(256), 0, s, x, dy, out, N, Cout, H, W, nw);
             else hipLaunchKernelGGL((tdw_wgrad_rows_kernel<5, 4>), grid, dim3(256), 0, s, x, dy, out, N, Cout, H, W, nw);
+            tsum_finish(out, scratch, chunks, nw, dw, s, defer);
+            return;
+        }
+        if (stride == 1 && W % 4 != 0 && W <= 16) {
+            if (k == 3) hipLaunchKernelGGL(tdw_plane_wgrad_kernel<3>, grid, dim3(256), 0, s, x, dy, out, N, Cout, H, W, nw);
+            else hipLaunchKernelGGL(tdw_plane_wgrad_kernel<5>, grid, dim3(256), 0, s, x, dy, out, N, Cout, H, W, nw);
             tsum_finish(out, scratch, chunks, nw, dw, s, defer);
             return;
         }
