@@ -263,6 +263,19 @@ def test_adam_matches_torch(yf, dev):
     with pytest.raises(RuntimeError):
         cpu = torch.nn.Parameter(torch.zeros(3)); cpu.grad = torch.ones(3)
         training.Adam([cpu]).step()
+    # a tensor that joins later (no gradient in the first step): its own step count, its own launch
+    a0, b0 = rng.normal(size=(5, 3)).astype(np.float32), rng.normal(size=(7,)).astype(np.float32)
+    ra, rb = torch.nn.Parameter(torch.from_numpy(a0.copy())), torch.nn.Parameter(torch.from_numpy(b0.copy()))
+    oa, ob = torch.nn.Parameter(torch.from_numpy(a0.copy()).to(dev)), torch.nn.Parameter(torch.from_numpy(b0.copy()).to(dev))
+    o_ref, o_our = torch.optim.Adam([ra, rb], lr=0.01), training.Adam([oa, ob], lr=0.01)
+    for it in range(3):
+        ga, gb = rng.normal(size=a0.shape).astype(np.float32), rng.normal(size=b0.shape).astype(np.float32)
+        ra.grad, oa.grad = torch.from_numpy(ga.copy()), torch.from_numpy(ga.copy()).to(dev)
+        if it > 0:
+            rb.grad, ob.grad = torch.from_numpy(gb.copy()), torch.from_numpy(gb.copy()).to(dev)
+        o_ref.step(); o_our.step()
+        assert np.abs(oa.detach().cpu().numpy() - ra.detach().numpy()).max() <= 1e-6 and np.abs(ob.detach().cpu().numpy() - rb.detach().numpy()).max() <= 1e-6
+    assert o_our.state[oa]["step"] == 3 and o_our.state[ob]["step"] == 2
 
 
 GRAD_RATIO = 1.5      # median and 90th percentile (over the parameter tensors) of our distance to the exact gradient, over the reference's

@@ -230,6 +230,18 @@ class _Trainer:
         self.n_params, self.n_bn = n.value, nb.value
         self._bytes = {}
 
+    def layout(self, params):
+        """sizes, shapes and byte offsets of the parameters in one flat buffer (the shapes of a YoloFastest never change)."""
+        lay = self.__dict__.get("_layout")
+        if lay is None or len(lay["sizes"]) != len(params):
+            sizes = [p.numel() for p in params]
+            offs, o = [], 0
+            for n in sizes:
+                offs.append(4 * o)
+                o += n
+            lay = self._layout = dict(sizes=sizes, shapes=[tuple(p.shape) for p in params], byte_offsets=offs, total=o)
+        return lay
+
     def workspace(self, N, device):
         if N not in self._bytes:
             need = ctypes.c_size_t()
@@ -257,6 +269,24 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+def _structure(model):
+    """The model's parameter slots and BatchNorm modules, found once: at the reference's batch 16 an iteration is 4 ms of GPU work, and
+    walking 430 modules three times per forward (parameters(), named_modules(), modules()) plus 170 `Module.__getattr__` lookups cost
+    2 ms of host time -- more than the forward's kernels.  The slots are (module._parameters, name) pairs in parameters() order, so a
+    replaced Parameter object is still picked up; the module SET is taken to be fixed (YoloFastest builds it in __init__)."""
+    st = model.__dict__.get("_yf_struct")
+    if st is None:
+        slots, seen = [], set()
+        for mod in model.modules():
+            for name, prm in mod._parameters.items():
+                if prm is not None and id(prm) not in seen:
+                    seen.add(id(prm))
+                    slots.append((mod._parameters, name))
+        st = model.__dict__["_yf_struct"] = dict(slots=slots, bns=[m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)],
+                                                 bn_names=[n for n, m in model.named_modules() if isinstance(m, torch.nn.BatchNorm2d)])
+    return st
+
+
 class _TrainForwardFn(torch.autograd.Function):
     """The whole network as one autograd node: inputs = the parameters, outputs = the two heads."""
 
@@ -266,8 +296,8 @@ class _TrainForwardFn(torch.autograd.Function):
             hl, hs, tape = train_forward(model, x)
             ctx.model, ctx.tape, ctx.params, ctx.tr = model, tape, params, None
             return hl, hs
-        hl, hs, tr, ws = _trainer_forward(model, x, params)
-        ctx.model, ctx.tape, ctx.params, ctx.tr = model, (x, ws), params, tr
+        hl, hs, tr, (ws, pp) = _trainer_forward(model, x, params)
+        ctx.model, ctx.tape, ctx.params, ctx.tr, ctx.params_ptr = model, (x, ws), params, tr, pp
         return hl, hs
 
     @staticmethod
@@ -281,12 +311,17 @@ class _TrainForwardFn(torch.autograd.Function):
         x, ws = ctx.tape
         tr, params = ctx.tr, ctx.params
         g_hl, g_hs = g_hl.contiguous().float(), g_hs.contiguous().float()
-        sizes = [p.numel() for p in params]
-        flat = torch.empty(sum(sizes), dtype=torch.float32, device=x.device)
-        grads = [g.view_as(p) for g, p in zip(flat.split(sizes), params)]
-        _lib.check(tr.lib.yf_trainer_backward(tr.handle, x.data_ptr(), g_hl.data_ptr(), g_hs.data_ptr(), x.shape[0], _ptr_array(params),
-                                              _ptr_array(grads), ws.data_ptr(), ws.numel(),
+        # The C call first, the 256 gradient views after it: this runs right behind the loss's device-to-host read (the reference's
+        # .item() calls), with the GPU idle until the first backward kernel is queued.  The gradients are one flat parameters()-order
+        # buffer (what the trainer's single multi-tensor sum of the split weight gradients needs): pointers = base + cached offsets.
+        lay = tr.layout(params)
+        flat = torch.empty(lay["total"], dtype=torch.float32, device=x.device)
+        base = flat.data_ptr()
+        gp = (ctypes.c_void_p * len(params))(*[base + o for o in lay["byte_offsets"]])
+        _lib.check(tr.lib.yf_trainer_backward(tr.handle, x.data_ptr(), g_hl.data_ptr(), g_hs.data_ptr(), x.shape[0], ctx.params_ptr,
+                                              gp, ws.data_ptr(), ws.numel(),
                                               ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        grads = [g.view(shp) for g, shp in zip(flat.split(lay["sizes"]), lay["shapes"])]
         ctx.tape = None
         sync = getattr(ctx.model, "_grad_sync", None)
         if sync is not None:                                     # data_parallel(): one all-reduce of the flat gradient buffer
@@ -300,21 +335,23 @@ def _trainer_forward(model, x, params):
     tr = _trainer(model, H, W, x.device)
     if len(params) != tr.n_params:
         raise RuntimeError("the model has %d parameters, the trainer expects %d" % (len(params), tr.n_params))
-    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    bns = _structure(model)["bns"]
     if len(bns) != tr.n_bn:
         raise RuntimeError("the model has %d BatchNorm layers, the trainer expects %d" % (len(bns), tr.n_bn))
     bufs = None
-    if all(b.running_mean is not None for b in bns):
-        bufs = (ctypes.c_void_p * (2 * len(bns)))(*[t.data_ptr() for b in bns for t in (b.running_mean, b.running_var)])
+    bb = [b._buffers for b in bns]                           # (the dicts, not the attributes: Module.__getattr__ is 3 us a lookup)
+    if all(d.get("running_mean") is not None for d in bb):
+        bufs = (ctypes.c_void_p * (2 * len(bns)))(*[d[k].data_ptr() for d in bb for k in ("running_mean", "running_var")])
     hl = torch.empty((N, model.num_out, H // 16, W // 16), dtype=torch.float32, device=x.device)
     hs = torch.empty((N, model.num_out, H // 32, W // 32), dtype=torch.float32, device=x.device)
     ws = tr.workspace(N, x.device)
-    _lib.check(tr.lib.yf_trainer_forward(tr.handle, x.data_ptr(), N, _ptr_array(params), bufs, hl.data_ptr(), hs.data_ptr(), ws.data_ptr(),
+    pp = _ptr_array(params)
+    _lib.check(tr.lib.yf_trainer_forward(tr.handle, x.data_ptr(), N, pp, bufs, hl.data_ptr(), hs.data_ptr(), ws.data_ptr(),
                                          ws.numel(), ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
-    nbt = [b.num_batches_tracked for b in bns if b.num_batches_tracked is not None]
+    nbt = [d["num_batches_tracked"] for d in bb if d.get("num_batches_tracked") is not None]
     if nbt:
         torch._foreach_add_(nbt, 1)
-    return hl, hs, tr, ws
+    return hl, hs, tr, (ws, pp)
 
 
 def forward(model, x):
@@ -323,15 +360,17 @@ def forward(model, x):
         raise RuntimeError("YoloFastest training (HIP) has no CPU path: move the model and input to the GPU")
     if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] % 32 or x.shape[3] % 32:
         raise ValueError("expected [N,1,H,W] with H and W multiples of 32, got %s" % (tuple(x.shape),))
-    params = list(model.parameters())
+    st = _structure(model)
+    params = [d[n] for d, n in st["slots"]]
+    f32 = torch.float32
     for p in params:
-        if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
+        if p.dtype is not f32 or not p.is_cuda or not p.is_contiguous():
             raise RuntimeError("training runs on contiguous float32 GPU parameters")
     x = x.contiguous().float()
-    for name, b in model.named_modules():
+    for name, b in zip(st["bn_names"], st["bns"]):
         # the BatchNorm kernels (and the backward's bit-exact recomputation of the ReLU mask) are built for nn.BatchNorm2d's defaults,
         # which is what the reference uses (yolo_fastest.py:12-13): anything else would train silently wrong
-        if isinstance(b, torch.nn.BatchNorm2d) and (b.eps != 1e-5 or b.momentum != 0.1 or not b.affine or not b.track_running_stats):
+        if b.eps != 1e-5 or b.momentum != 0.1 or not b.affine or not b.track_running_stats:
             raise NotImplementedError("%s: the training kernels implement BatchNorm2d(eps=1e-5, momentum=0.1, affine=True, "
                                       "track_running_stats=True) only (got eps=%r, momentum=%r, affine=%r, track_running_stats=%r)"
                                       % (name, b.eps, b.momentum, b.affine, b.track_running_stats))
@@ -383,28 +422,69 @@ class Adam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self.__dict__.pop("_groups", None)               # the cached state tensors may have been replaced
+
     @torch.no_grad()
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError("closure")
         lib = _lib.lib()
-        for group in self.param_groups:
+        f32 = torch.float32
+        for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
-            todo = {}                                     # (device, step) -> tensors: one launch each (yf_train_adam_multi)
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
-                    raise RuntimeError("training.Adam (HIP) has no CPU path: contiguous float32 GPU parameters only")
-                st = self.state[p]
-                if not st:
-                    st["step"], st["exp_avg"], st["exp_avg_sq"] = 0, torch.zeros_like(p), torch.zeros_like(p)
-                st["step"] = int(st["step"]) + 1         # (a loaded torch.optim.Adam state carries `step` as a tensor)
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                todo.setdefault((p.device, st["step"]), []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
-            for (device, step), items in todo.items():
-                n = len(items)
-                ptrs = tuple(tuple(it[k].data_ptr() for it in items) for k in range(4))
+            ps = group["params"]
+            gs = [p.grad for p in ps]
+            if any(g is None for g in gs):               # (not `None in gs`: that compares tensors with ==)
+                ps = [p for p, g in zip(ps, gs) if g is not None]
+                gs = [g for g in gs if g is not None]
+            if not ps:
+                continue
+            # per group, cached while the same Parameter objects take part: the state tensors, their pointers, the ctypes arrays of
+            # everything that does not change between steps (at batch 16 the host, not the GPU, was the slower side of an iteration)
+            cg = self.__dict__.setdefault("_groups", {}).get(gi)
+            if cg is None or len(cg["ps"]) != len(ps) or any(a is not b for a, b in zip(cg["ps"], ps)):
+                for q in ps:
+                    if not q.is_cuda or q.dtype is not f32 or not q.is_contiguous():
+                        raise RuntimeError("training.Adam (HIP) has no CPU path: contiguous float32 GPU parameters only")
+                    st = self.state[q]
+                    if not st:
+                        st["step"], st["exp_avg"], st["exp_avg_sq"] = 0, torch.zeros_like(q), torch.zeros_like(q)
+                sts = [self.state[q] for q in ps]
+                n = len(ps)
+                cg = self._groups[gi] = dict(ps=list(ps), sts=sts, m=[st["exp_avg"] for st in sts], v=[st["exp_avg_sq"] for st in sts],
+                                             sizes=(ctypes.c_long * n)(*[q.numel() for q in ps]))
+                cg["mp"] = tuple(t.data_ptr() for t in cg["m"])
+                cg["vp"] = tuple(t.data_ptr() for t in cg["v"])
+                cg["ma"], cg["va"] = (ctypes.c_void_p * n)(*cg["mp"]), (ctypes.c_void_p * n)(*cg["vp"])
+                cg["pp"] = None
+            n = len(ps)
+            pp = tuple(q.data_ptr() for q in ps)
+            if pp != cg["pp"]:                               # (a .to() / .float() of the model moves the parameters)
+                cg["pp"], cg["pa"] = pp, (ctypes.c_void_p * n)(*pp)
+            gs = [g if g.is_contiguous() else g.contiguous() for g in gs]
+            gp = tuple(g.data_ptr() for g in gs)
+            klist = []
+            for st in cg["sts"]:
+                k = st["step"] = int(st["step"]) + 1         # (a loaded torch.optim.Adam state carries `step` as a tensor)
+                klist.append(k)
+            device = ps[0].device
+            if min(klist) == max(klist) and all(q.device == device for q in ps):
+                launches = [(device, klist[0], None)]        # the usual case: one launch for the whole group
+            else:                                            # mixed devices / step counts: one launch per (device, step)
+                parts = {}
+                for i, (q, k) in enumerate(zip(ps, klist)):
+                    parts.setdefault((q.device, k), []).append(i)
+                launches = [(d, k, idx) for (d, k), idx in parts.items()]
+            for device, step, idx in launches:
+                if idx is None:
+                    n, ptrs = len(ps), (pp, gp, cg["mp"], cg["vp"])
+                    arrs = (cg["pa"], (ctypes.c_void_p * n)(*gp), cg["ma"], cg["va"], cg["sizes"])
+                else:
+                    n = len(idx)
+                    ptrs = tuple(tuple(t[i] for i in idx) for t in (pp, gp, cg["mp"], cg["vp"]))
+                    arrs = tuple((ctypes.c_void_p * n)(*t) for t in ptrs) + ((ctypes.c_long * n)(*[cg["sizes"][i] for i in idx]),)
                 # The pointer table lives on the device, with a pinned host copy, per (device, tensor count); it is re-uploaded only when
                 # a pointer changed (p, exp_avg, exp_avg_sq never do; the gradients are views of the trainer's flat buffer, which the
                 # caching allocator hands back every iteration) -- so a step is normally ONE asynchronous launch and the host runs ahead.
@@ -416,18 +496,16 @@ class Adam(torch.optim.Optimizer):
                 upload = ent["key"] != ptrs
                 if upload and ent["event"] is not None:
                     ent["event"].synchronize()           # the previous upload has left the pinned buffer
-                arr = lambda k: (ctypes.c_void_p * n)(*ptrs[k])
-                sizes = (ctypes.c_long * n)(*[it[0].numel() for it in items])
                 dev = device.index if device.index is not None else torch.cuda.current_device()
                 stream = torch.cuda.current_stream(device)
-                _lib.check(lib.yf_train_adam_multi_pinned(dev, n, arr(0), arr(1), arr(2), arr(3), sizes, float(group["lr"]), float(b1), float(b2),
-                                                          float(group["eps"]), int(step), ent["dev"].data_ptr(), ent["dev"].numel(),
+                _lib.check(lib.yf_train_adam_multi_pinned(dev, n, arrs[0], arrs[1], arrs[2], arrs[3], arrs[4], float(group["lr"]), float(b1),
+                                                          float(b2), float(group["eps"]), int(step), ent["dev"].data_ptr(), ent["dev"].numel(),
                                                           ent["host"].data_ptr(), int(upload), ctypes.c_void_p(stream.cuda_stream)))
                 if upload:
                     ent["key"] = ptrs
                     ent["event"] = torch.cuda.Event()
                     ent["event"].record(stream)
-                self._keep = items                   # alive until the next step: the launch is asynchronous
+            self._keep = gs                      # alive until the next step: the launch is asynchronous
 
 
 def train_step(model, model_loss, optimizer, imgs, targets):
