@@ -220,6 +220,9 @@ int yf_trainer_forward(yf_trainer t, const float *d_x, int N, const void *const 
                        float *d_head_small, void *d_ws, size_t ws_bytes, void *stream);
 int yf_trainer_backward(yf_trainer t, const float *d_x, const float *d_grad_head_large, const float *d_grad_head_small, int N,
                         const void *const *d_params, void *const *d_grads, void *d_ws, size_t ws_bytes, void *stream);
+/* how many passes ran as a HIP graph replay: a pass whose pointer arguments equal those of the call before it is captured once and
+   replayed from then on (the steady state of a training loop); YF_TRAIN_GRAPH_OFF=1 in the environment disables it */
+int yf_trainer_graph_replays(yf_trainer t, long *forward, long *backward);
 
 /* yf_forward + yf_decode_nms back to back on one stream (heads also returned; may be NULL to use
  * workspace-internal buffers). */

@@ -8,6 +8,7 @@
 """
 import ctypes
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -583,6 +584,38 @@ def test_training_network_against_the_fp64_oracle(yf, dev, seed, tol):
     # the running statistics moved like the module's buffers
     for k in ("conv0.1.running_mean", "res5_5.conv2.1.running_var", "conv4_1_5.1.running_var", "deconv5_1.1.running_mean"):
         assert np.allclose(m.state_dict()[k].cpu().numpy(), sd[k].numpy(), rtol=1e-5, atol=1e-7), k
+
+
+def test_training_passes_replay_as_graphs_with_the_same_results(yf, dev):
+    """A pass whose pointers repeat is captured once and replayed as a HIP graph (yf_train_engine.hip run_pass): ten iterations on one
+    batch in a child process with the graphs on and with YF_TRAIN_GRAPH_OFF=1 end at the same loss to the last printed digit
+    (the kernels are deterministic), and the trainer reports replays only in the first."""
+    import subprocess
+    code = ("import sys, ctypes, torch, numpy as np; sys.path.insert(0, %r)\n"
+            "import yolo_fastest_amd as yf; from yolo_fastest_amd import training, validation as val\n"
+            "dev = torch.device('cuda:0'); io = yf.io_params_for(256); torch.manual_seed(3)\n"
+            "m = yf.YoloFastest(io); m.initialize_weights(); m = m.to(dev).train()\n"
+            "x = (torch.rand(4, 1, 128, 160) - 0.5).to(dev)\n"
+            "t = np.zeros((4, 8, 6), np.float32); t[:, 0] = (0.4, 0.6, 0.3, 0.2, 1, 255.0); td = torch.from_numpy(t).to(dev)\n"
+            "crit = [val.YOLOLossV3(io['anchors'][i], 3, [128, 160, 1], dev, model=m) for i in range(2)]\n"
+            "opt = training.Adam(m.parameters(), lr=0.001)\n"
+            "for _ in range(10): loss = training.train_step(m, crit, opt, x, td)[0]\n"
+            "tr = training._trainer(m, 128, 160, dev); f, b = ctypes.c_long(), ctypes.c_long()\n"
+            "tr.lib.yf_trainer_graph_replays(tr.handle, ctypes.byref(f), ctypes.byref(b))\n"
+            "print('RESULT %%.9g %%d %%d' %% (float(loss.detach()), f.value, b.value))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for off in (False, True):
+        env = dict(os.environ)
+        env.pop("YF_TRAIN_GRAPH_OFF", None)
+        if off:
+            env["YF_TRAIN_GRAPH_OFF"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+        assert r.returncode == 0 and line, r.stderr[-2000:]
+        out[off] = line[0].split()[1:]
+    assert out[False][0] == out[True][0], out
+    assert int(out[True][1]) == 0 and int(out[True][2]) == 0, out
+    assert int(out[False][1]) >= 3 and int(out[False][2]) >= 1, out          # captured when a pointer set comes back, replayed after
 
 
 def test_training_forward_guards(yf, dev):
