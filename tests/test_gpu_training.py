@@ -98,7 +98,8 @@ def test_conv_forward_backward_match_torch(ops, dev, geom):
 # the bandwidth kernels of the large maps (float4 pointwise GEMM, multi-wave weight gradient, row-block depthwise kernels) only take
 # over above a size the small geometries above never reach: (N, Cin, Cout, k, stride, depthwise, H, W)
 BIG = [(64, 8, 32, 1, 1, 0, 64, 80), (40, 48, 8, 1, 1, 0, 64, 80), (24, 16, 96, 1, 1, 0, 32, 80), (6, 8, 8, 3, 1, 1, 64, 160), (5, 16, 16, 5, 1, 1, 32, 80),
-       (3, 8, 8, 3, 1, 1, 36, 72), (12, 24, 24, 3, 2, 0, 64, 80), (32, 1, 8, 3, 2, 0, 64, 160)]
+       (3, 8, 8, 3, 1, 1, 36, 72), (12, 24, 24, 3, 2, 0, 64, 80), (32, 1, 8, 3, 2, 0, 64, 160),
+       (64, 136, 24, 1, 1, 0, 16, 32), (40, 232, 96, 1, 1, 0, 16, 52), (300, 96, 96, 5, 1, 1, 16, 20)]     # weight-stationary GEMM; small planes, many
 
 
 @pytest.mark.parametrize("geom", BIG)

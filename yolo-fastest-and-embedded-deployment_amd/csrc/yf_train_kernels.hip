@@ -250,6 +250,135 @@ __global__ void __launch_bounds__(256) tpw4_mfma_kernel(const float* __restrict_
         }
 }
 
+// The same GEMM with the weights stationary: where the A operand is big (conv4_1_1: 232 x 96 = 89 KB) every wave of tpw4_mfma_kernel pulls
+// its MT x K slice of it through L2 -> L1 again -- 2560 waves x 44 KB at batch 256, more than the activations it multiplies, and the
+// fill path is what the kernel then waits for (the inference engine's pointwise GEMMs hit the same wall in round 1).  Here a workgroup
+// stages its 16 MT rows of A once, as a_lds[k][row] (row stride RS = 16, 48, 48, 80 floats: the four k-rows of a fragment read fall on
+// disjoint banks), and walks pixel blocks with it (persistent grid); the A fragments of a trip are LDS reads.
+template <int MT> __host__ __device__ constexpr int tpw4_rs() { return MT == 1 ? 16 : MT == 4 ? 80 : 48; }
+template <int MT, bool DECONV = false>
+__global__ void __launch_bounds__(256) tpw4_lds_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ bias,
+                                                       const float* __restrict__ addend, float* __restrict__ y, long Q, long HW, int M, int K,
+                                                       long sm, long sk, int mgroups, int Wd = 0)
+{
+    extern __shared__ __attribute__((aligned(16))) float a_lds[];
+    constexpr int RS = tpw4_rs<MT>(), ROWS = 16 * MT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
+    const unsigned lb = (unsigned)xcd_tile(blockIdx.x, gridDim.x);
+    const int m0 = (int)(lb % (unsigned)mgroups) * ROWS;
+    {   // stage A: 8 loads in flight per thread and trip (a rolled copy loop waits for every load before the next: isa_serial_loads.py)
+        const int total = ROWS * K;
+        for (int base = 0; base < total; base += 256 * 8) {
+            float v[8];
+            int dst[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + (int)threadIdx.x;
+                int r, k;
+                if (sk == 1) { k = idx % K; r = idx / K; } else { r = idx % ROWS; k = idx / ROWS; }     // along the contiguous side of A
+                const bool ok = idx < total && m0 + r < M;
+                v[u] = ok ? a[(long)(m0 + r) * sm + (long)k * sk] : 0.f;
+                dst[u] = idx < total ? k * RS + r : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (dst[u] >= 0) a_lds[dst[u]] = v[u];
+        }
+    }
+    __syncthreads();
+    const float* al = a_lds + lk * RS + lr;                 // + k0 RS + 16 t
+    const long npb = (Q + 255) / 256, pstep = gridDim.x / (unsigned)mgroups;
+    constexpr int UK = MT <= 2 ? 8 : 6;
+    for (long pb = lb / (unsigned)mgroups; pb < npb; pb += pstep) {
+        const long q0 = (pb * 4 + wave) * 64;
+        if (q0 >= Q) continue;
+        long q = q0 + 4 * lr;
+        const bool qv = q < Q;
+        if (!qv) q = Q - 4;
+        const long n = q / HW, i = q - n * HW;
+        const float* xp = x + (n * K + lk) * HW + i;
+        f32x4_t acc[MT][4];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][e] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < K; k0 += 4 * UK) {
+            float4 b[UK];
+#pragma unroll
+            for (int j = 0; j < UK; ++j) {
+                if (k0 + 4 * j >= K) break;
+                b[j] = *reinterpret_cast<const float4*>(xp + (long)(k0 + 4 * j) * HW);
+            }
+#pragma unroll
+            for (int j = 0; j < UK; ++j) {
+                if (k0 + 4 * j >= K) break;
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const float av = al[(k0 + 4 * j) * RS + 16 * t];
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[j].x, acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[j].y, acc[t][1], 0, 0, 0);
+                    acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[j].z, acc[t][2], 0, 0, 0);
+                    acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[j].w, acc[t][3], 0, 0, 0);
+                }
+            }
+        }
+        if (!qv) continue;
+        if constexpr (DECONV) {
+            const int Cout = M / 4;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const int m = m0 + 16 * t + 4 * lk;
+                if (m >= M) continue;
+                float* yc = y + (n * Cout + m / 4) * 4 * HW;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int iy = (int)((i + e) / Wd), ix = (int)(i + e - (long)iy * Wd);
+                    float* o = yc + (long)(2 * iy) * (2 * Wd) + 2 * ix;
+                    *reinterpret_cast<float2*>(o) = make_float2(acc[t][e][0], acc[t][e][1]);
+                    *reinterpret_cast<float2*>(o + 2 * Wd) = make_float2(acc[t][e][2], acc[t][e][3]);
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 16 * t + 4 * lk + r;
+                if (m >= M) continue;
+                const long o = (n * M + m) * HW + i;
+                const float bv = bias ? bias[m] : 0.f;
+                float4 v = make_float4(acc[t][0][r] + bv, acc[t][1][r] + bv, acc[t][2][r] + bv, acc[t][3][r] + bv);
+                if (addend) {
+                    const float4 ad = *reinterpret_cast<const float4*>(addend + o);
+                    v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+                }
+                *reinterpret_cast<float4*>(y + o) = v;
+            }
+    }
+}
+template <int MT, bool DECONV>
+static int launch_tpw4_lds(const float* x, const float* a, const float* bias, const float* addend, float* y, long Q, long HW, int M, int K, long sm,
+                           long sk, int mgroups, int Wd, hipStream_t s)
+{
+    static bool attr_done[YF_MAX_DEVICES] = {};
+    const int dev = current_device(), n_cu = device_cu_count(dev);
+    if (dev < 0 || n_cu <= 0) return -1;
+    const size_t lds = (size_t)tpw4_rs<MT>() * K * sizeof(float);
+    if (lds > 96 * 1024) return -1;
+    if (!attr_done[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(tpw4_lds_kernel<MT, DECONV>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+            return -1;
+        attr_done[dev] = true;
+    }
+    const long npb = (Q + 255) / 256;
+    long per = (2L * n_cu + mgroups - 1) / mgroups;                     // ~2 workgroups per CU in all
+    if (per > npb) per = npb;
+    hipLaunchKernelGGL((tpw4_lds_kernel<MT, DECONV>), dim3((unsigned)(per * mgroups)), dim3(256), lds, s, x, a, bias, addend, y, Q, HW, M, K, sm, sk,
+                       mgroups, Wd);
+    return 0;
+}
+
 // backward-data of the ConvTranspose2d(2, 2): dx[ci][p] = sum over k = (co, a, b) of w[ci][k] dY[co][2 iy + a][2 ix + b] -- the pointwise
 // GEMM again, lane (lk, lr) = tap (a, b) = lk of pixel lr, so a k-step is one channel of dY and the lane's operand address only
 // advances by a plane.  One wave = MT 16-channel tiles x 4 pixel tiles of 16 (the old gather kernel recomputed indices per element).
@@ -904,15 +1033,32 @@ __device__ __forceinline__ void tdw_row_window(const float* __restrict__ xr, boo
     }
 }
 
-template <int KS, bool FLIP, int R>
-__global__ void __launch_bounds__(256) tdw_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int C, int H, int W)
+// MANY: small planes (16x20: 20 threads' worth) -- the planes are numbered through the thread index as well, a workgroup covers a dozen
+// of them and the weights are per-lane loads; otherwise one plane per blockIdx.x and wave-uniform weights.
+template <int KS, bool FLIP, int R, bool MANY = false>
+__global__ void __launch_bounds__(256) tdw_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int C, int H, int W,
+                                                       long nplanes = 0)
 {
     constexpr int KK = KS * KS, PAD = (KS - 1) / 2;
-    const int plane = blockIdx.x, c = plane % C, lane = threadIdx.x & 63;
-    const int per_row = W / 4, count = (H / R) * per_row;
-    const int t = blockIdx.y * 256 + threadIdx.x, tc = t < count ? t : count - 1;
+    const int lane = threadIdx.x & 63;
+    const int per_row = W / 4, per_plane = (H / R) * per_row;
+    long plane, t, count;
+    if constexpr (MANY) {
+        const long g = (long)blockIdx.x * 256 + threadIdx.x;
+        count = nplanes * per_plane;
+        const long gc = g < count ? g : count - 1;
+        plane = gc / per_plane;
+        t = g < count ? gc - plane * per_plane : per_plane;      // (>= per_plane: nothing to store)
+        count = per_plane;
+    } else {
+        plane = blockIdx.x;
+        t = blockIdx.y * 256 + threadIdx.x;
+        count = per_plane;
+    }
+    const int c = (int)(plane % C);
+    const int tc = (int)(t < count ? t : count - 1);
     const int rb = tc / per_row, ox0 = (tc - rb * per_row) * 4, oy0 = rb * R;
-    const float* xp = x + (long)plane * H * W;
+    const float* xp = x + plane * H * W;
     float wk[KK];
 #pragma unroll
     for (int i = 0; i < KK; ++i) wk[i] = w[(long)c * KK + (FLIP ? KK - 1 - i : i)];
@@ -940,7 +1086,7 @@ __global__ void __launch_bounds__(256) tdw_rows_kernel(const float* __restrict__
     if (t >= count) return;
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        *reinterpret_cast<float4*>(y + ((long)plane * H + oy0 + r) * W + ox0) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+        *reinterpret_cast<float4*>(y + (plane * H + oy0 + r) * W + ox0) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
 }
 
 // the weight gradient of the same convolutions, same access pattern: per trip a thread takes 4 columns x R rows of dY (R float4) and the
@@ -1107,6 +1253,11 @@ static void launch_tdw_conv(const float* x, const float* w, float* y, int N, int
         if (!tdw_rows_off && H % 4 == 0 && (H / 4) * (W / 4) >= 64) {
             const int count = (H / 4) * (W / 4);
             hipLaunchKernelGGL((tdw_rows_kernel<KS, FLIP, 4>), dim3(N * C, (count + 255) / 256), dim3(256), 0, s, x, w, y, C, H, W);
+            return;
+        }
+        if (!tdw_rows_off && H % 4 == 0 && (long)N * C * (H / 4) * (W / 4) >= 16384) {      // small planes, many of them
+            const long total = (long)N * C * (H / 4) * (W / 4);
+            hipLaunchKernelGGL((tdw_rows_kernel<KS, FLIP, 4, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, y, C, H, W, (long)N * C);
             return;
         }
     }
@@ -1754,6 +1905,16 @@ static void launch_tpw_gemm(const float* x, const float* a, const float* bias, c
         mgroups = (tiles + mt - 1) / mt;
     }
     const long wg = (Q + 255) / 256 * mgroups;
+    // big A operand and enough pixel blocks per workgroup to pay for staging it: the weight-stationary form
+    static const bool lds_off = getenv("YF_TPW_LDS_OFF") != nullptr;
+    if (!old_only && !lds_off && HW % 4 == 0 && K % 4 == 0 && Q % 4 == 0 && (long)M * K >= 8192 && Q >= 32768) {
+        int rc = -1;
+        if (mt == 1) rc = launch_tpw4_lds<1, false>(x, a, bias, addend, y, Q, HW, M, K, sm, sk, mgroups, 0, s);
+        else if (mt == 2) rc = launch_tpw4_lds<2, false>(x, a, bias, addend, y, Q, HW, M, K, sm, sk, mgroups, 0, s);
+        else if (mt == 3) rc = launch_tpw4_lds<3, false>(x, a, bias, addend, y, Q, HW, M, K, sm, sk, mgroups, 0, s);
+        else rc = launch_tpw4_lds<4, false>(x, a, bias, addend, y, Q, HW, M, K, sm, sk, mgroups, 0, s);
+        if (rc == 0) return;
+    }
     if (!old_only && HW % 4 == 0 && K % 4 == 0 && Q % 4 == 0) {
 #define YF_PW4(MT_) hipLaunchKernelGGL(tpw4_mfma_kernel<MT_>, dim3((unsigned)wg), dim3(256), 0, s, x, a, bias, addend, y, Q, HW, M, K, sm, sk, mgroups)
         if (mt == 1) YF_PW4(1); else if (mt == 2) YF_PW4(2); else if (mt == 3) YF_PW4(3); else YF_PW4(4);
@@ -1982,10 +2143,12 @@ void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, 
     if (depthwise && (k == 3 || k == 5)) {
         long chunks = (P + 2047) / 2048;                                // ~8 pixels per thread
         while (chunks * Cout > 4096 && chunks > 1) chunks = (chunks + 1) / 2;
+        const bool rows = !tdw_rows_off && stride == 1 && W % 4 == 0 && H % 4 == 0 && (long)N * (H / 4) * (W / 4) >= 2048;
+        if (rows && (long)N * (H / 4) * (W / 4) / 512 < chunks) chunks = (long)N * (H / 4) * (W / 4) / 512;   // 16 outputs per thread and trip
         if (chunks > fit) chunks = fit < 1 ? 1 : fit;
         float* out = tsum_out(scratch, chunks, nw, dw, defer);
         const dim3 grid((unsigned)chunks, Cout);
-        if (!tdw_rows_off && stride == 1 && W % 4 == 0 && H % 4 == 0 && (long)N * (H / 4) * (W / 4) >= 256 * chunks) {
+        if (rows) {
             if (k == 3) hipLaunchKernelGGL((tdw_wgrad_rows_kernel<3, 4>), grid, dim3(256), 0, s, x, dy, out, N, Cout, H, W, nw);
             else hipLaunchKernelGGL((tdw_wgrad_rows_kernel<5, 4>), grid, dim3(256), 0, s, x, dy, out, N, Cout, H, W, nw);
             tsum_finish(out, scratch, chunks, nw, dw, s, defer);
