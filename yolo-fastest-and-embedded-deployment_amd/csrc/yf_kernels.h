@@ -302,8 +302,12 @@ size_t train_loss_workspace_bytes(int N, int fh, int fw);
 void launch_train_loss(const float* head, int N, int fh, int fw, const float* anc6, const float* targets, int T, float ignore_thres,
                        void* work, float* losses, float* grad, hipStream_t s);
 // training-step operators (yf_train_kernels.hip): NCHW fp32, correctness-first
+// BatchNorm's partial sums out of the conv's epilogue (the large maps): the caller sets part / cap_bytes (a region no concurrent kernel
+// uses: behind BatchNorm's own megabyte of the scratch), the conv launcher sets count (> 0: it left count pairs per channel in
+// part[channel][block]), launch_tbn_fwd then adds those instead of reading z for its statistics
+struct TStatPart { float2* part; size_t cap_bytes; long count; };
 void launch_tconv_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W, int Cout, int k, int stride,
-                      int depthwise, hipStream_t s);
+                      int depthwise, hipStream_t s, TStatPart* st = nullptr);
 void launch_tconv_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int k, int stride, int depthwise,
                            hipStream_t s, const float* addend = nullptr);
 // split weight-gradient reductions, summed once per pass: a layer's launcher puts its slabs into `slab` and records an entry instead of
@@ -324,7 +328,7 @@ void launch_tdeconv_bwd_weight(const float* x, const float* dy, float* dw, int N
                                hipStream_t s, TSumDefer* defer = nullptr);
 size_t train_scratch_bytes();
 void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* stats, float* y, int N,
-                    int C, long HW, int relu, void* scratch, hipStream_t s, const float* residual = nullptr);
+                    int C, long HW, int relu, void* scratch, hipStream_t s, const float* residual = nullptr, const TStatPart* st = nullptr);
 void launch_tbn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, float* dgamma, float* dbeta, float* dx,
                     int N, int C, long HW, int relu, void* scratch, hipStream_t s);
 int launch_tadam_multi(int nt, float* const* p, const float* const* g, float* const* m, float* const* v, const long* sizes, double lr, double b1,

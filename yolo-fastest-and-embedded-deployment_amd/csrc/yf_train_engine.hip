@@ -297,15 +297,17 @@ int yf_train_unit_forward(int device, int deconv, const float* d_x, const float*
     HIP_OK(hipSetDevice(device));
     hipStream_t s = (hipStream_t)stream;
     long HWo;
+    // the conv may leave BatchNorm's partial sums behind the first MB of the scratch (yf_kernels.h: TStatPart)
+    yf::TStatPart sp{reinterpret_cast<float2*>(static_cast<char*>(d_scratch) + (1 << 20)), yf::train_scratch_bytes() - (1 << 20), 0};
     if (deconv) {
         yf::launch_tdeconv_fwd(d_x, d_w, d_z, N, Cin, H, W, Cout, s);
         HWo = 4L * H * W;
     } else {
-        yf::launch_tconv_fwd(d_x, d_w, nullptr, d_z, N, Cin, H, W, Cout, k, stride, depthwise, s);
+        yf::launch_tconv_fwd(d_x, d_w, nullptr, d_z, N, Cin, H, W, Cout, k, stride, depthwise, s, &sp);
         const int pad = (k - 1) / 2;
         HWo = (long)((H + 2 * pad - k) / stride + 1) * ((W + 2 * pad - k) / stride + 1);
     }
-    yf::launch_tbn_fwd(d_z, d_gamma, d_beta, d_running_mean, d_running_var, d_stats, d_y, N, Cout, HWo, relu, d_scratch, s);
+    yf::launch_tbn_fwd(d_z, d_gamma, d_beta, d_running_mean, d_running_var, d_stats, d_y, N, Cout, HWo, relu, d_scratch, s, nullptr, &sp);
     HIP_OK(hipGetLastError());
     return YF_OK;
 }
@@ -405,8 +407,9 @@ static int trainer_forward_launches(yf_trainer t, const float* d_x, int N, const
         }
         float* z = w.act + L.z * N;
         float* y = w.act + L.y * N;
+        yf::TStatPart sp{reinterpret_cast<float2*>(w.scratch + (1 << 20)), yf::train_scratch_bytes() - (1 << 20), 0};
         if (S.kind == K_DECONV) yf::launch_tdeconv_fwd(x, P(L.p0), z, N, L.Cin, L.Hin, L.Win, L.Cout, s);
-        else yf::launch_tconv_fwd(x, P(L.p0), nullptr, z, N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, s);
+        else yf::launch_tconv_fwd(x, P(L.p0), nullptr, z, N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, s, &sp);
         tm.tick("conv", S.name);
         float* rm = d_bn_buffers ? static_cast<float*>(d_bn_buffers[2 * bn]) : nullptr;
         float* rv = d_bn_buffers ? static_cast<float*>(d_bn_buffers[2 * bn + 1]) : nullptr;
@@ -416,7 +419,7 @@ static int trainer_forward_launches(yf_trainer t, const float* d_x, int N, const
             const TLayer& R = t->L[L.res_from];
             residual = R.in == -1 ? d_x : w.act + t->L[R.in].y * N;
         }
-        yf::launch_tbn_fwd(z, P(L.p0 + 1), P(L.p0 + 2), rm, rv, w.stats + L.st, y, N, L.Cout, (long)L.Ho * L.Wo, S.relu, w.scratch, s, residual);
+        yf::launch_tbn_fwd(z, P(L.p0 + 1), P(L.p0 + 2), rm, rv, w.stats + L.st, y, N, L.Cout, (long)L.Ho * L.Wo, S.relu, w.scratch, s, residual, &sp);
         tm.tick("bn", S.name);
         if (i == t->i_deconv) {                                                 // torch.cat((conv4_2, deconv5_1), 1)        :209
             const TLayer& A = t->L[t->i_conv4_2];

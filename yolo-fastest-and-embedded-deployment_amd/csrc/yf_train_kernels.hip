@@ -153,6 +153,45 @@ __global__ void __launch_bounds__(256) tpw_mfma_kernel(const float* __restrict__
     }
 }
 
+// ---- BatchNorm statistics out of the conv's epilogue (the large maps: one pass over z less).  A workgroup leaves one (sum, sum of
+// squares) pair per output channel and pixel block in `stat` ([channel][block], float2 of values summed in double over the block);
+// tbn_stats_from_parts_kernel adds a channel's pairs in double, in block order.  Deterministic: fixed rotation / wave order.
+template <int N_> __device__ __forceinline__ float row16_rotate(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N_, 0xf, 0xf, false));   // row_ror:N_
+}
+__device__ __forceinline__ float row16_sum(float v)         // the sum over the 16 lanes of a DPP row (= the lanes lr of one lk), in every lane
+{
+    v += row16_rotate<8>(v);
+    v += row16_rotate<4>(v);
+    v += row16_rotate<2>(v);
+    v += row16_rotate<1>(v);
+    return v;
+}
+// rows 16 t + 4 lk + r of a wave's tile: acc[t][e][r] = pixel e of row r; lanes with ok == false hold nothing.  A pair covers the 64
+// pixels of the WAVE (no workgroup barrier in a kernel that lives on its waves not waiting for each other): summed in fp32 by a fixed
+// tree -- 4 in the lane, the 16 lanes of the row by DPP rotations -- the pairs themselves are then added in double.
+template <int MT>
+__device__ __forceinline__ void tile_stats_store(const f32x4_t (&acc)[MT][4], bool ok, int m0, int M, float2* __restrict__ stat, long nwaves, long wave_index)
+{
+    const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s1 = 0.f, s2 = 0.f;
+            if (ok) {
+                const float a = acc[t][0][r], b = acc[t][1][r], c = acc[t][2][r], d = acc[t][3][r];
+                s1 = (a + b) + (c + d);
+                s2 = (a * a + b * b) + (c * c + d * d);
+            }
+            s1 = row16_sum(s1);
+            s2 = row16_sum(s2);
+            const int m = m0 + 16 * t + 4 * lk + r;
+            if (lr == 0 && m < M) stat[(long)m * nwaves + wave_index] = make_float2(s1, s2);
+        }
+}
+
 // The same GEMM for maps with many pixels, built for bandwidth: every lane loads float4 = 4 consecutive pixels of ONE k-row (a wave's
 // load instruction covers 4 rows x 256 B), and MFMA e of a k-step takes element e -- column lr of accumulator e is pixel 4 lr + e, so
 // the lane ends up with 4 consecutive pixels of each of its 4 output rows and stores float4 too.  One wave = MT 16-channel tiles x 64
@@ -164,13 +203,13 @@ __global__ void __launch_bounds__(256) tpw_mfma_kernel(const float* __restrict__
 template <int MT, bool DECONV = false>
 __global__ void __launch_bounds__(256) tpw4_mfma_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ bias,
                                                         const float* __restrict__ addend, float* __restrict__ y, long Q, long HW, int M, int K,
-                                                        long sm, long sk, int mgroups, int Wd = 0)
+                                                        long sm, long sk, int mgroups, int Wd = 0, float2* __restrict__ stat = nullptr)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
     const unsigned lb = (unsigned)xcd_tile(blockIdx.x, gridDim.x);
     const int m0 = (int)(lb % (unsigned)mgroups) * (16 * MT);
     const long q0 = ((long)(lb / (unsigned)mgroups) * 4 + wave) * 64;
-    if (q0 >= Q) return;
+    if (q0 >= Q && !stat) return;                           // (with statistics a wave past the end still leaves its (zero) pairs)
     long q = q0 + 4 * lr;
     const bool qv = q < Q;
     if (!qv) q = Q - 4;
@@ -214,6 +253,9 @@ __global__ void __launch_bounds__(256) tpw4_mfma_kernel(const float* __restrict_
             if (k0 + 4 * j >= K) break;
             step(b[j], av[j]);
         }
+    }
+    if constexpr (!DECONV && MT <= 2) {
+        if (stat) tile_stats_store<MT>(acc, qv, m0, M, stat, (Q + 255) / 256 * 4, (long)(lb / (unsigned)mgroups) * 4 + wave);
     }
     if (!qv) return;
     if constexpr (DECONV) {
@@ -1038,7 +1080,7 @@ __device__ __forceinline__ void tdw_row_window(const float* __restrict__ xr, boo
 // of them and the weights are per-lane loads; otherwise one plane per blockIdx.x and wave-uniform weights.
 template <int KS, bool FLIP, int R, bool MANY = false>
 __global__ void __launch_bounds__(256) tdw_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int C, int H, int W,
-                                                       long nplanes = 0)
+                                                       long nplanes = 0, float2* __restrict__ stat = nullptr)
 {
     constexpr int KK = KS * KS, PAD = (KS - 1) / 2;
     const int lane = threadIdx.x & 63;
@@ -1082,6 +1124,28 @@ __global__ void __launch_bounds__(256) tdw_rows_kernel(const float* __restrict__
             for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
                 for (int o = 0; o < 4; ++o) acc[r][o] = fmaf(win[o + kx], wk[ky * KS + kx], acc[r][o]);
+        }
+    }
+    if constexpr (!MANY && !FLIP) {
+        if (stat) {                                         // BatchNorm statistics of this workgroup's outputs (one channel): see tile_stats_store
+            __shared__ double red[4][2];
+            double s1 = 0, s2 = 0;
+            if (t < count) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double a = acc[r][0], b = acc[r][1], c2 = acc[r][2], d = acc[r][3];
+                    s1 += (a + b) + (c2 + d);
+                    s2 += (a * a + b * b) + (c2 * c2 + d * d);
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o); s2 += __shfl_down(s2, o); }
+            if (lane == 0) { red[threadIdx.x >> 6][0] = s1; red[threadIdx.x >> 6][1] = s2; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const long nblocks = (long)(gridDim.x / C) * gridDim.y, block = (long)(plane / C) * gridDim.y + blockIdx.y;
+                stat[(long)c * nblocks + block] = make_float2((float)((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])),
+                                                              (float)((red[0][1] + red[1][1]) + (red[2][1] + red[3][1])));
+            }
         }
     }
     if (t >= count) return;
@@ -1245,15 +1309,25 @@ __global__ void tdw3s2_bwd_data_kernel(const float* __restrict__ dy, const float
     *reinterpret_cast<float2*>(o + W) = make_float2(fmaf(d00, k[7], d10 * k[1]), fmaf(d00, k[8], fmaf(d01, k[6], fmaf(d10, k[2], d11 * k[0]))));
 }
 
+// where a conv kernel may leave BatchNorm's partial sums: behind the first MB of the scratch (BatchNorm's own chunk pairs)
+static inline bool tstat_room(TStatPart* st, long count, int C)
+{
+    if (!st || !st->part) return false;
+    static const bool off = getenv("YF_TSTAT_OFF") != nullptr;
+    if (off || (size_t)count * C * sizeof(float2) > st->cap_bytes) return false;
+    st->count = count;
+    return true;
+}
 static const bool tdw_rows_off = getenv("YF_TDW_ROWS_OFF") != nullptr;
 template <int KS, int S, bool FLIP>
-static void launch_tdw_conv(const float* x, const float* w, float* y, int N, int C, int H, int W, int Ho, int Wo, hipStream_t s)
+static void launch_tdw_conv(const float* x, const float* w, float* y, int N, int C, int H, int W, int Ho, int Wo, hipStream_t s, TStatPart* st = nullptr)
 {
     if constexpr (S == 1) {
         // large maps: 4 rows per thread (see tdw_rows_kernel); the plane must still give a workgroup something to do
         if (!tdw_rows_off && H % 4 == 0 && (H / 4) * (W / 4) >= 64) {
-            const int count = (H / 4) * (W / 4);
-            hipLaunchKernelGGL((tdw_rows_kernel<KS, FLIP, 4>), dim3(N * C, (count + 255) / 256), dim3(256), 0, s, x, w, y, C, H, W);
+            const int count = (H / 4) * (W / 4), ny = (count + 255) / 256;
+            float2* sp = (!FLIP && tstat_room(st, (long)N * ny, C)) ? st->part : nullptr;
+            hipLaunchKernelGGL((tdw_rows_kernel<KS, FLIP, 4>), dim3(N * C, ny), dim3(256), 0, s, x, w, y, C, H, W, 0L, sp);
             return;
         }
         if (!tdw_rows_off && H % 4 == 0 && (long)N * C * (H / 4) * (W / 4) >= 16384) {      // small planes, many of them
@@ -1513,6 +1587,19 @@ __global__ void __launch_bounds__(256) tbn_stats_kernel(const float* __restrict_
 #pragma unroll
             for (int j = 0; j < V; ++j) { const double e = tbn_at<V>(v, j); s += e; ss += e * e; }
         }
+    }
+    tbn_block_store(s, ss, scratch + (long)c * TBN_MAXCHUNK * 2);
+}
+
+// the statistics from the pairs a conv kernel left per pixel block (tile_stats_store): grid (chunks, C), a chunk's share of the channel's
+// pairs added in double -> the chunk pair the elementwise kernel expects from tbn_stats_kernel
+__global__ void __launch_bounds__(256) tbn_stats_from_parts_kernel(const float2* __restrict__ part, long count, double* __restrict__ scratch)
+{
+    const int c = blockIdx.y;
+    double s = 0, ss = 0;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < count; p += (long)gridDim.x * 256) {
+        const float2 v = part[(long)c * count + p];
+        s += (double)v.x; ss += (double)v.y;
     }
     tbn_block_store(s, ss, scratch + (long)c * TBN_MAXCHUNK * 2);
 }
@@ -1893,8 +1980,9 @@ __global__ void __launch_bounds__(256) tadam_multi_kernel(const TAdamEntry* __re
 static inline unsigned nblk(long total) { return (unsigned)((total + 255) / 256); }
 
 static void launch_tpw_gemm(const float* x, const float* a, const float* bias, const float* addend, float* y, long Q, long HW, int M, int K, long sm,
-                            long sk, hipStream_t s)
+                            long sk, hipStream_t s, TStatPart* st = nullptr)
 {
+    if (st) st->count = 0;
     const int wm = tpw_waves_m(M), wq = 4 / wm;
     const unsigned my = (unsigned)((M + 16 * wm - 1) / (16 * wm));
     const long b4 = (Q + 64L * wq - 1) / (64L * wq), b1 = (Q + 16L * wq - 1) / (16L * wq);     // workgroups along the pixels, NT = 4 / 1
@@ -1908,7 +1996,8 @@ static void launch_tpw_gemm(const float* x, const float* a, const float* bias, c
     const long wg = (Q + 255) / 256 * mgroups;
     // big A operand and enough pixel blocks per workgroup to pay for staging it: the weight-stationary form
     static const bool lds_off = getenv("YF_TPW_LDS_OFF") != nullptr;
-    if (!old_only && !lds_off && HW % 4 == 0 && K % 4 == 0 && Q % 4 == 0 && (long)M * K >= 8192 && Q >= 32768) {
+    const bool want_stat = st && !bias && !addend && mt <= 2 && HW % 4 == 0 && K % 4 == 0 && Q % 4 == 0 && !old_only;
+    if (!want_stat && !old_only && !lds_off && HW % 4 == 0 && K % 4 == 0 && Q % 4 == 0 && (long)M * K >= 8192 && Q >= 32768) {
         int rc = -1;
         if (mt == 1) rc = launch_tpw4_lds<1, false>(x, a, bias, addend, y, Q, HW, M, K, sm, sk, mgroups, 0, s);
         else if (mt == 2) rc = launch_tpw4_lds<2, false>(x, a, bias, addend, y, Q, HW, M, K, sm, sk, mgroups, 0, s);
@@ -1917,7 +2006,8 @@ static void launch_tpw_gemm(const float* x, const float* a, const float* bias, c
         if (rc == 0) return;
     }
     if (!old_only && HW % 4 == 0 && K % 4 == 0 && Q % 4 == 0) {
-#define YF_PW4(MT_) hipLaunchKernelGGL(tpw4_mfma_kernel<MT_>, dim3((unsigned)wg), dim3(256), 0, s, x, a, bias, addend, y, Q, HW, M, K, sm, sk, mgroups)
+        float2* sp = (want_stat && tstat_room(st, (Q + 255) / 256 * 4, M)) ? st->part : nullptr;
+#define YF_PW4(MT_) hipLaunchKernelGGL(tpw4_mfma_kernel<MT_>, dim3((unsigned)wg), dim3(256), 0, s, x, a, bias, addend, y, Q, HW, M, K, sm, sk, mgroups, 0, sp)
         if (mt == 1) YF_PW4(1); else if (mt == 2) YF_PW4(2); else if (mt == 3) YF_PW4(3); else YF_PW4(4);
 #undef YF_PW4
         return;
@@ -1928,11 +2018,13 @@ static void launch_tpw_gemm(const float* x, const float* a, const float* bias, c
         hipLaunchKernelGGL(tpw_mfma_kernel<1>, dim3((unsigned)(b1 * my)), dim3(256), 0, s, x, a, bias, addend, y, Q, HW, M, K, sm, sk);
 }
 void launch_tconv_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W, int Cout, int k, int stride,
-                      int depthwise, hipStream_t s)
+                      int depthwise, hipStream_t s, TStatPart* st)
 {
     const int pad = (k - 1) / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    if (st) st->count = 0;
+    if (st && (long)N * Ho * Wo <= 4096 * 8) st = nullptr;              // BatchNorm's one-launch kernels read z once anyway
     if (!depthwise && k == 1 && stride == 1) {
-        launch_tpw_gemm(x, w, bias, nullptr, y, (long)N * H * W, (long)H * W, Cout, Cin, (long)Cin, 1L, s);
+        launch_tpw_gemm(x, w, bias, nullptr, y, (long)N * H * W, (long)H * W, Cout, Cin, (long)Cin, 1L, s, st);
         return;
     }
     static const bool s2_off = getenv("YF_TCONV3S2_OFF") != nullptr;
@@ -1971,9 +2063,9 @@ void launch_tconv_fwd(const float* x, const float* w, const float* bias, float* 
         return;
     }
     if (depthwise && !bias && Wo % 4 == 0) {
-        if (k == 3 && stride == 1) return launch_tdw_conv<3, 1, false>(x, w, y, N, Cout, H, W, Ho, Wo, s);
+        if (k == 3 && stride == 1) return launch_tdw_conv<3, 1, false>(x, w, y, N, Cout, H, W, Ho, Wo, s, st);
         if (k == 3 && stride == 2) return launch_tdw_conv<3, 2, false>(x, w, y, N, Cout, H, W, Ho, Wo, s);
-        if (k == 5 && stride == 1) return launch_tdw_conv<5, 1, false>(x, w, y, N, Cout, H, W, Ho, Wo, s);
+        if (k == 5 && stride == 1) return launch_tdw_conv<5, 1, false>(x, w, y, N, Cout, H, W, Ho, Wo, s, st);
     }
     hipLaunchKernelGGL(tconv_fwd_kernel, dim3(nblk((long)N * Cout * Ho * Wo)), dim3(256), 0, s, x, w, bias, y, N, Cin, H, W, Cout, Ho, Wo, k, stride, depthwise);
 }
@@ -2255,7 +2347,7 @@ void launch_tdeconv_bwd_weight(const float* x, const float* dy, float* dw, int N
     hipLaunchKernelGGL(tdeconv_bwd_weight_kernel, dim3((unsigned)(nw * nchunk)), dim3(256), 0, s, x, dy, dw, N, Cin, H, W, Cout, nchunk);
 }
 // one scratch for the split reductions of a stream: BatchNorm partial pairs (256 KB) or weight-gradient slabs (all of it)
-size_t train_scratch_bytes() { return (size_t)16 << 20; }
+size_t train_scratch_bytes() { return (size_t)32 << 20; }
 static inline unsigned tbn_apply_blocks(int N, int C, long HW, int V, bool flat)
 {
     const long U = tbn_units(N, HW, V, flat);
@@ -2274,7 +2366,7 @@ static inline int tbn_chunks(int N, int C, long HW, int V, bool flat)
 // scratch: >= 1 MB of device memory (partial sums; needs no initialisation); C <= 256
 // residual (optional, like y): y = bn(x) [relu] + residual
 void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* stats, float* y, int N,
-                    int C, long HW, int relu, void* scratch, hipStream_t s, const float* residual)
+                    int C, long HW, int relu, void* scratch, hipStream_t s, const float* residual, const TStatPart* st)
 {
     static const bool small4_off = getenv("YF_TBN_SMALL4_OFF") != nullptr;
     if (!small4_off && HW % 4 == 0 && (long)N * HW <= 4096 * 8) {
@@ -2291,14 +2383,18 @@ void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float
     }
     static const bool flat_off = getenv("YF_TBN_FLAT_OFF") != nullptr;
     const bool flat = !flat_off && HW % 4 == 0 && HW % 1024 != 0;      // float4 numbered across the frames (small / ragged planes)
-    const int V = (flat || (HW % 4 == 0 && HW >= 1024)) ? 4 : 1, nchunk = tbn_chunks(N, C, HW, V, flat);
+    const bool parts = st && st->count > 0;                             // the conv left the partial sums: no pass over z for them
+    int pchunks = parts ? (int)((st->count + 1023) / 1024) : 0;        // >= 4 pairs per thread
+    if (pchunks > 64) pchunks = 64;
+    const int V = (flat || (HW % 4 == 0 && HW >= 1024)) ? 4 : 1, nchunk = parts ? pchunks : tbn_chunks(N, C, HW, V, flat);
     const dim3 g1(nchunk, C), g2(tbn_apply_blocks(N, C, HW, V, flat), C);
+    if (parts) hipLaunchKernelGGL(tbn_stats_from_parts_kernel, dim3(pchunks, C), dim3(256), 0, s, (const float2*)st->part, st->count, (double*)scratch);
     if (flat) {
-        hipLaunchKernelGGL((tbn_stats_kernel<4, true>), g1, dim3(256), 0, s, x, N, C, HW, (double*)scratch);
+        if (!parts) hipLaunchKernelGGL((tbn_stats_kernel<4, true>), g1, dim3(256), 0, s, x, N, C, HW, (double*)scratch);
         hipLaunchKernelGGL((tbn_apply_kernel<4, true>), g2, dim3(256), 0, s, x, (const double*)scratch, nchunk, gamma, beta, y, N, C, HW, relu, 1e-5f, 0.1f,
                            stats, running_mean, running_var, residual);
     } else if (V == 4) {
-        hipLaunchKernelGGL(tbn_stats_kernel<4>, g1, dim3(256), 0, s, x, N, C, HW, (double*)scratch);
+        if (!parts) hipLaunchKernelGGL(tbn_stats_kernel<4>, g1, dim3(256), 0, s, x, N, C, HW, (double*)scratch);
         hipLaunchKernelGGL(tbn_apply_kernel<4>, g2, dim3(256), 0, s, x, (const double*)scratch, nchunk, gamma, beta, y, N, C, HW, relu, 1e-5f, 0.1f,
                            stats, running_mean, running_var, residual);
     } else {
