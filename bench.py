@@ -210,6 +210,9 @@ def live_train_traffic(batch, iters=3):
         shutil.rmtree(work, ignore_errors=True)
 
 
+TRAIN_WARMUP = 8
+
+
 def train_records(dev, pmc):
     """The training iteration (train.py:111-132: zero_grad, train-mode forward, two-head loss, backward, Adam) on synthetic frames at the
     reference's batch size (16, _config.py:41) and at 256: examples/s, and the physical roofs of the iteration -- flops over the fp32
@@ -236,7 +239,7 @@ def train_records(dev, pmc):
         td = torch.from_numpy(t).to(dev)
         crit = [val.YOLOLossV3(io["anchors"][i], 3, io["input_shape"], dev, model=m) for i in range(2)]
         opt = training.Adam(m.parameters(), lr=0.001)
-        for _ in range(3):
+        for _ in range(TRAIN_WARMUP):                          # (the trainer captures its passes as graphs once their pointers repeat: iterations 2-5)
             training.train_step(m, crit, opt, x, td)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -246,7 +249,7 @@ def train_records(dev, pmc):
         dt = (time.perf_counter() - t0) / steps
         flops = TRAIN_FLOPS_PER_EXAMPLE[256] * batch
         rec = {"workload": "train.py:111-132 iteration (zero_grad, train-mode forward, two-head loss, backward, Adam), 320x256, synthetic frames and targets",
-               "batch": batch, "steps": steps, "warmup": 3, "dtype": "f32", "value": round(batch / dt, 1), "unit": "examples/s",
+               "batch": batch, "steps": steps, "warmup": TRAIN_WARMUP, "dtype": "f32", "value": round(batch / dt, 1), "unit": "examples/s",
                "ms_per_iteration": round(1e3 * dt, 3), "loss_finite": bool(torch.isfinite(loss.detach()).item()),
                "roofline": {"flops_per_iteration": flops, "compute": {"achieved": round(flops / dt / 1e12, 2), "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
                                                                      "frac": round(flops / dt / 1e12 / FP32_PEAK_TF, 4)},

@@ -17,7 +17,7 @@ from yolo_fastest_amd import training, validation as val  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--steps", type=int, default=20)
-ap.add_argument("--warmup", type=int, default=3)
+ap.add_argument("--warmup", type=int, default=8)
 ap.add_argument("--res", type=int, default=256)
 ap.add_argument("--cpu", action="store_true")
 ap.add_argument("--json", action="store_true", help="also print one JSON line (metric, value, ms per iteration, cpu baseline)")
