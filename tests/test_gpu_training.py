@@ -800,7 +800,9 @@ def test_training_operators_random_geometries(ops, dev):
 
 def test_trainer_is_identical_to_the_per_block_path(yf, golden, dev):
     """yf_trainer_forward / yf_trainer_backward (the graph walked in C++) against the same kernels orchestrated from Python one block at
-    a time (model.train_impl = "ops"): the launches are the same, so heads, every gradient and the running statistics are bit-identical."""
+    a time (model.train_impl = "ops"): the forward's launches are the same, so heads and running statistics are bit-identical; in the
+    backward the trainer takes BatchNorm's two sums per channel out of the depthwise data-gradient kernel of the layer above where it
+    can (fp32 over a workgroup's pixels, then double) and the per-block path reduces dy and z itself (double throughout): gradients equal to rounding."""
     gt = golden("golden_train_256")
     x = ((torch.from_numpy(gt["input_u8"][:6].astype(np.float32))[:, None] - 128.0) / 255.0).to(dev)
     out = {}
@@ -816,8 +818,12 @@ def test_trainer_is_identical_to_the_per_block_path(yf, golden, dev):
         out[impl] = (hl.detach(), hs.detach(), [p.grad.clone() for p in m.parameters()], [b.clone() for b in m.buffers()])
     a, b = out["trainer"], out["ops"]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    for (n, _), ga, gb in zip(yf.YoloFastest(yf.io_params_for(256)).named_parameters(), a[2], b[2]):
-        assert torch.equal(ga, gb), n
+    zero = gt["grad_absmax_f64"] < 1e-9       # gradients that are zero in exact arithmetic (a BatchNorm bias in front of a conv + BatchNorm): noise
+    for (n, _), ga, gb, z in zip(yf.YoloFastest(yf.io_params_for(256)).named_parameters(), a[2], b[2], zero):
+        if z:
+            assert ga.abs().max() <= 1e-2 and gb.abs().max() <= 1e-2, n
+            continue
+        assert (ga - gb).abs().max() <= 2e-5 * gb.abs().max(), (n, float((ga - gb).abs().max()), float(gb.abs().max()))
     for ba, bb in zip(a[3], b[3]):
         assert torch.equal(ba, bb)
     # two forwards before the first backward: each pass owns its tape

@@ -308,8 +308,13 @@ void launch_train_loss(const float* head, int N, int fh, int fw, const float* an
 struct TStatPart { float2* part; size_t cap_bytes; long count; };
 void launch_tconv_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W, int Cout, int k, int stride,
                       int depthwise, hipStream_t s, TStatPart* st = nullptr);
+// The backward's BatchNorm sums of the layer BELOW out of the data-gradient kernel that produces its dy (the large maps): dx of this
+// layer IS dy of the layer whose output it consumed, so the epilogue reads that layer's z (the one extra pass) and leaves (sum dy_eff,
+// sum dy_eff xhat) pairs per channel; launch_tbn_bwd adds them instead of reading dy and z for its reduction.  The caller fills
+// z / stats / gamma / beta / relu of the layer below and part / cap_bytes; the launcher sets count (> 0: pairs left).
+struct TBnRed { const float* z; const float* stats; const float* gamma; const float* beta; int relu; float2* part; size_t cap_bytes; long count; };
 void launch_tconv_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int k, int stride, int depthwise,
-                           hipStream_t s, const float* addend = nullptr);
+                           hipStream_t s, const float* addend = nullptr, TBnRed* red = nullptr);
 // split weight-gradient reductions, summed once per pass: a layer's launcher puts its slabs into `slab` and records an entry instead of
 // launching its own sum; launch_tsum_multi adds them all (offsets relative to slab / dst_base, so the table is the same every iteration)
 struct TSumEntry { long part_off, dst_off, nw, blk0; int nsplit, spl; };
@@ -330,7 +335,7 @@ size_t train_scratch_bytes();
 void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* stats, float* y, int N,
                     int C, long HW, int relu, void* scratch, hipStream_t s, const float* residual = nullptr, const TStatPart* st = nullptr);
 void launch_tbn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, float* dgamma, float* dbeta, float* dx,
-                    int N, int C, long HW, int relu, void* scratch, hipStream_t s);
+                    int N, int C, long HW, int relu, void* scratch, hipStream_t s, const TBnRed* red = nullptr);
 int launch_tadam_multi(int nt, float* const* p, const float* const* g, float* const* m, float* const* v, const long* sizes, double lr, double b1,
                        double b2, double eps, int step, void* d_table, void* h_table, int upload, hipStream_t s);
 void launch_tchan_sum(const float* dy, float* out, int N, int C, long HW, hipStream_t s, void* scratch = nullptr /* >= 64 C doubles */);

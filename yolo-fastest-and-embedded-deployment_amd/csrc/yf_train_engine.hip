@@ -453,13 +453,26 @@ static int trainer_backward_launches(yf_trainer t, const float* d_x, const float
     yf::TSumDefer* dfr = flat ? &defer : nullptr;
     auto other = [&](int a, int b, int c) { for (int i = 0; i < 4; ++i) if (i != a && i != b && i != c) return i; return -1; };
     // backward of one conv + BN (+ ReLU) unit: gradient of its output in gy -> parameter gradients, gradient of its input in w.g[ret]
+    // The data-gradient kernel of layer i produces dy of layer j = its input; where that IS the whole gradient of j's output (every layer
+    // but the two branch points, whose second gradient is added afterwards) it also leaves j's backward BatchNorm sums (TBnRed): j's
+    // backward then skips its reduction pass over dy and z.  red_for: the layer the pairs in the scratch belong to.
+    yf::TBnRed red{nullptr, nullptr, nullptr, nullptr, 0, reinterpret_cast<float2*>(w.scratch + (1 << 20)), yf::train_scratch_bytes() - (1 << 20), 0};
+    int red_for = -1;
     auto unit = [&](int i, const float* gy, bool need_dx, const float* addend = nullptr) {
         const LayerSpec& S = kLayers[i];
         const TLayer& L = t->L[i];
         const int iz = other(cur, skip, -1), ix = other(cur, skip, iz);
         float* gz = w.g[iz];
         yf::launch_tbn_bwd(w.act + L.z * N, gy, w.stats + L.st, P(L.p0 + 1), P(L.p0 + 2), G(L.p0 + 1), G(L.p0 + 2), gz, N, L.Cout, (long)L.Ho * L.Wo,
-                           S.relu, w.scratch, s);
+                           S.relu, w.scratch, s, (red_for == i && red.count > 0) ? &red : nullptr);
+        red_for = -1;
+        yf::TBnRed* rp = nullptr;
+        if (need_dx && L.in >= 0 && L.in != t->i_conv4_2 && L.in != t->i_conv5_2 && kLayers[L.in].kind != K_HEAD && S.kind != K_DECONV) {
+            const TLayer& J = t->L[L.in];
+            red.z = w.act + J.z * N; red.stats = w.stats + J.st; red.gamma = P(J.p0 + 1); red.beta = P(J.p0 + 2); red.relu = kLayers[L.in].relu;
+            red.count = 0;
+            rp = &red;
+        }
         tm.tick("bn", S.name);
         if (S.kind == K_DECONV) {
             yf::launch_tdeconv_bwd_weight(xin(L), gz, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, w.scratch, sb, s, dfr);
@@ -468,7 +481,8 @@ static int trainer_backward_launches(yf_trainer t, const float* d_x, const float
         } else {
             yf::launch_tconv_bwd_weight(xin(L), gz, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, w.scratch, sb, s, dfr);
             tm.tick("wgrad", S.name);
-            if (need_dx) yf::launch_tconv_bwd_data(gz, P(L.p0), w.g[ix], N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, s, addend);
+            if (need_dx) yf::launch_tconv_bwd_data(gz, P(L.p0), w.g[ix], N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, s, addend, rp);
+            if (rp && red.count > 0) red_for = L.in;
         }
         tm.tick("dgrad", S.name);
         return ix;

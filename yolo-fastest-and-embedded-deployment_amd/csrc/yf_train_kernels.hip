@@ -156,6 +156,9 @@ __global__ void __launch_bounds__(256) tpw_mfma_kernel(const float* __restrict__
 // ---- BatchNorm statistics out of the conv's epilogue (the large maps: one pass over z less).  A workgroup leaves one (sum, sum of
 // squares) pair per output channel and pixel block in `stat` ([channel][block], float2 of values summed in double over the block);
 // tbn_stats_from_parts_kernel adds a channel's pairs in double, in block order.  Deterministic: fixed rotation / wave order.
+__device__ __forceinline__ float tbn_affine(float x, float mean, float invstd, float gamma, float beta);   // below, with BatchNorm
+// what a data-gradient kernel needs of the layer below to leave that layer's backward BatchNorm sums (yf_kernels.h: TBnRed)
+struct TRedArgs { const float* z; const float* stats; const float* gamma; const float* beta; float2* part; int relu; };
 template <int N_> __device__ __forceinline__ float row16_rotate(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N_, 0xf, 0xf, false));   // row_ror:N_
@@ -1080,7 +1083,8 @@ __device__ __forceinline__ void tdw_row_window(const float* __restrict__ xr, boo
 // of them and the weights are per-lane loads; otherwise one plane per blockIdx.x and wave-uniform weights.
 template <int KS, bool FLIP, int R, bool MANY = false>
 __global__ void __launch_bounds__(256) tdw_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int C, int H, int W,
-                                                       long nplanes = 0, float2* __restrict__ stat = nullptr)
+                                                       long nplanes = 0, float2* __restrict__ stat = nullptr,
+                                                       TRedArgs red = TRedArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0})
 {
     constexpr int KK = KS * KS, PAD = (KS - 1) / 2;
     const int lane = threadIdx.x & 63;
@@ -1145,6 +1149,35 @@ __global__ void __launch_bounds__(256) tdw_rows_kernel(const float* __restrict__
                 const long nblocks = (long)(gridDim.x / C) * gridDim.y, block = (long)(plane / C) * gridDim.y + blockIdx.y;
                 stat[(long)c * nblocks + block] = make_float2((float)((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])),
                                                               (float)((red[0][1] + red[1][1]) + (red[2][1] + red[3][1])));
+            }
+        }
+    }
+    if constexpr (!MANY && FLIP) {
+        if (red.part) {                                     // this IS dy of the layer below: its backward BatchNorm sums (see tpw4_mfma_kernel)
+            __shared__ float rred[4][2];
+            const float mean = red.stats[2 * c], inv = red.stats[2 * c + 1], gm = red.gamma[c], bt = red.beta[c];
+            float s1 = 0.f, s2 = 0.f;
+            if (t < count) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float4 z4 = *reinterpret_cast<const float4*>(red.z + (plane * H + oy0 + r) * W + ox0);
+                    const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        float g = acc[r][o];
+                        if (red.relu && !(tbn_affine(zz[o], mean, inv, gm, bt) > 0.f)) g = 0.f;
+                        s1 += g;
+                        s2 = fmaf(g, (zz[o] - mean) * inv, s2);
+                    }
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o); s2 += __shfl_down(s2, o); }
+            if (lane == 0) { rred[threadIdx.x >> 6][0] = s1; rred[threadIdx.x >> 6][1] = s2; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const long nblocks = (long)(gridDim.x / C) * gridDim.y, block = (long)(plane / C) * gridDim.y + blockIdx.y;
+                red.part[(long)c * nblocks + block] = make_float2((rred[0][0] + rred[1][0]) + (rred[2][0] + rred[3][0]),
+                                                                  (rred[0][1] + rred[1][1]) + (rred[2][1] + rred[3][1]));
             }
         }
     }
@@ -1318,16 +1351,27 @@ static inline bool tstat_room(TStatPart* st, long count, int C)
     st->count = count;
     return true;
 }
+static inline bool tred_room(TBnRed* red, long count, int C)
+{
+    if (!red || !red->part || !red->z) return false;
+    static const bool off = getenv("YF_TRED_OFF") != nullptr;
+    if (off || (size_t)count * C * sizeof(float2) > red->cap_bytes) return false;
+    red->count = count;
+    return true;
+}
 static const bool tdw_rows_off = getenv("YF_TDW_ROWS_OFF") != nullptr;
 template <int KS, int S, bool FLIP>
-static void launch_tdw_conv(const float* x, const float* w, float* y, int N, int C, int H, int W, int Ho, int Wo, hipStream_t s, TStatPart* st = nullptr)
+static void launch_tdw_conv(const float* x, const float* w, float* y, int N, int C, int H, int W, int Ho, int Wo, hipStream_t s, TStatPart* st = nullptr,
+                            TBnRed* red = nullptr)
 {
     if constexpr (S == 1) {
         // large maps: 4 rows per thread (see tdw_rows_kernel); the plane must still give a workgroup something to do
         if (!tdw_rows_off && H % 4 == 0 && (H / 4) * (W / 4) >= 64) {
             const int count = (H / 4) * (W / 4), ny = (count + 255) / 256;
             float2* sp = (!FLIP && tstat_room(st, (long)N * ny, C)) ? st->part : nullptr;
-            hipLaunchKernelGGL((tdw_rows_kernel<KS, FLIP, 4>), dim3(N * C, ny), dim3(256), 0, s, x, w, y, C, H, W, 0L, sp);
+            TRedArgs ra{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+            if (FLIP && tred_room(red, (long)N * ny, C)) ra = TRedArgs{red->z, red->stats, red->gamma, red->beta, red->part, red->relu};
+            hipLaunchKernelGGL((tdw_rows_kernel<KS, FLIP, 4>), dim3(N * C, ny), dim3(256), 0, s, x, w, y, C, H, W, 0L, sp, ra);
             return;
         }
         if (!tdw_rows_off && H % 4 == 0 && (long)N * C * (H / 4) * (W / 4) >= 16384) {      // small planes, many of them
@@ -2071,15 +2115,19 @@ void launch_tconv_fwd(const float* x, const float* w, const float* bias, float* 
 }
 // addend (optional, like dx): added to the result -- fused for the pointwise GEMM, a separate pass otherwise
 void launch_tconv_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, int k, int stride, int depthwise,
-                           hipStream_t s, const float* addend)
+                           hipStream_t s, const float* addend, TBnRed* red)
 {
+    if (red) red->count = 0;
+    if (red && (long)N * H * W <= 4096 * 8) red = nullptr;              // BatchNorm's one-launch backward reads dy and z once anyway
     if (addend && !(!depthwise && k == 1 && stride == 1)) {
-        launch_tconv_bwd_data(dy, w, dx, N, Cin, H, W, Cout, k, stride, depthwise, s, nullptr);
+        launch_tconv_bwd_data(dy, w, dx, N, Cin, H, W, Cout, k, stride, depthwise, s, nullptr, nullptr);
         launch_tadd(dx, addend, dx, (long)N * Cin * H * W, s);
         return;
     }
     const int pad = (k - 1) / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     if (!depthwise && k == 1 && stride == 1) {       // pointwise: dx[ci] = sum_co dy[co] w[co][ci] -- the same GEMM with the weight transposed
+        // (the same epilogue in the pointwise GEMM: a z load, 4 constants and ~45 instructions for each of a lane's 4 MT rows cost what
+        //  the reduction pass saved -- +60 / -58 us on the 8-channel layers at batch 256; only the depthwise kernel carries it)
         launch_tpw_gemm(dy, w, nullptr, addend, dx, (long)N * H * W, (long)H * W, Cin, Cout, 1L, (long)Cin, s);
         return;
     }
@@ -2094,8 +2142,8 @@ void launch_tconv_bwd_data(const float* dy, const float* w, float* dx, int N, in
             else hipLaunchKernelGGL((tdw_plane_kernel<5, true>), dim3(nblk(nrows)), dim3(256), 0, s, dy, w, dx, Cin, H, W, nrows);
             return;
         }
-        if (stride == 1 && W % 4 == 0 && k == 3) return launch_tdw_conv<3, 1, true>(dy, w, dx, N, Cin, H, W, H, W, s);
-        if (stride == 1 && W % 4 == 0 && k == 5) return launch_tdw_conv<5, 1, true>(dy, w, dx, N, Cin, H, W, H, W, s);
+        if (stride == 1 && W % 4 == 0 && k == 3) return launch_tdw_conv<3, 1, true>(dy, w, dx, N, Cin, H, W, H, W, s, nullptr, red);
+        if (stride == 1 && W % 4 == 0 && k == 5) return launch_tdw_conv<5, 1, true>(dy, w, dx, N, Cin, H, W, H, W, s, nullptr, red);
         if (stride == 2 && k == 3 && H == 2 * Ho && W == 2 * Wo) {
             const int threads = Ho * Wo, bs = threads <= 64 ? 64 : 256;
             hipLaunchKernelGGL(tdw3s2_bwd_data_kernel, dim3(N * Cin, (threads + bs - 1) / bs), dim3(bs), 0, s, dy, w, dx, Cin, Ho, Wo);
@@ -2404,7 +2452,7 @@ void launch_tbn_fwd(const float* x, const float* gamma, const float* beta, float
     }
 }
 void launch_tbn_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, float* dgamma, float* dbeta, float* dx,
-                    int N, int C, long HW, int relu, void* scratch, hipStream_t s)
+                    int N, int C, long HW, int relu, void* scratch, hipStream_t s, const TBnRed* red)
 {
     static const bool small4_off = getenv("YF_TBN_SMALL4_OFF") != nullptr;
     if (!small4_off && HW % 4 == 0 && (long)N * HW <= 4096 * 8) {
@@ -2420,8 +2468,24 @@ void launch_tbn_bwd(const float* x, const float* dy, const float* stats, const f
     }
     static const bool flat_off = getenv("YF_TBN_FLAT_OFF") != nullptr;
     const bool flat = !flat_off && HW % 4 == 0 && HW % 1024 != 0;
-    const int V = (flat || (HW % 4 == 0 && HW >= 1024)) ? 4 : 1, nchunk = tbn_chunks(N, C, HW, V, flat);
+    const bool parts = red && red->count > 0;                          // the data-gradient kernel above left the pairs: no reduction pass
+    int pchunks = parts ? (int)((red->count + 1023) / 1024) : 0;
+    if (pchunks > 64) pchunks = 64;
+    const int V = (flat || (HW % 4 == 0 && HW >= 1024)) ? 4 : 1, nchunk = parts ? pchunks : tbn_chunks(N, C, HW, V, flat);
     const dim3 g1(nchunk, C), g2(tbn_apply_blocks(N, C, HW, V, flat), C);
+    if (parts) {
+        hipLaunchKernelGGL(tbn_stats_from_parts_kernel, dim3(pchunks, C), dim3(256), 0, s, (const float2*)red->part, red->count, (double*)scratch);
+        if (flat)
+            hipLaunchKernelGGL((tbn_bwd_apply_kernel<4, true>), g2, dim3(256), 0, s, x, dy, stats, gamma, beta, (const double*)scratch, nchunk, dgamma, dbeta,
+                               dx, N, C, HW, relu);
+        else if (V == 4)
+            hipLaunchKernelGGL(tbn_bwd_apply_kernel<4>, g2, dim3(256), 0, s, x, dy, stats, gamma, beta, (const double*)scratch, nchunk, dgamma, dbeta, dx, N,
+                               C, HW, relu);
+        else
+            hipLaunchKernelGGL(tbn_bwd_apply_kernel<1>, g2, dim3(256), 0, s, x, dy, stats, gamma, beta, (const double*)scratch, nchunk, dgamma, dbeta, dx, N,
+                               C, HW, relu);
+        return;
+    }
     if (flat) {
         hipLaunchKernelGGL((tbn_bwd_reduce_kernel<4, true>), g1, dim3(256), 0, s, x, dy, stats, gamma, beta, N, C, HW, relu, (double*)scratch);
         hipLaunchKernelGGL((tbn_bwd_apply_kernel<4, true>), g2, dim3(256), 0, s, x, dy, stats, gamma, beta, (const double*)scratch, nchunk, dgamma, dbeta,
