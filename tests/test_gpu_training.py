@@ -588,8 +588,8 @@ def test_training_network_against_the_fp64_oracle(yf, dev, seed, tol):
 
 
 def test_training_passes_replay_as_graphs_with_the_same_results(yf, dev):
-    """A pass whose pointers repeat is captured once and replayed as a HIP graph (yf_train_engine.hip run_pass): ten iterations on one
-    batch in a child process with the graphs on and with YF_TRAIN_GRAPH_OFF=1 end at the same loss to the last printed digit
+    """A pass whose pointers repeat is captured once and replayed as a HIP graph (yf_train_engine.hip run_pass): fifteen iterations
+    (batch 4, then 2, then 4 again) in a child process with the graphs on and with YF_TRAIN_GRAPH_OFF=1 end at the same loss to the last printed digit
     (the kernels are deterministic), and the trainer reports replays only in the first."""
     import subprocess
     code = ("import sys, ctypes, torch, numpy as np; sys.path.insert(0, %r)\n"
@@ -600,7 +600,8 @@ def test_training_passes_replay_as_graphs_with_the_same_results(yf, dev):
             "t = np.zeros((4, 8, 6), np.float32); t[:, 0] = (0.4, 0.6, 0.3, 0.2, 1, 255.0); td = torch.from_numpy(t).to(dev)\n"
             "crit = [val.YOLOLossV3(io['anchors'][i], 3, [128, 160, 1], dev, model=m) for i in range(2)]\n"
             "opt = training.Adam(m.parameters(), lr=0.001)\n"
-            "for _ in range(10): loss = training.train_step(m, crit, opt, x, td)[0]\n"
+            "for n, k in ((4, 6), (2, 4), (4, 5)):\n"           # the batch size changes and comes back: the backward's sum table is rebuilt
+            "    for _ in range(k): loss = training.train_step(m, crit, opt, x[:n], td[:n])[0]\n"
             "tr = training._trainer(m, 128, 160, dev); f, b = ctypes.c_long(), ctypes.c_long()\n"
             "tr.lib.yf_trainer_graph_replays(tr.handle, ctypes.byref(f), ctypes.byref(b))\n"
             "print('RESULT %%.9g %%d %%d' %% (float(loss.detach()), f.value, b.value))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -373,7 +373,13 @@ int yf_trainer_create(int H, int W, int device, yf_trainer* out)
 }
 void yf_trainer_destroy(yf_trainer t)
 {
-    if (t && t->d_sum_tab) (void)hipFree(t->d_sum_tab);
+    if (t) {
+        if (t->d_sum_tab) (void)hipFree(t->d_sum_tab);
+        for (yf_trainer_s::PassGraphs* pg : {&t->gfwd, &t->gbwd})
+            for (yf_trainer_s::PassGraph& g : pg->g)
+                if (g.exec) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+        if (t->cap_stream) (void)hipStreamDestroy(t->cap_stream);
+    }
     delete t;
 }
 int yf_trainer_num_params(yf_trainer t, int* n_params, int* n_bn)
@@ -533,11 +539,9 @@ static int trainer_backward_launches(yf_trainer t, const float* d_x, const float
             // first pass at this batch size: the table goes to the device once (nothing of this trainer may still be reading the old one)
             if (capturing) return fail(YF_E_HIP, "yf_trainer_backward: the sum table changed between two identical calls");
             HIP_OK(hipStreamSynchronize(s));
+            for (yf_trainer_s::PassGraph& g : t->gbwd.g)         // a captured backward has the old table's address in its last node
+                if (g.exec) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); g.exec = nullptr; g.graph = nullptr; g.key.clear(); }
             if (t->d_sum_tab) (void)hipFree(t->d_sum_tab);
-        for (yf_trainer_s::PassGraphs* pg : {&t->gfwd, &t->gbwd})
-            for (yf_trainer_s::PassGraph& g : pg->g)
-                if (g.exec) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
-        if (t->cap_stream) (void)hipStreamDestroy(t->cap_stream);
             t->d_sum_tab = nullptr;
             HIP_OK(hipMalloc(&t->d_sum_tab, nb));
             HIP_OK(hipMemcpy(t->d_sum_tab, defer.entries.data(), nb, hipMemcpyHostToDevice));
@@ -580,14 +584,20 @@ static int run_pass(yf_trainer_s* t, yf_trainer_s::PassGraphs& pg, std::vector<u
         pg.seen[pg.nseen++ & 3] = key;
         return body(s, false);
     }
-    if (!t->cap_stream && hipStreamCreateWithFlags(&t->cap_stream, hipStreamNonBlocking) != hipSuccess) return body(s, false);
+    if (!t->cap_stream && hipStreamCreateWithFlags(&t->cap_stream, hipStreamNonBlocking) != hipSuccess) { t->cap_stream = nullptr; return body(s, false); }
     yf_trainer_s::PassGraph& g = pg.g[pg.next];
     pg.next ^= 1;
     if (g.exec) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); g.exec = nullptr; g.graph = nullptr; }
+    static const bool dbg = getenv("YF_TRAIN_GRAPH_DEBUG") != nullptr;
+    {
+        const hipError_t pre = hipGetLastError();
+        if (dbg && pre != hipSuccess) fprintf(stderr, "[run_pass] error pending before capture: %s\n", hipGetErrorString(pre));
+    }
     if (hipStreamBeginCapture(t->cap_stream, hipStreamCaptureModeRelaxed) != hipSuccess) return body(s, false);
     const int rc = body(t->cap_stream, true);
     hipGraph_t graph = nullptr;
     const hipError_t e = hipStreamEndCapture(t->cap_stream, &graph);
+    if (dbg) fprintf(stderr, "[run_pass] %s capture N=%d: body rc %d (%s), end capture %s, graph %p\n", &pg == &t->gfwd ? "forward" : "backward", N, rc, rc ? yf_last_error_string() : "", hipGetErrorString(e), (void*)graph);
     if (rc != YF_OK || e != hipSuccess || !graph) {
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
