@@ -66,7 +66,7 @@ struct yf_trainer_s {
     // a pass with the same pointers as the call before it is captured once (on cap_stream: the caller's may be the legacy stream,
     // which cannot capture) and replayed as a HIP graph on the caller's stream from then on: see run_pass()
     struct PassGraph { std::vector<uintptr_t> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
-    struct PassGraphs { std::vector<uintptr_t> seen[4]; int nseen = 0; PassGraph g[2]; int next = 0; long replays = 0; } gfwd, gbwd;
+    struct PassGraphs { std::vector<uintptr_t> seen[4]; int nseen = 0; PassGraph g[2]; int next = 0; long replays = 0; int failures = 0; } gfwd, gbwd;
     hipStream_t cap_stream = nullptr;
     int i_conv4_2, i_conv4_3, i_conv5_2, i_conv5_3, i_conv5_6, i_head5, i_deconv, i_c411, i_c415, i_head4;
 };
@@ -569,7 +569,7 @@ static int run_pass(yf_trainer_s* t, yf_trainer_s::PassGraphs& pg, std::vector<u
     static const bool always = getenv("YF_TRAIN_GRAPH_ALWAYS") != nullptr;
     // only where the host is the slower side: a replayed node costs the GPU ~1 us more than a plain launch (measured at batch 256:
     // 19.5 -> 20.1 ms with ~535 nodes), which a 4 ms iteration wins back several times over on the host and a 20 ms one does not
-    if (off || (!always && (long)N * t->H * t->W > 40L * 256 * 320)) return body(s, false);
+    if (off || pg.failures >= 2 || (!always && (long)N * t->H * t->W > 40L * 256 * 320)) return body(s, false);   // (two failed captures: never again)
     for (yf_trainer_s::PassGraph& g : pg.g)
         if (g.exec && g.key == key) {
             HIP_OK(hipGraphLaunch(g.exec, s));
@@ -601,12 +601,14 @@ static int run_pass(yf_trainer_s* t, yf_trainer_s::PassGraphs& pg, std::vector<u
     if (rc != YF_OK || e != hipSuccess || !graph) {
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
+        ++pg.failures;
         return body(s, false);
     }
     if (hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) != hipSuccess) {
         (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
         g.exec = nullptr;
+        ++pg.failures;
         return body(s, false);
     }
     g.graph = graph;
