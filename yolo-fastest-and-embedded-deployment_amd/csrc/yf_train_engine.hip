@@ -537,7 +537,7 @@ static int trainer_backward_launches(yf_trainer t, const float* d_x, const float
         const size_t nb = defer.entries.size() * sizeof(yf::TSumEntry);
         if (t->sum_tab.size() != defer.entries.size() || memcmp(t->sum_tab.data(), defer.entries.data(), nb)) {
             // first pass at this batch size: the table goes to the device once (nothing of this trainer may still be reading the old one)
-            if (capturing) return fail(YF_E_HIP, "yf_trainer_backward: the sum table changed between two identical calls");
+            if (capturing) return 1;                         // (another batch size ran in between: this call goes out as plain launches, which rebuild the table)
             HIP_OK(hipStreamSynchronize(s));
             for (yf_trainer_s::PassGraph& g : t->gbwd.g)         // a captured backward has the old table's address in its last node
                 if (g.exec) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); g.exec = nullptr; g.graph = nullptr; g.key.clear(); }
@@ -601,7 +601,7 @@ static int run_pass(yf_trainer_s* t, yf_trainer_s::PassGraphs& pg, std::vector<u
     if (rc != YF_OK || e != hipSuccess || !graph) {
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
-        ++pg.failures;
+        if (rc != 1) ++pg.failures;
         return body(s, false);
     }
     if (hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) != hipSuccess) {
