@@ -587,7 +587,10 @@ static int run_pass(yf_trainer_s* t, yf_trainer_s::PassGraphs& pg, std::vector<u
     if (!t->cap_stream && hipStreamCreateWithFlags(&t->cap_stream, hipStreamNonBlocking) != hipSuccess) { t->cap_stream = nullptr; return body(s, false); }
     yf_trainer_s::PassGraph& g = pg.g[pg.next];
     pg.next ^= 1;
-    if (g.exec) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); g.exec = nullptr; g.graph = nullptr; }
+    if (g.exec) {                                            // a third pointer set evicts the older graph (it may still be running on s)
+        (void)hipStreamSynchronize(s);
+        (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); g.exec = nullptr; g.graph = nullptr;
+    }
     static const bool dbg = getenv("YF_TRAIN_GRAPH_DEBUG") != nullptr;
     {
         const hipError_t pre = hipGetLastError();
