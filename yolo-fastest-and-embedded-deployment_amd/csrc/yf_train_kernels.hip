@@ -1099,7 +1099,7 @@ __global__ void __launch_bounds__(256) tdw_rows_kernel(const float* __restrict__
         count = per_plane;
     } else {
         plane = blockIdx.x;
-        t = blockIdx.y * 256 + threadIdx.x;
+        t = blockIdx.y * blockDim.x + threadIdx.x;          // (the workgroup is sized to the plane: 64 .. 256 threads)
         count = per_plane;
     }
     const int c = (int)(plane % C);
@@ -1133,6 +1133,8 @@ __global__ void __launch_bounds__(256) tdw_rows_kernel(const float* __restrict__
     if constexpr (!MANY && !FLIP) {
         if (stat) {                                         // BatchNorm statistics of this workgroup's outputs (one channel): see tile_stats_store
             __shared__ double red[4][2];
+            if (threadIdx.x < 8) red[threadIdx.x >> 1][threadIdx.x & 1] = 0;      // (a workgroup may have fewer than 4 waves)
+            __syncthreads();
             double s1 = 0, s2 = 0;
             if (t < count) {
 #pragma unroll
@@ -1155,6 +1157,8 @@ __global__ void __launch_bounds__(256) tdw_rows_kernel(const float* __restrict__
     if constexpr (!MANY && FLIP) {
         if (red.part) {                                     // this IS dy of the layer below: its backward BatchNorm sums (see tpw4_mfma_kernel)
             __shared__ float rred[4][2];
+            if (threadIdx.x < 8) rred[threadIdx.x >> 1][threadIdx.x & 1] = 0.f;
+            __syncthreads();
             const float mean = red.stats[2 * c], inv = red.stats[2 * c + 1], gm = red.gamma[c], bt = red.beta[c];
             float s1 = 0.f, s2 = 0.f;
             if (t < count) {
@@ -1367,11 +1371,18 @@ static void launch_tdw_conv(const float* x, const float* w, float* y, int N, int
     if constexpr (S == 1) {
         // large maps: 4 rows per thread (see tdw_rows_kernel); the plane must still give a workgroup something to do
         if (!tdw_rows_off && H % 4 == 0 && (H / 4) * (W / 4) >= 64) {
-            const int count = (H / 4) * (W / 4), ny = (count + 255) / 256;
+            // workgroup = 64 .. 256 threads, whichever leaves the fewest idle (a 32x40 plane is 80 threads' worth: 256 would idle 69 % of them)
+            const int count = (H / 4) * (W / 4);
+            int bs = 256, waste = (count + 255) / 256 * 256 - count;
+            for (int b = 192; b >= 64; b -= 64) {
+                const int wst = (count + b - 1) / b * b - count;
+                if (wst < waste) { waste = wst; bs = b; }
+            }
+            const int ny = (count + bs - 1) / bs;
             float2* sp = (!FLIP && tstat_room(st, (long)N * ny, C)) ? st->part : nullptr;
             TRedArgs ra{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
             if (FLIP && tred_room(red, (long)N * ny, C)) ra = TRedArgs{red->z, red->stats, red->gamma, red->beta, red->part, red->relu};
-            hipLaunchKernelGGL((tdw_rows_kernel<KS, FLIP, 4>), dim3(N * C, ny), dim3(256), 0, s, x, w, y, C, H, W, 0L, sp, ra);
+            hipLaunchKernelGGL((tdw_rows_kernel<KS, FLIP, 4>), dim3(N * C, ny), dim3(bs), 0, s, x, w, y, C, H, W, 0L, sp, ra);
             return;
         }
         if (!tdw_rows_off && H % 4 == 0 && (long)N * C * (H / 4) * (W / 4) >= 16384) {      // small planes, many of them
