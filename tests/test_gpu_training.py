@@ -827,6 +827,27 @@ def test_trainer_is_identical_to_the_per_block_path(yf, golden, dev):
         assert (ga - gb).abs().max() <= 2e-5 * gb.abs().max(), (n, float((ga - gb).abs().max()), float(gb.abs().max()))
     for ba, bb in zip(a[3], b[3]):
         assert torch.equal(ba, bb)
+    # another geometry (maps of 96x160 .. 6x10: other kernel choices per layer), random weights: the same statement
+    xr = (torch.rand(5, 1, 192, 320, generator=torch.Generator().manual_seed(4)) - 0.5).to(dev)
+    out = {}
+    for impl in ("trainer", "ops"):
+        torch.manual_seed(11)
+        m = yf.YoloFastest(yf.io_params_for(256))
+        m.initialize_weights()
+        m = m.to(dev).train()
+        m.train_impl = impl
+        hl, hs = m(xr)
+        torch.manual_seed(1)
+        ghl, ghs = torch.randn(hl.shape, device=dev), torch.randn(hs.shape, device=dev)
+        torch.autograd.backward([hl, hs], [ghl, ghs])
+        out[impl] = (hl.detach(), hs.detach(), [p.grad.clone() for p in m.parameters()])
+    a, b = out["trainer"], out["ops"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # (with beta = 0 at initialisation some gammas have a zero gradient in exact arithmetic too -- relu(gamma xhat) in front of a conv +
+    #  BatchNorm is scale-free: such tensors hold rounding noise of the others' magnitude, hence the floor relative to the largest gradient)
+    floor = 1e-6 * max(float(g.abs().max()) for g in b[2])
+    for (n, _), ga, gb in zip(yf.YoloFastest(yf.io_params_for(256)).named_parameters(), a[2], b[2]):
+        assert (ga - gb).abs().max() <= 2e-5 * gb.abs().max() + floor, (n, float((ga - gb).abs().max()), float(gb.abs().max()))
     # two forwards before the first backward: each pass owns its tape
     m = yf.YoloFastest(yf.io_params_for(256)).to(dev)
     m.load_state_dict(torch.load(WEIGHTS, map_location=dev))
