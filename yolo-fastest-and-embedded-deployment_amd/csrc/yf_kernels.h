@@ -327,6 +327,8 @@ struct TSumDefer {
 void launch_tsum_multi(const TSumEntry* d_tab, int n, long nblocks, const float* slab, float* dst, hipStream_t s);
 void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int k, int stride, int depthwise,
                              void* scratch, size_t scratch_bytes, hipStream_t s, TSumDefer* defer = nullptr);
+bool launch_tpw_bwd_dual(const float* x, const float* dz, const float* w, float* dw, float* dx, const float* addend, int N, int Cin, int H, int W,
+                         int Cout, void* scratch, size_t scratch_bytes, hipStream_t s, TSumDefer* defer);
 void launch_tdeconv_fwd(const float* x, const float* w, float* y, int N, int Cin, int H, int W, int Cout, hipStream_t s);
 void launch_tdeconv_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout, hipStream_t s);
 void launch_tdeconv_bwd_weight(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, void* scratch, size_t scratch_bytes,

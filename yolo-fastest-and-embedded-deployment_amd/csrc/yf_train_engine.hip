@@ -484,6 +484,9 @@ static int trainer_backward_launches(yf_trainer t, const float* d_x, const float
             yf::launch_tdeconv_bwd_weight(xin(L), gz, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, w.scratch, sb, s, dfr);
             tm.tick("wgrad", S.name);
             if (need_dx) yf::launch_tdeconv_bwd_data(gz, P(L.p0), w.g[ix], N, L.Cin, L.Hin, L.Win, L.Cout, s);
+        } else if (S.kind == K_PW && need_dx && !tm.on &&
+                   yf::launch_tpw_bwd_dual(xin(L), gz, P(L.p0), G(L.p0), w.g[ix], addend, N, L.Cin, L.Hin, L.Win, L.Cout, w.scratch, sb, s, dfr)) {
+            // (pointwise layer on a small map: both gradients in one launch)
         } else {
             yf::launch_tconv_bwd_weight(xin(L), gz, G(L.p0), N, L.Cin, L.Hin, L.Win, L.Cout, S.k, S.stride, S.kind == K_DW, w.scratch, sb, s, dfr);
             tm.tick("wgrad", S.name);

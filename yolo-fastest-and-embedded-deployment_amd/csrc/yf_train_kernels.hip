@@ -203,13 +203,14 @@ __device__ __forceinline__ void tile_stats_store(const f32x4_t (&acc)[MT][4], bo
 // Two k-steps per trip with the loads up front.
 // DECONV: the ConvTranspose2d(2, 2) forward is this GEMM with M = (co, a, b) rows (A = the weight [Cin][Cout 2 2] read by columns) and a
 // scattering epilogue: the lane's 4 rows are the 2x2 output block of ONE channel, for each of its 4 input pixels (Wd = input width).
-template <int MT, bool DECONV = false>
-__global__ void __launch_bounds__(256) tpw4_mfma_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ bias,
-                                                        const float* __restrict__ addend, float* __restrict__ y, long Q, long HW, int M, int K,
-                                                        long sm, long sk, int mgroups, int Wd = 0, float2* __restrict__ stat = nullptr)
+// (bid, nblocks: the workgroup's place in its grid -- blockIdx.x / gridDim.x, or a sub-range of a launch shared with another kernel body)
+template <int MT, bool DECONV>
+__device__ __forceinline__ void tpw4_body(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ bias,
+                                          const float* __restrict__ addend, float* __restrict__ y, long Q, long HW, int M, int K, long sm, long sk,
+                                          int mgroups, int Wd, float2* __restrict__ stat, unsigned bid, unsigned nblocks)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
-    const unsigned lb = (unsigned)xcd_tile(blockIdx.x, gridDim.x);
+    const unsigned lb = (unsigned)xcd_tile(bid, nblocks);
     const int m0 = (int)(lb % (unsigned)mgroups) * (16 * MT);
     const long q0 = ((long)(lb / (unsigned)mgroups) * 4 + wave) * 64;
     if (q0 >= Q && !stat) return;                           // (with statistics a wave past the end still leaves its (zero) pairs)
@@ -293,6 +294,14 @@ __global__ void __launch_bounds__(256) tpw4_mfma_kernel(const float* __restrict_
             }
             *reinterpret_cast<float4*>(y + o) = v;
         }
+}
+
+template <int MT, bool DECONV = false>
+__global__ void __launch_bounds__(256) tpw4_mfma_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ bias,
+                                                        const float* __restrict__ addend, float* __restrict__ y, long Q, long HW, int M, int K,
+                                                        long sm, long sk, int mgroups, int Wd = 0, float2* __restrict__ stat = nullptr)
+{
+    tpw4_body<MT, DECONV>(x, a, bias, addend, y, Q, HW, M, K, sm, sk, mgroups, Wd, stat, blockIdx.x, gridDim.x);
 }
 
 // The same GEMM with the weights stationary: where the A operand is big (conv4_1_1: 232 x 96 = 89 KB) every wave of tpw4_mfma_kernel pulls
@@ -654,16 +663,15 @@ __global__ void __launch_bounds__(256) tconv3s2_c1_kernel(const float* __restric
 // NW waves per workgroup share a slice (32-pixel trips dealt round-robin) and add their tiles through LDS in wave order: the layers with
 // the most pixels have ONE tile, and 1024 single-wave workgroups (the slab limit) leave a CU with 4 waves = 8 KB of loads in flight.
 template <int KS, int NW>
-__global__ void __launch_bounds__(64 * NW) tconv_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
-                                                                   int N, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride, long q_per,
-                                                                   long part_stride)
+__device__ __forceinline__ void twgrad_body(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, int N, int Cin, int H, int W,
+                                            int Cout, int Ho, int Wo, int stride, long q_per, long part_stride, unsigned bid, unsigned nblocks)
 {
     const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
     const int wv = NW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     constexpr int KK = KS * KS, PAD = (KS - 1) / 2;
     const int R = Cin * KK;
     // 1-D grid in XCD-contiguous order, tiles fastest: the waves of one pixel slice (they all read the same rows of dY and X) share an L2
-    const unsigned nct = (unsigned)((Cout + 15) / 16), nrt = (unsigned)((R + 63) / 64), lb = (unsigned)xcd_tile(blockIdx.x, gridDim.x);
+    const unsigned nct = (unsigned)((Cout + 15) / 16), nrt = (unsigned)((R + 63) / 64), lb = (unsigned)xcd_tile(bid, nblocks);
     const unsigned slice = lb / (nct * nrt), tile = lb - slice * (nct * nrt);
     const int c0 = (int)(tile % nct) * 16, r0 = (int)(tile / nct) * 64;
     const long HWo = (long)Ho * Wo, Q = (long)N * HWo;
@@ -754,6 +762,31 @@ __global__ void __launch_bounds__(64 * NW) tconv_wgrad_mfma_kernel(const float* 
             const int co = c0 + lk * 4 + r, rr = r0 + 16 * t + lr;
             if (co < Cout && rr < R) dw[(long)slice * part_stride + (long)co * R + rr] = acc[t][r];
         }
+}
+
+template <int KS, int NW>
+__global__ void __launch_bounds__(64 * NW) tconv_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                                                   int N, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride, long q_per,
+                                                                   long part_stride)
+{
+    twgrad_body<KS, NW>(x, dy, dw, N, Cin, H, W, Cout, Ho, Wo, stride, q_per, part_stride, blockIdx.x, gridDim.x);
+}
+
+// Backward-data and weight gradient of a pointwise layer as ONE launch: workgroups [0, nA) run the data-gradient GEMM (tpw4_body), the
+// rest the weight-gradient GEMM (twgrad_body, 4 waves per slice).  They only share their input dz; at the reference's batch 16 every
+// kernel of the backward is a few microseconds of mostly waiting, and two that can run side by side cost one launch and one drain.
+struct TPwBwdArgs {
+    const float* dz; const float* w; const float* addend; float* dx;          // data gradient: dx[ci] = sum_co dz[co] w[co][ci] (+ addend)
+    const float* x; float* dw;                                                // weight gradient: dW[co][ci] = sum_q dz[co][q] x[ci][q]
+    long Q, HW; int N, Cin, Cout, H, W; int mgroups; unsigned nA; long q_per, part_stride;
+};
+template <int MT>
+__global__ void __launch_bounds__(256) tpw_bwd_dual_kernel(TPwBwdArgs a)
+{
+    if (blockIdx.x < a.nA)
+        tpw4_body<MT, false>(a.dz, a.w, nullptr, a.addend, a.dx, a.Q, a.HW, a.Cin, a.Cout, 1L, (long)a.Cin, a.mgroups, 0, nullptr, blockIdx.x, a.nA);
+    else
+        twgrad_body<1, 4>(a.x, a.dz, a.dw, a.N, a.Cin, a.H, a.W, a.Cout, a.H, a.W, 1, a.q_per, a.part_stride, blockIdx.x - a.nA, gridDim.x - a.nA);
 }
 
 // Weight gradient of the dense 3x3 stride-2 pad-1 convolution (conv1_9) as NINE GEMMs that share their operands, no gather:
@@ -2337,6 +2370,39 @@ void launch_tconv_bwd_weight(const float* x, const float* dy, float* dw, int N, 
     while ((long)nchunk * nw > 262144 && nchunk > 1) nchunk /= 2;   // bound the grid
     hipLaunchKernelGGL(tconv_bwd_weight_kernel, dim3((unsigned)(nw * nchunk)), dim3(256), 0, s, x, dy, dw, N, Cin, H, W, Cout, Ho, Wo, k, stride,
                        depthwise, nchunk);
+}
+// backward-data + weight gradient of a pointwise layer in one launch (tpw_bwd_dual_kernel); false: not applicable, launch them separately
+bool launch_tpw_bwd_dual(const float* x, const float* dz, const float* w, float* dw, float* dx, const float* addend, int N, int Cin, int H, int W,
+                         int Cout, void* scratch, size_t scratch_bytes, hipStream_t s, TSumDefer* defer)
+{
+    static const bool off = getenv("YF_TPW_DUAL_OFF") != nullptr;
+    const long HW = (long)H * W, Q = (long)N * HW;
+    if (off || HW % 4 || Cout % 4 || Q > 131072 || Q < 256) return false;        // small maps only: there the two kernels wait, they do not stream
+    const long nw = (long)Cout * Cin;
+    const long fit = scratch ? (long)(scratch_bytes / ((size_t)nw * sizeof(float))) : 0;
+    // the data gradient's grid (launch_tpw_gemm's choice without the weight-stationary variant)
+    const int mtiles = (Cin + 15) / 16;
+    int mgroups = (mtiles + 3) / 4, mt = (mtiles + mgroups - 1) / mgroups;
+    while (mt > 1 && (Q + 63) / 64 * mgroups < 512) { mt = (mt + 1) / 2; mgroups = (mtiles + mt - 1) / mt; }
+    const long nA = (Q + 255) / 256 * mgroups;
+    // the weight gradient's: 4 waves per slice
+    const int tiles = ((Cout + 15) / 16) * ((Cin + 63) / 64);
+    long nsplit = (Q + 511) / 512;
+    while (nsplit * tiles * 4 > 8192 && nsplit > 1) nsplit = (nsplit + 1) / 2;
+    if (nsplit > 1024) nsplit = 1024;
+    if (nsplit > fit) nsplit = fit < 1 ? 1 : fit;
+    long q_per = (Q + nsplit - 1) / nsplit;
+    q_per = (q_per + 15) / 16 * 16;
+    nsplit = (Q + q_per - 1) / q_per;
+    float* out = tsum_out(scratch, nsplit, nw, dw, defer);
+    TPwBwdArgs a{dz, w, addend, dx, x, out, Q, HW, N, Cin, Cout, H, W, mgroups, (unsigned)nA, q_per, nw};
+    const dim3 grid((unsigned)(nA + nsplit * tiles));
+    if (mt == 1) hipLaunchKernelGGL(tpw_bwd_dual_kernel<1>, grid, dim3(256), 0, s, a);
+    else if (mt == 2) hipLaunchKernelGGL(tpw_bwd_dual_kernel<2>, grid, dim3(256), 0, s, a);
+    else if (mt == 3) hipLaunchKernelGGL(tpw_bwd_dual_kernel<3>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(tpw_bwd_dual_kernel<4>, grid, dim3(256), 0, s, a);
+    tsum_finish(out, scratch, nsplit, nw, dw, s, defer);
+    return true;
 }
 void launch_tdeconv_fwd(const float* x, const float* w, float* y, int N, int Cin, int H, int W, int Cout, hipStream_t s)
 {
