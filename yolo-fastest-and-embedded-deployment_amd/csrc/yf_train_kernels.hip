@@ -2377,7 +2377,10 @@ bool launch_tpw_bwd_dual(const float* x, const float* dz, const float* w, float*
 {
     static const bool off = getenv("YF_TPW_DUAL_OFF") != nullptr;
     const long HW = (long)H * W, Q = (long)N * HW;
-    if (off || HW % 4 || Cout % 4 || Q > 131072 || Q < 256) return false;        // small maps only: there the two kernels wait, they do not stream
+    // up to 2 M pixels per batch (batch 256: strides 4 and up; measured 18.11 -> 17.94 -> 17.80 ms for limits of 128 k / 400 k / 2 M, no
+    // further gain without a limit): below that the two kernels mostly wait, and side by side they wait once
+    static const long qmax = getenv("YF_TPW_DUAL_QMAX") ? atol(getenv("YF_TPW_DUAL_QMAX")) : 2000000;
+    if (off || HW % 4 || Cout % 4 || Q > qmax || Q < 256) return false;
     const long nw = (long)Cout * Cin;
     const long fit = scratch ? (long)(scratch_bytes / ((size_t)nw * sizeof(float))) : 0;
     // the data gradient's grid (launch_tpw_gemm's choice without the weight-stationary variant)
