@@ -254,7 +254,7 @@ def train_records(dev, pmc):
                "roofline": {"flops_per_iteration": flops, "compute": {"achieved": round(flops / dt / 1e12, 2), "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
                                                                      "frac": round(flops / dt / 1e12 / FP32_PEAK_TF, 4)},
                             "hbm": None, "bound": None, "dominant_kernel": None}}
-        tb, dom, share, note = pmc.get(batch, (None, None, None, "not measured at this batch size (kernel-latency-bound: ~535 launches per iteration)"))
+        tb, dom, share, note = pmc.get(batch, (None, None, None, "not measured at this batch size (kernel-latency-bound: ~475 launches per iteration)"))
         if tb is not None:
             gbs = tb / dt / 1e9
             rec["roofline"]["hbm"] = {"traffic": int(tb), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
