@@ -465,17 +465,24 @@ __global__ void __launch_bounds__(256) tdeconv_bwd_mfma_kernel(const float* __re
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int co = 0; co < Cout; ++co) {
-        float b[4], av[MT];
+    for (int co0 = 0; co0 < Cout; co0 += 4) {                // 4 channels of dY per trip, all of the trip's loads requested before its first MFMA
+        float b[4][4], av[4][MT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) b[u] = bp[u][(long)co * 4 * HW];
+        for (int j = 0; j < 4; ++j) {
+            if (co0 + j >= Cout) break;                          // wave-uniform
 #pragma unroll
-        for (int t = 0; t < MT; ++t) av[t] = ap[t][co * 4];
+            for (int u = 0; u < 4; ++u) b[j][u] = bp[u][(long)(co0 + j) * 4 * HW];
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
+            for (int t = 0; t < MT; ++t) av[j][t] = ap[t][(co0 + j) * 4];
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], b[u], acc[t][u], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+            if (co0 + j >= Cout) break;
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][t], b[j][u], acc[t][u], 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -991,8 +998,15 @@ __global__ void __launch_bounds__(256) tsum_partials_kernel(const float* __restr
     const long i = t / spl;
     const int j = (int)(t - i * spl);
     float v = 0.f;
-    if (i < nw)
-        for (int sidx = j; sidx < nsplit; sidx += spl) v += part[(long)sidx * part_stride + i];
+    if (i < nw) {
+        int sidx = j;
+        for (; sidx + 3 * spl < nsplit; sidx += 4 * spl) {                // four slabs requested at once, added in slab order
+            const float p0 = part[(long)sidx * part_stride + i], p1 = part[(long)(sidx + spl) * part_stride + i];
+            const float p2 = part[(long)(sidx + 2 * spl) * part_stride + i], p3 = part[(long)(sidx + 3 * spl) * part_stride + i];
+            v += p0; v += p1; v += p2; v += p3;
+        }
+        for (; sidx < nsplit; sidx += spl) v += part[(long)sidx * part_stride + i];
+    }
     for (int o = spl >> 1; o > 0; o >>= 1) v += __shfl_down(v, o);       // spl is a power of two <= 64: the lanes of one output are adjacent
     if (i < nw && j == 0) dw[i] = v;
 }
@@ -1652,7 +1666,15 @@ __device__ __forceinline__ void tbn_block_total(const double* __restrict__ part,
     __shared__ double tot[2];
     if (threadIdx.x < 64) {
         double a = 0, b = 0;
-        for (int i = threadIdx.x; i < nchunk; i += 64) { a += part[2 * i]; b += part[2 * i + 1]; }
+        double pa[4], pb[4];                                 // nchunk <= TBN_MAXCHUNK = 256: at most 4 per lane, requested together (a rolled
+#pragma unroll                                               // loop waits for every pair before asking for the next: 4 round trips at the top of
+        for (int u = 0; u < 4; ++u) {                        // every workgroup of the elementwise kernels)
+            const int i = threadIdx.x + 64 * u;
+            pa[u] = i < nchunk ? part[2 * i] : 0.0;
+            pb[u] = i < nchunk ? part[2 * i + 1] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a += pa[u]; b += pb[u]; }
         for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
         if (threadIdx.x == 0) { tot[0] = a; tot[1] = b; }
     }
@@ -1685,7 +1707,15 @@ __global__ void __launch_bounds__(256) tbn_stats_from_parts_kernel(const float2*
 {
     const int c = blockIdx.y;
     double s = 0, ss = 0;
-    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < count; p += (long)gridDim.x * 256) {
+    const long step = (long)gridDim.x * 256;
+    long p = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; p + 3 * step < count; p += 4 * step) {            // four pairs requested at once
+        const float2 v0 = part[(long)c * count + p], v1 = part[(long)c * count + p + step];
+        const float2 v2 = part[(long)c * count + p + 2 * step], v3 = part[(long)c * count + p + 3 * step];
+        s += (double)v0.x; ss += (double)v0.y; s += (double)v1.x; ss += (double)v1.y;
+        s += (double)v2.x; ss += (double)v2.y; s += (double)v3.x; ss += (double)v3.y;
+    }
+    for (; p < count; p += step) {
         const float2 v = part[(long)c * count + p];
         s += (double)v.x; ss += (double)v.y;
     }
@@ -2225,8 +2255,15 @@ __global__ void __launch_bounds__(256) tsum_multi_kernel(const TSumEntry* __rest
     const long i = t / E.spl;
     const int j = (int)(t - i * E.spl);
     float v = 0.f;
-    if (i < E.nw)
-        for (int sidx = j; sidx < E.nsplit; sidx += E.spl) v += part[(long)sidx * E.nw + i];
+    if (i < E.nw) {
+        int sidx = j;
+        for (; sidx + 3 * E.spl < E.nsplit; sidx += 4 * E.spl) {          // four slabs requested at once, added in slab order
+            const float p0 = part[(long)sidx * E.nw + i], p1 = part[(long)(sidx + E.spl) * E.nw + i];
+            const float p2 = part[(long)(sidx + 2 * E.spl) * E.nw + i], p3 = part[(long)(sidx + 3 * E.spl) * E.nw + i];
+            v += p0; v += p1; v += p2; v += p3;
+        }
+        for (; sidx < E.nsplit; sidx += E.spl) v += part[(long)sidx * E.nw + i];
+    }
     for (int o = E.spl >> 1; o > 0; o >>= 1) v += __shfl_down(v, o);
     if (i < E.nw && j == 0) dst[E.dst_off + i] = v;
 }
