@@ -1948,6 +1948,9 @@ __global__ void __launch_bounds__(1024) tbn_fwd_small4_kernel(const float* __res
         }
     }
     const float g = gamma[c], b = beta[c];
+    float4 rr[UPT];                                          // the residuals requested together (idx is clamped: always a valid address)
+#pragma unroll
+    for (int j = 0; j < UPT; ++j) rr[j] = res ? *reinterpret_cast<const float4*>(res + idx[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < UPT; ++j) {
         if (threadIdx.x + j * 1024 >= P4) continue;
@@ -1957,10 +1960,7 @@ __global__ void __launch_bounds__(1024) tbn_fwd_small4_kernel(const float* __res
             o[e] = tbn_affine(((const float*)&v[j])[e], fm, fi, g, b);
             if (relu) o[e] = fmaxf(o[e], 0.f);
         }
-        if (res) {
-            const float4 r = *reinterpret_cast<const float4*>(res + idx[j]);
-            o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
-        }
+        if (res) { o[0] += rr[j].x; o[1] += rr[j].y; o[2] += rr[j].z; o[3] += rr[j].w; }
         *reinterpret_cast<float4*>(y + idx[j]) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
