@@ -1056,6 +1056,98 @@ __global__ void __launch_bounds__(256) tconv3s2_bwd_data_kernel(const float* __r
     }
 }
 
+// Backward-data of the dense 3x3 stride-2 pad-1 convolution (conv1_9) on the matrix pipe: the four parity classes of dx are four small
+// stride-1 convolutions of dY with 1, 2, 2 and 4 of the nine taps,
+//   dx[2a][2b]     = dy[a][b] w11                              dx[2a][2b+1]   = dy[a][b] w12 + dy[a][b+1] w10
+//   dx[2a+1][2b]   = dy[a][b] w21 + dy[a+1][b] w01             dx[2a+1][2b+1] = dy[a][b] w22 + dy[a][b+1] w20 + dy[a+1][b] w02 + dy[a+1][b+1] w00
+// all on the same operands: lane (lk, lr) = output channel co0 + lk of dY and a GROUP of 4 consecutive columns b (one aligned float4 +
+// the next column, for rows a and a + 1); MFMA (class, tap, e) takes column e or e + 1; M = ci (A = the weight, a scalar load per tap).
+// The lane ends up with 8 consecutive columns of two rows of dx for each of its 4 MT input channels: float4 stores.
+// Needs Cout % 4 == 0, Wo % 4 == 0, Cin <= 16 MT.  One wave = 64 positions of dY = 256 of dx.  (The VALU kernel above: 318 us for conv1_9 at batch 256.)
+template <int MT>
+__global__ void __launch_bounds__(256) tconv3s2_bwd_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int N,
+                                                                int Cin, int Cout, int Ho, int Wo)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
+    const int per_row = Wo / 4;
+    const long G = (long)N * Ho * per_row, g0 = ((long)blockIdx.x * 4 + wave) * 16;
+    if (g0 >= G) return;
+    long g = g0 + lr;
+    const bool gv = g < G;
+    if (!gv) g = G - 1;
+    const int b4 = (int)(g % per_row), a = (int)((g / per_row) % Ho), n = (int)(g / ((long)per_row * Ho));
+    const bool row1 = a + 1 < Ho, col4 = 4 * b4 + 4 < Wo;
+    const float* dp = dy + (((long)n * Cout + lk) * Ho + a) * Wo + 4 * b4;      // + co0 Ho Wo (+ Wo for row a + 1)
+    const float* wp[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int ci = 16 * t + lr;
+        wp[t] = w + ((long)lk * Cin + (ci < Cin ? ci : Cin - 1)) * 9;          // + co0 Cin 9 + tap
+    }
+    // class (py, px) -> accumulators [py][px][t][e]
+    f32x4_t acc[2][2][MT][4];
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[py][px][t][e] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    struct Step { float4 r0, r1; float c0, c1; float wk[MT][9]; };
+    auto load = [&](int co0, Step& f) {
+        const float* d0 = dp + (long)co0 * Ho * Wo;
+        f.r0 = *reinterpret_cast<const float4*>(d0);
+        f.r1 = *reinterpret_cast<const float4*>(d0 + (row1 ? Wo : 0));
+        f.c0 = d0[col4 ? 4 : 0];
+        f.c1 = d0[(row1 ? Wo : 0) + (col4 ? 4 : 0)];
+        if (!row1) { f.r1 = make_float4(0.f, 0.f, 0.f, 0.f); f.c1 = 0.f; }
+        if (!col4) { f.c0 = 0.f; f.c1 = 0.f; }
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) f.wk[t][k] = wp[t][(long)co0 * Cin * 9 + k];
+    };
+    Step cur, nxt;
+    load(0, cur);
+    for (int co0 = 0; co0 < Cout; co0 += 4) {                // the next 4 channels of dY requested before this step's 18 MT MFMAs
+        load(co0 + 4 < Cout ? co0 + 4 : co0, nxt);
+        const float v0[5] = {cur.r0.x, cur.r0.y, cur.r0.z, cur.r0.w, cur.c0}, v1[5] = {cur.r1.x, cur.r1.y, cur.r1.z, cur.r1.w, cur.c1};
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f32x4_t& p00 = acc[0][0][t][e]; f32x4_t& p01 = acc[0][1][t][e]; f32x4_t& p10 = acc[1][0][t][e]; f32x4_t& p11 = acc[1][1][t][e];
+                const float (&wk)[9] = cur.wk[t];
+                p00 = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[4], v0[e], p00, 0, 0, 0);         // w11 dy[a][b]
+                p01 = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[5], v0[e], p01, 0, 0, 0);         // w12 dy[a][b]
+                p01 = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[3], v0[e + 1], p01, 0, 0, 0);     // w10 dy[a][b+1]
+                p10 = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[7], v0[e], p10, 0, 0, 0);         // w21 dy[a][b]
+                p10 = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[1], v1[e], p10, 0, 0, 0);         // w01 dy[a+1][b]
+                p11 = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[8], v0[e], p11, 0, 0, 0);         // w22 dy[a][b]
+                p11 = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[6], v0[e + 1], p11, 0, 0, 0);     // w20 dy[a][b+1]
+                p11 = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[2], v1[e], p11, 0, 0, 0);         // w02 dy[a+1][b]
+                p11 = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[0], v1[e + 1], p11, 0, 0, 0);     // w00 dy[a+1][b+1]
+            }
+        cur = nxt;
+    }
+    if (!gv) return;
+    const int H = 2 * Ho, W = 2 * Wo;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = 16 * t + 4 * lk + r;
+            if (ci >= Cin) continue;
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                float* o = dx + (((long)n * Cin + ci) * H + 2 * a + py) * W + 8 * b4;
+                *reinterpret_cast<float4*>(o) = make_float4(acc[py][0][t][0][r], acc[py][1][t][0][r], acc[py][0][t][1][r], acc[py][1][t][1][r]);
+                *reinterpret_cast<float4*>(o + 4) = make_float4(acc[py][0][t][2][r], acc[py][1][t][2][r], acc[py][0][t][3][r], acc[py][1][t][3][r]);
+            }
+        }
+}
+
 // ---- depthwise convolution, one (frame, channel) plane per blockIdx.x so that the KS*KS weights are wave-uniform; a thread computes 4
 // consecutive outputs of a row (Wo % 4 == 0) from the KS x (3 S + KS) input window.  FLIP: the weights reversed -- the backward-data
 // of a stride-1 depthwise conv is the same conv of dY with the flipped kernel. ----
@@ -2203,6 +2295,14 @@ void launch_tconv_bwd_data(const float* dy, const float* w, float* dx, int N, in
         // (the same epilogue in the pointwise GEMM: a z load, 4 constants and ~45 instructions for each of a lane's 4 MT rows cost what
         //  the reduction pass saved -- +60 / -58 us on the 8-channel layers at batch 256; only the depthwise kernel carries it)
         launch_tpw_gemm(dy, w, nullptr, addend, dx, (long)N * H * W, (long)H * W, Cin, Cout, 1L, (long)Cin, s);
+        return;
+    }
+    static const bool s2m_off = getenv("YF_TCONV3S2_OFF") != nullptr;
+    if (!depthwise && k == 3 && stride == 2 && H == 2 * Ho && W == 2 * Wo && !s2m_off && Cout % 4 == 0 && Wo % 4 == 0 && Cin <= 32 &&
+        (long)N * Ho * (Wo / 4) >= 2048) {
+        const dim3 grid((unsigned)(((long)N * Ho * (Wo / 4) + 63) / 64));
+        if (Cin <= 16) hipLaunchKernelGGL(tconv3s2_bwd_mfma_kernel<1>, grid, dim3(256), 0, s, dy, w, dx, N, Cin, Cout, Ho, Wo);
+        else hipLaunchKernelGGL(tconv3s2_bwd_mfma_kernel<2>, grid, dim3(256), 0, s, dy, w, dx, N, Cin, Cout, Ho, Wo);
         return;
     }
     if (!depthwise && k == 3 && stride == 2 && H == 2 * Ho && W == 2 * Wo) {
