@@ -497,6 +497,150 @@ def main_results():
     np.savez_compressed(os.path.join(HERE, "golden_results.npz"), **out)
 
 
+def main_io():
+    """io_params generality: the reference's constructors are parameterised on num_cls, input_channel and
+    num_anchors (yolo_fastest.py:72-78,138,148; detect.py:15-21,53-66; yolo_loss.py:28-33,58-60).  For every configuration of
+    seeded_weights.IO_CONFIGS the REFERENCE module is built, loaded with a numpy-seeded random state-dict (only the seed is stored)
+    and run on seeded u8 frames prepared like detect.py:119-124 (3-channel frames: BGR -> [::-1] -> CHW); recorded: its heads in
+    fp32 and -- model.double() -- fp64, the candidates / survivors of its own YOLO_post_process (with source indices), for the
+    3-anchor configurations the validation-time decode + NMS (yolo_loss.py:98-141 hard-codes 3 anchors at :110-111), the training
+    loss of both heads with its gradient, and -- two configurations, 64x96 frames -- one train-mode iteration (heads, losses, a
+    strided sample and the per-tensor sums of every parameter gradient)."""
+    import types, copy
+    from collections import OrderedDict
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    sys.path.insert(0, os.path.join(REF, "src", "model_training"))
+    sys.path.insert(0, HERE)
+    from loss.yolo_loss import YOLOLossV3            # the reference
+    from utils.general import non_max_suppression    # the reference
+    from seeded_weights import seeded_state_dict, IO_CONFIGS, io_inputs, io_targets
+    dev = torch.device("cpu")
+    out = {}
+
+    def build(C, Cin, A, H, W, seed):
+        io = dict(config_params["io_params"])
+        io.update(num_cls=C, input_channel=Cin, num_anchors=A, input_shape=[H, W, Cin], origin_img_shape=[H, W, Cin],
+                  anchors=[grp[:A] for grp in config_params["io_params"]["anchors"]])
+        m = YoloFastest(io).eval()
+        shapes = OrderedDict((k, tuple(v.shape)) for k, v in m.state_dict().items())
+        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in seeded_state_dict(shapes, seed).items()}
+        assert str(m.load_state_dict(sd)) == "<All keys matched successfully>"
+        return m, io
+
+    def to_x(u8, Cin):
+        if Cin == 1:
+            a = u8[:, None]
+        else:
+            a = np.ascontiguousarray(u8[:, :, :, ::-1].transpose(0, 3, 1, 2))   # detect.py:119: img[:, :, ::-1].transpose(2, 0, 1)
+        return (torch.from_numpy(a.astype(np.float32)) - 128.0) / 255.0
+
+    def src_idx(pred, conf_thres, A, attrs):
+        o, base = [], 0
+        for ph in pred:
+            a = ph.numpy()[0]
+            h, w = a.shape[1], a.shape[2]
+            a = a.reshape(A, attrs, h, w)
+            for pp in range(A):
+                for i in range(h):
+                    for j in range(w):
+                        if 1. / (1. + math.exp(-a[pp, 4, i, j])) > conf_thres:
+                            o.append(base + (pp * h + i) * w + j)
+            base += A * h * w
+        return o
+
+    for idx, (tag, C, Cin, A) in enumerate(IO_CONFIGS):
+        seed = 1000 + idx
+        model, io = build(C, Cin, A, 256, 320, seed)
+        u8 = io_inputs(tag, Cin)
+        x = to_x(u8, Cin)
+        with torch.no_grad():
+            pred = model(x)
+            p64 = copy.deepcopy(model).double()(x.double())
+        out[f"{tag}_seed"] = np.int64(seed)
+        out[f"{tag}_head_large"], out[f"{tag}_head_small"] = pred[0].numpy(), pred[1].numpy()
+        out[f"{tag}_head_large_f64"], out[f"{tag}_head_small_f64"] = p64[0].numpy(), p64[1].numpy()
+        # the reference's own post-process, frame by frame (it reads batch element 0, detect.py:46)
+        pp = YOLO_post_process(conf_thres=io["conf_thre"], nms_thres=io["nms_thre"], num_anchors=A, num_class=C,
+                               anchors=io["anchors"], input_shape=io["input_shape"])
+        cands, finals = [], []
+        for f in range(len(u8)):
+            pf = (pred[0][f:f + 1], pred[1][f:f + 1])
+            c = pp.decode_box(pf)
+            s = src_idx(pf, io["conf_thre"], A, 5 + C)
+            assert len(c) == len(s)
+            for ci, si in zip(c, s):
+                ci.append(si)
+            cands.append([list(v) for v in c])
+            buckets = [[] for _ in range(C)]
+            for b in c:
+                buckets[b[6]].append(b)
+            fin = []
+            try:
+                for cls in range(C):
+                    if buckets[cls]:
+                        buckets[cls].sort(key=lambda it: it[4], reverse=True)
+                        fin.extend(pp.non_maxium_supression(buckets[cls]))
+            except ZeroDivisionError:      # detect.py:39: two zero-area boxes compared -- recorded as count -2 for that frame
+                fin = None
+            finals.append(None if fin is None else [list(v) for v in fin])
+        kmax = max(len(c) for c in cands)
+        zde = [f is None for f in finals]
+        for t2, L in (("cand", cands), ("final", [f or [] for f in finals])):
+            for k, v in pack_lists(L, kmax).items():
+                out[f"{tag}_{t2}_{k}"] = v
+        out[f"{tag}_final_count"][zde] = -2
+        print(tag, "heads", tuple(pred[0].shape), tuple(pred[1].shape), "cands", [len(c) for c in cands], "survivors", [-2 if f is None else len(f) for f in finals],
+              "fp32 vs fp64", float((pred[0].double() - p64[0]).abs().max()), float((pred[1].double() - p64[1]).abs().max()))
+        # validation-time decode + NMS (3 anchors only: yolo_loss.py:110-111 repeats the grid 3 times)
+        crit = [YOLOLossV3(io["anchors"][i], C, io["input_shape"], dev) for i in range(2)]
+        if A == 3:
+            with torch.no_grad():
+                dec = torch.cat([crit[i](pred[i]) for i in range(2)], 1)
+                dets = non_max_suppression(dec.clone(), C, conf_thres=0.5, nms_thres=0.2)
+            km = max([0 if d is None else d.shape[0] for d in dets] + [1])
+            det = np.zeros((len(dets), km, 7), np.float32); cnt = np.zeros((len(dets),), np.int32)
+            for f, d in enumerate(dets):
+                if d is not None:
+                    cnt[f] = d.shape[0]; det[f, :d.shape[0]] = d.numpy()
+            out[f"{tag}_val_decode"] = dec.numpy()[:1, ::3].copy()     # every third row of frame 0
+            out[f"{tag}_val_det"] = det; out[f"{tag}_val_count"] = cnt
+            print(tag, "val detections", cnt.tolist())
+        # training loss of both heads + gradient
+        tt = torch.from_numpy(io_targets(tag, C, len(u8)))
+        for i, name in enumerate(("head_large", "head_small")):
+            xh = pred[i].clone().requires_grad_(True)
+            res = crit[i](xh, tt)
+            res[0].backward()
+            out[f"{tag}_{name}_losses"] = np.array([res[0].item()] + [float(v) for v in res[1:]], np.float32)
+            out[f"{tag}_{name}_grad"] = xh.grad.numpy().copy()
+            print(tag, "loss", name, out[f"{tag}_{name}_losses"].tolist())
+        # one train-mode iteration (train.py:111-131 without the optimizer step) on small frames
+        if tag in ("c5rgb", "a2"):
+            torch.manual_seed(0)
+            m, io2 = build(C, Cin, A, 64, 96, seed)
+            m.train()
+            u8t = io_inputs(tag + "_train", Cin, n=4, H=64, W=96)
+            ttt = torch.from_numpy(io_targets(tag + "_train", C, 4))
+            crit2 = [YOLOLossV3(io2["anchors"][i], C, io2["input_shape"], dev) for i in range(2)]
+            p = m(to_x(u8t, Cin))
+            losses = [[] for _ in range(7)]
+            for i, item in enumerate(p):
+                for j, v in enumerate(crit2[i](item, ttt)):
+                    losses[j].append(v)
+            losses = [sum(v) for v in losses]
+            losses[0].backward()
+            out[f"{tag}_train_head_large"], out[f"{tag}_train_head_small"] = p[0].detach().numpy(), p[1].detach().numpy()
+            out[f"{tag}_train_losses"] = np.array([float(v) for v in losses], np.float64)
+            gr = [q.grad.detach().numpy().ravel() for q in m.parameters()]
+            out[f"{tag}_train_grad_sample"] = np.concatenate(gr)[::37].copy()
+            out[f"{tag}_train_grad_abssum"] = np.array([np.abs(v.astype(np.float64)).sum() for v in gr])
+            out[f"{tag}_train_param_names"] = np.array([n for n, _ in m.named_parameters()])
+            bufs = [b.detach().numpy().ravel() for n, b in m.named_buffers() if not n.endswith("num_batches_tracked")]
+            out[f"{tag}_train_buffers_sample"] = np.concatenate(bufs)[::7].copy()
+            print(tag, "train losses", out[f"{tag}_train_losses"].tolist())
+    np.savez_compressed(os.path.join(HERE, "golden_io.npz"), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "map":
         main_map()
@@ -506,6 +650,8 @@ if __name__ == "__main__":
         main_loss()
     elif len(sys.argv) > 1 and sys.argv[1] == "train":
         main_train()
+    elif len(sys.argv) > 1 and sys.argv[1] == "io":
+        main_io()
     else:
         main()
         main_val()
@@ -513,3 +659,4 @@ if __name__ == "__main__":
         main_results()
         main_loss()
         main_train()
+        main_io()
