@@ -59,7 +59,11 @@ const char *yf_last_error_string(void);
 /* Build an engine for net-input size H x W (rows x cols, multiples of 32) from a packed-weights blob
  * (host memory; format: yolo-fastest-and-embedded-deployment_amd/packer.py -- BN-folded fp32, NHWC-friendly
  * layouts, self-describing layer table that is checked strictly against the YoloFastest graph).
- * The engine owns a device copy of the weights and nothing else. */
+ * The engine owns a device copy of the weights and nothing else.
+ * The blob's header carries the io_params the reference's constructor reads (src/model_training/model/yolo_fastest.py:72-78):
+ * input_channel (1 = gray, 3 = cv2's BGR frames; conv0's Cin, :78), num_anchors and num_cls (num_out = num_anchors * (5 + num_cls)
+ * channels per head, :76, :138, :148).  Below, C_in = input_channel, A = num_anchors (<= 8), C = num_cls, num_out = A * (5 + C);
+ * the shipped checkpoints are C_in = 1, A = 3, C = 3, num_out = 24.  yf_io_params() reads them back. */
 int yf_create(const void *packed_weights, size_t nbytes, int H, int W, int max_batch, int device, yf_handle *out);
 /* dtype 0 = fp32 (yf_create); 1 = BASELINE configs[2]: activations stored fp16 in HBM, the pointwise GEMMs on
  * v_mfma_f32_16x16x16_f16 with fp16 weights, fp32 accumulation everywhere; depthwise / small-channel kernels compute in fp32
@@ -72,12 +76,13 @@ int yf_create_ex(const void *packed_weights, size_t nbytes, int H, int W, int ma
 /* The fp32 -> fp16 rounding (nearest even) the weight packer uses on the host. */
 uint16_t yf_f32_to_f16_bits(float f);
 int yf_destroy(yf_handle h);
+int yf_io_params(yf_handle h, int *input_channel, int *num_anchors, int *num_cls, int *num_out);   /* any pointer may be NULL */
 
 /* Bytes of device scratch yf_forward / yf_detect need for a batch of N frames. */
 int yf_workspace_bytes(yf_handle h, int N, size_t *out);
 
-/* model(x): d_x float32 [N,1,H,W] contiguous, values (u8-128)/255.
- * d_head_large float32 [N,24,H/16,W/16], d_head_small float32 [N,24,H/32,W/32], NCHW like the reference. */
+/* model(x): d_x float32 [N,C_in,H,W] contiguous (NCHW like the reference's input), values (u8-128)/255.
+ * d_head_large float32 [N,num_out,H/16,W/16], d_head_small float32 [N,num_out,H/32,W/32], NCHW like the reference. */
 int yf_forward(yf_handle h, const float *d_x, int N, float *d_head_large, float *d_head_small,
                void *d_workspace, size_t workspace_bytes, void *stream);
 
@@ -89,7 +94,8 @@ int yf_forward_probe(yf_handle h, const float *d_x, int N, const char *name, flo
 
 /* Post-process of N frames (the reference handles batch element 0 only, detect.py:46; frame f here is
  * exactly what the reference computes for pred[f:f+1]).
- *   anchors: HOST double[2][3][2] = io_params["anchors"][head][anchor][w,h] in net-input pixels.
+ *   anchors: HOST double[2][A][2] = io_params["anchors"][head][anchor][w,h] in net-input pixels (the first A of each group,
+ *       detect.py:51,63-64).  Classes: argmax over the C raw class logits, first maximum wins (detect.py:59).
  *   conf_thres / nms_thres: strict '>' as in detect.py:58,79.
  *   origin_h/origin_w: if both > 0 and different from H/W, corners are rescaled and re-rounded as
  *       __adjust_coord does (detect.py:131-139); pass 0,0 to keep net-input coordinates.
@@ -115,22 +121,27 @@ int yf_nms_sorted(yf_handle h, const int32_t *d_boxes, int n, double nms_thres, 
 
 /* Validation-time decode and NMS (the reference's OTHER convention, used by validate.py for mAP):
  *   yf_val_decode_head = YOLOLossV3.forward(input, targets=None)   src/model_training/loss/yolo_loss.py:48-68, :98-141
- *       d_head float32 [N,24,fh,fw] -> rows m_off .. m_off+3*fh*fw of d_out float32 [N,M_total,8] = (cx,cy,w,h,conf,cls0..2),
- *       anchors: HOST double[3][2] of this head; calling it once per head with m_off = 0 / 3*fh*fw reproduces
- *       validate.py:38-42's torch.cat over heads.
+ *       d_head float32 [N,num_out,fh,fw] -> rows m_off .. m_off+A*fh*fw of d_out float32 [N,M_total,5+C] = (cx,cy,w,h,conf,cls0..),
+ *       anchors: HOST double[A][2] of this head; calling it once per head with m_off = 0 / A*fh*fw reproduces
+ *       validate.py:38-42's torch.cat over heads.  (The reference's own decode branch repeats its grid 3 times, yolo_loss.py:110-111,
+ *       and therefore only runs with 3 anchors; this one takes any A.)
  *   yf_val_nms = utils.general.non_max_suppression                 src/model_training/utils/general.py:87-143 (+ bbox_iou :29-52)
- *       d_pred float32 [N,M,8]; conf >= conf_thres, per-class greedy NMS, IoU with the +1 convention, keep iou < nms_thres;
+ *       d_pred float32 [N,M,5+C] (yf_val_nms: C = the engine's num_cls; yf_val_nms_ex: C = num_classes, the reference's argument);
+ *       conf >= conf_thres, per-class greedy NMS, IoU with the +1 convention, keep iou < nms_thres;
  *       d_det float32 [N,K_max,7] = (x1,y1,x2,y2,obj_conf,class_conf,class_pred), class-ascending then conf-descending;
  *       d_counts int32 [N] = true number of detections (0 <=> the reference's None). */
 int yf_val_decode_head(yf_handle h, const float *d_head, int N, int fh, int fw, const double *anchors, int M_total, int m_off,
                        float *d_out, void *stream);
 int yf_val_nms(yf_handle h, const float *d_pred, int N, int M, double conf_thres, double nms_thres, int K_max, float *d_det,
                int32_t *d_counts, void *stream);
+int yf_val_nms_ex(yf_handle h, const float *d_pred, int N, int M, int num_classes, double conf_thres, double nms_thres, int K_max,
+                  float *d_det, int32_t *d_counts, void *stream);
 
 /* The loss end of the reference's training step (first slice; the layers' backward is not part of it):
  *   yf_train_loss = YOLOLossV3.forward(input, targets) for ONE head   src/model_training/loss/yolo_loss.py:48-97 (+ get_target :144-196)
  *                   and, if d_grad_head is not NULL, d(total loss)/d(input): what loss.backward() (train.py:131) leaves in input.grad.
- *   d_head float32 [N,24,fh,fw]; anchors: HOST double[3][2] of this head (net-input pixels); d_targets float32 [N,T,6] =
+ *   d_head float32 [N,A*(5+C),fh,fw]; anchors: HOST double[A][2] of this head (net-input pixels; yf_train_loss: A, C of the engine;
+ *   yf_train_head_loss: 3, 3; yf_train_head_loss_ex: as given -- yolo_loss.py:28-33); d_targets float32 [N,T,6] =
  *   (x, y, w, h normalised to 0..1, class, marker >= 1; the first row with marker < 1 ends an image's list, yolo_loss.py:158);
  *   ignore_thres = config train_params.IOU_loss_thre.
  *   d_losses float32 [8] = total, x, y, w, h, conf, cls (the 7-tuple of yolo_loss.py:94-95) and, in [7], the number of targets whose
@@ -143,6 +154,10 @@ int yf_train_loss(yf_handle h, const float *d_head, int N, int fh, int fw, const
 int yf_train_head_loss_workspace_bytes(int N, int fh, int fw, size_t *out);
 int yf_train_head_loss(int device, int H, int W, const float *d_head, int N, int fh, int fw, const double *anchors, const float *d_targets,
                        int T, double ignore_thres, void *d_work, size_t work_bytes, float *d_losses, float *d_grad_head, void *stream);
+int yf_train_head_loss_workspace_bytes_ex(int N, int fh, int fw, int num_anchors, int num_classes, size_t *out);
+int yf_train_head_loss_ex(int device, int H, int W, const float *d_head, int N, int fh, int fw, const double *anchors, int num_anchors,
+                          int num_classes, const float *d_targets, int T, double ignore_thres, void *d_work, size_t work_bytes,
+                          float *d_losses, float *d_grad_head, void *stream);
 
 /* Operators of the reference's TRAINING step (second slice): every layer type of YoloFastest in train mode, forward
  * and backward, on NCHW float32 device tensors like the reference's (src/model_training/model/yolo_fastest.py:16-66, train.py:98-160).
@@ -212,7 +227,8 @@ int yf_train_adam_multi_pinned(int device, int ntensors, void *const *d_p, const
  *     untouched in between.  backward also needs the images again (d_x: the first conv's weight gradient).
  * Stream-ordered, no allocation, no synchronisation. */
 typedef struct yf_trainer_s *yf_trainer;
-int yf_trainer_create(int H, int W, int device, yf_trainer *out);
+int yf_trainer_create(int H, int W, int device, yf_trainer *out);                                       /* input_channel 1, num_out 24 */
+int yf_trainer_create_ex(int H, int W, int device, int input_channel, int num_out, yf_trainer *out);   /* yolo_fastest.py:72-78 */
 void yf_trainer_destroy(yf_trainer t);
 int yf_trainer_num_params(yf_trainer t, int *n_params, int *n_bn);
 int yf_trainer_workspace_bytes(yf_trainer t, int N, size_t *bytes);
@@ -233,11 +249,13 @@ int yf_detect(yf_handle h, const float *d_x, int N, double conf_thres, double nm
 
 /* Detect_YOLO.__pre_process arithmetic on device: d_u8 uint8 [N,src_h,src_w] gray frames ->
  * d_x float32 [N,1,H,W] = (v-128)/255 where v is the pixel itself (src == net size) or the 2x2
- * box mean (a+b+c+d+2)>>2 (src == 2x net size).  Other ratios: YF_E_INVALID. */
+ * box mean (a+b+c+d+2)>>2 (src == 2x net size).  Other ratios: YF_E_INVALID.
+ * C_in = 3: d_u8 uint8 [N,src_h,src_w,3] as cv2.imread returns a frame (HWC, BGR) -> d_x float32 [N,3,H,W] with the channel order
+ * reversed, detect.py:119 `img[:, :, ::-1].transpose(2, 0, 1)`; the box mean is taken per channel. */
 int yf_preprocess_u8(yf_handle h, const uint8_t *d_u8, int N, int src_h, int src_w, float *d_x, void *stream);
 
 /* yf_forward on u8 gray frames: Detect_YOLO.__pre_process's arithmetic (src/detect.py:115-124) is fused into the first
- * kernel's loads -- d_u8 uint8 [N,src_h,src_w], src == net size or exactly 2x (2x2 box mean).  Bit-identical to
+ * kernel's loads -- d_u8 uint8 [N,src_h,src_w] (C_in = 3: [N,src_h,src_w,3] HWC BGR), src == net size or exactly 2x (2x2 box mean).  Bit-identical to
  * yf_preprocess_u8 followed by yf_forward, one pass and 3-15 bytes per pixel less HBM traffic. */
 int yf_forward_u8(yf_handle h, const uint8_t *d_u8, int N, int src_h, int src_w, float *d_head_large, float *d_head_small,
                   void *d_workspace, size_t workspace_bytes, void *stream);

@@ -24,7 +24,9 @@ import torch.nn.functional as F
 
 BN_EPS = 1e-5  # nn.BatchNorm2d default, yolo_fastest.py:12-13
 
-# (name, kind, cin, cout, k, stride, relu)   kind: 'c' dense conv, 'dw' depthwise, 'dc' deconv
+# (name, kind, cin, cout, k, stride, relu)   kind: 'c' dense conv, 'dw' depthwise, 'dc' deconv.  The table is for io_params'
+# input_channel = 1; `cin` is only read for the depthwise layers' group count, so a state-dict built for another input_channel /
+# num_cls / num_anchors (conv0 [8,Cin,3,3], heads [A*(5+C),.,1,1]: yolo_fastest.py:72-78,138,148) runs through the same code.
 # Order == module definition order == state-dict order (yolo_fastest.py:78-148).
 def _res(name, c, e):
     return [(f"{name}.conv1", "c", c, e, 1, 1, True), (f"{name}.conv2", "dw", e, e, 3, 1, True),
@@ -154,9 +156,16 @@ def training_state(sd, dtype=torch.float32):
     return out
 
 
-def preprocess(u8):
-    """src/detect.py:122-127: u8 [N,H,W] (or [H,W]) -> float32 [N,1,H,W], (x-128)/255."""
-    x = torch.as_tensor(u8).to(torch.float32)
+def preprocess(u8, input_channel=1):
+    """src/detect.py:119-127: u8 [N,H,W] (or [H,W]) -> float32 [N,1,H,W], (x-128)/255; input_channel 3: u8 [N,H,W,3] as cv2.imread
+    hands it over (BGR) -> `img[:, :, ::-1].transpose(2, 0, 1)` (:119) -> float32 [N,3,H,W]."""
+    x = torch.as_tensor(u8)
+    if input_channel != 1:
+        if x.dim() == 3:
+            x = x[None]
+        x = x.flip(-1).permute(0, 3, 1, 2).to(torch.float32)
+        return ((x - 128.0) / 255.0).contiguous()
+    x = x.to(torch.float32)
     x = (x - 128.0) / 255.0
     if x.dim() == 2:
         x = x[None]

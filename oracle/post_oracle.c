@@ -30,11 +30,11 @@ typedef struct {
 /* returns number of survivors written (<= kmax), -1 if kmax too small, -2 for the reference's
  * ZeroDivisionError (two zero-area boxes compared, detect.py:39). */
 int yf_oracle_post(const float *head_large, int hl, int wl, const float *head_small, int hs, int ws,
-                   const double *anchors /*[2][3][2]*/, int in_h, int in_w, double conf_thres, double nms_thres,
-                   int num_cls, int kmax, int32_t *out_box /*[kmax][4]*/, double *out_conf, double *out_score,
+                   const double *anchors /*[2][num_anchors][2]*/, int in_h, int in_w, double conf_thres, double nms_thres,
+                   int num_cls, int num_anchors, int kmax, int32_t *out_box /*[kmax][4]*/, double *out_conf, double *out_score,
                    int32_t *out_cls, int32_t *out_src, int32_t *n_candidates)
 {
-    const int A = 3, attrs = 5 + num_cls;
+    const int A = num_anchors, attrs = 5 + num_cls;
     int total = A * (hl * wl + hs * ws);
     cand_t *c = (cand_t *)malloc(sizeof(cand_t) * (size_t)total);
     int n = 0, base = 0;
@@ -56,8 +56,8 @@ int yf_oracle_post(const float *head_large, int hl, int wl, const float *head_sm
                     }
                     double x = (j + sigmoid_d(T(0))) * scale_w;
                     double y = (i + sigmoid_d(T(1))) * scale_h;
-                    double bw = exp(T(2)) * anchors[(head * 3 + pp) * 2 + 0];
-                    double bh = exp(T(3)) * anchors[(head * 3 + pp) * 2 + 1];
+                    double bw = exp(T(2)) * anchors[(head * A + pp) * 2 + 0];
+                    double bh = exp(T(3)) * anchors[(head * A + pp) * 2 + 1];
 #undef T
                     cand_t *q = &c[n++];
                     q->x1 = (long long)rint(x - bw / 2); q->y1 = (long long)rint(y - bh / 2);

@@ -109,6 +109,6 @@ def adjust_coord(boxes, origin_shape, input_shape):  # detect.py:131-139
     return boxes
 
 
-def post_process(heads, anchors, input_shape, conf_thres=0.5, nms_thres=0.2, num_cls=3):
+def post_process(heads, anchors, input_shape, conf_thres=0.5, nms_thres=0.2, num_cls=3, num_anchors=3):
     """decode + per-class NMS for one frame; returns the class-major survivor list."""
-    return detect_glue(decode_box(heads, anchors, input_shape, conf_thres, 3, num_cls), nms_thres, num_cls)
+    return detect_glue(decode_box(heads, anchors, input_shape, conf_thres, num_anchors, num_cls), nms_thres, num_cls)

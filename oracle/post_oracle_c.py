@@ -24,19 +24,19 @@ def lib():
     return _lib
 
 
-def post_process(head_large, head_small, anchors, input_shape, conf_thres=0.5, nms_thres=0.2, num_cls=3, kmax=None):
-    """One frame. head_*: float32 [24,h,w]. Returns dict(box,conf,score,cls,src,count,n_candidates)."""
+def post_process(head_large, head_small, anchors, input_shape, conf_thres=0.5, nms_thres=0.2, num_cls=3, kmax=None, num_anchors=3):
+    """One frame. head_*: float32 [num_anchors*(5+num_cls),h,w]. Returns dict(box,conf,score,cls,src,count,n_candidates)."""
     hl = np.ascontiguousarray(head_large, np.float32)
     hs = np.ascontiguousarray(head_small, np.float32)
-    anc = np.ascontiguousarray(np.asarray(anchors, np.float64)[:2]).reshape(-1)
+    anc = np.ascontiguousarray(np.asarray(anchors, np.float64)[:2, :num_anchors]).reshape(-1)
     if kmax is None:
-        kmax = 3 * (hl.shape[1] * hl.shape[2] + hs.shape[1] * hs.shape[2])
+        kmax = num_anchors * (hl.shape[1] * hl.shape[2] + hs.shape[1] * hs.shape[2])
     box = np.zeros((kmax, 4), np.int32); conf = np.zeros(kmax); score = np.zeros(kmax)
     cls = np.zeros(kmax, np.int32); src = np.zeros(kmax, np.int32); ncand = ctypes.c_int32(0)
     P = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t))
     n = lib().yf_oracle_post(P(hl, ctypes.c_float), hl.shape[1], hl.shape[2], P(hs, ctypes.c_float), hs.shape[1],
                              hs.shape[2], P(anc, ctypes.c_double), int(input_shape[0]), int(input_shape[1]),
-                             ctypes.c_double(conf_thres), ctypes.c_double(nms_thres), num_cls, kmax,
+                             ctypes.c_double(conf_thres), ctypes.c_double(nms_thres), num_cls, num_anchors, kmax,
                              P(box, ctypes.c_int32), P(conf, ctypes.c_double), P(score, ctypes.c_double),
                              P(cls, ctypes.c_int32), P(src, ctypes.c_int32), ctypes.byref(ncand))
     if n == -2:

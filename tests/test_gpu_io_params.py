@@ -1,0 +1,305 @@
+"""io_params generality of the drop-in boundary: `YoloFastest(io_params)`, `YOLO_post_process`, the
+validation decode / NMS, the training loss and the training step for num_cls / input_channel / num_anchors other than the shipped
+(3, 1, 3) -- the reference's constructors are parameterised on all three (yolo_fastest.py:72-78,138,148; detect.py:15-21,53-66;
+yolo_loss.py:28-33,58-60).  Expected values: tests/golden/golden_io.npz, which tests/golden/make_golden.py (main_io) made by running the
+REFERENCE module / post-process / loss on numpy-seeded weights and inputs for every configuration of seeded_weights.IO_CONFIGS:
+  c1 (1 class), c5rgb (5 classes, 3-channel input), c20 (20 classes: 75 head channels, the run-time head loop), a2 (2 anchors),
+  c80rgb (80 classes: 255 head channels, 3-channel input).
+Tolerances as in test_gpu_parity.py: heads within max(3 x E, 5e-5) of the graph in fp64 (E = the reference's own fp32 distance from
+it), decode + NMS bit-exact including order given identical logits."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import io_cfg
+
+pytestmark = pytest.mark.gpu
+
+ACCURACY_RATIO, ACCURACY_FLOOR, SCORE_TOL = 3.0, 5e-5, 1e-4
+
+
+@pytest.fixture(scope="module")
+def yf():
+    import yolo_fastest_amd
+    return yolo_fastest_amd
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+_MODELS = {}
+
+
+def _model(yf, dev, golden, tag):
+    if tag not in _MODELS:
+        g = golden("golden_io")
+        io = io_cfg.io_for(tag)
+        m = yf.YoloFastest(io).to(dev).eval()
+        m.load_state_dict({k: v.to(dev) for k, v in io_cfg.state_dict_for(tag, int(g[tag + "_seed"])).items()})   # strict
+        post = yf.YOLO_post_process(io["conf_thre"], io["nms_thre"], io["num_anchors"], io["num_cls"], io["anchors"], io["input_shape"]).bind(m)
+        _MODELS[tag] = (m, post, io)
+    return _MODELS[tag]
+
+
+def _x(tag, dev):
+    from oracle import backbone_oracle as bo
+    C, Cin, A = io_cfg.CONFIG[tag]
+    return bo.preprocess(io_cfg.io_inputs(tag, Cin), Cin).to(dev)
+
+
+def _check_heads(got, ref32, ref64, tag):
+    got = got.cpu().numpy()
+    assert got.shape == ref32.shape
+    ours, theirs = np.abs(got - ref64).max(), np.abs(ref32 - ref64).max()
+    bound = max(ACCURACY_RATIO * theirs, ACCURACY_FLOOR)
+    assert ours <= bound, (tag, ours, theirs)
+    sig = lambda a: 1.0 / (1.0 + np.exp(-a.astype(np.float64)))
+    assert np.abs(sig(got) - sig(ref32)).max() < SCORE_TOL      # every sigmoid the reference could emit: conf, class scores, x, y
+
+
+@pytest.mark.parametrize("tag", io_cfg.TAGS)
+@pytest.mark.parametrize("fusion", [0, 1, 2])
+def test_heads_match_the_reference_for_other_io_params(yf, dev, golden, tag, fusion):
+    g = golden("golden_io")
+    m, _, io = _model(yf, dev, golden, tag)
+    C, Cin, A = io_cfg.CONFIG[tag]
+    assert m.num_out == A * (5 + C) and m.head_5.weight.shape == (A * (5 + C), 128, 1, 1) and m.conv0[0].weight.shape == (8, Cin, 3, 3)
+    m.fusion = fusion
+    try:
+        with torch.no_grad():
+            hl, hs = m(_x(tag, dev))
+    finally:
+        m.fusion = yf.model.DEFAULT_FUSION
+    assert hl.shape == (2, A * (5 + C), 16, 20) and hs.shape == (2, A * (5 + C), 8, 10)
+    _check_heads(hl, g[tag + "_head_large"], g[tag + "_head_large_f64"], tag)
+    _check_heads(hs, g[tag + "_head_small"], g[tag + "_head_small_f64"], tag)
+
+
+@pytest.mark.parametrize("tag", io_cfg.TAGS)
+def test_fusion_levels_agree_bitwise_for_other_io_params(yf, dev, golden, tag):
+    """levels 1 and 2 issue the same arithmetic in the same order (the chained small head included); level 0's per-layer kernels are a
+    different summation order and only agree to rounding."""
+    m, _, _ = _model(yf, dev, golden, tag)
+    x = _x(tag, dev)
+    out = {}
+    for f in (1, 2):
+        m.fusion = f
+        with torch.no_grad():
+            out[f] = [t.clone() for t in m(x)]
+    m.fusion = yf.model.DEFAULT_FUSION
+    assert torch.equal(out[1][0], out[2][0]) and torch.equal(out[1][1], out[2][1])
+
+
+@pytest.mark.parametrize("tag", io_cfg.TAGS)
+@pytest.mark.parametrize("prec", ["f16x3", "f16"])
+def test_fp16_matrix_paths_for_other_io_params(yf, dev, golden, tag, prec):
+    g = golden("golden_io")
+    io = io_cfg.io_for(tag)
+    m = yf.YoloFastest(io).to(dev).eval()
+    m.load_state_dict({k: v.to(dev) for k, v in io_cfg.state_dict_for(tag, int(g[tag + "_seed"])).items()})
+    m.precision = prec
+    with torch.no_grad():
+        hl, hs = m(_x(tag, dev))
+    if prec == "f16x3":      # split-operand fp16 MFMA: the fp32 bounds
+        _check_heads(hl, g[tag + "_head_large"], g[tag + "_head_large_f64"], tag)
+        _check_heads(hs, g[tag + "_head_small"], g[tag + "_head_small_f64"], tag)
+    else:                    # fp16 storage: the throughput variant's bound (test_gpu_parity.test_random_weights_against_oracle)
+        for got, ref in ((hl, g[tag + "_head_large"]), (hs, g[tag + "_head_small"])):
+            d = np.abs(got.cpu().numpy() - ref).max()
+            assert d <= 5e-3 * max(1.0, np.abs(ref).max()), (tag, d)
+
+
+@pytest.mark.parametrize("tag", io_cfg.TAGS)
+def test_post_process_bit_exact_for_other_io_params(yf, dev, golden, tag):
+    """decode + class buckets + stable sort + NMS on the REFERENCE's logits: candidates and survivors equal the reference's own
+    YOLO_post_process run, in its order; a frame where the reference raised ZeroDivisionError raises here."""
+    g = golden("golden_io")
+    m, post, io = _model(yf, dev, golden, tag)
+    C, Cin, A = io_cfg.CONFIG[tag]
+    hl = torch.from_numpy(g[tag + "_head_large"]).to(dev)
+    hs = torch.from_numpy(g[tag + "_head_small"]).to(dev)
+    raw = post.detect_raw((hl, hs), kmax=A * 400)
+    counts = raw["counts"].cpu().numpy()
+    for f in range(hl.shape[0]):
+        want = io_cfg.unpack_lists(g, tag + "_final", f)
+        assert counts[f] == want["count"], (tag, f)
+        if want["count"] == -2:
+            with pytest.raises(ZeroDivisionError):
+                post.to_lists(raw)
+            continue
+        n = want["count"]
+        assert np.array_equal(raw["src"][f, :n].cpu().numpy(), want["src"])
+        assert np.array_equal(raw["boxes"][f, :n].cpu().numpy(), want["box"])
+        assert np.array_equal(raw["cls"][f, :n].cpu().numpy(), want["cls"])
+        sc = raw["scores"][f, :n].cpu().numpy().astype(np.float64)
+        assert np.abs(sc[:, 0] - want["conf"]).max() < 1e-6 and np.abs(sc[:, 1] - want["score"]).max() < 1e-6
+        # the reference-named method: candidates of batch element 0 in decode order (detect.py:41-67)
+        if f == 0:
+            cands = post.decode_box((hl, hs))
+            wc = io_cfg.unpack_lists(g, tag + "_cand", 0)
+            assert len(cands) == wc["count"]
+            assert np.array_equal(np.array([c[:4] for c in cands]), wc["box"]) and [c[6] for c in cands] == wc["cls"].tolist()
+
+
+@pytest.mark.parametrize("tag", ["c5rgb", "c20", "a2"])
+def test_detect_single_call_and_own_logits(yf, dev, golden, tag):
+    """yf_detect (forward + decode + NMS in one C call, two lanes) on the engine's OWN logits == the C oracle on those logits."""
+    from oracle import post_oracle_c as poc
+    m, post, io = _model(yf, dev, golden, tag)
+    C, Cin, A = io_cfg.CONFIG[tag]
+    x = _x(tag, dev)
+    raw = post.detect_raw_from_input(x, kmax=A * 400)
+    with torch.no_grad():
+        hl, hs = m(x)
+    assert torch.equal(raw["head_large"], hl) and torch.equal(raw["head_small"], hs)
+    for f in range(x.shape[0]):
+        try:
+            r = poc.post_process(hl[f].cpu().numpy(), hs[f].cpu().numpy(), io["anchors"], io["input_shape"][:2], io["conf_thre"], io["nms_thre"], C,
+                                 num_anchors=A)
+        except ZeroDivisionError:
+            assert int(raw["counts"][f]) == -2
+            continue
+        n = r["count"]
+        assert int(raw["counts"][f]) == n
+        assert np.array_equal(raw["src"][f, :n].cpu().numpy(), r["src"]) and np.array_equal(raw["boxes"][f, :n].cpu().numpy(), r["box"])
+        assert np.array_equal(raw["cls"][f, :n].cpu().numpy(), r["cls"])
+
+
+@pytest.mark.parametrize("tag", ["c5rgb", "c80rgb"])
+def test_rgb_u8_frames_fused_preprocess(yf, dev, golden, tag):
+    """3-channel frames as cv2.imread returns them (HWC, BGR): yf_preprocess_u8 == detect.py:119-124's arithmetic, and the fused
+    u8 stem (yf_forward_u8) is bit-identical to pre-process + forward; also from frames of exactly twice the net size (2x2 box mean per
+    channel)."""
+    from oracle import backbone_oracle as bo
+    m, _, io = _model(yf, dev, golden, tag)
+    u8 = io_cfg.io_inputs(tag, 3)
+    x = yf.preprocess_u8(m, torch.from_numpy(u8).to(dev), io["input_shape"])
+    assert torch.equal(x.cpu(), bo.preprocess(u8, 3))
+    with torch.no_grad():
+        a = m(x)
+        b = m.forward_u8(torch.from_numpy(u8).to(dev), io["input_shape"])
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    big = np.random.default_rng(5).integers(0, 256, size=(2, 512, 640, 3), dtype=np.uint8)
+    small = ((big[:, 0::2, 0::2].astype(np.uint16) + big[:, 0::2, 1::2] + big[:, 1::2, 0::2] + big[:, 1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    x2 = yf.preprocess_u8(m, torch.from_numpy(big).to(dev), io["input_shape"])
+    assert torch.equal(x2.cpu(), bo.preprocess(small, 3))
+    with torch.no_grad():
+        a = m(x2)
+        b = m.forward_u8(torch.from_numpy(big).to(dev), io["input_shape"])
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 1, 256, 320, device=dev))       # a 3-channel model on a 1-channel tensor
+
+
+@pytest.mark.parametrize("tag", io_cfg.TAGS)
+def test_validation_decode_nms_and_loss_for_other_io_params(yf, dev, golden, tag):
+    from yolo_fastest_amd import validation
+    from oracle import val_oracle as vo
+    g = golden("golden_io")
+    m, _, io = _model(yf, dev, golden, tag)
+    C, Cin, A = io_cfg.CONFIG[tag]
+    pred = (torch.from_numpy(g[tag + "_head_large"]).to(dev), torch.from_numpy(g[tag + "_head_small"]).to(dev))
+    crit = [validation.YOLOLossV3(io["anchors"][i], C, io["input_shape"], dev, model=m) for i in range(2)]
+    dec = torch.cat([crit[i](pred[i]) for i in range(2)], 1)
+    assert dec.shape == (2, A * 400, 5 + C)
+    ref = vo.decode(tuple(p.cpu() for p in pred), io["anchors"], C, io["input_shape"])      # the oracle, pinned by the reference where A == 3
+    assert (dec.cpu() - ref).abs().max().item() < 2e-4          # exp / sigmoid on the device against the host's, boxes up to ~300 px
+    if A == 3:
+        np.testing.assert_allclose(dec.cpu().numpy()[:1, ::3], g[tag + "_val_decode"], rtol=0, atol=2e-4)
+    # NMS on the ORACLE's decode (identical inputs): bit-identical detections, order included
+    dets = validation.non_max_suppression(ref.to(dev), C, conf_thres=0.5, nms_thres=0.2, model=m)
+    want = vo.non_max_suppression(ref, C, 0.5, 0.2)
+    for d, w in zip(dets, want):
+        assert (d is None) == (w is None)
+        if d is not None:
+            assert torch.equal(d.cpu(), w)
+    if A == 3:
+        for f, d in enumerate(dets):
+            n = int(g[tag + "_val_count"][f])
+            assert (0 if d is None else d.shape[0]) == n
+            np.testing.assert_allclose(d.cpu().numpy(), g[tag + "_val_det"][f, :n], rtol=0, atol=1e-5)
+    # the training loss of both heads and its gradient against the reference's own run
+    tt = torch.from_numpy(io_cfg.io_targets(tag, C, 2)).to(dev)
+    for i, name in enumerate(("head_large", "head_small")):
+        x = pred[i].clone().requires_grad_(True)
+        res = crit[i](x, tt)
+        res[0].backward()
+        want_l = g[f"{tag}_{name}_losses"]
+        got_l = np.array([float(res[0])] + [float(v) for v in res[1:]])
+        np.testing.assert_allclose(got_l, want_l, rtol=2e-5, atol=1e-7)
+        wg = g[f"{tag}_{name}_grad"]
+        assert np.abs(x.grad.cpu().numpy() - wg).max() <= 2e-5 * np.abs(wg).max()
+
+
+@pytest.mark.parametrize("tag", ["c5rgb", "a2"])
+def test_training_step_for_other_io_params(yf, dev, golden, tag):
+    """model.train(); pred = model(imgs); the two-head loss; loss.backward() (train.py:111-131) for an RGB 5-class and a 2-anchor model
+    against the reference's own iteration: train-mode heads, the seven losses, a strided sample and the per-tensor sums of every
+    parameter gradient, the BatchNorm running statistics."""
+    from yolo_fastest_amd import validation
+    from oracle import backbone_oracle as bo
+    g = golden("golden_io")
+    C, Cin, A = io_cfg.CONFIG[tag]
+    io = io_cfg.io_for(tag, 64, 96)
+    m = yf.YoloFastest(io).to(dev)
+    m.load_state_dict({k: v.to(dev) for k, v in io_cfg.state_dict_for(tag, int(g[tag + "_seed"])).items()})
+    m.train()
+    u8 = io_cfg.io_inputs(tag + "_train", Cin, n=4, H=64, W=96)
+    tt = torch.from_numpy(io_cfg.io_targets(tag + "_train", C, 4)).to(dev)
+    crit = [validation.YOLOLossV3(io["anchors"][i], C, io["input_shape"], dev, model=m) for i in range(2)]
+    pred = m(bo.preprocess(u8, Cin).to(dev))
+    np.testing.assert_allclose(pred[0].detach().cpu().numpy(), g[tag + "_train_head_large"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(pred[1].detach().cpu().numpy(), g[tag + "_train_head_small"], rtol=0, atol=5e-5)
+    losses = [[] for _ in range(7)]
+    for i, p in enumerate(pred):
+        for j, v in enumerate(crit[i](p, tt)):
+            losses[j].append(v)
+    losses = [sum(v) for v in losses]
+    np.testing.assert_allclose([float(v) for v in losses], g[tag + "_train_losses"], rtol=5e-5)
+    losses[0].backward()
+    names = [n for n, _ in m.named_parameters()]
+    assert names == [str(k) for k in g[tag + "_train_param_names"]]
+    grads = [p.grad.detach().cpu().numpy().ravel() for p in m.parameters()]
+    flat, want = np.concatenate(grads)[::37], g[tag + "_train_grad_sample"]
+    assert np.abs(flat - want).max() <= 2e-3 * np.abs(want).max(), np.abs(flat - want).max() / np.abs(want).max()
+    got_sum = np.array([np.abs(v.astype(np.float64)).sum() for v in grads])
+    big = g[tag + "_train_grad_abssum"] > 1e-3 * g[tag + "_train_grad_abssum"].max()      # (BatchNorm biases whose exact gradient is 0 carry noise only)
+    np.testing.assert_allclose(got_sum[big], g[tag + "_train_grad_abssum"][big], rtol=2e-2)
+    bufs = np.concatenate([b.detach().cpu().numpy().ravel() for n, b in m.named_buffers() if not n.endswith("num_batches_tracked")])
+    np.testing.assert_allclose(bufs[::7], g[tag + "_train_buffers_sample"], rtol=1e-4, atol=1e-5)
+    # eval() after training re-packs the updated parameters for the inference engine
+    m.eval()
+    with torch.no_grad():
+        hl, hs = m(bo.preprocess(u8, Cin).to(dev))
+    assert hl.shape == (4, A * (5 + C), 4, 6) and torch.isfinite(hl).all() and torch.isfinite(hs).all()
+
+
+def test_blob_header_is_checked(yf, dev, golden):
+    """yf_create reads num_anchors / num_cls / input_channel from the blob header and refuses inconsistent ones."""
+    import struct
+    from yolo_fastest_amd import _lib, packer
+    g = golden("golden_io")
+    lib = _lib.lib()
+    sd = io_cfg.state_dict_for("a2", int(g["a2_seed"]))
+    blob = packer.pack_state_dict(sd, 16, 1, 2, 3)
+    h = ctypes.c_void_p()
+    buf = ctypes.create_string_buffer(blob, len(blob))
+    assert lib.yf_create(buf, len(blob), 64, 96, 2, 0, ctypes.byref(h)) == 0
+    vals = [ctypes.c_int() for _ in range(4)]
+    assert lib.yf_io_params(h, *[ctypes.byref(v) for v in vals]) == 0
+    assert [v.value for v in vals] == [1, 2, 3, 16]
+    lib.yf_destroy(h)
+    bad = bytearray(blob)
+    struct.pack_into("<I", bad, 8 + 4 * 4, 3)                  # num_anchors 3 with num_out 16: 3 * (5 + 3) != 16
+    b2 = ctypes.create_string_buffer(bytes(bad), len(bad))
+    assert lib.yf_create(b2, len(bad), 64, 96, 2, 0, ctypes.byref(h)) == _lib.YF_E_BLOB
+    assert b"num_out" in lib.yf_last_error_string()
+    with pytest.raises(RuntimeError, match="Missing key|size mismatch|Unexpected key"):   # strict load: a 3-class checkpoint into a 5-class model
+        m = yf.YoloFastest(io_cfg.io_for("c5rgb"))
+        m.load_state_dict(sd)

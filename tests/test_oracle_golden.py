@@ -270,3 +270,97 @@ def test_relu_flips_confine_the_fp32_gradient_error(golden):
     assert 1e-3 <= reach_worst <= 5e-2, reach_worst
     # upstream(): the two heads' private layers are not upstream of each other, the trunk is upstream of both
     assert "conv5_3" not in fr.upstream("conv4_1_2") and "conv5_2" in fr.upstream("conv4_1_2") and "deconv5_1" not in fr.upstream("conv5_5")
+
+
+# ---- io_params generality: the oracles against what the REFERENCE computed for five (num_cls, input_channel,
+# num_anchors) configurations with numpy-seeded weights (tests/golden/make_golden.py main_io -> golden_io.npz) ----
+from tests import io_cfg  # noqa: E402
+
+
+@pytest.mark.parametrize("tag", io_cfg.TAGS)
+def test_io_configs_backbone_and_post_oracles(golden, tag):
+    g = golden("golden_io")
+    C, Cin, A = io_cfg.CONFIG[tag]
+    io = io_cfg.io_for(tag)
+    sd = io_cfg.state_dict_for(tag, int(g[tag + "_seed"]))
+    assert sd["conv0.0.weight"].shape == (8, Cin, 3, 3) and sd["head_4.weight"].shape[0] == A * (5 + C)
+    u8 = io_cfg.io_inputs(tag, Cin)
+    hl, hs = bo.forward(sd, bo.preprocess(u8, Cin))
+    np.testing.assert_allclose(hl.numpy(), g[tag + "_head_large"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(hs.numpy(), g[tag + "_head_small"], rtol=0, atol=2e-5)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    h64 = bo.forward(sd64, bo.preprocess(u8, Cin).double())
+    np.testing.assert_allclose(h64[0].numpy(), g[tag + "_head_large_f64"], rtol=0, atol=1e-9)
+    # post-process oracles (Python doubles and C) on the reference's own logits: candidates and survivors bit for bit, in order
+    for f in range(len(u8)):
+        heads = (g[tag + "_head_large"][f], g[tag + "_head_small"][f])
+        want_c, want_f = io_cfg.unpack_lists(g, tag + "_cand", f), io_cfg.unpack_lists(g, tag + "_final", f)
+        cands = po.decode_box(heads, io["anchors"], io["input_shape"][:2], io["conf_thre"], A, C)
+        assert [c[7] for c in cands] == want_c["src"].tolist()
+        assert np.array_equal(np.array([c[:4] for c in cands], np.int64).reshape(-1, 4), want_c["box"])
+        assert [c[6] for c in cands] == want_c["cls"].tolist()
+        assert [c[4] for c in cands] == want_c["conf"].tolist() and [c[5] for c in cands] == want_c["score"].tolist()
+        if want_f["count"] == -2:
+            with pytest.raises(ZeroDivisionError):
+                po.detect_glue(cands, io["nms_thre"], C)
+            with pytest.raises(ZeroDivisionError):
+                poc.post_process(heads[0], heads[1], io["anchors"], io["input_shape"][:2], io["conf_thre"], io["nms_thre"], C, num_anchors=A)
+            continue
+        fin = po.detect_glue(cands, io["nms_thre"], C)
+        assert [c[7] for c in fin] == want_f["src"].tolist()
+        r = poc.post_process(heads[0], heads[1], io["anchors"], io["input_shape"][:2], io["conf_thre"], io["nms_thre"], C, num_anchors=A)
+        assert r["n_candidates"] == want_c["count"] and r["count"] == want_f["count"]
+        assert np.array_equal(r["src"], want_f["src"]) and np.array_equal(r["box"], want_f["box"]) and np.array_equal(r["cls"], want_f["cls"])
+        assert np.array_equal(r["conf"], want_f["conf"]) and np.array_equal(r["score"], want_f["score"])
+
+
+@pytest.mark.parametrize("tag", io_cfg.TAGS)
+def test_io_configs_val_and_loss_oracles(golden, tag):
+    from oracle import val_oracle as vo
+    from oracle import loss_oracle as lo
+    g = golden("golden_io")
+    C, Cin, A = io_cfg.CONFIG[tag]
+    io = io_cfg.io_for(tag)
+    pred = (torch.from_numpy(g[tag + "_head_large"]), torch.from_numpy(g[tag + "_head_small"]))
+    if A == 3:   # the reference's decode branch only runs with 3 anchors (yolo_loss.py:110-111)
+        dec = vo.decode(pred, io["anchors"], C, io["input_shape"])
+        np.testing.assert_allclose(dec.numpy()[:1, ::3], g[tag + "_val_decode"], rtol=0, atol=1e-6)
+        dets = vo.non_max_suppression(dec, C, 0.5, 0.2)
+        for f, d in enumerate(dets):
+            n = int(g[tag + "_val_count"][f])
+            assert (0 if d is None else d.shape[0]) == n
+            if n:
+                np.testing.assert_allclose(d.numpy(), g[tag + "_val_det"][f, :n], rtol=0, atol=1e-5)
+    tt = torch.from_numpy(io_cfg.io_targets(tag, C, pred[0].shape[0]))
+    for i, name in enumerate(("head_large", "head_small")):
+        losses, grad = lo.loss_and_grad(pred[i], tt, io["anchors"][i], C, io["input_shape"])
+        np.testing.assert_allclose(losses, g[f"{tag}_{name}_losses"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(grad.numpy(), g[f"{tag}_{name}_grad"], rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("tag", ["c5rgb", "a2"])
+def test_io_configs_train_mode_oracle(golden, tag):
+    """The train-mode graph + loss oracle against the reference's own iteration for an RGB 5-class and a 2-anchor model."""
+    from oracle import loss_oracle as lo
+    g = golden("golden_io")
+    C, Cin, A = io_cfg.CONFIG[tag]
+    io = io_cfg.io_for(tag, 64, 96)
+    sd = bo.training_state(io_cfg.state_dict_for(tag, int(g[tag + "_seed"])))
+    u8 = io_cfg.io_inputs(tag + "_train", Cin, n=4, H=64, W=96)
+    tt = torch.from_numpy(io_cfg.io_targets(tag + "_train", C, 4))
+    hl, hs = bo.forward(sd, bo.preprocess(u8, Cin), train=True)
+    np.testing.assert_allclose(hl.detach().numpy(), g[tag + "_train_head_large"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(hs.detach().numpy(), g[tag + "_train_head_small"], rtol=0, atol=2e-5)
+    parts = [lo.loss_head(h, tt, io["anchors"][i], C, io["input_shape"]) for i, h in enumerate((hl, hs))]
+    total = parts[0][0] + parts[1][0]
+    np.testing.assert_allclose([float(total)] + [parts[0][k] + parts[1][k] for k in range(1, 7)], g[tag + "_train_losses"], rtol=2e-5)
+    keys = bo.parameter_keys(sd)
+    assert keys == [str(k) for k in g[tag + "_train_param_names"]]
+    grads = torch.autograd.grad(total, [sd[k] for k in keys])
+    flat = np.concatenate([v.numpy().ravel() for v in grads])
+    want = g[tag + "_train_grad_sample"]
+    assert np.abs(flat[::37] - want).max() <= 2e-4 * np.abs(want).max()
+    np.testing.assert_allclose(np.array([np.abs(v.numpy().astype(np.float64)).sum() for v in grads]), g[tag + "_train_grad_abssum"], rtol=2e-3,
+                               atol=1e-6)
+    bufs = np.concatenate([sd[k].numpy().ravel() for k in sd if k.endswith(("running_mean", "running_var"))])
+    np.testing.assert_allclose(bufs[::7], g[tag + "_train_buffers_sample"], rtol=1e-5, atol=1e-6)

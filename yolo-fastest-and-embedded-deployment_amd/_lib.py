@@ -20,6 +20,7 @@ _SIGS = {
     "yf_create_ex": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_void_p)]),
     "yf_f32_to_f16_bits": (_c.c_uint16, [_c.c_float]),
     "yf_destroy": (_c.c_int, [_c.c_void_p]),
+    "yf_io_params": (_c.c_int, [_c.c_void_p] + [_c.POINTER(_c.c_int)] * 4),
     "yf_workspace_bytes": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_size_t)]),
     "yf_forward": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t,
                               _c.c_void_p]),
@@ -39,12 +40,18 @@ _SIGS = {
                                       _c.c_void_p, _c.c_void_p]),
     "yf_val_nms": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_int, _c.c_void_p, _c.c_void_p,
                               _c.c_void_p]),
+    "yf_val_nms_ex": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_int, _c.c_void_p,
+                                 _c.c_void_p, _c.c_void_p]),
     "yf_train_loss_workspace_bytes": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_size_t)]),
     "yf_train_loss": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.c_void_p, _c.c_int,
                                  _c.c_double, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "yf_train_head_loss_workspace_bytes": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_size_t)]),
     "yf_train_head_loss": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_double),
                                       _c.c_void_p, _c.c_int, _c.c_double, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "yf_train_head_loss_workspace_bytes_ex": (_c.c_int, [_c.c_int] * 5 + [_c.POINTER(_c.c_size_t)]),
+    "yf_train_head_loss_ex": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_double),
+                                         _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_double, _c.c_void_p, _c.c_size_t, _c.c_void_p,
+                                         _c.c_void_p, _c.c_void_p]),
     "yf_train_conv_forward": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 8 + [_c.c_void_p]),
     "yf_train_conv_backward_data": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 8 + [_c.c_void_p]),
     "yf_train_conv_backward_weight": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 8 +
@@ -56,6 +63,7 @@ _SIGS = {
     "yf_train_unit_forward": (_c.c_int, [_c.c_int, _c.c_int] + [_c.c_void_p] * 9 + [_c.c_int] * 9 + [_c.c_void_p, _c.c_void_p]),
     "yf_train_unit_backward": (_c.c_int, [_c.c_int, _c.c_int] + [_c.c_void_p] * 12 + [_c.c_int] * 9 + [_c.c_void_p, _c.c_size_t, _c.c_void_p]),  # x z gy stats w gamma beta dgamma dbeta gz dw dx
     "yf_trainer_create": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_void_p)]),
+    "yf_trainer_create_ex": (_c.c_int, [_c.c_int] * 5 + [_c.POINTER(_c.c_void_p)]),
     "yf_trainer_destroy": (None, [_c.c_void_p]),
     "yf_trainer_num_params": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
     "yf_trainer_workspace_bytes": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_size_t)]),

@@ -207,6 +207,70 @@ __global__ void __launch_bounds__(256) dense3x3s2_kernel(DenseArgs a)
                                                          fmaxf(acc[c + 2], 0.f), fmaxf(acc[c + 3], 0.f));
 }
 
+// conv0 of an RGB model (io_params input_channel = 3, yolo_fastest.py:78): the net input is NCHW, i.e. three PLANES per frame, not
+// NHWC.  thread: one output pixel x 8 channels; k order (ky, kx, ci) -- the order of the fused stem's conv0 (yf_fused_kernels.hip).
+template <int C0>
+__global__ void __launch_bounds__(256) conv0_planar_kernel(DenseArgs a)
+{
+    long opix = (long)blockIdx.x * 256 + threadIdx.x;
+    if (opix >= a.total) return;
+    const int ox = (int)(opix % a.Wo);
+    long t = opix / a.Wo;
+    const int oy = (int)(t % a.Ho);
+    const long n = t / a.Ho;
+    const long plane = (long)a.H * a.W;
+    const float* __restrict__ in = a.in + n * C0 * plane;
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = a.b[c];
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - 1 + ky;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 - 1 + kx;
+            const bool v = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+#pragma unroll
+            for (int ci = 0; ci < C0; ++ci) {
+                const float x = v ? in[ci * plane + (long)iy * a.W + ix] : 0.f;
+                const float* wt = a.w + ((ky * 3 + kx) * C0 + ci) * 8;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] = fmaf(x, wt[c], acc[c]);
+            }
+        }
+    }
+    float* o = a.out + opix * 8;
+    *reinterpret_cast<float4*>(o) = make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+    *reinterpret_cast<float4*>(o + 4) = make_float4(fmaxf(acc[4], 0.f), fmaxf(acc[5], 0.f), fmaxf(acc[6], 0.f), fmaxf(acc[7], 0.f));
+}
+
+// Head conv of the per-layer plan for any Cout = num_anchors * (5 + num_cls) (yolo_fastest.py:138,148; the shipped 24 keeps its
+// pw_kernel instantiation).  thread: one pixel x CT consecutive output channels (blockIdx.y = channel tile, wave-uniform -> the
+// weights come through the scalar path); input NHWC in the engine's storage type, logits NCHW float32.
+template <typename T, int CT>
+__global__ void __launch_bounds__(256) head_conv_kernel(const T* __restrict__ in, const float* __restrict__ w, const float* __restrict__ b,
+                                                        float* __restrict__ out, int cin, int cout, long HW, long total)
+{
+    const long pix = (long)blockIdx.x * 256 + threadIdx.x;   // over N * HW
+    if (pix >= total) return;
+    const int c0 = blockIdx.y * CT;
+    float acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = c0 + c < cout ? b[c0 + c] : 0.f;
+    const T* __restrict__ x = in + pix * cin;
+    for (int k = 0; k < cin; k += 4) {      // every 1x1 input of this net has a multiple of 4 channels
+        const float4 v = ld4<T>(x + k);
+        const float xv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                acc[c] = fmaf(xv[kk], c0 + c < cout ? w[(long)(k + kk) * cout + c0 + c] : 0.f, acc[c]);
+    }
+    const long n = pix / HW, hw = pix - n * HW;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+        if (c0 + c < cout) out[(n * cout + c0 + c) * HW + hw] = acc[c];
+}
+
 // NHWC -> NCHW copy for yf_forward_probe (test hook only).
 template <typename T>
 __global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out,
@@ -237,6 +301,31 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const uint8_t* __restri
         v = (float)((p[0] + p[1] + p[2 * W] + p[2 * W + 1] + 2) >> 2);
     } else {
         v = (float)in[idx];
+    }
+    out[idx] = (v - 128.0f) / 255.0f;
+}
+
+// The same for 3-channel frames: `in` is what cv2.imread returns, HWC BGR u8 [N,h,w,3]; `out` NCHW float [N,3,H,W] with the channel
+// order reversed (detect.py:119 `img[:, :, ::-1].transpose(2, 0, 1)`); the exact-2x resize is the 2x2 box mean per channel.
+__global__ void __launch_bounds__(256) preprocess3_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, long total, int H, int W,
+                                                           int down2)
+{
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;   // over the NCHW output
+    if (idx >= total) return;
+    const int x = (int)(idx % W);
+    long t = idx / W;
+    const int y = (int)(t % H);
+    t /= H;
+    const int c = (int)(t % 3);
+    const long n = t / 3;
+    const int sc = 2 - c;
+    float v;
+    if (down2) {
+        const long sw = 2L * W * 3;
+        const uint8_t* p = in + (n * 2 * H + 2 * y) * sw + 2 * x * 3 + sc;
+        v = (float)((p[0] + p[3] + p[sw] + p[sw + 3] + 2) >> 2);
+    } else {
+        v = (float)in[((n * H + y) * W + x) * 3 + sc];
     }
     out[idx] = (v - 128.0f) / 255.0f;
 }
@@ -312,7 +401,21 @@ int launch_dense3x3s2(int cin, int cout, const DenseArgs& a, hipStream_t s)
     dim3 grid((unsigned)((a.total + 255) / 256));
     if (cin == 1 && cout == 8) hipLaunchKernelGGL((dense3x3s2_kernel<1, 8>), grid, dim3(256), 0, s, a);
     else if (cin == 24 && cout == 24) hipLaunchKernelGGL((dense3x3s2_kernel<24, 24>), grid, dim3(256), 0, s, a);
+    else if (cin == 3 && cout == 8) hipLaunchKernelGGL(conv0_planar_kernel<3>, grid, dim3(256), 0, s, a);
     else return -1;
+    return 0;
+}
+
+int launch_head_conv(const float* in, const float* w, const float* b, float* out, int cin, int cout, long HW, int N, hipStream_t s, int dtype)
+{
+    if (cin % 4 || cout <= 0) return -1;
+    constexpr int CT = 8;
+    const long total = (long)N * HW;
+    const dim3 grid((unsigned)((total + 255) / 256), (unsigned)((cout + CT - 1) / CT));
+    if (dtype == DT_F16)
+        hipLaunchKernelGGL((head_conv_kernel<half_t, CT>), grid, dim3(256), 0, s, reinterpret_cast<const half_t*>(in), w, b, out, cin, cout, HW, total);
+    else
+        hipLaunchKernelGGL((head_conv_kernel<float, CT>), grid, dim3(256), 0, s, in, w, b, out, cin, cout, HW, total);
     return 0;
 }
 
@@ -326,10 +429,13 @@ void launch_nhwc_to_nchw(const float* in, float* out, long N, int C, long HW, hi
         hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, C, HW);
 }
 
-void launch_preprocess(const uint8_t* in, float* out, long N, int H, int W, int down2, hipStream_t s)
+void launch_preprocess(const uint8_t* in, float* out, long N, int H, int W, int down2, hipStream_t s, int channels)
 {
-    long total = N * H * W;
-    hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, H, W, down2);
+    long total = N * H * W * channels;
+    if (channels == 3)
+        hipLaunchKernelGGL(preprocess3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, H, W, down2);
+    else
+        hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, H, W, down2);
 }
 
 }  // namespace yf

@@ -114,6 +114,9 @@ struct yf_engine {
     float* d_weights = nullptr;
     float* d_wmfma = nullptr;         // MFMA B fragments of the GEMM-worthy pointwise layers (fused plan)
     size_t n_floats = 0;
+    // io_params of the blob (yolo_fastest.py:72-78): the graph is kBaseLayers with conv0's Cin and the two heads' Cout set from them
+    int input_channel = 1, num_anchors = 3, num_cls = 3, num_out = 24;
+    LayerSpec layers[kNumLayers];
     uint32_t w_off[kNumLayers], b_off[kNumLayers];
     // [0] one launch per layer (bring-up / probes), [1] block-fused, [2] (default) block-fused + the per-frame deep stage's launch
     // boundaries removed: conv5_2 rides in the res5 launch, ...
@@ -151,6 +154,8 @@ namespace {
 
 struct Builder {
     Plan* e;
+    const LayerSpec* kLayers = nullptr;   // the engine's layer table (make_layers)
+    int num_out = 24;
     int add_tensor(const std::string& name, int C, int H, int W, int slot = 0)
     {
         e->tensors.push_back(Tensor{name, C, H, W, slot, -1});
@@ -215,7 +220,7 @@ struct Builder {
     int dwpw(const char* dw, const char* pw, const char* head, int in, const char* out_name, int ext)
     {
         const LayerSpec &LD = kLayers[find_layer(dw)], &LP = kLayers[find_layer(pw)];
-        if (!fused || !yf::mdw_has_kernel(LD.cin, LP.cout, head ? 24 : 0)) {
+        if (!fused || !yf::mdw_has_kernel(LD.cin, LP.cout, head ? num_out : 0)) {
             int x = unit(pw, unit(dw, in));
             return head ? unit(head, x, out_name, -1, -1, ext) : x;
         }
@@ -224,7 +229,7 @@ struct Builder {
         o.l_dw = find_layer(dw); o.l_proj = find_layer(pw); o.l_head = head ? find_layer(head) : -1;
         o.layer = o.l_dw; o.in1 = in; o.in2 = -1; o.res = -1; o.omode = head ? 1 : 0;
         const Tensor& ti = e->tensors[in];
-        o.out = add_tensor(head ? out_name : pw, head ? 24 : LP.cout, ti.H, ti.W, head ? ext : 0);
+        o.out = add_tensor(head ? out_name : pw, head ? num_out : LP.cout, ti.H, ti.W, head ? ext : 0);
         e->ops.push_back(o);
         return o.out;
     }
@@ -233,12 +238,12 @@ struct Builder {
     {
         const LayerSpec &LD = kLayers[find_layer(dw1)], &LP = kLayers[find_layer(pw1)], &LQ = kLayers[find_layer(pw2)];
         const Tensor& ti = e->tensors[in];
-        if (!yf::mdw2_can_chain(LD.cin, LP.cout, LQ.cout, 24, ti.H, ti.W)) return -1;
+        if (!yf::mdw2_can_chain(LD.cin, LP.cout, LQ.cout, num_out, ti.H, ti.W)) return -1;
         Op o{};
         o.type = OP_MDW2;
         o.l_dw = find_layer(dw1); o.l_proj = find_layer(pw1); o.l_dw2 = find_layer(dw2); o.l_proj2 = find_layer(pw2); o.l_head = find_layer(head);
         o.layer = o.l_dw; o.in1 = in; o.in2 = -1; o.res = -1; o.omode = 1;
-        o.out = add_tensor(out_name, 24, ti.H, ti.W, ext);
+        o.out = add_tensor(out_name, num_out, ti.H, ti.W, ext);
         e->ops.push_back(o);
         return o.out;
     }
@@ -266,13 +271,15 @@ struct Builder {
     int dtype = yf::DT_F32;   // the engine's: some blocks are planned on a different kernel per dtype (mres_has_kernel)
 };
 
-void build_plan(Plan* e, int level, int dtype)
+void build_plan(Plan* e, int level, int dtype, const LayerSpec* kLayers)
 {
     const bool fused = level >= 1, deep = level >= 2;
     Builder b{e};
+    b.kLayers = kLayers;
+    b.num_out = kLayers[find_layer("head_4")].cout;
     b.fused = fused;
     b.dtype = dtype;
-    int x = b.add_tensor("input", 1, e->H, e->W, BUF_INPUT);
+    int x = b.add_tensor("input", kLayers[0].cin, e->H, e->W, BUF_INPUT);   // NCHW [N, input_channel, H, W]: planes, not NHWC
     if (fused) {
         x = b.fused_block("conv0", "conv1_2", "conv1_3", "conv1_4", x, "conv1_4", false);
     } else {
@@ -510,6 +517,7 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
     const size_t esz = e->esz();
     if (N > e->max_batch) return fail(YF_E_INVALID, "yf_forward: N=%d exceeds max_batch=%d", N, e->max_batch);
     const Plan& P = e->plan();
+    const LayerSpec* const kLayers = e->layers;
     const int cf = prof ? N : chunk_frames(e, N);  // profiling: the whole batch in one pass on the caller's stream
     const int nchunks = (N + cf - 1) / cf;
     const int lanes = (probe || prof || nchunks < 2) ? 1 : (e->lanes < nchunks ? e->lanes : nchunks);
@@ -588,10 +596,10 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
             if (o.type == OP_DCAT) {
                 rc = yf::launch_dcat(ptr(o.in1), ptr(o.in2), e->d_wmfma + o.mfma_off, e->d_wmfma + o.mfma_off2, ptr(o.out), ti.H, ti.W, n, s, o.kdt);
             } else if (o.type == OP_MDW2) {
-                rc = yf::launch_mdw2(ptr(o.in1), e->d_wmfma + o.mfma_off, e->d_wmfma + o.mfma_off2, ptr(o.out), ti.H, ti.W, n, s, o.kdt);
+                rc = yf::launch_mdw2(ptr(o.in1), e->d_wmfma + o.mfma_off, e->d_wmfma + o.mfma_off2, ptr(o.out), ti.H, ti.W, e->num_out, n, s, o.kdt);
             } else if (o.type == OP_MDW) {
                 yf::MdwArgs a{ptr(o.in1), e->d_wmfma + o.mfma_off, ptr(o.out), ti.H, ti.W, 0, 0};
-                rc = yf::launch_mdw(ti.C, kLayers[o.l_proj].cout, o.l_head >= 0 ? 24 : 0, a, n, s, o.kdt);
+                rc = yf::launch_mdw(ti.C, kLayers[o.l_proj].cout, o.l_head >= 0 ? e->num_out : 0, a, n, s, o.kdt);
             } else if (o.type == OP_MRES) {
                 const LayerSpec &LE = kLayers[o.l_exp], &LP = kLayers[o.l_proj];
                 yf::MresArgs a{ptr(o.in1), e->d_wmfma + o.mfma_off, ptr(o.out), ti.H, ti.W, 0, 0, o.out2 >= 0 ? ptr(o.out2) : nullptr,
@@ -612,7 +620,7 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                 a.wp = e->d_wmfma + o.mfma_off;
                 a.out = ptr(o.out);
                 a.H = pre ? ti.H / 2 : ti.H; a.W = pre ? ti.W / 2 : ti.W; a.Ho = to.H; a.Wo = to.W;
-                rc = yf::launch_fused_block(LE.cin, LE.cout, LP.cout, LD.stride, o.res >= 0, LP.relu != 0, pre, a, n, s, o.kdt);
+                rc = yf::launch_fused_block(LE.cin, LE.cout, LP.cout, LD.stride, o.res >= 0, LP.relu != 0, pre ? e->input_channel : 0, a, n, s, o.kdt);
             } else if (o.type == OP_K19) {
                 yf::K19Args a{};
                 a.in = ptr(o.in1);
@@ -621,6 +629,9 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                 a.H = ti.H; a.W = ti.W; a.Ho = to.H; a.Wo = to.W;
                 a.wp = e->d_wmfma + o.mfma_off;
                 rc = yf::launch_k19m(a, n, s, o.kdt);
+            } else if (L.kind == K_HEAD && L.cout != 24) {
+                // per-layer plan, a head other than the shipped 3 x (5 + 3): the generic head conv (any Cout), NHWC -> NCHW logits
+                rc = yf::launch_head_conv(ptr(o.in1), W(o.layer), B(o.layer), ptr(o.out), ti.C, L.cout, (long)ti.H * ti.W, n, s, e->sdt());
             } else if (L.kind == K_PW || L.kind == K_HEAD || L.kind == K_DECONV) {
                 yf::PwArgs a{ptr(o.in1), o.in2 >= 0 ? ptr(o.in2) : nullptr, W(o.layer), B(o.layer), o.res >= 0 ? ptr(o.res) : nullptr,
                              ptr(o.out), (long)n * ti.H * ti.W, (long)ti.H * ti.W, ti.W};
@@ -636,7 +647,7 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                 rc = yf::launch_dw(L.k, L.stride, a, s, e->sdt());
             } else {
                 yf::DenseArgs a{ptr(o.in1), W(o.layer), B(o.layer), ptr(o.out), (long)n * to.H * to.W, ti.H, ti.W, to.H, to.W};
-                rc = yf::launch_dense3x3s2(L.cin, L.cout, a, s);
+                rc = yf::launch_dense3x3s2(L.cin, L.cout, a, s);   // (conv0 with Cin > 1 reads the NCHW planes of the net input)
             }
             if (rc) return fail(YF_E_INVALID, "no kernel for layer %s", L.name);
             if (o.out == probe_t) {
@@ -730,13 +741,21 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
     BlobHeader hd;
     memcpy(&hd, blob, sizeof hd);
     if (memcmp(hd.magic, "YFHIPW01", 8) || hd.version != 1) return fail(YF_E_BLOB, "bad magic/version");
-    if (hd.n_layers != (uint32_t)kNumLayers || hd.num_out != 24 || hd.input_channel != 1)
-        return fail(YF_E_BLOB, "blob describes n_layers=%u num_out=%u input_channel=%u; this build implements 86/24/1",
-                    hd.n_layers, hd.num_out, hd.input_channel);
+    if (hd.n_layers != (uint32_t)kNumLayers)
+        return fail(YF_E_BLOB, "blob describes n_layers=%u; YoloFastest has %d", hd.n_layers, kNumLayers);
+    if (hd.input_channel != 1 && hd.input_channel != 3)
+        return fail(YF_E_BLOB, "input_channel=%u: the HIP engine implements 1 (gray) and 3 (cv2's BGR) input channels", hd.input_channel);
+    if (hd.num_anchors < 1 || hd.num_anchors > (uint32_t)yf::POST_MAX_ANCHORS || hd.num_cls < 1 || hd.num_cls > 4096 ||
+        hd.num_out != hd.num_anchors * (5 + hd.num_cls))
+        return fail(YF_E_BLOB, "blob describes num_anchors=%u num_cls=%u num_out=%u: need 1..%d anchors, >= 1 class and num_out == "
+                    "num_anchors * (5 + num_cls) (yolo_fastest.py:76)", hd.num_anchors, hd.num_cls, hd.num_out, yf::POST_MAX_ANCHORS);
     size_t data_off = sizeof(BlobHeader) + sizeof(BlobLayer) * (size_t)kNumLayers;
     if (nbytes < data_off + hd.data_floats * 4) return fail(YF_E_BLOB, "blob truncated");
     yf_engine* e = new yf_engine;
     e->device = device; e->H = H; e->W = W; e->max_batch = max_batch; e->dtype = dtype;
+    e->input_channel = (int)hd.input_channel; e->num_anchors = (int)hd.num_anchors; e->num_cls = (int)hd.num_cls; e->num_out = (int)hd.num_out;
+    make_layers(e->layers, e->input_channel, e->num_out);
+    const LayerSpec* const kLayers = e->layers;
     const BlobLayer* tab = reinterpret_cast<const BlobLayer*>(static_cast<const char*>(blob) + sizeof(BlobHeader));
     for (int i = 0; i < kNumLayers; ++i) {
         BlobLayer bl;
@@ -765,10 +784,10 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
     }
     for (int f = 0; f < 3; ++f) {
         e->plans[f].H = H; e->plans[f].W = W;
-        build_plan(&e->plans[f], f, dtype);
+        build_plan(&e->plans[f], f, dtype, e->layers);
     }
-    e->head_l_elems = 24u * (H / 16) * (W / 16);
-    e->head_s_elems = 24u * (H / 32) * (W / 32);
+    e->head_l_elems = (size_t)e->num_out * (H / 16) * (W / 16);
+    e->head_s_elems = (size_t)e->num_out * (H / 32) * (W / 32);
     {   // matrix-core layers of the fused plan: pre-pack W[K][N] into MFMA B fragments (host) and upload
         const float* hw = reinterpret_cast<const float*>(static_cast<const char*>(blob) + data_off);
         const bool h16 = e->dtype == yf::DT_F16;
@@ -808,7 +827,7 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
             }
             if (o.type == OP_FUSED_BLOCK) {
                 const LayerSpec &LE = kLayers[o.l_exp], &LD = kLayers[o.l_dw], &LP = kLayers[o.l_proj];
-                const int ec = yf::fb_chunk_channels(LE.cin, LE.cout, LP.cout, LD.stride, o.res >= 0, LP.relu != 0, o.l_pre >= 0);
+                const int ec = yf::fb_chunk_channels(LE.cin, LE.cout, LP.cout, LD.stride, o.res >= 0, LP.relu != 0, o.l_pre >= 0 ? e->input_channel : 0);
                 if (ec <= 0) { (void)hipFree(e->d_weights); delete e; return fail(YF_E_INVALID, "no fused kernel for block %s", LE.name); }
                 o.mfma_off = (long)packed.size();
                 packed.resize(packed.size() + ((yf::fb_packed_floats(LE.cin, LE.cout, LP.cout, ec) + 63) & ~(size_t)63));
@@ -819,7 +838,7 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
             }
             if (o.type == OP_MDW) {
                 const LayerSpec &LD = kLayers[o.l_dw], &LP = kLayers[o.l_proj];
-                const int headn = o.l_head >= 0 ? 24 : 0;
+                const int headn = o.l_head >= 0 ? e->num_out : 0;
                 if (x3) o.kdt = yf::DT_F16X3;
                 o.mfma_off = (long)packed.size();
                 packed.resize(packed.size() + ((yf::mdw_packed_floats(LD.cin, LP.cout, headn, o.kdt) + 63) & ~(size_t)63));
@@ -848,7 +867,7 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
             if (o.type == OP_MDW2) {   // two mdw weight streams, one after the other
                 if (x3) o.kdt = yf::DT_F16X3;
                 for (int st = 0; st < 2; ++st) {
-                    const int ld = st ? o.l_dw2 : o.l_dw, lp = st ? o.l_proj2 : o.l_proj, headn = st ? 24 : 0;
+                    const int ld = st ? o.l_dw2 : o.l_dw, lp = st ? o.l_proj2 : o.l_proj, headn = st ? e->num_out : 0;
                     const LayerSpec &LD = kLayers[ld], &LP = kLayers[lp];
                     const long off = (long)packed.size();
                     (st ? o.mfma_off2 : o.mfma_off) = off;
@@ -979,7 +998,8 @@ static yf::PostArgs make_post_args(yf_handle h, const float* d_hl, const float* 
     a.in_h = h->H; a.in_w = h->W;
     a.logit_min = logit_threshold(conf_thres);
     a.nms_thres = nms_thres;
-    for (int i = 0; i < 12; ++i) a.anchors[i] = anchors[i];
+    a.na = h->num_anchors; a.nc = h->num_cls;
+    for (int i = 0; i < 2 * yf::POST_MAX_ANCHORS * 2; ++i) a.anchors[i] = i < 2 * a.na * 2 ? anchors[i] : 0.0;   // [2][na][2]
     bool adj = origin_h > 0 && origin_w > 0 && (origin_h != h->H || origin_w != h->W);
     a.adj_h = adj ? (double)origin_h / h->H : 0.0;
     a.adj_w = adj ? (double)origin_w / h->W : 0.0;
@@ -1034,14 +1054,15 @@ int yf_nms_sorted(yf_handle h, const int32_t* d_boxes, int n, double nms_thres, 
 int yf_val_decode_head(yf_handle h, const float* d_head, int N, int fh, int fw, const double* anchors, int M_total, int m_off,
                        float* d_out, void* stream)
 {
-    if (!h || !d_head || !anchors || !d_out || N <= 0 || fh <= 0 || fw <= 0 || m_off < 0 || m_off + 3 * fh * fw > M_total)
+    const int na = h ? h->num_anchors : 0;
+    if (!h || !d_head || !anchors || !d_out || N <= 0 || fh <= 0 || fw <= 0 || m_off < 0 || m_off + na * fh * fw > M_total)
         return fail(YF_E_INVALID, "yf_val_decode_head: bad argument");
     HIP_OK(hipSetDevice(h->device));
     // yolo_loss.py:52-56: strides and feature-map-scaled anchors are Python doubles, stored into FloatTensors
     const double stride_h = (double)h->H / fh, stride_w = (double)h->W / fw;
-    float anc6[6];
-    for (int a = 0; a < 3; ++a) { anc6[2 * a] = (float)(anchors[2 * a] / stride_w); anc6[2 * a + 1] = (float)(anchors[2 * a + 1] / stride_h); }
-    yf::launch_val_decode(d_head, d_out, N, fh, fw, M_total, m_off, anc6, (float)stride_w, (float)stride_h, (hipStream_t)stream);
+    float anc[2 * yf::POST_MAX_ANCHORS];
+    for (int a = 0; a < na; ++a) { anc[2 * a] = (float)(anchors[2 * a] / stride_w); anc[2 * a + 1] = (float)(anchors[2 * a + 1] / stride_h); }
+    yf::launch_val_decode(d_head, d_out, N, fh, fw, M_total, m_off, anc, na, h->num_cls, (float)stride_w, (float)stride_h, (hipStream_t)stream);
     HIP_OK(hipGetLastError());
     return YF_OK;
 }
@@ -1049,9 +1070,16 @@ int yf_val_decode_head(yf_handle h, const float* d_head, int N, int fh, int fw, 
 int yf_val_nms(yf_handle h, const float* d_pred, int N, int M, double conf_thres, double nms_thres, int K_max, float* d_det,
                int32_t* d_counts, void* stream)
 {
-    if (!h || !d_pred || !d_det || !d_counts || N <= 0 || M <= 0 || K_max <= 0) return fail(YF_E_INVALID, "yf_val_nms: bad argument");
+    if (!h) return fail(YF_E_INVALID, "yf_val_nms: null handle");
+    return yf_val_nms_ex(h, d_pred, N, M, h->num_cls, conf_thres, nms_thres, K_max, d_det, d_counts, stream);
+}
+
+int yf_val_nms_ex(yf_handle h, const float* d_pred, int N, int M, int num_classes, double conf_thres, double nms_thres, int K_max, float* d_det,
+                  int32_t* d_counts, void* stream)
+{
+    if (!h || !d_pred || !d_det || !d_counts || N <= 0 || M <= 0 || K_max <= 0 || num_classes < 1) return fail(YF_E_INVALID, "yf_val_nms: bad argument");
     HIP_OK(hipSetDevice(h->device));
-    int rc = yf::launch_val_nms(d_pred, N, M, (float)conf_thres, (float)nms_thres, K_max, d_det, d_counts, (hipStream_t)stream);
+    int rc = yf::launch_val_nms(d_pred, N, M, num_classes, (float)conf_thres, (float)nms_thres, K_max, d_det, d_counts, (hipStream_t)stream);
     if (rc == -1) return fail(YF_E_INVALID, "yf_val_nms: at most 8191 boxes per image");
     if (rc) return fail(YF_E_HIP, "hipFuncSetAttribute(val_nms_kernel) failed");
     HIP_OK(hipGetLastError());
@@ -1062,13 +1090,16 @@ int yf_val_nms(yf_handle h, const float* d_pred, int N, int M, double conf_thres
 int yf_train_loss_workspace_bytes(yf_handle h, int N, int fh, int fw, size_t* out)
 {
     if (!h) return fail(YF_E_INVALID, "yf_train_loss_workspace_bytes: null handle");
-    return yf_train_head_loss_workspace_bytes(N, fh, fw, out);
+    return yf_train_head_loss_workspace_bytes_ex(N, fh, fw, h->num_anchors, h->num_cls, out);
 }
 
-int yf_train_head_loss_workspace_bytes(int N, int fh, int fw, size_t* out)
+int yf_train_head_loss_workspace_bytes(int N, int fh, int fw, size_t* out) { return yf_train_head_loss_workspace_bytes_ex(N, fh, fw, 3, 3, out); }
+
+int yf_train_head_loss_workspace_bytes_ex(int N, int fh, int fw, int num_anchors, int num_classes, size_t* out)
 {
-    if (!out || N <= 0 || fh <= 0 || fw <= 0) return fail(YF_E_INVALID, "yf_train_head_loss_workspace_bytes: bad argument");
-    *out = yf::train_loss_workspace_bytes(N, fh, fw);
+    if (!out || N <= 0 || fh <= 0 || fw <= 0 || num_anchors < 1 || num_anchors > yf::POST_MAX_ANCHORS || num_classes < 1)
+        return fail(YF_E_INVALID, "yf_train_head_loss_workspace_bytes: bad argument");
+    *out = yf::train_loss_workspace_bytes(N, fh, fw, num_anchors, num_classes);
     return YF_OK;
 }
 
@@ -1076,24 +1107,34 @@ int yf_train_loss(yf_handle h, const float* d_head, int N, int fh, int fw, const
                   double ignore_thres, void* d_work, size_t work_bytes, float* d_losses, float* d_grad_head, void* stream)
 {
     if (!h) return fail(YF_E_INVALID, "yf_train_loss: null handle");
-    return yf_train_head_loss(h->device, h->H, h->W, d_head, N, fh, fw, anchors, d_targets, T, ignore_thres, d_work, work_bytes, d_losses,
-                              d_grad_head, stream);
+    return yf_train_head_loss_ex(h->device, h->H, h->W, d_head, N, fh, fw, anchors, h->num_anchors, h->num_cls, d_targets, T, ignore_thres, d_work,
+                                 work_bytes, d_losses, d_grad_head, stream);
 }
 
 // The same without an engine handle (the loss needs the net-input size only for the head's stride), like the other yf_train_* entries.
 int yf_train_head_loss(int device, int H, int W, const float* d_head, int N, int fh, int fw, const double* anchors, const float* d_targets,
                        int T, double ignore_thres, void* d_work, size_t work_bytes, float* d_losses, float* d_grad_head, void* stream)
 {
-    if (!d_head || !anchors || !d_targets || !d_work || !d_losses || N <= 0 || fh <= 0 || fw <= 0 || T <= 0 || H <= 0 || W <= 0)
+    return yf_train_head_loss_ex(device, H, W, d_head, N, fh, fw, anchors, 3, 3, d_targets, T, ignore_thres, d_work, work_bytes, d_losses, d_grad_head,
+                                 stream);
+}
+
+int yf_train_head_loss_ex(int device, int H, int W, const float* d_head, int N, int fh, int fw, const double* anchors, int num_anchors,
+                          int num_classes, const float* d_targets, int T, double ignore_thres, void* d_work, size_t work_bytes, float* d_losses,
+                          float* d_grad_head, void* stream)
+{
+    if (!d_head || !anchors || !d_targets || !d_work || !d_losses || N <= 0 || fh <= 0 || fw <= 0 || T <= 0 || H <= 0 || W <= 0 ||
+        num_anchors < 1 || num_anchors > yf::POST_MAX_ANCHORS || num_classes < 1)
         return fail(YF_E_INVALID, "yf_train_head_loss: bad argument");
-    if (work_bytes < yf::train_loss_workspace_bytes(N, fh, fw)) return fail(YF_E_WORKSPACE, "yf_train_head_loss: workspace too small");
+    if (work_bytes < yf::train_loss_workspace_bytes(N, fh, fw, num_anchors, num_classes)) return fail(YF_E_WORKSPACE, "yf_train_head_loss: workspace too small");
     if (reinterpret_cast<uintptr_t>(d_work) & 7) return fail(YF_E_INVALID, "yf_train_head_loss: workspace must be 8-byte aligned");
     HIP_OK(hipSetDevice(device));
     // yolo_loss.py:52-56: strides and feature-map-scaled anchors are Python doubles; torch uses them as float32
     const double stride_h = (double)H / fh, stride_w = (double)W / fw;
-    float anc6[6];
-    for (int a = 0; a < 3; ++a) { anc6[2 * a] = (float)(anchors[2 * a] / stride_w); anc6[2 * a + 1] = (float)(anchors[2 * a + 1] / stride_h); }
-    yf::launch_train_loss(d_head, N, fh, fw, anc6, d_targets, T, (float)ignore_thres, d_work, d_losses, d_grad_head, (hipStream_t)stream);
+    float anc[2 * yf::POST_MAX_ANCHORS];
+    for (int a = 0; a < num_anchors; ++a) { anc[2 * a] = (float)(anchors[2 * a] / stride_w); anc[2 * a + 1] = (float)(anchors[2 * a + 1] / stride_h); }
+    yf::launch_train_loss(d_head, N, fh, fw, anc, num_anchors, num_classes, d_targets, T, (float)ignore_thres, d_work, d_losses, d_grad_head,
+                          (hipStream_t)stream);
     HIP_OK(hipGetLastError());
     return YF_OK;
 }
@@ -1127,7 +1168,7 @@ int yf_preprocess_u8(yf_handle h, const uint8_t* d_u8, int N, int src_h, int src
     else if (src_h == 2 * h->H && src_w == 2 * h->W) down2 = 1;
     else return fail(YF_E_INVALID, "source %dx%d: only 1x or exact 2x of the net input %dx%d is supported", src_h, src_w, h->H, h->W);
     HIP_OK(hipSetDevice(h->device));
-    yf::launch_preprocess(d_u8, d_x, N, h->H, h->W, down2, (hipStream_t)stream);
+    yf::launch_preprocess(d_u8, d_x, N, h->H, h->W, down2, (hipStream_t)stream, h->input_channel);
     HIP_OK(hipGetLastError());
     return YF_OK;
 }
@@ -1139,6 +1180,16 @@ int yf_streams_overlap(yf_handle h, void* stream_a, void* stream_b, int* overlap
     bool ov = false;
     if (int rc = streams_overlap(h, (hipStream_t)stream_a, (hipStream_t)stream_b, &ov)) return rc;
     *overlap = ov ? 1 : 0;
+    return YF_OK;
+}
+
+int yf_io_params(yf_handle h, int* input_channel, int* num_anchors, int* num_cls, int* num_out)
+{
+    if (!h) return fail(YF_E_INVALID, "yf_io_params: null handle");
+    if (input_channel) *input_channel = h->input_channel;
+    if (num_anchors) *num_anchors = h->num_anchors;
+    if (num_cls) *num_cls = h->num_cls;
+    if (num_out) *num_out = h->num_out;
     return YF_OK;
 }
 
@@ -1165,6 +1216,7 @@ int yf_op_info_ex(yf_handle h, int op, char* name, int name_len, double* algorit
 {
     if (!h || op < 0 || op >= (int)h->plan().ops.size()) return fail(YF_E_INVALID, "bad op index");
     const Plan& P = h->plan();
+    const LayerSpec* const kLayers = h->layers;
     const Op& o = P.ops[op];
     const Tensor &ti = P.tensors[o.in1], &to = P.tensors[o.out];
     std::string nm;

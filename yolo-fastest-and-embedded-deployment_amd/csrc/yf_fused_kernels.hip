@@ -75,9 +75,11 @@ __device__ __forceinline__ unsigned long long yf_stamp()
 __host__ __device__ constexpr int fb_chunk_floats(int cin, int cout, int ec) { return cin * ec + ec + 9 * ec + ec + ec * cout; }
 
 template <int CIN, int CEXP, int COUT, int S, bool RES, bool RELU_OUT, bool PRE, int TYB, int TXB, int BH, int BW,
-          int EC, int CG, int PE, bool XL, typename T>
+          int EC, int CG, int PE, bool XL, typename T, int C0 = 1>
 __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
 {
+    // C0 (PRE only): input channels of conv0 = io_params input_channel (yolo_fastest.py:78): 1 (gray) or 3 (NCHW planes; u8: HWC BGR)
+    static_assert(C0 == 1 || (PRE && !XL && C0 == 3), "conv0 on 1 or 3 input channels");
     constexpr int NT = TYB * TXB, NW = NT / 64;
     constexpr int O_B1 = CIN * EC, O_WD = O_B1 + EC, O_BD = O_WD + 9 * EC, O_W2 = O_BD + EC, CHF = O_W2 + EC * COUT;
     static_assert(CHF == fb_chunk_floats(CIN, COUT, EC), "pack layout");
@@ -152,8 +154,8 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
                 inimg[p] = inreg[p] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
                 const int rpc = inreg[p] ? rp : 0;
                 if constexpr (PRE) {
-                    // conv0: 3x3 stride 2 pad 1 on the 1-channel net input (+ReLU)
-                    float v[9];
+                    // conv0: 3x3 stride 2 pad 1 on the C0-channel net input (+ReLU); v[(ky * 3 + kx) * C0 + ci]
+                    float v[9 * C0];
                     if constexpr (XL) {  // window rows 2*ry.., cols 2*rx.. of the staged input
                         const float* win0 = X + (2 * (rpc / RW)) * IRWP + 2 * (rpc % RW);
 #pragma unroll
@@ -163,35 +165,41 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
                     } else if (a.in_u8) {
                         // Detect_YOLO.__pre_process fused into the load (src/detect.py:115-124): u8 gray frame, optional
                         // exact-2x box mean (a+b+c+d+2)>>2, then (v-128)/255; conv0 zero-pads the NORMALISED tensor
-                        const int sw = a.u8_down2 ? 4 * a.W : 2 * a.W;
-                        const uint8_t* __restrict__ src = a.in_u8 + (long)n * (a.u8_down2 ? 16L : 4L) * a.H * a.W;
+                        // (C0 = 3: the frame is cv2's HWC BGR; net channel ci is source channel 2 - ci, detect.py:119)
+                        const int sw = (a.u8_down2 ? 4 * a.W : 2 * a.W) * C0;
+                        const uint8_t* __restrict__ src = a.in_u8 + (long)n * (a.u8_down2 ? 16L : 4L) * a.H * a.W * C0;
 #pragma unroll
                         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                             for (int kx = 0; kx < 3; ++kx) {
                                 int yy = 2 * iy - 1 + ky, xx = 2 * ix - 1 + kx;
                                 bool ok = inimg[p] && yy >= 0 && yy < 2 * a.H && xx >= 0 && xx < 2 * a.W;
-                                float val = 0.f;
-                                if (ok) {
-                                    if (a.u8_down2) {
-                                        const uint8_t* q = src + (long)(2 * yy) * sw + 2 * xx;
-                                        val = (float)((q[0] + q[1] + q[sw] + q[sw + 1] + 2) >> 2);
-                                    } else {
-                                        val = (float)src[(long)yy * sw + xx];
+#pragma unroll
+                                for (int ci = 0; ci < C0; ++ci) {
+                                    float val = 0.f;
+                                    if (ok) {
+                                        if (a.u8_down2) {
+                                            const uint8_t* q = src + (long)(2 * yy) * sw + 2 * xx * C0 + (C0 - 1 - ci);
+                                            val = (float)((q[0] + q[C0] + q[sw] + q[sw + C0] + 2) >> 2);
+                                        } else {
+                                            val = (float)src[(long)yy * sw + xx * C0 + (C0 - 1 - ci)];
+                                        }
+                                        val = (val - 128.0f) / 255.0f;
                                     }
-                                    val = (val - 128.0f) / 255.0f;
+                                    v[(ky * 3 + kx) * C0 + ci] = val;
                                 }
-                                v[ky * 3 + kx] = val;
                             }
                     } else {
-                        const float* __restrict__ src = a.in + (long)n * (4L * a.H * a.W);
+                        const long plane = 4L * a.H * a.W;   // NCHW input: C0 planes per frame
+                        const float* __restrict__ src = a.in + (long)n * C0 * plane;
 #pragma unroll
                         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                             for (int kx = 0; kx < 3; ++kx) {
                                 int yy = 2 * iy - 1 + ky, xx = 2 * ix - 1 + kx;
                                 bool ok = inimg[p] && yy >= 0 && yy < 2 * a.H && xx >= 0 && xx < 2 * a.W;
-                                v[ky * 3 + kx] = ok ? src[(long)yy * (2 * a.W) + xx] : 0.f;
+#pragma unroll
+                                for (int ci = 0; ci < C0; ++ci) v[(ky * 3 + kx) * C0 + ci] = ok ? src[ci * plane + (long)yy * (2 * a.W) + xx] : 0.f;
                             }
                     }
 #if YF_FB_PK
@@ -199,7 +207,7 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
                     for (int c = 0; c < CIN; c += 2) {
                         fb_f32x2 s2 = *(const cfloat2*)(const cfloat*)(a.b0 + c);
 #pragma unroll
-                        for (int t = 0; t < 9; ++t)
+                        for (int t = 0; t < 9 * C0; ++t)
                             s2 = __builtin_elementwise_fma(fb_f32x2{v[t], v[t]}, *(const cfloat2*)(const cfloat*)(a.w0 + t * CIN + c), s2);
                         x[p][c] = fmaxf(s2[0], 0.f); x[p][c + 1] = fmaxf(s2[1], 0.f);
                     }
@@ -208,7 +216,7 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
                     for (int c = 0; c < CIN; ++c) {
                         float s = a.b0[c];
 #pragma unroll
-                        for (int t = 0; t < 9; ++t) s = fmaf(v[t], a.w0[t * CIN + c], s);
+                        for (int t = 0; t < 9 * C0; ++t) s = fmaf(v[t], a.w0[t * CIN + c], s);
                         x[p][c] = fmaxf(s, 0.f);
                     }
 #endif
@@ -459,13 +467,13 @@ __global__ void __launch_bounds__(256) k19_kernel(K19Args a)
 // ------------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int CEXP, int COUT, int S, bool RES, bool RELU_OUT, bool PRE, int TYB, int TXB, int BH, int BW, int EC, int CG, int PE, bool XL, typename T>
+template <int CIN, int CEXP, int COUT, int S, bool RES, bool RELU_OUT, bool PRE, int TYB, int TXB, int BH, int BW, int EC, int CG, int PE, bool XL, typename T, int C0 = 1>
 static int launch_fb_t(FbArgs a, int N, hipStream_t s)
 {
     a.tiles_y = (a.Ho + TYB * BH - 1) / (TYB * BH);
     a.tiles_x = (a.Wo + TXB * BW - 1) / (TXB * BW);
     dim3 grid((unsigned)(N * a.tiles_y * a.tiles_x));
-    hipLaunchKernelGGL((fused_block_kernel<CIN, CEXP, COUT, S, RES, RELU_OUT, PRE, TYB, TXB, BH, BW, EC, CG, PE, XL, T>), grid,
+    hipLaunchKernelGGL((fused_block_kernel<CIN, CEXP, COUT, S, RES, RELU_OUT, PRE, TYB, TXB, BH, BW, EC, CG, PE, XL, T, C0>), grid,
                        dim3(TYB * TXB), 0, s, a);
     return 0;
 }
@@ -483,9 +491,16 @@ static int launch_fb_t(FbArgs a, int N, hipStream_t s)
     FB(16, 96, 24, 2, false, false, false, 16, 20, 1, 1, 8, 8, 1, false) /* conv3_5/3_6/4_1               H/8 -> H/16 */     \
     FB(24, 136, 24, 1, true, false, false, 16, 20, 1, 1, 8, 8, 1, false) /* res4_1 .. res4_4 (fallback)   @ H/16 */
 
-int launch_fused_block(int cin, int cexp, int cout, int stride, bool res, bool relu_out, bool pre, const FbArgs& a, int N,
+int launch_fused_block(int cin, int cexp, int cout, int stride, bool res, bool relu_out, int pre_c0, const FbArgs& a, int N,
                        hipStream_t s, int dtype)
 {
+    const bool pre = pre_c0 != 0;
+    if (pre && pre_c0 != 1 && pre_c0 != 3) return -1;
+    if (pre_c0 == 3) {   // the stem of an RGB model: the same tile shape, conv0 over 3 input planes
+        if (!(cin == 8 && cexp == 8 && cout == 4 && stride == 1 && !res && !relu_out)) return -1;
+        return dtype == DT_F16 ? launch_fb_t<8, 8, 4, 1, false, false, true, 16, 16, YF_STEM_BH, YF_STEM_BW, 8, 8, 1, false, half_t, 3>(a, N, s)
+                               : launch_fb_t<8, 8, 4, 1, false, false, true, 16, 16, YF_STEM_BH, YF_STEM_BW, 8, 8, 1, false, float, 3>(a, N, s);
+    }
 #define FB(ci, ce, co, st, rs, ro, pr, tyb, txb, bh, bw, ec, cg, pe, xl)                                          \
     if (cin == ci && cexp == ce && cout == co && stride == st && res == rs && relu_out == ro && pre == pr)         \
         return dtype == DT_F16 ? launch_fb_t<ci, ce, co, st, rs, ro, pr, tyb, txb, bh, bw, ec, cg, pe, xl, half_t>(a, N, s)   \
@@ -495,8 +510,9 @@ int launch_fused_block(int cin, int cexp, int cout, int stride, bool res, bool r
     return -1;
 }
 
-int fb_chunk_channels(int cin, int cexp, int cout, int stride, bool res, bool relu_out, bool pre)
+int fb_chunk_channels(int cin, int cexp, int cout, int stride, bool res, bool relu_out, int pre_c0)
 {
+    const bool pre = pre_c0 != 0;
 #define FB(ci, ce, co, st, rs, ro, pr, tyb, txb, bh, bw, ec, cg, pe, xl) \
     if (cin == ci && cexp == ce && cout == co && stride == st && res == rs && relu_out == ro && pre == pr) return ec;
     YF_FB_SHAPES(FB)

@@ -189,24 +189,29 @@ size_t mfma_packed_floats_x3(int k1, int k2, int n);
 void mfma_pack_weights_x3(const float* w, int k1, int k2, int n, float* out);
 size_t mfma_packed_floats(int k1, int k2, int n);
 void mfma_pack_weights(const float* w, int k1, int k2, int n, float* out);
-int launch_dense3x3s2(int cin, int cout, const DenseArgs& a, hipStream_t s);
+int launch_dense3x3s2(int cin, int cout, const DenseArgs& a, hipStream_t s);   // cin 3 (conv0 on RGB): `in` is NCHW planes [N,3,H,W]
+// head conv of the per-layer plan for any Cout = num_anchors * (5 + num_cls) (yolo_fastest.py:138,148): NHWC [N,HW,cin] (storage
+// dtype) x w[cin][cout] + b -> NCHW float32 [N,cout,HW]; fp32 arithmetic in every engine dtype
+int launch_head_conv(const float* in, const float* w, const float* b, float* out, int cin, int cout, long HW, int N, hipStream_t s, int dtype = DT_F32);
 void launch_nhwc_to_nchw(const float* in, float* out, long N, int C, long HW, hipStream_t s, int dtype = DT_F32);
-void launch_preprocess(const uint8_t* in, float* out, long N, int H, int W, int down2, hipStream_t s);
+void launch_preprocess(const uint8_t* in, float* out, long N, int H, int W, int down2, hipStream_t s, int channels = 1);   // channels 3: HWC BGR in, NCHW RGB planes out
 
 struct FbArgs {
-    const float* in;              // NHWC [N,H,W,CIN]; PRE: the 1-channel net input [N,2H,2W]
-    const float *w0, *b0;         // PRE only: conv0 [9][8], [8]
+    const float* in;              // NHWC [N,H,W,CIN]; PRE: the net input, NCHW planes [N,C0,2H,2W] (C0 = io_params input_channel: 1 or 3)
+    const float *w0, *b0;         // PRE only: conv0 [9][C0][8], [8]
     const float* wp;              // chunk-major weight stream of expand / depthwise / project (fb_pack_weights)
     float* out;                   // NHWC [N,Ho,Wo,COUT]
     int H, W, Ho, Wo;             // expansion-resolution and output-resolution frame sizes
     int tiles_y, tiles_x;         // filled by the launcher
-    const uint8_t* in_u8;         // PRE only, optional: u8 gray frames instead of `in` (pre-process fused into the load)
+    const uint8_t* in_u8;         // PRE only, optional: u8 frames instead of `in` (pre-process fused into the load): gray [N,h,w], or --
+                                  // C0 = 3 -- cv2's HWC BGR [N,h,w,3], channel-flipped on the fly (detect.py:119)
     int u8_down2;                 //   1: the u8 frame is exactly 2x the net input (2x2 box mean first)
     unsigned long long* dbg;      // diagnostic builds only (-DYF_STAMP): per-phase cycle sums; null in the product
 };
-int launch_fused_block(int cin, int cexp, int cout, int stride, bool res, bool relu_out, bool pre, const FbArgs& a, int N,
+// pre: 0 = no conv0 in front; 1 / 3 = conv0 on that many input channels evaluated on the fly
+int launch_fused_block(int cin, int cexp, int cout, int stride, bool res, bool relu_out, int pre, const FbArgs& a, int N,
                        hipStream_t s, int dtype = DT_F32);
-int fb_chunk_channels(int cin, int cexp, int cout, int stride, bool res, bool relu_out, bool pre);  // EC of that shape, -1 if none
+int fb_chunk_channels(int cin, int cexp, int cout, int stride, bool res, bool relu_out, int pre);  // EC of that shape, -1 if none
 size_t fb_packed_floats(int cin, int cexp, int cout, int ec);
 void fb_pack_weights(const float* w1, const float* b1, const float* wd, const float* bd, const float* w2, const float* b2, int cin,
                      int cexp, int cout, int ec, float* out);
@@ -236,15 +241,16 @@ void mres_pack_weights(const float* w1, const float* b1, const float* wd, const 
 struct MdwArgs {
     const float* in;   // NHWC [N,H,W,C]
     const float* wp;   // host-packed weight stream (mdw_pack_weights)
-    float* out;        // NHWC [N,H,W,N_out], or NCHW [N,24,H,W] when the head conv is fused
+    float* out;        // NHWC [N,H,W,N_out], or NCHW [N,headn,H,W] when the head conv is fused
     int H, W;
     int tiles_y, tiles_x;
+    int headn;         // fused head conv: its output channels = num_anchors * (5 + num_cls) (filled by the launcher)
 };
 int launch_mdw(int c, int n, int headn, const MdwArgs& a, int Nf, hipStream_t s, int dtype = DT_F32);
 bool mdw_has_kernel(int c, int n, int headn);
 // the small head's two pairs as ONE launch (frames that fit one tile): stage 1 (c1 -> n1, no head) feeds stage 2 (n1 -> n2 -> head) in LDS
 bool mdw2_can_chain(int c1, int n1, int n2, int headn, int H, int W);
-int launch_mdw2(const float* in, const float* wp1, const float* wp2, float* out_nchw, int H, int W, int Nf, hipStream_t s, int dtype = DT_F32);
+int launch_mdw2(const float* in, const float* wp1, const float* wp2, float* out_nchw, int H, int W, int headn, int Nf, hipStream_t s, int dtype = DT_F32);
 size_t mdw_packed_floats(int c, int n, int headn, int wmode = WM_F32);
 void mdw_pack_weights(const float* wd, const float* bd, const float* w, const float* b, const float* hw, const float* hb, int c,
                       int n, int headn, float* out, int wmode = WM_F32);
@@ -276,14 +282,16 @@ size_t k19m_lds_bytes(int dtype);
 size_t k19m_guard_elems(int W);   // the engine keeps this many elements free before and after the workspace slots
 void k19_pack_weights(const float* w9, const float* w21, float* out, int wmode = WM_F32);
 
+enum { POST_MAX_ANCHORS = 8 };   // anchors per head the post-process kernels take (the reference ships 3)
 struct PostArgs {
-    const float* head_large;  // [N,24,hl,wl]
-    const float* head_small;  // [N,24,hs,ws]
+    const float* head_large;  // [N,na*(5+nc),hl,wl]
+    const float* head_small;  // [N,na*(5+nc),hs,ws]
+    int na, nc;               // io_params num_anchors, num_cls (detect.py:15-21)
     int hl, wl, hs, ws;
     int in_h, in_w;           // net-input rows/cols
     float logit_min;          // smallest fp32 conf logit the reference's `sigmoid(t) > conf_thres` accepts
     double nms_thres;
-    double anchors[12];       // [2][3][2]
+    double anchors[2 * POST_MAX_ANCHORS * 2];   // [2][na][2]
     double adj_h, adj_w;      // __adjust_coord scales (0 = no adjustment)
     int kmax;
     int32_t* boxes;           // [N,kmax,4]
@@ -294,12 +302,13 @@ struct PostArgs {
 };
 int launch_post(const PostArgs& a, int N, hipStream_t s);
 size_t post_lds_bytes(int ncell);
-void launch_val_decode(const float* in, float* out, int N, int h, int w, int M_total, int m_off, const float* anc6, float stride_w,
+// anc: na (w, h) pairs in feature-map units; rows of `out` / `pred` are 5 + nc floats
+void launch_val_decode(const float* in, float* out, int N, int h, int w, int M_total, int m_off, const float* anc, int na, int nc, float stride_w,
                        float stride_h, hipStream_t s);
-int launch_val_nms(const float* pred, int N, int M, float conf_thres, float nms_thres, int kmax, float* det, int32_t* counts, hipStream_t s);
+int launch_val_nms(const float* pred, int N, int M, int nc, float conf_thres, float nms_thres, int kmax, float* det, int32_t* counts, hipStream_t s);
 // training-time loss of one head and its gradient with respect to the head tensor (yf_loss_kernels.hip)
-size_t train_loss_workspace_bytes(int N, int fh, int fw);
-void launch_train_loss(const float* head, int N, int fh, int fw, const float* anc6, const float* targets, int T, float ignore_thres,
+size_t train_loss_workspace_bytes(int N, int fh, int fw, int na = 3, int nc = 3);
+void launch_train_loss(const float* head, int N, int fh, int fw, const float* anc, int na, int nc, const float* targets, int T, float ignore_thres,
                        void* work, float* losses, float* grad, hipStream_t s);
 // training-step operators (yf_train_kernels.hip): NCHW fp32, correctness-first
 // BatchNorm's partial sums out of the conv's epilogue (the large maps): the caller sets part / cap_bytes (a region no concurrent kernel

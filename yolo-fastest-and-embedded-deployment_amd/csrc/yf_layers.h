@@ -8,12 +8,15 @@ namespace yf_layers {
 enum Kind { K_PW = 0, K_DW = 1, K_DENSE = 2, K_DECONV = 3, K_HEAD = 4 };
 
 // The YoloFastest layer table, module-definition order (yolo_fastest.py:78-148). The blob must match it.
+// kBaseLayers is the graph for the shipped io_params (input_channel 1, num_out = 3 anchors x (5 + 3 classes) = 24); the reference's
+// constructor is parameterised on input_channel (conv0's Cin, :78) and num_out = num_anchors * (5 + num_cls) (the two head convs,
+// :138, :148): make_layers() gives an engine / trainer its own copy with those three entries set.
 struct LayerSpec {
     const char* name;
     int kind, cin, cout, k, stride, relu;
 };
 #define RES(n, c, e) {n ".conv1", K_PW, c, e, 1, 1, 1}, {n ".conv2", K_DW, e, e, 3, 1, 1}, {n ".conv3", K_PW, e, c, 1, 1, 0}
-static const LayerSpec kLayers[] = {
+static const LayerSpec kBaseLayers[] = {
     {"conv0", K_DENSE, 1, 8, 3, 2, 1}, {"conv1_2", K_PW, 8, 8, 1, 1, 1}, {"conv1_3", K_DW, 8, 8, 3, 1, 1},
     {"conv1_4", K_PW, 8, 4, 1, 1, 0}, RES("res1_1", 4, 8),
     {"conv1_8", K_PW, 4, 24, 1, 1, 1}, {"conv1_9", K_DENSE, 24, 24, 3, 2, 1}, {"conv2_1", K_PW, 24, 8, 1, 1, 0},
@@ -33,14 +36,23 @@ static const LayerSpec kLayers[] = {
     {"conv4_1_1", K_PW, 232, 96, 1, 1, 1}, {"conv4_1_2", K_DW, 96, 96, 5, 1, 1}, {"conv4_1_3", K_PW, 96, 96, 1, 1, 0},
     {"conv4_1_4", K_DW, 96, 96, 5, 1, 1}, {"conv4_1_5", K_PW, 96, 96, 1, 1, 0}, {"head_4", K_HEAD, 96, 24, 1, 1, 0},
 };
-constexpr int kNumLayers = sizeof(kLayers) / sizeof(kLayers[0]);
+constexpr int kNumLayers = sizeof(kBaseLayers) / sizeof(kBaseLayers[0]);
 static_assert(kNumLayers == 86, "84 conv+BN units + 2 heads");
 
 inline int find_layer(const char* name)
 {
     for (int i = 0; i < kNumLayers; ++i)
-        if (!strcmp(kLayers[i].name, name)) return i;
+        if (!strcmp(kBaseLayers[i].name, name)) return i;
     return -1;
+}
+
+inline void make_layers(LayerSpec* out, int input_channel, int num_out)
+{
+    for (int i = 0; i < kNumLayers; ++i) {
+        out[i] = kBaseLayers[i];
+        if (i == 0) out[i].cin = input_channel;           // conv0
+        if (out[i].kind == K_HEAD) out[i].cout = num_out;  // head_5, head_4
+    }
 }
 
 }  // namespace yf_layers

@@ -44,10 +44,14 @@ __host__ __device__ constexpr int mdw_chunk_floats(int n, int wmode = WM_F32)
 {
     return 25 * 16 + 16 + (wmode != WM_F32 ? (wmode == WM_F16X3 ? 2 : 1) * (n / 16) * 128 : 4 * (n / 16) * 64);
 }
+// head conv: its output channels headn = num_anchors * (5 + num_cls) (yolo_fastest.py:76,138,148) are padded to PAIRS of 16-column
+// MFMA tiles (nthp tiles): the shipped 24 and anything up to 32 is one pair -- the same stream as ever
+__host__ __device__ constexpr int mdw_head_tiles(int headn) { return headn ? 2 * ((headn + 31) / 32) : 0; }
 __host__ __device__ constexpr int mdw_stream_floats(int c, int n, int headn, int wmode = WM_F32)
 {
     int f = (c / 16) * mdw_chunk_floats(n, wmode) + n;
-    if (headn) f += (wmode != WM_F32 ? (wmode == WM_F16X3 ? 2 : 1) * (n / 16) * 2 * 128 : (n / 4) * 2 * 64) + 32;
+    const int nthp = mdw_head_tiles(headn);
+    if (headn) f += (wmode != WM_F32 ? (wmode == WM_F16X3 ? 2 : 1) * (n / 16) * nthp * 128 : (n / 4) * nthp * 64) + nthp * 16;
     return (f + 3) & ~3;
 }
 
@@ -69,7 +73,11 @@ __host__ __device__ constexpr int mdw_epl(int th, int tw, int nwave)
     return ((nrp + 15) / 16) * 16 + (adj ? 1 : 0) + YF_MDW_EPL_ADD;
 }
 
-template <int C, int N, int HEADN, int TH, int TW, int NWAVE, typename TT>
+// HM (head mode): 0 = no head conv; 1 = head conv of up to 32 channels (one pair of MFMA column tiles, fragments staged in LDS with the
+// rest of the stream: the shipped 3 x (5 + 3) = 24 and every num_out <= 32); 2 = any width: a run-time loop over pairs of column
+// tiles whose fragments come straight from global memory / L2 (they would not fit the LDS beside the stream: 255 channels = 128 KB).
+// a.headn is the real channel count in both modes.
+template <int C, int N, int HM, int TH, int TW, int NWAVE, typename TT>
 __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
 {
     constexpr bool X3 = is_x3<TT>::value;       // fp32 storage, split-operand fp16 MFMAs (yf_kernels.h DT_F16X3)
@@ -85,10 +93,9 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
     constexpr int OFF_BD = 400, OFF_W = 416, CHUNK = 416 + (H16 ? WM * NT * 128 : 4 * NT * 64);
     constexpr int OFF_BPW = NCH * CHUNK, OFF_HW = OFF_BPW + N, KSH = N / 4, NTH = 2;
     constexpr int OFF_HB = OFF_HW + (H16 ? WM * (N / 16) * NTH * 128 : KSH * NTH * 64);
-    constexpr int WFLOATS = mdw_stream_floats(C, N, HEADN, wmode_of<TT>());
+    constexpr int WFLOATS = mdw_stream_floats(C, N, HM == 1 ? 32 : 0, wmode_of<TT>());   // what is staged in LDS
     constexpr int NLD = (NRP * 4 + NTHR - 1) / NTHR;  // float4 loads per thread per chunk
     static_assert((TH * TW) % 16 == 0 && C % 16 == 0 && N % 16 == 0 && CHUNK == mdw_chunk_floats(N, wmode_of<TT>()), "shape");
-    static_assert(HEADN == 0 || HEADN <= 32, "head width");
     extern __shared__ __attribute__((aligned(16))) float mdw_smem[];
     float* E = mdw_smem;           // [4][EPL][4]
     float* WL = E + 16 * EPL;      // weight stream
@@ -270,13 +277,82 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
         const int oy = op / TW, ox = op - oy * TW;
         const int gy = oy0 + oy, gx = ox0 + ox;
         const bool inside = gy < a.H && gx < a.W;
-        if constexpr (HEADN == 0) {
+        if constexpr (HM == 0) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const float4 bias = *reinterpret_cast<const float4*>(bpw + nt * 16 + 4 * q);
                 if (inside)
                     st4<TT>(reinterpret_cast<TT*>(a.out) + (((long)n * a.H + gy) * a.W + gx) * N + nt * 16 + 4 * q,
                             make_float4(acc[i][nt][0] + bias.x, acc[i][nt][1] + bias.y, acc[i][nt][2] + bias.z, acc[i][nt][3] + bias.w));
+            }
+        } else if constexpr (HM == 2) {
+            // any head width: pairs of column tiles in a run-time loop; the fragments of a pair come from global memory (all of a
+            // pair's loads are requested before its first MFMA); same k order per output channel as mode 1
+            const int nthp = mdw_head_tiles(a.headn);
+            const float* hwg = a.wp + OFF_HW;
+            const float* hbg = hwg + (H16 ? WM * (N / 16) * nthp * 128 : KSH * nthp * 64);
+            float hv[NT][4];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 bias = *reinterpret_cast<const float4*>(bpw + nt * 16 + 4 * q);
+                hv[nt][0] = acc[i][nt][0] + bias.x; hv[nt][1] = acc[i][nt][1] + bias.y; hv[nt][2] = acc[i][nt][2] + bias.z; hv[nt][3] = acc[i][nt][3] + bias.w;
+            }
+#pragma unroll 1
+            for (int pr = 0; pr < nthp; pr += 2) {
+                f32x4 h[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                if constexpr (X3) {
+                    const f16x4* hwh = reinterpret_cast<const f16x4*>(hwg);
+                    const f16x4* hwl = hwh + (N / 16) * nthp * 64;
+                    f16x4 fh[NT][2], fl[NT][2];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int nth = 0; nth < 2; ++nth) { fh[nt][nth] = hwh[(nt * nthp + pr + nth) * 64 + lane]; fl[nt][nth] = hwl[(nt * nthp + pr + nth) * 64 + lane]; }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        f16x4 bh, bl;
+                        split_f16x4(hv[nt][0], hv[nt][1], hv[nt][2], hv[nt][3], bh, bl);
+#pragma unroll
+                        for (int nth = 0; nth < 2; ++nth) {
+                            h[nth] = __builtin_amdgcn_mfma_f32_16x16x16f16(fl[nt][nth], bh, h[nth], 0, 0, 0);
+                            h[nth] = __builtin_amdgcn_mfma_f32_16x16x16f16(fh[nt][nth], bl, h[nth], 0, 0, 0);
+                            h[nth] = __builtin_amdgcn_mfma_f32_16x16x16f16(fh[nt][nth], bh, h[nth], 0, 0, 0);
+                        }
+                    }
+                } else if constexpr (H16) {
+                    const f16x4* hwh = reinterpret_cast<const f16x4*>(hwg);
+                    f16x4 fh[NT][2];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int nth = 0; nth < 2; ++nth) fh[nt][nth] = hwh[(nt * nthp + pr + nth) * 64 + lane];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const f16x4 bh = f16x4{(half_t)hv[nt][0], (half_t)hv[nt][1], (half_t)hv[nt][2], (half_t)hv[nt][3]};
+#pragma unroll
+                        for (int nth = 0; nth < 2; ++nth) h[nth] = __builtin_amdgcn_mfma_f32_16x16x16f16(fh[nt][nth], bh, h[nth], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        float f[4][2];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int nth = 0; nth < 2; ++nth) f[j][nth] = hwg[((nt * 4 + j) * nthp + pr + nth) * 64 + lane];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int nth = 0; nth < 2; ++nth) h[nth] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[j][nth], hv[nt][j], h[nth], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int nth = 0; nth < 2; ++nth)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int hc = (pr + nth) * 16 + 4 * q + reg;
+                        if (hc < a.headn && inside) a.out[(((long)n * a.headn + hc) * a.H + gy) * a.W + gx] = h[nth][reg] + hbg[hc];  // NCHW
+                    }
             }
         } else {
             const float* hw = WL + OFF_HW;
@@ -315,7 +391,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int hc = nth * 16 + 4 * q + reg;
-                    if (hc < HEADN && inside) a.out[(((long)n * HEADN + hc) * a.H + gy) * a.W + gx] = h[nth][reg] + hb[hc];  // NCHW
+                    if (hc < a.headn && inside) a.out[(((long)n * a.headn + hc) * a.H + gy) * a.W + gx] = h[nth][reg] + hb[hc];  // NCHW
                 }
         }
     }
@@ -339,8 +415,9 @@ struct Mdw2Args {
     const float* in;    // NHWC [N,H,W,C1]
     const float* wp1;   // stage 1 stream: mdw_pack_weights(C1, N1, no head)
     const float* wp2;   // stage 2 stream: mdw_pack_weights(N1, N2, HEADN)
-    float* out;         // NCHW [N,HEADN,H,W]
+    float* out;         // NCHW [N,headn,H,W]
     int H, W;
+    int headn;          // the head conv's output channels (<= 32: one pair of MFMA column tiles)
 };
 
 __host__ __device__ constexpr int mdw2_split(int c1, int n1, int n2, int headn, int wmode)
@@ -409,9 +486,10 @@ __device__ __forceinline__ void mdw_chunk_1tile(const float* E, int epl, const f
     }
 }
 
-template <int C1, int N1, int N2, int HEADN, int TH, int TW, int NWAVE, typename TT>
+template <int C1, int N1, int N2, int TH, int TW, int NWAVE, typename TT>
 __global__ void __launch_bounds__(NWAVE * 64) mdw2_kernel(Mdw2Args a)
 {
+    constexpr int HEADN = 32;   // stream layout of any head of up to 32 channels; a.headn is the real count
     constexpr bool X3 = is_x3<TT>::value;
     constexpr bool H16 = sizeof(TT) == 2 || X3;
     constexpr int WMODE = wmode_of<TT>(), WM = X3 ? 2 : 1;
@@ -431,7 +509,6 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw2_kernel(Mdw2Args a)
     constexpr int OFF_HB = OFF_HW + (H16 ? WM * (N2 / 16) * NTH * 128 : KSH * NTH * 64);
     constexpr int NLD = (NRP * 4 + NTHR - 1) / NTHR;
     constexpr int NB4 = (PART_B / 4 + NTHR - 1) / NTHR;
-    static_assert(HEADN > 0 && HEADN <= 32, "head width");
     extern __shared__ __attribute__((aligned(16))) float mdw_smem[];
     float* E = mdw_smem;                 // [4][EPL][4]
     float* Y = E + 16 * EPL;             // [NCH2][4][NPX][4]: stage 1's result
@@ -580,58 +657,61 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw2_kernel(Mdw2Args a)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int hc = nth * 16 + 4 * q + reg;
-                if (hc < HEADN && inside) a.out[(((long)n * HEADN + hc) * a.H + oy) * a.W + ox] = h[nth][reg] + hb[hc];  // NCHW
+                if (hc < a.headn && inside) a.out[(((long)n * a.headn + hc) * a.H + oy) * a.W + ox] = h[nth][reg] + hb[hc];  // NCHW
             }
     }
 }
 
-template <int C1, int N1, int N2, int HEADN, int TH, int TW, int NWAVE, typename T>
+template <int C1, int N1, int N2, int TH, int TW, int NWAVE, typename T>
 static int launch_mdw2_t(const Mdw2Args& a, int Nf, hipStream_t s)
 {
-    if (a.H > TH || a.W > TW) return -4;   // the chain needs tile == frame
-    constexpr size_t lds = mdw2_lds_floats(C1, N1, N2, HEADN, TH, TW, NWAVE, wmode_of<T>()) * sizeof(float);
+    if (a.H > TH || a.W > TW || a.headn < 1 || a.headn > 32) return -4;   // the chain needs tile == frame and one pair of head tiles
+    constexpr size_t lds = mdw2_lds_floats(C1, N1, N2, 32, TH, TW, NWAVE, wmode_of<T>()) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done[YF_MAX_DEVICES] = {};
     const int dev = current_device();
     if (dev < 0) return -2;
     if (lds > 64 * 1024 && !attr_done[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mdw2_kernel<C1, N1, N2, HEADN, TH, TW, NWAVE, T>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mdw2_kernel<C1, N1, N2, TH, TW, NWAVE, T>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL((mdw2_kernel<C1, N1, N2, HEADN, TH, TW, NWAVE, T>), dim3((unsigned)Nf), dim3(NWAVE * 64), lds, s, a);
+    hipLaunchKernelGGL((mdw2_kernel<C1, N1, N2, TH, TW, NWAVE, T>), dim3((unsigned)Nf), dim3(NWAVE * 64), lds, s, a);
     return 0;
 }
 
 // conv5_3 -> conv5_4 -> conv5_5 -> conv5_6 -> head_5 on H x W frames in one launch?
-bool mdw2_can_chain(int c1, int n1, int n2, int headn, int H, int W) { return c1 == 96 && n1 == 128 && n2 == 128 && headn == 24 && H <= 8 && W <= 10; }
-
-int launch_mdw2(const float* in, const float* wp1, const float* wp2, float* out, int H, int W, int Nf, hipStream_t s, int dtype)
+bool mdw2_can_chain(int c1, int n1, int n2, int headn, int H, int W)
 {
-    const Mdw2Args a{in, wp1, wp2, out, H, W};
-    return dtype == DT_F16 ? launch_mdw2_t<96, 128, 128, 24, 8, 10, 5, half_t>(a, Nf, s)
-         : dtype == DT_F16X3 ? launch_mdw2_t<96, 128, 128, 24, 8, 10, 5, x3_t>(a, Nf, s) : launch_mdw2_t<96, 128, 128, 24, 8, 10, 5, float>(a, Nf, s);
+    return c1 == 96 && n1 == 128 && n2 == 128 && headn >= 1 && headn <= 32 && H <= 8 && W <= 10;
 }
 
-template <int C, int N, int HEADN, int TH, int TW, int NWAVE, typename T>
+int launch_mdw2(const float* in, const float* wp1, const float* wp2, float* out, int H, int W, int headn, int Nf, hipStream_t s, int dtype)
+{
+    const Mdw2Args a{in, wp1, wp2, out, H, W, headn};
+    return dtype == DT_F16 ? launch_mdw2_t<96, 128, 128, 8, 10, 5, half_t>(a, Nf, s)
+         : dtype == DT_F16X3 ? launch_mdw2_t<96, 128, 128, 8, 10, 5, x3_t>(a, Nf, s) : launch_mdw2_t<96, 128, 128, 8, 10, 5, float>(a, Nf, s);
+}
+
+template <int C, int N, int HM, int TH, int TW, int NWAVE, typename T>
 static int launch_mdw_t(MdwArgs a, int Nf, hipStream_t s)
 {
     a.tiles_y = (a.H + TH - 1) / TH;
     a.tiles_x = (a.W + TW - 1) / TW;
     constexpr int NRP = (TH + 4) * (TW + 4);
-    constexpr size_t lds = ((size_t)16 * mdw_epl(TH, TW, NWAVE) + mdw_stream_floats(C, N, HEADN, wmode_of<T>())) * sizeof(float);
+    constexpr size_t lds = ((size_t)16 * mdw_epl(TH, TW, NWAVE) + mdw_stream_floats(C, N, HM == 1 ? 32 : 0, wmode_of<T>())) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done[YF_MAX_DEVICES] = {};
     const int dev = current_device();
     if (dev < 0) return -2;
     if (lds > 64 * 1024 && !attr_done[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mdw_kernel<C, N, HEADN, TH, TW, NWAVE, T>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mdw_kernel<C, N, HM, TH, TW, NWAVE, T>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL((mdw_kernel<C, N, HEADN, TH, TW, NWAVE, T>), dim3((unsigned)(Nf * a.tiles_y * a.tiles_x)), dim3(NWAVE * 64),
+    hipLaunchKernelGGL((mdw_kernel<C, N, HM, TH, TW, NWAVE, T>), dim3((unsigned)(Nf * a.tiles_y * a.tiles_x)), dim3(NWAVE * 64),
                        lds, s, a);
     return 0;
 }
@@ -639,17 +719,24 @@ static int launch_mdw_t(MdwArgs a, int Nf, hipStream_t s)
 #ifndef YF_MDW_LARGE_NW
 #define YF_MDW_LARGE_NW 10
 #endif
-//      (c, n, head, TH, TW, waves)
+//      (c, n, head mode, TH, TW, waves)      head mode: 0 none, 1 = up to 32 head channels (the shipped 24), 2 = any width
 #define YF_MDW_SHAPES(MD)                                            \
     MD(96, 128, 0, 8, 10, 5)    /* conv5_3 -> conv5_4            @ H/32 */ \
-    MD(128, 128, 24, 8, 10, 5)  /* conv5_5 -> conv5_6 -> head_5  @ H/32 */ \
+    MD(128, 128, 1, 8, 10, 5)   /* conv5_5 -> conv5_6 -> head_5  @ H/32 */ \
+    MD(128, 128, 2, 8, 10, 5)                                              \
     MD(96, 96, 0, 16, 20, YF_MDW_LARGE_NW)   /* conv4_1_2 -> conv4_1_3        @ H/16 */ \
-    MD(96, 96, 24, 16, 20, YF_MDW_LARGE_NW)  /* conv4_1_4 -> conv4_1_5 -> head_4      */
+    MD(96, 96, 1, 16, 20, YF_MDW_LARGE_NW)   /* conv4_1_4 -> conv4_1_5 -> head_4      */ \
+    MD(96, 96, 2, 16, 20, YF_MDW_LARGE_NW)
 
-int launch_mdw(int c, int n, int headn, const MdwArgs& a, int Nf, hipStream_t s, int dtype)
+static int mdw_head_mode(int headn) { return headn <= 0 ? 0 : headn <= 32 ? 1 : 2; }
+
+int launch_mdw(int c, int n, int headn, const MdwArgs& a0, int Nf, hipStream_t s, int dtype)
 {
+    MdwArgs a = a0;
+    a.headn = headn;
+    const int hm = mdw_head_mode(headn);
 #define MD(cc, nn, hh, th, tw, nw)                                                               \
-    if (c == cc && n == nn && headn == hh)                                                        \
+    if (c == cc && n == nn && hm == hh)                                                           \
         return dtype == DT_F16 ? launch_mdw_t<cc, nn, hh, th, tw, nw, half_t>(a, Nf, s)           \
              : dtype == DT_F16X3 ? launch_mdw_t<cc, nn, hh, th, tw, nw, x3_t>(a, Nf, s) : launch_mdw_t<cc, nn, hh, th, tw, nw, float>(a, Nf, s);
     YF_MDW_SHAPES(MD)
@@ -659,8 +746,9 @@ int launch_mdw(int c, int n, int headn, const MdwArgs& a, int Nf, hipStream_t s,
 
 bool mdw_has_kernel(int c, int n, int headn)
 {
+    const int hm = mdw_head_mode(headn);
 #define MD(cc, nn, hh, th, tw, nw) \
-    if (c == cc && n == nn && headn == hh) return true;
+    if (c == cc && n == nn && hm == hh) return true;
     YF_MDW_SHAPES(MD)
 #undef MD
     return false;
@@ -699,6 +787,7 @@ void mdw_pack_weights(const float* wd /*[25][c]*/, const float* bd, const float*
     for (int i = 0; i < n; ++i) o[i] = b[i];
     o += n;
     if (headn) {
+        const int nthp = mdw_head_tiles(headn);   // column tiles, padded to pairs (2 for every head of up to 32 channels)
         auto h_at = [&](int s, int nt, int lane) -> float {
             const int k = (s / 4) * 16 + 4 * (lane >> 4) + (s % 4), col = nt * 16 + (lane & 15);
             return col < headn ? hw[(size_t)k * headn + col] : 0.f;
@@ -706,20 +795,20 @@ void mdw_pack_weights(const float* wd /*[25][c]*/, const float* bd, const float*
         if (h16) {
             uint16_t* o16 = reinterpret_cast<uint16_t*>(o);
             for (int kb = 0; kb < n / 16; ++kb)
-                for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < nthp; ++nt)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int j = 0; j < 4; ++j) {
-                            o16[((kb * 2 + nt) * 64 + lane) * 4 + j] = f32_to_f16_bits(h_at(kb * 4 + j, nt, lane));
-                            if (x3) o16[(((n / 16 + kb) * 2 + nt) * 64 + lane) * 4 + j] = f16_lo_bits(h_at(kb * 4 + j, nt, lane));
+                            o16[((kb * nthp + nt) * 64 + lane) * 4 + j] = f32_to_f16_bits(h_at(kb * 4 + j, nt, lane));
+                            if (x3) o16[(((n / 16 + kb) * nthp + nt) * 64 + lane) * 4 + j] = f16_lo_bits(h_at(kb * 4 + j, nt, lane));
                         }
-            o += (x3 ? 2 : 1) * (n / 16) * 2 * 128;
+            o += (x3 ? 2 : 1) * (n / 16) * nthp * 128;
         } else {
             for (int s = 0; s < n / 4; ++s)
-                for (int nt = 0; nt < 2; ++nt)
-                    for (int lane = 0; lane < 64; ++lane) o[(s * 2 + nt) * 64 + lane] = h_at(s, nt, lane);
-            o += (n / 4) * 2 * 64;
+                for (int nt = 0; nt < nthp; ++nt)
+                    for (int lane = 0; lane < 64; ++lane) o[(s * nthp + nt) * 64 + lane] = h_at(s, nt, lane);
+            o += (n / 4) * nthp * 64;
         }
-        for (int i = 0; i < 32; ++i) o[i] = i < headn ? hb[i] : 0.f;
+        for (int i = 0; i < nthp * 16; ++i) o[i] = i < headn ? hb[i] : 0.f;
     }
 }
 

@@ -57,24 +57,27 @@ __device__ inline int32_t clamp_i32(double v)
 struct CellRef {
     const float* p;  // frame's head tensor
     int h, w, head, pp, i, j;
+    int attrs;       // 5 + num_cls
 };
 __device__ inline CellRef locate(const PostArgs& a, long frame, int cell)
 {
     CellRef r;
-    int nl = 3 * a.hl * a.wl;
+    const int nl = a.na * a.hl * a.wl;
+    const long nout = (long)a.na * (5 + a.nc);   // channels of a head tensor: num_anchors * (5 + num_cls), detect.py:53
     if (cell < nl) {
-        r.head = 0; r.h = a.hl; r.w = a.wl; r.p = a.head_large + frame * 24L * a.hl * a.wl;
+        r.head = 0; r.h = a.hl; r.w = a.wl; r.p = a.head_large + frame * nout * a.hl * a.wl;
     } else {
-        cell -= nl; r.head = 1; r.h = a.hs; r.w = a.ws; r.p = a.head_small + frame * 24L * a.hs * a.ws;
+        cell -= nl; r.head = 1; r.h = a.hs; r.w = a.ws; r.p = a.head_small + frame * nout * a.hs * a.ws;
     }
     r.j = cell % r.w;
     int t = cell / r.w;
     r.i = t % r.h;
     r.pp = t / r.h;
+    r.attrs = 5 + a.nc;
     return r;
 }
 __device__ inline long s_area(const int4& b) { return ((long)b.z - b.x) * ((long)b.w - b.y); }
-__device__ inline float logit_at(const CellRef& r, int k) { return r.p[((r.pp * 8 + k) * r.h + r.i) * r.w + r.j]; }
+__device__ inline float logit_at(const CellRef& r, int k) { return r.p[((r.pp * r.attrs + k) * r.h + r.i) * r.w + r.j]; }
 
 // LDS carve: keys u64[mpad] | boxes int4[ncell] | kept u16[ncell] | alive u8[ncell] | small scalars
 // (worst case 512x640: 8192*8 + 4800*19 = 156.7 KB of the CU's 160 KB)
@@ -106,10 +109,9 @@ __global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncel
                 if (t4 == 0.f) t4 = 0.f;  // -0.0 and +0.0 have the same conf
                 float best = logit_at(r, 5);
                 int cls = 0;
-#pragma unroll
-                for (int k = 1; k < 3; ++k) {
+                for (int k = 1; k < a.nc; ++k) {
                     float v = logit_at(r, 5 + k);
-                    if (v > best) { best = v; cls = k; }  // np.argmax: first maximum wins
+                    if (v > best) { best = v; cls = k; }  // np.argmax: first maximum wins (detect.py:59)
                 }
                 key = ((uint64_t)cls << 45) | ((uint64_t)conf_order(t4) << 13) | (uint64_t)cell;
             }
@@ -161,8 +163,8 @@ __global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncel
         double scale_h = (double)a.in_h / r.h, scale_w = (double)a.in_w / r.w;
         double x = (r.j + sigmoid_d((double)logit_at(r, 0))) * scale_w;
         double y = (r.i + sigmoid_d((double)logit_at(r, 1))) * scale_h;
-        double bw = exp((double)logit_at(r, 2)) * a.anchors[(r.head * 3 + r.pp) * 2 + 0];
-        double bh = exp((double)logit_at(r, 3)) * a.anchors[(r.head * 3 + r.pp) * 2 + 1];
+        double bw = exp((double)logit_at(r, 2)) * a.anchors[(r.head * a.na + r.pp) * 2 + 0];
+        double bh = exp((double)logit_at(r, 3)) * a.anchors[(r.head * a.na + r.pp) * 2 + 1];
         boxes[k] = make_int4(clamp_i32(rint(x - bw / 2)), clamp_i32(rint(y - bh / 2)), clamp_i32(rint(x + bw / 2)),
                              clamp_i32(rint(y + bh / 2)));
         alive[k] = 1;
@@ -364,9 +366,9 @@ void launch_nms_sorted(const int32_t* boxes, int n, double nms_thres, int32_t* s
 //   src/model_training/loss/yolo_loss.py:48-68,98-141   fp32 decode of one head to (cx, cy, w, h, conf, cls...)
 //   src/model_training/utils/general.py:29-52, 87-143   corners, conf >= thres, per-class greedy NMS, IoU with +1, keep iou < thres
 // ================================================================================================
+struct ValAnchors { float wh[2 * POST_MAX_ANCHORS]; };
 __global__ void __launch_bounds__(256) val_decode_kernel(const float* __restrict__ in, float* __restrict__ out, long total, int h, int w,
-                                                          int M_total, int m_off, float aw0, float ah0, float aw1, float ah1, float aw2,
-                                                          float ah2, float stride_w, float stride_h)
+                                                          int M_total, int m_off, ValAnchors anc, int na, int nc, float stride_w, float stride_h)
 {
     long idx = (long)blockIdx.x * 256 + threadIdx.x;  // (frame, anchor, i, j)
     if (idx >= total) return;
@@ -374,36 +376,37 @@ __global__ void __launch_bounds__(256) val_decode_kernel(const float* __restrict
     long t = idx / w;
     const int i = (int)(t % h);
     t /= h;
-    const int a = (int)(t % 3);
-    const long n = t / 3;
-    const float* p = in + ((n * 3 + a) * 8) * (long)h * w + (long)i * w + j;
+    const int a = (int)(t % na);
+    const long n = t / na;
+    const int attrs = 5 + nc;
+    const float* p = in + ((n * na + a) * attrs) * (long)h * w + (long)i * w + j;
     const long hw = (long)h * w;
     auto sg = [](float v) { return 1.f / (1.f + expf(-v)); };
-    const float aw = a == 0 ? aw0 : a == 1 ? aw1 : aw2, ah = a == 0 ? ah0 : a == 1 ? ah1 : ah2;
-    float* o = out + (n * M_total + m_off + ((long)a * h + i) * w + j) * 8;
-    float4 v0, v1;
-    v0.x = (sg(p[0]) + (float)j) * stride_w;          // (x + grid_x) * stride_w        yolo_loss.py:133,139
-    v0.y = (sg(p[hw]) + (float)i) * stride_h;
-    v0.z = (expf(p[2 * hw]) * aw) * stride_w;         // exp(w) * anchor_w (feature-map units), then * stride
-    v0.w = (expf(p[3 * hw]) * ah) * stride_h;
-    v1.x = sg(p[4 * hw]); v1.y = sg(p[5 * hw]); v1.z = sg(p[6 * hw]); v1.w = sg(p[7 * hw]);
-    reinterpret_cast<float4*>(o)[0] = v0;
-    reinterpret_cast<float4*>(o)[1] = v1;
+    const float aw = anc.wh[2 * a], ah = anc.wh[2 * a + 1];
+    float* o = out + (n * M_total + m_off + ((long)a * h + i) * w + j) * attrs;
+    o[0] = (sg(p[0]) + (float)j) * stride_w;          // (x + grid_x) * stride_w        yolo_loss.py:133,139
+    o[1] = (sg(p[hw]) + (float)i) * stride_h;
+    o[2] = (expf(p[2 * hw]) * aw) * stride_w;         // exp(w) * anchor_w (feature-map units), then * stride
+    o[3] = (expf(p[3 * hw]) * ah) * stride_h;
+    for (int k = 4; k < attrs; ++k) o[k] = sg(p[k * hw]);   // conf, class scores
 }
 
-void launch_val_decode(const float* in, float* out, int N, int h, int w, int M_total, int m_off, const float* anc6, float stride_w,
+void launch_val_decode(const float* in, float* out, int N, int h, int w, int M_total, int m_off, const float* anc, int na, int nc, float stride_w,
                        float stride_h, hipStream_t s)
 {
-    long total = (long)N * 3 * h * w;
+    long total = (long)N * na * h * w;
+    ValAnchors va{};
+    for (int i = 0; i < 2 * na && i < 2 * POST_MAX_ANCHORS; ++i) va.wh[i] = anc[i];
     hipLaunchKernelGGL(val_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, h, w, M_total, m_off,
-                       anc6[0], anc6[1], anc6[2], anc6[3], anc6[4], anc6[5], stride_w, stride_h);
+                       va, na, nc, stride_w, stride_h);
 }
 
 // One workgroup per image.  All arithmetic after the decode is fp32 add/mul/div, so given the same prediction tensor the
 // result is bit-identical to the reference's torch code (ties in conf: index order; the reference's sort is unstable).
-__global__ void __launch_bounds__(POST_THREADS) val_nms_kernel(const float* __restrict__ pred, int M, int mpad_max, float conf_thres,
+__global__ void __launch_bounds__(POST_THREADS) val_nms_kernel(const float* __restrict__ pred, int M, int mpad_max, int nc, float conf_thres,
                                                                float nms_thres, int kmax, float* __restrict__ det, int32_t* counts)
 {
+    const int attrs = 5 + nc;   // floats per prediction row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
     uint16_t* kept = reinterpret_cast<uint16_t*>(smem + (size_t)mpad_max * 8);
@@ -411,7 +414,7 @@ __global__ void __launch_bounds__(POST_THREADS) val_nms_kernel(const float* __re
     __shared__ int s_wave_cnt[POST_THREADS / 64];
     __shared__ int s_total, s_nkept;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* P = pred + (long)blockIdx.x * M * 8;
+    const float* P = pred + (long)blockIdx.x * M * attrs;
     if (tid == 0) { s_total = 0; s_nkept = 0; }
     __syncthreads();
     for (int base = 0; base < M; base += POST_THREADS) {
@@ -419,12 +422,12 @@ __global__ void __launch_bounds__(POST_THREADS) val_nms_kernel(const float* __re
         bool pass = false;
         uint64_t key = 0;
         if (m < M) {
-            const float conf = P[m * 8 + 4];
+            const float conf = P[(long)m * attrs + 4];
             pass = conf >= conf_thres;
             if (pass) {
-                float best = P[m * 8 + 5];
+                float best = P[(long)m * attrs + 5];
                 int cls = 0;
-                for (int k = 1; k < 3; ++k) { float v = P[m * 8 + 5 + k]; if (v > best) { best = v; cls = k; } }
+                for (int k = 1; k < nc; ++k) { float v = P[(long)m * attrs + 5 + k]; if (v > best) { best = v; cls = k; } }   // torch.max: first maximum
                 key = ((uint64_t)cls << 45) | ((uint64_t)(~__float_as_uint(conf)) << 13) | (uint64_t)m;
             }
         }
@@ -460,7 +463,7 @@ __global__ void __launch_bounds__(POST_THREADS) val_nms_kernel(const float* __re
     for (int i = tid; i < K; i += POST_THREADS) alive[i] = 1;
     __syncthreads();
     auto corners = [&](int k) {  // general.py:90-95, fp32
-        const float* q = P + (long)(keys[k] & 0x1fffu) * 8;
+        const float* q = P + (long)(keys[k] & 0x1fffu) * attrs;
         const float cx = q[0], cy = q[1], w = q[2], h = q[3];
         return make_float4(cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2);
     };
@@ -488,7 +491,7 @@ __global__ void __launch_bounds__(POST_THREADS) val_nms_kernel(const float* __re
     if (tid == 0) counts[blockIdx.x] = nk;
     for (int k = tid; k < (nk < kmax ? nk : kmax); k += POST_THREADS) {
         const int i = kept[k];
-        const float* q = P + (long)(keys[i] & 0x1fffu) * 8;
+        const float* q = P + (long)(keys[i] & 0x1fffu) * attrs;
         const float4 c = corners(i);
         const int cls = (int)(keys[i] >> 45);
         float* o = det + ((long)blockIdx.x * kmax + k) * 7;
@@ -497,9 +500,9 @@ __global__ void __launch_bounds__(POST_THREADS) val_nms_kernel(const float* __re
 }
 
 static int pow2_at_least(int n);
-int launch_val_nms(const float* pred, int N, int M, float conf_thres, float nms_thres, int kmax, float* det, int32_t* counts, hipStream_t s)
+int launch_val_nms(const float* pred, int N, int M, int nc, float conf_thres, float nms_thres, int kmax, float* det, int32_t* counts, hipStream_t s)
 {
-    if (M > 8191) return -1;
+    if (M > 8191 || nc < 1) return -1;
     int mp = pow2_at_least(M);
     size_t lds = (size_t)mp * 8 + (size_t)M * 3 + 16;
     static size_t attr_set[YF_MAX_DEVICES] = {};
@@ -510,7 +513,7 @@ int launch_val_nms(const float* pred, int N, int M, float conf_thres, float nms_
             return -2;
         attr_set[dev] = lds;
     }
-    hipLaunchKernelGGL(val_nms_kernel, dim3(N), dim3(POST_THREADS), lds, s, pred, M, mp, conf_thres, nms_thres, kmax, det, counts);
+    hipLaunchKernelGGL(val_nms_kernel, dim3(N), dim3(POST_THREADS), lds, s, pred, M, mp, nc, conf_thres, nms_thres, kmax, det, counts);
     return 0;
 }
 
@@ -529,7 +532,8 @@ size_t post_lds_bytes(int ncell)
 
 int launch_post(const PostArgs& a, int N, hipStream_t s)
 {
-    int ncell = 3 * (a.hl * a.wl + a.hs * a.ws);
+    if (a.na < 1 || a.na > POST_MAX_ANCHORS || a.nc < 1 || a.nc >= (1 << 18)) return -1;   // (the class sits above bit 45 of the sort key)
+    int ncell = a.na * (a.hl * a.wl + a.hs * a.ws);
     if (ncell > 8191) return -1;  // 13-bit cell field of the sort key
     size_t lds = post_lds_bytes(ncell);
     if (lds > 160 * 1024 - 64) return -1;  // + 28 B of static LDS

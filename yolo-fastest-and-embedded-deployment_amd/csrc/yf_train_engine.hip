@@ -52,6 +52,7 @@ struct TLayer {
 };
 struct yf_trainer_s {
     int device, H, W;
+    LayerSpec layers[kNumLayers];   // the graph for this trainer's io_params: kBaseLayers with conv0's Cin and the heads' Cout set (make_layers)
     TLayer L[kNumLayers];
     size_t act_floats;      // per frame: all z / y, the concat buffer
     size_t cat;             // per-frame offset of the concat buffer
@@ -75,6 +76,7 @@ namespace {
 
 int trainer_build(yf_trainer_s* t, int H, int W)
 {
+    const LayerSpec* const kLayers = t->layers;
     t->H = H; t->W = W;
     t->i_conv4_2 = find_layer("conv4_2"); t->i_conv4_3 = find_layer("conv4_3"); t->i_conv5_2 = find_layer("conv5_2");
     t->i_conv5_3 = find_layer("conv5_3"); t->i_conv5_6 = find_layer("conv5_6"); t->i_head5 = find_layer("head_5");
@@ -91,7 +93,7 @@ int trainer_build(yf_trainer_s* t, int H, int W)
         if (i == t->i_deconv) L.in = t->i_conv5_2;              // deconv5_1(conv5_2)              yolo_fastest.py:208
         if (i == t->i_c411) L.in = -2;                          // conv4_1_1(cat(conv4_2, deconv5_1))       :209-211
         if (L.in >= 0) { L.Cin = t->L[L.in].Cout; L.Hin = t->L[L.in].Ho; L.Win = t->L[L.in].Wo; }
-        else if (L.in == -1) { L.Cin = 1; L.Hin = H; L.Win = W; }
+        else if (L.in == -1) { L.Cin = kLayers[0].cin; L.Hin = H; L.Win = W; }
         else { L.Cin = t->L[t->i_conv4_2].Cout + t->L[t->i_deconv].Cout; L.Hin = t->L[t->i_conv4_2].Ho; L.Win = t->L[t->i_conv4_2].Wo; }
         if (L.Cin != S.cin) return -1;
         L.Cout = S.cout;
@@ -118,7 +120,7 @@ int trainer_build(yf_trainer_s* t, int H, int W)
     off += (size_t)t->L[t->i_c411].Cin * t->L[t->i_c411].Hin * t->L[t->i_c411].Win;
     if ((size_t)t->L[t->i_c411].Cin * t->L[t->i_c411].Hin * t->L[t->i_c411].Win > t->gmax)
         t->gmax = (size_t)t->L[t->i_c411].Cin * t->L[t->i_c411].Hin * t->L[t->i_c411].Win;
-    if ((size_t)H * W > t->gmax) t->gmax = (size_t)H * W;
+    if ((size_t)kLayers[0].cin * H * W > t->gmax) t->gmax = (size_t)kLayers[0].cin * H * W;
     t->act_floats = off;
     t->stats_floats = st;
     t->n_params = p;
@@ -137,6 +139,7 @@ struct TWs {
 // more than the shared scratch holds
 size_t trainer_slab_floats(const yf_trainer_s* t, int N)
 {
+    const LayerSpec* const kLayers = t->layers;
     size_t total = 0;
     for (int i = 0; i < kNumLayers; ++i) {
         const LayerSpec& S = kLayers[i];
@@ -362,11 +365,16 @@ int yf_train_adam_multi_pinned(int device, int ntensors, void* const* d_p, const
     return YF_OK;
 }
 // ---- the trainer: forward and backward of the whole network as one call each ----
-int yf_trainer_create(int H, int W, int device, yf_trainer* out)
+int yf_trainer_create(int H, int W, int device, yf_trainer* out) { return yf_trainer_create_ex(H, W, device, 1, 24, out); }
+
+int yf_trainer_create_ex(int H, int W, int device, int input_channel, int num_out, yf_trainer* out)
 {
     if (!out || H <= 0 || W <= 0 || H % 32 || W % 32) return fail(YF_E_INVALID, "yf_trainer_create: H and W must be positive multiples of 32");
+    if (input_channel < 1 || input_channel > 4 || num_out < 1 || num_out > 4096)
+        return fail(YF_E_INVALID, "yf_trainer_create: input_channel must be 1..4 and num_out 1..4096");
     yf_trainer_s* t = new yf_trainer_s();
     t->device = device;
+    make_layers(t->layers, input_channel, num_out);
     if (trainer_build(t, H, W)) { delete t; return fail(YF_E_INVALID, "yf_trainer_create: layer table inconsistent"); }
     *out = t;
     return YF_OK;
@@ -399,6 +407,7 @@ static int trainer_forward_launches(yf_trainer t, const float* d_x, int N, const
                                     float* d_head_large, float* d_head_small, void* d_ws, hipStream_t s)
 {
     const TWs w = trainer_ws(t, N, d_ws);
+    const LayerSpec* const kLayers = t->layers;
     auto P = [&](int i) { return static_cast<const float*>(d_params[i]); };
     int bn = 0;
     PassTimer tm(s);
@@ -444,6 +453,7 @@ static int trainer_backward_launches(yf_trainer t, const float* d_x, const float
                                      const void* const* d_params, void* const* d_grads, void* d_ws, hipStream_t s, bool capturing)
 {
     const TWs w = trainer_ws(t, N, d_ws);
+    const LayerSpec* const kLayers = t->layers;
     auto P = [&](int i) { return static_cast<const float*>(d_params[i]); };
     auto G = [&](int i) { return static_cast<float*>(d_grads[i]); };
     const size_t sb = yf::train_scratch_bytes();

@@ -25,13 +25,16 @@ from .post_process import YOLO_post_process
 
 def preprocess_u8(model, u8, input_shape):
     """Detect_YOLO.__pre_process arithmetic (detect.py:115-127) on device.
-    u8: uint8 GPU tensor [N,h,w] (h,w == net input or exactly 2x) -> float32 [N,1,H,W]."""
-    if not u8.is_cuda or u8.dtype != torch.uint8 or u8.dim() != 3:
-        raise ValueError("expected a uint8 GPU tensor [N,h,w]")
+    u8: uint8 GPU tensor [N,h,w] (h,w == net input or exactly 2x) -> float32 [N,1,H,W]; a 3-channel model takes [N,h,w,3] as
+    cv2.imread returns frames (BGR) -> float32 [N,3,H,W], channels reversed like `img[:, :, ::-1].transpose(2, 0, 1)` (:119)."""
+    cin = model.input_channel
+    want = 3 if cin == 1 else 4
+    if not u8.is_cuda or u8.dtype != torch.uint8 or u8.dim() != want or (want == 4 and u8.shape[3] != cin):
+        raise ValueError("expected a uint8 GPU tensor [N,h,w]" + ("" if cin == 1 else " + [%d] (HWC)" % cin))
     H, W = int(input_shape[0]), int(input_shape[1])
     N = u8.shape[0]
     e = model.engine(H, W, N, u8.device)
-    x = torch.empty((N, 1, H, W), dtype=torch.float32, device=u8.device)
+    x = torch.empty((N, cin, H, W), dtype=torch.float32, device=u8.device)
     u8 = u8.contiguous()
     stream = torch.cuda.current_stream(u8.device).cuda_stream
     _lib.check(e.lib.yf_preprocess_u8(e.handle, u8.data_ptr(), N, u8.shape[1], u8.shape[2], x.data_ptr(),
@@ -59,9 +62,13 @@ class Detect_YOLO():
         self.colors = [[106, 90, 205], [199, 97, 20], [112, 128, 105]]
 
     def _read_gray(self, path):
+        """-> (the frame the pre-process takes, the RGB original for drawing).  A 3-channel model (input_shape[2] == 3) gets what
+        cv2.imread would return: HWC in BGR order (detect.py:108-113); a 1-channel model the gray frame (:110-111)."""
         from PIL import Image
         img = Image.open(path)
         ori = np.asarray(img.convert("RGB"))
+        if self.model.input_channel == 3:
+            return np.ascontiguousarray(ori[:, :, ::-1]), ori
         return np.asarray(img.convert("L")), ori
 
     def detect_u8(self, u8, kmax=64):
@@ -115,7 +122,8 @@ class Detect_YOLO():
         labels = []
         for *xyxy, conf, cls_score, cls_pred in boxes:
             label = '%s %.2f' % (self.class_names[int(cls_pred)], conf * cls_score)
-            plot_one_box(xyxy, img, label=label, color=self.colors[int(cls_pred)], line_thickness=3)
+            # (the reference has three colours, :105, and would raise IndexError from the fourth class on: they repeat here)
+            plot_one_box(xyxy, img, label=label, color=self.colors[int(cls_pred) % len(self.colors)], line_thickness=3)
             labels.append(label)
         if path is not None and os.path.isdir(os.path.dirname(path)):
             from PIL import Image

@@ -5,8 +5,9 @@ Drop-in surface kept:
   * ctor `YoloFastest(io_params)` reading num_cls / input_channel / num_anchors (:70-76);
   * the 508-key state-dict: `load_state_dict(torch.load(path, map_location=device))` works strictly
     (src/detect.py:90-91), `.to(device)` / `.eval()` chain (:89);
-  * `model(x)`: x float32 [N,1,H,W] NCHW, H and W multiples of 32 -> `(head_large, head_small)` float32
-    NCHW on the same device (:218).
+  * `model(x)`: x float32 [N,input_channel,H,W] NCHW, H and W multiples of 32 -> `(head_large, head_small)` float32
+    NCHW [N, num_anchors * (5 + num_cls), ...] on the same device (:218).  Every num_cls and num_anchors (up to 8) of io_params is
+    implemented, and input_channel 1 (gray) or 3 (cv2's BGR frames, detect.py:109-119).
 The torch.nn modules below are parameter CONTAINERS only (they give the state-dict its names and shapes);
 they are never called.  In eval mode forward() packs them once (BN fold, packer.py) and runs the tuned HIP engine; in train mode it
 runs the training operators (training.py: batch-statistics BatchNorm, differentiable).  There is no CPU path: a non-GPU tensor or
@@ -95,9 +96,11 @@ class YoloFastest(nn.Module):
         num_anchor = io_params["num_anchors"]
         self.num_anchors = num_anchor
         self.num_out = num_anchor * (5 + self.num_cls)
-        if self.input_channel != 1 or self.num_out != 24:
-            raise NotImplementedError("the HIP engine implements the shipped configuration: 1 input channel, "
-                                      "3 anchors x (5 + 3 classes) = 24 outputs per cell")
+        if self.input_channel not in (1, 3):
+            raise NotImplementedError("the HIP engine implements input_channel 1 (gray) and 3 (cv2's BGR frames), not %r"
+                                      % (self.input_channel,))
+        if not (1 <= int(num_anchor) <= 8) or int(self.num_cls) < 1:
+            raise ValueError("num_anchors must be 1..8 and num_cls >= 1")
         # parameter containers, module-definition order of the reference (state-dict order follows it)
         blocks = {}
         for name, kind, cin, cout, k, stride, relu in packer.layer_table(self.num_out, self.input_channel):
@@ -227,8 +230,8 @@ class YoloFastest(nn.Module):
             return training.forward(self, x)
         if not x.is_cuda:
             raise RuntimeError("YoloFastest (HIP engine) has no CPU path: move the model and input to the GPU")
-        if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] % 32 or x.shape[3] % 32:
-            raise ValueError("expected [N,1,H,W] with H and W multiples of 32, got %s" % (tuple(x.shape),))
+        if x.dim() != 4 or x.shape[1] != self.input_channel or x.shape[2] % 32 or x.shape[3] % 32:
+            raise ValueError("expected [N,%d,H,W] with H and W multiples of 32, got %s" % (self.input_channel, tuple(x.shape)))
         in_dtype = x.dtype
         x = x.contiguous().float()
         N, _, H, W = x.shape
@@ -245,11 +248,12 @@ class YoloFastest(nn.Module):
 
     def forward_u8(self, u8, input_shape):
         """model(preprocess(u8)) with the pre-process fused into the first kernel: u8 GPU tensor [N,h,w] (h,w == the net
-        input or exactly 2x) -> (head_large, head_small)."""
+        input or exactly 2x; input_channel 3: [N,h,w,3] as cv2.imread returns frames, BGR) -> (head_large, head_small)."""
         if self.training:
             raise RuntimeError("YoloFastest (HIP engine) is inference-only: call .eval() first")
-        if not u8.is_cuda or u8.dtype != torch.uint8 or u8.dim() != 3:
-            raise ValueError("expected a uint8 GPU tensor [N,h,w]")
+        want = 3 if self.input_channel == 1 else 4
+        if not u8.is_cuda or u8.dtype != torch.uint8 or u8.dim() != want or (want == 4 and u8.shape[3] != self.input_channel):
+            raise ValueError("expected a uint8 GPU tensor [N,h,w]" + ("" if want == 3 else " + [%d] (HWC)" % self.input_channel))
         H, W = int(input_shape[0]), int(input_shape[1])
         u8 = u8.contiguous()
         N = u8.shape[0]

@@ -24,9 +24,12 @@ class YOLO_post_process:
         self.bbox_attrs = 5 + num_class
         self.anchors = anchors
         self.input_shape = input_shape
-        if num_anchors != 3 or num_class != 3:
-            raise NotImplementedError("the HIP post-process implements 3 anchors x 3 classes")
-        self._anc = (ctypes.c_double * 12)(*[float(v) for head in anchors[:2] for a in head for v in a])
+        if not (1 <= int(num_anchors) <= 8) or int(num_class) < 1:
+            raise ValueError("num_anchors must be 1..8 and num_class >= 1")
+        if len(anchors) < 2 or any(len(head) < num_anchors for head in anchors[:2]):
+            raise ValueError("anchors must hold at least num_anchors [w, h] pairs for each of the two heads (detect.py:51,63-64)")
+        # [2][num_anchors][2]: the heads use anchors[head][0 .. num_anchors - 1] (detect.py:51,54,63-64)
+        self._anc = (ctypes.c_double * (4 * num_anchors))(*[float(v) for head in anchors[:2] for a in head[:num_anchors] for v in a[:2]])
         self._model = None
 
     # the kernels need an engine handle (it carries H, W and the device); bind the model that made `pred`
@@ -43,6 +46,11 @@ class YOLO_post_process:
         H, W = hl.shape[2] * 16, hl.shape[3] * 16
         if [H, W] != list(self.input_shape[:2]):
             raise ValueError("pred is for a %dx%d input, input_shape says %s" % (H, W, self.input_shape[:2]))
+        if hl.shape[1] != self.num_anchors * self.bbox_attrs or pred[1].shape[1] != hl.shape[1]:
+            raise ValueError("pred has %d channels per cell, num_anchors x (5 + num_class) = %d"
+                             % (hl.shape[1], self.num_anchors * self.bbox_attrs))   # detect.py:53's reshape would raise
+        if (self._model.num_anchors, self._model.num_cls) != (self.num_anchors, self.bbox_attrs - 5):
+            raise ValueError("the bound model was built for %d anchors x %d classes" % (self._model.num_anchors, self._model.num_cls))
         return self._model.engine(H, W, hl.shape[0], hl.device, slot)
 
     def detect_raw(self, pred, kmax=64, nms_thres=None, origin_shape=None, slot=0):
@@ -66,7 +74,7 @@ class YOLO_post_process:
         return out
 
     def detect_raw_from_input(self, x, kmax=64, origin_shape=None):
-        """model forward + decode + NMS in ONE C call (yf_detect): x float32 GPU tensor [N,1,H,W] -> the same dict as
+        """model forward + decode + NMS in ONE C call (yf_detect): x float32 GPU tensor [N,input_channel,H,W] -> the same dict as
         detect_raw, plus the two head tensors."""
         if self._model is None:
             raise RuntimeError("call post_process.bind(model) first")
@@ -81,8 +89,8 @@ class YOLO_post_process:
                    cls=torch.empty((N, kmax), dtype=torch.int32, device=dev),
                    src=torch.empty((N, kmax), dtype=torch.int32, device=dev),
                    counts=torch.empty((N,), dtype=torch.int32, device=dev),
-                   head_large=torch.empty((N, 24, H // 16, W // 16), dtype=torch.float32, device=dev),
-                   head_small=torch.empty((N, 24, H // 32, W // 32), dtype=torch.float32, device=dev))
+                   head_large=torch.empty((N, self._model.num_out, H // 16, W // 16), dtype=torch.float32, device=dev),
+                   head_small=torch.empty((N, self._model.num_out, H // 32, W // 32), dtype=torch.float32, device=dev))
         ws = e.workspace(N, dev)
         oh, ow = (origin_shape[0], origin_shape[1]) if origin_shape is not None else (0, 0)
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -123,7 +131,7 @@ class YOLO_post_process:
     def decode_box(self, pred):
         """detect.py:41-67: candidates of batch element 0 in decode order (pre-NMS)."""
         hl, hs = pred[0][:1], pred[1][:1]
-        ncell = 3 * (hl.shape[2] * hl.shape[3] + hs.shape[2] * hs.shape[3])
+        ncell = self.num_anchors * (hl.shape[2] * hl.shape[3] + hs.shape[2] * hs.shape[3])
         raw = self.detect_raw((hl, hs), kmax=ncell, nms_thres=float("inf"))  # iou > inf never: nothing suppressed
         lst = self.to_lists(raw, with_src=True)[0]
         lst.sort(key=lambda e: e[7])  # back to (head, anchor, row, col) order

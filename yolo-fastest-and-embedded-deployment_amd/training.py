@@ -220,11 +220,11 @@ def train_backward(model, tape, g_hl, g_hs):
 class _Trainer:
     """yf_trainer handle for one (H, W, device): the whole forward / backward as one C call each (include/yolo_fastest_hip.h)."""
 
-    def __init__(self, H, W, device):
+    def __init__(self, H, W, device, input_channel=1, num_out=24):
         self.lib = _lib.lib()
         self.dev = device.index if device.index is not None else torch.cuda.current_device()
         self.handle = ctypes.c_void_p()
-        _lib.check(self.lib.yf_trainer_create(H, W, self.dev, ctypes.byref(self.handle)))
+        _lib.check(self.lib.yf_trainer_create_ex(H, W, self.dev, int(input_channel), int(num_out), ctypes.byref(self.handle)))
         n, nb = ctypes.c_int(), ctypes.c_int()
         _lib.check(self.lib.yf_trainer_num_params(self.handle, ctypes.byref(n), ctypes.byref(nb)))
         self.n_params, self.n_bn = n.value, nb.value
@@ -261,7 +261,7 @@ def _trainer(model, H, W, device):
     key = (H, W, device.index if device.index is not None else torch.cuda.current_device())
     cache = model.__dict__.setdefault("_trainers", {})
     if key not in cache:
-        cache[key] = _Trainer(H, W, device)
+        cache[key] = _Trainer(H, W, device, model.input_channel, model.num_out)
     return cache[key]
 
 
@@ -358,8 +358,8 @@ def forward(model, x):
     """model(imgs) in train mode (train.py:114)."""
     if not x.is_cuda:
         raise RuntimeError("YoloFastest training (HIP) has no CPU path: move the model and input to the GPU")
-    if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] % 32 or x.shape[3] % 32:
-        raise ValueError("expected [N,1,H,W] with H and W multiples of 32, got %s" % (tuple(x.shape),))
+    if x.dim() != 4 or x.shape[1] != model.input_channel or x.shape[2] % 32 or x.shape[3] % 32:
+        raise ValueError("expected [N,%d,H,W] with H and W multiples of 32, got %s" % (model.input_channel, tuple(x.shape)))
     st = _structure(model)
     params = [d[n] for d, n in st["slots"]]
     f32 = torch.float32

@@ -45,8 +45,8 @@ class YOLOLossV3(torch.nn.Module):
         self.input_shape = input_shape
         self.device = device
         self.ignore_threshold = 0.5    # config_params["train_params"]["IOU_loss_thre"] (_config.py:45)
-        if self.num_anchors != 3 or num_classes != 3:
-            raise NotImplementedError("the HIP decode implements 3 anchors x 3 classes")
+        if not (1 <= self.num_anchors <= 8) or int(num_classes) < 1:
+            raise ValueError("1..8 anchors and at least one class")
 
     def forward(self, input, targets=None):
         if targets is not None:
@@ -56,10 +56,15 @@ class YOLOLossV3(torch.nn.Module):
         if (fh * 16, fw * 16) != (int(self.input_shape[0]), int(self.input_shape[1])) and \
            (fh * 32, fw * 32) != (int(self.input_shape[0]), int(self.input_shape[1])):
             raise ValueError("head of %dx%d cells does not belong to a %s input" % (fh, fw, tuple(self.input_shape[:2])))
+        m = _model(self.model)
+        if x.shape[1] != self.num_anchors * self.bbox_attrs or (m.num_anchors, m.num_cls) != (self.num_anchors, self.num_classes):
+            raise RuntimeError("head of %d channels / a model of %d anchors x %d classes, this loss: %d anchors x (5 + %d classes)"
+                               % (x.shape[1], m.num_anchors, m.num_cls, self.num_anchors, self.num_classes))   # yolo_loss.py:58's view raises
         e = _engine(x, int(self.input_shape[0]), int(self.input_shape[1]), self.model)
-        M = 3 * fh * fw
+        # (the reference's decode branch repeats its grid 3 times, yolo_loss.py:110-111, and only runs with 3 anchors; any count here)
+        M = self.num_anchors * fh * fw
         out = torch.empty((bs, M, self.bbox_attrs), dtype=torch.float32, device=x.device)
-        anc = (ctypes.c_double * 6)(*[float(v) for a in self.anchors for v in a])
+        anc = (ctypes.c_double * (2 * self.num_anchors))(*[float(v) for a in self.anchors for v in a[:2]])
         stream = torch.cuda.current_stream(x.device).cuda_stream
         _lib.check(e.lib.yf_val_decode_head(e.handle, x.data_ptr(), bs, fh, fw, anc, M, 0, out.data_ptr(), ctypes.c_void_p(stream)))
         return out
@@ -75,15 +80,16 @@ class _TrainLossFn(torch.autograd.Function):
         lib = _lib.lib()                                     # no inference engine needed: the loss takes (device, H, W)
         dev_index = x.device.index if x.device.index is not None else torch.cuda.current_device()
         need = ctypes.c_size_t()
-        _lib.check(lib.yf_train_head_loss_workspace_bytes(bs, fh, fw, ctypes.byref(need)))
+        na, nc = loss_mod.num_anchors, loss_mod.num_classes
+        _lib.check(lib.yf_train_head_loss_workspace_bytes_ex(bs, fh, fw, na, nc, ctypes.byref(need)))
         work = torch.empty((need.value + 7) // 8, dtype=torch.float64, device=x.device)     # 8-byte aligned scratch
         losses = torch.empty(8, dtype=torch.float32, device=x.device)
         grad = torch.empty_like(x)
-        anc = (ctypes.c_double * 6)(*[float(v) for a in loss_mod.anchors for v in a])
+        anc = (ctypes.c_double * (2 * na))(*[float(v) for a in loss_mod.anchors for v in a[:2]])
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        _lib.check(lib.yf_train_head_loss(dev_index, H, W, x.data_ptr(), bs, fh, fw, anc, targets.data_ptr(), targets.shape[1],
-                                          float(loss_mod.ignore_threshold), work.data_ptr(), work.numel() * 8, losses.data_ptr(),
-                                          grad.data_ptr(), ctypes.c_void_p(stream)))
+        _lib.check(lib.yf_train_head_loss_ex(dev_index, H, W, x.data_ptr(), bs, fh, fw, anc, na, nc, targets.data_ptr(), targets.shape[1],
+                                             float(loss_mod.ignore_threshold), work.data_ptr(), work.numel() * 8, losses.data_ptr(),
+                                             grad.data_ptr(), ctypes.c_void_p(stream)))
         ctx.save_for_backward(grad)
         ctx.mark_non_differentiable(losses)
         return losses[0].clone(), losses
@@ -97,8 +103,8 @@ class _TrainLossFn(torch.autograd.Function):
 def _train_loss(self, input, targets):
     """yolo_loss.py:70-97 with targets: (loss, x, y, w, h, conf, cls) -- loss a 0-dim tensor whose backward() fills input.grad, the rest
     Python floats like the reference's .item() values.  Targets outside the feature map raise IndexError like the reference's indexing."""
-    if self.num_anchors != 3 or self.num_classes != 3:
-        raise NotImplementedError("3 anchors x 3 classes")
+    if input.dim() != 4 or input.shape[1] != self.num_anchors * self.bbox_attrs:
+        raise RuntimeError("input must be [batch, %d x (5 + %d), h, w]" % (self.num_anchors, self.num_classes))   # yolo_loss.py:58's view
     if not input.is_cuda:
         raise RuntimeError("training loss (HIP) has no CPU implementation: pass GPU tensors")
     x = input if (input.is_contiguous() and input.dtype == torch.float32) else input.contiguous().float()
@@ -118,19 +124,19 @@ YOLOLossV3._train_loss = _train_loss
 def non_max_suppression(prediction, num_classes, conf_thres=0.5, nms_thres=0.4, kmax=None, model=None):
     """-> list with one [n,7] tensor (x1,y1,x2,y2,obj_conf,class_conf,class_pred) or None per image, like the reference.
     (The reference also overwrites prediction[..., :4] with the corners in place; this does not touch its input.)"""
-    if num_classes != 3:
-        raise NotImplementedError("3 classes")
     if not prediction.is_cuda:
         raise RuntimeError("validation path (HIP) has no CPU implementation: pass GPU tensors")
     p = prediction.contiguous().float()
-    bs, M, _ = p.shape
+    bs, M, attrs = p.shape
+    if int(num_classes) < 1 or attrs != 5 + int(num_classes):
+        raise ValueError("prediction rows have %d values, 5 + num_classes = %d" % (attrs, 5 + int(num_classes)))
     e = _model(model).engine_on(p.device)   # yf_val_nms is size-agnostic: any engine of that model on the tensor's device
     kmax = kmax or M
     det = torch.empty((bs, kmax, 7), dtype=torch.float32, device=p.device)
     cnt = torch.empty((bs,), dtype=torch.int32, device=p.device)
     stream = torch.cuda.current_stream(p.device).cuda_stream
-    _lib.check(e.lib.yf_val_nms(e.handle, p.data_ptr(), bs, M, float(conf_thres), float(nms_thres), kmax, det.data_ptr(), cnt.data_ptr(),
-                                ctypes.c_void_p(stream)))
+    _lib.check(e.lib.yf_val_nms_ex(e.handle, p.data_ptr(), bs, M, int(num_classes), float(conf_thres), float(nms_thres), kmax, det.data_ptr(),
+                                   cnt.data_ptr(), ctypes.c_void_p(stream)))
     counts = cnt.cpu().tolist()
     if max(counts) > kmax:
         raise OverflowError("more than kmax detections in an image")
