@@ -56,7 +56,10 @@ def _close(got, want, rel, what):
 CONVS = [(1, 8, 3, 2, 0, 16, 12), (24, 24, 3, 2, 0, 10, 8), (8, 8, 3, 1, 1, 9, 7), (32, 32, 3, 2, 1, 12, 10), (136, 136, 3, 2, 1, 6, 8),
          (96, 96, 5, 1, 1, 7, 9), (128, 128, 5, 1, 1, 4, 5), (4, 24, 1, 1, 0, 6, 5), (232, 96, 1, 1, 0, 4, 6), (224, 48, 1, 1, 0, 3, 4),
          (24, 136, 1, 1, 0, 5, 5), (3, 5, 3, 2, 0, 7, 9), (48, 48, 3, 1, 1, 8, 12), (96, 96, 5, 1, 1, 8, 12), (32, 32, 3, 2, 1, 16, 16),
-         (16, 96, 1, 1, 0, 8, 10), (24, 24, 3, 2, 0, 16, 24)]
+         (16, 96, 1, 1, 0, 8, 10), (24, 24, 3, 2, 0, 16, 24),
+         # io_params other than the shipped ones (yolo_fastest.py:72-78,138,148): conv0 on 3 input channels, heads of A * (5 + C) channels
+         (3, 8, 3, 2, 0, 64, 96), (3, 8, 3, 2, 0, 18, 14), (128, 30, 1, 1, 0, 2, 3), (96, 30, 1, 1, 0, 4, 6), (96, 18, 1, 1, 0, 4, 6),
+         (128, 75, 1, 1, 0, 8, 10), (96, 255, 1, 1, 0, 16, 20), (128, 16, 1, 1, 0, 2, 3)]
 
 
 @pytest.mark.parametrize("geom", CONVS)
@@ -99,7 +102,8 @@ def test_conv_forward_backward_match_torch(ops, dev, geom):
 # over above a size the small geometries above never reach: (N, Cin, Cout, k, stride, depthwise, H, W)
 BIG = [(64, 8, 32, 1, 1, 0, 64, 80), (40, 48, 8, 1, 1, 0, 64, 80), (24, 16, 96, 1, 1, 0, 32, 80), (6, 8, 8, 3, 1, 1, 64, 160), (5, 16, 16, 5, 1, 1, 32, 80),
        (3, 8, 8, 3, 1, 1, 36, 72), (12, 24, 24, 3, 2, 0, 64, 80), (32, 1, 8, 3, 2, 0, 64, 160),
-       (64, 136, 24, 1, 1, 0, 16, 32), (40, 232, 96, 1, 1, 0, 16, 52), (300, 96, 96, 5, 1, 1, 16, 20)]     # weight-stationary GEMM; small planes, many
+       (64, 136, 24, 1, 1, 0, 16, 32), (40, 232, 96, 1, 1, 0, 16, 52), (300, 96, 96, 5, 1, 1, 16, 20),     # weight-stationary GEMM; small planes, many
+       (16, 3, 8, 3, 2, 0, 256, 320), (64, 96, 30, 1, 1, 0, 16, 20), (64, 128, 255, 1, 1, 0, 8, 10), (256, 96, 75, 1, 1, 0, 16, 20)]   # RGB conv0, other heads
 
 
 @pytest.mark.parametrize("geom", BIG)
