@@ -122,49 +122,62 @@ def _run_child(cmd, timeout):
         return -9, "timed out after %d s" % timeout
 
 
-def live_traffic(args):
-    """HBM bytes per launch, measured IN THIS RUN: two child runs of this script's single-lane pass under `rocprofv3 --pmc` (FETCH_SIZE and
-    WRITE_SIZE in separate passes, counters with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes), started before this
-    process touches the GPU.  Units and corrections of that guide: both counters are KiB of 64-byte fabric requests; on gfx950 FETCH_SIZE
-    reports half of the bytes of wide (16 B / lane) coalesced streaming reads, so it is doubled; WRITE_SIZE is exact for 16-byte-per-lane
-    streaming stores.  Launches are matched to the plan's ops by order (one lane, one batch in flight: deterministic).
-    Returns ({op name: bytes per launch}, note): ({}, why) when the profiler is not usable here."""
+ISSUE_COUNTERS = ("SQ_INSTS_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_LDS")
+SIMDS, PEAK_GHZ = 1024, 2.4
+
+
+def live_pmc(res, batch, dtype, frames, kmax, with_issue=False):
+    """Counters of every launch of a single-lane forward pass of that workload, measured IN THIS RUN: child runs of this script under
+    `rocprofv3 --pmc` (counters with --kernel-trace only; FETCH_SIZE and WRITE_SIZE in separate passes, as MI355X_MICROARCH.md's HBM section
+    prescribes; with_issue: a third pass with the issue-side SQ counters), started before this process touches the GPU.  Units and
+    corrections of that guide: FETCH_SIZE / WRITE_SIZE are KiB of 64-byte fabric requests; on gfx950 FETCH_SIZE reports half of the bytes of
+    wide (16 B / lane) coalesced streaming reads, so it is doubled; WRITE_SIZE is exact for 16-byte-per-lane streaming stores.  Launches
+    are matched to the plan's ops by order (one lane, one batch in flight: deterministic).
+    Returns ({op name: HBM bytes per launch}, {op name: {counter: value per launch}}, note): ({}, {}, why) when the profiler is not usable."""
     import csv
     import shutil
     import tempfile
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
-        return {}, "rocprofv3 not found"
+        return {}, {}, "rocprofv3 not found"
     work = tempfile.mkdtemp(prefix="yf_pmc_", dir="/tmp")
     vals = {}
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(work, counter)
-            cmd = [prof, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
+        passes = [("FETCH_SIZE",), ("WRITE_SIZE",)] + ([ISSUE_COUNTERS] if with_issue else [])
+        ops = None
+        for pi, counters in enumerate(passes):
+            d = os.path.join(work, "p%d" % pi)
+            cmd = [prof, "--pmc"] + list(counters) + ["--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
                    os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-variants", "--no-configs",
-                   "--no-live-traffic", "--no-train", "--in-flight", "1", "--lanes", "1", "--res", str(args.res), "--batch", str(args.batch), "--dtype", args.dtype,
-                   "--frames", args.frames, "--kmax", str(args.kmax), "--dump-ops", os.path.join(work, "ops.json")]
+                   "--no-live-traffic", "--no-train", "--no-extras", "--in-flight", "1", "--lanes", "1", "--res", str(res), "--batch", str(batch),
+                   "--dtype", dtype, "--frames", frames, "--kmax", str(kmax), "--dump-ops", os.path.join(work, "ops.json")]
             rc, tail = _run_child(cmd, 180)
             path = os.path.join(d, "p_counter_collection.csv")
             if rc != 0 or not os.path.exists(path):
-                return {}, "rocprofv3 --pmc %s child failed (rc %d): %s" % (counter, rc, tail.replace("\n", " | "))
+                return {}, {}, "rocprofv3 --pmc %s child failed (rc %d): %s" % (counters[0], rc, tail.replace("\n", " | "))
             with open(os.path.join(work, "ops.json")) as f:
                 ops = json.load(f)
-            with open(path) as f:
-                rows = [x for x in csv.DictReader(f) if x["Counter_Name"] == counter and "yf::" in x["Kernel_Name"]
-                        and "post_kernel" not in x["Kernel_Name"] and "nms_sorted" not in x["Kernel_Name"]]
-            rows.sort(key=lambda x: int(x["Dispatch_Id"]))
             n = len(ops)
-            if n == 0 or len(rows) < n or len(rows) % n:
-                return {}, "PMC rows (%d) do not divide into forward passes of %d launches" % (len(rows), n)
-            passes = len(rows) // n
-            vals[counter] = [sum(float(rows[q * n + i]["Counter_Value"]) for q in range(passes)) / passes for i in range(n)]
-        out = {}
+            by = {}
+            with open(path) as f:   # (kernels instantiated on _Float16 come out mangled: the demangler does not know DF16_)
+                for x in csv.DictReader(f):
+                    k = x["Kernel_Name"]
+                    if ("yf::" in k or k.startswith("_ZN2yf")) and "post_kernel" not in k and "nms_sorted" not in k and "spin" not in k:
+                        by.setdefault(int(x["Dispatch_Id"]), {})[x["Counter_Name"]] = float(x["Counter_Value"])
+            ids = sorted(by)
+            if n == 0 or len(ids) < n or len(ids) % n:
+                return {}, {}, "PMC rows (%d) do not divide into forward passes of %d launches" % (len(ids), n)
+            np_ = len(ids) // n
+            for c in counters:
+                vals[c] = [sum(by[ids[q * n + i]].get(c, 0.0) for q in range(np_)) / np_ for i in range(n)]
+        traffic, issue = {}, {}
         for i, o in enumerate(ops):
-            out[o["name"]] = out.get(o["name"], 0.0) + vals["FETCH_SIZE"][i] * 1024 * 2 + vals["WRITE_SIZE"][i] * 1024
-        return {k: int(round(v)) for k, v in out.items()}, None
+            traffic[o["name"]] = traffic.get(o["name"], 0.0) + vals["FETCH_SIZE"][i] * 1024 * 2 + vals["WRITE_SIZE"][i] * 1024
+            if with_issue:
+                issue[o["name"]] = {c: vals[c][i] for c in ISSUE_COUNTERS}
+        return {k: int(round(v)) for k, v in traffic.items()}, issue, None
     except Exception as e:   # the profiler is evidence, not product: never fail the benchmark over it
-        return {}, "live PMC pass failed: %r" % (e,)
+        return {}, {}, "live PMC pass failed: %r" % (e,)
     finally:
         shutil.rmtree(work, ignore_errors=True)
 
@@ -288,9 +301,14 @@ def self_launch(n_gpus):
     return subprocess.call(cmd, env=env)
 
 
-def launch_roofline(o, dtype, traffic):
+def launch_roofline(o, dtype, traffic, issue=None):
     """Physical roof of one launch.  fp32: MFMA and vector FMAs share one issue rate on this part (measured), so the
-    floor is (all flops) / 157.3 TF.  fp16: the matrix cores run beside the vector ALU, the floor is the larger of the two."""
+    floor is (all flops) / 157.3 TF.  fp16: the matrix cores run beside the vector ALU, the floor is the larger of the two.
+    issue (optional): the launch's issue-side counters from live_pmc().  Then `bound` is COUNTER-BACKED instead of the larger of two flop
+    ratios: the share of the launch's time the VALU needs to issue its instructions (SQ_INSTS_VALU x 4 cycles per SIMD -- address math,
+    operand splitting and epilogues included, not only FMAs), the matrix pipe's busy share (SQ_VALU_MFMA_BUSY_CYCLES), the HBM share
+    (counter bytes at 8 TB/s) and the share its waves are parked at s_waitcnt / barriers (SQ_WAIT_ANY / SQ_WAVE_CYCLES): the largest
+    pipe names the bound if it holds at least half of the time or more than the parked share, else the launch is latency-bound."""
     t = o["ms"] * 1e-3
     dtype = o.get("kernel_dtype", dtype)   # a f16x3 engine runs the launches without a split-operand kernel in exact fp32
     if dtype != "f32":
@@ -311,6 +329,32 @@ def launch_roofline(o, dtype, traffic):
     hbm_bound = r["hbm_gbs"] is not None and r["hbm_gbs"] > 0.5 * HBM_STREAM_GBS
     r["bound"] = "hbm" if hbm_bound else ("mfma" if on_mfma else "valu")
     r["frac"] = r["hbm_frac"] if hbm_bound else r["compute_frac"]
+    if issue:
+        sec = SIMDS * PEAK_GHZ * 1e9
+        c = {"valu": issue["SQ_INSTS_VALU"] * 4 / sec / t, "mfma": issue["SQ_VALU_MFMA_BUSY_CYCLES"] / sec / t,
+             "hbm": r["hbm_frac"] or 0.0, "lds": issue["SQ_ACTIVE_INST_LDS"] / max(issue["SQ_WAVE_CYCLES"], 1.0)}
+        parked = issue["SQ_WAIT_ANY"] / max(issue["SQ_WAVE_CYCLES"], 1.0)
+        if dtype == "f32":     # fp32 MFMAs and VALU instructions share the issue slots: one pipe
+            c = {"mfma": c["valu"] + c["mfma"], "hbm": c["hbm"], "lds": c["lds"]}
+        pipe = max(c, key=c.get)
+        r["counters"] = dict({k + "_frac": round(v, 3) for k, v in c.items()}, parked_frac=round(parked, 3))
+        r["bound"] = pipe if (c[pipe] >= 0.5 or c[pipe] >= parked) else "latency"
+        # `frac` stays a ROOFLINE fraction -- useful flops (or bytes) over the peak of the pipe that binds -- the counter shares above are
+        # the evidence for WHICH pipe; a VALU-bound launch is priced by its vector flops against the fp32 vector peak
+        if r["bound"] == "valu":
+            r["peak_tf"], r["achieved_tf"] = FP32_PEAK_TF, o["valu_flops"] / t / 1e12
+            r["frac"] = r["achieved_tf"] / FP32_PEAK_TF
+        elif r["bound"] == "mfma" and dtype != "f32":
+            issued = o["mfma_flops"] * (3 if dtype == "f16x3" else 1)
+            r["peak_tf"], r["achieved_tf"] = F16_MFMA_PEAK_TF, issued / t / 1e12
+            r["frac"] = r["achieved_tf"] / F16_MFMA_PEAK_TF
+        elif r["bound"] == "hbm":
+            r["frac"] = r["hbm_frac"]
+        elif r["bound"] in ("latency", "lds"):
+            r["frac"] = r["compute_frac"]
+            r["bound_note"] = "no pipe holds half of the launch's time (parked share %.2f): frac is the compute floor over the duration" % parked
+        else:
+            r["frac"] = r["compute_frac"]
     return r
 
 
@@ -348,6 +392,9 @@ def main():
                          "roofline.traffic then comes from profiles/pmc_traffic.json if it was taken at this build, else null")
     ap.add_argument("--no-train", action="store_true", help="skip the training-iteration records (the `training` array)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other single-GPU BASELINE.json configurations (the `configs` array)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra records of the default run: `fixtures` (the 20 bundled frames tiled to the batch), `u8` (the same "
+                         "batch entering as u8 through the fused pre-process), `batch1` (latency of one frame), `exchange_rehearsal`")
     ap.add_argument("--dump-ops", default=None, help="write the launch names of one forward pass to this JSON file")
     ap.add_argument("--dump-records", default=None,
                     help="rank 0 writes the LAST step's detection records of all frames (N > 1: as gathered over RCCL) to this .npz")
@@ -371,8 +418,13 @@ def main():
     if profiled:
         args.no_live_traffic = True
         live_note = "this process runs under a profiler: no nested counter passes"
+    live_issue, cfg2_pmc = {}, {}
+    default_wl = args.res == 256 and args.dtype == "f32" and not args.dense and args.frames == "noise"
     if world == 1 and not args.no_live_traffic and not args.dense and not args.exchange_at_1:
-        live, live_note = live_traffic(args)
+        live, live_issue, live_note = live_pmc(args.res, args.batch, args.dtype, args.frames, args.kmax, with_issue=True)
+        if not args.no_configs and default_wl:     # BASELINE configs[2]: HBM bytes and issue counters of the 640x512 fp16-pipe passes
+            for dt in ("f16x3", "f16"):
+                cfg2_pmc[dt] = live_pmc(512, 128, dt, "noise", 64, with_issue=True)
 
     train_pmc = {}
     if world == 1 and not args.no_train and not args.no_live_traffic and args.res == 256 and args.dtype == "f32" and not args.dense:
@@ -456,7 +508,7 @@ def main():
 
     def forward(m):
         with torch.no_grad():
-            pred = m(cur["x"])
+            pred = m.forward_u8(cur["x"], io["input_shape"]) if cur["x"].dtype == torch.uint8 else m(cur["x"])
         if cur["syn"] is not None:   # the net's own logits on noise are ~no detections: the synthetic field replaces them
             pred = (pred[0] * 0 + cur["syn"][0], pred[1] * 0 + cur["syn"][1])
         return pred
@@ -468,10 +520,11 @@ def main():
         steps are issued round-robin on `depth` streams, each with its own engine (yolo_fastest_amd.BatchPipeline): a batch's late,
         per-frame stages run beside the next batch's early, machine-filling ones.  Every step -- and every exchange -- completes
         inside the timed region (device synchronisation + barrier on both sides).  Returns (seconds, last step's records)."""
-        pipe = yf.BatchPipeline(m, p, depth=depth, kmax=cur["kmax"], lanes=m.lanes, branches=m.branches) if depth > 1 else None
+        # exchange: the post-process writes ONE packed record block per batch (yf_decode_nms_packed) and the all-gather sends that buffer
+        pipe = yf.BatchPipeline(m, p, depth=depth, kmax=cur["kmax"], lanes=m.lanes, branches=m.branches, packed=bool(exchange)) if depth > 1 else None
         if pipe is not None:
             pipe.tune_streams(cur["x"])      # untimed: which streams the batches overlap best on (pipeline.BatchPipeline.tune_streams)
-        gather = (lambda out: yfd.all_gather_detections_async({k: out[k] for k in REC}, cur["n_total"])) if exchange else None
+        gather = (lambda out: yfd.all_gather_detections_async(out, cur["n_total"])) if exchange else None
 
         def run(n):
             last, pend = None, []
@@ -481,7 +534,7 @@ def main():
                     if gather is not None:
                         pend.append(last.extra)
                 else:
-                    raw = p.detect_raw(forward(m), kmax=cur["kmax"])
+                    raw = p.detect_raw(forward(m), kmax=cur["kmax"], packed=bool(exchange))
                     last = raw
                     if gather is not None:
                         pend.append(gather(raw))
@@ -497,20 +550,21 @@ def main():
                 return last.synchronize()
             return last
 
+        grouped = multi or bool(exchange)
         run(warmup)
         torch.cuda.synchronize(dev)
-        if multi:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         raw = run(steps)
         torch.cuda.synchronize(dev)
-        if multi:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
         tt = torch.tensor([el], dtype=torch.float64, device=dev)
-        if multi:
+        if grouped:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item()), raw
 
@@ -519,6 +573,20 @@ def main():
             return False
         valid = torch.arange(a["cls"].shape[1], device=dev)[None, :] < a["counts"][:, None]
         return all(torch.equal(a[k][valid], b[k][valid]) for k in ("boxes", "cls", "src"))
+
+    def post_mean_ms(m, p, kmax, reps=10):
+        """decode + sort + NMS of one batch: mean of `reps` warmed repetitions on the same logits (HIP events on the launch stream)."""
+        pred = forward(m)
+        for _ in range(3):
+            p.detect_raw(pred, kmax=kmax)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(reps):
+            p.detect_raw(pred, kmax=kmax)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / reps
 
     model, post = make(args.dtype, lanes, branches)
     elapsed, raw = timed(model, post, in_flight, args.steps, args.warmup, multi)
@@ -562,6 +630,133 @@ def main():
                    "detections_identical_to_f32_on_this_batch": bool(same_detections(raw, raw2))}
         del m2, p2
 
+    # What already exists, in front of the driver (same process, after the headline, never `value`):
+    extras = None
+    if world == 1 and not args.no_extras and default_wl and args.batch == 256 and not args.exchange_at_1:
+        extras = {}
+        saved = dict(cur)
+
+        def stem_us(m, xin):
+            return round(1e3 * m.profile(xin, reps=5)[0]["ms"], 2)
+
+        # (a) SURVEY.md 8(d).2 "realistic": configs[1] on the reference's 20 bundled frames tiled to 256 -- every frame has >= 1 box, so
+        #     decode + sort + NMS do real work (the noise frames of the headline give ~0.02 survivors per frame)
+        _, xf, _ = workload(256, args.batch, "fixtures", False)
+        cur.update(x=xf, syn=None)
+        ef, rawf = timed(model, post, in_flight, args.steps, args.warmup, False)
+        cf = rawf["counts"].cpu().numpy()
+        extras["fixtures"] = {"workload": "configs[1] on the reference's 20 bundled test_data frames tiled to the batch (SURVEY.md 8(d).2 'realistic')",
+                              "value": round(args.batch * args.steps / ef, 1), "unit": "frames/s", "ms_per_step": round(1e3 * ef / args.steps, 4),
+                              "steps": args.steps, "warmup": args.warmup, "in_flight": in_flight,
+                              "survivors_per_frame_mean": round(float(np.clip(cf, 0, None).mean()), 3),
+                              "frames_with_a_detection": int((cf > 0).sum()), "post_ms": round(post_mean_ms(m1, p1, args.kmax), 4)}
+        # (b) SURVEY.md 8(f).1: the same noise batch entering as u8 -- Detect_YOLO.__pre_process's arithmetic (detect.py:107-129) fused
+        #     into the stem's loads (yf_forward_u8) -> decode -> NMS; 1 byte per pixel read instead of 4
+        g8 = torch.Generator(device="cpu").manual_seed(rank)
+        u8 = torch.randint(0, 256, (args.batch, H, W), generator=g8, dtype=torch.uint8).to(dev)      # the headline's frames before (u8 - 128) / 255
+        cur.update(x=u8, syn=None)
+        eu, rawu = timed(model, post, in_flight, args.steps, args.warmup, False)
+        with torch.no_grad():
+            hu = model.forward_u8(u8, io["input_shape"])
+            hx = model(saved["x"])
+        t_u8 = []
+        for _ in range(5):   # the stem launch alone, u8 input: HIP events around one pass's first launch are not exposed for this entry,
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # so time whole single-lane passes
+            torch.cuda.synchronize(dev)
+            e0.record(); m1.forward_u8(u8, io["input_shape"]); e1.record()
+            torch.cuda.synchronize(dev)
+            t_u8.append(e0.elapsed_time(e1))
+        t_f32 = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            e0.record(); m1(saved["x"]); e1.record()
+            torch.cuda.synchronize(dev)
+            t_f32.append(e0.elapsed_time(e1))
+        extras["u8"] = {"workload": "configs[1]'s frames entering as uint8 [256,256,320]: pre-process fused into the first kernel's loads "
+                                    "(yf_forward_u8, detect.py:107-129) -> decode -> NMS",
+                        "value": round(args.batch * args.steps / eu, 1), "unit": "frames/s", "ms_per_step": round(1e3 * eu / args.steps, 4),
+                        "steps": args.steps, "warmup": args.warmup, "in_flight": in_flight,
+                        "heads_bit_identical_to_the_f32_input_path": bool(torch.equal(hu[0], hx[0]) and torch.equal(hu[1], hx[1])),
+                        "detections_identical_to_the_headline": bool(same_detections(raw, rawu)),
+                        "forward_ms_two_lanes": {"u8_input": round(sorted(t_u8)[2], 4), "f32_input": round(sorted(t_f32)[2], 4)},
+                        "stem_launch_us": {"u8_input": stem_us(model, u8), "f32_input": stem_us(model, saved["x"])}}
+        cur.clear(); cur.update(saved)
+        # (c) one frame at a time, the reference's actual calling pattern (detect.py:146-171: model(img), then the post-process, each
+        #     followed by a host synchronisation): median over 200 frames, eager launches; and the same pass replayed as a HIP graph
+        #     (single lane, small head in line: a graph without parallel branches)
+        mb, pb = make(args.dtype, 1, 0)
+        x1 = saved["x"][:1].contiguous()
+        tm, tp = [], []
+        with torch.no_grad():
+            for i in range(220):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                pred = mb(x1)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                pb.detect_raw(pred, kmax=args.kmax)
+                torch.cuda.synchronize(dev)
+                t2 = time.perf_counter()
+                if i >= 20:
+                    tm.append(1e3 * (t1 - t0)); tp.append(1e3 * (t2 - t1))
+        med = lambda v: sorted(v)[len(v) // 2]
+        b1 = {"workload": "one 320x256 frame per call, model then post-process, host-synchronised after each (detect.py:146-171), 200 frames",
+              "eager": {"model_ms": round(med(tm), 4), "post_ms": round(med(tp), 4), "total_ms": round(med([a + b for a, b in zip(tm, tp)]), 4)}}
+        try:
+            with torch.no_grad():
+                sg = torch.cuda.Stream()
+                sg.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(sg):
+                    pb.detect_raw_from_input(x1, kmax=args.kmax)
+                torch.cuda.current_stream().wait_stream(sg)
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gph):
+                    gout = pb.detect_raw_from_input(x1, kmax=args.kmax)
+                tg = []
+                for i in range(220):
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    gph.replay()
+                    torch.cuda.synchronize(dev)
+                    if i >= 20:
+                        tg.append(1e3 * (time.perf_counter() - t0))
+                ref1 = pb.detect_raw_from_input(x1, kmax=args.kmax)
+                gph.replay()
+                torch.cuda.synchronize(dev)
+                b1["graph_replay"] = {"total_ms": round(med(tg), 4), "what": "yf_detect (model + decode + NMS) captured once, one hipGraphLaunch per frame",
+                                      "identical_to_eager": bool(torch.equal(gout["counts"], ref1["counts"]) and torch.equal(gout["head_large"], ref1["head_large"]))}
+                del gph
+        except Exception as ex:     # evidence, not product
+            b1["graph_replay"] = {"error": repr(ex)[:200]}
+        extras["batch1"] = b1
+        del mb, pb
+        # (d) the N > 1 code path at one rank: a 1-rank RCCL group and the all-gather of every step's packed records -- its frames/s
+        #     beside the plain figure is the per-step cost of the exchange machinery (record block + collective launch + wait)
+        try:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if "MASTER_ADDR" not in os.environ:
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
+            dist.init_process_group("nccl", device_id=dev)
+            ex_e, ex_raw = timed(model, post, in_flight, args.steps, args.warmup, True)
+            pl_e, _ = timed(model, post, in_flight, args.steps, args.warmup, False)
+            gathered = cur.get("gathered")
+            extras["exchange_rehearsal"] = {
+                "workload": "configs[1] with a 1-rank RCCL group: every step's packed record block (yf_decode_nms_packed) all-gathered "
+                            "(all_gather_into_tensor), waits pipelined like N > 1",
+                "value": round(args.batch * args.steps / ex_e, 1), "unit": "frames/s", "ms_per_step": round(1e3 * ex_e / args.steps, 4),
+                "plain_value_same_loop": round(args.batch * args.steps / pl_e, 1), "plain_ms_per_step": round(1e3 * pl_e / args.steps, 4),
+                "exchange_overhead_ms_per_step": round(1e3 * (ex_e - pl_e) / args.steps, 4),
+                "exchange_overhead_frac_of_step": round((ex_e - pl_e) / pl_e, 4),
+                "record_bytes_per_step": int(args.batch * (1 + 8 * args.kmax) * 4),
+                "gathered_equals_local": bool(gathered is not None and same_detections(ex_raw, gathered))}
+            dist.destroy_process_group()
+        except Exception as ex:
+            extras["exchange_rehearsal"] = {"error": repr(ex)[:200]}
+        cur.clear(); cur.update(saved)
+
     # The other single-GPU configurations BASELINE.json names, measured in the SAME process after the headline (never `value`):
     #   configs[2]  640x512 batch 128 on the fp16 MFMA path: `f16x3` (split operands: the variant that meets the stated 2e-2 on logits)
     #               and `f16` (fp16 storage, single operands: the throughput mode, 8.5e-2) beside it, each checked against fp32 here;
@@ -571,15 +766,34 @@ def main():
         extra_configs = []
         saved = dict(cur)
 
-        def dominant(m):
+        def dominant(m, pmc=None):
+            """Roofline object of the launch that takes longest.  pmc = (traffic, issue, note) of live_pmc() for this workload: then the
+            bound is counter-backed (launch_roofline) and `traffic` / `hbm_frac` are this run's counter bytes; `pass_binding` sums the
+            shares over all launches of the pass -- what binds the configuration as a whole."""
             ops_ = m.profile(cur["x"], reps=3)
+            tr, iss, note = pmc if pmc else ({}, {}, None)
             for o in ops_:
-                o["roof"] = launch_roofline(o, m.precision, None)
+                o["roof"] = launch_roofline(o, m.precision, tr.get(o["name"]), iss.get(o["name"]))
             d = max(ops_, key=lambda o: o["ms"])
-            return {"kernel": d["name"] if len(d["name"]) < 48 else d["name"][:20] + ".." + d["name"][-24:], "launch_ms": round(d["ms"], 4),
-                    "bound": d["roof"]["bound"], "achieved": round(d["roof"]["achieved_tf"], 2), "peak": d["roof"]["peak_tf"],
-                    "unit": "TFLOP/s", "frac": round(d["roof"]["compute_frac"], 4), "traffic": None,
+            r = d["roof"]
+            unit = "GB/s" if r["bound"] == "hbm" else "TFLOP/s"
+            out_ = {"kernel": d["name"] if len(d["name"]) < 48 else d["name"][:20] + ".." + d["name"][-24:], "launch_ms": round(d["ms"], 4),
+                    "bound": r["bound"], "achieved": round(r["hbm_gbs"] if r["bound"] == "hbm" else r["achieved_tf"], 2),
+                    "peak": HBM_PEAK_GBS if r["bound"] == "hbm" else r["peak_tf"], "unit": unit, "frac": round(r["frac"], 4),
+                    "traffic": tr.get(d["name"]), "hbm_frac": None if r["hbm_frac"] is None else round(r["hbm_frac"], 4),
                     "launches": len(ops_), "sum_of_launch_ms": round(sum(o["ms"] for o in ops_), 4)}
+            if "counters" in r:
+                out_["counters"] = r["counters"]
+                tot = sum(o["ms"] for o in ops_)
+                keys = [k for k in ("valu_frac", "mfma_frac", "hbm_frac", "lds_frac", "parked_frac") if all(k in o["roof"]["counters"] for o in ops_)]
+                out_["pass_binding"] = {k: round(sum(o["roof"]["counters"][k] * o["ms"] for o in ops_) / tot, 3) for k in keys}
+                out_["pass_binding"]["hbm_bytes"] = int(sum(tr.get(o["name"], 0) for o in ops_))
+                out_["pass_binding"]["launches_by_bound"] = {b: sum(1 for o in ops_ if o["roof"]["bound"] == b) for b in sorted({o["roof"]["bound"] for o in ops_})}
+                out_["bound_source"] = ("counters measured in this run (rocprofv3 --pmc child passes: FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU, "
+                                        "SQ_VALU_MFMA_BUSY_CYCLES, SQ_WAIT_ANY / SQ_WAVE_CYCLES)")
+            elif note:
+                out_["traffic_note"] = note
+            return out_
 
         io5, x5, _ = workload(512, 128, "noise", False)
         cur.update(x=x5, syn=None, kmax=64, n_total=128)
@@ -600,7 +814,7 @@ def main():
                 "steps": args.steps, "warmup": args.warmup, "in_flight": 2, "lanes": 1,
                 "max_abs_logit_diff_vs_f32_on_this_batch": round(max(float((ref_heads[0] - hc[0]).abs().max()), float((ref_heads[1] - hc[1]).abs().max())), 6),
                 "detections_identical_to_f32_on_this_batch": bool(same_detections(ref_raw, rawc)),
-                "roofline": dominant(mc)})
+                "roofline": dominant(mc, cfg2_pmc.get(dt))})
             del mc, pc
         del ref_m, ref_p
         io5, x5, syn5 = workload(512, 64, "noise", True)
@@ -609,11 +823,7 @@ def main():
             mc, pc = make(dt, 2, 1, io5, 512)
             ec, rawc = timed(mc, pc, 1, args.steps, args.warmup, False)
             again = pc.detect_raw(forward(mc), kmax=1024)           # the same records from a second, untimed evaluation
-            evs = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            pred = forward(mc)
-            torch.cuda.synchronize(dev)
-            evs[0].record(); pc.detect_raw(pred, kmax=1024); evs[1].record()
-            torch.cuda.synchronize(dev)
+            post64 = post_mean_ms(mc, pc, 1024)                     # mean of 10 warmed repetitions on the same logits
             cnt = rawc["counts"].cpu().numpy()
             cand = float(((syn5[0][:, 4::8] > 0).sum() + (syn5[1][:, 4::8] > 0).sum()).item()) / 64   # sigmoid(t) > 0.5 <=> t > 0
             extra_configs.append({
@@ -622,7 +832,7 @@ def main():
                 "dtype": dt, "value": round(64 * args.steps / ec, 1), "unit": "frames/s", "ms_per_step": round(1e3 * ec / args.steps, 4),
                 "steps": args.steps, "warmup": args.warmup, "in_flight": 1, "lanes": 2,
                 "candidates_per_frame": round(cand, 1), "survivors_per_frame": round(float(np.clip(cnt, 0, None).mean()), 1),
-                "frames_over_kmax_or_failed": int((cnt < 0).sum()), "post_ms_per_64_frames": round(evs[0].elapsed_time(evs[1]), 4),
+                "frames_over_kmax_or_failed": int((cnt < 0).sum()), "post_ms_per_64_frames": round(post64, 4),
                 "detections_identical_on_re_evaluation": bool(same_detections(rawc, again)),
                 "roofline": dominant(mc)})
             del mc, pc
@@ -665,7 +875,7 @@ def main():
         else:
             traffic_note = "profiles/pmc_traffic.json not found" + ("; live PMC: " + live_note if live_note else "")
         for o in ops:
-            o["roof"] = launch_roofline(o, args.dtype, traffic.get(o["name"]))
+            o["roof"] = launch_roofline(o, args.dtype, traffic.get(o["name"]), live_issue.get(o["name"]) if live else None)
         dom = max(ops, key=lambda o: o["ms"])
         dr = dom["roof"]
         bytes_sum = sum(o["algorithmic_bytes"] for o in ops) / args.batch
@@ -735,6 +945,8 @@ def main():
             out["variants"] = [variant]
         if extra_configs is not None:
             out["configs"] = extra_configs
+        if extras is not None:
+            out.update(extras)      # fixtures, u8, batch1, exchange_rehearsal
         if world == 1 and not args.no_train and args.res == 256 and args.dtype == "f32" and not args.dense and args.frames == "noise":
             del model, post
             torch.cuda.empty_cache()

@@ -114,6 +114,13 @@ int yf_decode_nms(yf_handle h, const float *d_head_large, const float *d_head_sm
                   double nms_thres, const double *anchors, int origin_h, int origin_w, int K_max, int32_t *d_boxes,
                   float *d_scores, int32_t *d_cls, int32_t *d_src, int32_t *d_counts, void *stream);
 
+/* The same with ONE output: d_records int32 [N, 1 + 8 K_max], one row per frame =
+ *   count | boxes x1,y1,x2,y2 (4 K_max) | conf, cls_score as float32 bit patterns (2 K_max) | cls (K_max) | src (K_max)
+ * -- the record block the multi-GPU exchange sends (one all-gather of fixed-capacity records per step): the collective
+ * takes the kernel's own output buffer, nothing is packed or copied on the way.  Entries beyond `count` are not written. */
+int yf_decode_nms_packed(yf_handle h, const float *d_head_large, const float *d_head_small, int N, double conf_thres, double nms_thres,
+                         const double *anchors, int origin_h, int origin_w, int K_max, int32_t *d_records, void *stream);
+
 /* YOLO_post_process.non_maxium_supression (detect.py:69-84) on its own: d_boxes int32 [n,4] is ONE class's
  * list already sorted by conf descending.  d_suppressor int32 [n] receives -1 for a kept box, else the index
  * of the kept box that removed it (-2 in every entry: the reference's ZeroDivisionError). */
@@ -247,6 +254,11 @@ int yf_detect(yf_handle h, const float *d_x, int N, double conf_thres, double nm
               int32_t *d_src, int32_t *d_counts, float *d_head_large, float *d_head_small, void *d_workspace,
               size_t workspace_bytes, void *stream);
 
+/* yf_detect with the packed record block of yf_decode_nms_packed as its output. */
+int yf_detect_packed(yf_handle h, const float *d_x, int N, double conf_thres, double nms_thres, const double *anchors, int origin_h,
+                     int origin_w, int K_max, int32_t *d_records, float *d_head_large, float *d_head_small, void *d_workspace,
+                     size_t workspace_bytes, void *stream);
+
 /* Detect_YOLO.__pre_process arithmetic on device: d_u8 uint8 [N,src_h,src_w] gray frames ->
  * d_x float32 [N,1,H,W] = (v-128)/255 where v is the pixel itself (src == net size) or the 2x2
  * box mean (a+b+c+d+2)>>2 (src == 2x net size).  Other ratios: YF_E_INVALID.
@@ -275,6 +287,9 @@ int yf_op_dtype(yf_handle h, int op, int *kernel_dtype);
  * the pass is done and returns each launch's duration in ms in op_ms[yf_num_launches]. */
 int yf_profile_forward(yf_handle h, const float *d_x, int N, void *d_workspace, size_t workspace_bytes, void *stream,
                        float *op_ms, int n_ops);
+/* the same pass from u8 frames (yf_forward_u8's input conventions): the first launch then includes the fused pre-process */
+int yf_profile_forward_u8(yf_handle h, const uint8_t *d_u8, int N, int src_h, int src_w, void *d_workspace, size_t workspace_bytes,
+                          void *stream, float *op_ms, int n_ops);
 int yf_streams_overlap(yf_handle h, void *stream_a, void *stream_b, int *overlap);
                                                    /* do two HIP streams run concurrently?  The runtime multiplexes streams onto a few
                                                       hardware queues; two on one queue execute strictly in issue order (measured: -30 %

@@ -38,6 +38,19 @@ def test_pack_unpack_roundtrip():
         assert torch.equal(raw[k], back[k]), k
 
 
+def test_packed_record_block_is_what_the_exchange_sends():
+    """The kernel's packed output (yf_decode_nms_packed: one int32 row per frame) has exactly pack_records' layout, its five result
+    tensors are views of it (YOLO_post_process.record_views), and the exchange takes the block itself."""
+    from yolo_fastest_amd import YOLO_post_process
+    raw = _fake_raw(6, 9, 1)
+    rec = yfd.pack_records(raw)
+    v = YOLO_post_process.record_views(rec, 9)
+    assert v["records"] is rec and all(torch.equal(v[k], raw[k]) for k in raw)
+    assert all(v[k].untyped_storage().data_ptr() == rec.untyped_storage().data_ptr() for k in raw)      # views, not copies
+    u = yfd.unpack_records(rec, 9)
+    assert all(torch.equal(u[k], raw[k]) for k in raw) and u["records"] is rec
+
+
 def _worker(rank, world, port, n_total, kmax, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -49,6 +62,11 @@ def _worker(rank, world, port, n_total, kmax, q):
     pending = yfd.all_gather_detections_async(mine, n_total)   # the overlapped form bench.py uses
     got2 = pending.wait()
     assert all(torch.equal(got[k], got2[k]) for k in got)
+    # zero-copy form: the shard's records already are one packed block (what the post-process writes with packed=True)
+    from yolo_fastest_amd import YOLO_post_process
+    packed = YOLO_post_process.record_views(yfd.pack_records(mine), kmax)
+    got3 = yfd.all_gather_detections_async(packed, n_total).wait()
+    assert all(torch.equal(got[k], got3[k]) for k in got)
     ok = all(torch.equal(got[k], full[k]) for k in full)
     q.put((rank, ok))
     dist.destroy_process_group()

@@ -29,6 +29,10 @@ _SIGS = {
     "yf_decode_nms": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_double, _c.c_double,
                                  _c.POINTER(_c.c_double), _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p,
                                  _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "yf_decode_nms_packed": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_double, _c.c_double, _c.POINTER(_c.c_double), _c.c_int,
+                                        _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    "yf_detect_packed": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_double, _c.c_double, _c.POINTER(_c.c_double), _c.c_int, _c.c_int,
+                                    _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "yf_detect": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_double, _c.c_double, _c.POINTER(_c.c_double),
                              _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                              _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
@@ -94,6 +98,8 @@ _SIGS = {
     "yf_op_dtype": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_int)]),
     "yf_profile_forward": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_size_t, _c.c_void_p,
                                       _c.POINTER(_c.c_float), _c.c_int]),
+    "yf_profile_forward_u8": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_size_t, _c.c_void_p,
+                                         _c.POINTER(_c.c_float), _c.c_int]),
     "yf_set_chunk": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "yf_set_fusion": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "yf_streams_overlap": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_int)]),

@@ -679,8 +679,11 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
             }
             yf::PostArgs a = *post;
             a.head_large += (size_t)f0 * e->head_l_elems; a.head_small += (size_t)f0 * e->head_s_elems;
-            a.boxes += (size_t)f0 * a.kmax * 4; a.scores += (size_t)f0 * a.kmax * 2;
-            a.cls += (size_t)f0 * a.kmax; a.src += (size_t)f0 * a.kmax; a.counts += f0;
+            if (a.records) a.records += (size_t)f0 * (1 + 8 * (size_t)a.kmax);
+            else {
+                a.boxes += (size_t)f0 * a.kmax * 4; a.scores += (size_t)f0 * a.kmax * 2;
+                a.cls += (size_t)f0 * a.kmax; a.src += (size_t)f0 * a.kmax; a.counts += f0;
+            }
             const int rc = yf::launch_post(a, n, sl);
             if (rc == -1) return fail(YF_E_INVALID, "frame of %dx%d has too many cells for the on-chip NMS (limit 8191 cells / 160 KiB LDS)", e->H, e->W);
             if (rc) return fail(YF_E_HIP, "hipFuncSetAttribute(post_kernel) failed");
@@ -1005,6 +1008,7 @@ static yf::PostArgs make_post_args(yf_handle h, const float* d_hl, const float* 
     a.adj_w = adj ? (double)origin_w / h->W : 0.0;
     a.kmax = K_max;
     a.boxes = d_boxes; a.scores = d_scores; a.cls = d_cls; a.src = d_src; a.counts = d_counts;
+    a.records = nullptr;
     return a;
 }
 
@@ -1017,6 +1021,21 @@ int yf_decode_nms(yf_handle h, const float* d_hl, const float* d_hs, int N, doub
     HIP_OK(hipSetDevice(h->device));
     const yf::PostArgs a = make_post_args(h, d_hl, d_hs, conf_thres, nms_thres, anchors, origin_h, origin_w, K_max, d_boxes, d_scores,
                                           d_cls, d_src, d_counts);
+    int rc = yf::launch_post(a, N, (hipStream_t)stream);
+    if (rc == -1) return fail(YF_E_INVALID, "frame of %dx%d has too many cells for the on-chip NMS (limit 8191 cells / 160 KiB LDS)", h->H, h->W);
+    if (rc) return fail(YF_E_HIP, "hipFuncSetAttribute(post_kernel) failed");
+    HIP_OK(hipGetLastError());
+    return YF_OK;
+}
+
+int yf_decode_nms_packed(yf_handle h, const float* d_hl, const float* d_hs, int N, double conf_thres, double nms_thres, const double* anchors,
+                         int origin_h, int origin_w, int K_max, int32_t* d_records, void* stream)
+{
+    if (!h || !d_hl || !d_hs || !anchors || !d_records || N <= 0 || K_max <= 0)
+        return fail(YF_E_INVALID, "yf_decode_nms_packed: null pointer or non-positive size");
+    HIP_OK(hipSetDevice(h->device));
+    yf::PostArgs a = make_post_args(h, d_hl, d_hs, conf_thres, nms_thres, anchors, origin_h, origin_w, K_max, nullptr, nullptr, nullptr, nullptr, nullptr);
+    a.records = d_records;
     int rc = yf::launch_post(a, N, (hipStream_t)stream);
     if (rc == -1) return fail(YF_E_INVALID, "frame of %dx%d has too many cells for the on-chip NMS (limit 8191 cells / 160 KiB LDS)", h->H, h->W);
     if (rc) return fail(YF_E_HIP, "hipFuncSetAttribute(post_kernel) failed");
@@ -1160,6 +1179,24 @@ int yf_detect(yf_handle h, const float* d_x, int N, double conf_thres, double nm
     return YF_OK;
 }
 
+int yf_detect_packed(yf_handle h, const float* d_x, int N, double conf_thres, double nms_thres, const double* anchors, int origin_h,
+                     int origin_w, int K_max, int32_t* d_records, float* d_hl, float* d_hs, void* ws, size_t ws_bytes, void* stream)
+{
+    if (!h) return fail(YF_E_INVALID, "yf_detect_packed: null handle");
+    size_t chain = ((h->frame_floats_max() * (size_t)chunk_frames(h, N) * h->lanes * h->esz()) + 255) & ~(size_t)255;
+    size_t heads = (h->head_l_elems + h->head_s_elems) * (size_t)N * sizeof(float);
+    if (!ws || ws_bytes < chain + ((d_hl && d_hs) ? 0 : heads)) return fail(YF_E_WORKSPACE, "workspace too small");
+    float* hl = d_hl ? d_hl : reinterpret_cast<float*>(static_cast<char*>(ws) + chain);
+    float* hs = d_hs ? d_hs : reinterpret_cast<float*>(static_cast<char*>(ws) + chain) + h->head_l_elems * (size_t)N;
+    if (!anchors || !d_records || N <= 0 || K_max <= 0) return fail(YF_E_INVALID, "yf_detect_packed: null pointer or non-positive size");
+    yf::PostArgs pa = make_post_args(h, hl, hs, conf_thres, nms_thres, anchors, origin_h, origin_w, K_max, nullptr, nullptr, nullptr, nullptr, nullptr);
+    pa.records = d_records;
+    int rc = run_forward(h, d_x, N, hl, hs, ws, chain, (hipStream_t)stream, nullptr, nullptr, 0, nullptr, nullptr, 0, &pa);
+    if (rc) return rc;
+    HIP_OK(hipGetLastError());
+    return YF_OK;
+}
+
 int yf_preprocess_u8(yf_handle h, const uint8_t* d_u8, int N, int src_h, int src_w, float* d_x, void* stream)
 {
     if (!h || !d_u8 || !d_x || N <= 0) return fail(YF_E_INVALID, "yf_preprocess_u8: bad argument");
@@ -1268,7 +1305,24 @@ int yf_op_dtype(yf_handle h, int op, int* kernel_dtype)
     return YF_OK;
 }
 
+static int profile_forward(yf_handle h, const float* d_x, const uint8_t* d_u8, int down2, int N, void* ws, size_t ws_bytes, void* stream, float* op_ms,
+                           int n_ops);
 int yf_profile_forward(yf_handle h, const float* d_x, int N, void* ws, size_t ws_bytes, void* stream, float* op_ms, int n_ops)
+{
+    return profile_forward(h, d_x, nullptr, 0, N, ws, ws_bytes, stream, op_ms, n_ops);
+}
+
+int yf_profile_forward_u8(yf_handle h, const uint8_t* d_u8, int N, int src_h, int src_w, void* ws, size_t ws_bytes, void* stream, float* op_ms,
+                          int n_ops)
+{
+    if (!h || !d_u8) return fail(YF_E_INVALID, "yf_profile_forward_u8: null pointer");
+    int down2;
+    if (int rc = u8_mode(h, src_h, src_w, &down2)) return rc;
+    return profile_forward(h, nullptr, d_u8, down2, N, ws, ws_bytes, stream, op_ms, n_ops);
+}
+
+static int profile_forward(yf_handle h, const float* d_x, const uint8_t* d_u8, int down2, int N, void* ws, size_t ws_bytes, void* stream, float* op_ms,
+                           int n_ops)
 {
     if (!h || !op_ms) return fail(YF_E_INVALID, "yf_profile_forward: null pointer");
     const size_t nops = h->plan().ops.size();
@@ -1281,7 +1335,7 @@ int yf_profile_forward(yf_handle h, const float* d_x, int N, void* ws, size_t ws
     ProfileEvents pe;
     pe.ev.resize(nops + 1);
     for (auto& ev : pe.ev) HIP_OK(hipEventCreate(&ev));
-    int rc = run_forward(h, d_x, N, hl, hs, ws, chain, (hipStream_t)stream, nullptr, nullptr, 0, &pe);
+    int rc = run_forward(h, d_x, N, hl, hs, ws, chain, (hipStream_t)stream, nullptr, nullptr, 0, &pe, d_u8, down2);
     if (rc == YF_OK) {
         HIP_OK(hipEventSynchronize(pe.ev[nops]));
         for (size_t i = 0; i < nops; ++i) HIP_OK(hipEventElapsedTime(&op_ms[i], pe.ev[i], pe.ev[i + 1]));

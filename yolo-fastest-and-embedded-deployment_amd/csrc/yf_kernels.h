@@ -299,6 +299,10 @@ struct PostArgs {
     int32_t* cls;             // [N,kmax]
     int32_t* src;             // [N,kmax]
     int32_t* counts;          // [N]
+    // optional, instead of the five arrays above: ONE packed record row per frame, int32 [N, 1 + 8 kmax] =
+    // count | boxes (4 kmax) | conf, cls_score as float bits (2 kmax) | cls (kmax) | src (kmax) -- the layout of the multi-GPU exchange
+    // (dist.pack_records), so that the all-gather sends the kernel's own buffer
+    int32_t* records;
 };
 int launch_post(const PostArgs& a, int N, hipStream_t s);
 size_t post_lds_bytes(int ncell);

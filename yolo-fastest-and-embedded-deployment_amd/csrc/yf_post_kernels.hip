@@ -132,8 +132,9 @@ __global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncel
         __syncthreads();
     }
     const int M = s_total;
+    int32_t* const rec = a.records ? a.records + frame * (1 + 8L * a.kmax) : nullptr;   // packed record row of this frame
     if (M == 0) {
-        if (tid == 0) a.counts[frame] = 0;
+        if (tid == 0) { if (rec) rec[0] = 0; else a.counts[frame] = 0; }
         return;
     }
     int mpad = 64;
@@ -304,7 +305,7 @@ __global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncel
 
     // ---- phase 5: write survivors ----
     const int nk = s_nkept;
-    if (tid == 0) a.counts[frame] = s_err ? -2 : nk;
+    if (tid == 0) { if (rec) rec[0] = s_err ? -2 : nk; else a.counts[frame] = s_err ? -2 : nk; }
     const int nw = nk < a.kmax ? nk : a.kmax;
     for (int k = tid; k < nw; k += POST_THREADS) {
         int i = kept[k];
@@ -316,10 +317,20 @@ __global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncel
             b.x = clamp_i32(rint((double)b.x * a.adj_w)); b.z = clamp_i32(rint((double)b.z * a.adj_w));
             b.y = clamp_i32(rint((double)b.y * a.adj_h)); b.w = clamp_i32(rint((double)b.w * a.adj_h));
         }
+        const float conf = (float)sigmoid_d((double)logit_at(r, 4)), score = (float)sigmoid_d((double)logit_at(r, 5 + cls));
+        if (rec) {   // (rows start at an odd int32 offset: no 16-byte stores here)
+            int32_t* bx = rec + 1 + 4 * k;
+            bx[0] = b.x; bx[1] = b.y; bx[2] = b.z; bx[3] = b.w;
+            rec[1 + 4 * a.kmax + 2 * k] = __float_as_int(conf);
+            rec[1 + 4 * a.kmax + 2 * k + 1] = __float_as_int(score);
+            rec[1 + 6 * a.kmax + k] = cls;
+            rec[1 + 7 * a.kmax + k] = cell;
+            continue;
+        }
         long o = frame * a.kmax + k;
         reinterpret_cast<int4*>(a.boxes)[o] = b;
-        a.scores[o * 2 + 0] = (float)sigmoid_d((double)logit_at(r, 4));
-        a.scores[o * 2 + 1] = (float)sigmoid_d((double)logit_at(r, 5 + cls));
+        a.scores[o * 2 + 0] = conf;
+        a.scores[o * 2 + 1] = score;
         a.cls[o] = cls;
         a.src[o] = cell;
     }

@@ -22,14 +22,11 @@ def pack_records(raw):
 
 
 def unpack_records(buf, kmax):
+    """-> the five tensors as VIEWS of the record block (no copies: `records` keeps the block itself)."""
     n = buf.shape[0]
-    o = 1
-    boxes = buf[:, o:o + 4 * kmax].reshape(n, kmax, 4); o += 4 * kmax
-    scores = buf[:, o:o + 2 * kmax].contiguous().view(torch.float32).reshape(n, kmax, 2); o += 2 * kmax
-    cls = buf[:, o:o + kmax]; o += kmax
-    src = buf[:, o:o + kmax]
-    return dict(counts=buf[:, 0].contiguous(), boxes=boxes.contiguous(), scores=scores, cls=cls.contiguous(),
-                src=src.contiguous())
+    return dict(counts=buf[:, 0], boxes=buf[:, 1:1 + 4 * kmax].view(n, kmax, 4),
+                scores=buf[:, 1 + 4 * kmax:1 + 6 * kmax].view(torch.float32).view(n, kmax, 2),
+                cls=buf[:, 1 + 6 * kmax:1 + 7 * kmax], src=buf[:, 1 + 7 * kmax:1 + 8 * kmax], records=buf)
 
 
 class _PendingGather:
@@ -45,6 +42,8 @@ class _PendingGather:
             self._work.wait()
             self._work = None
         out = torch.cat(self._parts, dim=0) if self._parts is not None else self._out
+        if self._per * self._world == self._n_total:      # even shards: the gathered block IS the result, in frame order
+            return unpack_records(out, self._kmax)
         keep = []
         for r in range(self._world):
             lo, hi = shard_range(self._n_total, r, self._world)
@@ -58,7 +57,9 @@ def all_gather_detections_async(raw, n_total, group=None):
     Shards may differ by one frame: each rank pads to the largest shard, the pad is dropped after the gather."""
     world = dist.get_world_size(group)
     kmax = raw["cls"].shape[1]
-    rec = pack_records(raw)
+    # zero-copy: a post-process that ran with packed=True already wrote its results as one record block (yf_decode_nms_packed) --
+    # the collective sends that buffer; otherwise the five tensors are packed here (a torch.cat per step)
+    rec = raw["records"] if raw.get("records") is not None else pack_records(raw)
     per = -(-n_total // world)
     if rec.shape[0] < per:
         rec = torch.cat([rec, rec.new_zeros((per - rec.shape[0], rec.shape[1]))], dim=0)

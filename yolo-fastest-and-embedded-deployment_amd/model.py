@@ -246,7 +246,7 @@ class YoloFastest(nn.Module):
             return hl.half(), hs.half()
         return hl, hs
 
-    def forward_u8(self, u8, input_shape):
+    def forward_u8(self, u8, input_shape, slot=0):
         """model(preprocess(u8)) with the pre-process fused into the first kernel: u8 GPU tensor [N,h,w] (h,w == the net
         input or exactly 2x; input_channel 3: [N,h,w,3] as cv2.imread returns frames, BGR) -> (head_large, head_small)."""
         if self.training:
@@ -257,7 +257,7 @@ class YoloFastest(nn.Module):
         H, W = int(input_shape[0]), int(input_shape[1])
         u8 = u8.contiguous()
         N = u8.shape[0]
-        e = self.engine(H, W, N, u8.device)
+        e = self.engine(H, W, N, u8.device, slot)
         hl = torch.empty((N, self.num_out, H // 16, W // 16), dtype=torch.float32, device=u8.device)
         hs = torch.empty((N, self.num_out, H // 32, W // 32), dtype=torch.float32, device=u8.device)
         ws = e.workspace(N, u8.device)
@@ -269,9 +269,11 @@ class YoloFastest(nn.Module):
     def profile(self, x, reps=5):
         """Per-launch timing of one forward pass (HIP events on the launch stream around every kernel).
         Returns a list of dicts: name, ms (mean over reps), algorithmic_bytes, flops (= mfma_flops + valu_flops, by the pipe
-        the layer runs on in this plan) -- for the whole batch."""
-        x = x.contiguous().float()
-        N, _, H, W = x.shape
+        the layer runs on in this plan) -- for the whole batch.  x uint8 [N,H,W] ([N,H,W,3]): the pass from u8 frames of the net's
+        size (forward_u8's fused pre-process in the first launch)."""
+        u8 = x.dtype == torch.uint8
+        x = x.contiguous() if u8 else x.contiguous().float()
+        N, H, W = (x.shape[0], x.shape[1], x.shape[2]) if u8 else (x.shape[0], x.shape[2], x.shape[3])
         e = self.engine(H, W, N, x.device)
         ws = e.workspace(N, x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
@@ -280,8 +282,12 @@ class YoloFastest(nn.Module):
         acc = [0.0] * n.value
         buf = (ctypes.c_float * n.value)()
         for _ in range(reps):
-            _lib.check(e.lib.yf_profile_forward(e.handle, x.data_ptr(), N, ws.data_ptr(), ws.numel(), ctypes.c_void_p(stream),
-                                                buf, n.value))
+            if u8:
+                _lib.check(e.lib.yf_profile_forward_u8(e.handle, x.data_ptr(), N, H, W, ws.data_ptr(), ws.numel(), ctypes.c_void_p(stream),
+                                                       buf, n.value))
+            else:
+                _lib.check(e.lib.yf_profile_forward(e.handle, x.data_ptr(), N, ws.data_ptr(), ws.numel(), ctypes.c_void_p(stream),
+                                                    buf, n.value))
             for i in range(n.value):
                 acc[i] += buf[i] / reps
         out = []

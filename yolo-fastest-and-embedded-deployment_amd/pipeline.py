@@ -31,7 +31,7 @@ class _Ticket:
 
 
 class BatchPipeline:
-    def __init__(self, model, post, depth=2, kmax=64, origin_shape=None, lanes=1, branches=0):
+    def __init__(self, model, post, depth=2, kmax=64, origin_shape=None, lanes=1, branches=0, packed=False):
         """model: yolo_fastest_amd.YoloFastest on a GPU; post: YOLO_post_process bound to it.  depth: batches in flight (2 is the
         measured optimum).  lanes / branches: the per-engine concurrency knobs while the pipeline is used -- with two batches in
         flight the best setting is one lane and the small head in line (the other batch fills the machine instead)."""
@@ -41,13 +41,16 @@ class BatchPipeline:
         if not p.is_cuda:
             raise RuntimeError("BatchPipeline (HIP) has no CPU path: move the model to the GPU")
         self.model, self.post, self.depth, self.kmax, self.origin_shape = model, post, depth, kmax, origin_shape
+        self.packed = packed     # True: the post-process writes one packed record block per batch (`records`: what the exchange sends as is)
         model.lanes, model.branches = lanes, branches
         self.device = p.device
         self.streams = [torch.cuda.Stream(self.device) for _ in range(depth)]
         self._n = 0
 
     def submit(self, x, then=None):
-        """x: float32 GPU tensor [N,1,H,W], ready on the caller's current stream.  Returns a ticket at once.
+        """x: float32 GPU tensor [N,input_channel,H,W] -- or uint8 frames [N,h,w] ([N,h,w,3] for a 3-channel model), which take the
+        fused pre-process (model.forward_u8: h, w == the net input or exactly 2x) -- ready on the caller's current stream.  Returns a
+        ticket at once.
         then(out): optional, called with the batch's result dict INSIDE the batch's stream context -- work it queues (e.g. the
         asynchronous all-gather of the records, dist.all_gather_detections_async) is ordered behind this batch only, not behind the
         caller's stream; its return value is kept in the ticket's `extra`."""
@@ -59,8 +62,11 @@ class BatchPipeline:
             x.record_stream(s)
             # engine slots 1 .. depth: slot 0 stays the engine of plain `model(x)` calls on the caller's own stream, so those may
             # be mixed with batches in flight
-            pred = self.model(x, slot=k + 1)
-            out = self.post.detect_raw(pred, kmax=self.kmax, origin_shape=self.origin_shape, slot=k + 1)
+            if x.dtype == torch.uint8:
+                pred = self.model.forward_u8(x, self.post.input_shape, slot=k + 1)
+            else:
+                pred = self.model(x, slot=k + 1)
+            out = self.post.detect_raw(pred, kmax=self.kmax, origin_shape=self.origin_shape, slot=k + 1, packed=self.packed)
             out["head_large"], out["head_small"] = pred
             extra = then(out) if then is not None else None
             ev = torch.cuda.Event()

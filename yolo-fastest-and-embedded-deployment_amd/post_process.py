@@ -53,12 +53,29 @@ class YOLO_post_process:
             raise ValueError("the bound model was built for %d anchors x %d classes" % (self._model.num_anchors, self._model.num_cls))
         return self._model.engine(H, W, hl.shape[0], hl.device, slot)
 
-    def detect_raw(self, pred, kmax=64, nms_thres=None, origin_shape=None, slot=0):
+    @staticmethod
+    def record_views(rec, kmax):
+        """The five result tensors as VIEWS of a packed record block int32 [N, 1 + 8 kmax] (yf_decode_nms_packed's output, the
+        multi-GPU exchange's layout: count | boxes | scores as float bits | cls | src)."""
+        n = rec.shape[0]
+        return dict(counts=rec[:, 0], boxes=rec[:, 1:1 + 4 * kmax].view(n, kmax, 4),
+                    scores=rec[:, 1 + 4 * kmax:1 + 6 * kmax].view(torch.float32).view(n, kmax, 2),
+                    cls=rec[:, 1 + 6 * kmax:1 + 7 * kmax], src=rec[:, 1 + 7 * kmax:1 + 8 * kmax], records=rec)
+
+    def detect_raw(self, pred, kmax=64, nms_thres=None, origin_shape=None, slot=0, packed=False):
         """Batched. Returns dict of GPU tensors: boxes [N,kmax,4] i32, scores [N,kmax,2] f32, cls, src [N,kmax] i32,
-        counts [N] i32 (see include/yolo_fastest_hip.h for the conventions)."""
+        counts [N] i32 (see include/yolo_fastest_hip.h for the conventions).  packed=True: the kernel writes ONE record block
+        (`records`, int32 [N, 1 + 8 kmax]) and the five tensors are views of it -- what dist.all_gather_detections sends as is."""
         hl, hs = pred[0].contiguous(), pred[1].contiguous()
         e = self._engine(pred, slot)
         N, dev = hl.shape[0], hl.device
+        if packed:
+            rec = torch.empty((N, 1 + 8 * kmax), dtype=torch.int32, device=dev)
+            oh, ow = (origin_shape[0], origin_shape[1]) if origin_shape is not None else (0, 0)
+            _lib.check(e.lib.yf_decode_nms_packed(e.handle, hl.data_ptr(), hs.data_ptr(), N, float(self.conf_thres),
+                                                  float(self.nms_thres if nms_thres is None else nms_thres), self._anc, int(oh), int(ow), kmax,
+                                                  rec.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+            return self.record_views(rec, kmax)
         out = dict(boxes=torch.empty((N, kmax, 4), dtype=torch.int32, device=dev),
                    scores=torch.empty((N, kmax, 2), dtype=torch.float32, device=dev),
                    cls=torch.empty((N, kmax), dtype=torch.int32, device=dev),
@@ -73,9 +90,9 @@ class YOLO_post_process:
                                        ctypes.c_void_p(stream)))
         return out
 
-    def detect_raw_from_input(self, x, kmax=64, origin_shape=None):
+    def detect_raw_from_input(self, x, kmax=64, origin_shape=None, packed=False):
         """model forward + decode + NMS in ONE C call (yf_detect): x float32 GPU tensor [N,input_channel,H,W] -> the same dict as
-        detect_raw, plus the two head tensors."""
+        detect_raw, plus the two head tensors.  packed: as in detect_raw (yf_detect_packed)."""
         if self._model is None:
             raise RuntimeError("call post_process.bind(model) first")
         if not x.is_cuda:
@@ -94,6 +111,12 @@ class YOLO_post_process:
         ws = e.workspace(N, dev)
         oh, ow = (origin_shape[0], origin_shape[1]) if origin_shape is not None else (0, 0)
         stream = torch.cuda.current_stream(dev).cuda_stream
+        if packed:
+            rec = torch.empty((N, 1 + 8 * kmax), dtype=torch.int32, device=dev)
+            _lib.check(e.lib.yf_detect_packed(e.handle, x.data_ptr(), N, float(self.conf_thres), float(self.nms_thres), self._anc, int(oh),
+                                              int(ow), kmax, rec.data_ptr(), out["head_large"].data_ptr(), out["head_small"].data_ptr(),
+                                              ws.data_ptr(), ws.numel(), ctypes.c_void_p(stream)))
+            return dict(self.record_views(rec, kmax), head_large=out["head_large"], head_small=out["head_small"])
         _lib.check(e.lib.yf_detect(e.handle, x.data_ptr(), N, float(self.conf_thres), float(self.nms_thres), self._anc, int(oh),
                                    int(ow), kmax, out["boxes"].data_ptr(), out["scores"].data_ptr(), out["cls"].data_ptr(),
                                    out["src"].data_ptr(), out["counts"].data_ptr(), out["head_large"].data_ptr(),
