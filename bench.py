@@ -334,27 +334,17 @@ def launch_roofline(o, dtype, traffic, issue=None):
         c = {"valu": issue["SQ_INSTS_VALU"] * 4 / sec / t, "mfma": issue["SQ_VALU_MFMA_BUSY_CYCLES"] / sec / t,
              "hbm": r["hbm_frac"] or 0.0, "lds": issue["SQ_ACTIVE_INST_LDS"] / max(issue["SQ_WAVE_CYCLES"], 1.0)}
         parked = issue["SQ_WAIT_ANY"] / max(issue["SQ_WAVE_CYCLES"], 1.0)
-        if dtype == "f32":     # fp32 MFMAs and VALU instructions share the issue slots: one pipe
-            c = {"mfma": c["valu"] + c["mfma"], "hbm": c["hbm"], "lds": c["lds"]}
-        pipe = max(c, key=c.get)
         r["counters"] = dict({k + "_frac": round(v, 3) for k, v in c.items()}, parked_frac=round(parked, 3))
-        r["bound"] = pipe if (c[pipe] >= 0.5 or c[pipe] >= parked) else "latency"
-        # `frac` stays a ROOFLINE fraction -- useful flops (or bytes) over the peak of the pipe that binds -- the counter shares above are
-        # the evidence for WHICH pipe; a VALU-bound launch is priced by its vector flops against the fp32 vector peak
-        if r["bound"] == "valu":
-            r["peak_tf"], r["achieved_tf"] = FP32_PEAK_TF, o["valu_flops"] / t / 1e12
-            r["frac"] = r["achieved_tf"] / FP32_PEAK_TF
-        elif r["bound"] == "mfma" and dtype != "f32":
-            issued = o["mfma_flops"] * (3 if dtype == "f16x3" else 1)
-            r["peak_tf"], r["achieved_tf"] = F16_MFMA_PEAK_TF, issued / t / 1e12
-            r["frac"] = r["achieved_tf"] / F16_MFMA_PEAK_TF
-        elif r["bound"] == "hbm":
-            r["frac"] = r["hbm_frac"]
-        elif r["bound"] in ("latency", "lds"):
-            r["frac"] = r["compute_frac"]
-            r["bound_note"] = "no pipe holds half of the launch's time (parked share %.2f): frac is the compute floor over the duration" % parked
-        else:
-            r["frac"] = r["compute_frac"]
+        pipes = dict(c)
+        if dtype == "f32":     # fp32 MFMAs and VALU instructions share the issue slots: ONE pipe, named after where the launch's flops are
+            pipes = {("mfma" if on_mfma else "valu"): c["valu"] + c["mfma"], "hbm": c["hbm"], "lds": c["lds"]}
+            r["counters"]["fp32_issue_frac"] = round(c["valu"] + c["mfma"], 3)
+        pipe = max(pipes, key=pipes.get)
+        # `bound` is counter-backed; achieved / peak / frac stay the ROOFLINE figures above (useful flops over the peak of the pipe they
+        # run on, or counter bytes over the HBM peak): a launch whose VALU is busy issuing address math, operand splits and epilogues
+        # around its MFMAs is "valu"-bound at a low flop fraction -- that gap is the finding, not a rounding of it
+        r["bound"] = pipe if (pipes[pipe] >= 0.5 or pipes[pipe] >= parked) else "latency"
+        r["frac"] = r["hbm_frac"] if r["bound"] == "hbm" else r["compute_frac"]
     return r
 
 
@@ -785,7 +775,7 @@ def main():
             if "counters" in r:
                 out_["counters"] = r["counters"]
                 tot = sum(o["ms"] for o in ops_)
-                keys = [k for k in ("valu_frac", "mfma_frac", "hbm_frac", "lds_frac", "parked_frac") if all(k in o["roof"]["counters"] for o in ops_)]
+                keys = ("valu_frac", "mfma_frac", "hbm_frac", "lds_frac", "parked_frac")
                 out_["pass_binding"] = {k: round(sum(o["roof"]["counters"][k] * o["ms"] for o in ops_) / tot, 3) for k in keys}
                 out_["pass_binding"]["hbm_bytes"] = int(sum(tr.get(o["name"], 0) for o in ops_))
                 out_["pass_binding"]["launches_by_bound"] = {b: sum(1 for o in ops_ if o["roof"]["bound"] == b) for b in sorted({o["roof"]["bound"] for o in ops_})}

@@ -98,6 +98,10 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
     constexpr int XFLOATS = !XL ? 4 : PRE ? IRH * IRWP : NRP * XP;  // XL = false: inputs come straight from HBM/L2
     __shared__ __attribute__((aligned(16))) float E[EC * PLANE];
     __shared__ __attribute__((aligned(16))) float X[XFLOATS];
+    // u8 input (PRE): (v - 128) / 255 of the 256 possible pixel values (a 2x2 box mean is an integer 0..255 too).  The IEEE division is
+    // ~10 VALU instructions and sat in the loop nine times per region pixel (stem 98 us from u8 against 67 us from f32, batch 256); one
+    // division per thread here and an LDS read per tap give the same bits (torch's `(img - 128.0) / 255.0`, detect.py:124)
+    __shared__ float LUT[PRE ? 256 : 1];
 
     const int b = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = b % a.tiles_x, ty = (b / a.tiles_x) % a.tiles_y, n = b / (a.tiles_x * a.tiles_y);
@@ -105,6 +109,10 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
     const int wave = wave_id(), lane = threadIdx.x & 63;
     const int tyb = threadIdx.x / TXB, txb = threadIdx.x % TXB;
 
+    if constexpr (PRE) {
+        if (a.in_u8)
+            for (int i = threadIdx.x; i < 256; i += NT) LUT[i] = ((float)i - 128.0f) / 255.0f;
+    }
     // ---------------- stage the input tile (one exposed HBM latency per workgroup) ----------------
     if constexpr (!XL) {
     } else if constexpr (PRE) {
@@ -178,13 +186,14 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
                                 for (int ci = 0; ci < C0; ++ci) {
                                     float val = 0.f;
                                     if (ok) {
+                                        int pix;
                                         if (a.u8_down2) {
                                             const uint8_t* q = src + (long)(2 * yy) * sw + 2 * xx * C0 + (C0 - 1 - ci);
-                                            val = (float)((q[0] + q[C0] + q[sw] + q[sw + C0] + 2) >> 2);
+                                            pix = (q[0] + q[C0] + q[sw] + q[sw + C0] + 2) >> 2;
                                         } else {
-                                            val = (float)src[(long)yy * sw + xx * C0 + (C0 - 1 - ci)];
+                                            pix = src[(long)yy * sw + xx * C0 + (C0 - 1 - ci)];
                                         }
-                                        val = (val - 128.0f) / 255.0f;
+                                        val = LUT[pix];
                                     }
                                     v[(ky * 3 + kx) * C0 + ci] = val;
                                 }
