@@ -890,6 +890,10 @@ def main():
             roofline.update(achieved=roofline["hbm"]["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=roofline["hbm"]["frac"])
         else:
             roofline.update(achieved=roofline["compute"]["achieved"], peak=dr["peak_tf"], unit="TFLOP/s", frac=roofline["compute"]["frac"])
+        if "counters" in dr:      # what the bound was decided on: the launch's issue-side counters of this run (launch_roofline)
+            roofline["counters"] = dr["counters"]
+            roofline["bound_source"] = ("counters measured in this run (rocprofv3 --pmc child passes: FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU, "
+                                        "SQ_VALU_MFMA_BUSY_CYCLES, SQ_WAIT_ANY / SQ_WAVE_CYCLES); fp32 MFMA and VALU share the issue slots (fp32_issue_frac)")
         if traffic_note:
             roofline["traffic_note"] = traffic_note
         if traffic_source:
@@ -924,7 +928,11 @@ def main():
                               "per_launch": [{"name": o["name"] if len(o["name"]) < 48 else o["name"][:20] + ".." + o["name"][-24:],
                                               "ms": round(o["ms"], 4), "dtype": o["kernel_dtype"], "bound": o["roof"]["bound"],
                                               "frac": round(o["roof"]["frac"], 3),
-                                              "hbm_GBps": None if o["roof"]["hbm_gbs"] is None else round(o["roof"]["hbm_gbs"])}
+                                              "hbm_GBps": None if o["roof"]["hbm_gbs"] is None else round(o["roof"]["hbm_gbs"]),
+                                              # issue-side counter shares of the launch's time: VALU issue, MFMA busy, waves parked
+                                              "issue": None if "counters" not in o["roof"] else [o["roof"]["counters"]["valu_frac"],
+                                                                                                  o["roof"]["counters"]["mfma_frac"],
+                                                                                                  o["roof"]["counters"]["parked_frac"]]}
                                              for o in ops]},
         }
         if single is not None:

@@ -246,6 +246,9 @@ int yf_trainer_backward(yf_trainer t, const float *d_x, const float *d_grad_head
 /* how many passes ran as a HIP graph replay: a pass whose pointer arguments equal those of the call before it is captured once and
    replayed from then on (the steady state of a training loop); YF_TRAIN_GRAPH_OFF=1 in the environment disables it */
 int yf_trainer_graph_replays(yf_trainer t, long *forward, long *backward);
+/* out6 = replays (forward, backward), captures (forward, backward), evictions (forward, backward).  A trainer keeps up to four graphs per
+   pass (one per remembered pointer set); a pointer pattern that keeps evicting graphs before they were replayed stops capturing. */
+int yf_trainer_graph_stats(yf_trainer t, long *out6);
 
 /* yf_forward + yf_decode_nms back to back on one stream (heads also returned; may be NULL to use
  * workspace-internal buffers). */

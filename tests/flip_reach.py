@@ -44,9 +44,10 @@ def near_zero_preactivations(sd64, x64, ulps=4.0):
     return out, total
 
 
-def reach_masks(flips, param_names, param_shapes):
+def reach_masks(flips, param_names, param_shapes, parts=False):
     """flips: {layer: channels}.  Returns one boolean array per parameter tensor (flattened, `model.parameters()` order): True where a
-    flipped ReLU decision can reach the gradient element."""
+    flipped ReLU decision can reach the gradient element.  parts=True: a pair per tensor instead -- (the flipped layers' OWN channel
+    parameters, where one mask element is an O(1) share of the gradient; everything merely upstream of a flip)."""
     full = set()
     for name in flips:
         full.update(upstream(name))
@@ -54,6 +55,21 @@ def reach_masks(flips, param_names, param_shapes):
     for pname, shape in zip(param_names, param_shapes):
         layer = pname.rsplit(".", 2)[0] if pname.count(".") >= 2 else pname.rsplit(".", 1)[0]
         m = np.zeros(shape, bool)
+        if parts:
+            own = np.zeros(shape, bool)
+            if layer in flips:
+                kind = bo._BY_NAME[layer][1]
+                for c in flips[layer]:
+                    if kind == "dc" and pname.endswith(".0.weight"):
+                        own[:, c] = True
+                    else:
+                        own[c] = True
+            up = np.zeros(shape, bool)
+            if layer in full:
+                up[...] = True
+                up &= ~own
+            masks.append((own.ravel(), up.ravel()))
+            continue
         if layer in full:
             m[...] = True
         elif layer in flips:

@@ -565,27 +565,38 @@ def test_training_network_against_the_fp64_oracle(yf, dev, seed, tol):
     with torch.no_grad():
         _, _, tape = training.train_forward(m, x.to(dev))
     m.load_state_dict(saved, strict=False)
-    flips = {}
+    flips, n_flips = {}, 0
     for name, d in pre.items():
         diff = (tape[name][2] > 0).cpu() != (d["z"] > 0)
         if diff.any():
             flips[name] = torch.nonzero(diff.any(0).any(-1).any(-1)).ravel().tolist()
+            n_flips += int(diff.sum())
+    # a handful at most: with N = 3 frames of 64x96 there are ~1 M ReLU decisions, of which 0 .. 2 land on the other side of zero
+    # (without a bound on the flips a late one would mark everything upstream "reachable" and the test would check nothing)
+    assert n_flips <= 8, (n_flips, flips)
     names = [n for n, _ in m.named_parameters()]
-    masks = fr.reach_masks(flips, names, [tuple(p.shape) for p in m.parameters()])
-    n_clean = 0
-    for (name, p), w, mask in zip(m.named_parameters(), g64, masks):
+    masks = fr.reach_masks(flips, names, [tuple(p.shape) for p in m.parameters()], parts=True)
+    n_clean = n_clean_elems = n_elems = 0
+    for (name, p), w, (own, up) in zip(m.named_parameters(), g64, masks):
         g, w = p.grad.cpu().numpy().astype(np.float64).ravel(), w.numpy().ravel()
         scale = np.abs(w).max()
         if scale < 1e-9:                        # zero in exact arithmetic (see the step test)
             assert np.abs(g).max() <= 1e-4, name
             continue
         err = np.abs(g - w) / scale
-        if (~mask).any():
+        clean = ~(own | up)
+        n_elems += err.size; n_clean_elems += int(clean.sum())
+        if clean.any():
             n_clean += 1
-            assert err[~mask].max() <= tol, (name, err[~mask].max(), flips)
-        if mask.any():
-            assert err[mask].max() <= 2.0, (name, err[mask].max(), flips)      # a flipped channel's own gamma moves by O(1)
+            assert err[clean].max() <= tol, (name, err[clean].max(), flips)
+        # upstream of a flip: flip-level, not O(1) -- with 3 frames one mask element is 1/18 .. 1/1152 of a channel's batch; measured
+        # 3e-2 .. 2e-1 (torch's own fp32: 1e-2 .. 1e-1).  An O(1) error of an upstream backward kernel does not fit under this cap.
+        if up.any():
+            assert err[up].max() <= 0.5, (name, err[up].max(), flips)
+        if own.any():                           # the flipped channel's own filter / gamma / beta: one mask element is an O(1) share
+            assert err[own].max() <= 2.0, (name, err[own].max(), flips)
     assert n_clean >= 10, (n_clean, flips)      # the flips (if any) leave at least the large head's private layers untouched
+    assert n_clean_elems >= 0.2 * n_elems, (n_clean_elems, n_elems, flips)
     # the running statistics moved like the module's buffers
     for k in ("conv0.1.running_mean", "res5_5.conv2.1.running_var", "conv4_1_5.1.running_var", "deconv5_1.1.running_mean"):
         assert np.allclose(m.state_dict()[k].cpu().numpy(), sd[k].numpy(), rtol=1e-5, atol=1e-7), k
@@ -622,6 +633,47 @@ def test_training_passes_replay_as_graphs_with_the_same_results(yf, dev):
     assert out[False][0] == out[True][0], out
     assert int(out[True][1]) == 0 and int(out[True][2]) == 0, out
     assert int(out[False][1]) >= 3 and int(out[False][2]) >= 1, out          # captured when a pointer set comes back, replayed after
+
+
+def test_training_graphs_with_three_rotating_input_buffers(yf, dev):
+    """a loop that cycles through three input tensors (alternating buffers, gradient accumulation, interleaved validation
+    tensors) must not re-capture a pass every iteration.  The trainer keeps a graph per remembered pointer set (four) and stops capturing
+    a pass whose pattern keeps evicting graphs before they were replayed: over the second half of 36 iterations the captures of each
+    pass stay bounded while the losses stay those of the eager path (the kernels are deterministic)."""
+    import ctypes
+    from yolo_fastest_amd import training, validation as val
+    io = yf.io_params_for(256)
+
+    def run(graphs):
+        torch.manual_seed(5)
+        m = yf.YoloFastest(io)
+        m.initialize_weights()
+        m = m.to(dev).train()
+        xs = [(torch.rand(4, 1, 64, 96, generator=torch.Generator().manual_seed(i)) - 0.5).to(dev) for i in range(3)]
+        t = np.zeros((4, 8, 6), np.float32); t[:, 0] = (0.4, 0.6, 0.3, 0.2, 1, 255.0)
+        td = torch.from_numpy(t).to(dev)
+        crit = [val.YOLOLossV3(io["anchors"][i], 3, [64, 96, 1], dev, model=m) for i in range(2)]
+        opt = training.Adam(m.parameters(), lr=0.001)
+        tr = training._trainer(m, 64, 96, dev)
+        stats, losses = [], []
+        for it in range(36):
+            losses.append(float(training.train_step(m, crit, opt, xs[it % 3], td)[0].detach()))
+            if graphs and it in (17, 35):
+                out = (ctypes.c_long * 6)()
+                tr.lib.yf_trainer_graph_stats(tr.handle, out)
+                stats.append(list(out))
+        return losses, stats
+
+    if os.environ.get("YF_TRAIN_GRAPH_OFF"):
+        pytest.skip("graphs are switched off in this environment")
+    losses, stats = run(True)
+    half, full = stats
+    print("\n[rotating inputs] replays fwd/bwd %d/%d, captures %d/%d, evictions %d/%d after 36 iterations (after 18: captures %d/%d)"
+          % (full[0], full[1], full[2], full[3], full[4], full[5], half[2], half[3]))
+    for p in (0, 1):
+        assert full[2 + p] <= 12, full                       # never "a capture per iteration"
+        assert full[2 + p] - half[2 + p] <= 4, (half, full)    # and bounded in the steady state: replaying, or given up capturing
+    assert all(np.isfinite(losses))
 
 
 def test_training_forward_guards(yf, dev):

@@ -5,8 +5,16 @@
 cd "$(dirname "$0")"
 [ -x ./cap_repro.bin ] || /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 cap_repro.hip -o cap_repro.bin || exit 1
 T=/usr/local/lib/python3.10/dist-packages/torch/lib
+# Default: the topologies the engine ISSUES today (branches join the capture's origin stream; with a post-process the lane joins its
+# branch) -- a regression check that passes on both runtimes.  `tools/cap_repro.sh crashing` adds the "branch joins its forked lane"
+# variants that are KNOWN to segfault in hipStreamEndCapture of the torch-bundled runtime (profiles/r03_capture_repro.txt): their cause is
+# on record and the engine no longer issues them, so they are not re-provoked on a GPU box unless asked for.
+CASES=("1 1 nopost joinorigin" "2 0 nopost" "2 1 nopost joinorigin" "3 1 nopost joinorigin" "1 1 postonbranch" "2 0 postonbranch" "2 1 postonbranch" "3 1 postonbranch")
+if [ "$1" = crashing ]; then
+    CASES+=("1 1" "2 0" "2 1" "2 1 fresh" "2 1 lanemajor" "2 1 thread" "1 1 nopost" "2 1 nopost" "2 1 nopost fresh" "2 1 nopost lanemajor" "3 1 nopost" "3 1")
+fi
 for rt in rocm torch; do
-for args in "1 1" "2 0" "2 1" "2 1 fresh" "2 1 lanemajor" "2 1 thread" "1 1 nopost" "2 0 nopost" "2 1 nopost" "2 1 nopost fresh" "2 1 nopost lanemajor" "2 1 nopost joinorigin" "3 1 nopost" "3 1 nopost joinorigin" "3 1" "2 1 postonbranch" "3 1 postonbranch" "1 1 postonbranch" "2 0 postonbranch"; do
+for args in "${CASES[@]}"; do
     if [ $rt = torch ]; then
         LD_LIBRARY_PATH=$T LD_PRELOAD=$T/libamdhip64.so timeout -k 5 60 ./cap_repro.bin $args > /tmp/cap_repro.out 2>&1
     else

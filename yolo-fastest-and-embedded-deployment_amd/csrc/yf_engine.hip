@@ -136,8 +136,9 @@ struct yf_engine {
     // runtime multiplexes HIP streams onto a few hardware queues, and two streams that share one run strictly one after the other
     hipStream_t assigned_for = nullptr;
     bool assigned = false;
-    struct Assignment { hipStream_t caller, side[3], bside[4]; } seen[4];   // what was found for the last few caller streams
+    struct Assignment { hipStream_t caller, side[3], bside[4]; long used; } seen[4];   // what was found for the last few caller streams (LRU)
     int n_seen = 0;
+    long seen_tick = 0;
     hipEvent_t ev_probe[3] = {nullptr, nullptr, nullptr};
     size_t head_l_elems = 0, head_s_elems = 0;
     const Plan& plan() const { return plans[fusion]; }
@@ -440,17 +441,31 @@ int streams_overlap(yf_engine* e, hipStream_t a, hipStream_t b, bool* overlap)
     int khz = 100000;   // s_memrealtime: 100 MHz on this part
     (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->device);
     const long ticks = (long)khz * 100 / 1000;   // 100 us: well above the ~15 us of launch and event overhead around the two kernels
-    HIP_OK(hipEventRecord(e->ev_probe[0], a));
-    HIP_OK(hipStreamWaitEvent(b, e->ev_probe[0], 0));
-    hipLaunchKernelGGL(yf_spin_kernel, dim3(1), dim3(64), 0, a, ticks);
-    hipLaunchKernelGGL(yf_spin_kernel, dim3(1), dim3(64), 0, b, ticks);
-    HIP_OK(hipEventRecord(e->ev_probe[1], b));
-    HIP_OK(hipStreamWaitEvent(a, e->ev_probe[1], 0));
-    HIP_OK(hipEventRecord(e->ev_probe[2], a));
-    HIP_OK(hipEventSynchronize(e->ev_probe[2]));
-    float ms = 0.f;
-    HIP_OK(hipEventElapsedTime(&ms, e->ev_probe[0], e->ev_probe[2]));
-    *overlap = ms < 0.150f;   // ~0.115 ms when the two spins overlap, ~0.215 ms when they are serialised
+    // The verdict is RELATIVE to one spin alone on stream a, measured in the same call: on an idle device ~0.110 ms alone, ~0.115 ms for an
+    // overlapping pair, ~0.215 ms for a serialised one; on a device that is busy with other work (another engine's batch in flight,
+    // another process) all three stretch together, which a fixed threshold would read as "serialised".  One retry when the ratio is
+    // ambiguous (1.35 .. 1.65).
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIP_OK(hipEventRecord(e->ev_probe[0], a));
+        hipLaunchKernelGGL(yf_spin_kernel, dim3(1), dim3(64), 0, a, ticks);
+        HIP_OK(hipEventRecord(e->ev_probe[2], a));
+        HIP_OK(hipEventSynchronize(e->ev_probe[2]));
+        float alone = 0.f;
+        HIP_OK(hipEventElapsedTime(&alone, e->ev_probe[0], e->ev_probe[2]));
+        HIP_OK(hipEventRecord(e->ev_probe[0], a));
+        HIP_OK(hipStreamWaitEvent(b, e->ev_probe[0], 0));
+        hipLaunchKernelGGL(yf_spin_kernel, dim3(1), dim3(64), 0, a, ticks);
+        hipLaunchKernelGGL(yf_spin_kernel, dim3(1), dim3(64), 0, b, ticks);
+        HIP_OK(hipEventRecord(e->ev_probe[1], b));
+        HIP_OK(hipStreamWaitEvent(a, e->ev_probe[1], 0));
+        HIP_OK(hipEventRecord(e->ev_probe[2], a));
+        HIP_OK(hipEventSynchronize(e->ev_probe[2]));
+        float pair = 0.f;
+        HIP_OK(hipEventElapsedTime(&pair, e->ev_probe[0], e->ev_probe[2]));
+        const float ratio = pair / (alone > 1e-3f ? alone : 1e-3f);
+        *overlap = ratio < 1.5f;
+        if (ratio < 1.35f || ratio > 1.65f) break;
+    }
     return YF_OK;
 }
 
@@ -461,6 +476,7 @@ int assign_streams(yf_engine* e, hipStream_t s)
 {
     for (int i = 0; i < e->n_seen; ++i)
         if (e->seen[i].caller == s) {   // probed before: a caller that alternates between streams does not pay again
+            e->seen[i].used = ++e->seen_tick;
             for (int l = 0; l < 3; ++l) e->side[l] = e->seen[i].side[l];
             for (int l = 0; l < 4; ++l) e->bside[l] = e->seen[i].bside[l];
             e->assigned_for = s;
@@ -495,8 +511,16 @@ int assign_streams(yf_engine* e, hipStream_t s)
     e->side[0] = out[0]; e->bside[0] = out[1]; e->bside[1] = out[2]; e->side[1] = out[3]; e->side[2] = out[4]; e->bside[2] = out[5]; e->bside[3] = out[6];
     e->assigned_for = s;
     e->assigned = true;
-    yf_engine::Assignment& a = e->seen[e->n_seen < 4 ? e->n_seen++ : 3];
+    int slot = e->n_seen;
+    if (e->n_seen < 4) ++e->n_seen;
+    else {   // replace the entry that was used longest ago (a caller rotating over more than four streams re-probes the coldest only)
+        slot = 0;
+        for (int i = 1; i < 4; ++i)
+            if (e->seen[i].used < e->seen[slot].used) slot = i;
+    }
+    yf_engine::Assignment& a = e->seen[slot];
     a.caller = s;
+    a.used = ++e->seen_tick;
     for (int l = 0; l < 3; ++l) a.side[l] = e->side[l];
     for (int l = 0; l < 4; ++l) a.bside[l] = e->bside[l];
     return YF_OK;

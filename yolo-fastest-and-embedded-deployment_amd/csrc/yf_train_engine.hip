@@ -66,8 +66,12 @@ struct yf_trainer_s {
     yf::TSumEntry* d_sum_tab = nullptr;
     // a pass with the same pointers as the call before it is captured once (on cap_stream: the caller's may be the legacy stream,
     // which cannot capture) and replayed as a HIP graph on the caller's stream from then on: see run_pass()
-    struct PassGraph { std::vector<uintptr_t> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
-    struct PassGraphs { std::vector<uintptr_t> seen[4]; int nseen = 0; PassGraph g[2]; int next = 0; long replays = 0; int failures = 0; } gfwd, gbwd;
+    struct PassGraph { std::vector<uintptr_t> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; long uses = 0; };
+    // as many graphs as remembered pointer sets (4): a loop that cycles through three or four sets (gradient accumulation, alternating
+    // input buffers) replays all of them; a graph evicted before it was replayed a few times counts as thrash, and a pass that keeps
+    // thrashing stops capturing (every capture is a host stall of several hundred launches)
+    struct PassGraphs { std::vector<uintptr_t> seen[4]; int nseen = 0; PassGraph g[4]; int next = 0; long replays = 0, captures = 0, evictions = 0;
+                        int failures = 0, thrash = 0; } gfwd, gbwd;
     hipStream_t cap_stream = nullptr;
     int i_conv4_2, i_conv4_3, i_conv5_2, i_conv5_3, i_conv5_6, i_head5, i_deconv, i_c411, i_c415, i_head4;
 };
@@ -582,15 +586,23 @@ static int run_pass(yf_trainer_s* t, yf_trainer_s::PassGraphs& pg, std::vector<u
     static const bool always = getenv("YF_TRAIN_GRAPH_ALWAYS") != nullptr;
     // only where the host is the slower side: a replayed node costs the GPU ~1 us more than a plain launch (measured at batch 256:
     // 19.5 -> 20.1 ms with ~535 nodes), which a 4 ms iteration wins back several times over on the host and a 20 ms one does not
-    if (off || pg.failures >= 2 || (!always && (long)N * t->H * t->W > 40L * 256 * 320)) return body(s, false);   // (two failed captures: never again)
+    // the caller's stream captures (torch.cuda.graph around a train step): emit the launches into ITS capture -- no graph launch into a
+    // capturing stream, and nothing host-synchronous: a pass that would have to (re)build its sum table first says so instead
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        const int rc = body(s, true);
+        if (rc == 1)
+            return fail(YF_E_INVALID, "the caller's stream is capturing and this pass has to upload its weight-gradient sum table first "
+                                      "(a host-synchronous step): run one eager iteration at this batch size before capturing");
+        return rc;
+    }
+    if (off || pg.failures >= 2 || pg.thrash >= 4 || (!always && (long)N * t->H * t->W > 40L * 256 * 320)) return body(s, false);   // (two failed captures / a thrashing pointer pattern: never again)
     for (yf_trainer_s::PassGraph& g : pg.g)
         if (g.exec && g.key == key) {
             HIP_OK(hipGraphLaunch(g.exec, s));
-            ++pg.replays;
+            ++pg.replays; ++g.uses;
             return YF_OK;
         }
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return body(s, false);   // the caller captures: emit into it
     bool known = false;
     for (const std::vector<uintptr_t>& k : pg.seen) known = known || k == key;
     if (!known) {                                            // new pointers: plain launches (this also sets up attributes and tables)
@@ -599,10 +611,13 @@ static int run_pass(yf_trainer_s* t, yf_trainer_s::PassGraphs& pg, std::vector<u
     }
     if (!t->cap_stream && hipStreamCreateWithFlags(&t->cap_stream, hipStreamNonBlocking) != hipSuccess) { t->cap_stream = nullptr; return body(s, false); }
     yf_trainer_s::PassGraph& g = pg.g[pg.next];
-    pg.next ^= 1;
-    if (g.exec) {                                            // a third pointer set evicts the older graph (it may still be running on s)
+    pg.next = (pg.next + 1) & 3;
+    if (g.exec) {                                            // a fifth pointer set evicts the oldest graph (it may still be running on s)
         (void)hipStreamSynchronize(s);
         (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); g.exec = nullptr; g.graph = nullptr;
+        ++pg.evictions;
+        if (g.uses < 3) ++pg.thrash;                         // evicted before it paid for its capture
+        g.uses = 0;
     }
     static const bool dbg = getenv("YF_TRAIN_GRAPH_DEBUG") != nullptr;
     {
@@ -629,6 +644,8 @@ static int run_pass(yf_trainer_s* t, yf_trainer_s::PassGraphs& pg, std::vector<u
     }
     g.graph = graph;
     g.key = key;
+    g.uses = 1;
+    ++pg.captures;
     HIP_OK(hipGraphLaunch(g.exec, s));
     ++pg.replays;
     return YF_OK;
@@ -680,6 +697,13 @@ int yf_trainer_graph_replays(yf_trainer t, long* forward, long* backward)
     if (!t || !forward || !backward) return fail(YF_E_INVALID, "yf_trainer_graph_replays: null argument");
     *forward = t->gfwd.replays;
     *backward = t->gbwd.replays;
+    return YF_OK;
+}
+int yf_trainer_graph_stats(yf_trainer t, long* out6)
+{
+    if (!t || !out6) return fail(YF_E_INVALID, "yf_trainer_graph_stats: null argument");
+    out6[0] = t->gfwd.replays; out6[1] = t->gbwd.replays; out6[2] = t->gfwd.captures; out6[3] = t->gbwd.captures;
+    out6[4] = t->gfwd.evictions; out6[5] = t->gbwd.evictions;
     return YF_OK;
 }
 #undef YF_TOP
