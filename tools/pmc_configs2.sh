@@ -5,7 +5,7 @@
 # tools/c2_report.py turns them into profiles/r04_configs2_binding.txt.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-COMMON="--steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-configs --no-train --no-live-traffic --in-flight 1 --lanes 1 --res 512 --batch 128"
+COMMON="--steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-configs --no-train --no-extras --no-live-traffic --in-flight 1 --lanes 1 --res 512 --batch 128"
 for DT in f16x3 f16 f32; do
   O=$R/gpurun_out/r04_c2_$DT
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --kernel-trace -d ${O}_wait -o p --output-format csv -- python3 $R/bench.py $COMMON --dtype $DT --dump-ops ${O}_ops.json > ${O}_wait.log 2>&1 || exit 1
@@ -15,6 +15,6 @@ for DT in f16x3 f16 f32; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d ${O}_fetch -o p --output-format csv -- python3 $R/bench.py $COMMON --dtype $DT > ${O}_fetch.log 2>&1 || exit 1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace -d ${O}_write -o p --output-format csv -- python3 $R/bench.py $COMMON --dtype $DT > ${O}_write.log 2>&1 || exit 1
   echo "$DT traffic done"
-  rocprofv3 --kernel-trace --stats -d ${O}_stats -o p --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-configs --no-train --no-live-traffic --in-flight 1 --lanes 1 --res 512 --batch 128 --dtype $DT > ${O}_stats.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --stats -d ${O}_stats -o p --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-configs --no-train --no-extras --no-live-traffic --in-flight 1 --lanes 1 --res 512 --batch 128 --dtype $DT > ${O}_stats.log 2>&1 || exit 1
   tail -1 ${O}_stats.log | cut -c1-300
 done
