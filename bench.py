@@ -479,8 +479,6 @@ def main():
     # frames/s against 281-283 k one at a time (on an unlucky stream pair 253-261 k); 640x512 batch 128: 72.6 k against 69.7 k fp32,
     # 91.4 k against 85.4 k f16x3 (round 2's "no gain at 640x512" was such an unlucky pair)
     in_flight = args.in_flight if args.in_flight > 0 else 2
-    if syn is not None:
-        in_flight = 1    # the dense field is spliced in between model and post-process: one at a time
     lanes = args.lanes if args.lanes else (1 if in_flight > 1 else 2)
     # the small head in line: since it is ONE launch (fusion level 2) the side stream no longer pays at this batch size
     # (tools/fusion_ab.py, one batch at a time on two lanes: 280 k frames/s in line, 273 k on the side stream)
@@ -520,7 +518,10 @@ def main():
             last, pend = None, []
             for _ in range(n):
                 if pipe is not None:
-                    last = pipe.submit(cur["x"], then=gather)
+                    # (dense configurations: the synthetic logit field replaces the heads between model and post-process, inside the
+                    #  batch's own stream: pipeline.BatchPipeline.submit `mid`)
+                    splice = (lambda pred: (pred[0] * 0 + cur["syn"][0], pred[1] * 0 + cur["syn"][1])) if cur["syn"] is not None else None
+                    last = pipe.submit(cur["x"], then=gather, mid=splice)
                     if gather is not None:
                         pend.append(last.extra)
                 else:
@@ -814,8 +815,8 @@ def main():
         io5, x5, syn5 = workload(512, 64, "noise", True)
         cur.update(x=x5, syn=syn5, kmax=1024, n_total=64)
         for dt in ("f16x3", "f32"):
-            mc, pc = make(dt, 2, 1, io5, 512)
-            ec, rawc = timed(mc, pc, 1, args.steps, args.warmup, False)
+            mc, pc = make(dt, 1, 0, io5, 512)
+            ec, rawc = timed(mc, pc, 2, args.steps, args.warmup, False)
             again = pc.detect_raw(forward(mc), kmax=1024)           # the same records from a second, untimed evaluation
             post64 = post_mean_ms(mc, pc, 1024)                     # mean of 10 warmed repetitions on the same logits
             cnt = rawc["counts"].cpu().numpy()
@@ -824,7 +825,7 @@ def main():
                 "config": "BASELINE.json configs[4], per-GPU share: YOLO-Fastest 640x512, 64 frames, dense synthetic head logits "
                           "(SURVEY.md 8(d).5), kmax 1024" + (" -- fp32 beside it" if dt == "f32" else ""),
                 "dtype": dt, "value": round(64 * args.steps / ec, 1), "unit": "frames/s", "ms_per_step": round(1e3 * ec / args.steps, 4),
-                "steps": args.steps, "warmup": args.warmup, "in_flight": 1, "lanes": 2,
+                "steps": args.steps, "warmup": args.warmup, "in_flight": 2, "lanes": 1,
                 "candidates_per_frame": round(cand, 1), "survivors_per_frame": round(float(np.clip(cnt, 0, None).mean()), 1),
                 "frames_over_kmax_or_failed": int((cnt < 0).sum()), "post_ms_per_64_frames": round(post64, 4),
                 "detections_identical_on_re_evaluation": bool(same_detections(rawc, again)),

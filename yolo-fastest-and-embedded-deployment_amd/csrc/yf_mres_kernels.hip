@@ -933,7 +933,15 @@ bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride, bool rel
 {
     // the 8/32 residual blocks at stride 4: on fp32 MFMAs this kernel only ties the VALU block kernel (61.5 vs 64 us alone, nothing end
     // to end); with split-operand fp16 MFMAs, which run beside the depthwise VALU work, it wins
-    if (cin == 8 && cexp == 32 && cout == 8 && res && stride == 1) return dtype == DT_F16X3 && !relu_out;
+    if (cin == 8 && cexp == 32 && cout == 8 && res && stride == 1) {
+        // The res2 pair (8 / 32 / 8 at stride 4) stays on the fp32 VALU block kernel in EVERY dtype since round 4: in an f16x3 engine the
+        // split-operand MFMA form spends as much VALU time (depthwise + operand splits + E records: 0.66 of 80 us at 640x512) as the VALU
+        // kernel needs in total (0.72 of 73 us) and is slower alone -- interleaved A/B (tools/res2_ab.sh, three rounds): 640x512 batch 128
+        // 92.1 -> 92.7 k frames/s (one batch at a time 90.5 -> 92.2 k), 320x256 batch 256 363.9 -> 366.9 k (352.8 -> 359.6 k).
+        // YF_RES2_X3=1 (developer switch) restores round 3's choice.
+        static const bool res2_x3 = getenv("YF_RES2_X3") != nullptr;
+        return dtype == DT_F16X3 && !relu_out && res2_x3;
+    }
 #define MR(ci, ce, co, rs, st, th, tw, np, nw) \
     if (cin == ci && cexp == ce && cout == co && res == rs && stride == st) return relu_out == mres_relu_out(ci, ce, co, st);
     YF_MRES_SHAPES(MR)

@@ -47,13 +47,15 @@ class BatchPipeline:
         self.streams = [torch.cuda.Stream(self.device) for _ in range(depth)]
         self._n = 0
 
-    def submit(self, x, then=None):
+    def submit(self, x, then=None, mid=None):
         """x: float32 GPU tensor [N,input_channel,H,W] -- or uint8 frames [N,h,w] ([N,h,w,3] for a 3-channel model), which take the
         fused pre-process (model.forward_u8: h, w == the net input or exactly 2x) -- ready on the caller's current stream.  Returns a
         ticket at once.
         then(out): optional, called with the batch's result dict INSIDE the batch's stream context -- work it queues (e.g. the
         asynchronous all-gather of the records, dist.all_gather_detections_async) is ordered behind this batch only, not behind the
-        caller's stream; its return value is kept in the ticket's `extra`."""
+        caller's stream; its return value is kept in the ticket's `extra`.
+        mid(pred): optional, called between the model and the post-process inside the batch's stream context; what it returns is
+        post-processed instead of the model's heads (bench.py splices its synthetic dense logit field in this way)."""
         k = self._n % self.depth
         self._n += 1
         s = self.streams[k]
@@ -66,6 +68,8 @@ class BatchPipeline:
                 pred = self.model.forward_u8(x, self.post.input_shape, slot=k + 1)
             else:
                 pred = self.model(x, slot=k + 1)
+            if mid is not None:
+                pred = mid(pred)
             out = self.post.detect_raw(pred, kmax=self.kmax, origin_shape=self.origin_shape, slot=k + 1, packed=self.packed)
             out["head_large"], out["head_small"] = pred
             extra = then(out) if then is not None else None
