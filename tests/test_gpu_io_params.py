@@ -359,3 +359,79 @@ def test_blob_header_is_checked(yf, dev, golden):
     with pytest.raises(RuntimeError, match="Missing key|size mismatch|Unexpected key"):   # strict load: a 3-class checkpoint into a 5-class model
         m = yf.YoloFastest(io_cfg.io_for("c5rgb"))
         m.load_state_dict(sd)
+
+
+@pytest.mark.parametrize("tag,H,W", [("c20", 512, 640), ("c5rgb", 96, 160), ("c80rgb", 96, 160), ("a2", 512, 640)])
+def test_other_io_params_at_other_input_sizes(yf, dev, golden, tag, H, W):
+    """Sizes where the stride-16 / 32 tiles are not whole frames (640x512: several tiles per frame in the head kernels, no chained small
+    head) and a ragged one: heads against the oracle in fp32 and fp64, detections against the C oracle on the engine's own logits."""
+    from oracle import backbone_oracle as bo
+    from oracle import post_oracle_c as poc
+    g = golden("golden_io")
+    C, Cin, A = io_cfg.CONFIG[tag]
+    io = io_cfg.io_for(tag, H, W)
+    sd = io_cfg.state_dict_for(tag, int(g[tag + "_seed"]))
+    m = yf.YoloFastest(io).to(dev).eval()
+    m.load_state_dict({k: v.to(dev) for k, v in sd.items()})
+    u8 = io_cfg.io_inputs(tag + "_sz", Cin, n=2, H=H, W=W)
+    x = bo.preprocess(u8, Cin)
+    with torch.no_grad():
+        hl, hs = m(x.to(dev))
+    ol, os_ = bo.forward(sd, x)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    tl, ts = bo.forward(sd64, x.double())
+    _check_heads(hl, ol.numpy(), tl.numpy(), tag)
+    _check_heads(hs, os_.numpy(), ts.numpy(), tag)
+    post = yf.YOLO_post_process(io["conf_thre"], io["nms_thre"], A, C, io["anchors"], io["input_shape"]).bind(m)
+    ncell = A * (H // 16 * (W // 16) + H // 32 * (W // 32))
+    raw = post.detect_raw((hl, hs), kmax=ncell)
+    for f in range(2):
+        try:
+            r = poc.post_process(hl[f].cpu().numpy(), hs[f].cpu().numpy(), io["anchors"], io["input_shape"][:2], io["conf_thre"], io["nms_thre"], C,
+                                 num_anchors=A)
+        except ZeroDivisionError:
+            assert int(raw["counts"][f]) == -2
+            continue
+        n = r["count"]
+        assert int(raw["counts"][f]) == n
+        assert np.array_equal(raw["src"][f, :n].cpu().numpy(), r["src"]) and np.array_equal(raw["boxes"][f, :n].cpu().numpy(), r["box"])
+        assert np.array_equal(raw["cls"][f, :n].cpu().numpy(), r["cls"])
+
+
+def test_eight_anchors_and_the_cell_limit(yf, dev):
+    """num_anchors = 8 (the most the post-process takes): the model runs at any size; the on-chip post-process holds at most 8191 cells
+    per frame (13-bit field of its sort key / 160 KB of LDS) and says so beyond -- 8 anchors x (16x20 + 8x10) = 3200 cells at 320x256 fit,
+    8 x (32x40 + 16x20) = 12800 at 640x512 do not."""
+    from yolo_fastest_amd import _lib
+    from oracle import backbone_oracle as bo
+    from oracle import post_oracle_c as poc
+    import copy
+    io = copy.deepcopy(yf.config_params["io_params"])
+    anchors = [[[10 + 7 * k, 13 + 5 * k] for k in range(8)], [[40 + 20 * k, 150 - 15 * k] for k in range(8)], [[1, 1]] * 8]
+    io.update(num_cls=2, num_anchors=8, anchors=anchors)
+    m = yf.YoloFastest(io)
+    from collections import OrderedDict
+    sd = OrderedDict((k, torch.from_numpy(np.asarray(v))) for k, v in io_cfg.seeded_state_dict(
+        OrderedDict((k, tuple(v.shape)) for k, v in m.state_dict().items()), 77).items())
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    assert m.num_out == 56
+    u8 = np.random.default_rng(8).integers(0, 256, size=(1, 256, 320), dtype=np.uint8)
+    with torch.no_grad():
+        hl, hs = m(bo.preprocess(u8).to(dev))
+    ol, os_ = bo.forward(sd, bo.preprocess(u8))
+    assert (hl.cpu() - ol).abs().max().item() < 1e-4 and (hs.cpu() - os_).abs().max().item() < 1e-4
+    post = yf.YOLO_post_process(0.5, 0.2, 8, 2, anchors, io["input_shape"]).bind(m)
+    raw = post.detect_raw((hl, hs), kmax=3200)
+    r = poc.post_process(hl[0].cpu().numpy(), hs[0].cpu().numpy(), anchors, [256, 320], 0.5, 0.2, 2, num_anchors=8)
+    n = r["count"]
+    assert int(raw["counts"][0]) == n and n > 50
+    assert np.array_equal(raw["src"][0, :n].cpu().numpy(), r["src"]) and np.array_equal(raw["boxes"][0, :n].cpu().numpy(), r["box"])
+    io5 = dict(io, input_shape=[512, 640, 1])
+    post5 = yf.YOLO_post_process(0.5, 0.2, 8, 2, anchors, io5["input_shape"]).bind(m)
+    with torch.no_grad():
+        h5 = m(torch.zeros(1, 1, 512, 640, device=dev))
+    with pytest.raises(_lib.YFError, match="too many cells"):
+        post5.detect_raw(h5, kmax=64)
+    with pytest.raises(ValueError):
+        yf.YoloFastest(dict(io, num_anchors=9))
