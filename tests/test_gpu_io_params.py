@@ -435,3 +435,36 @@ def test_eight_anchors_and_the_cell_limit(yf, dev):
         post5.detect_raw(h5, kmax=64)
     with pytest.raises(ValueError):
         yf.YoloFastest(dict(io, num_anchors=9))
+
+
+def test_detect_yolo_driver_with_an_rgb_five_class_model(yf, dev, golden, tmp_path):
+    """`Detect_YOLO(device, model_path, config_params, logger).batch_detect(data_path, result_path)` (detect.py:87-192) for io_params other
+    than the shipped ones: a 5-class model on 3-channel frames read from image files -- what it logs and draws equals the direct path
+    (BGR frame -> fused u8 pre-process -> model -> post-process) on the same files."""
+    import logging
+    from PIL import Image
+    g = golden("golden_io")
+    io = io_cfg.io_for("c5rgb")
+    io["origin_img_shape"] = [512, 640, 3]        # frames of twice the net size: the exact-2x box mean per channel + __adjust_coord
+    sd = io_cfg.state_dict_for("c5rgb", int(g["c5rgb_seed"]))
+    torch.save(sd, tmp_path / "m.pth")
+    data, res = tmp_path / "data", tmp_path / "res"
+    data.mkdir(); res.mkdir()
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, size=(3, 512, 640, 3), dtype=np.uint8)      # RGB as stored in the files
+    for i, f in enumerate(frames):
+        Image.fromarray(f).save(data / ("f%d.png" % i))
+    lines = []
+
+    class H(logging.Handler):
+        def emit(self, rec):
+            lines.append(rec.getMessage())
+    logger = logging.getLogger("yf-rgb"); logger.setLevel(logging.INFO); logger.addHandler(H())
+    det = yf.Detect_YOLO(dev, str(tmp_path / "m.pth"), {"io_params": io}, logger)
+    det.batch_detect(str(data), str(res))
+    assert len(lines) == 4 and lines[-1].startswith("detect avg_time") and all((res / ("result_f%d.png" % i)).exists() for i in range(3))
+    bgr = torch.from_numpy(np.ascontiguousarray(frames[:, :, :, ::-1])).to(dev)   # what cv2.imread hands over
+    direct = det.detect_u8(bgr, kmax=1200)
+    for i in range(3):
+        want = ["%s %.2f" % (io["class_names"][int(b[6])], b[4] * b[5]) for b in direct[i]]
+        assert det.last_labels["f%d.png" % i] == want and ("detect finished" in lines[i]) == (len(want) > 0)

@@ -147,8 +147,14 @@ class YOLO_post_process:
         return frames
 
     def detect(self, pred, kmax=64, origin_shape=None, with_src=False):
-        """All frames: [[x1,y1,x2,y2,conf,cls_score,cls], ...] per frame, class-major like detect.py:162-169."""
-        return self.to_lists(self.detect_raw(pred, kmax=kmax, origin_shape=origin_shape), with_src=with_src)
+        """All frames: [[x1,y1,x2,y2,conf,cls_score,cls], ...] per frame, class-major like detect.py:162-169.  kmax is the capacity the
+        first attempt reserves per frame; a frame with more survivors (the count is always the true number) makes this run the
+        post-process once more with room for all of them -- the reference's lists have no capacity."""
+        raw = self.detect_raw(pred, kmax=kmax, origin_shape=origin_shape)
+        most = int(raw["counts"].max().item()) if raw["counts"].numel() else 0
+        if most > kmax:
+            raw = self.detect_raw(pred, kmax=most, origin_shape=origin_shape)
+        return self.to_lists(raw, with_src=with_src)
 
     # -- reference-named methods ------------------------------------------------------------------
     def decode_box(self, pred):
