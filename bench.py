@@ -151,7 +151,7 @@ def live_pmc(res, batch, dtype, frames, kmax, with_issue=False):
                    os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-variants", "--no-configs",
                    "--no-live-traffic", "--no-train", "--no-extras", "--in-flight", "1", "--lanes", "1", "--res", str(res), "--batch", str(batch),
                    "--dtype", dtype, "--frames", frames, "--kmax", str(kmax), "--dump-ops", os.path.join(work, "ops.json")]
-            rc, tail = _run_child(cmd, 180)
+            rc, tail = _run_child(cmd, 120)
             path = os.path.join(d, "p_counter_collection.csv")
             if rc != 0 or not os.path.exists(path):
                 return {}, {}, "rocprofv3 --pmc %s child failed (rc %d): %s" % (counters[0], rc, tail.replace("\n", " | "))
@@ -412,12 +412,14 @@ def main():
     default_wl = args.res == 256 and args.dtype == "f32" and not args.dense and args.frames == "noise"
     if world == 1 and not args.no_live_traffic and not args.dense and not args.exchange_at_1:
         live, live_issue, live_note = live_pmc(args.res, args.batch, args.dtype, args.frames, args.kmax, with_issue=True)
-        if not args.no_configs and default_wl:     # BASELINE configs[2]: HBM bytes and issue counters of the 640x512 fp16-pipe passes
-            for dt in ("f16x3", "f16"):
+        if not args.no_configs and default_wl and live_note is None:   # (a profiler that failed once is not asked again)
+            for dt in ("f16x3", "f16"):                # BASELINE configs[2]: HBM bytes and issue counters of the 640x512 fp16-pipe passes
                 cfg2_pmc[dt] = live_pmc(512, 128, dt, "noise", 64, with_issue=True)
+                if cfg2_pmc[dt][2] is not None:
+                    break
 
     train_pmc = {}
-    if world == 1 and not args.no_train and not args.no_live_traffic and args.res == 256 and args.dtype == "f32" and not args.dense:
+    if world == 1 and not args.no_train and not args.no_live_traffic and args.res == 256 and args.dtype == "f32" and not args.dense and live_note is None:
         train_pmc[256] = live_train_traffic(256)
 
     import numpy as np
