@@ -51,6 +51,9 @@ __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane
 
 
 // Diagnostic build only (-DYF_STAMP, tools/kbench.hip): per-phase shader-clock sums, written to a buffer nothing else reads.
+#ifndef YF_FB_HOIST
+#define YF_FB_HOIST 0   // 1: the res2 pair keeps its region's input channels in registers across the expansion chunks (A/B: DESIGN.md)
+#endif
 #ifdef YF_STAMP
 __device__ __forceinline__ unsigned long long yf_stamp()
 {
@@ -143,12 +146,37 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
 #pragma unroll
         for (int co = 0; co < COUT / 2; ++co) acc2[p][co] = fb_f32x2{0.f, 0.f};
 
+    // HOIST (blocks with several expansion chunks whose items are whole pixel blocks: the res2 pair): a region pixel's input channels do
+    // not depend on the chunk, yet the item loop below re-loaded them in every chunk -- and every load was one exposed L2 round trip per
+    // item and chunk (load, wait, 32 packed FMAs, next item).  With HOIST the wave's MAXI items are loaded ONCE, all requests in flight
+    // together, before the chunk loop, and stay in registers (MAXI x CIN VGPRs).
+    constexpr int MAXI = (NITEM + NW - 1) / NW;
+    constexpr bool HOIST = YF_FB_HOIST && !PRE && !XL && CEXP / EC > 1 && NCG == 1 && PE == 1 && MAXI * CIN <= 32;
+    float xh[HOIST ? MAXI : 1][CIN];
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int it = 0; it < MAXI; ++it) {
+            const int rp = (wave + it * NW) * 64 + lane;      // item = pixel block (NCG == 1, PE == 1); beyond the region: pixel 0, unused
+            const int ryh = (rp < NRP ? rp : 0) / RW, rxh = (rp < NRP ? rp : 0) - ryh * RW;
+            const int iy = iy0 + ryh, ix = ix0 + rxh;
+            const bool in = rp < NRP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const T* __restrict__ srch = reinterpret_cast<const T*>(a.in) + (((long)n * a.H + (in ? iy : 0)) * a.W + (in ? ix : 0)) * CIN;
+#pragma unroll
+            for (int k = 0; k < CIN; k += 4) {
+                const float4 t = ld4<T>(srch + k);
+                xh[it][k] = t.x; xh[it][k + 1] = t.y; xh[it][k + 2] = t.z; xh[it][k + 3] = t.w;
+            }
+        }
+    }
+
     YF_STAMP_DECL
     for (int ch = 0; ch < CEXP / EC; ++ch) {
         YF_STAMP_AT(0)
         const cfloat* __restrict__ wc = (const cfloat*)(a.wp + ch * CHF);  // this chunk's weights (wave-uniform, constant address space -> scalar loads)
         // ---------------- expansion of the halo'd region into LDS: PE pixels per lane per item ----------------
-        for (int item = wave; item < NITEM; item += NW) {
+#pragma unroll
+        for (int it = 0; it < (HOIST ? MAXI : 1); ++it)   // HOIST: item it of this wave, unrolled so that xh[it] is a register; else the plain item loop
+        for (int item = HOIST ? wave + it * NW : wave; item < (HOIST ? (wave + it * NW < NITEM ? wave + it * NW + 1 : 0) : NITEM); item += NW) {
             const int pb = item % NPB, cg = item / NPB;
             float x[PE][CIN];
             int ry[PE], rx[PE];
@@ -259,6 +287,9 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
                         float4 t = *reinterpret_cast<const float4*>(&X[rpc * XP + k]);
                         x[p][k] = t.x; x[p][k + 1] = t.y; x[p][k + 2] = t.z; x[p][k + 3] = t.w;
                     }
+                } else if constexpr (HOIST) {
+#pragma unroll
+                    for (int k = 0; k < CIN; ++k) x[p][k] = xh[it][k];
                 } else {
                     const T* __restrict__ src = reinterpret_cast<const T*>(a.in) + (((long)n * a.H + (inimg[p] ? iy : 0)) * a.W + (inimg[p] ? ix : 0)) * CIN;
 #pragma unroll
