@@ -147,7 +147,7 @@ def test_post_process_bit_exact_for_other_io_params(yf, dev, golden, tag):
             assert np.array_equal(np.array([c[:4] for c in cands]), wc["box"]) and [c[6] for c in cands] == wc["cls"].tolist()
 
 
-@pytest.mark.parametrize("tag", ["c5rgb", "c20", "a2"])
+@pytest.mark.parametrize("tag", ["c5rgb", "c20", "a2", "ch2"])
 def test_detect_single_call_and_own_logits(yf, dev, golden, tag):
     """yf_detect (forward + decode + NMS in one C call, two lanes) on the engine's OWN logits == the C oracle on those logits."""
     from oracle import post_oracle_c as poc
@@ -171,30 +171,31 @@ def test_detect_single_call_and_own_logits(yf, dev, golden, tag):
         assert np.array_equal(raw["cls"][f, :n].cpu().numpy(), r["cls"])
 
 
-@pytest.mark.parametrize("tag", ["c5rgb", "c80rgb"])
+@pytest.mark.parametrize("tag", ["c5rgb", "c80rgb", "ch2", "ch4"])
 def test_rgb_u8_frames_fused_preprocess(yf, dev, golden, tag):
-    """3-channel frames as cv2.imread returns them (HWC, BGR): yf_preprocess_u8 == detect.py:119-124's arithmetic, and the fused
-    u8 stem (yf_forward_u8) is bit-identical to pre-process + forward; also from frames of exactly twice the net size (2x2 box mean per
-    channel)."""
+    """Multi-channel frames as cv2.imread returns them (HWC; 3 channels: BGR): yf_preprocess_u8 == detect.py:119-124's arithmetic
+    (`img[:, :, ::-1]` reverses the channel axis whatever its length), and the fused u8 stem (yf_forward_u8) is bit-identical to
+    pre-process + forward; also from frames of exactly twice the net size (2x2 box mean per channel)."""
     from oracle import backbone_oracle as bo
     m, _, io = _model(yf, dev, golden, tag)
-    u8 = io_cfg.io_inputs(tag, 3)
+    Cin = io_cfg.CONFIG[tag][1]
+    u8 = io_cfg.io_inputs(tag, Cin)
     x = yf.preprocess_u8(m, torch.from_numpy(u8).to(dev), io["input_shape"])
-    assert torch.equal(x.cpu(), bo.preprocess(u8, 3))
+    assert torch.equal(x.cpu(), bo.preprocess(u8, Cin))
     with torch.no_grad():
         a = m(x)
         b = m.forward_u8(torch.from_numpy(u8).to(dev), io["input_shape"])
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    big = np.random.default_rng(5).integers(0, 256, size=(2, 512, 640, 3), dtype=np.uint8)
+    big = np.random.default_rng(5).integers(0, 256, size=(2, 512, 640, Cin), dtype=np.uint8)
     small = ((big[:, 0::2, 0::2].astype(np.uint16) + big[:, 0::2, 1::2] + big[:, 1::2, 0::2] + big[:, 1::2, 1::2] + 2) >> 2).astype(np.uint8)
     x2 = yf.preprocess_u8(m, torch.from_numpy(big).to(dev), io["input_shape"])
-    assert torch.equal(x2.cpu(), bo.preprocess(small, 3))
+    assert torch.equal(x2.cpu(), bo.preprocess(small, Cin))
     with torch.no_grad():
         a = m(x2)
         b = m.forward_u8(torch.from_numpy(big).to(dev), io["input_shape"])
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     with pytest.raises(ValueError):
-        m(torch.zeros(1, 1, 256, 320, device=dev))       # a 3-channel model on a 1-channel tensor
+        m(torch.zeros(1, 1, 256, 320, device=dev))       # a multi-channel model on a 1-channel tensor
 
 
 @pytest.mark.parametrize("tag", io_cfg.TAGS)
@@ -237,7 +238,7 @@ def test_validation_decode_nms_and_loss_for_other_io_params(yf, dev, golden, tag
         assert np.abs(x.grad.cpu().numpy() - wg).max() <= 2e-5 * np.abs(wg).max()
 
 
-@pytest.mark.parametrize("tag", ["c5rgb", "a2"])
+@pytest.mark.parametrize("tag", ["c5rgb", "a2", "ch4"])
 def test_training_step_for_other_io_params(yf, dev, golden, tag):
     """model.train(); pred = model(imgs); the two-head loss; loss.backward() (train.py:111-131) for an RGB 5-class and a 2-anchor model
     against the reference's own iteration: train-mode heads, the seven losses, a strided sample and the per-tensor sums of every

@@ -272,7 +272,7 @@ def test_relu_flips_confine_the_fp32_gradient_error(golden):
     assert "conv5_3" not in fr.upstream("conv4_1_2") and "conv5_2" in fr.upstream("conv4_1_2") and "deconv5_1" not in fr.upstream("conv5_5")
 
 
-# ---- io_params generality: the oracles against what the REFERENCE computed for five (num_cls, input_channel,
+# ---- io_params generality: the oracles against what the REFERENCE computed for seven (num_cls, input_channel,
 # num_anchors) configurations with numpy-seeded weights (tests/golden/make_golden.py main_io -> golden_io.npz) ----
 from tests import io_cfg  # noqa: E402
 
@@ -338,7 +338,7 @@ def test_io_configs_val_and_loss_oracles(golden, tag):
         np.testing.assert_allclose(grad.numpy(), g[f"{tag}_{name}_grad"], rtol=0, atol=1e-8)
 
 
-@pytest.mark.parametrize("tag", ["c5rgb", "a2"])
+@pytest.mark.parametrize("tag", ["c5rgb", "a2", "ch4"])
 def test_io_configs_train_mode_oracle(golden, tag):
     """The train-mode graph + loss oracle against the reference's own iteration for an RGB 5-class and a 2-anchor model."""
     from oracle import loss_oracle as lo

@@ -305,10 +305,10 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const uint8_t* __restri
     out[idx] = (v - 128.0f) / 255.0f;
 }
 
-// The same for 3-channel frames: `in` is what cv2.imread returns, HWC BGR u8 [N,h,w,3]; `out` NCHW float [N,3,H,W] with the channel
-// order reversed (detect.py:119 `img[:, :, ::-1].transpose(2, 0, 1)`); the exact-2x resize is the 2x2 box mean per channel.
+// The same for multi-channel frames: `in` is what cv2.imread returns, HWC u8 [N,h,w,C] (C = 3: BGR); `out` NCHW float [N,C,H,W] with the
+// channel order reversed (detect.py:119 `img[:, :, ::-1].transpose(2, 0, 1)`); the exact-2x resize is the 2x2 box mean per channel.
 __global__ void __launch_bounds__(256) preprocess3_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, long total, int H, int W,
-                                                           int down2)
+                                                           int down2, int C)
 {
     long idx = (long)blockIdx.x * 256 + threadIdx.x;   // over the NCHW output
     if (idx >= total) return;
@@ -316,16 +316,16 @@ __global__ void __launch_bounds__(256) preprocess3_kernel(const uint8_t* __restr
     long t = idx / W;
     const int y = (int)(t % H);
     t /= H;
-    const int c = (int)(t % 3);
-    const long n = t / 3;
-    const int sc = 2 - c;
+    const int c = (int)(t % C);
+    const long n = t / C;
+    const int sc = C - 1 - c;
     float v;
     if (down2) {
-        const long sw = 2L * W * 3;
-        const uint8_t* p = in + (n * 2 * H + 2 * y) * sw + 2 * x * 3 + sc;
-        v = (float)((p[0] + p[3] + p[sw] + p[sw + 3] + 2) >> 2);
+        const long sw = 2L * W * C;
+        const uint8_t* p = in + (n * 2 * H + 2 * y) * sw + 2 * x * C + sc;
+        v = (float)((p[0] + p[C] + p[sw] + p[sw + C] + 2) >> 2);
     } else {
-        v = (float)in[((n * H + y) * W + x) * 3 + sc];
+        v = (float)in[((n * H + y) * W + x) * C + sc];
     }
     out[idx] = (v - 128.0f) / 255.0f;
 }
@@ -401,7 +401,9 @@ int launch_dense3x3s2(int cin, int cout, const DenseArgs& a, hipStream_t s)
     dim3 grid((unsigned)((a.total + 255) / 256));
     if (cin == 1 && cout == 8) hipLaunchKernelGGL((dense3x3s2_kernel<1, 8>), grid, dim3(256), 0, s, a);
     else if (cin == 24 && cout == 24) hipLaunchKernelGGL((dense3x3s2_kernel<24, 24>), grid, dim3(256), 0, s, a);
+    else if (cin == 2 && cout == 8) hipLaunchKernelGGL(conv0_planar_kernel<2>, grid, dim3(256), 0, s, a);
     else if (cin == 3 && cout == 8) hipLaunchKernelGGL(conv0_planar_kernel<3>, grid, dim3(256), 0, s, a);
+    else if (cin == 4 && cout == 8) hipLaunchKernelGGL(conv0_planar_kernel<4>, grid, dim3(256), 0, s, a);
     else return -1;
     return 0;
 }
@@ -432,8 +434,8 @@ void launch_nhwc_to_nchw(const float* in, float* out, long N, int C, long HW, hi
 void launch_preprocess(const uint8_t* in, float* out, long N, int H, int W, int down2, hipStream_t s, int channels)
 {
     long total = N * H * W * channels;
-    if (channels == 3)
-        hipLaunchKernelGGL(preprocess3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, H, W, down2);
+    if (channels > 1)
+        hipLaunchKernelGGL(preprocess3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, H, W, down2, channels);
     else
         hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, H, W, down2);
 }

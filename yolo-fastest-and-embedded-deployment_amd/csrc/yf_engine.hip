@@ -770,8 +770,8 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
     if (memcmp(hd.magic, "YFHIPW01", 8) || hd.version != 1) return fail(YF_E_BLOB, "bad magic/version");
     if (hd.n_layers != (uint32_t)kNumLayers)
         return fail(YF_E_BLOB, "blob describes n_layers=%u; YoloFastest has %d", hd.n_layers, kNumLayers);
-    if (hd.input_channel != 1 && hd.input_channel != 3)
-        return fail(YF_E_BLOB, "input_channel=%u: the HIP engine implements 1 (gray) and 3 (cv2's BGR) input channels", hd.input_channel);
+    if (hd.input_channel < 1 || hd.input_channel > 4)
+        return fail(YF_E_BLOB, "input_channel=%u: the HIP engine implements 1 .. 4 input channels", hd.input_channel);
     if (hd.num_anchors < 1 || hd.num_anchors > (uint32_t)yf::POST_MAX_ANCHORS || hd.num_cls < 1 || hd.num_cls > 4096 ||
         hd.num_out != hd.num_anchors * (5 + hd.num_cls))
         return fail(YF_E_BLOB, "blob describes num_anchors=%u num_cls=%u num_out=%u: need 1..%d anchors, >= 1 class and num_out == "

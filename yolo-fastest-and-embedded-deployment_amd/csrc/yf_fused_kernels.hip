@@ -81,8 +81,9 @@ template <int CIN, int CEXP, int COUT, int S, bool RES, bool RELU_OUT, bool PRE,
           int EC, int CG, int PE, bool XL, typename T, int C0 = 1>
 __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
 {
-    // C0 (PRE only): input channels of conv0 = io_params input_channel (yolo_fastest.py:78): 1 (gray) or 3 (NCHW planes; u8: HWC BGR)
-    static_assert(C0 == 1 || (PRE && !XL && C0 == 3), "conv0 on 1 or 3 input channels");
+    // C0 (PRE only): input channels of conv0 = io_params input_channel (yolo_fastest.py:78): 1 (gray), 3 (cv2's BGR), or 2 / 4 (NCHW
+    // planes; u8 frames: HWC, channel order reversed like `img[:, :, ::-1]`, detect.py:119)
+    static_assert(C0 == 1 || (PRE && !XL && C0 >= 2 && C0 <= 4), "conv0 on 1 .. 4 input channels");
     constexpr int NT = TYB * TXB, NW = NT / 64;
     constexpr int O_B1 = CIN * EC, O_WD = O_B1 + EC, O_BD = O_WD + 9 * EC, O_W2 = O_BD + EC, CHF = O_W2 + EC * COUT;
     static_assert(CHF == fb_chunk_floats(CIN, COUT, EC), "pack layout");
@@ -559,11 +560,16 @@ int launch_fused_block(int cin, int cexp, int cout, int stride, bool res, bool r
                        hipStream_t s, int dtype)
 {
     const bool pre = pre_c0 != 0;
-    if (pre && pre_c0 != 1 && pre_c0 != 3) return -1;
-    if (pre_c0 == 3) {   // the stem of an RGB model: the same tile shape, conv0 over 3 input planes
+    if (pre && (pre_c0 < 1 || pre_c0 > 4)) return -1;
+    if (pre_c0 > 1) {   // the stem of a multi-channel model: the same tile shape, conv0 over C0 input planes
         if (!(cin == 8 && cexp == 8 && cout == 4 && stride == 1 && !res && !relu_out)) return -1;
-        return dtype == DT_F16 ? launch_fb_t<8, 8, 4, 1, false, false, true, 16, 16, YF_STEM_BH, YF_STEM_BW, 8, 8, 1, false, half_t, 3>(a, N, s)
-                               : launch_fb_t<8, 8, 4, 1, false, false, true, 16, 16, YF_STEM_BH, YF_STEM_BW, 8, 8, 1, false, float, 3>(a, N, s);
+#define YF_STEM_C0(C0_)                                                                                                                            \
+        if (pre_c0 == C0_)                                                                                                                          \
+            return dtype == DT_F16 ? launch_fb_t<8, 8, 4, 1, false, false, true, 16, 16, YF_STEM_BH, YF_STEM_BW, 8, 8, 1, false, half_t, C0_>(a, N, s) \
+                                   : launch_fb_t<8, 8, 4, 1, false, false, true, 16, 16, YF_STEM_BH, YF_STEM_BW, 8, 8, 1, false, float, C0_>(a, N, s);
+        YF_STEM_C0(2) YF_STEM_C0(3) YF_STEM_C0(4)
+#undef YF_STEM_C0
+        return -1;
     }
 #define FB(ci, ce, co, st, rs, ro, pr, tyb, txb, bh, bw, ec, cg, pe, xl)                                          \
     if (cin == ci && cexp == ce && cout == co && stride == st && res == rs && relu_out == ro && pre == pr)         \

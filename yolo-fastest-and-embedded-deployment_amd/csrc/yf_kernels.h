@@ -197,7 +197,7 @@ void launch_nhwc_to_nchw(const float* in, float* out, long N, int C, long HW, hi
 void launch_preprocess(const uint8_t* in, float* out, long N, int H, int W, int down2, hipStream_t s, int channels = 1);   // channels 3: HWC BGR in, NCHW RGB planes out
 
 struct FbArgs {
-    const float* in;              // NHWC [N,H,W,CIN]; PRE: the net input, NCHW planes [N,C0,2H,2W] (C0 = io_params input_channel: 1 or 3)
+    const float* in;              // NHWC [N,H,W,CIN]; PRE: the net input, NCHW planes [N,C0,2H,2W] (C0 = io_params input_channel: 1 .. 4)
     const float *w0, *b0;         // PRE only: conv0 [9][C0][8], [8]
     const float* wp;              // chunk-major weight stream of expand / depthwise / project (fb_pack_weights)
     float* out;                   // NHWC [N,Ho,Wo,COUT]

@@ -69,6 +69,8 @@ class Detect_YOLO():
         ori = np.asarray(img.convert("RGB"))
         if self.model.input_channel == 3:
             return np.ascontiguousarray(ori[:, :, ::-1]), ori
+        if self.model.input_channel != 1:      # cv2.imread as detect.py:108-113 calls it yields 1 or 3 channels: nothing to mirror
+            raise ValueError("image files decode to 1 or 3 channels; feed a %d-channel model through detect_u8" % self.model.input_channel)
         return np.asarray(img.convert("L")), ori
 
     def detect_u8(self, u8, kmax=64):

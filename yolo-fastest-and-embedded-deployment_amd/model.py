@@ -7,7 +7,7 @@ Drop-in surface kept:
     (src/detect.py:90-91), `.to(device)` / `.eval()` chain (:89);
   * `model(x)`: x float32 [N,input_channel,H,W] NCHW, H and W multiples of 32 -> `(head_large, head_small)` float32
     NCHW [N, num_anchors * (5 + num_cls), ...] on the same device (:218).  Every num_cls and num_anchors (up to 8) of io_params is
-    implemented, and input_channel 1 (gray) or 3 (cv2's BGR frames, detect.py:109-119).
+    implemented, and input_channel 1 (gray), 3 (cv2's BGR frames, detect.py:109-119), 2 or 4.
 The torch.nn modules below are parameter CONTAINERS only (they give the state-dict its names and shapes);
 they are never called.  In eval mode forward() packs them once (BN fold, packer.py) and runs the tuned HIP engine; in train mode it
 runs the training operators (training.py: batch-statistics BatchNorm, differentiable).  There is no CPU path: a non-GPU tensor or
@@ -96,8 +96,8 @@ class YoloFastest(nn.Module):
         num_anchor = io_params["num_anchors"]
         self.num_anchors = num_anchor
         self.num_out = num_anchor * (5 + self.num_cls)
-        if self.input_channel not in (1, 3):
-            raise NotImplementedError("the HIP engine implements input_channel 1 (gray) and 3 (cv2's BGR frames), not %r"
+        if self.input_channel not in (1, 2, 3, 4):
+            raise NotImplementedError("the HIP engine implements input_channel 1 (gray), 3 (cv2's BGR frames), 2 and 4, not %r"
                                       % (self.input_channel,))
         if not (1 <= int(num_anchor) <= 8) or int(self.num_cls) < 1:
             raise ValueError("num_anchors must be 1..8 and num_cls >= 1")
