@@ -52,8 +52,8 @@ __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane
 
 // Diagnostic build only (-DYF_STAMP, tools/kbench.hip): per-phase shader-clock sums, written to a buffer nothing else reads.
 #ifndef YF_FB_HOIST
-#define YF_FB_HOIST 0   // 1: the res2 pair keeps its region's input channels in registers across the expansion chunks (A/B: DESIGN.md)
-#endif
+#define YF_FB_HOIST 2   // >= 1: the res2 pair keeps its region's input channels in registers across the expansion chunks; 2: single-chunk
+#endif                  // blocks (res1_1) request all their items' inputs together as well (A/B: DESIGN.md section 4)
 #ifdef YF_STAMP
 __device__ __forceinline__ unsigned long long yf_stamp()
 {
@@ -147,12 +147,12 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
 #pragma unroll
         for (int co = 0; co < COUT / 2; ++co) acc2[p][co] = fb_f32x2{0.f, 0.f};
 
-    // HOIST (blocks with several expansion chunks whose items are whole pixel blocks: the res2 pair): a region pixel's input channels do
-    // not depend on the chunk, yet the item loop below re-loaded them in every chunk -- and every load was one exposed L2 round trip per
-    // item and chunk (load, wait, 32 packed FMAs, next item).  With HOIST the wave's MAXI items are loaded ONCE, all requests in flight
-    // together, before the chunk loop, and stay in registers (MAXI x CIN VGPRs).
+    // HOIST (blocks whose items are whole pixel blocks: res1_1, the res2 pair): a region pixel's input channels do not depend on the
+    // chunk, yet the item loop below re-loaded them in every chunk -- and every load was one exposed L2 round trip per item and chunk
+    // (load, wait, 16 / 32 packed FMAs, next item).  With HOIST the wave's MAXI items are loaded ONCE, all requests in flight together,
+    // before the chunk loop, and stay in registers (MAXI x CIN VGPRs).
     constexpr int MAXI = (NITEM + NW - 1) / NW;
-    constexpr bool HOIST = YF_FB_HOIST && !PRE && !XL && CEXP / EC > 1 && NCG == 1 && PE == 1 && MAXI * CIN <= 32;
+    constexpr bool HOIST = YF_FB_HOIST && !PRE && !XL && (CEXP / EC > 1 || YF_FB_HOIST > 1) && NCG == 1 && PE == 1 && MAXI * CIN <= 32;
     float xh[HOIST ? MAXI : 1][CIN];
     if constexpr (HOIST) {
 #pragma unroll
