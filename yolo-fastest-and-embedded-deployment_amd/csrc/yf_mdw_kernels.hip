@@ -285,76 +285,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
                     st4<TT>(reinterpret_cast<TT*>(a.out) + (((long)n * a.H + gy) * a.W + gx) * N + nt * 16 + 4 * q,
                             make_float4(acc[i][nt][0] + bias.x, acc[i][nt][1] + bias.y, acc[i][nt][2] + bias.z, acc[i][nt][3] + bias.w));
             }
-        } else if constexpr (HM == 2) {
-            // any head width: pairs of column tiles in a run-time loop; the fragments of a pair come from global memory (all of a
-            // pair's loads are requested before its first MFMA); same k order per output channel as mode 1
-            const int nthp = mdw_head_tiles(a.headn);
-            const float* hwg = a.wp + OFF_HW;
-            const float* hbg = hwg + (H16 ? WM * (N / 16) * nthp * 128 : KSH * nthp * 64);
-            float hv[NT][4];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float4 bias = *reinterpret_cast<const float4*>(bpw + nt * 16 + 4 * q);
-                hv[nt][0] = acc[i][nt][0] + bias.x; hv[nt][1] = acc[i][nt][1] + bias.y; hv[nt][2] = acc[i][nt][2] + bias.z; hv[nt][3] = acc[i][nt][3] + bias.w;
-            }
-#pragma unroll 1
-            for (int pr = 0; pr < nthp; pr += 2) {
-                f32x4 h[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-                if constexpr (X3) {
-                    const f16x4* hwh = reinterpret_cast<const f16x4*>(hwg);
-                    const f16x4* hwl = hwh + (N / 16) * nthp * 64;
-                    f16x4 fh[NT][2], fl[NT][2];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int nth = 0; nth < 2; ++nth) { fh[nt][nth] = hwh[(nt * nthp + pr + nth) * 64 + lane]; fl[nt][nth] = hwl[(nt * nthp + pr + nth) * 64 + lane]; }
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        f16x4 bh, bl;
-                        split_f16x4(hv[nt][0], hv[nt][1], hv[nt][2], hv[nt][3], bh, bl);
-#pragma unroll
-                        for (int nth = 0; nth < 2; ++nth) {
-                            h[nth] = __builtin_amdgcn_mfma_f32_16x16x16f16(fl[nt][nth], bh, h[nth], 0, 0, 0);
-                            h[nth] = __builtin_amdgcn_mfma_f32_16x16x16f16(fh[nt][nth], bl, h[nth], 0, 0, 0);
-                            h[nth] = __builtin_amdgcn_mfma_f32_16x16x16f16(fh[nt][nth], bh, h[nth], 0, 0, 0);
-                        }
-                    }
-                } else if constexpr (H16) {
-                    const f16x4* hwh = reinterpret_cast<const f16x4*>(hwg);
-                    f16x4 fh[NT][2];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int nth = 0; nth < 2; ++nth) fh[nt][nth] = hwh[(nt * nthp + pr + nth) * 64 + lane];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const f16x4 bh = f16x4{(half_t)hv[nt][0], (half_t)hv[nt][1], (half_t)hv[nt][2], (half_t)hv[nt][3]};
-#pragma unroll
-                        for (int nth = 0; nth < 2; ++nth) h[nth] = __builtin_amdgcn_mfma_f32_16x16x16f16(fh[nt][nth], bh, h[nth], 0, 0, 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        float f[4][2];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-#pragma unroll
-                            for (int nth = 0; nth < 2; ++nth) f[j][nth] = hwg[((nt * 4 + j) * nthp + pr + nth) * 64 + lane];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-#pragma unroll
-                            for (int nth = 0; nth < 2; ++nth) h[nth] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[j][nth], hv[nt][j], h[nth], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int nth = 0; nth < 2; ++nth)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int hc = (pr + nth) * 16 + 4 * q + reg;
-                        if (hc < a.headn && inside) a.out[(((long)n * a.headn + hc) * a.H + gy) * a.W + gx] = h[nth][reg] + hbg[hc];  // NCHW
-                    }
-            }
-        } else {
+        } else if constexpr (HM == 1) {
             const float* hw = WL + OFF_HW;
             const float* hb = WL + OFF_HB;
             f32x4 h[NTH] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -393,6 +324,115 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
                     const int hc = nth * 16 + 4 * q + reg;
                     if (hc < a.headn && inside) a.out[(((long)n * a.headn + hc) * a.H + gy) * a.W + gx] = h[nth][reg] + hb[hc];  // NCHW
                 }
+        }
+    }
+    if constexpr (HM == 2) {
+        // any head width: pairs of column tiles in a run-time loop, the fragments of a pair from global memory / L2.  The pair loop is
+        // the OUTER one: a pair's fragments (all k-blocks) are requested together and serve every M-tile of the wave (with the tile
+        // loop outside, each tile re-read them, k-block by k-block: 122 us for the 255-channel head_4 launch against 40 us for 24
+        // channels).  Same k order per output channel as mode 1.
+        const int nthp = mdw_head_tiles(a.headn);
+        const float* hwg = a.wp + OFF_HW;
+        const float* hbg = hwg + (H16 ? WM * (N / 16) * nthp * 128 : KSH * nthp * 64);
+        int gyv[MTOW], gxv[MTOW];
+        bool ins[MTOW];
+#pragma unroll
+        for (int i = 0; i < MTOW; ++i) {
+            const int op = out_pixel(wave, i, r);
+            const int oy = op / TW, ox = op - oy * TW;
+            gyv[i] = oy0 + oy; gxv[i] = ox0 + ox;
+            ins[i] = (EVEN || wave + i * NWAVE < MTO) && gyv[i] < a.H && gxv[i] < a.W;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 bias = *reinterpret_cast<const float4*>(bpw + nt * 16 + 4 * q);
+                acc[i][nt][0] += bias.x; acc[i][nt][1] += bias.y; acc[i][nt][2] += bias.z; acc[i][nt][3] += bias.w;
+            }
+        }
+#pragma unroll 1
+        for (int pr = 0; pr < nthp; pr += 2) {
+            if constexpr (X3) {
+                const f16x4* hwh = reinterpret_cast<const f16x4*>(hwg);
+                const f16x4* hwl = hwh + (N / 16) * nthp * 64;
+                f16x4 fh[NT][2], fl[NT][2];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int nth = 0; nth < 2; ++nth) { fh[nt][nth] = hwh[(nt * nthp + pr + nth) * 64 + lane]; fl[nt][nth] = hwl[(nt * nthp + pr + nth) * 64 + lane]; }
+#pragma unroll
+                for (int i = 0; i < MTOW; ++i) {
+                    if (!EVEN && wave + i * NWAVE >= MTO) continue;
+                    f32x4 h[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        f16x4 bh, bl;
+                        split_f16x4(acc[i][nt][0], acc[i][nt][1], acc[i][nt][2], acc[i][nt][3], bh, bl);
+#pragma unroll
+                        for (int nth = 0; nth < 2; ++nth) {
+                            h[nth] = __builtin_amdgcn_mfma_f32_16x16x16f16(fl[nt][nth], bh, h[nth], 0, 0, 0);
+                            h[nth] = __builtin_amdgcn_mfma_f32_16x16x16f16(fh[nt][nth], bl, h[nth], 0, 0, 0);
+                            h[nth] = __builtin_amdgcn_mfma_f32_16x16x16f16(fh[nt][nth], bh, h[nth], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int nth = 0; nth < 2; ++nth)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int hc = (pr + nth) * 16 + 4 * q + reg;
+                            if (hc < a.headn && ins[i]) a.out[(((long)n * a.headn + hc) * a.H + gyv[i]) * a.W + gxv[i]] = h[nth][reg] + hbg[hc];  // NCHW
+                        }
+                }
+            } else if constexpr (H16) {
+                const f16x4* hwh = reinterpret_cast<const f16x4*>(hwg);
+                f16x4 fh[NT][2];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int nth = 0; nth < 2; ++nth) fh[nt][nth] = hwh[(nt * nthp + pr + nth) * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < MTOW; ++i) {
+                    if (!EVEN && wave + i * NWAVE >= MTO) continue;
+                    f32x4 h[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const f16x4 bh = f16x4{(half_t)acc[i][nt][0], (half_t)acc[i][nt][1], (half_t)acc[i][nt][2], (half_t)acc[i][nt][3]};
+#pragma unroll
+                        for (int nth = 0; nth < 2; ++nth) h[nth] = __builtin_amdgcn_mfma_f32_16x16x16f16(fh[nt][nth], bh, h[nth], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int nth = 0; nth < 2; ++nth)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int hc = (pr + nth) * 16 + 4 * q + reg;
+                            if (hc < a.headn && ins[i]) a.out[(((long)n * a.headn + hc) * a.H + gyv[i]) * a.W + gxv[i]] = h[nth][reg] + hbg[hc];  // NCHW
+                        }
+                }
+            } else {
+                float f[NT][4][2];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int nth = 0; nth < 2; ++nth) f[nt][j][nth] = hwg[((nt * 4 + j) * nthp + pr + nth) * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < MTOW; ++i) {
+                    if (!EVEN && wave + i * NWAVE >= MTO) continue;
+                    f32x4 h[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int nth = 0; nth < 2; ++nth) h[nth] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[nt][j][nth], acc[i][nt][j], h[nth], 0, 0, 0);
+#pragma unroll
+                    for (int nth = 0; nth < 2; ++nth)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int hc = (pr + nth) * 16 + 4 * q + reg;
+                            if (hc < a.headn && ins[i]) a.out[(((long)n * a.headn + hc) * a.H + gyv[i]) * a.W + gxv[i]] = h[nth][reg] + hbg[hc];  // NCHW
+                        }
+                }
+            }
         }
     }
     MDW_STAMP(6)   // epilogue
@@ -699,7 +739,6 @@ static int launch_mdw_t(MdwArgs a, int Nf, hipStream_t s)
 {
     a.tiles_y = (a.H + TH - 1) / TH;
     a.tiles_x = (a.W + TW - 1) / TW;
-    constexpr int NRP = (TH + 4) * (TW + 4);
     constexpr size_t lds = ((size_t)16 * mdw_epl(TH, TW, NWAVE) + mdw_stream_floats(C, N, HM == 1 ? 32 : 0, wmode_of<T>())) * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done[YF_MAX_DEVICES] = {};
