@@ -25,11 +25,13 @@
 // reads and phase 1's writes are conflict-free (bank rules of MI355X_MICROARCH.md).
 #include "yf_kernels.h"
 #include <math.h>
+#include <stdlib.h>
 #include <type_traits>
 
 namespace yf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 constexpr int TH = 8, TW = 16;             // output tile
@@ -453,9 +455,196 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k19r_kernel (fp32): the same three layers WITHOUT the region buffers.  conv1_8 is a K = 4 GEMM, one v_mfma_f32_16x16x4_f32 per 16
+// pixels and 16 channels, and the MFMA's result layout (lane (pixel p, group j): channels 4j .. 4j+3 of pixel p) IS the B operand
+// of conv1_9's k-steps for those channels -- the chain yf_dcat_kernels.hip uses for deconv5_1 -> conv4_1_1.  So conv1_8 is evaluated
+// PER TAP, in registers, right in front of that tap's conv1_9 k-steps (channels 16..23: eight FMAs per lane on the VALU, two channels per
+// lane group), and its 24-channel tensor never exists -- not in HBM and not in LDS.  What that buys against k19m_kernel: no 2 x 55 KB
+// region buffers (a wave needs its 3 x 33 four-channel input pixels: 2.4 KB), hence no workgroup barrier per tile and no phase-1 store
+// traffic, waves that are independent of each other, and twelve of them per CU (three per SIMD) instead of eight.  The matrix-pipe work
+// is unchanged (per 16 output pixels 9 + 54 + 8 v_mfma_f32_16x16x4_f32 and 108 v_mfma_f32_4x4x1_16B_f32: conv1_8 costs one MFMA per
+// tap here, one per region pixel tile there); the k order inside an output element differs (per tap: channels 0..15, then 16..23).
+//   item = 16 consecutive output pixels of one output row; a persistent wave walks items w, w + S, ..; the 99 input pixels of the NEXT
+//   item are in flight (two 16-byte loads per lane) while the current one is computed, and go to the wave's own LDS slice
+//   (even-column / odd-column planes per row, so that the 16 pixels of a tap are consecutive records) when it is done.
+//   Padding: conv1_9 pads conv1_8's OUTPUT.  With even H and W only input row -1 (output row 0: the three ky = 0 taps are skipped,
+//   wave-uniform) and input column -1 (first segment of a row: lane p = 0 of the kx = 0 taps is zeroed) are outside; the loads
+//   themselves are not bounds-checked (guard band: k19m_guard_elems).
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int R_NW = 12;                     // waves per workgroup, one workgroup per CU
+constexpr int R_PS = 100, R_RS = 2 * R_PS;   // floats: plane (17 even-column records + pad) and row stride of a wave's slice
+constexpr int R_SLICE = 3 * R_RS;            // floats per wave
+constexpr int R_WA = 9 * 4 * 64, R_WB = 9 * 2 * 64, R_WQ = 9 * 3 * 64 * 4;   // floats: conv1_9 A fragments (channels 0..15 / 16..23), 4x4x1 table
+constexpr int R_OFF = W9_F32 + W21_F32 + WQ_F32 + W21Q_F32;                     // the k19r stream follows k19m's in the packed blob
+}  // namespace
+
+__global__ void __launch_bounds__(R_NW * 64) k19r_kernel(K19Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char k19_smem[];
+    float* const WQ = reinterpret_cast<float*>(k19_smem);          // [9][3][64][4]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = lane & 15, j = lane >> 4;
+    float* const SL = WQ + R_WQ + wave * R_SLICE;
+
+    stage_to_lds<R_WQ, R_NW * 64>(WQ, a.wp + R_OFF + R_WA + R_WB);
+    // ---- weights in registers for the lifetime of the wave ----
+    float wA[9][4], wB[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wA[t][s] = a.wp[R_OFF + (t * 4 + s) * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) wB[t][s] = a.wp[R_OFF + R_WA + (t * 2 + s) * 64 + lane];
+    }
+    float w21f[4], w21q[2], biasq[2], bias9[4], bias21[4], bias8[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        w21f[r] = a.wp[W9_F32 + r * 64 + lane];            // M-tile 0 of k19m's conv2_1 fragments: k-step r <-> channel 4j + r
+        bias9[r] = a.b9[4 * j + r];
+        bias8[r] = a.b8[4 * j + r];
+        bias21[r] = j < 2 ? a.b21[4 * j + r] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        w21q[t] = a.wp[W9_F32 + W21_F32 + WQ_F32 + t * 64 + lane];
+        biasq[t] = a.b9[16 + 4 * t + j];
+    }
+    const float w8a = a.w8[j * 24 + p];                     // conv1_8's A operand, channels 0..15: row = cout p, k = cin j
+    f32x2 w8h[4], b8h;                                      // channels 16 + 2j, 17 + 2j on the VALU
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w8h[c] = f32x2{a.w8[c * 24 + 16 + 2 * j], a.w8[c * 24 + 17 + 2 * j]};
+    b8h = f32x2{a.b8[16 + 2 * j], a.b8[17 + 2 * j]};
+
+    // ---- the lane's two staging records (region pixel idx = lane, lane + 64 < 99): global offset from the item origin, LDS offset ----
+    const int row0 = lane / 33, c0 = lane - 33 * row0;
+    const int idx1 = lane + 64 < 99 ? lane + 64 : 0, row1 = idx1 / 33, c1 = idx1 - 33 * row1;
+    const unsigned vo0 = (unsigned)((row0 * a.W + c0) * 4), vo1 = (unsigned)((row1 * a.W + c1) * 4);
+    const int so0 = row0 * R_RS + (c0 & 1) * R_PS + (c0 >> 1) * 4, so1 = row1 * R_RS + (c1 & 1) * R_PS + (c1 >> 1) * 4;
+    const int segs = (a.Wo + 15) >> 4;
+    const int nwaves = gridDim.x * R_NW;
+    // item = (frame n, output row oy, segment sx), walked incrementally: the stride's (dn, doy, dsx) decomposition is added with carries
+    const int per_frame = a.Ho * segs;
+    const int d_n = nwaves / per_frame, d_r = nwaves - d_n * per_frame, d_oy = d_r / segs, d_sx = d_r - d_oy * segs;
+    const int w0 = blockIdx.x * R_NW + wave;
+    int n = w0 / per_frame, oy = (w0 - n * per_frame) / segs, sx = w0 - n * per_frame - oy * segs;
+    auto advance = [&](int& n_, int& oy_, int& sx_) {
+        sx_ += d_sx; oy_ += d_oy; n_ += d_n;
+        if (sx_ >= segs) { sx_ -= segs; ++oy_; }
+        if (oy_ >= a.Ho) { oy_ -= a.Ho; ++n_; }
+    };
+    auto origin = [&](int n_, int oy_, int sx_) {   // region pixel (row 0, column 0) = input (2 oy - 1, 32 sx - 1); beyond the last frame: frame 0 (unused)
+        const int nn = n_ < a.n_frames ? n_ : 0;
+        return a.in + (((long)nn * a.H + (2 * oy_ - 1)) * a.W + (32 * sx_ - 1)) * 4;
+    };
+    f32x4 xin0, xin1;   // (scalars, not an array: the array form lived in scratch)
+    {
+        const float* o0 = origin(n, oy, sx);
+        xin0 = *reinterpret_cast<const f32x4*>(o0 + vo0);
+        xin1 = *reinterpret_cast<const f32x4*>(o0 + vo1);
+    }
+    __syncthreads();   // the 4x4x1 table is staged (the only workgroup-wide step)
+    int n2 = n, oy2 = oy, sx2 = sx;
+    advance(n2, oy2, sx2);
+    // per-lane LDS bases: the tap reads are immediates on top of them
+    const float* const xb = SL + p * 4;        // the 16-byte record of pixel p
+    const float* const xjb = SL + p * 4 + j;   // its channel j (conv1_8's B operand)
+    const float* const wqb = WQ + lane * 4;
+
+    for (; n < a.n_frames;) {
+        // the item's region -> the wave's slice (its loads were requested one iteration ago); the next item's loads go out
+        *reinterpret_cast<f32x4*>(SL + so0) = xin0;
+        if (lane < 35) *reinterpret_cast<f32x4*>(SL + so1) = xin1;
+        {
+            const float* o2 = origin(n2, oy2, sx2);
+            xin0 = *reinterpret_cast<const f32x4*>(o2 + vo0);
+            xin1 = *reinterpret_cast<const f32x4*>(o2 + vo1);
+        }
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 accq0 = f32x4{0.f, 0.f, 0.f, 0.f}, accq1 = f32x4{0.f, 0.f, 0.f, 0.f};   // channels 16 + 4 cg + i of pixel p, this lane group's k-values
+        // Two copies of the nine taps: items that touch the top row or the left column (a fifth of them) select zeros into the padded
+        // taps' operands; the others run without those selects.  (One copy with per-tap wave-uniform branches: accumulators in scratch.)
+        auto taps = [&](auto border) {
+            constexpr bool BORDER = decltype(border)::value;
+            const bool top = oy == 0, left = sx == 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ky = t / 3, kx = t - 3 * ky;
+                const int off = ky * R_RS + (kx == 1 ? R_PS : 0) + (kx == 2 ? 4 : 0);
+                const float xj = xjb[off];
+                const f32x4 x4 = *reinterpret_cast<const f32x4*>(xb + off);
+                const f32x4 wq0 = *reinterpret_cast<const f32x4*>(wqb + (t * 3 + 0) * 256);
+                const f32x4 wq1 = *reinterpret_cast<const f32x4*>(wqb + (t * 3 + 1) * 256);
+                const f32x4 wq2 = *reinterpret_cast<const f32x4*>(wqb + (t * 3 + 2) * 256);
+                // conv1_8 of the tap's pixel: channels 4j .. 4j+3 on the matrix pipe (bias = C operand), 16 + 2j, 17 + 2j on the VALU
+                const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(w8a, xj, f32x4{bias8[0], bias8[1], bias8[2], bias8[3]}, 0, 0, 0);
+                f32x2 h = b8h;
+                h = __builtin_elementwise_fma(f32x2{x4[0], x4[0]}, w8h[0], h);
+                h = __builtin_elementwise_fma(f32x2{x4[1], x4[1]}, w8h[1], h);
+                h = __builtin_elementwise_fma(f32x2{x4[2], x4[2]}, w8h[2], h);
+                h = __builtin_elementwise_fma(f32x2{x4[3], x4[3]}, w8h[3], h);
+                float b[6];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b[r] = __int_as_float(max(__float_as_int(d[r]), 0));   // ReLU as one v_max_i32
+                b[4] = __int_as_float(max(__float_as_int(h[0]), 0));
+                b[5] = __int_as_float(max(__float_as_int(h[1]), 0));
+                if constexpr (BORDER) {
+                    if (ky == 0 || kx == 0) {   // input row -1 (all lanes of a top item) / column -1 (lane p = 0 of a left item): conv1_9's zero padding
+                        const bool z = (ky == 0 && top) || (kx == 0 && left && p == 0);
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) b[r] = z ? 0.f : b[r];
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[t][s], b[s], acc, 0, 0, 0);
+                    accq0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wq0[s], b[s], accq0, 0, 0, 0);
+                    accq1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wq1[s], b[s], accq1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[t][s], b[4 + s], acc, 0, 0, 0);
+                    accq0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wq2[s], b[4 + s], accq0, 0, 0, 0);
+                    accq1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wq2[2 + s], b[4 + s], accq1, 0, 0, 0);
+                }
+            }
+        };
+        if (oy == 0 || sx == 0) taps(std::true_type{});
+        else taps(std::false_type{});
+        // ---- epilogue: bias + ReLU, conv2_1 (24 -> 8) chained in registers, store (k19m_kernel's) ----
+        {
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float tot[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = t == 0 ? accq0[i] : accq1[i];
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    tot[i] = v;
+                }
+                const float mine = j == 0 ? tot[0] : j == 1 ? tot[1] : j == 2 ? tot[2] : tot[3];
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(w21q[t], fmaxf(mine + biasq[t], 0.f), o, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(w21f[r], fmaxf(acc[r] + bias9[r], 0.f), o, 0, 0, 0);
+            const int ox = 16 * sx + p;
+            if (j < 2 && ox < a.Wo)
+                *reinterpret_cast<float4*>(a.out + (((long)n * a.Ho + oy) * a.Wo + ox) * 8 + 4 * j) =
+                    make_float4(o[0] + bias21[0], o[1] + bias21[1], o[2] + bias21[2], o[3] + bias21[3]);
+        }
+        n = n2; oy = oy2; sx = sx2;
+        advance(n2, oy2, sx2);
+    }
+}
+
 size_t k19_packed_floats(int wmode)
 {
-    return wmode == WM_F16X3 ? (size_t)2 * WX3_HALF : wmode == WM_F16 ? (size_t)(W9_F16 + W21_F16) : (size_t)(W9_F32 + W21_F32 + WQ_F32 + W21Q_F32);
+    return wmode == WM_F16X3 ? (size_t)2 * WX3_HALF : wmode == WM_F16 ? (size_t)(W9_F16 + W21_F16) : (size_t)(R_OFF + R_WA + R_WB + R_WQ);
 }
 
 // w9: [tap][cin][cout] (blob layout of the dense 3x3), w21: [cin][cout]
@@ -509,6 +698,22 @@ void k19_pack_weights(const float* w9, const float* w21, float* out, int wmode)
                 const int c2 = l & 15, c1 = 16 + 4 * t + (l >> 4);
                 w21q[t * 64 + l] = c2 < 8 ? w21[c1 * 8 + c2] : 0.f;
             }
+        // k19r_kernel: per tap, k-step s of lane group jj is input channel 4 jj + s (channels 0..15) resp. 16 + 2 jj + s (16..23)
+        float* wa = out + R_OFF;
+        float* wb = wa + R_WA;
+        float* wr = wb + R_WB;
+        for (int tap = 0; tap < 9; ++tap)
+            for (int l = 0; l < 64; ++l) {
+                const int m = l & 15, jj = l >> 4;
+                for (int s = 0; s < 4; ++s) wa[(tap * 4 + s) * 64 + l] = w9[((size_t)tap * 24 + 4 * jj + s) * 24 + m];
+                for (int s = 0; s < 2; ++s) wb[(tap * 2 + s) * 64 + l] = w9[((size_t)tap * 24 + 16 + 2 * jj + s) * 24 + m];
+                // the 4x4x1 table: [tap][0: cg 0, s 0..3 | 1: cg 1, s 0..3 | 2: (cg 0, s 4..5), (cg 1, s 4..5)][lane][4]
+                for (int cg = 0; cg < 2; ++cg) {
+                    const int cout = 16 + 4 * cg + (l & 3);
+                    for (int s = 0; s < 4; ++s) wr[((tap * 3 + cg) * 64 + l) * 4 + s] = w9[((size_t)tap * 24 + 4 * jj + s) * 24 + cout];
+                    for (int s = 0; s < 2; ++s) wr[((tap * 3 + 2) * 64 + l) * 4 + 2 * cg + s] = w9[((size_t)tap * 24 + 16 + 2 * jj + s) * 24 + cout];
+                }
+            }
     }
 }
 
@@ -518,6 +723,13 @@ size_t k19m_guard_elems(int W) { return ((size_t)(W + 34) * 4 + 63) & ~(size_t)6
 size_t k19m_lds_bytes(int dtype)
 {
     return (size_t)2 * RH * row_stride(dtype == DT_F16) * (dtype == DT_F16 ? 2 : 4) + (dtype != DT_F32 || !YF_K19_Q4 ? 0 : (size_t)WQ_F32 * 4);
+}
+
+// fp32: k19r_kernel unless YF_K19R=0 (A/B: the region-buffer kernel of rounds 1-3)
+static bool k19r_enabled()
+{
+    static const bool on = [] { const char* v = getenv("YF_K19R"); return !(v && v[0] == '0'); }();
+    return on;
 }
 
 int launch_k19m(K19Args a, int N, hipStream_t s, int dtype)
@@ -535,9 +747,21 @@ int launch_k19m(K19Args a, int N, hipStream_t s, int dtype)
             return -1;
         attr_done[dev] = true;
     }
+    a.n_frames = N;
+    if (dtype == DT_F32 && k19r_enabled() && a.H % 2 == 0 && a.W % 2 == 0) {
+        static bool attr_r[YF_MAX_DEVICES] = {};
+        constexpr size_t lds = (size_t)(R_WQ + R_NW * R_SLICE) * sizeof(float);
+        if (!attr_r[dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k19r_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return -1;
+            attr_r[dev] = true;
+        }
+        const long items = (long)N * a.Ho * ((a.Wo + 15) / 16), wgs = (items + R_NW - 1) / R_NW;
+        hipLaunchKernelGGL(k19r_kernel, dim3((unsigned)(wgs < n_cu ? wgs : n_cu)), dim3(R_NW * 64), lds, s, a);
+        return 0;
+    }
     a.tiles_y = (a.Ho + TH - 1) / TH;
     a.tiles_x = (a.Wo + TW - 1) / TW;
-    a.n_frames = N;
     const long total = (long)N * a.tiles_y * a.tiles_x;
     // persistent: one workgroup (8 waves, two per SIMD) per CU
     const long want = (long)n_cu;
