@@ -65,6 +65,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef YF_K19_Q4
 #define YF_K19_Q4 1
 #endif
+#ifndef YF_K19R_DBG
+#define YF_K19R_DBG 0   // timing builds only (tools/build_variant.sh): 1 = no 4x4x1 MFMAs, 4 = no 16x16x4 k-steps of conv1_9
+#endif
+#ifndef YF_K19R_PIPE
+#define YF_K19R_PIPE 1   // k19r_kernel: the next tap's conv1_8 is issued in front of the current tap's k-steps (0: behind them; 2: in front, no scheduling barrier per tap)
+#endif
 #ifndef YF_K19_PF
 #define YF_K19_PF 1   // how many k groups ahead phase 2's LDS operands are requested
 #endif
@@ -474,13 +480,14 @@ __global__ void __launch_bounds__(512) k19m_kernel(K19Args a)
 //   themselves are not bounds-checked (guard band: k19m_guard_elems).
 // ------------------------------------------------------------------------------------------------
 namespace {
-constexpr int R_NW = 12;                     // waves per workgroup, one workgroup per CU
 constexpr int R_PS = 100, R_RS = 2 * R_PS;   // floats: plane (17 even-column records + pad) and row stride of a wave's slice
 constexpr int R_SLICE = 3 * R_RS;            // floats per wave
 constexpr int R_WA = 9 * 4 * 64, R_WB = 9 * 2 * 64, R_WQ = 9 * 3 * 64 * 4;   // floats: conv1_9 A fragments (channels 0..15 / 16..23), 4x4x1 table
 constexpr int R_OFF = W9_F32 + W21_F32 + WQ_F32 + W21Q_F32;                     // the k19r stream follows k19m's in the packed blob
 }  // namespace
 
+// WLDS: conv1_9's A fragments (54 per lane) are read from LDS per tap instead of living in registers -- 16 waves per CU fit then
+template <int R_NW, bool WLDS = false>   // waves per workgroup, one workgroup per CU
 __global__ void __launch_bounds__(R_NW * 64) k19r_kernel(K19Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char k19_smem[];
@@ -488,17 +495,29 @@ __global__ void __launch_bounds__(R_NW * 64) k19r_kernel(K19Args a)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p = lane & 15, j = lane >> 4;
-    float* const SL = WQ + R_WQ + wave * R_SLICE;
+    float* const WAL = WQ + R_WQ;                                   // WLDS: [9][64][4] + [9][64][2] (lane-major: one b128 + one b64 per tap)
+    float* const SL = WQ + R_WQ + (WLDS ? R_WA + R_WB : 0) + wave * R_SLICE;
 
     stage_to_lds<R_WQ, R_NW * 64>(WQ, a.wp + R_OFF + R_WA + R_WB);
     // ---- weights in registers for the lifetime of the wave ----
-    float wA[9][4], wB[9][2];
+    float wA[WLDS ? 1 : 9][4], wB[WLDS ? 1 : 9][2];
+    if constexpr (WLDS) {
+        for (int i = threadIdx.x; i < R_WA; i += R_NW * 64) {   // [t][s][lane] -> [t][lane][s]
+            const int ts = i >> 6, l = i & 63;
+            WAL[((ts >> 2) * 64 + l) * 4 + (ts & 3)] = a.wp[R_OFF + i];
+        }
+        for (int i = threadIdx.x; i < R_WB; i += R_NW * 64) {
+            const int ts = i >> 6, l = i & 63;
+            WAL[R_WA + ((ts >> 1) * 64 + l) * 2 + (ts & 1)] = a.wp[R_OFF + R_WA + i];
+        }
+    } else {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < 9; ++t) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wA[t][s] = a.wp[R_OFF + (t * 4 + s) * 64 + lane];
+            for (int s = 0; s < 4; ++s) wA[t][s] = a.wp[R_OFF + (t * 4 + s) * 64 + lane];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) wB[t][s] = a.wp[R_OFF + R_WA + (t * 2 + s) * 64 + lane];
+            for (int s = 0; s < 2; ++s) wB[t][s] = a.wp[R_OFF + R_WA + (t * 2 + s) * 64 + lane];
+        }
     }
     float w21f[4], w21q[2], biasq[2], bias9[4], bias21[4], bias8[4];
 #pragma unroll
@@ -570,22 +589,37 @@ __global__ void __launch_bounds__(R_NW * 64) k19r_kernel(K19Args a)
         auto taps = [&](auto border) {
             constexpr bool BORDER = decltype(border)::value;
             const bool top = oy == 0, left = sx == 0;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
+            // conv1_8 of tap t's pixel: channels 4j .. 4j+3 on the matrix pipe (bias = C operand), 16 + 2j, 17 + 2j on the VALU
+            auto c8 = [&](int t, f32x4& d, f32x2& h) {
                 const int ky = t / 3, kx = t - 3 * ky;
                 const int off = ky * R_RS + (kx == 1 ? R_PS : 0) + (kx == 2 ? 4 : 0);
                 const float xj = xjb[off];
                 const f32x4 x4 = *reinterpret_cast<const f32x4*>(xb + off);
-                const f32x4 wq0 = *reinterpret_cast<const f32x4*>(wqb + (t * 3 + 0) * 256);
-                const f32x4 wq1 = *reinterpret_cast<const f32x4*>(wqb + (t * 3 + 1) * 256);
-                const f32x4 wq2 = *reinterpret_cast<const f32x4*>(wqb + (t * 3 + 2) * 256);
-                // conv1_8 of the tap's pixel: channels 4j .. 4j+3 on the matrix pipe (bias = C operand), 16 + 2j, 17 + 2j on the VALU
-                const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(w8a, xj, f32x4{bias8[0], bias8[1], bias8[2], bias8[3]}, 0, 0, 0);
-                f32x2 h = b8h;
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(w8a, xj, f32x4{bias8[0], bias8[1], bias8[2], bias8[3]}, 0, 0, 0);
+                h = b8h;
                 h = __builtin_elementwise_fma(f32x2{x4[0], x4[0]}, w8h[0], h);
                 h = __builtin_elementwise_fma(f32x2{x4[1], x4[1]}, w8h[1], h);
                 h = __builtin_elementwise_fma(f32x2{x4[2], x4[2]}, w8h[2], h);
                 h = __builtin_elementwise_fma(f32x2{x4[3], x4[3]}, w8h[3], h);
+            };
+            f32x4 d;
+            f32x2 h;
+            c8(0, d, h);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ky = t / 3, kx = t - 3 * ky;
+                const f32x4 wq0 = *reinterpret_cast<const f32x4*>(wqb + (t * 3 + 0) * 256);
+                const f32x4 wq1 = *reinterpret_cast<const f32x4*>(wqb + (t * 3 + 1) * 256);
+                const f32x4 wq2 = *reinterpret_cast<const f32x4*>(wqb + (t * 3 + 2) * 256);
+                f32x4 wa;
+                f32x2 wb;
+                if constexpr (WLDS) {
+                    wa = *reinterpret_cast<const f32x4*>(WAL + lane * 4 + t * 256);
+                    wb = *reinterpret_cast<const f32x2*>(WAL + R_WA + lane * 2 + t * 128);
+                } else {
+                    wa = f32x4{wA[t][0], wA[t][1], wA[t][2], wA[t][3]};
+                    wb = f32x2{wB[t][0], wB[t][1]};
+                }
                 float b[6];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) b[r] = __int_as_float(max(__float_as_int(d[r]), 0));   // ReLU as one v_max_i32
@@ -598,18 +632,35 @@ __global__ void __launch_bounds__(R_NW * 64) k19r_kernel(K19Args a)
                         for (int r = 0; r < 6; ++r) b[r] = z ? 0.f : b[r];
                     }
                 }
+#if YF_K19R_PIPE
+                if (t + 1 < 9) c8(t + 1, d, h);   // the next tap's conv1_8 goes out in front of this tap's k-steps: its result is ready when they are done
+#endif
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[t][s], b[s], acc, 0, 0, 0);
-                    accq0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wq0[s], b[s], accq0, 0, 0, 0);
-                    accq1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wq1[s], b[s], accq1, 0, 0, 0);
+                    if (!(YF_K19R_DBG & 4)) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], b[s], acc, 0, 0, 0);
+                    if (!(YF_K19R_DBG & 1)) {
+                        accq0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wq0[s], b[s], accq0, 0, 0, 0);
+                        accq1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wq1[s], b[s], accq1, 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[t][s], b[4 + s], acc, 0, 0, 0);
-                    accq0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wq2[s], b[4 + s], accq0, 0, 0, 0);
-                    accq1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wq2[2 + s], b[4 + s], accq1, 0, 0, 0);
+                    if (!(YF_K19R_DBG & 4)) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[s], b[4 + s], acc, 0, 0, 0);
+                    if (!(YF_K19R_DBG & 1)) {
+                        accq0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wq2[s], b[4 + s], accq0, 0, 0, 0);
+                        accq1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wq2[2 + s], b[4 + s], accq1, 0, 0, 0);
+                    }
                 }
+                if (YF_K19R_DBG & 5) {   // (timing builds: keep the operands alive)
+                    acc[0] += b[0] + b[1] + b[2] + b[3] + b[4] + b[5];
+                    if (YF_K19R_DBG & 1) accq0[0] += wq0[0] + wq1[1] + wq2[2];
+                }
+#if YF_K19R_PIPE == 1
+                __builtin_amdgcn_sched_barrier(0);
+#elif YF_K19R_PIPE == 2
+#else
+                if (t + 1 < 9) c8(t + 1, d, h);
+#endif
             }
         };
         if (oy == 0 || sx == 0) taps(std::true_type{});
@@ -725,6 +776,21 @@ size_t k19m_lds_bytes(int dtype)
     return (size_t)2 * RH * row_stride(dtype == DT_F16) * (dtype == DT_F16 ? 2 : 4) + (dtype != DT_F32 || !YF_K19_Q4 ? 0 : (size_t)WQ_F32 * 4);
 }
 
+template <int R_NW, bool WLDS>
+static int launch_k19r_t(const K19Args& a, long items, int n_cu, int dev, hipStream_t s)
+{
+    static bool attr_r[YF_MAX_DEVICES] = {};
+    constexpr size_t lds = (size_t)(R_WQ + (WLDS ? R_WA + R_WB : 0) + R_NW * R_SLICE) * sizeof(float);
+    if (!attr_r[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k19r_kernel<R_NW, WLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -1;
+        attr_r[dev] = true;
+    }
+    const long wgs = (items + R_NW - 1) / R_NW;
+    hipLaunchKernelGGL((k19r_kernel<R_NW, WLDS>), dim3((unsigned)(wgs < n_cu ? wgs : n_cu)), dim3(R_NW * 64), lds, s, a);
+    return 0;
+}
+
 // fp32: k19r_kernel unless YF_K19R=0 (A/B: the region-buffer kernel of rounds 1-3)
 static bool k19r_enabled()
 {
@@ -749,16 +815,10 @@ int launch_k19m(K19Args a, int N, hipStream_t s, int dtype)
     }
     a.n_frames = N;
     if (dtype == DT_F32 && k19r_enabled() && a.H % 2 == 0 && a.W % 2 == 0) {
-        static bool attr_r[YF_MAX_DEVICES] = {};
-        constexpr size_t lds = (size_t)(R_WQ + R_NW * R_SLICE) * sizeof(float);
-        if (!attr_r[dev]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k19r_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return -1;
-            attr_r[dev] = true;
-        }
-        const long items = (long)N * a.Ho * ((a.Wo + 15) / 16), wgs = (items + R_NW - 1) / R_NW;
-        hipLaunchKernelGGL(k19r_kernel, dim3((unsigned)(wgs < n_cu ? wgs : n_cu)), dim3(R_NW * 64), lds, s, a);
-        return 0;
+        static const int nw = [] { const char* v = getenv("YF_K19R_NW"); return v ? atoi(v) : 16; }();   // 16 = weights from LDS (default: 156 us); A/B: 8 (166 us) | 12 (160 us) | 1012 = 12 waves, weights from LDS (162 us)
+        const long items = (long)N * a.Ho * ((a.Wo + 15) / 16);
+        return nw == 8 ? launch_k19r_t<8, false>(a, items, n_cu, dev, s) : nw == 16 ? launch_k19r_t<16, true>(a, items, n_cu, dev, s)
+                       : nw == 1012 ? launch_k19r_t<12, true>(a, items, n_cu, dev, s) : launch_k19r_t<12, false>(a, items, n_cu, dev, s);
     }
     a.tiles_y = (a.Ho + TH - 1) / TH;
     a.tiles_x = (a.Wo + TW - 1) / TW;
