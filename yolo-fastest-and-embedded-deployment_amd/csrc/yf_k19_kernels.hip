@@ -69,7 +69,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define YF_K19R_DBG 0   // timing builds only (tools/build_variant.sh): 1 = no 4x4x1 MFMAs, 4 = no 16x16x4 k-steps of conv1_9
 #endif
 #ifndef YF_K19R_PIPE
-#define YF_K19R_PIPE 1   // k19r_kernel: the next tap's conv1_8 is issued in front of the current tap's k-steps (0: behind them; 2: in front, no scheduling barrier per tap)
+#define YF_K19R_PIPE 2   // k19r_kernel: the next tap's conv1_8 is issued in front of the current tap's k-steps (0: behind them; 2: in front, no scheduling barrier per tap)
 #endif
 #ifndef YF_K19_PF
 #define YF_K19_PF 1   // how many k groups ahead phase 2's LDS operands are requested

@@ -101,7 +101,7 @@ class BatchPipeline:
                 replaced += 1
         return replaced
 
-    def tune_streams(self, x=None, candidates=3, batches=6):
+    def tune_streams(self, x=None, candidates=3, batches=16):
         """Make sure the batches in flight run on streams that really overlap.  The HIP runtime multiplexes streams onto a few hardware
         queues (GPU_MAX_HW_QUEUES, default 4) in first-use order, and HOW WELL two batches overlap is a property of the pair of streams
         they are issued on -- measured on MI355X, same engines, same process, 20 steps of batch 256 (tools/queue_try2.py): 253-261 k
@@ -110,7 +110,9 @@ class BatchPipeline:
           1. streams that do not overlap at all with the ones before them are replaced (yf_streams_overlap: a 100 us spin kernel on
              each stream, ~0.2 ms per pair) -- this alone removes the worst case and needs no input;
           2. with a batch `x`: `candidates` such sets of streams are timed on `batches` real submissions each and the fastest is kept
-             (a few milliseconds per candidate).
+             (~15 ms per candidate at batch 256).  The candidates differ by 1-10 %, the device's clocks take tens of milliseconds of
+             load to settle after an idle period, and a candidate timed while they still ramp loses to one timed after: the first
+             candidate is therefore preceded by `batches` untimed submissions (round 3 timed 6 submissions per candidate from cold).
         Call once, before the first real batch.  Returns the measured frames/s per candidate (empty without x)."""
         if self.depth < 2:
             return []
@@ -118,6 +120,9 @@ class BatchPipeline:
         if x is None:
             return []
         rates, sets = [], []
+        for _ in range(batches):      # settle (see above); not timed
+            self.submit(x)
+        self.drain()
         for c in range(candidates):
             if c > 0:
                 self.streams = [torch.cuda.Stream(self.device) for _ in range(self.depth)]
