@@ -150,7 +150,7 @@ def live_pmc(res, batch, dtype, frames, kmax, with_issue=False):
             cmd = [prof, "--pmc"] + list(counters) + ["--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
                    os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-variants", "--no-configs",
                    "--no-live-traffic", "--no-train", "--no-extras", "--in-flight", "1", "--lanes", "1", "--res", str(res), "--batch", str(batch),
-                   "--dtype", dtype, "--frames", frames, "--kmax", str(kmax), "--dump-ops", os.path.join(work, "ops.json")]
+                   "--dtype", dtype, "--frames", frames, "--kmax", str(kmax), "--launch-repeats", "1", "--dump-ops", os.path.join(work, "ops.json")]
             rc, tail = _run_child(cmd, 120)
             path = os.path.join(d, "p_counter_collection.csv")
             if rc != 0 or not os.path.exists(path):
@@ -385,10 +385,14 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra records of the default run: `fixtures` (the 20 bundled frames tiled to the batch), `u8` (the same "
                          "batch entering as u8 through the fused pre-process), `batch1` (latency of one frame), `exchange_rehearsal`")
+    ap.add_argument("--launch-repeats", type=int, default=4,
+                    help="per-launch timing (forward_chain.per_launch, roofline.launch_ms): back-to-back launches of each kernel between the two "
+                         "HIP events that time it; 1 = one launch per event pair (the counter passes, which match dispatches to ops by order, use 1)")
     ap.add_argument("--dump-ops", default=None, help="write the launch names of one forward pass to this JSON file")
     ap.add_argument("--dump-records", default=None,
                     help="rank 0 writes the LAST step's detection records of all frames (N > 1: as gathered over RCCL) to this .npz")
     args = ap.parse_args()
+    args.launch_repeats = max(1, min(64, args.launch_repeats))
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
 
@@ -630,7 +634,7 @@ def main():
         saved = dict(cur)
 
         def stem_us(m, xin):
-            return round(1e3 * m.profile(xin, reps=5)[0]["ms"], 2)
+            return round(1e3 * m.profile(xin, reps=5, launch_repeats=args.launch_repeats)[0]["ms"], 2)
 
         # (a) SURVEY.md 8(d).2 "realistic": configs[1] on the reference's 20 bundled frames tiled to 256 -- every frame has >= 1 box, so
         #     decode + sort + NMS do real work (the noise frames of the headline give ~0.02 survivors per frame)
@@ -767,7 +771,7 @@ def main():
             """Roofline object of the launch that takes longest.  pmc = (traffic, issue, note) of live_pmc() for this workload: then the
             bound is counter-backed (launch_roofline) and `traffic` / `hbm_frac` are this run's counter bytes; `pass_binding` sums the
             shares over all launches of the pass -- what binds the configuration as a whole."""
-            ops_ = m.profile(cur["x"], reps=3)
+            ops_ = m.profile(cur["x"], reps=3, launch_repeats=args.launch_repeats)
             tr, iss, note = pmc if pmc else ({}, {}, None)
             for o in ops_:
                 o["roof"] = launch_roofline(o, m.precision, tr.get(o["name"]), iss.get(o["name"]))
@@ -843,8 +847,14 @@ def main():
     if rank == 0:
         counts = raw["counts"].cpu().numpy()
         fps = n_total * args.steps / elapsed
-        # per-launch timing, HIP events on the launch stream around every kernel of one forward pass (mean of 5 passes)
-        ops = model.profile(x, reps=5)
+        # per-launch timing, HIP events on the launch stream around every kernel of one forward pass (mean of 5 passes).  An event pair
+        # around ONE launch also times the event packets and the dispatch gap behind them -- 5-7 us per launch on some hosts, which is why
+        # rocprofv3's kernel durations of the same pass are shorter (profiles/r04_lanes1_kernel_stats.csv: 936 us against 1067 us over the
+        # 21 launches) -- so every launch is issued args.launch_repeats times back to back between its two events and the time divided
+        # (yf_set_profile_repeats; a launch writes its whole output from inputs it does not modify).  The one-launch-per-event-pair sum
+        # stays in the line beside it.
+        ops = model.profile(x, reps=5, launch_repeats=args.launch_repeats)
+        chain_ms_pairs = sum(o["ms"] for o in model.profile(x, reps=5, launch_repeats=1))
         if args.dump_ops:
             with open(args.dump_ops, "w") as f:
                 json.dump([{"name": o["name"], "ms": o["ms"], "algorithmic_bytes": o["algorithmic_bytes"], "mfma_flops": o["mfma_flops"],
@@ -924,6 +934,9 @@ def main():
             # the whole forward pass (all launches)
             "forward_chain": {"launches": len(ops), "forward_ms": round(fwd_ms, 4), "post_ms": round(post_ms, 4),
                               "sum_of_launch_ms_single_stream": round(chain_ms, 4),
+                              "launch_timing": f"HIP events around {args.launch_repeats} back-to-back launches of each kernel, divided by {args.launch_repeats} (agrees with "
+                                               "rocprofv3's kernel durations); one launch per event pair also times the event packets and the dispatch gap",
+                              "sum_of_launch_ms_one_launch_per_event_pair": round(chain_ms_pairs, 4),
                               "compute_frac": round(chain_floor / (fwd_ms * 1e-3), 4),
                               "hbm_traffic_bytes": total_traffic,
                               "hbm_GBps": None if not total_traffic else round(total_traffic / (fwd_ms * 1e-3) / 1e9, 1),

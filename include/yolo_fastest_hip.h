@@ -299,6 +299,12 @@ int yf_streams_overlap(yf_handle h, void *stream_a, void *stream_b, int *overlap
                                                       for two lanes, no gain from two batches in flight).  Host-blocking probe (~0.2 ms:
                                                       a 100 us spin kernel on each); the engine uses it to pick its lane / branch streams
                                                       per caller stream, BatchPipeline to pick the streams of the batches in flight */
+int yf_set_profile_repeats(yf_handle h, int repeats);
+                                                   /* yf_profile_forward[_u8]: every launch is issued `repeats` (1 .. 64, default 1) times back to
+                                                      back between its two events and the elapsed time divided by it -- an event pair around ONE
+                                                      launch also times the event packets and the dispatch gap (5-7 us per launch, host dependent:
+                                                      rocprofv3's kernel durations are that much shorter); every launch writes its whole output
+                                                      from inputs it does not modify, so repeating it changes nothing */
 int yf_num_launches(yf_handle h, int *out);       /* kernel launches one yf_forward issues            */
 int yf_set_chunk(yf_handle h, int frames);        /* frames per pass of the layer chain (0 = whole batch) */
 int yf_set_lanes(yf_handle h, int lanes);          /* 1..4: chunks of the batch (yf_set_chunk) run on this many concurrent

@@ -106,6 +106,7 @@ _SIGS = {
     "yf_streams_overlap": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_int)]),
     "yf_set_branches": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "yf_set_lanes": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "yf_set_profile_repeats": (_c.c_int, [_c.c_void_p, _c.c_int]),
 }
 EXPORTS = tuple(_SIGS)
 _lib = None

@@ -125,6 +125,7 @@ struct yf_engine {
     // Chunks of the batch can run on `lanes` concurrent streams (fork/join with events around the caller's stream):
     // at the deep stages one workgroup owns a CU and is latency-bound; a second chunk in flight fills the bubbles.
     int lanes = 2;
+    int profile_repeats = 1;   // yf_set_profile_repeats
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     // per lane: the side stream of the small-head branch and its fork / join events
@@ -529,6 +530,7 @@ int assign_streams(yf_engine* e, hipStream_t s)
 // per-op profiling state (yf_profile_forward): events recorded around every launch of a single-lane pass
 struct ProfileEvents {
     std::vector<hipEvent_t> ev;  // ops.size() + 1
+    int repeats = 1;             // every launch is issued this many times back to back between its two events (yf_set_profile_repeats)
 };
 
 int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs, void* ws, size_t ws_bytes,
@@ -617,6 +619,9 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
             const Tensor& to = P.tensors[o.out];
             int rc = 0;
             struct AtExit { ProfileEvents* p; size_t* i; hipStream_t st; ~AtExit() { if (p) { ++*i; (void)hipEventRecord(p->ev[*i], st); } } } at_exit{prof, &op_idx, s};
+            // (profiling: `repeats` back-to-back launches of the op between its two events -- every op writes its whole output from inputs it
+            //  does not modify, so repeating it is idempotent -- take the event and dispatch gap out of the per-launch figure)
+            for (int rep_ = 0, nrep_ = prof ? prof->repeats : 1; rep_ < nrep_ && !rc; ++rep_) {
             if (o.type == OP_DCAT) {
                 rc = yf::launch_dcat(ptr(o.in1), ptr(o.in2), e->d_wmfma + o.mfma_off, e->d_wmfma + o.mfma_off2, ptr(o.out), ti.H, ti.W, n, s, o.kdt);
             } else if (o.type == OP_MDW2) {
@@ -672,6 +677,7 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
             } else {
                 yf::DenseArgs a{ptr(o.in1), W(o.layer), B(o.layer), ptr(o.out), (long)n * to.H * to.W, ti.H, ti.W, to.H, to.W};
                 rc = yf::launch_dense3x3s2(L.cin, L.cout, a, s);   // (conv0 with Cin > 1 reads the NCHW planes of the net input)
+            }
             }
             if (rc) return fail(YF_E_INVALID, "no kernel for layer %s", L.name);
             if (o.out == probe_t) {
@@ -1357,15 +1363,26 @@ static int profile_forward(yf_handle h, const float* d_x, const uint8_t* d_u8, i
     float* hl = reinterpret_cast<float*>(static_cast<char*>(ws) + chain);
     float* hs = hl + h->head_l_elems * (size_t)N;
     ProfileEvents pe;
+    pe.repeats = h->profile_repeats > 0 ? h->profile_repeats : 1;
     pe.ev.resize(nops + 1);
     for (auto& ev : pe.ev) HIP_OK(hipEventCreate(&ev));
     int rc = run_forward(h, d_x, N, hl, hs, ws, chain, (hipStream_t)stream, nullptr, nullptr, 0, &pe, d_u8, down2);
     if (rc == YF_OK) {
         HIP_OK(hipEventSynchronize(pe.ev[nops]));
-        for (size_t i = 0; i < nops; ++i) HIP_OK(hipEventElapsedTime(&op_ms[i], pe.ev[i], pe.ev[i + 1]));
+        for (size_t i = 0; i < nops; ++i) {
+            HIP_OK(hipEventElapsedTime(&op_ms[i], pe.ev[i], pe.ev[i + 1]));
+            op_ms[i] /= (float)pe.repeats;
+        }
     }
     for (auto& ev : pe.ev) (void)hipEventDestroy(ev);
     return rc;
+}
+
+int yf_set_profile_repeats(yf_handle h, int repeats)
+{
+    if (!h || repeats < 1 || repeats > 64) return fail(YF_E_INVALID, "yf_set_profile_repeats: repeats must be 1 .. 64");
+    h->profile_repeats = repeats;
+    return YF_OK;
 }
 
 int yf_set_lanes(yf_handle h, int lanes)

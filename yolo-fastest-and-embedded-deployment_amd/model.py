@@ -266,8 +266,9 @@ class YoloFastest(nn.Module):
                                        ws.data_ptr(), ws.numel(), ctypes.c_void_p(stream)))
         return hl, hs
 
-    def profile(self, x, reps=5):
-        """Per-launch timing of one forward pass (HIP events on the launch stream around every kernel).
+    def profile(self, x, reps=5, launch_repeats=1):
+        """Per-launch timing of one forward pass (HIP events on the launch stream around every kernel; launch_repeats > 1: around that
+        many back-to-back launches of it, divided -- the event packets and the dispatch gap of a lone launch, 5-7 us, drop out).
         Returns a list of dicts: name, ms (mean over reps), algorithmic_bytes, flops (= mfma_flops + valu_flops, by the pipe
         the layer runs on in this plan) -- for the whole batch.  x uint8 [N,H,W] ([N,H,W,3]): the pass from u8 frames of the net's
         size (forward_u8's fused pre-process in the first launch)."""
@@ -281,6 +282,7 @@ class YoloFastest(nn.Module):
         _lib.check(e.lib.yf_num_launches(e.handle, ctypes.byref(n)))
         acc = [0.0] * n.value
         buf = (ctypes.c_float * n.value)()
+        _lib.check(e.lib.yf_set_profile_repeats(e.handle, int(launch_repeats)))
         for _ in range(reps):
             if u8:
                 _lib.check(e.lib.yf_profile_forward_u8(e.handle, x.data_ptr(), N, H, W, ws.data_ptr(), ws.numel(), ctypes.c_void_p(stream),
