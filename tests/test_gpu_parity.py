@@ -1255,3 +1255,27 @@ def test_training_loss_matches_the_reference(yf, models, golden, dev):
     bad = np.zeros((1, 2, 6), np.float32); bad[0, 0] = [1.0, 0.5, 0.1, 0.1, 0, 255.0]       # x == 1.0: column index == width
     with pytest.raises(IndexError):
         val.YOLOLossV3(io["anchors"][0], 3, io["input_shape"], dev, model=m)(torch.zeros(1, 24, 16, 20, device=dev), torch.from_numpy(bad).to(dev))
+
+
+@pytest.mark.gpu
+def test_profile_with_repeated_launches_changes_nothing(yf, golden, dev):
+    """yf_set_profile_repeats: every launch of the profiled pass is issued N times back to back between its two events (the event
+    packets and dispatch gap of a lone launch drop out of the per-launch figure).  A launch writes its whole output from inputs it does
+    not modify, so the pass's result is the same bits, and the per-launch times stay in the range of the one-launch-per-pair ones."""
+    io = yf.io_params_for(256)
+    m = yf.YoloFastest(io).to(dev).eval()
+    m.load_state_dict(torch.load(WEIGHTS[256], map_location=dev))
+    g = golden("golden_256")
+    x = _x(g["input_u8"], dev)
+    with torch.no_grad():
+        a = m(x)
+    one = m.profile(x, reps=3, launch_repeats=1)
+    four = m.profile(x, reps=3, launch_repeats=4)
+    assert [o["name"] for o in one] == [o["name"] for o in four] and all(o["ms"] > 0 for o in four)
+    assert sum(o["ms"] for o in four) <= 1.25 * sum(o["ms"] for o in one)
+    with torch.no_grad():
+        b = m(x)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    with pytest.raises(RuntimeError):     # _lib.YFError
+        m.profile(x, reps=1, launch_repeats=0)
+    m.profile(x, reps=1, launch_repeats=1)
