@@ -37,6 +37,9 @@
 #ifndef YF_RES2_BW
 #define YF_RES2_BW 1
 #endif
+#ifndef YF_FB_MED3
+#define YF_FB_MED3 1
+#endif
 #ifndef YF_FB_PK
 #define YF_FB_PK 1   // expansion / projection / conv0 FMAs over output-channel PAIRS as v_pk_fma_f32 (scalar weight pair x broadcast value)
 #endif
@@ -344,10 +347,15 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
             for (int p = 0; p < PE; ++p)
                 if (inreg[p]) {
                     float* dst = E + (cg * CG) * PLANE + (ry[p] * RWP + rx[p]) * 2;
+                    // ReLU and the zero outside the image in ONE instruction per value: median(x, 0, lim), lim = +inf inside, 0 outside
+                    // (v_max + v_cndmask before: 2 of every ~7 VALU instructions of the res2 expansion: res2_1 / res2_2 40.2 -> 36.7 us; not in the
+                    //  stem, which it slows from 57.7 to 62.1 us -- A/B, tools/ops_abn.sh)
+                    const float lim = inimg[p] ? __builtin_inff() : 0.f;
 #pragma unroll
                     for (int j = 0; j < CG; j += 2)
                         *reinterpret_cast<float2*>(dst + j * PLANE) =
-                            make_float2(inimg[p] ? fmaxf(e[p][j], 0.f) : 0.f, inimg[p] ? fmaxf(e[p][j + 1], 0.f) : 0.f);
+                            (YF_FB_MED3 && !PRE) ? make_float2(__builtin_amdgcn_fmed3f(e[p][j], 0.f, lim), __builtin_amdgcn_fmed3f(e[p][j + 1], 0.f, lim))
+                                       : make_float2(inimg[p] ? fmaxf(e[p][j], 0.f) : 0.f, inimg[p] ? fmaxf(e[p][j + 1], 0.f) : 0.f);
                 }
         }
         YF_STAMP_AT(1)
