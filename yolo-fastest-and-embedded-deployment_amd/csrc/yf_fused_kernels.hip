@@ -157,6 +157,8 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
     constexpr int MAXI = (NITEM + NW - 1) / NW;
     constexpr bool HOIST = YF_FB_HOIST && !PRE && !XL && (CEXP / EC > 1 || YF_FB_HOIST > 1) && NCG == 1 && PE == 1 && MAXI * CIN <= 32;
     float xh[HOIST ? MAXI : 1][CIN];
+    int hdst[HOIST ? MAXI : 1];       // ... and so are the item's E offset (-1: no pixel) and its ReLU limit (+inf inside the image, 0 outside):
+    float hlim[HOIST ? MAXI : 1];     // 13 of the 64 VALU instructions of an item and chunk were this index arithmetic
     if constexpr (HOIST) {
 #pragma unroll
         for (int it = 0; it < MAXI; ++it) {
@@ -164,6 +166,8 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
             const int ryh = (rp < NRP ? rp : 0) / RW, rxh = (rp < NRP ? rp : 0) - ryh * RW;
             const int iy = iy0 + ryh, ix = ix0 + rxh;
             const bool in = rp < NRP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            hdst[it] = rp < NRP ? (ryh * RWP + rxh) * 2 : -1;
+            hlim[it] = in ? __builtin_inff() : 0.f;
             const T* __restrict__ srch = reinterpret_cast<const T*>(a.in) + (((long)n * a.H + (in ? iy : 0)) * a.W + (in ? ix : 0)) * CIN;
 #pragma unroll
             for (int k = 0; k < CIN; k += 4) {
@@ -345,12 +349,12 @@ __global__ void __launch_bounds__(TYB* TXB) fused_block_kernel(FbArgs a)
             // its taps on both channels of a pair with one v_pk_fma_f32
 #pragma unroll
             for (int p = 0; p < PE; ++p)
-                if (inreg[p]) {
-                    float* dst = E + (cg * CG) * PLANE + (ry[p] * RWP + rx[p]) * 2;
+                if (HOIST ? hdst[it] >= 0 : inreg[p]) {
+                    float* dst = E + (cg * CG) * PLANE + (HOIST ? hdst[it] : (ry[p] * RWP + rx[p]) * 2);
                     // ReLU and the zero outside the image in ONE instruction per value: median(x, 0, lim), lim = +inf inside, 0 outside
                     // (v_max + v_cndmask before: 2 of every ~7 VALU instructions of the res2 expansion: res2_1 / res2_2 40.2 -> 36.7 us; not in the
                     //  stem, which it slows from 57.7 to 62.1 us -- A/B, tools/ops_abn.sh)
-                    const float lim = inimg[p] ? __builtin_inff() : 0.f;
+                    const float lim = HOIST ? hlim[it] : inimg[p] ? __builtin_inff() : 0.f;
 #pragma unroll
                     for (int j = 0; j < CG; j += 2)
                         *reinterpret_cast<float2*>(dst + j * PLANE) =
