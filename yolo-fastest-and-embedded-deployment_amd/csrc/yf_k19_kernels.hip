@@ -498,19 +498,12 @@ __global__ void __launch_bounds__(R_NW * 64) k19r_kernel(K19Args a)
     float* const WAL = WQ + R_WQ;                                   // WLDS: [9][64][4] + [9][64][2] (lane-major: one b128 + one b64 per tap)
     float* const SL = WQ + R_WQ + (WLDS ? R_WA + R_WB : 0) + wave * R_SLICE;
 
-    stage_to_lds<R_WQ, R_NW * 64>(WQ, a.wp + R_OFF + R_WA + R_WB);
+    // the 4x4x1 table and, WLDS, the lane-major copies of the fragments ([t][lane][4] | [t][lane][2]) that follow it in the blob: one staging
+    // pass with every 16-byte load in flight (transposing [t][s][lane] here cost three dependent rounds of 4-byte loads per workgroup)
+    stage_to_lds<R_WQ + (WLDS ? R_WA + R_WB : 0), R_NW * 64>(WQ, a.wp + R_OFF + R_WA + R_WB);
     // ---- weights in registers for the lifetime of the wave ----
     float wA[WLDS ? 1 : 9][4], wB[WLDS ? 1 : 9][2];
-    if constexpr (WLDS) {
-        for (int i = threadIdx.x; i < R_WA; i += R_NW * 64) {   // [t][s][lane] -> [t][lane][s]
-            const int ts = i >> 6, l = i & 63;
-            WAL[((ts >> 2) * 64 + l) * 4 + (ts & 3)] = a.wp[R_OFF + i];
-        }
-        for (int i = threadIdx.x; i < R_WB; i += R_NW * 64) {
-            const int ts = i >> 6, l = i & 63;
-            WAL[R_WA + ((ts >> 1) * 64 + l) * 2 + (ts & 1)] = a.wp[R_OFF + R_WA + i];
-        }
-    } else {
+    if constexpr (!WLDS) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
 #pragma unroll
@@ -695,7 +688,7 @@ __global__ void __launch_bounds__(R_NW * 64) k19r_kernel(K19Args a)
 
 size_t k19_packed_floats(int wmode)
 {
-    return wmode == WM_F16X3 ? (size_t)2 * WX3_HALF : wmode == WM_F16 ? (size_t)(W9_F16 + W21_F16) : (size_t)(R_OFF + R_WA + R_WB + R_WQ);
+    return wmode == WM_F16X3 ? (size_t)2 * WX3_HALF : wmode == WM_F16 ? (size_t)(W9_F16 + W21_F16) : (size_t)(R_OFF + 2 * (R_WA + R_WB) + R_WQ);
 }
 
 // w9: [tap][cin][cout] (blob layout of the dense 3x3), w21: [cin][cout]
@@ -764,6 +757,9 @@ void k19_pack_weights(const float* w9, const float* w21, float* out, int wmode)
                     for (int s = 0; s < 4; ++s) wr[((tap * 3 + cg) * 64 + l) * 4 + s] = w9[((size_t)tap * 24 + 4 * jj + s) * 24 + cout];
                     for (int s = 0; s < 2; ++s) wr[((tap * 3 + 2) * 64 + l) * 4 + 2 * cg + s] = w9[((size_t)tap * 24 + 16 + 2 * jj + s) * 24 + cout];
                 }
+                // lane-major copies of the A fragments (the 16-wave form reads them from LDS: one b128 + one b64 per tap), behind the 4x4x1 table
+                for (int s = 0; s < 4; ++s) wr[R_WQ + (tap * 64 + l) * 4 + s] = wa[(tap * 4 + s) * 64 + l];
+                for (int s = 0; s < 2; ++s) wr[R_WQ + R_WA + (tap * 64 + l) * 2 + s] = wb[(tap * 2 + s) * 64 + l];
             }
     }
 }
