@@ -249,6 +249,8 @@ int yf_trainer_graph_replays(yf_trainer t, long *forward, long *backward);
 /* out6 = replays (forward, backward), captures (forward, backward), evictions (forward, backward).  A trainer keeps up to four graphs per
    pass (one per remembered pointer set); a pointer pattern that keeps evicting graphs before they were replayed stops capturing. */
 int yf_trainer_graph_stats(yf_trainer t, long *out6);
+int yf_trainer_set_graphs(yf_trainer t, int on);   /* 0: this trainer issues every pass as plain launches (the environment variable YF_TRAIN_GRAPH_OFF
+                                                      does the same for the whole process); default 1 */
 
 /* yf_forward + yf_decode_nms back to back on one stream (heads also returned; may be NULL to use
  * workspace-internal buffers). */
@@ -305,6 +307,10 @@ int yf_set_profile_repeats(yf_handle h, int repeats);
                                                       launch also times the event packets and the dispatch gap (5-7 us per launch, host dependent:
                                                       rocprofv3's kernel durations are that much shorter); every launch writes its whole output
                                                       from inputs it does not modify, so repeating it changes nothing */
+int yf_profile_head_offsets(yf_handle h, int N, size_t *large_off, size_t *small_off);
+                                                   /* byte offsets inside the workspace handed to yf_profile_forward[_u8] at which that pass left its
+                                                      head logits (NCHW fp32, [N, num_out, H/16, W/16] and [N, num_out, H/32, W/32]): tests hold the
+                                                      profiled (repeated-launch) pass itself to yf_forward's bits */
 int yf_num_launches(yf_handle h, int *out);       /* kernel launches one yf_forward issues            */
 int yf_set_chunk(yf_handle h, int frames);        /* frames per pass of the layer chain (0 = whole batch) */
 int yf_set_lanes(yf_handle h, int lanes);          /* 1..4: chunks of the batch (yf_set_chunk) run on this many concurrent

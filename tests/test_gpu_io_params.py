@@ -96,23 +96,68 @@ def test_fusion_levels_agree_bitwise_for_other_io_params(yf, dev, golden, tag):
     assert torch.equal(out[1][0], out[2][0]) and torch.equal(out[1][1], out[2][1])
 
 
-@pytest.mark.parametrize("tag", io_cfg.TAGS)
-@pytest.mark.parametrize("prec", ["f16x3", "f16"])
-def test_fp16_matrix_paths_for_other_io_params(yf, dev, golden, tag, prec):
+def _fp16_model(yf, dev, golden, tag, prec):
     g = golden("golden_io")
     io = io_cfg.io_for(tag)
     m = yf.YoloFastest(io).to(dev).eval()
     m.load_state_dict({k: v.to(dev) for k, v in io_cfg.state_dict_for(tag, int(g[tag + "_seed"])).items()})
     m.precision = prec
+    return g, io, m
+
+
+@pytest.mark.parametrize("tag", io_cfg.TAGS)
+def test_f16x3_path_for_other_io_params(yf, dev, golden, tag):
+    """split-operand fp16 MFMA (the variant that conforms to SURVEY.md 8(d).3): the fp32 bounds, and inside the survey's 2e-2 absolute."""
+    g, io, m = _fp16_model(yf, dev, golden, tag, "f16x3")
     with torch.no_grad():
         hl, hs = m(_x(tag, dev))
-    if prec == "f16x3":      # split-operand fp16 MFMA: the fp32 bounds
-        _check_heads(hl, g[tag + "_head_large"], g[tag + "_head_large_f64"], tag)
-        _check_heads(hs, g[tag + "_head_small"], g[tag + "_head_small_f64"], tag)
-    else:                    # fp16 storage: the throughput variant's bound (test_gpu_parity.test_random_weights_against_oracle)
-        for got, ref in ((hl, g[tag + "_head_large"]), (hs, g[tag + "_head_small"])):
-            d = np.abs(got.cpu().numpy() - ref).max()
-            assert d <= 5e-3 * max(1.0, np.abs(ref).max()), (tag, d)
+    _check_heads(hl, g[tag + "_head_large"], g[tag + "_head_large_f64"], tag)
+    _check_heads(hs, g[tag + "_head_small"], g[tag + "_head_small_f64"], tag)
+    for got, ref in ((hl, g[tag + "_head_large"]), (hs, g[tag + "_head_small"])):
+        assert np.abs(got.cpu().numpy() - ref).max() <= 2e-2
+
+
+# fp16 STORAGE (dtype 1) on the seeded-weight models, absolute: SURVEY.md 8(d).3's own 2e-2.  These models' logits reach 1.4 .. 2.9 (one
+# fp16 ulp there: 1e-3 .. 2e-3) and the measured maxima are 1.9e-3 .. 3.9e-3, so here the fp16-storage variant CONFORMS; on the shipped
+# checkpoints (logits to +-36) it cannot (tests/test_gpu_parity.py FP16_STORAGE_MAX, test_fp16_rounding_alone_exceeds_the_surveys_tolerance).
+SURVEY_FP16_TOL = 2e-2
+
+
+@pytest.mark.parametrize("tag", io_cfg.TAGS)
+def test_fp16_storage_variant_for_other_io_params(yf, dev, golden, tag):
+    """The throughput variant (fp16 storage, single fp16 operands): max |logit - the reference's fp32 logit| <= 2e-2 ABSOLUTE (the survey's
+    figure; measured 4e-3 at most) and the fp32 path's detections on the same frames."""
+    g, io, m = _fp16_model(yf, dev, golden, tag, "f16")
+    C, Cin, A = io_cfg.CONFIG[tag]
+    with torch.no_grad():
+        hl, hs = m(_x(tag, dev))
+    worst, rng = 0.0, 0.0
+    for got, ref in ((hl, g[tag + "_head_large"]), (hs, g[tag + "_head_small"])):
+        worst = max(worst, float(np.abs(got.cpu().numpy() - ref).max())); rng = max(rng, float(np.abs(ref).max()))
+    print(tag, "fp16 storage: max |dlogit| %.4g (logits reach %.3g; survey 2e-2)" % (worst, rng))
+    assert worst <= SURVEY_FP16_TOL, (tag, worst, rng)
+    # detections: those of the fp32 path on the same frames (class, cell, order; corners within 1 px)
+    m32, post, _ = _model(yf, dev, golden, tag)
+    with torch.no_grad():
+        ref_heads = m32(_x(tag, dev))
+    try:
+        want = post.detect(tuple(ref_heads), kmax=A * 400, with_src=True)
+    except ZeroDivisionError:
+        with pytest.raises(ZeroDivisionError):
+            post.detect((hl, hs), kmax=A * 400, with_src=True)
+        return
+    got = post.detect((hl, hs), kmax=A * 400, with_src=True)
+    both = total = 0
+    for f, (L, Wl) in enumerate(zip(got, want)):
+        # seeded random weights put hundreds of candidates per frame around the thresholds: one whose conf lies within the fp16 variant's
+        # error of conf_thre may appear or vanish, and a pair whose IoU lies at nms_thre may flip (the shipped checkpoints' frames, where
+        # neither happens, are held to EXACT equality in test_gpu_parity).  Here: the detections clear of the confidence threshold are
+        # the same set to 95 %, by (class, cell).
+        clear = lambda E: {(e[6], e[7]) for e in E if abs(e[4] - io["conf_thre"]) > 0.02}
+        a, b = clear(L), clear(Wl)
+        both += len(a & b); total += max(len(a), len(b))
+    print(tag, "fp16 storage: %d of %d detections (clear of the confidence threshold) shared with the fp32 path" % (both, total))
+    assert both >= 0.95 * total, (tag, both, total)
 
 
 @pytest.mark.parametrize("tag", io_cfg.TAGS)
@@ -307,25 +352,49 @@ def test_training_step_for_other_io_params(yf, dev, golden, tag):
         if diff.any():
             flips[name] = torch.nonzero(diff.any(0).any(-1).any(-1)).ravel().tolist()
             n_flips += int(diff.sum())
-    masks = fr.reach_masks(flips, names, [tuple(p.shape) for p in m.parameters()])
-    worst_clean, worst_reach, n_clean = 0.0, 0.0, 0
-    for gv, ex, mask, nm in zip(grads, g64, masks, names):
+    shapes = [tuple(p.shape) for p in m.parameters()]
+    masks = fr.reach_masks(flips, names, shapes, parts=True)
+    # The yardstick for "rounding level" in the clean set: torch's OWN fp32 evaluation of the same iteration on the CPU (the oracle graph in
+    # fp32), against the same fp64 result, on the elements neither its flips nor ours can reach -- the rule the head logits are held to
+    # (ours <= max(3 E, floor)); no bound here comes from a measurement of the kernels under test.
+    pre32 = {}
+    sd32 = bo.training_state(io_cfg.state_dict_for(tag, int(g[tag + "_seed"])), torch.float32)
+    t32 = bo.forward(sd32, bo.preprocess(u8, Cin), train=True, pre=pre32)
+    parts32 = [lo.loss_head(h, tt.cpu(), io["anchors"][i], C, io["input_shape"]) for i, h in enumerate(t32)]
+    g32 = [v.numpy().ravel() for v in torch.autograd.grad(parts32[0][0] + parts32[1][0], [sd32[k] for k in bo.parameter_keys(sd32)])]
+    flips32 = {}
+    for name, d in pre.items():
+        diff = (pre32[name]["z"] > 0) != (d["z"] > 0)
+        if diff.any():
+            flips32[name] = torch.nonzero(diff.any(0).any(-1).any(-1)).ravel().tolist()
+    masks32 = fr.reach_masks(flips32, names, shapes)
+    worst_clean, torch_clean, worst_up, worst_own, n_clean, n_elems = 0.0, 0.0, 0.0, 0.0, 0, 0
+    for gv, ex, e32, (own, up), m32, nm in zip(grads, g64, g32, masks, masks32, names):
         if np.abs(ex).max() < 1e-9:      # zero in exact arithmetic (a BatchNorm bias that only feeds train-mode BatchNorms): rounding noise only
             continue
-        err = np.abs(gv - ex) / np.abs(ex).max()
-        if (~mask).any():
-            worst_clean = max(worst_clean, float(err[~mask].max())); n_clean += int((~mask).sum())
-        if mask.any():
-            worst_reach = max(worst_reach, float(err[mask].max()))
+        err, err32 = np.abs(gv - ex) / np.abs(ex).max(), np.abs(e32 - ex) / np.abs(ex).max()
+        clean = ~(own | up | m32)
+        n_elems += err.size
+        if clean.any():
+            worst_clean = max(worst_clean, float(err[clean].max())); torch_clean = max(torch_clean, float(err32[clean].max())); n_clean += int(clean.sum())
+        if up.any():
+            worst_up = max(worst_up, float(err[up].max()))
+        if own.any():
+            worst_own = max(worst_own, float(err[own].max()))
     f64s = np.concatenate(g64)[::37]
-    print(tag, "%d ReLU decisions differ from the fp64 forward (%s); gradient elements they cannot reach: %d, worst %.3g; reachable: worst %.3g; "
-          "the reference's own fp32 sample vs fp64: %.3g" % (n_flips, {k: len(v) for k, v in flips.items()}, n_clean, worst_clean, worst_reach,
-                                                              np.abs(want - f64s).max() / np.abs(f64s).max()))
-    # (4 frames of 64x96: a stride-32 BatchNorm normalises over 24 values, so one flipped element is 4 % of its channel's batch -- the
-    #  reachable elements move by tens of percents (measured: 0.45 / 0.013) and rounding is amplified in the clean set too (8.6e-5 / 2.8e-4);
-    #  conv0's weight gradient on 3 input channels, upstream of every flip, is held to torch in test_gpu_training's operator tests)
-    assert n_flips < 200 and n_clean >= 50000
-    assert worst_clean <= 1e-3 and worst_reach <= 1.0, (worst_clean, worst_reach)
+    print(tag, "%d ReLU decisions differ from the fp64 forward (%s; torch's own fp32: %s); gradient elements neither can reach: %d of %d, worst %.3g "
+          "(torch fp32: %.3g); merely upstream of one of our flips: worst %.3g; the flipped channels' own parameters: worst %.3g; the reference's own "
+          "fp32 sample vs fp64: %.3g" % (n_flips, {k: len(v) for k, v in flips.items()}, {k: len(v) for k, v in flips32.items()}, n_clean, n_elems,
+                                        worst_clean, torch_clean, worst_up, worst_own, np.abs(want - f64s).max() / np.abs(f64s).max()))
+    # the same structure as test_gpu_training.test_training_network_against_the_fp64_oracle -- few flips (4 frames of 64x96 hold
+    # ~1.4 M ReLU decisions), what is merely UPSTREAM of a flip stays at flip level (one mask element of a stride-32 BatchNorm over 24 values
+    # is 4 % of its channel's batch: tens of percents, not O(1)), only the flipped channel's own filter / gamma / beta may move by O(1), and
+    # a real share of the elements is out of every flip's reach and held to rounding level.  An O(1) error of an upstream backward kernel
+    # (conv0's 3-channel weight gradient included) does not fit under the upstream cap.
+    assert n_flips <= 16, (n_flips, flips)
+    assert n_clean >= 50000 and n_clean >= 0.1 * n_elems, (n_clean, n_elems, flips)
+    assert worst_clean <= max(ACCURACY_RATIO * torch_clean, 1e-4), (worst_clean, torch_clean)
+    assert worst_up <= 0.25 and worst_own <= 1.0, (worst_up, worst_own, flips)     # test_gpu_training.UP_CAP / OWN_CAP (measured here: 0.12 / 0.45 at most)
     if n_flips == 0:
         assert np.abs(flat - want).max() <= 1e-3 * np.abs(want).max()
     bufs = np.concatenate([b.detach().cpu().numpy().ravel() for n, b in m.named_buffers() if not n.endswith("num_batches_tracked")])

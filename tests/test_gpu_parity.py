@@ -648,25 +648,41 @@ def test_f16x3_other_sizes_random_weights_and_u8(yf, dev):
         assert torch.equal(ul, hl) and torch.equal(us, hs)
 
 
+# Absolute bounds of the fp16-STORAGE variant, per configuration, next to the survey's figure.  SURVEY.md 8(d).3 asks 2e-2 on logits for
+# "activations/weights fp16, fp32 accumulate".  That figure cannot be met by ANY implementation of that arithmetic on these checkpoints:
+# the logits reach +-36, where ONE fp16 ulp is 3.1e-2, and tests/test_oracle_golden.py::test_fp16_rounding_alone_exceeds_the_surveys_tolerance
+# shows on the CPU (torch fp32 with a single class of tensors rounded to fp16, nothing of this library involved) that rounding the weights
+# ALONE moves the 640x512 logits by 4.5e-2, the tensors between launches alone by 8e-2, the MFMA activation operands alone by 4e-2.
+# So `f16` is NON-CONFORMING to 8(d).3 by arithmetic, `f16x3` (above) is the conforming configs[2] variant, and `f16` is held to what
+# fp16 storage can deliver: the measured maxima (4.2e-2 / 8.5e-2) with a margin, absolute.
+SURVEY_FP16_TOL = 2e-2
+FP16_STORAGE_MAX = {256: 6e-2, 512: 1.2e-1}      # max |logit - reference fp32 logit| over all cells of the 20 bundled frames
+FP16_STORAGE_P99 = {256: 2e-2, 512: 3e-2}
+FP16_STORAGE_MEAN = {256: 3e-3, 512: 7e-3}
+
+
 @pytest.mark.parametrize("res", [512, 256])
-def test_fp16_path_logits_and_boxes(yf, golden, dev, res):
+def test_fp16_storage_variant_is_nonconforming_but_detects_identically(yf, golden, dev, res):
+    """dtype 1 (`model.half()` / storage_dtype = float16): fp16 in HBM, single fp16 MFMA operands, fp32 accumulation -- the throughput
+    variant.  NON-CONFORMING to SURVEY.md 8(d).3's 2e-2 (see the constants above: no fp16-storage arithmetic can conform); held to stated
+    absolute bounds, to score bounds, and to DETECTIONS IDENTICAL to the fp32 path's and the reference's on the 20 bundled frames."""
     io = yf.io_params_for(res)
     m = yf.YoloFastest(io).to(dev).eval()
     m.load_state_dict(torch.load(WEIGHTS[res], map_location=dev))
-    m.storage_dtype = torch.float16
     g = golden(f"golden_{res}")
+    with torch.no_grad():
+        f32_heads = [t.clone() for t in m(_x(g["input_u8"], dev))]
+    m.storage_dtype = torch.float16
     with torch.no_grad():
         hl, hs = m(_x(g["input_u8"], dev))
     assert hl.dtype == torch.float32
-    # The single-operand fp16 variant: SURVEY.md 8(d).3's "2e-2 on logits" is out of its reach (see the header above; the f16x3
-    # variant meets it).  Stated instead: with fp16 storage (eps 4.9e-4 per rounding, 86 layers, logits reach +-36) the measured
-    # deviation from the reference's fp32 logits is mean 2.1e-3 / max 4.2e-2 at 256x320 and mean 5.4e-3 / p99 2.7e-2 / max 8.5e-2 at
-    # 512x640 over the 20 bundled frames (tools/x3_check.py).  The test bounds: max <= 3e-3 of the logit range, p99 <= 3e-2,
-    # mean <= 7e-3; scores within 2.5e-2 (sigmoid' <= 1/4 of the max logit deviation); detections identical.
+    worst = 0.0
     for got, ref in ((hl.cpu().numpy(), g["head_large"]), (hs.cpu().numpy(), g["head_small"])):
         d = np.abs(got - ref)
-        assert d.max() <= 3e-3 * np.abs(ref).max(), (d.max(), np.abs(ref).max())
-        assert np.quantile(d, 0.99) <= 3e-2 and d.mean() <= 7e-3, (np.quantile(d, 0.99), d.mean())
+        worst = max(worst, float(d.max()))
+        assert d.max() <= FP16_STORAGE_MAX[res], (d.max(), np.abs(ref).max())
+        assert np.quantile(d, 0.99) <= FP16_STORAGE_P99[res] and d.mean() <= FP16_STORAGE_MEAN[res], (np.quantile(d, 0.99), d.mean())
+    assert worst > SURVEY_FP16_TOL, worst    # it really is outside the survey's figure (if this ever fails, rename the test and conform)
     assert _score_err(hl.cpu().numpy(), g["head_large"]) < 2.5e-2 and _score_err(hs.cpu().numpy(), g["head_small"]) < 2.5e-2
     post = yf.YOLO_post_process(io["conf_thre"], io["nms_thre"], io["num_anchors"], io["num_cls"], io["anchors"], io["input_shape"]).bind(m)
     got = post.detect((hl, hs), with_src=True)
@@ -676,6 +692,12 @@ def test_fp16_path_logits_and_boxes(yf, golden, dev, res):
         assert [e[7] for e in L] == g["final_src"][f, :n].tolist(), (res, f)
         assert [e[6] for e in L] == g["final_cls"][f, :n].tolist()
         assert np.abs(np.array([e[:4] for e in L]).reshape(-1, 4) - g["final_box"][f, :n]).max(initial=0) <= 1
+    # ... and as our own fp32 path on the same frames (cell, class, order; corners within 1 px)
+    m.storage_dtype = torch.float32
+    want = post.detect(tuple(f32_heads), with_src=True)
+    for f, (L, Wl) in enumerate(zip(got, want)):
+        assert [(e[6], e[7]) for e in L] == [(e[6], e[7]) for e in Wl], (res, f)
+        assert np.abs(np.array([e[:4] for e in L]).reshape(-1, 4) - np.array([e[:4] for e in Wl]).reshape(-1, 4)).max(initial=0) <= 1
     # .half() like a reference module: half in, half out
     mh = yf.YoloFastest(io).to(dev).eval()
     mh.load_state_dict(torch.load(WEIGHTS[res], map_location=dev))
@@ -1269,8 +1291,12 @@ def test_profile_with_repeated_launches_changes_nothing(yf, golden, dev):
     x = _x(g["input_u8"], dev)
     with torch.no_grad():
         a = m(x)
-    one = m.profile(x, reps=3, launch_repeats=1)
-    four = m.profile(x, reps=3, launch_repeats=4)
+    one, h1 = m.profile(x, reps=3, launch_repeats=1, return_heads=True)
+    four, h4 = m.profile(x, reps=3, launch_repeats=4, return_heads=True)
+    # the heads the profiled passes THEMSELVES wrote (an op with an aliased slot would be relaunched on other data than its
+    # first launch saw and this is where it would show)
+    for h in (h1, h4):
+        assert torch.equal(h[0], a[0]) and torch.equal(h[1], a[1])
     assert [o["name"] for o in one] == [o["name"] for o in four] and all(o["ms"] > 0 for o in four)
     assert sum(o["ms"] for o in four) <= 1.25 * sum(o["ms"] for o in one)
     with torch.no_grad():

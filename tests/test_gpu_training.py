@@ -513,6 +513,13 @@ def test_training_free_running_two_steps(yf, golden, dev, capsys):
     assert tot > 1000 and bad <= 0.01 * tot, (bad, tot)
 
 
+# Flip-level caps of test_training_network_against_the_fp64_oracle.  One flipped mask element of a BatchNorm'd channel
+# moves what is merely upstream of it by its share of the channel's batch -- measured 3e-2 .. 2e-1 for these seeds, torch's own fp32 1e-2 ..
+# 1e-1 -- and the flipped channel's own filter / gamma / beta by an O(1) share.  An upstream backward kernel that is wrong by O(0.3) of a
+# tensor's range no longer fits under UP_CAP (it was 0.5), a wrong own-channel reduction no longer under OWN_CAP (it was 2.0).
+UP_CAP, OWN_CAP = 0.25, 1.0
+
+
 @pytest.mark.parametrize("seed,tol", [(1, 1e-3), (2, 2e-2)])
 def test_training_network_against_the_fp64_oracle(yf, dev, seed, tol):
     """The composition (residual adds, the conv4_2 / conv5_2 branch points, deconv, torch.cat, both heads, the loss) on random weights
@@ -577,6 +584,7 @@ def test_training_network_against_the_fp64_oracle(yf, dev, seed, tol):
     names = [n for n, _ in m.named_parameters()]
     masks = fr.reach_masks(flips, names, [tuple(p.shape) for p in m.parameters()], parts=True)
     n_clean = n_clean_elems = n_elems = 0
+    worst_up = worst_own = 0.0
     for (name, p), w, (own, up) in zip(m.named_parameters(), g64, masks):
         g, w = p.grad.cpu().numpy().astype(np.float64).ravel(), w.numpy().ravel()
         scale = np.abs(w).max()
@@ -592,9 +600,12 @@ def test_training_network_against_the_fp64_oracle(yf, dev, seed, tol):
         # upstream of a flip: flip-level, not O(1) -- with 3 frames one mask element is 1/18 .. 1/1152 of a channel's batch; measured
         # 3e-2 .. 2e-1 (torch's own fp32: 1e-2 .. 1e-1).  An O(1) error of an upstream backward kernel does not fit under this cap.
         if up.any():
-            assert err[up].max() <= 0.5, (name, err[up].max(), flips)
+            worst_up = max(worst_up, float(err[up].max()))
+            assert err[up].max() <= UP_CAP, (name, err[up].max(), flips)
         if own.any():                           # the flipped channel's own filter / gamma / beta: one mask element is an O(1) share
-            assert err[own].max() <= 2.0, (name, err[own].max(), flips)
+            worst_own = max(worst_own, float(err[own].max()))
+            assert err[own].max() <= OWN_CAP, (name, err[own].max(), flips)
+    print("seed %d: %d flips %s; worst upstream-of-a-flip error %.3g, worst own-channel error %.3g" % (seed, n_flips, flips, worst_up, worst_own))
     assert n_clean >= 10, (n_clean, flips)      # the flips (if any) leave at least the large head's private layers untouched
     assert n_clean_elems >= 0.1 * n_elems, (n_clean_elems, n_elems, flips)   # (seed 2: 16 %, a flip as far down as res3_5.conv2)
     # the running statistics moved like the module's buffers
@@ -655,6 +666,7 @@ def test_training_graphs_with_three_rotating_input_buffers(yf, dev):
         crit = [val.YOLOLossV3(io["anchors"][i], 3, [64, 96, 1], dev, model=m) for i in range(2)]
         opt = training.Adam(m.parameters(), lr=0.001)
         tr = training._trainer(m, 64, 96, dev)
+        assert tr.lib.yf_trainer_set_graphs(tr.handle, 1 if graphs else 0) == 0
         stats, losses = [], []
         for it in range(36):
             losses.append(float(training.train_step(m, crit, opt, xs[it % 3], td)[0].detach()))
@@ -674,6 +686,9 @@ def test_training_graphs_with_three_rotating_input_buffers(yf, dev):
         assert full[2 + p] <= 12, full                       # never "a capture per iteration"
         assert full[2 + p] - half[2 + p] <= 4, (half, full)    # and bounded in the steady state: replaying, or given up capturing
     assert all(np.isfinite(losses))
+    # ... and the 36 losses ARE those of the same loop issued as plain launches (the docstring said so, the test did not)
+    eager, no_stats = run(False)
+    assert no_stats == [] and losses == eager, [(i, a, b) for i, (a, b) in enumerate(zip(losses, eager)) if a != b][:4]
 
 
 def test_training_forward_guards(yf, dev):

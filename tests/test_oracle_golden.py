@@ -364,3 +364,26 @@ def test_io_configs_train_mode_oracle(golden, tag):
                                atol=1e-6)
     bufs = np.concatenate([sd[k].numpy().ravel() for k in sd if k.endswith(("running_mean", "running_var"))])
     np.testing.assert_allclose(bufs[::7], g[tag + "_train_buffers_sample"], rtol=1e-5, atol=1e-6)
+
+
+def test_fp16_rounding_alone_exceeds_the_surveys_tolerance(golden, sds):
+    """SURVEY.md 8(d).3 states 2e-2 on logits for "activations/weights fp16, fp32 accumulate" at 640x512.  Nothing of the library is
+    involved here: torch on the CPU evaluates the folded graph in fp32 with ONE class of tensors rounded to fp16 (oracle/fp16_rounding_sim.py)
+    on bundled frames, against the reference's own fp32 logits.  Each class alone is outside 2e-2 -- the weights (4.5e-2 on six frames),
+    the tensors between launches (8e-2), the activation operands (4e-2) -- because the logits reach +-36, where ONE fp16 ulp is 3.1e-2.
+    Hence the fp16-storage variant (`f16`) is non-conforming by arithmetic and the split-operand variant (`f16x3`: every fp16 operand
+    carries a second fp16 with the rounding remainder) is the configs[2] implementation that is held to 2e-2 (tests/test_gpu_parity.py)."""
+    from oracle.fp16_rounding_sim import Sim, fold
+    g = golden("golden_512")
+    nf = 3
+    fw = fold(sds[512])
+    x = bo.preprocess(g["input_u8"][:nf])
+    ref = (g["head_large"][:nf], g["head_small"][:nf])
+    assert max(np.abs(r).max() for r in ref) > 32.0          # one fp16 ulp in [32, 64) is 2^-5 = 3.1e-2 > 2e-2
+    def worst(**kw):
+        out = Sim(fw, **kw).forward(x)
+        return max(float(np.abs(o.numpy() - r).max()) for o, r in zip(out, ref))
+    assert worst() < 2e-3                                     # the fp32 folded graph itself: rounding noise only
+    errs = {k: worst(**{k: True}) for k in ("W", "T", "A")}
+    print("max |dlogit| at 640x512 with ONE class rounded to fp16:", errs)
+    assert all(v > 2e-2 for v in errs.values()), errs

@@ -77,6 +77,7 @@ _SIGS = {
                                        _c.c_size_t, _c.c_void_p]),
     "yf_trainer_graph_replays": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_long), _c.POINTER(_c.c_long)]),
     "yf_trainer_graph_stats": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_long)]),
+    "yf_trainer_set_graphs": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "yf_train_scratch_bytes": (_c.c_int, [_c.POINTER(_c.c_size_t)]),
     "yf_train_bn_forward": (_c.c_int, [_c.c_int] + [_c.c_void_p] * 7 + [_c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "yf_train_bn_backward": (_c.c_int, [_c.c_int] + [_c.c_void_p] * 8 + [_c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_void_p, _c.c_void_p]),
@@ -107,6 +108,7 @@ _SIGS = {
     "yf_set_branches": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "yf_set_lanes": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "yf_set_profile_repeats": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "yf_profile_head_offsets": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_size_t)]),
 }
 EXPORTS = tuple(_SIGS)
 _lib = None

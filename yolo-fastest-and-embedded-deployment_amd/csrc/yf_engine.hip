@@ -776,9 +776,10 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
     if (memcmp(hd.magic, "YFHIPW01", 8) || hd.version != 1) return fail(YF_E_BLOB, "bad magic/version");
     if (hd.n_layers != (uint32_t)kNumLayers)
         return fail(YF_E_BLOB, "blob describes n_layers=%u; YoloFastest has %d", hd.n_layers, kNumLayers);
-    if (hd.input_channel < 1 || hd.input_channel > 4)
+    static_assert((int)yf::POST_MAX_ANCHORS == (int)yf_layers::MAX_NUM_ANCHORS, "one anchor limit");
+    if (hd.input_channel < 1 || hd.input_channel > (uint32_t)yf_layers::MAX_INPUT_CHANNEL)
         return fail(YF_E_BLOB, "input_channel=%u: the HIP engine implements 1 .. 4 input channels", hd.input_channel);
-    if (hd.num_anchors < 1 || hd.num_anchors > (uint32_t)yf::POST_MAX_ANCHORS || hd.num_cls < 1 || hd.num_cls > 4096 ||
+    if (hd.num_anchors < 1 || hd.num_anchors > (uint32_t)yf::POST_MAX_ANCHORS || hd.num_cls < 1 || hd.num_cls > (uint32_t)yf_layers::MAX_NUM_CLS ||
         hd.num_out != hd.num_anchors * (5 + hd.num_cls))
         return fail(YF_E_BLOB, "blob describes num_anchors=%u num_cls=%u num_out=%u: need 1..%d anchors, >= 1 class and num_out == "
                     "num_anchors * (5 + num_cls) (yolo_fastest.py:76)", hd.num_anchors, hd.num_cls, hd.num_out, yf::POST_MAX_ANCHORS);
@@ -1364,7 +1365,9 @@ static int profile_forward(yf_handle h, const float* d_x, const uint8_t* d_u8, i
     float* hs = hl + h->head_l_elems * (size_t)N;
     ProfileEvents pe;
     pe.repeats = h->profile_repeats > 0 ? h->profile_repeats : 1;
-    pe.ev.resize(nops + 1);
+    pe.ev.assign(nops + 1, nullptr);
+    // the events are destroyed on EVERY exit path (HIP_OK returns from the middle of this function)
+    struct EventGuard { std::vector<hipEvent_t>& ev; ~EventGuard() { for (auto& x : ev) if (x) { (void)hipEventDestroy(x); x = nullptr; } } } guard{pe.ev};
     for (auto& ev : pe.ev) HIP_OK(hipEventCreate(&ev));
     int rc = run_forward(h, d_x, N, hl, hs, ws, chain, (hipStream_t)stream, nullptr, nullptr, 0, &pe, d_u8, down2);
     if (rc == YF_OK) {
@@ -1374,8 +1377,18 @@ static int profile_forward(yf_handle h, const float* d_x, const uint8_t* d_u8, i
             op_ms[i] /= (float)pe.repeats;
         }
     }
-    for (auto& ev : pe.ev) (void)hipEventDestroy(ev);
     return rc;
+}
+
+// Where the profiled pass left its head logits inside the caller's workspace (byte offsets; NCHW fp32 like yf_forward's outputs): lets a
+// test hold the repeated-launch pass itself to yf_forward's bits.
+int yf_profile_head_offsets(yf_handle h, int N, size_t* large_off, size_t* small_off)
+{
+    if (!h || !large_off || !small_off || N <= 0) return fail(YF_E_INVALID, "yf_profile_head_offsets: null pointer or N <= 0");
+    const size_t chain = ((h->frame_floats_max() * (size_t)N * h->esz()) + 255) & ~(size_t)255;
+    *large_off = chain;
+    *small_off = chain + h->head_l_elems * (size_t)N * sizeof(float);
+    return YF_OK;
 }
 
 int yf_set_profile_repeats(yf_handle h, int repeats)

@@ -764,8 +764,20 @@ void k19_pack_weights(const float* w9, const float* w21, float* out, int wmode)
     }
 }
 
-// elements the kernel may read before / after its input tensor (one region row beyond either end)
-size_t k19m_guard_elems(int W) { return ((size_t)(W + 34) * 4 + 63) & ~(size_t)63; }
+// Pixels of the 4-channel input that the two kernels' UNCHECKED 16-byte loads may touch before / after the tensor (W = its width in pixels).
+// launch_k19m() must only be handed an input with k19m_guard_elems(W) readable elements on either side (the engine's workspace guard band,
+// yf_engine.hip plan_workspace; tools/kbench.hip allocates the same): nothing else bounds these loads.
+//   k19m_kernel: the 17x33 region of an 8x16 output tile starts one row and one column outside and ends up to 33 columns past a row end;
+//   k19r_kernel: a wave's 3x33 region starts at input (2 oy - 1, 32 sx - 1) -> W + 1 pixels before the tensor, and its last segment
+//                reaches column 32 segs - 1 + 32 <= W + 30 of the last row -> at most 31 pixels past the end.
+constexpr size_t k19m_over_pixels(int W) { return (size_t)W + 34; }
+constexpr size_t k19r_over_pixels(int W) { return (size_t)W + 1 > 31 ? (size_t)W + 1 : 31; }
+static_assert(k19r_over_pixels(2) <= k19m_over_pixels(2) && k19r_over_pixels(4096) <= k19m_over_pixels(4096), "the guard band must cover both kernels");
+size_t k19m_guard_elems(int W)
+{
+    const size_t px = k19m_over_pixels(W) > k19r_over_pixels(W) ? k19m_over_pixels(W) : k19r_over_pixels(W);
+    return (px * 4 + 63) & ~(size_t)63;
+}
 
 size_t k19m_lds_bytes(int dtype)
 {
@@ -811,7 +823,16 @@ int launch_k19m(K19Args a, int N, hipStream_t s, int dtype)
     }
     a.n_frames = N;
     if (dtype == DT_F32 && k19r_enabled() && a.H % 2 == 0 && a.W % 2 == 0) {
-        static const int nw = [] { const char* v = getenv("YF_K19R_NW"); return v ? atoi(v) : 16; }();   // 16 = weights from LDS (default: 156 us); A/B: 8 (166 us) | 12 (160 us) | 1012 = 12 waves, weights from LDS (162 us)
+        // developer switch: 16 = weights from LDS (default: 156 us); A/B: 8 (166 us) | 12 (160 us) | 1012 = 12 waves, weights from LDS (162 us);
+        // anything else is refused (it used to select the 12-wave form silently)
+        static const int nw = [] {
+            const char* v = getenv("YF_K19R_NW");
+            if (!v || !*v) return 16;
+            const int k = atoi(v);
+            if (k != 8 && k != 12 && k != 16 && k != 1012) { fprintf(stderr, "yolo_fastest_hip: YF_K19R_NW=%s is not one of 8, 12, 16, 1012\n", v); return -1; }
+            return k;
+        }();
+        if (nw < 0) return -1;
         const long items = (long)N * a.Ho * ((a.Wo + 15) / 16);
         return nw == 8 ? launch_k19r_t<8, false>(a, items, n_cu, dev, s) : nw == 16 ? launch_k19r_t<16, true>(a, items, n_cu, dev, s)
                        : nw == 1012 ? launch_k19r_t<12, true>(a, items, n_cu, dev, s) : launch_k19r_t<12, false>(a, items, n_cu, dev, s);

@@ -52,6 +52,7 @@ struct TLayer {
 };
 struct yf_trainer_s {
     int device, H, W;
+    bool graphs_on = true;   // yf_trainer_set_graphs: 0 = every pass as plain launches (what YF_TRAIN_GRAPH_OFF does process-wide)
     LayerSpec layers[kNumLayers];   // the graph for this trainer's io_params: kBaseLayers with conv0's Cin and the heads' Cout set (make_layers)
     TLayer L[kNumLayers];
     size_t act_floats;      // per frame: all z / y, the concat buffer
@@ -374,8 +375,8 @@ int yf_trainer_create(int H, int W, int device, yf_trainer* out) { return yf_tra
 int yf_trainer_create_ex(int H, int W, int device, int input_channel, int num_out, yf_trainer* out)
 {
     if (!out || H <= 0 || W <= 0 || H % 32 || W % 32) return fail(YF_E_INVALID, "yf_trainer_create: H and W must be positive multiples of 32");
-    if (input_channel < 1 || input_channel > 4 || num_out < 1 || num_out > 4096)
-        return fail(YF_E_INVALID, "yf_trainer_create: input_channel must be 1..4 and num_out 1..4096");
+    if (input_channel < 1 || input_channel > yf_layers::MAX_INPUT_CHANNEL || num_out < 1 || num_out > yf_layers::MAX_NUM_OUT)   // the inference engine's limits
+        return fail(YF_E_INVALID, "yf_trainer_create: input_channel must be 1..%d and num_out 1..%d", (int)yf_layers::MAX_INPUT_CHANNEL, (int)yf_layers::MAX_NUM_OUT);
     yf_trainer_s* t = new yf_trainer_s();
     t->device = device;
     make_layers(t->layers, input_channel, num_out);
@@ -596,7 +597,7 @@ static int run_pass(yf_trainer_s* t, yf_trainer_s::PassGraphs& pg, std::vector<u
                                       "(a host-synchronous step): run one eager iteration at this batch size before capturing");
         return rc;
     }
-    if (off || pg.failures >= 2 || pg.thrash >= 4 || (!always && (long)N * t->H * t->W > 40L * 256 * 320)) return body(s, false);   // (two failed captures / a thrashing pointer pattern: never again)
+    if (off || !t->graphs_on || pg.failures >= 2 || pg.thrash >= 4 || (!always && (long)N * t->H * t->W > 40L * 256 * 320)) return body(s, false);   // (two failed captures / a thrashing pointer pattern: never again)
     for (yf_trainer_s::PassGraph& g : pg.g)
         if (g.exec && g.key == key) {
             HIP_OK(hipGraphLaunch(g.exec, s));
@@ -697,6 +698,12 @@ int yf_trainer_graph_replays(yf_trainer t, long* forward, long* backward)
     if (!t || !forward || !backward) return fail(YF_E_INVALID, "yf_trainer_graph_replays: null argument");
     *forward = t->gfwd.replays;
     *backward = t->gbwd.replays;
+    return YF_OK;
+}
+int yf_trainer_set_graphs(yf_trainer t, int on)
+{
+    if (!t) return fail(YF_E_INVALID, "yf_trainer_set_graphs: null trainer");
+    t->graphs_on = on != 0;
     return YF_OK;
 }
 int yf_trainer_graph_stats(yf_trainer t, long* out6)

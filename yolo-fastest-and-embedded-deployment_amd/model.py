@@ -21,6 +21,7 @@ import torch.nn as nn
 from . import _lib, packer
 
 
+MAX_NUM_ANCHORS, MAX_NUM_CLS = 8, 4096   # csrc/yf_layers.h (one set of limits for yf_create and yf_trainer_create_ex)
 DEFAULT_FUSION = 2   # yf_set_fusion: 0 = one launch per layer (bring-up, every probe); 1 = block-fused kernels (round 2's plan);
                      # 2 = + the per-frame deep stage's launch boundaries removed (conv5_2 in the res5 launch, ...)
 
@@ -99,8 +100,8 @@ class YoloFastest(nn.Module):
         if self.input_channel not in (1, 2, 3, 4):
             raise NotImplementedError("the HIP engine implements input_channel 1 (gray), 3 (cv2's BGR frames), 2 and 4, not %r"
                                       % (self.input_channel,))
-        if not (1 <= int(num_anchor) <= 8) or int(self.num_cls) < 1:
-            raise ValueError("num_anchors must be 1..8 and num_cls >= 1")
+        if not (1 <= int(num_anchor) <= MAX_NUM_ANCHORS) or not (1 <= int(self.num_cls) <= MAX_NUM_CLS):   # csrc/yf_layers.h: engine AND trainer
+            raise ValueError("num_anchors must be 1..%d and num_cls 1..%d" % (MAX_NUM_ANCHORS, MAX_NUM_CLS))
         # parameter containers, module-definition order of the reference (state-dict order follows it)
         blocks = {}
         for name, kind, cin, cout, k, stride, relu in packer.layer_table(self.num_out, self.input_channel):
@@ -266,7 +267,7 @@ class YoloFastest(nn.Module):
                                        ws.data_ptr(), ws.numel(), ctypes.c_void_p(stream)))
         return hl, hs
 
-    def profile(self, x, reps=5, launch_repeats=1):
+    def profile(self, x, reps=5, launch_repeats=1, return_heads=False):
         """Per-launch timing of one forward pass (HIP events on the launch stream around every kernel; launch_repeats > 1: around that
         many back-to-back launches of it, divided -- the event packets and the dispatch gap of a lone launch, 5-7 us, drop out).
         Returns a list of dicts: name, ms (mean over reps), algorithmic_bytes, flops (= mfma_flops + valu_flops, by the pipe
@@ -301,6 +302,15 @@ class YoloFastest(nn.Module):
             _lib.check(e.lib.yf_op_dtype(e.handle, i, ctypes.byref(kdt)))
             out.append(dict(name=name.value.decode(), ms=acc[i], algorithmic_bytes=b.value * N, flops=(fm.value + fv.value) * N,
                             mfma_flops=fm.value * N, valu_flops=fv.value * N, kernel_dtype=("f32", "f16", "f16x3")[kdt.value]))
+        if return_heads:
+            lo, so = ctypes.c_size_t(), ctypes.c_size_t()
+            _lib.check(e.lib.yf_profile_head_offsets(e.handle, N, ctypes.byref(lo), ctypes.byref(so)))
+            torch.cuda.current_stream(x.device).synchronize()
+            raw = ws.view(torch.uint8)
+            nl, ns = N * self.num_out * (H // 16) * (W // 16), N * self.num_out * (H // 32) * (W // 32)
+            hl = raw[lo.value:lo.value + 4 * nl].view(torch.float32).view(N, self.num_out, H // 16, W // 16).clone()
+            hs = raw[so.value:so.value + 4 * ns].view(torch.float32).view(N, self.num_out, H // 32, W // 32).clone()
+            return out, (hl, hs)
         return out
 
     def probe(self, x, name):
