@@ -301,6 +301,64 @@ def self_launch(n_gpus):
     return subprocess.call(cmd, env=env)
 
 
+def pin_rank_to_cpus(local_rank, local_world):
+    """One rank = one GPU = one slice of the host's CPUs: at 8 ranks every host thread issues ~26 k launches/s and
+    must neither migrate nor share a core with another rank's.  Called BEFORE the first GPU call, so the HIP runtime's and RCCL's helper
+    threads inherit the mask.  Which CPUs: those of the NUMA node the rank's GPU hangs off, read from sysfs without touching the GPU
+    (KFD topology node -> PCI address -> numa_node -> cpulist), divided among the ranks whose GPUs share that node; where sysfs does not
+    say, contiguous equal slices of the allowed set.  Returns a small dict for the JSON line (or None: nothing pinned)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return None
+    if local_world < 2 or len(allowed) < 2 * local_world:
+        return None
+
+    def gpu_numa_nodes():
+        out, base = [], "/sys/class/kfd/kfd/topology/nodes"
+        for n in sorted(os.listdir(base), key=int):
+            props = dict(l.split()[:2] for l in open(f"{base}/{n}/properties") if len(l.split()) >= 2)
+            if int(props.get("simd_count", "0")) == 0:
+                continue        # a CPU node
+            loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+            bdf = "%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 7)
+            with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+                out.append(int(f.read()))
+        return out
+
+    def cpulist(node):
+        cpus = []
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus += list(range(int(a), int(b or a) + 1))
+        return cpus
+
+    mine, how = None, "contiguous slice of the allowed CPUs"
+    try:
+        nodes = gpu_numa_nodes()
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+        if vis:
+            nodes = [nodes[int(v)] for v in vis.split(",") if v.strip().isdigit() and int(v) < len(nodes)]
+        if local_rank < len(nodes) and nodes[local_rank] >= 0:
+            node = nodes[local_rank]
+            peers = [r for r in range(min(local_world, len(nodes))) if nodes[r] == node]
+            cpus = [c for c in cpulist(node) if c in set(allowed)]
+            per = len(cpus) // len(peers)
+            if per >= 2:
+                k = peers.index(local_rank)
+                mine, how = cpus[k * per:(k + 1) * per], f"NUMA node {node} of the rank's GPU (sysfs), shared by {len(peers)} rank(s)"
+    except (OSError, ValueError, IndexError, KeyError):
+        mine = None
+    if not mine:
+        per = len(allowed) // local_world
+        mine = allowed[local_rank * per:(local_rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return {"cpus": len(mine), "first": mine[0], "last": mine[-1], "how": how}
+
+
 def launch_roofline(o, dtype, traffic, issue=None):
     """Physical roof of one launch.  fp32: MFMA and vector FMAs share one issue rate on this part (measured), so the
     floor is (all flops) / 157.3 TF.  fp16: the matrix cores run beside the vector ALU, the floor is the larger of the two.
@@ -375,6 +433,11 @@ def main():
     ap.add_argument("--kmax", type=int, default=64)
     ap.add_argument("--exchange-at-1", action="store_true",
                     help="rehearsal of the N > 1 code path on one GPU: a 1-rank RCCL group and the all-gather of every step's records")
+    ap.add_argument("--pin-cpus", type=int, nargs=2, default=None, metavar=("RANK", "OF"),
+                    help="rehearse the multi-GPU CPU pinning on one GPU: pin this process like local rank RANK of OF ranks")
+    ap.add_argument("--regions", type=int, default=5,
+                    help="timed regions of --steps steps each, run back to back in the same loop after ONE warm-up: `value` is the first "
+                         "(the contract's K steps), `repeat_values` lists them all (the box-to-box and run-to-run spread in the record)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra f16x3 measurement of the same workload")
     ap.add_argument("--no-live-traffic", action="store_true",
@@ -403,6 +466,13 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; "
                          f"use --nproc-per-node == --gpus (or run plain `python bench.py --gpus N`, which launches the ranks itself)")
+
+    # rank -> CPU slice, before the first GPU call of this process (N = 1: the whole host stays available)
+    affinity = None
+    if world > 1:
+        affinity = pin_rank_to_cpus(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    elif args.pin_cpus:
+        affinity = pin_rank_to_cpus(args.pin_cpus[0], args.pin_cpus[1])
 
     # HBM traffic of every launch, by the counters, in THIS run (children; this process has not touched the GPU yet)
     live, live_note = ({}, "not requested")
@@ -509,7 +579,7 @@ def main():
 
     REC = ("counts", "boxes", "scores", "cls", "src")
 
-    def timed(m, p, depth, steps, warmup, exchange):
+    def timed(m, p, depth, steps, warmup, exchange, regions=1, region_times=None):
         """W untimed + K timed steps; a step = model -> decode -> NMS over the resident batch [-> all-gather].  depth > 1: consecutive
         steps are issued round-robin on `depth` streams, each with its own engine (yolo_fastest_amd.BatchPipeline): a batch's late,
         per-frame stages run beside the next batch's early, machine-filling ones.  Every step -- and every exchange -- completes
@@ -549,21 +619,27 @@ def main():
 
         grouped = multi or bool(exchange)
         run(warmup)
-        torch.cuda.synchronize(dev)
-        if grouped:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        raw = run(steps)
-        torch.cuda.synchronize(dev)
-        if grouped:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        el = time.perf_counter() - t0
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
-        if grouped:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return float(tt.item()), raw
+        first = None
+        for reg in range(max(1, regions)):     # region 0 is THE timed region (exactly K steps); the others repeat it for the spread
+            torch.cuda.synchronize(dev)
+            if grouped:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            raw_r = run(steps)
+            torch.cuda.synchronize(dev)
+            if grouped:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            if grouped:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            if region_times is not None:
+                region_times.append(float(tt.item()))
+            if first is None:
+                first = (float(tt.item()), raw_r)
+        return first
 
     def same_detections(a, b):
         if not torch.equal(a["counts"], b["counts"]):
@@ -586,7 +662,8 @@ def main():
         return e0.elapsed_time(e1) / reps
 
     model, post = make(args.dtype, lanes, branches)
-    elapsed, raw = timed(model, post, in_flight, args.steps, args.warmup, multi)
+    region_s = []
+    elapsed, raw = timed(model, post, in_flight, args.steps, args.warmup, multi, regions=args.regions, region_times=region_s)
 
     # model / post-process split and the one-batch-at-a-time figure (two half-batch lanes, the small head on its side stream): measured
     # after the headline's timed region, same process
@@ -920,6 +997,8 @@ def main():
                       if args.res == 256 else "frames/sec end-to-end, 640x512",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "ms_per_frame": round(1e3 * elapsed / args.steps / n_total, 6),
+            # `value` is region 0; the same K-step region repeated in the same loop (no re-warm-up, same streams): the spread of the headline
+            "repeat_values": [round(n_total * args.steps / t, 1) for t in region_s],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic" if args.frames == "noise" else "the reference's 20 bundled frames tiled to the batch",
             "config": {"workload": f"YOLO-Fastest {W}x{H} batch={args.batch} fp32 per GPU, synthetic uniform-u8 frames "
@@ -927,7 +1006,7 @@ def main():
                                    f"YOLO-Fastest {W}x{H} batch={args.batch} {args.dtype} per GPU, {args.frames} frames"
                                    + (", dense synthetic head logits (SURVEY.md 8(d) config 5)" if args.dense else ""),
                        "global_batch": n_total, "weights": wname, "kmax": args.kmax, "chunk": args.chunk, "in_flight": in_flight, "lanes": lanes, "branches": branches,
-                       "world_size": world,
+                       "world_size": world, "cpu_affinity": affinity,
                        "parallelism": f"dp{world} (frames sharded, one RCCL all-gather of box records)" if world > 1 else "single GPU",
                        "survivors_per_frame_mean": round(float(np.clip(counts, 0, None).mean()), 3)},
             "roofline": roofline,

@@ -94,6 +94,52 @@ def test_all_gather_two_ranks_equals_unsharded():
         assert res == [(0, True), (1, True)]
 
 
+def _worker8(rank, world, port, n_total, kmax, q):
+    """world size 8, ragged shards, and two frames that did NOT end normally: frame 3 (rank 0's shard) overflowed its capacity -- count =
+    the true number of survivors > kmax -- and frame n_total - 2 (the last rank's shard) hit the reference's ZeroDivisionError (count -2).
+    What every rank must see: the gathered counts are bit-identical to the unsharded ones (status included), to_lists(on_error='mark') names
+    exactly those two frames with the same exception types on every rank, every other frame's list equals the unsharded one, and the
+    default on_error='raise' raises like the single-GPU call does."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from yolo_fastest_amd import YOLO_post_process
+    full = _fake_raw(n_total, kmax, 321)
+    full["counts"][3] = kmax + 17
+    full["counts"][n_total - 2] = -2
+    lo, hi = yfd.shard_range(n_total, rank, world)
+    mine = YOLO_post_process.record_views(yfd.pack_records({k: v[lo:hi].contiguous() for k, v in full.items()}), kmax)
+    got = yfd.all_gather_detections_async(mine, n_total).wait()
+    ok = all(torch.equal(got[k], full[k]) for k in full) and got["counts"].shape[0] == n_total
+    lists = YOLO_post_process.to_lists(got, with_src=True, on_error="mark")
+    want = YOLO_post_process.to_lists(full, with_src=True, on_error="mark")
+    bad = [f for f, L in enumerate(lists) if isinstance(L, Exception)]
+    ok = ok and bad == [3, n_total - 2] and isinstance(lists[3], OverflowError) and isinstance(lists[n_total - 2], ZeroDivisionError)
+    ok = ok and all(a == b for f, (a, b) in enumerate(zip(lists, want)) if f not in bad)
+    try:
+        YOLO_post_process.to_lists(got)
+        ok = False
+    except ZeroDivisionError:      # the reference's loop dies at that frame (detect.py:39); -2 wins over an overflow elsewhere
+        pass
+    q.put((rank, ok, hi - lo))
+    dist.destroy_process_group()
+
+
+def test_all_gather_eight_ranks_ragged_with_error_frames():
+    """the N = 8 exchange on gloo.  29 frames over 8 ranks = shards of 4, 4, 4, 4, 4, 3, 3, 3."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker8, args=(r, 8, port, 29, 6, q)) for r in range(8)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in ps)
+    for p in ps:
+        p.join(60)
+    assert [r[:2] for r in res] == [(r, True) for r in range(8)], res
+    assert [r[2] for r in res] == [4, 4, 4, 4, 4, 3, 3, 3]
+
+
 def _worker_grad(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -124,18 +124,33 @@ class YOLO_post_process:
         return out
 
     @staticmethod
-    def to_lists(raw, with_src=False):
-        """GPU result -> per-frame Python lists in the reference's element format."""
+    def to_lists(raw, with_src=False, on_error="raise"):
+        """GPU result -> per-frame Python lists in the reference's element format.
+        A frame's count says how the frame ended (include/yolo_fastest_hip.h): 0 .. kmax survivors; more than kmax = the TRUE number, of
+        which the first kmax are stored (capacity overflow); -2 = the reference's own ZeroDivisionError (detect.py:39: two zero-area boxes
+        of one class compared).  on_error="raise" (default) behaves like the reference's loop, which dies at such a frame:
+        ZeroDivisionError / OverflowError for the whole batch.  on_error="mark": the frame's entry is the exception INSTANCE and the other
+        frames are returned -- what a caller that gathers many ranks' frames wants (dist.all_gather_detections: the count travels in the
+        record block, so every rank sees the same status for every frame)."""
+        if on_error not in ("raise", "mark"):
+            raise ValueError("on_error must be 'raise' or 'mark'")
         counts = raw["counts"].cpu().numpy()
         kmax = raw["boxes"].shape[1]
-        if (counts == -2).any():
-            raise ZeroDivisionError("division by zero")  # detect.py:39, two zero-area boxes compared
-        if (counts > kmax).any():
-            raise OverflowError("more than kmax=%d survivors in a frame (max %d): raise kmax" % (kmax, counts.max()))
+        if on_error == "raise":
+            if (counts == -2).any():
+                raise ZeroDivisionError("division by zero")  # detect.py:39, two zero-area boxes compared
+            if (counts > kmax).any():
+                raise OverflowError("more than kmax=%d survivors in a frame (max %d): raise kmax" % (kmax, counts.max()))
         boxes, scores = raw["boxes"].cpu().numpy(), raw["scores"].cpu().numpy()
         cls, src = raw["cls"].cpu().numpy(), raw["src"].cpu().numpy()
         frames = []
         for f, n in enumerate(counts):
+            if n == -2:
+                frames.append(ZeroDivisionError("division by zero"))
+                continue
+            if n > kmax:
+                frames.append(OverflowError("frame %d: %d survivors, capacity kmax=%d" % (f, n, kmax)))
+                continue
             L = []
             for k in range(int(n)):
                 e = [int(boxes[f, k, 0]), int(boxes[f, k, 1]), int(boxes[f, k, 2]), int(boxes[f, k, 3]),
