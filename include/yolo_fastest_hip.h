@@ -271,11 +271,30 @@ int yf_detect_packed(yf_handle h, const float *d_x, int N, double conf_thres, do
  * reversed, detect.py:119 `img[:, :, ::-1].transpose(2, 0, 1)`; the box mean is taken per channel. */
 int yf_preprocess_u8(yf_handle h, const uint8_t *d_u8, int N, int src_h, int src_w, float *d_x, void *stream);
 
-/* yf_forward on u8 gray frames: Detect_YOLO.__pre_process's arithmetic (src/detect.py:115-124) is fused into the first
- * kernel's loads -- d_u8 uint8 [N,src_h,src_w] (C_in = 3: [N,src_h,src_w,3] HWC BGR), src == net size or exactly 2x (2x2 box mean).  Bit-identical to
- * yf_preprocess_u8 followed by yf_forward, one pass and 3-15 bytes per pixel less HBM traffic. */
+/* yf_forward on u8 frames: Detect_YOLO.__pre_process's arithmetic (src/detect.py:115-124) in front of the net.  d_u8 uint8 [N,src_h,src_w]
+ * (C_in = 3: [N,src_h,src_w,3] HWC BGR) of ANY size (detect.py:115-116: `cv2.resize(img, (input_shape[1], input_shape[0]))`):
+ *   src == net size, or exactly 2x (cv::resize turns INTER_LINEAR into INTER_AREA there: the 2x2 box mean (a+b+c+d+2)>>2): fused into the
+ *     first kernel's loads -- bit-identical to yf_preprocess_u8 followed by yf_forward, one pass and 3-15 bytes per pixel less HBM traffic;
+ *   any other size: one extra pass (yf_cv_preprocess_u8: cv::resize's 8-bit INTER_LINEAR) into net-sized u8 frames at the end of the
+ *     workspace, then the fused entry.  The first call for a new source size builds and uploads cv::resize's coefficient tables
+ *     (host-synchronous: not inside a stream capture). */
 int yf_forward_u8(yf_handle h, const uint8_t *d_u8, int N, int src_h, int src_w, float *d_head_large, float *d_head_small,
                   void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* The two OpenCV calls of Detect_YOLO.__pre_process (src/detect.py:110-116) on the device, for any source size:
+ *     img = cv2.cvtColor(ori_img, cv2.COLOR_BGR2GRAY)        1-channel net, src_c == 3 (cv2.imread's BGR frames)
+ *     img = cv2.resize(img, (W, H))                           INTER_LINEAR; exactly 1/2 -> the 2x2 mean; same size -> copy
+ * d_src uint8 [N,src_h,src_w(,3)] -> d_dst uint8 [N,H,W(,C_in)] (a 3-channel net keeps BGR order: detect.py:119's reversal is the next step).
+ * OpenCV's published 8-bit arithmetic is restated: gray = (B*BY + G*GY + R*RY + half) >> shift with gray_bits 14 (4899/9617/1868; 0 means
+ * 14) or 15 (9798/19235/3735: newer 4.x builds); resize with 11-bit coefficients, dst = (((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2) >> 2.
+ * Bit-exact against oracle/cv_oracle.py; parity with an actual OpenCV build is UNPINNED (cv2 is not available where this was built, and an
+ * IPP / vendor-HAL build may round differently). */
+int yf_cv_preprocess_u8(yf_handle h, const uint8_t *d_src, int N, int src_h, int src_w, int src_c, int gray_bits, uint8_t *d_dst, void *stream);
+
+/* yf_forward on cv2.imread's frames (uint8 [N,src_h,src_w,3], BGR) of any size: yf_cv_preprocess_u8 + the fused (v-128)/255 entry.  What
+ * `Detect_YOLO.batch_detect` does per image (detect.py:108-127, 152), batched.  A 3-channel net: identical to yf_forward_u8. */
+int yf_forward_bgr_u8(yf_handle h, const uint8_t *d_bgr, int N, int src_h, int src_w, int gray_bits, float *d_head_large, float *d_head_small,
+                      void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* Introspection used by tests / bench. */
 /* Name ("conv1_8+conv1_9+conv2_1"), layer-granular algorithmic bytes and flops per frame of launch `op` of the

@@ -1,0 +1,143 @@
+"""SURVEY.md 8 row A0, the part rounds 1-4 left out: `Detect_YOLO.__pre_process`'s OpenCV calls (src/detect.py:107-116) for ANY frame
+size on the device -- cvtColor(BGR2GRAY) + cv2.resize (yf_cv_preprocess_u8, yf_forward_bgr_u8, yf_forward_u8 at any source size).
+Byte work: bit-exact against oracle/cv_oracle.py (OpenCV's published 8-bit arithmetic restated; parity with OpenCV itself is unpinned,
+see that file's header and tests/test_oracle_golden.py::test_cv_oracle_*)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WDIR = os.path.join(ROOT, "yolo-fastest-and-embedded-deployment_amd", "assets", "weights")
+WEIGHTS = {256: os.path.join(WDIR, "yolo_fastest_256x320_epoch28.pth"), 512: os.path.join(WDIR, "yolo_fastest_512x640_epoch27.pth")}
+# (source h, w): exactly 2x (area path), the net's own size, non-integer and integer ratios down, up-scaling, odd sizes, one pixel off,
+# a source narrower than 2 pixels per 4 destination pixels, and a single row / column
+SIZES = [(512, 640), (256, 320), (480, 640), (300, 400), (720, 1280), (128, 160), (257, 321), (101, 77), (768, 960), (1, 320), (256, 1), (1080, 1920)]
+
+
+@pytest.fixture(scope="module")
+def yf():
+    import yolo_fastest_amd
+    return yolo_fastest_amd
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def gray_model(yf, dev):
+    io = yf.io_params_for(256)
+    m = yf.YoloFastest(io).to(dev).eval()
+    m.load_state_dict(torch.load(WEIGHTS[256], map_location=dev))
+    return m, io
+
+
+def _rgb_model(yf, dev, golden):
+    import io_cfg
+    g = golden("golden_io")
+    io = io_cfg.io_for("c5rgb")
+    m = yf.YoloFastest(io).to(dev).eval()
+    m.load_state_dict({k: v.to(dev) for k, v in io_cfg.state_dict_for("c5rgb", int(g["c5rgb_seed"])).items()})
+    return m, io
+
+
+@pytest.mark.parametrize("size", SIZES)
+def test_bgr_frames_to_net_sized_gray_frames_bit_exact(gray_model, dev, size):
+    """cvtColor(BGR2GRAY) + resize of cv2.imread's frames, both of OpenCV's gray coefficient sets: every byte equals the oracle's."""
+    from oracle import cv_oracle as cv
+    m, io = gray_model
+    rng = np.random.default_rng(size[0] * 3 + size[1])
+    bgr = rng.integers(0, 256, (3,) + size + (3,), dtype=np.uint8)
+    bgr[1] = np.clip(bgr[1].astype(np.int32) // 4 + np.arange(size[1])[None, :, None] % 190, 0, 255).astype(np.uint8)   # a smoother frame
+    for bits in (14, 15):
+        got = m.cv_preprocess_u8(torch.from_numpy(bgr).to(dev), io["input_shape"], gray_bits=bits).cpu().numpy()
+        want = np.stack([cv.resize_linear_u8(cv.cvt_bgr2gray(f, bits), (320, 256)) for f in bgr])
+        assert got.shape == (3, 256, 320) and np.array_equal(got, want), (size, bits, int((got != want).sum()))
+    # gray source frames (1 channel in, 1 channel out): the resize alone
+    gray = np.ascontiguousarray(bgr[..., 1])
+    got = m.cv_preprocess_u8(torch.from_numpy(gray).to(dev), io["input_shape"]).cpu().numpy()
+    assert np.array_equal(got, np.stack([cv.resize_linear_u8(f, (320, 256)) for f in gray]))
+
+
+@pytest.mark.parametrize("size", [(512, 640), (480, 640), (64, 96), (200, 333), (128, 192)])
+def test_three_channel_net_keeps_bgr_and_resizes_per_channel(yf, dev, golden, size):
+    from oracle import cv_oracle as cv
+    m, io = _rgb_model(yf, dev, golden)      # 64 x 96 net, 3 input channels
+    H, W = io["input_shape"][:2]
+    rng = np.random.default_rng(size[0] + size[1])
+    bgr = rng.integers(0, 256, (2,) + size + (3,), dtype=np.uint8)
+    got = m.cv_preprocess_u8(torch.from_numpy(bgr).to(dev), io["input_shape"]).cpu().numpy()
+    want = np.stack([cv.resize_linear_u8(f, (W, H)) for f in bgr])
+    assert got.shape == (2, H, W, 3) and np.array_equal(got, want)
+    # forward_bgr_u8 == forward_u8 for a 3-channel net (detect.py:112-113: the frame as it is), == model(preprocess(resized frames)) bitwise
+    from oracle import backbone_oracle as bo
+    with torch.no_grad():
+        a = m.forward_bgr_u8(torch.from_numpy(bgr).to(dev), io["input_shape"])
+        b = m.forward_u8(torch.from_numpy(bgr).to(dev), io["input_shape"])
+        c = m(bo.preprocess(want, 3).to(dev))
+    assert all(torch.equal(x, y) and torch.equal(x, z) for x, y, z in zip(a, b, c))
+
+
+@pytest.mark.parametrize("size", [(512, 640), (256, 320), (480, 640), (300, 400), (720, 1280), (101, 77)])
+def test_forward_from_bgr_frames_of_any_size(gray_model, dev, size):
+    """yf_forward_bgr_u8 = detect.py:108-127 + the net: bitwise the heads of model(preprocess(oracle's frames)); yf_forward_u8 takes gray
+    frames of any size the same way; batch 1 and a batch that runs on two lanes."""
+    from oracle import backbone_oracle as bo
+    from oracle import cv_oracle as cv
+    m, io = gray_model
+    rng = np.random.default_rng(size[0] * 5 + size[1])
+    for n in (1, 5):
+        bgr = rng.integers(0, 256, (n,) + size + (3,), dtype=np.uint8)
+        frames = np.stack([cv.cv_pre_process_u8(f, io["input_shape"], [size[0], size[1], 3]) for f in bgr])
+        with torch.no_grad():
+            want = m(bo.preprocess(frames).to(dev))
+            got = m.forward_bgr_u8(torch.from_numpy(bgr).to(dev), io["input_shape"])
+            gray = np.stack([cv.cvt_bgr2gray(f) for f in bgr])
+            got_gray = m.forward_u8(torch.from_numpy(gray).to(dev), io["input_shape"])
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), (size, n)
+        assert torch.equal(got_gray[0], want[0]) and torch.equal(got_gray[1], want[1]), (size, n)
+
+
+def test_detect_yolo_takes_the_references_frames_as_cv2_imread_would(yf, dev, golden, tmp_path):
+    """Detect_YOLO on the bundled 640x512 JPEGs handed over as BGR frames: BGR2GRAY + the exact-1/2 resize on the device give the golden
+    input frames, and detect_bgr_u8's boxes are the reference's adjusted boxes (golden adj_box)."""
+    import logging
+    from PIL import Image
+    io = yf.io_params_for(256)
+    g = golden("golden_256")
+    det = yf.Detect_YOLO(dev, WEIGHTS[256], {"io_params": io}, logging.getLogger("cv"))
+    names = [str(n) for n in g["names"][:6]]
+    bgrs, _ = zip(*[det._read_bgr(os.path.join(ROOT, "tests", "golden", "test_data", n)) for n in names])
+    bgr = torch.from_numpy(np.stack(bgrs)).to(dev)
+    assert bgr.shape == (6, 512, 640, 3)
+    u8 = det.model.cv_preprocess_u8(bgr, io["input_shape"]).cpu().numpy()
+    assert np.array_equal(u8, g["input_u8"][:6])
+    got = det.detect_bgr_u8(bgr)
+    for f, L in enumerate(got):
+        n = int(g["final_count"][f])
+        assert [e[:4] for e in L] == g["adj_box"][f, :n].tolist(), f
+    # frames of another size (480 x 640 crops): the same call, finite heads, and the result equals the two-step path
+    crop = bgr[:, 16:496].contiguous()
+    with torch.no_grad():
+        a = det.model.forward_bgr_u8(crop, io["input_shape"])
+        b = det.model.forward_u8(det.model.cv_preprocess_u8(crop, io["input_shape"]), io["input_shape"])
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.isfinite(a[0]).all()
+
+
+def test_cv_preprocess_argument_errors(yf, gray_model, dev, golden):
+    m, io = gray_model
+    with pytest.raises(RuntimeError, match="1 channel or 3"):
+        m.cv_preprocess_u8(torch.zeros((1, 8, 8, 2), dtype=torch.uint8, device=dev), io["input_shape"])
+    with pytest.raises(RuntimeError, match="gray_bits"):
+        m.cv_preprocess_u8(torch.zeros((1, 8, 8, 3), dtype=torch.uint8, device=dev), io["input_shape"], gray_bits=13)
+    with pytest.raises(ValueError):
+        m.forward_bgr_u8(torch.zeros((1, 8, 8), dtype=torch.uint8, device=dev), io["input_shape"])
+    m3, io3 = _rgb_model(yf, dev, golden)
+    with pytest.raises(RuntimeError, match="cannot take"):
+        m3.cv_preprocess_u8(torch.zeros((1, 8, 8), dtype=torch.uint8, device=dev), io3["input_shape"])

@@ -387,3 +387,53 @@ def test_fp16_rounding_alone_exceeds_the_surveys_tolerance(golden, sds):
     errs = {k: worst(**{k: True}) for k in ("W", "T", "A")}
     print("max |dlogit| at 640x512 with ONE class rounded to fp16:", errs)
     assert all(v > 2e-2 for v in errs.values()), errs
+
+
+# ---- oracle/cv_oracle.py: OpenCV's cvtColor(BGR2GRAY) + resize restated (detect.py:110-116).  PARITY UNPINNED vs OpenCV itself (no cv2 here,
+# the reference has no fixture at this boundary): pinned instead by what the reference's data and an independent float evaluation can say. ----
+
+def test_cv_oracle_gray_and_area_path_reproduce_the_golden_input_frames(golden):
+    """The reference's test_data frames are gray 640x512 JPEGs: cv2.imread returns three equal channels, BGR2GRAY of which is the pixel itself
+    for both coefficient sets (they sum to 2^shift), and the 320x256 net takes them through cv::resize's exact-1/2 path (INTER_LINEAR ->
+    INTER_AREA, 2x2 mean) -- the frames golden_256.npz holds, which reproduce the has-target flags of the reference's own logs."""
+    from PIL import Image
+    from oracle import cv_oracle as cv
+    assert sum(cv.GRAY_COEFFS[14]) == 1 << 14 and sum(cv.GRAY_COEFFS[15]) == 1 << 15
+    g = golden("golden_256")
+    for i in (0, 7, 19):
+        gray = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "test_data", str(g["names"][i]))))
+        bgr = np.repeat(gray[:, :, None], 3, axis=2)
+        for bits in (14, 15):
+            assert np.array_equal(cv.cvt_bgr2gray(bgr, bits), gray)
+        assert np.array_equal(cv.cv_pre_process_u8(bgr, [256, 320, 1], [512, 640, 3]), g["input_u8"][i])
+        assert np.array_equal(cv.cv_pre_process_u8(bgr, [512, 640, 1], [512, 640, 3]), gray)      # sizes equal: no resize (detect.py:115)
+    rng = np.random.default_rng(0)
+    bgr = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    lum = 0.114 * bgr[..., 0] + 0.587 * bgr[..., 1] + 0.299 * bgr[..., 2]
+    for bits in (14, 15):
+        assert np.abs(cv.cvt_bgr2gray(bgr, bits).astype(np.float64) - lum).max() <= 0.51      # the rounded luma, to fixed-point precision
+
+
+@pytest.mark.parametrize("src,dst", [((480, 640), (256, 320)), ((300, 400), (256, 320)), ((720, 1280), (256, 320)), ((128, 160), (256, 320)),
+                                     ((257, 321), (256, 320)), ((1080, 1920), (512, 640)), ((101, 77), (256, 320)), ((512, 640), (256, 320))])
+def test_cv_oracle_linear_resize_against_float_bilinear(src, dst):
+    """cv::resize's 8-bit INTER_LINEAR (11-bit coefficients, two fixed-point passes) against torch's float bilinear with half-pixel centres
+    (align_corners=False, no antialiasing -- the same sampling geometry): within 1 LSB everywhere; constants stay constant; and exactly 1/2
+    takes the area path, which differs from plain bilinear."""
+    import torch.nn.functional as F
+    from oracle import cv_oracle as cv
+    rng = np.random.default_rng(src[0] * 7 + src[1])
+    img = rng.integers(0, 256, src, dtype=np.uint8)
+    lin = cv.resize_linear_u8(img, (dst[1], dst[0]), _force_linear=True)
+    ref = F.interpolate(torch.from_numpy(img)[None, None].double(), size=dst, mode="bilinear", align_corners=False)[0, 0].numpy()
+    assert lin.shape == dst and np.abs(lin.astype(np.float64) - ref).max() < 1.0
+    assert (cv.resize_linear_u8(np.full(src, 93, np.uint8), (dst[1], dst[0])) == 93).all()
+    out = cv.resize_linear_u8(img, (dst[1], dst[0]))
+    if src == (2 * dst[0], 2 * dst[1]):
+        a = img.astype(np.int64)
+        assert np.array_equal(out, ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8))
+    else:
+        assert np.array_equal(out, lin)
+    bgr = rng.integers(0, 256, src + (3,), dtype=np.uint8)         # 3 channels: each channel on its own
+    out3 = cv.resize_linear_u8(bgr, (dst[1], dst[0]))
+    assert all(np.array_equal(out3[..., c], cv.resize_linear_u8(np.ascontiguousarray(bgr[..., c]), (dst[1], dst[0]))) for c in range(3))

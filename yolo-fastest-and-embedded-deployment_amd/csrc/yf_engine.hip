@@ -142,6 +142,10 @@ struct yf_engine {
     long seen_tick = 0;
     hipEvent_t ev_probe[3] = {nullptr, nullptr, nullptr};
     size_t head_l_elems = 0, head_s_elems = 0;
+    // cv::resize's per-column / per-row tables of the source sizes seen so far (cv_tables; a handful per engine, LRU)
+    struct CvTab { int sh = 0, sw = 0; int4* d_x = nullptr; int4* d_y = nullptr; long used = 0; } cvtab[4];
+    long cv_tick = 0;
+    size_t cv_scratch_bytes(int N) const { return (((size_t)N * H * W * input_channel) + 255) & ~(size_t)255; }
     const Plan& plan() const { return plans[fusion]; }
     size_t frame_floats_max() const
     {
@@ -988,6 +992,7 @@ int yf_destroy(yf_handle h)
         if (h->ev_bjoin[l]) (void)hipEventDestroy(h->ev_bjoin[l]);
         if (h->ev_l2b[l]) (void)hipEventDestroy(h->ev_l2b[l]);
     }
+    for (auto& t : h->cvtab) { if (t.d_x) (void)hipFree(t.d_x); if (t.d_y) (void)hipFree(t.d_y); }
     (void)hipFree(h->d_weights);
     (void)hipFree(h->d_wmfma);
     delete h;
@@ -1001,6 +1006,7 @@ int yf_workspace_bytes(yf_handle h, int N, size_t* out)
     size_t per_pass = (size_t)chunk_frames(h, N) * h->lanes;
     if (per_pass < (size_t)N) per_pass = N;  // yf_profile_forward / yf_forward_probe run the whole batch in one pass
     *out = h->frame_floats_max() * per_pass * h->esz() + (h->head_l_elems + h->head_s_elems) * (size_t)N * sizeof(float) + 1024;
+    *out = ((*out + 255) & ~(size_t)255) + h->cv_scratch_bytes(N);   // + the net-sized u8 frames of yf_forward_u8 / yf_forward_bgr_u8 at other source sizes
     return YF_OK;
 }
 
@@ -1078,7 +1084,89 @@ static int u8_mode(yf_handle h, int src_h, int src_w, int* down2)
 {
     if (src_h == h->H && src_w == h->W) { *down2 = 0; return YF_OK; }
     if (src_h == 2 * h->H && src_w == 2 * h->W) { *down2 = 1; return YF_OK; }
-    return fail(YF_E_INVALID, "source %dx%d: only 1x or exact 2x of the net input %dx%d is supported", src_h, src_w, h->H, h->W);
+    *down2 = -1;   // any other size: cv::resize's INTER_LINEAR in front of the stem (cv_pre)
+    return YF_OK;
+}
+
+// cv::resize(INTER_LINEAR, 8-bit): the tables OpenCV's resize() builds on the host -- xofs / ialpha with the edge resets of its horizontal
+// pass, yofs / ibeta with clamped row indices -- from ITS float arithmetic (modules/imgproc/src/resize.cpp; restated in oracle/cv_oracle.py).
+static int cv_tables(yf_engine* e, int sh, int sw, const int4** dx, const int4** dy)
+{
+    yf_engine::CvTab* slot = &e->cvtab[0];
+    for (auto& t : e->cvtab) {
+        if (t.d_x && t.sh == sh && t.sw == sw) { t.used = ++e->cv_tick; *dx = t.d_x; *dy = t.d_y; return YF_OK; }
+        if (t.used < slot->used) slot = &t;
+    }
+    auto build = [](int src, int dst, bool reset, std::vector<int4>& out) {
+        const double inv_scale = (double)dst / (double)src, scale = 1.0 / inv_scale;   // `scale_x = 1./inv_scale_x`
+        out.resize(dst);
+        for (int d = 0; d < dst; ++d) {
+            float f = (float)((d + 0.5) * scale - 0.5);
+            int s = (int)floorf(f);
+            f -= (float)s;
+            if (reset) {
+                if (s < 0) { f = 0.f; s = 0; }
+                if (s >= src - 1) { f = 0.f; s = src - 1; }
+            }
+            const int c1 = (int)nearbyintf(f * 2048.f), c0 = (int)nearbyintf((1.f - f) * 2048.f);   // cvRound: half to even
+            const int i0 = s < 0 ? 0 : (s > src - 1 ? src - 1 : s), i1 = s + 1 < 0 ? 0 : (s + 1 > src - 1 ? src - 1 : s + 1);
+            out[d] = make_int4(i0, i1, c0, c1);
+        }
+    };
+    std::vector<int4> hx, hy;
+    build(sw, e->W, true, hx);
+    build(sh, e->H, false, hy);
+    if (slot->d_x) { (void)hipFree(slot->d_x); (void)hipFree(slot->d_y); slot->d_x = slot->d_y = nullptr; }
+    HIP_OK(hipMalloc(&slot->d_x, hx.size() * sizeof(int4)));
+    HIP_OK(hipMalloc(&slot->d_y, hy.size() * sizeof(int4)));
+    HIP_OK(hipMemcpy(slot->d_x, hx.data(), hx.size() * sizeof(int4), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(slot->d_y, hy.data(), hy.size() * sizeof(int4), hipMemcpyHostToDevice));
+    slot->sh = sh; slot->sw = sw; slot->used = ++e->cv_tick;
+    *dx = slot->d_x; *dy = slot->d_y;
+    return YF_OK;
+}
+
+// detect.py:110-116 on the device: [cvtColor(BGR2GRAY)] + [resize] of N source frames into net-sized u8 frames
+static int cv_pre(yf_engine* e, const uint8_t* d_src, int N, int src_h, int src_w, int src_c, int gray_bits, uint8_t* d_dst, hipStream_t s)
+{
+    if (src_h <= 0 || src_w <= 0 || src_h > 16384 || src_w > 16384) return fail(YF_E_INVALID, "source size %dx%d", src_h, src_w);
+    if (src_c != 1 && src_c != 3) return fail(YF_E_INVALID, "source frames have 1 channel or 3 (cv2.imread's BGR), not %d", src_c);
+    yf::CvArgs a{};
+    a.src = d_src; a.dst = d_dst; a.n = N; a.sh = src_h; a.sw = src_w; a.sc = src_c; a.dh = e->H; a.dw = e->W; a.dc = e->input_channel;
+    if (e->input_channel == 1 && src_c == 3) {
+        if (gray_bits != 0 && gray_bits != 14 && gray_bits != 15) return fail(YF_E_INVALID, "gray_bits must be 14, 15 or 0 (= 14)");
+        a.gray = gray_bits == 15 ? 15 : 14;
+    } else if (e->input_channel == src_c) {
+        a.gray = 0;
+    } else {
+        return fail(YF_E_INVALID, "a %d-channel net cannot take %d-channel frames (detect.py:110-113: gray from BGR, or the channels as they are)",
+                    e->input_channel, src_c);
+    }
+    a.mode = (src_h == e->H && src_w == e->W) ? 0 : (src_h == 2 * e->H && src_w == 2 * e->W) ? 1 : 2;
+    if (a.mode == 2)
+        if (int rc = cv_tables(e, src_h, src_w, &a.xtab, &a.ytab)) return rc;
+    if (yf::launch_cv_pre(a, s)) return fail(YF_E_INVALID, "no pre-process kernel for this combination");
+    HIP_OK(hipGetLastError());
+    return YF_OK;
+}
+
+int yf_cv_preprocess_u8(yf_handle h, const uint8_t* d_src, int N, int src_h, int src_w, int src_c, int gray_bits, uint8_t* d_dst, void* stream)
+{
+    if (!h || !d_src || !d_dst || N <= 0) return fail(YF_E_INVALID, "yf_cv_preprocess_u8: bad argument");
+    HIP_OK(hipSetDevice(h->device));
+    return cv_pre(h, d_src, N, src_h, src_w, src_c, gray_bits, d_dst, (hipStream_t)stream);
+}
+
+// the net-sized u8 frames of a pass whose source has another size live at the END of the caller's workspace (yf_workspace_bytes counts them)
+static int forward_via_cv(yf_handle h, const uint8_t* d_src, int N, int src_h, int src_w, int src_c, int gray_bits, float* d_hl, float* d_hs, void* ws,
+                          size_t ws_bytes, void* stream)
+{
+    const size_t scr = h->cv_scratch_bytes(N);
+    if (!ws || ws_bytes < scr) return fail(YF_E_WORKSPACE, "workspace %zu B cannot hold the resized frames (%zu B)", ws_bytes, scr);
+    HIP_OK(hipSetDevice(h->device));
+    uint8_t* frames = static_cast<uint8_t*>(ws) + ((ws_bytes - scr) & ~(size_t)255);
+    if (int rc = cv_pre(h, d_src, N, src_h, src_w, src_c, gray_bits, frames, (hipStream_t)stream)) return rc;
+    return run_forward(h, nullptr, N, d_hl, d_hs, ws, (ws_bytes - scr) & ~(size_t)255, (hipStream_t)stream, nullptr, nullptr, 0, nullptr, frames, 0);
 }
 
 int yf_forward_u8(yf_handle h, const uint8_t* d_u8, int N, int src_h, int src_w, float* d_hl, float* d_hs, void* ws, size_t ws_bytes,
@@ -1087,7 +1175,17 @@ int yf_forward_u8(yf_handle h, const uint8_t* d_u8, int N, int src_h, int src_w,
     if (!h || !d_u8) return fail(YF_E_INVALID, "yf_forward_u8: null pointer");
     int down2;
     if (int rc = u8_mode(h, src_h, src_w, &down2)) return rc;
+    if (down2 < 0) return forward_via_cv(h, d_u8, N, src_h, src_w, h->input_channel, 0, d_hl, d_hs, ws, ws_bytes, stream);
     return run_forward(h, nullptr, N, d_hl, d_hs, ws, ws_bytes, (hipStream_t)stream, nullptr, nullptr, 0, nullptr, d_u8, down2);
+}
+
+int yf_forward_bgr_u8(yf_handle h, const uint8_t* d_bgr, int N, int src_h, int src_w, int gray_bits, float* d_hl, float* d_hs, void* ws,
+                      size_t ws_bytes, void* stream)
+{
+    if (!h || !d_bgr) return fail(YF_E_INVALID, "yf_forward_bgr_u8: null pointer");
+    if (h->input_channel == 3) return yf_forward_u8(h, d_bgr, N, src_h, src_w, d_hl, d_hs, ws, ws_bytes, stream);   // detect.py:112-113: the frame as it is
+    if (h->input_channel != 1) return fail(YF_E_INVALID, "cv2.imread's 3-channel frames feed 1- and 3-channel nets (detect.py:110-113), not %d", h->input_channel);
+    return forward_via_cv(h, d_bgr, N, src_h, src_w, 3, gray_bits, d_hl, d_hs, ws, ws_bytes, stream);
 }
 
 int yf_nms_sorted(yf_handle h, const int32_t* d_boxes, int n, double nms_thres, int32_t* d_sup, void* stream)
@@ -1349,6 +1447,7 @@ int yf_profile_forward_u8(yf_handle h, const uint8_t* d_u8, int N, int src_h, in
     if (!h || !d_u8) return fail(YF_E_INVALID, "yf_profile_forward_u8: null pointer");
     int down2;
     if (int rc = u8_mode(h, src_h, src_w, &down2)) return rc;
+    if (down2 < 0) return fail(YF_E_INVALID, "yf_profile_forward_u8: source %dx%d -- the profiled pass takes frames of the net's size or exactly 2x", src_h, src_w);
     return profile_forward(h, nullptr, d_u8, down2, N, ws, ws_bytes, stream, op_ms, n_ops);
 }
 

@@ -194,6 +194,17 @@ int launch_dense3x3s2(int cin, int cout, const DenseArgs& a, hipStream_t s);   /
 // dtype) x w[cin][cout] + b -> NCHW float32 [N,cout,HW]; fp32 arithmetic in every engine dtype
 int launch_head_conv(const float* in, const float* w, const float* b, float* out, int cin, int cout, long HW, int N, hipStream_t s, int dtype = DT_F32);
 void launch_nhwc_to_nchw(const float* in, float* out, long N, int C, long HW, hipStream_t s, int dtype = DT_F32);
+// cv2.cvtColor(BGR2GRAY) + cv2.resize of detect.py:110-116 for any source size (yf_cv_kernels.hip).  u8 in, u8 out.
+struct CvArgs {
+    const uint8_t* src; uint8_t* dst;
+    int n, sh, sw, sc;          // frames, source rows / columns / channels (1, or 3 = cv2.imread's BGR)
+    int dh, dw, dc;             // destination (the net's input) rows / columns / channels
+    int mode;                   // 0: same size, 1: exactly 1/2 (2x2 mean), 2: INTER_LINEAR through the tables
+    int gray;                   // 0: channels kept (sc == dc); 14 | 15: BGR -> gray with OpenCV's 14- / 15-bit coefficients (sc 3, dc 1)
+    const int4* xtab;           // [dw] {sx, sx + 1 clamped, a0, a1}   (mode 2)
+    const int4* ytab;           // [dh] {y0, y1, b0, b1}
+};
+int launch_cv_pre(const CvArgs& a, hipStream_t s);
 void launch_preprocess(const uint8_t* in, float* out, long N, int H, int W, int down2, hipStream_t s, int channels = 1);   // channels 3: HWC BGR in, NCHW RGB planes out
 
 struct FbArgs {

@@ -3,8 +3,9 @@
 Same constructor and `batch_detect(data_path, result_path)`; one log line per image in the reference's format
 (:177,190,192).  Differences that follow from the design, not from taste:
   * frames are processed `batch_size` at a time (the reference loops one image per iteration, :146);
-  * pre-processing arithmetic ((u8-128)/255 and the exact-2x box mean) runs on the device (yf_preprocess_u8);
-    image decode uses PIL (this image has no cv2);
+  * the whole of `__pre_process` behind the file decode runs on the device: cvtColor(BGR2GRAY) + cv2.resize for ANY frame size
+    (yf_cv_preprocess_u8: OpenCV's 8-bit arithmetic restated -- include/yolo_fastest_hip.h; exactly 2x = the 2x2 box mean) and (u8-128)/255
+    (yf_preprocess_u8); image decode uses PIL (this image has no cv2) and hands over what cv2.imread would: HWC, BGR;
   * model + post-process are stream-ordered launches (yf_forward, yf_decode_nms); times in the log are
     per-batch wall times divided by the batch size.
 Result writer: `result_<name>` images with the reference's boxes and labels (`plot.plot_one_box`, the
@@ -61,22 +62,35 @@ class Detect_YOLO():
                                               input_shape=self.input_shape, num_class=self.num_cls).bind(self.model)
         self.colors = [[106, 90, 205], [199, 97, 20], [112, 128, 105]]
 
-    def _read_gray(self, path):
-        """-> (the frame the pre-process takes, the RGB original for drawing).  A 3-channel model (input_shape[2] == 3) gets what
-        cv2.imread would return: HWC in BGR order (detect.py:108-113); a 1-channel model the gray frame (:110-111)."""
+    def _read_bgr(self, path):
+        """-> (what cv2.imread(path) returns: uint8 [h,w,3] in BGR order, detect.py:108; the RGB original for drawing).  BGR2GRAY for a
+        1-channel net (:110-111) and the resize (:115-116) happen on the device (`_pre_process`)."""
         from PIL import Image
-        img = Image.open(path)
-        ori = np.asarray(img.convert("RGB"))
-        if self.model.input_channel == 3:
-            return np.ascontiguousarray(ori[:, :, ::-1]), ori
-        if self.model.input_channel != 1:      # cv2.imread as detect.py:108-113 calls it yields 1 or 3 channels: nothing to mirror
-            raise ValueError("image files decode to 1 or 3 channels; feed a %d-channel model through detect_u8" % self.model.input_channel)
-        return np.asarray(img.convert("L")), ori
+        if self.model.input_channel not in (1, 3):   # cv2.imread as detect.py:108-113 calls it yields 3 channels: nothing to mirror
+            raise ValueError("image files decode to 3 channels; feed a %d-channel model through detect_u8" % self.model.input_channel)
+        ori = np.asarray(Image.open(path).convert("RGB"))
+        return np.ascontiguousarray(ori[:, :, ::-1]), ori
+
+    def _pre_process(self, bgr):
+        """detect.py:107-127 for a batch: uint8 GPU tensor [N,h,w,3] (BGR, any size) -> float32 [N,C,H,W].  The reference resizes when its
+        CONFIGURED shapes differ (:115); a frame whose actual size is not the net's is resized as well (cv2.resize there would be the only
+        way to feed it)."""
+        u8 = self.model.cv_preprocess_u8(bgr, self.input_shape)
+        return preprocess_u8(self.model, u8, self.input_shape)
+
+    def detect_bgr_u8(self, bgr, kmax=64, gray_bits=14):
+        """bgr: uint8 GPU tensor [N,h,w,3] as cv2.imread returns frames, any size.  The whole of detect.py:108-182 on the device; per-frame
+        lists in the coordinates of `origin_img_shape` (after __adjust_coord, :131-139)."""
+        pred = self.model.forward_bgr_u8(bgr, self.input_shape, gray_bits=gray_bits)
+        origin = None
+        if list(self.input_shape[0:2]) != list(self.origin_img_shape[0:2]):
+            origin = self.origin_img_shape
+        return self.post_process.detect(pred, kmax=kmax, origin_shape=origin)
 
     def detect_u8(self, u8, kmax=64):
-        """u8: uint8 GPU tensor [N,h,w] in the ORIGINAL image geometry. Returns per-frame lists in original
-        coordinates (after __adjust_coord, detect.py:181-182)."""
-        pred = self.model.forward_u8(u8, self.input_shape)  # pre-process fused into the first kernel's loads
+        """u8: uint8 GPU tensor [N,h,w] in the ORIGINAL image geometry (any size: cv2.resize's arithmetic brings it to the net's). Returns
+        per-frame lists in original coordinates (after __adjust_coord, detect.py:181-182)."""
+        pred = self.model.forward_u8(u8, self.input_shape)  # pre-process in front of / fused into the first kernel's loads
         origin = None
         if list(self.input_shape[0:2]) != list(self.origin_img_shape[0:2]):
             origin = self.origin_img_shape
@@ -89,9 +103,11 @@ class Detect_YOLO():
         self.last_labels = {}
         for b0 in range(0, num, batch_size):
             names = img_list[b0:b0 + batch_size]
-            grays, oris = zip(*[self._read_gray(os.path.join(data_path, n)) for n in names])
-            u8 = torch.from_numpy(np.stack(grays)).to(self.device)
-            x = preprocess_u8(self.model, u8, self.input_shape)
+            bgrs, oris = zip(*[self._read_bgr(os.path.join(data_path, n)) for n in names])
+            if len({b.shape for b in bgrs}) == 1:
+                x = self._pre_process(torch.from_numpy(np.stack(bgrs)).to(self.device))
+            else:                      # frames of different sizes: the resize brings them to one
+                x = torch.cat([self._pre_process(torch.from_numpy(b[None]).to(self.device)) for b in bgrs])
             torch.cuda.synchronize(self.device)
             start_time = time.time()
             with torch.no_grad():

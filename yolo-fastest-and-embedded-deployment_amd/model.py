@@ -247,9 +247,46 @@ class YoloFastest(nn.Module):
             return hl.half(), hs.half()
         return hl, hs
 
+    def forward_bgr_u8(self, bgr, input_shape, gray_bits=14, slot=0):
+        """model(__pre_process(frame)) for cv2.imread's frames (detect.py:108-127): uint8 GPU tensor [N,h,w,3] in BGR order and of ANY size
+        -> cvtColor(BGR2GRAY) for a 1-channel net + cv2.resize to the net's input (yf_cv_preprocess_u8, OpenCV's 8-bit arithmetic) +
+        (v - 128) / 255 fused into the first kernel -> (head_large, head_small).  gray_bits: OpenCV's 14- or 15-bit gray coefficients."""
+        if self.training:
+            raise RuntimeError("YoloFastest (HIP engine) is inference-only: call .eval() first")
+        if not bgr.is_cuda or bgr.dtype != torch.uint8 or bgr.dim() != 4 or bgr.shape[3] != 3:
+            raise ValueError("expected a uint8 GPU tensor [N,h,w,3] (cv2.imread's BGR frames)")
+        H, W = int(input_shape[0]), int(input_shape[1])
+        bgr = bgr.contiguous()
+        N = bgr.shape[0]
+        e = self.engine(H, W, N, bgr.device, slot)
+        hl = torch.empty((N, self.num_out, H // 16, W // 16), dtype=torch.float32, device=bgr.device)
+        hs = torch.empty((N, self.num_out, H // 32, W // 32), dtype=torch.float32, device=bgr.device)
+        ws = e.workspace(N, bgr.device)
+        stream = torch.cuda.current_stream(bgr.device).cuda_stream
+        _lib.check(e.lib.yf_forward_bgr_u8(e.handle, bgr.data_ptr(), N, bgr.shape[1], bgr.shape[2], int(gray_bits), hl.data_ptr(), hs.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), ctypes.c_void_p(stream)))
+        return hl, hs
+
+    def cv_preprocess_u8(self, src, input_shape, gray_bits=14):
+        """detect.py:110-116 alone (yf_cv_preprocess_u8): uint8 GPU frames [N,h,w] or [N,h,w,3] of any size -> the uint8 frames
+        [N,H,W] ([N,H,W,3] for a 3-channel net) that `(img - 128.0) / 255.0` is applied to next."""
+        if not src.is_cuda or src.dtype != torch.uint8 or src.dim() not in (3, 4):
+            raise ValueError("expected a uint8 GPU tensor [N,h,w] or [N,h,w,3]")
+        H, W = int(input_shape[0]), int(input_shape[1])
+        src = src.contiguous()
+        N, sc = src.shape[0], (1 if src.dim() == 3 else src.shape[3])
+        e = self.engine(H, W, N, src.device)
+        shape = (N, H, W) if self.input_channel == 1 else (N, H, W, self.input_channel)
+        dst = torch.empty(shape, dtype=torch.uint8, device=src.device)
+        stream = torch.cuda.current_stream(src.device).cuda_stream
+        _lib.check(e.lib.yf_cv_preprocess_u8(e.handle, src.data_ptr(), N, src.shape[1], src.shape[2], sc, int(gray_bits), dst.data_ptr(),
+                                             ctypes.c_void_p(stream)))
+        return dst
+
     def forward_u8(self, u8, input_shape, slot=0):
-        """model(preprocess(u8)) with the pre-process fused into the first kernel: u8 GPU tensor [N,h,w] (h,w == the net
-        input or exactly 2x; input_channel 3: [N,h,w,3] as cv2.imread returns frames, BGR) -> (head_large, head_small)."""
+        """model(preprocess(u8)) with the pre-process in front of the first kernel: u8 GPU tensor [N,h,w] of ANY size (the net's input size or
+        exactly 2x: fused into the first kernel's loads; otherwise cv2.resize's INTER_LINEAR runs as one extra pass; input_channel 3:
+        [N,h,w,3] as cv2.imread returns frames, BGR) -> (head_large, head_small)."""
         if self.training:
             raise RuntimeError("YoloFastest (HIP engine) is inference-only: call .eval() first")
         want = 3 if self.input_channel == 1 else 4
