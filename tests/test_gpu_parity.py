@@ -1305,3 +1305,31 @@ def test_profile_with_repeated_launches_changes_nothing(yf, golden, dev):
     with pytest.raises(RuntimeError):     # _lib.YFError
         m.profile(x, reps=1, launch_repeats=0)
     m.profile(x, reps=1, launch_repeats=1)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "f16"])
+@pytest.mark.parametrize("res", [256, 512])
+def test_small_batch_plan_is_bitwise_the_large_batch_plan(yf, golden, dev, res, prec):
+    """at N x tiles < #CU the per-frame deep-stage launches spread a frame over several workgroups (deconv5_1 +
+    conv4_1_1: one M-tile per work item instead of five; the stride-16 head launches: 8x10 tiles instead of the 16x20 frame).  The
+    arithmetic of a pixel does not depend on how pixels are grouped into workgroups: frames pushed through alone (N = 1), in twos and in
+    eights carry the SAME BITS as the same frames inside a batch large enough for the whole-frame launches, and the reference's bounds."""
+    io = yf.io_params_for(res)
+    m = yf.YoloFastest(io).to(dev).eval()
+    m.load_state_dict(torch.load(WEIGHTS[res], map_location=dev))
+    if prec != "f32":
+        m.precision = prec
+    g = golden(f"golden_{res}")
+    rng = np.random.default_rng(11)
+    nbig = 160 if res == 256 else 48         # 2 x (frames x whole-frame tiles) > 256 CUs: the large-batch launches
+    noise = rng.integers(0, 256, (nbig - 20,) + g["input_u8"].shape[1:], dtype=np.uint8)
+    u8 = np.concatenate([g["input_u8"], noise])
+    x = _x(u8, dev)
+    with torch.no_grad():
+        big = [t.clone() for t in m(x)]
+        for n, picks in ((1, (0, 7, 19, 25)), (2, (0, 18, 30)), (8, (0, 12, 24))):
+            for f0 in picks:
+                small = m(x[f0:f0 + n].contiguous())
+                assert torch.equal(small[0], big[0][f0:f0 + n]) and torch.equal(small[1], big[1][f0:f0 + n]), (res, prec, n, f0)
+    if prec != "f16":
+        _check_heads(big[0][:20], big[1][:20], g["head_large"], g["head_small"], g["head_large_f64"], g["head_small_f64"], res == 256)

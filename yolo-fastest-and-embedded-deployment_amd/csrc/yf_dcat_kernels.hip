@@ -38,7 +38,7 @@ constexpr int DC_OFF_K2 = DC_OFF_TAIL + 2 * DC_NT * 64;  //         [j][nt][lane
 constexpr int DC_OFF_BD = DC_OFF_K2 + DC_KB_D * DC_NT * 64 * 4;
 constexpr int DC_OFF_BC = DC_OFF_BD + DC_N;
 constexpr int DC_WFLOATS = DC_OFF_BC + DC_N;             // 22464 floats = 89856 B
-constexpr int DC_MT = 5;                                 // M-tiles per work item
+constexpr int DC_MT = 5;                                 // M-tiles per work item (small batches: 1, so that a frame spreads over five workgroups)
 }  // namespace
 
 struct DcatArgs {
@@ -51,6 +51,7 @@ struct DcatArgs {
     int nitems, items_per_frame;
 };
 
+template <int MT>   // M-tiles per work item
 __global__ void __launch_bounds__(256) dcat_kernel(DcatArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float dc_smem[];
@@ -74,13 +75,13 @@ __global__ void __launch_bounds__(256) dcat_kernel(DcatArgs a)
     const float4* WL4 = reinterpret_cast<const float4*>(WL);
 
     const int npx = a.h * a.w, ow = 2 * a.w;
-    const long ntile = (long)((a.nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * DC_MT;   // this workgroup's M-tiles
+    const long ntile = (long)((a.nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * MT;   // this workgroup's M-tiles
     // M-tile t of this workgroup: item blockIdx.x + (t / 5) * gridDim.x, tile t % 5 -> operand pointers of this lane's pixel
     struct Tile { const float* sp; const float* cp; long o; bool ok; };
     auto tile = [&](long t) {
-        const long it = (long)blockIdx.x + (t / DC_MT) * gridDim.x;
+        const long it = (long)blockIdx.x + (t / MT) * gridDim.x;
         const int n = (int)(it / a.items_per_frame), chunk = (int)(it - (long)n * a.items_per_frame);
-        const int p = chunk * (DC_MT * 16) + (int)(t % DC_MT) * 16 + r;
+        const int p = chunk * (MT * 16) + (int)(t % MT) * 16 + r;
         Tile T;
         T.ok = p < npx;
         const int pc = T.ok ? p : npx - 1;   // clamp the loads, guard the stores
@@ -204,6 +205,7 @@ constexpr int DX_OFF_BC = DX_OFF_BD + DC_N;
 constexpr int DX_WFLOATS = DX_OFF_BC + DC_N;                 // 23232 floats = 92928 B
 }  // namespace
 
+template <int MT>
 __global__ void __launch_bounds__(256) dcat_x3_kernel(DcatArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float dc_smem[];
@@ -230,12 +232,12 @@ __global__ void __launch_bounds__(256) dcat_x3_kernel(DcatArgs a)
     const float4* WL4 = reinterpret_cast<const float4*>(WL);
 
     const int npx = a.h * a.w, ow = 2 * a.w;
-    const long ntile = (long)((a.nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * DC_MT;
+    const long ntile = (long)((a.nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * MT;
     struct Tile { const float* sp; const float* cp; long o; bool ok; };
     auto tile = [&](long t) {
-        const long it = (long)blockIdx.x + (t / DC_MT) * gridDim.x;
+        const long it = (long)blockIdx.x + (t / MT) * gridDim.x;
         const int n = (int)(it / a.items_per_frame), chunk = (int)(it - (long)n * a.items_per_frame);
-        const int p = chunk * (DC_MT * 16) + (int)(t % DC_MT) * 16 + r;
+        const int p = chunk * (MT * 16) + (int)(t % MT) * 16 + r;
         Tile T;
         T.ok = p < npx;
         const int pc = T.ok ? p : npx - 1;
@@ -379,7 +381,7 @@ bool dcat_has_kernel(int cin, int cskip, int cout) { return cin == DC_CIN && csk
 
 int launch_dcat(const float* x, const float* skip, const float* wd, const float* wc, float* out, int h, int w, int Nf, hipStream_t s, int dtype)
 {
-    static bool attr_done[2][YF_MAX_DEVICES] = {};
+    static bool attr_done[2][2][YF_MAX_DEVICES] = {};
     const int dev = current_device();
     const int n_cu = device_cu_count(dev);
     if (dev < 0 || n_cu <= 0) return -2;
@@ -387,19 +389,25 @@ int launch_dcat(const float* x, const float* skip, const float* wd, const float*
     const bool x3 = dtype == DT_F16X3;
     const size_t lds = (size_t)(x3 ? DX_WFLOATS : DC_WFLOATS) * sizeof(float);
     static_assert((size_t)DX_WFLOATS * sizeof(float) <= 160 * 1024 && (size_t)DC_WFLOATS * sizeof(float) <= 160 * 1024, "LDS");
-    if (!attr_done[x3][dev]) {
-        if (hipFuncSetAttribute(x3 ? reinterpret_cast<const void*>(dcat_x3_kernel) : reinterpret_cast<const void*>(dcat_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return -2;
-        attr_done[x3][dev] = true;
+    // Small batches: an item of five M-tiles is 33 us of MFMA time on ONE CU; when the five-tile items would leave more
+    // than half of the CUs idle, an item is ONE M-tile -- a frame of the 320x256 net then runs on five workgroups.  Same tiles, same
+    // arithmetic, same bits (an M-tile does not see how the tiles are grouped).
+    const int items5 = Nf * ((h * w + DC_MT * 16 - 1) / (DC_MT * 16));
+    const bool small = 2 * items5 <= n_cu;
+    const void* fn = x3 ? (small ? reinterpret_cast<const void*>(dcat_x3_kernel<1>) : reinterpret_cast<const void*>(dcat_x3_kernel<DC_MT>))
+                        : (small ? reinterpret_cast<const void*>(dcat_kernel<1>) : reinterpret_cast<const void*>(dcat_kernel<DC_MT>));
+    if (!attr_done[x3][small][dev]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+        attr_done[x3][small][dev] = true;
     }
     DcatArgs a{x, skip, wd, wc, out, h, w, 0, 0};
-    a.items_per_frame = (h * w + DC_MT * 16 - 1) / (DC_MT * 16);
+    const int mt = small ? 1 : DC_MT;
+    a.items_per_frame = (h * w + mt * 16 - 1) / (mt * 16);
     a.nitems = Nf * a.items_per_frame;
     // persistent grid, every workgroup the same number of items
     const int rounds = (a.nitems + n_cu - 1) / n_cu, grid = (a.nitems + rounds - 1) / rounds;
-    if (x3) hipLaunchKernelGGL(dcat_x3_kernel, dim3((unsigned)grid), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(dcat_kernel, dim3((unsigned)grid), dim3(256), lds, s, a);
+    if (x3) { if (small) hipLaunchKernelGGL(dcat_x3_kernel<1>, dim3((unsigned)grid), dim3(256), lds, s, a); else hipLaunchKernelGGL(dcat_x3_kernel<DC_MT>, dim3((unsigned)grid), dim3(256), lds, s, a); }
+    else { if (small) hipLaunchKernelGGL(dcat_kernel<1>, dim3((unsigned)grid), dim3(256), lds, s, a); else hipLaunchKernelGGL(dcat_kernel<DC_MT>, dim3((unsigned)grid), dim3(256), lds, s, a); }
     return 0;
 }
 

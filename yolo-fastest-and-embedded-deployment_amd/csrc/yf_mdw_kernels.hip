@@ -767,6 +767,14 @@ static int launch_mdw_t(MdwArgs a, int Nf, hipStream_t s)
     MD(96, 96, 1, 16, 20, YF_MDW_LARGE_NW)   /* conv4_1_4 -> conv4_1_5 -> head_4      */ \
     MD(96, 96, 2, 16, 20, YF_MDW_LARGE_NW)
 
+// Small batches: the stride-16 launches own a whole 16x20 frame per workgroup -- at batch 1 ONE CU works for ~30 us.
+// When those tiles would leave more than half of the CUs idle, the same kernel runs on 8x10 tiles with 5 waves (the stride-32 shapes'
+// geometry): four workgroups per 16x20 frame.  A pixel's arithmetic does not depend on the tile it is computed in: same bits.
+#define YF_MDW_SMALL_SHAPES(MD) \
+    MD(96, 96, 0, 8, 10, 5)     \
+    MD(96, 96, 1, 8, 10, 5)     \
+    MD(96, 96, 2, 8, 10, 5)
+
 static int mdw_head_mode(int headn) { return headn <= 0 ? 0 : headn <= 32 ? 1 : 2; }
 
 int launch_mdw(int c, int n, int headn, const MdwArgs& a0, int Nf, hipStream_t s, int dtype)
@@ -778,6 +786,11 @@ int launch_mdw(int c, int n, int headn, const MdwArgs& a0, int Nf, hipStream_t s
     if (c == cc && n == nn && hm == hh)                                                           \
         return dtype == DT_F16 ? launch_mdw_t<cc, nn, hh, th, tw, nw, half_t>(a, Nf, s)           \
              : dtype == DT_F16X3 ? launch_mdw_t<cc, nn, hh, th, tw, nw, x3_t>(a, Nf, s) : launch_mdw_t<cc, nn, hh, th, tw, nw, float>(a, Nf, s);
+    {
+        const int n_cu = device_cu_count(current_device());
+        const long big_tiles = (long)Nf * ((a.H + 15) / 16) * ((a.W + 19) / 20);
+        if (a.H > 8 && n_cu > 0 && 2 * big_tiles <= n_cu) { YF_MDW_SMALL_SHAPES(MD) }
+    }
     YF_MDW_SHAPES(MD)
 #undef MD
     return -1;
