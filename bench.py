@@ -360,8 +360,10 @@ def pin_rank_to_cpus(local_rank, local_world):
 
 
 def launch_roofline(o, dtype, traffic, issue=None):
-    """Physical roof of one launch.  fp32: MFMA and vector FMAs share one issue rate on this part (measured), so the
-    floor is (all flops) / 157.3 TF.  fp16: the matrix cores run beside the vector ALU, the floor is the larger of the two.
+    """Physical roof of one launch.  fp32: MFMA and vector FMAs share ONE issue path on this part -- measured in isolation in round 5
+    (tools/coissue_probe.hip, profiles/r05_mfma_valu_coissue.txt: a wave streaming v_mfma_f32_16x16x4_f32 / 4x4x1 / 32x32x2 and a wave
+    streaming v_fma_f32 / v_pk_fma_f32 / v_mov_b32 on the same SIMD reach 1.00-1.02 of ONE issue rate together, in either age order; the
+    fp16 MFMA control reaches 1.84-2.00) -- so the floor is (all flops) / 157.3 TF, the SUM of the two, not the larger.  fp16: the matrix cores run beside the vector ALU, the floor is the larger of the two.
     issue (optional): the launch's issue-side counters from live_pmc().  Then `bound` is COUNTER-BACKED instead of the larger of two flop
     ratios: the share of the launch's time the VALU needs to issue its instructions (SQ_INSTS_VALU x 4 cycles per SIMD -- address math,
     operand splitting and epilogues included, not only FMAs), the matrix pipe's busy share (SQ_VALU_MFMA_BUSY_CYCLES), the HBM share
@@ -572,7 +574,10 @@ def main():
 
     def forward(m):
         with torch.no_grad():
-            pred = m.forward_u8(cur["x"], io["input_shape"]) if cur["x"].dtype == torch.uint8 else m(cur["x"])
+            if cur["x"].dtype == torch.uint8 and cur["x"].dim() == 4 and m.input_channel == 1:
+                pred = m.forward_bgr_u8(cur["x"], io["input_shape"])
+            else:
+                pred = m.forward_u8(cur["x"], io["input_shape"]) if cur["x"].dtype == torch.uint8 else m(cur["x"])
         if cur["syn"] is not None:   # the net's own logits on noise are ~no detections: the synthetic field replaces them
             pred = (pred[0] * 0 + cur["syn"][0], pred[1] * 0 + cur["syn"][1])
         return pred
@@ -755,6 +760,29 @@ def main():
                         "detections_identical_to_the_headline": bool(same_detections(raw, rawu)),
                         "forward_ms_two_lanes": {"u8_input": round(sorted(t_u8)[2], 4), "f32_input": round(sorted(t_f32)[2], 4)},
                         "stem_launch_us": {"u8_input": stem_us(model, u8), "f32_input": stem_us(model, saved["x"])}}
+        # (b2) SURVEY.md 8 row A0 in full: the frames as cv2.imread returns them -- uint8 [256,480,640,3], BGR, a size that is neither the
+        #      net's nor twice it -- through cvtColor(BGR2GRAY) + cv2.resize's INTER_LINEAR on the device (yf_forward_bgr_u8: one extra
+        #      pass, HBM-bound byte work) -> the fused (v - 128) / 255 entry -> decode -> NMS
+        gb = torch.Generator(device="cpu").manual_seed(rank + 1)
+        bgr = torch.randint(0, 256, (args.batch, 480, 640, 3), generator=gb, dtype=torch.uint8).to(dev)
+        cur.update(x=bgr, syn=None)
+        eb, rawb = timed(model, post, in_flight, args.steps, args.warmup, False)
+        t_cv = []
+        for _ in range(7):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            e0.record(); model.cv_preprocess_u8(bgr, io["input_shape"]); e1.record()
+            torch.cuda.synchronize(dev)
+            t_cv.append(e0.elapsed_time(e1))
+        cv_ms = sorted(t_cv)[3]
+        cv_bytes = bgr.numel() + args.batch * H * W          # every source byte in, every net-sized byte out
+        extras["bgr"] = {"workload": "configs[1]'s batch entering as cv2.imread's frames, uint8 [256,480,640,3] BGR: cvtColor + cv2.resize (any size) on "
+                                     "the device (yf_forward_bgr_u8, detect.py:108-127) -> model -> decode -> NMS",
+                         "value": round(args.batch * args.steps / eb, 1), "unit": "frames/s", "ms_per_step": round(1e3 * eb / args.steps, 4),
+                         "steps": args.steps, "warmup": args.warmup, "in_flight": in_flight,
+                         "cv_pre_kernel": {"ms": round(cv_ms, 4), "algorithmic_bytes": cv_bytes, "GBps": round(cv_bytes / (cv_ms * 1e-3) / 1e9, 1),
+                                           "hbm_frac": round(cv_bytes / (cv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bound": "hbm (byte work)"}}
+        del bgr
         cur.clear(); cur.update(saved)
         # (c) one frame at a time, the reference's actual calling pattern (detect.py:146-171: model(img), then the post-process, each
         #     followed by a host synchronisation): median over 200 frames, eager launches; and the same pass replayed as a HIP graph

@@ -506,8 +506,15 @@ def test_forward_u8_fused_preprocess_is_bit_identical(yf, models, golden, dev):
             a = m(yf.preprocess_u8(m, full_t, io["input_shape"]))
         b = m.forward_u8(full_t, io["input_shape"])
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # any other source size (rounds 1-4 raised here): cv2.resize's INTER_LINEAR as one extra pass (tests/test_gpu_cv_preprocess.py holds
+    # it to the oracle), then the same fused entry -- bitwise the two-step path; the float-output entry still takes 1x / 2x only
+    m256 = models[256][0]
+    odd = full_t[:, :300, :300].contiguous()
+    two_step = m256.forward_u8(m256.cv_preprocess_u8(odd, (256, 320)), (256, 320))
+    one_call = m256.forward_u8(odd, (256, 320))
+    assert torch.equal(one_call[0], two_step[0]) and torch.equal(one_call[1], two_step[1])
     with pytest.raises(yf._lib.YFError):
-        models[256][0].forward_u8(full_t[:, :300, :300].contiguous(), (256, 320))
+        yf.preprocess_u8(m256, odd, (256, 320))
     # Detect_YOLO's batched entry on the bundled frames reproduces the reference's boxes in original coordinates
     import logging
     cfg = {"io_params": yf.io_params_for(256)}

@@ -13,6 +13,7 @@
 // a row, its taps are two short runs of consecutive source bytes per source row (hit in L1/L2 after the first touch), every source byte
 // crosses HBM once, and four destination pixels leave as one 4-byte store where the row is 4-aligned.
 #include "yf_kernels.h"
+#include <stdlib.h>
 
 namespace yf {
 
@@ -87,9 +88,149 @@ __global__ void __launch_bounds__(256) cv_pre_kernel(CvArgs a)
     }
 }
 
+// The same arithmetic with the source rows staged through LDS (the direct kernel above gathers single bytes from global memory: 12 byte
+// loads per destination pixel, 2.4 TB/s on 480x640 BGR frames).  A workgroup owns CV_TR destination rows of one frame: the 2 CV_TR source
+// rows they read are fetched ONCE with coalesced 4-byte loads -- BGR pixels converted to gray on the way, so that LDS holds the image the
+// resize works on (detect.py:110-116: cvtColor first, then resize) -- and the taps come from LDS.  Needs 4-byte aligned source rows
+// ((sw * sc) % 4 == 0) and rows that fit the staging buffer; the launcher falls back to the direct kernel otherwise.
+constexpr int CV_TR = 4;                 // destination rows per workgroup
+
+template <int GRAY, int MODE, int DC>
+__global__ void __launch_bounds__(256) cv_pre_lds_kernel(CvArgs a, int pitch)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t cv_smem[];   // [2 * CV_TR][pitch]
+    const int groups = (a.dh + CV_TR - 1) / CV_TR;
+    const int n = blockIdx.x / groups, dy0 = (blockIdx.x - n * groups) * CV_TR;
+    const uint8_t* const src = a.src + (long)n * a.sh * a.sw * a.sc;
+    const long rs = (long)a.sw * a.sc;
+    // ---- stage: row slot 2 k + j = source row y_j of destination row dy0 + k; CV_UNR units per thread in flight together (one unit per
+    // trip waited for every load in turn: 108 -> 71 us with the staging alone, the batched loads and the LDS copy of the column table take
+    // the rest) ----
+    const int upr = a.sw >> 2;                       // 4-pixel units per row (a tail of sw % 4 pixels: byte path below)
+    const int total = 2 * CV_TR * upr;
+    int4* const xl = reinterpret_cast<int4*>(cv_smem + 2 * CV_TR * pitch);   // the column table, staged for the CV_TR rows that share it
+    if constexpr (MODE == 2)
+        for (int i = threadIdx.x; i < a.dw; i += 256) xl[i] = a.xtab[i];
+    constexpr int CV_UNR = 6, NW = GRAY != 0 ? 3 : DC;
+#pragma unroll 1
+    for (int base = threadIdx.x; base < total; base += 256 * CV_UNR) {
+        uint32_t w[CV_UNR][NW];
+        int dsto[CV_UNR];
+#pragma unroll
+        for (int j = 0; j < CV_UNR; ++j) {
+            const int u = base + j * 256;
+            dsto[j] = -1;
+            if (u < total) {
+                const int slot = u / upr, x4 = (u - slot * upr) * 4;
+                const int dy = dy0 + (slot >> 1);
+                if (dy < a.dh) {
+                    int y;
+                    if constexpr (MODE == 0) y = dy;
+                    else if constexpr (MODE == 1) y = 2 * dy + (slot & 1);
+                    else { const int4 ty = a.ytab[dy]; y = (slot & 1) ? ty.y : ty.x; }
+                    const uint32_t* p = reinterpret_cast<const uint32_t*>(src + y * rs + (long)x4 * (GRAY != 0 ? 3 : DC));
+#pragma unroll
+                    for (int k = 0; k < NW; ++k) w[j][k] = p[k];
+                    dsto[j] = slot * pitch + x4 * DC;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CV_UNR; ++j) {
+            if (dsto[j] < 0) continue;
+            uint32_t* o = reinterpret_cast<uint32_t*>(cv_smem + dsto[j]);
+            if constexpr (GRAY != 0) {
+                const uint32_t w0 = w[j][0], w1 = w[j][1], w2 = w[j][2];     // B G R B | G R B G | R B G R
+                constexpr int RY = GRAY == 14 ? 4899 : 9798, GY = GRAY == 14 ? 9617 : 19235, BY = GRAY == 14 ? 1868 : 3735, HALF = 1 << (GRAY - 1);
+                const int g0 = (int)((w0 & 255) * BY + ((w0 >> 8) & 255) * GY + ((w0 >> 16) & 255) * RY + HALF) >> GRAY;
+                const int g1 = (int)((w0 >> 24) * BY + (w1 & 255) * GY + ((w1 >> 8) & 255) * RY + HALF) >> GRAY;
+                const int g2 = (int)(((w1 >> 16) & 255) * BY + (w1 >> 24) * GY + (w2 & 255) * RY + HALF) >> GRAY;
+                const int g3 = (int)(((w2 >> 8) & 255) * BY + ((w2 >> 16) & 255) * GY + (w2 >> 24) * RY + HALF) >> GRAY;
+                o[0] = (uint32_t)g0 | ((uint32_t)g1 << 8) | ((uint32_t)g2 << 16) | ((uint32_t)g3 << 24);
+            } else {
+#pragma unroll
+                for (int k = 0; k < DC; ++k) o[k] = w[j][k];
+            }
+        }
+    }
+    if (a.sw & 3) {   // the last sw % 4 pixels of every row, byte by byte
+        const int x_lo = a.sw & ~3, tail = a.sw - x_lo;
+        for (int u = threadIdx.x; u < 2 * CV_TR * tail; u += 256) {
+            const int slot = u / tail, x = x_lo + (u - slot * tail);
+            const int dy = dy0 + (slot >> 1);
+            if (dy >= a.dh) continue;
+            int y;
+            if constexpr (MODE == 0) y = dy;
+            else if constexpr (MODE == 1) y = 2 * dy + (slot & 1);
+            else { const int4 ty = a.ytab[dy]; y = (slot & 1) ? ty.y : ty.x; }
+            for (int c = 0; c < DC; ++c) cv_smem[slot * pitch + x * DC + c] = (uint8_t)cv_px<GRAY>(src + y * rs, x, a.sc, c);
+        }
+    }
+    __syncthreads();
+    // ---- interpolate from LDS: one task = 4 consecutive destination pixels of one of the CV_TR rows ----
+    const int quads = (a.dw + 3) >> 2;
+#pragma unroll 1
+    for (int t = threadIdx.x; t < CV_TR * quads; t += 256) {
+        const int k = t / quads, dx0 = (t - k * quads) * 4, dy = dy0 + k;
+        if (dy >= a.dh) continue;
+        const uint8_t* const row0 = cv_smem + (2 * k) * pitch;
+        const uint8_t* const row1 = cv_smem + (2 * k + 1) * pitch;
+        int b0 = 0, b1 = 0;
+        if constexpr (MODE == 2) { const int4 ty = a.ytab[dy]; b0 = ty.z; b1 = ty.w; }
+        uint32_t packed[DC];
+#pragma unroll
+        for (int w = 0; w < DC; ++w) packed[w] = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int dx = dx0 + i;
+            if (dx >= a.dw) break;
+            int x0 = dx, x1 = dx, a0 = 0, a1 = 0;
+            if constexpr (MODE == 1) { x0 = 2 * dx; x1 = 2 * dx + 1; }
+            if constexpr (MODE == 2) { const int4 tx = xl[dx]; x0 = tx.x; x1 = tx.y; a0 = tx.z; a1 = tx.w; }
+#pragma unroll
+            for (int c = 0; c < DC; ++c) {
+                int v;
+                if constexpr (MODE == 0) {
+                    v = row0[x0 * DC + c];
+                } else if constexpr (MODE == 1) {
+                    v = (row0[x0 * DC + c] + row0[x1 * DC + c] + row1[x0 * DC + c] + row1[x1 * DC + c] + 2) >> 2;
+                } else {
+                    const int r0 = row0[x0 * DC + c] * a0 + row0[x1 * DC + c] * a1;
+                    const int r1 = row1[x0 * DC + c] * a0 + row1[x1 * DC + c] * a1;
+                    v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                }
+                const int kk = i * DC + c;
+                packed[kk >> 2] |= (uint32_t)(v & 255) << (8 * (kk & 3));
+            }
+        }
+        uint8_t* o = a.dst + (((long)n * a.dh + dy) * a.dw + dx0) * DC;
+        const int nb = (a.dw - dx0 < 4 ? a.dw - dx0 : 4) * DC;
+        if (nb == 4 * DC && ((reinterpret_cast<uintptr_t>(o) & 3) == 0)) {
+#pragma unroll
+            for (int w = 0; w < DC; ++w) reinterpret_cast<uint32_t*>(o)[w] = packed[w];
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4 * DC; ++kk)
+                if (kk < nb) o[kk] = (uint8_t)(packed[kk >> 2] >> (8 * (kk & 3)));
+        }
+    }
+}
+
 template <int GRAY, int DC>
 void launch_mode(const CvArgs& a, unsigned grid, hipStream_t s)
 {
+    // rows staged through LDS when they are 4-byte aligned and fit (every common frame size); the byte-gather kernel otherwise
+    const bool aligned = ((long)a.sw * a.sc) % 4 == 0 && (reinterpret_cast<uintptr_t>(a.src) & 3) == 0 && ((long)a.sh * a.sw * a.sc) % 4 == 0;
+    static const bool lds_off = getenv("YF_CV_DIRECT") != nullptr;   // developer switch: A/B against the direct kernel
+    const int pitch = ((a.sw * DC + 15) & ~15) + 16;
+    const size_t lds = (size_t)2 * CV_TR * pitch + (a.mode == 2 ? (size_t)a.dw * sizeof(int4) : 0);
+    if (aligned && lds <= 64 * 1024 && !lds_off) {
+        const unsigned g2 = (unsigned)((long)a.n * ((a.dh + CV_TR - 1) / CV_TR));
+        if (a.mode == 0) hipLaunchKernelGGL((cv_pre_lds_kernel<GRAY, 0, DC>), dim3(g2), dim3(256), lds, s, a, pitch);
+        else if (a.mode == 1) hipLaunchKernelGGL((cv_pre_lds_kernel<GRAY, 1, DC>), dim3(g2), dim3(256), lds, s, a, pitch);
+        else hipLaunchKernelGGL((cv_pre_lds_kernel<GRAY, 2, DC>), dim3(g2), dim3(256), lds, s, a, pitch);
+        return;
+    }
     if (a.mode == 0) hipLaunchKernelGGL((cv_pre_kernel<GRAY, 0, DC>), dim3(grid), dim3(256), 0, s, a);
     else if (a.mode == 1) hipLaunchKernelGGL((cv_pre_kernel<GRAY, 1, DC>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((cv_pre_kernel<GRAY, 2, DC>), dim3(grid), dim3(256), 0, s, a);

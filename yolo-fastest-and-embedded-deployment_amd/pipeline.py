@@ -49,7 +49,7 @@ class BatchPipeline:
 
     def submit(self, x, then=None, mid=None):
         """x: float32 GPU tensor [N,input_channel,H,W] -- or uint8 frames [N,h,w] ([N,h,w,3] for a 3-channel model), which take the
-        fused pre-process (model.forward_u8: h, w == the net input or exactly 2x) -- ready on the caller's current stream.  Returns a
+        device pre-process (model.forward_u8 / forward_bgr_u8: any h, w; BGR frames [N,h,w,3] for a 1-channel net go through cvtColor + resize) -- ready on the caller's current stream.  Returns a
         ticket at once.
         then(out): optional, called with the batch's result dict INSIDE the batch's stream context -- work it queues (e.g. the
         asynchronous all-gather of the records, dist.all_gather_detections_async) is ordered behind this batch only, not behind the
@@ -64,7 +64,9 @@ class BatchPipeline:
             x.record_stream(s)
             # engine slots 1 .. depth: slot 0 stays the engine of plain `model(x)` calls on the caller's own stream, so those may
             # be mixed with batches in flight
-            if x.dtype == torch.uint8:
+            if x.dtype == torch.uint8 and x.dim() == 4 and self.model.input_channel == 1:     # cv2.imread's BGR frames for a 1-channel net: detect.py:108-127
+                pred = self.model.forward_bgr_u8(x, self.post.input_shape, slot=k + 1)
+            elif x.dtype == torch.uint8:
                 pred = self.model.forward_u8(x, self.post.input_shape, slot=k + 1)
             else:
                 pred = self.model(x, slot=k + 1)
