@@ -615,7 +615,7 @@ def main_io():
             out[f"{tag}_{name}_grad"] = xh.grad.numpy().copy()
             print(tag, "loss", name, out[f"{tag}_{name}_losses"].tolist())
         # one train-mode iteration (train.py:111-131 without the optimizer step) on small frames
-        if tag in ("c5rgb", "a2", "ch4"):
+        if tag in ("c5rgb", "a2", "ch4", "ch6"):
             torch.manual_seed(0)
             m, io2 = build(C, Cin, A, 64, 96, seed)
             m.train()

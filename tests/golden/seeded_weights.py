@@ -47,7 +47,7 @@ def seeded_state_dict(shapes, seed):
 # (tag, num_cls, input_channel, num_anchors): the io_params the reference's constructors are parameterised on
 # (yolo_fastest.py:72-78,138,148; detect.py:15-21,53-66; yolo_loss.py:28-33,58-60)
 IO_CONFIGS = [("c1", 1, 1, 3), ("c5rgb", 5, 3, 3), ("c20", 20, 1, 3), ("a2", 3, 1, 2), ("c80rgb", 80, 3, 3), ("ch2", 3, 2, 3),
-              ("ch4", 2, 4, 3)]
+              ("ch4", 2, 4, 3), ("ch6", 3, 6, 3)]      # ch6 (round 5): more input channels than the fused stem kernel takes
 
 
 def io_inputs(tag, input_channel, n=2, H=256, W=320):

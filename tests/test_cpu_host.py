@@ -130,7 +130,9 @@ def test_no_cpu_fallback(sd):
     with pytest.raises(RuntimeError, match="no CPU path"):
         post.detect((torch.zeros(1, 24, 16, 20), torch.zeros(1, 24, 8, 10)))
     with pytest.raises(NotImplementedError):
-        yf.YoloFastest(dict(io, input_channel=5))                   # 1 .. 4 input channels are implemented
+        yf.YoloFastest(dict(io, input_channel=65))                  # 1 .. 64 input channels are implemented (yf_layers.h MAX_INPUT_CHANNEL)
+    six = yf.YoloFastest(dict(io, input_channel=6))                 # more than the fused stem's 4: conv0 becomes a launch of its own
+    assert six.conv0[0].weight.shape == (8, 6, 3, 3)
     rgb = yf.YoloFastest(dict(io, input_channel=3, num_cls=5, num_anchors=2)).eval()   # the constructor's three io_params (yolo_fastest.py:72-78)
     assert rgb.conv0[0].weight.shape == (8, 3, 3, 3) and rgb.head_4.weight.shape == (20, 96, 1, 1) and rgb.head_5.bias.shape == (20,)
     with pytest.raises(RuntimeError, match="no CPU path"):

@@ -81,6 +81,23 @@ def test_heads_match_the_reference_for_other_io_params(yf, dev, golden, tag, fus
     _check_heads(hs, g[tag + "_head_small"], g[tag + "_head_small_f64"], tag)
 
 
+def test_more_input_channels_than_the_fused_stem_takes(yf, dev, golden):
+    """input_channel = 6 (yolo_fastest.py:78 takes any; the fused stem kernel is instantiated for 1 .. 4): conv0 is a launch of its own in
+    the fused plans (one more launch than the shipped model), the pre-process handles 6-channel HWC frames (`img[:, :, ::-1]` reverses the
+    channel axis whatever its length), and the fused u8 entry says what to call instead."""
+    from oracle import backbone_oracle as bo
+    m, _, io = _model(yf, dev, golden, "ch6")
+    u8 = io_cfg.io_inputs("ch6", 6)
+    x = yf.preprocess_u8(m, torch.from_numpy(u8).to(dev), io["input_shape"])
+    assert torch.equal(x.cpu(), bo.preprocess(u8, 6))
+    ops = m.profile(x, reps=1)
+    assert ops[0]["name"] == "conv0" and ops[1]["name"].startswith("conv1_2") and len(ops) == 22
+    with pytest.raises(RuntimeError, match="yf_preprocess_u8"):
+        m.forward_u8(torch.from_numpy(u8).to(dev), io["input_shape"])
+    with pytest.raises(NotImplementedError):
+        yf.YoloFastest(dict(io, input_channel=65))
+
+
 @pytest.mark.parametrize("tag", io_cfg.TAGS)
 def test_fusion_levels_agree_bitwise_for_other_io_params(yf, dev, golden, tag):
     """levels 1 and 2 issue the same arithmetic in the same order (the chained small head included); level 0's per-layer kernels are a
@@ -283,7 +300,7 @@ def test_validation_decode_nms_and_loss_for_other_io_params(yf, dev, golden, tag
         assert np.abs(x.grad.cpu().numpy() - wg).max() <= 2e-5 * np.abs(wg).max()
 
 
-@pytest.mark.parametrize("tag", ["c5rgb", "a2", "ch4"])
+@pytest.mark.parametrize("tag", ["c5rgb", "a2", "ch4", "ch6"])
 def test_training_step_for_other_io_params(yf, dev, golden, tag):
     """model.train(); pred = model(imgs); the two-head loss; loss.backward() (train.py:111-131) for an RGB 5-class and a 2-anchor model
     against the reference's own iteration: train-mode heads, the seven losses, a strided sample and the per-tensor sums of every

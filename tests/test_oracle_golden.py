@@ -338,7 +338,7 @@ def test_io_configs_val_and_loss_oracles(golden, tag):
         np.testing.assert_allclose(grad.numpy(), g[f"{tag}_{name}_grad"], rtol=0, atol=1e-8)
 
 
-@pytest.mark.parametrize("tag", ["c5rgb", "a2", "ch4"])
+@pytest.mark.parametrize("tag", ["c5rgb", "a2", "ch4", "ch6"])
 def test_io_configs_train_mode_oracle(golden, tag):
     """The train-mode graph + loss oracle against the reference's own iteration for an RGB 5-class and a 2-anchor model."""
     from oracle import loss_oracle as lo

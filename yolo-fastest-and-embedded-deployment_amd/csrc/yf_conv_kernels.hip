@@ -242,6 +242,41 @@ __global__ void __launch_bounds__(256) conv0_planar_kernel(DenseArgs a)
     *reinterpret_cast<float4*>(o + 4) = make_float4(fmaxf(acc[4], 0.f), fmaxf(acc[5], 0.f), fmaxf(acc[6], 0.f), fmaxf(acc[7], 0.f));
 }
 
+// conv0 for ANY number of input channels (io_params input_channel > 4: yolo_fastest.py:78 takes any; the fused stem kernel is instantiated
+// for 1 .. 4): the same thread mapping and k order (ky, kx, ci) with a run-time channel loop; the 8-channel result goes out NHWC in the
+// engine's storage type, so the fused plans can continue with a block kernel.
+template <typename T>
+__global__ void __launch_bounds__(256) conv0_any_kernel(DenseArgs a, int cin)
+{
+    long opix = (long)blockIdx.x * 256 + threadIdx.x;
+    if (opix >= a.total) return;
+    const int ox = (int)(opix % a.Wo);
+    long t = opix / a.Wo;
+    const int oy = (int)(t % a.Ho);
+    const long n = t / a.Ho;
+    const long plane = (long)a.H * a.W;
+    const float* __restrict__ in = a.in + n * cin * plane;
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = a.b[c];
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - 1 + ky;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 - 1 + kx;
+            const bool v = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            for (int ci = 0; ci < cin; ++ci) {
+                const float x = v ? in[ci * plane + (long)iy * a.W + ix] : 0.f;
+                const float* wt = a.w + ((ky * 3 + kx) * cin + ci) * 8;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] = fmaf(x, wt[c], acc[c]);
+            }
+        }
+    }
+    T* o = reinterpret_cast<T*>(a.out) + opix * 8;
+    st4<T>(o, make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f)));
+    st4<T>(o + 4, make_float4(fmaxf(acc[4], 0.f), fmaxf(acc[5], 0.f), fmaxf(acc[6], 0.f), fmaxf(acc[7], 0.f)));
+}
+
 // Head conv of the per-layer plan for any Cout = num_anchors * (5 + num_cls) (yolo_fastest.py:138,148; the shipped 24 keeps its
 // pw_kernel instantiation).  thread: one pixel x CT consecutive output channels (blockIdx.y = channel tile, wave-uniform -> the
 // weights come through the scalar path); input NHWC in the engine's storage type, logits NCHW float32.
@@ -396,9 +431,15 @@ int launch_dw(int k, int stride, const DwArgs& a, hipStream_t s, int dtype)
     return dtype == DT_F16 ? launch_dw_t<half_t>(k, stride, a, s) : launch_dw_t<float>(k, stride, a, s);
 }
 
-int launch_dense3x3s2(int cin, int cout, const DenseArgs& a, hipStream_t s)
+int launch_dense3x3s2(int cin, int cout, const DenseArgs& a, hipStream_t s, int out_dtype)
 {
     dim3 grid((unsigned)((a.total + 255) / 256));
+    if (cout == 8 && (cin > 4 || out_dtype == DT_F16)) {   // conv0 of a model with more than 4 input channels (any plan), fp32 or fp16 storage out
+        if (cin < 1) return -1;
+        if (out_dtype == DT_F16) hipLaunchKernelGGL(conv0_any_kernel<half_t>, grid, dim3(256), 0, s, a, cin);
+        else hipLaunchKernelGGL(conv0_any_kernel<float>, grid, dim3(256), 0, s, a, cin);
+        return 0;
+    }
     if (cin == 1 && cout == 8) hipLaunchKernelGGL((dense3x3s2_kernel<1, 8>), grid, dim3(256), 0, s, a);
     else if (cin == 24 && cout == 24) hipLaunchKernelGGL((dense3x3s2_kernel<24, 24>), grid, dim3(256), 0, s, a);
     else if (cin == 2 && cout == 8) hipLaunchKernelGGL(conv0_planar_kernel<2>, grid, dim3(256), 0, s, a);

@@ -286,8 +286,11 @@ void build_plan(Plan* e, int level, int dtype, const LayerSpec* kLayers)
     b.fused = fused;
     b.dtype = dtype;
     int x = b.add_tensor("input", kLayers[0].cin, e->H, e->W, BUF_INPUT);   // NCHW [N, input_channel, H, W]: planes, not NHWC
-    if (fused) {
+    if (fused && kLayers[0].cin <= yf_layers::MAX_STEM_INPUT_CHANNEL) {
         x = b.fused_block("conv0", "conv1_2", "conv1_3", "conv1_4", x, "conv1_4", false);
+    } else if (fused) {     // more input channels than the stem kernel is instantiated for: conv0 as a launch of its own, then the block
+        x = b.unit("conv0", x);
+        x = b.fused_block(nullptr, "conv1_2", "conv1_3", "conv1_4", x, "conv1_4", false);
     } else {
         for (const char* n : {"conv0", "conv1_2", "conv1_3", "conv1_4"}) x = b.unit(n, x);
     }
@@ -680,7 +683,9 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                 rc = yf::launch_dw(L.k, L.stride, a, s, e->sdt());
             } else {
                 yf::DenseArgs a{ptr(o.in1), W(o.layer), B(o.layer), ptr(o.out), (long)n * to.H * to.W, ti.H, ti.W, to.H, to.W};
-                rc = yf::launch_dense3x3s2(L.cin, L.cout, a, s);   // (conv0 with Cin > 1 reads the NCHW planes of the net input)
+                // (conv0 with Cin > 1 reads the NCHW planes of the net input; with Cin > 4 it is a launch of its own in the fused plans
+                //  too and writes the engine's storage type)
+                rc = yf::launch_dense3x3s2(L.cin, L.cout, a, s, o.layer == 0 && e->fusion >= 1 ? e->sdt() : yf::DT_F32);
             }
             }
             if (rc) return fail(YF_E_INVALID, "no kernel for layer %s", L.name);
@@ -782,7 +787,7 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
         return fail(YF_E_BLOB, "blob describes n_layers=%u; YoloFastest has %d", hd.n_layers, kNumLayers);
     static_assert((int)yf::POST_MAX_ANCHORS == (int)yf_layers::MAX_NUM_ANCHORS, "one anchor limit");
     if (hd.input_channel < 1 || hd.input_channel > (uint32_t)yf_layers::MAX_INPUT_CHANNEL)
-        return fail(YF_E_BLOB, "input_channel=%u: the HIP engine implements 1 .. 4 input channels", hd.input_channel);
+        return fail(YF_E_BLOB, "input_channel=%u: the HIP engine implements 1 .. %d input channels", hd.input_channel, (int)yf_layers::MAX_INPUT_CHANNEL);
     if (hd.num_anchors < 1 || hd.num_anchors > (uint32_t)yf::POST_MAX_ANCHORS || hd.num_cls < 1 || hd.num_cls > (uint32_t)yf_layers::MAX_NUM_CLS ||
         hd.num_out != hd.num_anchors * (5 + hd.num_cls))
         return fail(YF_E_BLOB, "blob describes num_anchors=%u num_cls=%u num_out=%u: need 1..%d anchors, >= 1 class and num_out == "
@@ -1173,6 +1178,9 @@ int yf_forward_u8(yf_handle h, const uint8_t* d_u8, int N, int src_h, int src_w,
                   void* stream)
 {
     if (!h || !d_u8) return fail(YF_E_INVALID, "yf_forward_u8: null pointer");
+    if (h->input_channel > yf_layers::MAX_STEM_INPUT_CHANNEL)
+        return fail(YF_E_INVALID, "yf_forward_u8: the fused u8 entry takes 1 .. %d input channels; a %d-channel net goes through yf_preprocess_u8 + yf_forward",
+                    (int)yf_layers::MAX_STEM_INPUT_CHANNEL, h->input_channel);
     int down2;
     if (int rc = u8_mode(h, src_h, src_w, &down2)) return rc;
     if (down2 < 0) return forward_via_cv(h, d_u8, N, src_h, src_w, h->input_channel, 0, d_hl, d_hs, ws, ws_bytes, stream);
@@ -1445,6 +1453,7 @@ int yf_profile_forward_u8(yf_handle h, const uint8_t* d_u8, int N, int src_h, in
                           int n_ops)
 {
     if (!h || !d_u8) return fail(YF_E_INVALID, "yf_profile_forward_u8: null pointer");
+    if (h->input_channel > yf_layers::MAX_STEM_INPUT_CHANNEL) return fail(YF_E_INVALID, "yf_profile_forward_u8: 1 .. %d input channels", (int)yf_layers::MAX_STEM_INPUT_CHANNEL);
     int down2;
     if (int rc = u8_mode(h, src_h, src_w, &down2)) return rc;
     if (down2 < 0) return fail(YF_E_INVALID, "yf_profile_forward_u8: source %dx%d -- the profiled pass takes frames of the net's size or exactly 2x", src_h, src_w);

@@ -559,6 +559,7 @@ static int launch_fb_t(FbArgs a, int N, hipStream_t s)
 //     slower at these shapes: it costs occupancy and LDS bandwidth, the L2-served loads were already hidden)
 #define YF_FB_SHAPES(FB)                                                                                                 \
     FB(8, 8, 4, 1, false, false, true, 16, 16, YF_STEM_BH, YF_STEM_BW, 8, 8, 1, false)     /* conv0 + conv1_2/1_3/1_4      @ H/2  */          \
+    FB(8, 8, 4, 1, false, false, false, 16, 16, 1, 2, 8, 8, 1, false)    /* conv1_2/1_3/1_4 behind a separate conv0 (input_channel > 4) */ \
     FB(4, 8, 4, 1, true, false, false, 16, 16, 1, 2, 8, 8, 1, false)     /* res1_1                        @ H/2  */          \
     FB(8, 32, 8, 1, true, false, false, 16, 16, YF_RES2_BH, YF_RES2_BW, 8, 8, 1, false)    /* res2_1, res2_2                @ H/4  */          \
     FB(8, 32, 8, 2, false, false, false, 16, 20, 1, 1, 8, 8, 1, false)   /* conv2_2/2_3/3_1               H/4 -> H/8 */      \

@@ -189,7 +189,7 @@ size_t mfma_packed_floats_x3(int k1, int k2, int n);
 void mfma_pack_weights_x3(const float* w, int k1, int k2, int n, float* out);
 size_t mfma_packed_floats(int k1, int k2, int n);
 void mfma_pack_weights(const float* w, int k1, int k2, int n, float* out);
-int launch_dense3x3s2(int cin, int cout, const DenseArgs& a, hipStream_t s);   // cin 3 (conv0 on RGB): `in` is NCHW planes [N,3,H,W]
+int launch_dense3x3s2(int cin, int cout, const DenseArgs& a, hipStream_t s, int out_dtype = DT_F32);   // cin 3 (conv0 on RGB): `in` is NCHW planes [N,3,H,W]
 // head conv of the per-layer plan for any Cout = num_anchors * (5 + num_cls) (yolo_fastest.py:138,148): NHWC [N,HW,cin] (storage
 // dtype) x w[cin][cout] + b -> NCHW float32 [N,cout,HW]; fp32 arithmetic in every engine dtype
 int launch_head_conv(const float* in, const float* w, const float* b, float* out, int cin, int cout, long HW, int N, hipStream_t s, int dtype = DT_F32);

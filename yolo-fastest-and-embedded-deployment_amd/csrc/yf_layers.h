@@ -9,7 +9,7 @@ enum Kind { K_PW = 0, K_DW = 1, K_DENSE = 2, K_DECONV = 3, K_HEAD = 4 };
 
 // ONE set of io_params limits for the inference engine (yf_create: blob header), the trainer (yf_trainer_create_ex) and model.py
 // (MAX_* there mirror these): a model that constructs also runs inference AND trains.
-enum { MAX_INPUT_CHANNEL = 4, MAX_NUM_ANCHORS = 8, MAX_NUM_CLS = 4096, MAX_NUM_OUT = MAX_NUM_ANCHORS * (5 + MAX_NUM_CLS) };
+enum { MAX_INPUT_CHANNEL = 64, MAX_STEM_INPUT_CHANNEL = 4 /* conv0 fused into the stem kernel; above: a launch of its own */, MAX_NUM_ANCHORS = 8, MAX_NUM_CLS = 4096, MAX_NUM_OUT = MAX_NUM_ANCHORS * (5 + MAX_NUM_CLS) };
 
 // The YoloFastest layer table, module-definition order (yolo_fastest.py:78-148). The blob must match it.
 // kBaseLayers is the graph for the shipped io_params (input_channel 1, num_out = 3 anchors x (5 + 3 classes) = 24); the reference's

@@ -7,7 +7,7 @@ Drop-in surface kept:
     (src/detect.py:90-91), `.to(device)` / `.eval()` chain (:89);
   * `model(x)`: x float32 [N,input_channel,H,W] NCHW, H and W multiples of 32 -> `(head_large, head_small)` float32
     NCHW [N, num_anchors * (5 + num_cls), ...] on the same device (:218).  Every num_cls and num_anchors (up to 8) of io_params is
-    implemented, and input_channel 1 (gray), 3 (cv2's BGR frames, detect.py:109-119), 2 or 4.
+    implemented, and every input_channel up to 64 (1 gray, 3 = cv2 BGR frames, detect.py:109-119; above 4 conv0 is a launch of its own).
 The torch.nn modules below are parameter CONTAINERS only (they give the state-dict its names and shapes);
 they are never called.  In eval mode forward() packs them once (BN fold, packer.py) and runs the tuned HIP engine; in train mode it
 runs the training operators (training.py: batch-statistics BatchNorm, differentiable).  There is no CPU path: a non-GPU tensor or
@@ -21,7 +21,7 @@ import torch.nn as nn
 from . import _lib, packer
 
 
-MAX_NUM_ANCHORS, MAX_NUM_CLS = 8, 4096   # csrc/yf_layers.h (one set of limits for yf_create and yf_trainer_create_ex)
+MAX_NUM_ANCHORS, MAX_NUM_CLS, MAX_INPUT_CHANNEL = 8, 4096, 64   # csrc/yf_layers.h (one set of limits for yf_create and yf_trainer_create_ex)
 DEFAULT_FUSION = 2   # yf_set_fusion: 0 = one launch per layer (bring-up, every probe); 1 = block-fused kernels (round 2's plan);
                      # 2 = + the per-frame deep stage's launch boundaries removed (conv5_2 in the res5 launch, ...)
 
@@ -97,9 +97,9 @@ class YoloFastest(nn.Module):
         num_anchor = io_params["num_anchors"]
         self.num_anchors = num_anchor
         self.num_out = num_anchor * (5 + self.num_cls)
-        if self.input_channel not in (1, 2, 3, 4):
-            raise NotImplementedError("the HIP engine implements input_channel 1 (gray), 3 (cv2's BGR frames), 2 and 4, not %r"
-                                      % (self.input_channel,))
+        if not isinstance(self.input_channel, int) or not (1 <= self.input_channel <= MAX_INPUT_CHANNEL):
+            raise NotImplementedError("the HIP engine implements input_channel 1 .. %d (1 .. 4: conv0 fused into the first kernel; more: a launch "
+                                      "of its own), not %r" % (MAX_INPUT_CHANNEL, self.input_channel))
         if not (1 <= int(num_anchor) <= MAX_NUM_ANCHORS) or not (1 <= int(self.num_cls) <= MAX_NUM_CLS):   # csrc/yf_layers.h: engine AND trainer
             raise ValueError("num_anchors must be 1..%d and num_cls 1..%d" % (MAX_NUM_ANCHORS, MAX_NUM_CLS))
         # parameter containers, module-definition order of the reference (state-dict order follows it)
