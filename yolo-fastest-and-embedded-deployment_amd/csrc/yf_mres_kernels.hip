@@ -69,6 +69,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef YF_MRES_FRAME
 #define YF_MRES_FRAME 1   // frame-sized tiles of the producer/consumer kernel expand the interior pixels only (0: round 2's behaviour, for A/B builds)
 #endif
+#ifndef YF_MRES_Q4
+#define YF_MRES_Q4 0   // 1: fp32 blocks with 8 output channels project on v_mfma_f32_4x4x1_16B_f32 (no half-empty 16-wide N tile).  Built and measured in
+                       // round 5, OFF: half the matrix-pipe cycles of the projection, but every lane group keeps its own partial sums
+                       // (8 accumulator registers per tile instead of 4): 120 -> 136 VGPRs in the 8/48/8 blocks (one resident workgroup fewer) and
+                       // 78 -> 100 in the stride-2 8/32/8 triple (two instead of three): res3_1 20.3 -> 26.9 us, res3_2 19.4 -> 26.0, conv2_2 triple
+                       // 30.1 -> 37.5 (tools/ops_abn.sh, three interleaved rounds; same heads to rounding, parity tests green)
+#endif
 #ifndef YF_MRES_PK
 #define YF_MRES_PK 1   // depthwise taps as v_pk_fma_f32 (two channels per instruction; same fused multiply-add per element)
 #endif
@@ -90,7 +97,7 @@ __host__ __device__ constexpr int mres_chunk_floats(int cin, int cout, int wmode
 {
     return wmode != WM_F32 ? (wmode == WM_F16X3 ? 2 : 1) * ((mres_ksteps(cin) + 3) / 4) * 128 + 16 + 9 * 16 + 16 +
                                  (wmode == WM_F16X3 ? 2 : 1) * ((cout + 15) / 16) * 128
-                           : mres_ksteps(cin) * 64 + 16 + 9 * 16 + 16 + 4 * ((cout + 15) / 16) * 64;
+                           : mres_ksteps(cin) * 64 + 16 + 9 * 16 + 16 + ((YF_MRES_Q4 && cout == 8) ? 2 * 64 * 4 : 4 * ((cout + 15) / 16) * 64);
 }
 
 // Stage the block's weight stream and the halo'd input tile (zeros outside the image / beyond the region) in LDS.  ALL global loads
@@ -180,7 +187,13 @@ __global__ void __launch_bounds__(NWAVE * 64) YF_MRES_WAVES_ATTR mres_kernel(Mre
     constexpr int KS1 = mres_ksteps(CIN), NB1 = CIN / 16, NT2 = (COUT + 15) / 16, NCH = (CEXP + 15) / 16;
     constexpr int NK1 = (KS1 + 3) / 4;    // f16 MFMAs per expansion tile
     constexpr int OFF_B1 = H16 ? WM * NK1 * 128 : KS1 * 64, OFF_WD = OFF_B1 + 16, OFF_BD = OFF_WD + 144, OFF_W2 = OFF_BD + 16;
-    constexpr int CHUNK = OFF_W2 + (H16 ? WM * NT2 * 128 : 4 * NT2 * 64);
+    // Q4 (round 5): an 8-channel projection fills half of a 16x16x4 MFMA's N tile.  v_mfma_f32_4x4x1_16B_f32 multiplies, in 16 independent
+    // 4x4 blocks, the 4 output channels of lanes 4b .. 4b+3's A registers with the 4 pixels of their B registers at ONE k: with the depthwise
+    // result as B (lane (r, q): channel 4q + j of pixel r) block (q, r / 4) accumulates channels 4h .. 4h+3 of ITS four pixels over the k
+    // values lane group q holds -- two instructions (h = 0, 1) of 8 cycles per k-step instead of one of 32 -- and the four lane groups'
+    // partial sums are added once per tile in the epilogue (k19r_kernel's scheme for conv1_9's channels 16 .. 23).
+    constexpr bool Q4 = YF_MRES_Q4 && !H16 && COUT == 8;
+    constexpr int CHUNK = OFF_W2 + (H16 ? WM * NT2 * 128 : (Q4 ? 2 * 64 * 4 : 4 * NT2 * 64));
     static_assert((TH * TW) % 16 == 0 && CIN % 8 == 0 && COUT % 4 == 0, "shape");
     static_assert(!RES || (CIN == COUT && S == 1), "residual needs same shape");
     static_assert(CHUNK == mres_chunk_floats(CIN, COUT, wmode_of<T>()), "pack layout");
@@ -242,11 +255,13 @@ __global__ void __launch_bounds__(NWAVE * 64) YF_MRES_WAVES_ATTR mres_kernel(Mre
     }
     // ---- projection accumulators and the E offsets of this lane's output pixel (as A-fragment row r) ----
     f32x4 acc[MTOW][NT2];
+    f32x4 accq[Q4 ? MTOW : 1][2];   // Q4: channels 4h .. 4h+3 of this lane's pixel, partial over this lane group's k values
     int rp0[MTOW];
 #pragma unroll
     for (int i = 0; i < MTOW; ++i) {
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) acc[i][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (Q4) { accq[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; accq[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         const int mo = wave + i * NWAVE;
         int oy, ox;
         mres_out_px<TH, TW, RW, S>(mo < MTO ? mo : 0, r, oy, ox);
@@ -284,11 +299,16 @@ __global__ void __launch_bounds__(NWAVE * 64) YF_MRES_WAVES_ATTR mres_kernel(Mre
 #pragma unroll
                 for (int nt = 0; nt < NT2; ++nt) w2l[nt] = reinterpret_cast<const f16x4*>(wc + OFF_W2)[(NT2 + nt) * 64 + lane];
             }
-        } else {
+        } else if constexpr (!Q4) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int nt = 0; nt < NT2; ++nt) w2f[j][nt] = wc[OFF_W2 + (j * NT2 + nt) * 64 + lane];
+        }
+        float4 wq[2];   // Q4: W2[4h + (r & 3)][chunk channel 4q + j], j = x y z w
+        if constexpr (Q4) {
+            wq[0] = reinterpret_cast<const float4*>(wc + OFF_W2)[lane];
+            wq[1] = reinterpret_cast<const float4*>(wc + OFF_W2)[64 + lane];
         }
 
         MRES_STAMP(2)   // chunk weights from LDS
@@ -384,6 +404,13 @@ __global__ void __launch_bounds__(NWAVE * 64) YF_MRES_WAVES_ATTR mres_kernel(Mre
                     const f16x4 dh = f16x4{(half_t)fmaxf(d[0], 0.f), (half_t)fmaxf(d[1], 0.f), (half_t)fmaxf(d[2], 0.f), (half_t)fmaxf(d[3], 0.f)};
 #pragma unroll
                     for (int nt = 0; nt < NT2; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(w2h[nt], dh, acc[i][nt], 0, 0, 0);
+                } else if constexpr (Q4) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float dj = relu_bits(d[j]);
+                        accq[i][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(((const float*)&wq[0])[j], dj, accq[i][0], 0, 0, 0);
+                        accq[i][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(((const float*)&wq[1])[j], dj, accq[i][1], 0, 0, 0);
+                    }
                 } else {
 #pragma unroll
                     for (int j = 0; j < ((YF_MRES_DBG & 4) ? 1 : 4); ++j) {
@@ -407,6 +434,18 @@ __global__ void __launch_bounds__(NWAVE * 64) YF_MRES_WAVES_ATTR mres_kernel(Mre
 #pragma unroll
     for (int i = 0; i < MTOW; ++i) {
         const int mo = wave + i * NWAVE;
+        if constexpr (Q4) {   // add the four lane groups' partial sums (every group then holds the totals of its pixel); group q stores channels 4q .. 4q+3
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float v = accq[i][h][k];
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    accq[i][h][k] = v;
+                }
+            acc[i][0] = q == 0 ? accq[i][0] : accq[i][1];
+        }
         if (!EVEN_O && i == MTOW - 1 && mo >= MTO) continue;
         int oy, ox;
         mres_out_px<TH, TW, RW, S>(mo, r, oy, ox);
@@ -1006,6 +1045,13 @@ void mres_pack_weights(const float* w1 /*[cin][cexp]*/, const float* b1, const f
                         const float v = w2_at(j, nt, lane);
                         o16[(nt * 64 + lane) * 4 + j] = f32_to_f16_bits(v);
                         if (x3) o16[((NT2 + nt) * 64 + lane) * 4 + j] = f16_lo_bits(v);
+                    }
+        } else if (YF_MRES_Q4 && cout == 8) {   // 4x4x1 form: [h][lane][j] = W2[chunk channel 4q + j][output channel 4h + (lane & 3)]
+            for (int h = 0; h < 2; ++h)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        const int ch = 4 * (lane >> 4) + j;
+                        o[(h * 64 + lane) * 4 + j] = ch_ok(ch) ? w2[(size_t)(c * 16 + ch) * cout + 4 * h + (lane & 3)] : 0.f;
                     }
         } else {
             for (int j = 0; j < 4; ++j)
