@@ -440,6 +440,8 @@ def main():
     ap.add_argument("--regions", type=int, default=5,
                     help="timed regions of --steps steps each, run back to back in the same loop after ONE warm-up: `value` is the first "
                          "(the contract's K steps), `repeat_values` lists them all (the box-to-box and run-to-run spread in the record)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="stop after the headline's timed regions and print a short line (kernel traces of exactly the headline loop: tools/refresh_profiles.sh)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra f16x3 measurement of the same workload")
     ap.add_argument("--no-live-traffic", action="store_true",
@@ -669,6 +671,15 @@ def main():
     model, post = make(args.dtype, lanes, branches)
     region_s = []
     elapsed, raw = timed(model, post, in_flight, args.steps, args.warmup, multi, regions=args.regions, region_times=region_s)
+    if args.headline_only:
+        if rank == 0:
+            print(json.dumps({"metric": "frames/sec end-to-end (headline loop only)", "value": round(n_total * args.steps / elapsed, 1), "unit": "frames/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+                              "repeat_values": [round(n_total * args.steps / t, 1) for t in region_s], "dtype": args.dtype, "in_flight": in_flight,
+                              "source_hash": source_hash()}))
+        if multi:
+            dist.destroy_process_group()
+        return
 
     # model / post-process split and the one-batch-at-a-time figure (two half-batch lanes, the small head on its side stream): measured
     # after the headline's timed region, same process

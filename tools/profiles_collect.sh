@@ -3,7 +3,7 @@
 # summaries under profiles/ (kernel stats per run, PMC rows of the yf:: kernels, pmc_traffic.json stamped with the source hash).
 set -e
 cd "$(dirname "$0")/.."
-TAG=${1:-r03}
+TAG=${1:-r05}
 python tools/pmc_traffic.py gpurun_out/ops.json gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv profiles/pmc_traffic.json gpurun_out/${TAG}_source_hash.txt 256 256 f32 | head -1
 for t in default lanes1 f16 f16x3 f16x3_512; do
   f=$(ls gpurun_out/prof_$t/*_kernel_stats.csv)
@@ -28,4 +28,17 @@ for src, dst in (('gpurun_out/pmc_fetch/f_counter_collection.csv', 'profiles/${T
             r = dict(r); r['Kernel_Name'] = r['Kernel_Name'].replace('void yf::', '').split('(yf::')[0][:100]
             w.writerow({c: r[c] for c in cols})
 PY
+# overlap of the headline loop (two batches in flight): which kernels run alone, which beside another batch's
+if ls gpurun_out/prof_headline/*_kernel_trace.csv >/dev/null 2>&1; then
+  { echo "# tools/trace_overlap.py over the kernel trace of \`bench.py --headline-only --regions 1\` (the headline loop alone, two batches in flight); build $(cat gpurun_out/${TAG}_source_hash.txt)";
+    python tools/trace_overlap.py $(ls gpurun_out/prof_headline/*_kernel_trace.csv | head -1) --steps 20 --pairs k19r; } > profiles/${TAG}_overlap_headline.txt
+fi
+# what binds BASELINE configs[2] per launch (tools/pmc_configs2.sh)
+for DT in f16x3 f16 f32; do
+  if [ -f gpurun_out/${TAG}_c2_${DT}_ops.json ]; then
+    { echo "# tools/c2_report.py over the five counter passes of tools/pmc_configs2.sh, 640x512 batch 128 $DT; build $(cat gpurun_out/${TAG}_source_hash.txt)";
+      python tools/c2_report.py gpurun_out/${TAG}_c2_$DT profiles/${TAG}_configs2_binding_$DT.json; } > profiles/${TAG}_configs2_binding_$DT.txt
+    cp $(ls gpurun_out/${TAG}_c2_${DT}_stats/*_kernel_stats.csv | head -1) profiles/${TAG}_c2_${DT}_640x512_lanes1_kernel_stats.csv
+  fi
+done
 echo "profiled build: $(cat gpurun_out/${TAG}_source_hash.txt)   this tree: $(python -c 'import bench; print(bench.source_hash())')"
