@@ -329,3 +329,31 @@ def test_plot_one_box_geometry():
     img2 = np.zeros((120, 200, 3), np.uint8)
     plot_one_box([10, 10, 30, 30], img2, color=[0, 0, 255])
     assert tuple(img2[10, 20]) == (255, 0, 0) and tuple(img2[11, 20]) == (0, 0, 0)
+
+
+def test_bench_pins_each_rank_to_its_own_cpu_slice():
+    """bench.py pins a rank to a slice of the host's CPUs before its first GPU call.  In a child process per rank (the
+    mask is inherited by whatever the process starts afterwards): the slices of four ranks are disjoint, non-empty subsets of the allowed
+    set; one rank alone is left unpinned."""
+    import json
+    import subprocess
+    import sys
+    code = ("import json, os, sys; sys.path.insert(0, %r); sys.argv = ['bench.py']; import bench\n"
+            "before = sorted(os.sched_getaffinity(0)); info = bench.pin_rank_to_cpus(int(sys.argv_rank), int(sys.argv_world))\n"
+            "print(json.dumps({'before': before, 'after': sorted(os.sched_getaffinity(0)), 'info': info}))\n") % ROOT
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 8:
+        pytest.skip("needs at least 8 allowed CPUs for four ranks")
+    seen = []
+    for rank in range(4):
+        r = subprocess.run([sys.executable, "-c", code.replace("sys.argv_rank", "'%d'" % rank).replace("sys.argv_world", "'4'")],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        assert out["before"] == allowed and out["info"] is not None and out["info"]["cpus"] == len(out["after"]) >= 2
+        assert set(out["after"]) <= set(allowed)
+        seen.append(set(out["after"]))
+    assert all(not (a & b) for i, a in enumerate(seen) for b in seen[i + 1:])
+    r = subprocess.run([sys.executable, "-c", code.replace("sys.argv_rank", "'0'").replace("sys.argv_world", "'1'")], capture_output=True, text=True, timeout=300)
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["info"] is None and out["after"] == allowed
