@@ -18,4 +18,9 @@ for DT in f16x3 f16 f32; do
   echo "$DT traffic done"
   rocprofv3 --kernel-trace --stats -d ${O}_stats -o p --output-format csv -- python3 $R/bench.py --launch-repeats 1 --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-configs --no-train --no-extras --no-live-traffic --in-flight 1 --lanes 1 --res 512 --batch 128 --dtype $DT > ${O}_stats.log 2>&1 || exit 1
   tail -1 ${O}_stats.log | cut -c1-300
+  # summarise ON THE BOX (the raw counter files of 15 passes exceed what gpurun copies back) and drop the raw files
+  ( cd $R && { echo "# tools/c2_report.py over the five counter passes of tools/pmc_configs2.sh, 640x512 batch 128 $DT; build $(python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.source_hash())")";
+      python3 tools/c2_report.py gpurun_out/${TAG}_c2_$DT gpurun_out/${TAG}_configs2_binding_$DT.json; } > gpurun_out/${TAG}_configs2_binding_$DT.txt )
+  cp ${O}_stats/p_kernel_stats.csv $R/gpurun_out/${TAG}_c2_${DT}_640x512_lanes1_kernel_stats.csv
+  rm -rf ${O}_wait ${O}_issue ${O}_fetch ${O}_write ${O}_stats ${O}_*.log
 done

@@ -33,12 +33,10 @@ if ls gpurun_out/prof_headline/*_kernel_trace.csv >/dev/null 2>&1; then
   { echo "# tools/trace_overlap.py over the kernel trace of \`bench.py --headline-only --regions 1\` (the headline loop alone, two batches in flight); build $(cat gpurun_out/${TAG}_source_hash.txt)";
     python tools/trace_overlap.py $(ls gpurun_out/prof_headline/*_kernel_trace.csv | head -1) --steps 20 --pairs k19r; } > profiles/${TAG}_overlap_headline.txt
 fi
-# what binds BASELINE configs[2] per launch (tools/pmc_configs2.sh)
+# what binds BASELINE configs[2] per launch (tools/pmc_configs2.sh summarises on the box)
 for DT in f16x3 f16 f32; do
-  if [ -f gpurun_out/${TAG}_c2_${DT}_ops.json ]; then
-    { echo "# tools/c2_report.py over the five counter passes of tools/pmc_configs2.sh, 640x512 batch 128 $DT; build $(cat gpurun_out/${TAG}_source_hash.txt)";
-      python tools/c2_report.py gpurun_out/${TAG}_c2_$DT profiles/${TAG}_configs2_binding_$DT.json; } > profiles/${TAG}_configs2_binding_$DT.txt
-    cp $(ls gpurun_out/${TAG}_c2_${DT}_stats/*_kernel_stats.csv | head -1) profiles/${TAG}_c2_${DT}_640x512_lanes1_kernel_stats.csv
-  fi
+  for ext in txt json; do [ -f gpurun_out/${TAG}_configs2_binding_$DT.$ext ] && cp gpurun_out/${TAG}_configs2_binding_$DT.$ext profiles/; done
+  [ -f gpurun_out/${TAG}_c2_${DT}_640x512_lanes1_kernel_stats.csv ] && cp gpurun_out/${TAG}_c2_${DT}_640x512_lanes1_kernel_stats.csv profiles/
 done
+[ -f gpurun_out/${TAG}_bench_line.json ] && cp gpurun_out/${TAG}_bench_line.json profiles/
 echo "profiled build: $(cat gpurun_out/${TAG}_source_hash.txt)   this tree: $(python -c 'import bench; print(bench.source_hash())')"
