@@ -202,6 +202,9 @@ struct Builder {
         const int out = fused_block(nullptr, (std::string(first) + ".conv1").c_str(), (std::string(first) + ".conv2").c_str(),
                                     (std::string(first) + ".conv3").c_str(), x, last, true);
         e->ops.back().nblk = (int)names.size();
+        // a scratch tensor of the chain's shape (unnamed: not probe-able): at small batches the launcher runs the blocks as separate launches on
+        // quarter-frame tiles (yf_mres_kernels.hip launch_mres: "small batches") and needs a third buffer beside the chain's input and output
+        e->ops.back().out2 = add_tensor("", L0.cin, tx.H, tx.W);
         return out;
     }
     // pw-expand -> dw3x3 -> pw-project in one launch (optionally conv0 in front, optionally + residual)

@@ -940,8 +940,44 @@ static int launch_mres_any(const MresArgs& a, int N, hipStream_t s)
 bool mres_has_post(int cin, int cexp, int cout, int postn) { return cin == 48 && cexp == 224 && cout == 48 && postn == 96; }
 size_t mres_post_packed_floats(int cout, int postn) { return (size_t)mres_ksteps(cout) * (postn / 16) * 64 + postn; }
 
+// Small batches (round 5): when the whole-frame / 16x20 tiling of a launch would leave more than half of the CUs idle, the same arithmetic
+// runs on 8x10 tiles -- four times the workgroups.  A residual CHAIN (tile == frame, one workgroup per frame for all its blocks) is then
+// issued block by block on those tiles: each block reads the previous one's result WITH its halo, so consecutive blocks go through HBM and
+// alternate between the chain's input tensor, a scratch tensor of the same shape (MresArgs::out_exp, from the engine's plan) and, last, the
+// output.  fp32 storage only (a block's result is the same fp32 value in LDS and in HBM: bitwise the chained launch; fp16 storage would
+// round between the blocks).  The launch count rises by nblk - 1; measured in DESIGN.md section 4 "Small batches".
+static bool mres_small_batch(int N, int H, int W, int th, int tw)
+{
+    static const bool off = getenv("YF_MRES_SMALL_OFF") != nullptr;   // developer switch (A/B)
+    const int n_cu = device_cu_count(current_device());
+    const long big_tiles = (long)N * ((H + th - 1) / th) * ((W + tw - 1) / tw);
+    return !off && n_cu > 0 && H > 8 && 2 * big_tiles <= n_cu;
+}
+
+template <typename T>
+static int launch_res4_unchained(const MresArgs& a, int N, hipStream_t s)
+{
+    float* const I = const_cast<float*>(a.in);     // the chain's input: read by nothing after the chain (the engine's plan), so it is scratch from block 2 on
+    float* const Tmp = a.out_exp;
+    const float* src = a.in;
+    for (int k = 0; k < a.nblk; ++k) {
+        float* dst = k == a.nblk - 1 ? a.out : (src == I ? Tmp : I);
+        MresArgs b = a;
+        b.in = src; b.out = dst; b.wp = a.wp + (size_t)k * a.wstride; b.nblk = 1; b.wstride = 0; b.out_exp = nullptr; b.post_w = nullptr; b.post_out = nullptr;
+        if (int rc = launch_mres_pc_t<24, 136, 24, true, 8, 10, 3, 5, T>(b, N, s)) return rc;
+        src = dst;
+    }
+    return 0;
+}
+
 int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArgs& a, int N, hipStream_t s, int dtype)
 {
+    if (dtype != DT_F16 && cin == 24 && cexp == 136 && cout == 24 && res && stride == 1 && a.nblk > 1 && a.out_exp && !a.post_w &&
+        mres_small_batch(N, a.H, a.W, 16, 20))
+        return dtype == DT_F16X3 ? launch_res4_unchained<x3_t>(a, N, s) : launch_res4_unchained<float>(a, N, s);
+    if (cin == 16 && cexp == 96 && cout == 16 && res && stride == 1 && a.nblk <= 1 && mres_small_batch(N, a.H, a.W, 16, 20))
+        return dtype == DT_F16 ? launch_mres_t<16, 96, 16, true, 1, 8, 10, 8, half_t>(a, N, s)
+             : dtype == DT_F16X3 ? launch_mres_t<16, 96, 16, true, 1, 8, 10, 8, x3_t>(a, N, s) : launch_mres_t<16, 96, 16, true, 1, 8, 10, 8, float>(a, N, s);
     if (a.post_w) {
         if (!(cin == 48 && cexp == 224 && cout == 48 && res && stride == 1)) return -5;
         return dtype == DT_F16 ? launch_mres_pc_t<48, 224, 48, true, 8, 10, YF_RES5_NWP, YF_RES5_NWC, half_t, 96>(a, N, s)
