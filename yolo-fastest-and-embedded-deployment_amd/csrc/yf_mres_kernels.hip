@@ -951,21 +951,27 @@ static bool mres_small_batch(int N, int H, int W, int th, int tw)
     static const bool off = getenv("YF_MRES_SMALL_OFF") != nullptr;   // developer switch (A/B)
     const int n_cu = device_cu_count(current_device());
     const long big_tiles = (long)N * ((H + th - 1) / th) * ((W + tw - 1) / tw);
-    return !off && n_cu > 0 && H > 8 && 2 * big_tiles <= n_cu;
+    return !off && n_cu > 0 && 2 * big_tiles <= n_cu;
 }
 
-template <typename T>
-static int launch_res4_unchained(const MresArgs& a, int N, hipStream_t s)
+template <int CIN, int CEXP, int TH, int TW, int NWP, int NWC, typename T>
+static int launch_chain_unchained(const MresArgs& a, int N, hipStream_t s)
 {
     float* const I = const_cast<float*>(a.in);     // the chain's input: read by nothing after the chain (the engine's plan), so it is scratch from block 2 on
     float* const Tmp = a.out_exp;
     const float* src = a.in;
     for (int k = 0; k < a.nblk; ++k) {
-        float* dst = k == a.nblk - 1 ? a.out : (src == I ? Tmp : I);
+        // a trailing 1x1 conv (conv5_2 behind res5_5) reads the last block's result from a scratch buffer; without one the last block writes the output
+        float* dst = (k == a.nblk - 1 && !a.post_w) ? a.out : (src == I ? Tmp : I);
         MresArgs b = a;
         b.in = src; b.out = dst; b.wp = a.wp + (size_t)k * a.wstride; b.nblk = 1; b.wstride = 0; b.out_exp = nullptr; b.post_w = nullptr; b.post_out = nullptr;
-        if (int rc = launch_mres_pc_t<24, 136, 24, true, 8, 10, 3, 5, T>(b, N, s)) return rc;
+        if (int rc = launch_mres_pc_t<CIN, CEXP, CIN, true, TH, TW, NWP, NWC, T>(b, N, s)) return rc;
         src = dst;
+    }
+    if (a.post_w) {   // the pw GEMM's own fp32 fragments + bias (what the fused form evaluates on chip): pw_ws_kernel, the same bits
+        if (!(CIN == 48 && a.post_out)) return -5;
+        const PwArgs pw{src, nullptr, a.post_w, a.post_w + mfma_packed_floats(48, 0, 96), nullptr, a.post_out, (long)N * a.H * a.W, (long)a.H * a.W, a.W};
+        return launch_pw_mfma(48, 0, 96, true, false, 0, pw, s, DT_F32);
     }
     return 0;
 }
@@ -974,7 +980,9 @@ int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArg
 {
     if (dtype != DT_F16 && cin == 24 && cexp == 136 && cout == 24 && res && stride == 1 && a.nblk > 1 && a.out_exp && !a.post_w &&
         mres_small_batch(N, a.H, a.W, 16, 20))
-        return dtype == DT_F16X3 ? launch_res4_unchained<x3_t>(a, N, s) : launch_res4_unchained<float>(a, N, s);
+        return dtype == DT_F16X3 ? launch_chain_unchained<24, 136, 8, 10, 3, 5, x3_t>(a, N, s) : launch_chain_unchained<24, 136, 8, 10, 3, 5, float>(a, N, s);
+    // (the stride-32 chain the same way -- 8x4 tiles, three workgroups per 8x10 frame, conv5_2 as a launch of its own behind it -- measures 64 -> 58 us
+    //  at batch 1 for six launches instead of one and no gain end to end: every workgroup stages the block's 94 KB weight stream; not kept)
     if (cin == 16 && cexp == 96 && cout == 16 && res && stride == 1 && a.nblk <= 1 && mres_small_batch(N, a.H, a.W, 16, 20))
         return dtype == DT_F16 ? launch_mres_t<16, 96, 16, true, 1, 8, 10, 8, half_t>(a, N, s)
              : dtype == DT_F16X3 ? launch_mres_t<16, 96, 16, true, 1, 8, 10, 8, x3_t>(a, N, s) : launch_mres_t<16, 96, 16, true, 1, 8, 10, 8, float>(a, N, s);
