@@ -17,7 +17,7 @@ if dtype != "f32":
     m.precision = dtype
 H, Wd = io["input_shape"][:2]
 cols = {}
-for n in (1, 2, 4, 8, 16, 256):
+for n in [int(v) for v in os.environ.get("YF_SMALL_NS", "1,2,4,8,16,256").split(",")]:
     x = ((torch.randint(0, 256, (n, 1, H, Wd), generator=torch.Generator().manual_seed(0)).float() - 128.0) / 255.0).to(dev)
     m.profile(x, reps=2, launch_repeats=4)
     cols[n] = m.profile(x, reps=5, launch_repeats=4)
@@ -28,7 +28,7 @@ for n in (1, 2, 4, 8, 16, 256):
         for _ in range(20): m(x)
         t1.record(); torch.cuda.synchronize()
     cols[n].append(dict(name="model(x), eager, per call", ms=t0.elapsed_time(t1) / 20))
-names = [o["name"] for o in cols[1]]
+names = [o["name"] for o in cols[next(iter(cols))]]
 print("%-44s" % "launch (us)" + "".join("%9s" % ("N=%d" % n) for n in cols))
 for i, nm in enumerate(names):
     print("%-44s" % nm[:44] + "".join("%9.1f" % (cols[n][i]["ms"] * 1e3) for n in cols))

@@ -584,6 +584,16 @@ int launch_fused_block(int cin, int cexp, int cout, int stride, bool res, bool r
 #undef YF_STEM_C0
         return -1;
     }
+    // Small batches (round 5): the res2 blocks (stride 4: 80x64 pixels per frame of the 320x256 net) on 16x16 tiles instead of 32x16 when the
+    // larger tiling would leave more than half of the CUs idle -- one output pixel per lane instead of two; a pixel's arithmetic is the same.
+    if (cin == 8 && cexp == 32 && cout == 8 && stride == 1 && res && !relu_out && !pre) {
+        const int n_cu = device_cu_count(current_device());
+        const long big = (long)N * ((a.Ho + 16 * YF_RES2_BH - 1) / (16 * YF_RES2_BH)) * ((a.Wo + 16 * YF_RES2_BW - 1) / (16 * YF_RES2_BW));
+        static const bool off = getenv("YF_MRES_SMALL_OFF") != nullptr;
+        if (!off && n_cu > 0 && 2 * big <= n_cu)
+            return dtype == DT_F16 ? launch_fb_t<8, 32, 8, 1, true, false, false, 16, 16, 1, 1, 8, 8, 1, false, half_t>(a, N, s)
+                                   : launch_fb_t<8, 32, 8, 1, true, false, false, 16, 16, 1, 1, 8, 8, 1, false, float>(a, N, s);
+    }
 #define FB(ci, ce, co, st, rs, ro, pr, tyb, txb, bh, bw, ec, cg, pe, xl)                                          \
     if (cin == ci && cexp == ce && cout == co && stride == st && res == rs && relu_out == ro && pre == pr)         \
         return dtype == DT_F16 ? launch_fb_t<ci, ce, co, st, rs, ro, pr, tyb, txb, bh, bw, ec, cg, pe, xl, half_t>(a, N, s)   \

@@ -983,6 +983,9 @@ int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArg
         return dtype == DT_F16X3 ? launch_chain_unchained<24, 136, 8, 10, 3, 5, x3_t>(a, N, s) : launch_chain_unchained<24, 136, 8, 10, 3, 5, float>(a, N, s);
     // (the stride-32 chain the same way -- 8x4 tiles, three workgroups per 8x10 frame, conv5_2 as a launch of its own behind it -- measures 64 -> 58 us
     //  at batch 1 for six launches instead of one and no gain end to end: every workgroup stages the block's 94 KB weight stream; not kept)
+    if (cin == 24 && cexp == 136 && cout == 48 && !res && stride == 2 && mres_small_batch(N, a.H / 2, a.W / 2, 8, 10))   // conv4_2 triple: 8x4 output tiles
+        return dtype == DT_F16 ? launch_mres_t<24, 136, 48, false, 2, 8, 4, 8, half_t>(a, N, s)
+             : dtype == DT_F16X3 ? launch_mres_t<24, 136, 48, false, 2, 8, 4, 8, x3_t>(a, N, s) : launch_mres_t<24, 136, 48, false, 2, 8, 4, 8, float>(a, N, s);
     if (cin == 16 && cexp == 96 && cout == 16 && res && stride == 1 && a.nblk <= 1 && mres_small_batch(N, a.H, a.W, 16, 20))
         return dtype == DT_F16 ? launch_mres_t<16, 96, 16, true, 1, 8, 10, 8, half_t>(a, N, s)
              : dtype == DT_F16X3 ? launch_mres_t<16, 96, 16, true, 1, 8, 10, 8, x3_t>(a, N, s) : launch_mres_t<16, 96, 16, true, 1, 8, 10, 8, float>(a, N, s);
