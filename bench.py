@@ -157,7 +157,10 @@ def live_pmc(res, batch, dtype, frames, kmax, with_issue=False):
                 return {}, {}, "rocprofv3 --pmc %s child failed (rc %d): %s" % (counters[0], rc, tail.replace("\n", " | "))
             with open(os.path.join(work, "ops.json")) as f:
                 ops = json.load(f)
-            n = len(ops)
+            # kernel dispatches per launch: 1, except a residual chain issued block by block at small batches (yf_op_dispatches)
+            disp = [int(o.get("dispatches", 1)) for o in ops]
+            first = [sum(disp[:i]) for i in range(len(ops))]
+            n = sum(disp)
             by = {}
             with open(path) as f:   # (kernels instantiated on _Float16 come out mangled: the demangler does not know DF16_)
                 for x in csv.DictReader(f):
@@ -169,7 +172,7 @@ def live_pmc(res, batch, dtype, frames, kmax, with_issue=False):
                 return {}, {}, "PMC rows (%d) do not divide into forward passes of %d launches" % (len(ids), n)
             np_ = len(ids) // n
             for c in counters:
-                vals[c] = [sum(by[ids[q * n + i]].get(c, 0.0) for q in range(np_)) / np_ for i in range(n)]
+                vals[c] = [sum(by[ids[q * n + first[i] + d]].get(c, 0.0) for q in range(np_) for d in range(disp[i])) / np_ for i in range(len(ops))]
         traffic, issue = {}, {}
         for i, o in enumerate(ops):
             traffic[o["name"]] = traffic.get(o["name"], 0.0) + vals["FETCH_SIZE"][i] * 1024 * 2 + vals["WRITE_SIZE"][i] * 1024
@@ -974,7 +977,7 @@ def main():
         if args.dump_ops:
             with open(args.dump_ops, "w") as f:
                 json.dump([{"name": o["name"], "ms": o["ms"], "algorithmic_bytes": o["algorithmic_bytes"], "mfma_flops": o["mfma_flops"],
-                            "valu_flops": o["valu_flops"]} for o in ops], f)
+                            "valu_flops": o["valu_flops"], "dispatches": o.get("dispatches", 1)} for o in ops], f)
         chain_ms = sum(o["ms"] for o in ops)
         # measured HBM bytes per launch (PMC passes of tools/refresh_profiles.sh), valid for this build and this workload only
         traffic, traffic_note, traffic_source = {}, None, None

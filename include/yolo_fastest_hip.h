@@ -307,6 +307,9 @@ int yf_op_info_ex(yf_handle h, int op, char *name, int name_len, double *algorit
 /* Arithmetic the kernel of launch `op` runs in: 0 fp32, 1 fp16 storage + fp16 MFMA, 2 fp32 storage + split-operand fp16 MFMA (a
  * dtype-2 engine runs the launches that have no split-operand kernel in exact fp32: same storage, same accuracy class). */
 int yf_op_dtype(yf_handle h, int op, int *kernel_dtype);
+/* Kernel dispatches launch `op` issues at batch N: 1, except a chained residual launch at small batches, which is issued block by block
+ * (DESIGN.md section 4 "Small batches").  Counter tools that match rocprofv3's dispatch rows to launches by order need it. */
+int yf_op_dispatches(yf_handle h, int op, int N, int *dispatches);
 /* One forward pass (whole batch in one pass) with a HIP event recorded on `stream` around every launch; blocks until
  * the pass is done and returns each launch's duration in ms in op_ms[yf_num_launches]. */
 int yf_profile_forward(yf_handle h, const float *d_x, int N, void *d_workspace, size_t workspace_bytes, void *stream,

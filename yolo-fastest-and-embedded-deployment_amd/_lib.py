@@ -111,6 +111,7 @@ _SIGS = {
     "yf_cv_preprocess_u8": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "yf_forward_bgr_u8": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                      _c.c_size_t, _c.c_void_p]),
+    "yf_op_dispatches": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.POINTER(_c.c_int)]),
     "yf_profile_head_offsets": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_size_t)]),
 }
 EXPORTS = tuple(_SIGS)

@@ -1445,6 +1445,19 @@ int yf_op_dtype(yf_handle h, int op, int* kernel_dtype)
     return YF_OK;
 }
 
+int yf_op_dispatches(yf_handle h, int op, int N, int* dispatches)
+{
+    if (!h || !dispatches || N <= 0 || op < 0 || op >= (int)h->plan().ops.size()) return fail(YF_E_INVALID, "yf_op_dispatches: bad argument");
+    const Op& o = h->plan().ops[op];
+    *dispatches = 1;
+    if (o.type == OP_MRES) {
+        const LayerSpec &LE = h->layers[o.l_exp], &LP = h->layers[o.l_proj];
+        const Tensor& ti = h->plan().tensors[o.in1];
+        *dispatches = yf::mres_dispatches(LE.cin, LE.cout, LP.cout, o.res >= 0, h->layers[o.l_dw].stride, o.nblk, o.out2 >= 0, o.l_post >= 0, ti.H, ti.W, N, o.kdt);
+    }
+    return YF_OK;
+}
+
 static int profile_forward(yf_handle h, const float* d_x, const uint8_t* d_u8, int down2, int N, void* ws, size_t ws_bytes, void* stream, float* op_ms,
                            int n_ops);
 int yf_profile_forward(yf_handle h, const float* d_x, int N, void* ws, size_t ws_bytes, void* stream, float* op_ms, int n_ops)

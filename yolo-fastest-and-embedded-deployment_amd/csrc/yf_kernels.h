@@ -241,6 +241,7 @@ struct MresArgs {
     float* post_out;      // NHWC [N,H,W,POSTN]
 };
 int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArgs& a, int N, hipStream_t s, int dtype = DT_F32);
+int mres_dispatches(int cin, int cexp, int cout, bool res, int stride, int nblk, bool has_scratch, bool has_post, int H, int W, int N, int dtype);
 bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride = 1, bool relu_out = false, int dtype = DT_F32);
 bool mres_can_chain(int cin, int cexp, int cout, int H, int W);  // relu_out: ReLU after the projection
 bool mres_has_post(int cin, int cexp, int cout, int postn);      // a trailing 1x1 conv (+ReLU) of postn channels can ride in the launch

@@ -943,8 +943,8 @@ size_t mres_post_packed_floats(int cout, int postn) { return (size_t)mres_ksteps
 // Small batches (round 5): when the whole-frame / 16x20 tiling of a launch would leave more than half of the CUs idle, the same arithmetic
 // runs on 8x10 tiles -- four times the workgroups.  A residual CHAIN (tile == frame, one workgroup per frame for all its blocks) is then
 // issued block by block on those tiles: each block reads the previous one's result WITH its halo, so consecutive blocks go through HBM and
-// alternate between the chain's input tensor, a scratch tensor of the same shape (MresArgs::out_exp, from the engine's plan) and, last, the
-// output.  fp32 storage only (a block's result is the same fp32 value in LDS and in HBM: bitwise the chained launch; fp16 storage would
+// alternate between a scratch tensor of the same shape (MresArgs::out_exp, from the engine's plan) and the output tensor, the last block
+// writing the output; the chain's input is only read (the launch stays repeatable).  fp32 storage only (a block's result is the same fp32 value in LDS and in HBM: bitwise the chained launch; fp16 storage would
 // round between the blocks).  The launch count rises by nblk - 1; measured in DESIGN.md section 4 "Small batches".
 static bool mres_small_batch(int N, int H, int W, int th, int tw)
 {
@@ -957,23 +957,27 @@ static bool mres_small_batch(int N, int H, int W, int th, int tw)
 template <int CIN, int CEXP, int TH, int TW, int NWP, int NWC, typename T>
 static int launch_chain_unchained(const MresArgs& a, int N, hipStream_t s)
 {
-    float* const I = const_cast<float*>(a.in);     // the chain's input: read by nothing after the chain (the engine's plan), so it is scratch from block 2 on
-    float* const Tmp = a.out_exp;
+    // Block k writes the output tensor or the scratch tensor, alternating so that the LAST block writes the output; the chain's input is only
+    // ever read.  (A first version also used the input tensor as a buffer: the launch was then not repeatable -- yf_set_profile_repeats issues
+    // every op several times back to back -- and test_profile_with_repeated_launches_changes_nothing caught it.)
+    if (a.post_w || !a.out_exp || !a.out) return -5;
     const float* src = a.in;
     for (int k = 0; k < a.nblk; ++k) {
-        // a trailing 1x1 conv (conv5_2 behind res5_5) reads the last block's result from a scratch buffer; without one the last block writes the output
-        float* dst = (k == a.nblk - 1 && !a.post_w) ? a.out : (src == I ? Tmp : I);
+        float* dst = ((a.nblk - 1 - k) & 1) ? a.out_exp : a.out;
         MresArgs b = a;
         b.in = src; b.out = dst; b.wp = a.wp + (size_t)k * a.wstride; b.nblk = 1; b.wstride = 0; b.out_exp = nullptr; b.post_w = nullptr; b.post_out = nullptr;
         if (int rc = launch_mres_pc_t<CIN, CEXP, CIN, true, TH, TW, NWP, NWC, T>(b, N, s)) return rc;
         src = dst;
     }
-    if (a.post_w) {   // the pw GEMM's own fp32 fragments + bias (what the fused form evaluates on chip): pw_ws_kernel, the same bits
-        if (!(CIN == 48 && a.post_out)) return -5;
-        const PwArgs pw{src, nullptr, a.post_w, a.post_w + mfma_packed_floats(48, 0, 96), nullptr, a.post_out, (long)N * a.H * a.W, (long)a.H * a.W, a.W};
-        return launch_pw_mfma(48, 0, 96, true, false, 0, pw, s, DT_F32);
-    }
     return 0;
+}
+
+// kernel dispatches launch_mres() issues for this op at batch N (counter tools match dispatches to launches by order)
+int mres_dispatches(int cin, int cexp, int cout, bool res, int stride, int nblk, bool has_scratch, bool has_post, int H, int W, int N, int dtype)
+{
+    if (dtype != DT_F16 && cin == 24 && cexp == 136 && cout == 24 && res && stride == 1 && nblk > 1 && has_scratch && !has_post && mres_small_batch(N, H, W, 16, 20))
+        return nblk;
+    return 1;
 }
 
 int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArgs& a, int N, hipStream_t s, int dtype)

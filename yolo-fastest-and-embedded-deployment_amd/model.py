@@ -335,9 +335,10 @@ class YoloFastest(nn.Module):
             name = ctypes.create_string_buffer(512)
             b, fm, fv = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
             _lib.check(e.lib.yf_op_info_ex(e.handle, i, name, 512, ctypes.byref(b), ctypes.byref(fm), ctypes.byref(fv)))
-            kdt = ctypes.c_int()
+            kdt, nd = ctypes.c_int(), ctypes.c_int()
             _lib.check(e.lib.yf_op_dtype(e.handle, i, ctypes.byref(kdt)))
-            out.append(dict(name=name.value.decode(), ms=acc[i], algorithmic_bytes=b.value * N, flops=(fm.value + fv.value) * N,
+            _lib.check(e.lib.yf_op_dispatches(e.handle, i, N, ctypes.byref(nd)))
+            out.append(dict(name=name.value.decode(), ms=acc[i], dispatches=nd.value, algorithmic_bytes=b.value * N, flops=(fm.value + fv.value) * N,
                             mfma_flops=fm.value * N, valu_flops=fv.value * N, kernel_dtype=("f32", "f16", "f16x3")[kdt.value]))
         if return_heads:
             lo, so = ctypes.c_size_t(), ctypes.c_size_t()
