@@ -1316,7 +1316,7 @@ def test_profile_with_repeated_launches_changes_nothing(yf, golden, dev):
 
 @pytest.mark.parametrize("prec", ["f32", "f16x3", "f16"])
 @pytest.mark.parametrize("res", [256, 512])
-def test_small_batch_plan_is_bitwise_the_large_batch_plan(yf, golden, dev, res, prec):
+def test_small_batch_plan_against_the_large_batch_plan_and_the_goldens(yf, golden, dev, res, prec):
     """at N x tiles < #CU the per-frame deep-stage launches spread a frame over several workgroups (deconv5_1 +
     conv4_1_1: one M-tile per work item instead of five; the stride-16 head launches: 8x10 tiles instead of the 16x20 frame).  The
     arithmetic of a pixel does not depend on how pixels are grouped into workgroups: frames pushed through alone (N = 1), in twos and in
@@ -1337,6 +1337,24 @@ def test_small_batch_plan_is_bitwise_the_large_batch_plan(yf, golden, dev, res, 
         for n, picks in ((1, (0, 7, 19, 25)), (2, (0, 18, 30)), (8, (0, 12, 24))):
             for f0 in picks:
                 small = m(x[f0:f0 + n].contiguous())
-                assert torch.equal(small[0], big[0][f0:f0 + n]) and torch.equal(small[1], big[1][f0:f0 + n]), (res, prec, n, f0)
+                if res == 256 and prec == "f32":
+                    # the stride-32 chain of an fp32 engine on 320x256 frames splits a block's expanded channels over 14 workgroups at <= 9 frames
+                    # (mres_esplit_kernel): the same real numbers, another association of the 224-term sums -- two fp32 evaluations, within
+                    # the noise floor of this graph (the goldens below hold the path itself); detections identical
+                    for a_, b_ in zip(small, (big[0][f0:f0 + n], big[1][f0:f0 + n])):
+                        assert float((a_ - b_).abs().max()) <= 2e-4, (res, prec, n, f0, float((a_ - b_).abs().max()))
+                else:
+                    assert torch.equal(small[0], big[0][f0:f0 + n]) and torch.equal(small[1], big[1][f0:f0 + n]), (res, prec, n, f0)
     if prec != "f16":
         _check_heads(big[0][:20], big[1][:20], g["head_large"], g["head_small"], g["head_large_f64"], g["head_small_f64"], res == 256)
+        # ... and the small-batch launches themselves against the reference: the 20 golden frames four at a time, and one by one for the detections
+        with torch.no_grad():
+            four = [m(x[f0:f0 + 4].contiguous()) for f0 in range(0, 20, 4)]
+        _check_heads(torch.cat([h[0] for h in four]), torch.cat([h[1] for h in four]), g["head_large"], g["head_small"], g["head_large_f64"],
+                     g["head_small_f64"], res == 256)
+        post = yf.YOLO_post_process(io["conf_thre"], io["nms_thre"], io["num_anchors"], io["num_cls"], io["anchors"], io["input_shape"]).bind(m)
+        for f in (0, 5, 13, 19):
+            with torch.no_grad():
+                L = post.detect(m(x[f:f + 1].contiguous()), with_src=True)[0]
+            k = int(g["final_count"][f])
+            assert [e[:4] for e in L] == g["final_box"][f, :k].tolist() and [e[7] for e in L] == g["final_src"][f, :k].tolist(), (res, prec, f)

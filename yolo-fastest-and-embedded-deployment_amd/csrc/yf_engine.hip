@@ -113,6 +113,7 @@ struct yf_engine {
     size_t esz() const { return dtype == yf::DT_F16 ? 2 : 4; }
     float* d_weights = nullptr;
     float* d_wmfma = nullptr;         // MFMA B fragments of the GEMM-worthy pointwise layers (fused plan)
+    float* d_esplit = nullptr;        // scratch of the stride-32 chain's few-frames form (yf_mres_kernels.hip mres_esplit_kernel): partial sums + block inputs
     size_t n_floats = 0;
     // io_params of the blob (yolo_fastest.py:72-78): the graph is kBaseLayers with conv0's Cin and the two heads' Cout set from them
     int input_channel = 1, num_anchors = 3, num_cls = 3, num_out = 24;
@@ -644,6 +645,7 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                 yf::MresArgs a{ptr(o.in1), e->d_wmfma + o.mfma_off, ptr(o.out), ti.H, ti.W, 0, 0, o.out2 >= 0 ? ptr(o.out2) : nullptr,
                                o.nblk, o.wstride, nullptr, nullptr};
                 if (o.l_post >= 0) { a.post_w = e->d_wmfma + o.post_off; a.post_out = ptr(o.out); a.out = nullptr; }
+                a.esplit = e->d_esplit ? e->d_esplit + (size_t)lane_id * yf::mres_esplit_scratch_floats() : nullptr;   // one region per lane: lanes run concurrently
                 rc = yf::launch_mres(LE.cin, LE.cout, LP.cout, o.res >= 0, kLayers[o.l_dw].stride, a, n, s, o.kdt);
             } else if (o.type == OP_FUSED_BLOCK) {
                 const bool pre = o.l_pre >= 0;
@@ -954,6 +956,12 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
             }
         }
     }
+    if (dtype == yf::DT_F32 && H / 32 == 8 && W / 32 == 10) {   // the stride-32 chain's few-frames form keeps its partial sums here (4 MB per lane)
+        if (hipMalloc(&e->d_esplit, 4 * yf::mres_esplit_scratch_floats() * sizeof(float)) != hipSuccess) {   // x 4 lanes (yf_set_lanes' maximum)
+            (void)yf_destroy(e);
+            return fail(YF_E_HIP, "hipMalloc(esplit scratch) failed");
+        }
+    }
     for (int l = 0; l < 3; ++l) {
         if (hipStreamCreateWithFlags(&e->side[l], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_join[l], hipEventDisableTiming) != hipSuccess) {
@@ -1001,6 +1009,7 @@ int yf_destroy(yf_handle h)
         if (h->ev_l2b[l]) (void)hipEventDestroy(h->ev_l2b[l]);
     }
     for (auto& t : h->cvtab) { if (t.d_x) (void)hipFree(t.d_x); if (t.d_y) (void)hipFree(t.d_y); }
+    if (h->d_esplit) (void)hipFree(h->d_esplit);
     (void)hipFree(h->d_weights);
     (void)hipFree(h->d_wmfma);
     delete h;

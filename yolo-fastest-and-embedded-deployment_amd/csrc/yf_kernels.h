@@ -239,7 +239,9 @@ struct MresArgs {
     const float* post_w;  // optional (mres_has_post shapes): a 1x1 conv + ReLU applied to the last block's result on chip --
                           // mfma_pack_weights fragments followed by the bias; the block's own result is then NOT stored
     float* post_out;      // NHWC [N,H,W,POSTN]
+    float* esplit;        // optional: mres_esplit_scratch_floats() floats of engine-owned scratch (the stride-32 chain at a handful of frames)
 };
+size_t mres_esplit_scratch_floats();
 int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArgs& a, int N, hipStream_t s, int dtype = DT_F32);
 int mres_dispatches(int cin, int cexp, int cout, bool res, int stride, int nblk, bool has_scratch, bool has_post, int H, int W, int N, int dtype);
 bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride = 1, bool relu_out = false, int dtype = DT_F32);

@@ -940,6 +940,163 @@ static int launch_mres_any(const MresArgs& a, int N, hipStream_t s)
 bool mres_has_post(int cin, int cexp, int cout, int postn) { return cin == 48 && cexp == 224 && cout == 48 && postn == 96; }
 size_t mres_post_packed_floats(int cout, int postn) { return (size_t)mres_ksteps(cout) * (postn / 16) * 64 + postn; }
 
+// ------------------------------------------------------------------------------------------------
+// mres_esplit_kernel (round 5, batch-1 latency): the stride-32 residual chain res5_1 .. res5_5 (+ conv5_2) when only a few frames are in
+// flight.  One workgroup per frame runs a block at ~50 % of ONE CU's fp32 peak (12 us); a block can only get faster on several CUs, and
+// every block ends in a sum over ALL expanded channels.  Here the NCH = 14 chunks of 16 expanded channels of a block go to 14 workgroups
+// (expansion -> depthwise -> the projection's PARTIAL sum over those 16 channels), the partial sums go to HBM, and the kernel LAUNCH
+// BOUNDARY is the exchange: launch k first adds the 14 partial sums of block k - 1, in chunk order, + bias + the block's input (what
+// its input X_k is), then computes its own chunk of block k.  nblk + 1 launches of ~5 us instead of one of 64; no grid barrier, nothing
+// spins, every launch only reads what earlier launches wrote and writes the other half of two alternating buffers (repeatable).
+// The last launch forms the chain's result and applies the trailing 1x1 conv (conv5_2: n-tile g on workgroup g) or stores the result.
+// NOT the bits of the chained launch: a block's 224-term sums are associated per chunk here ((c0 + c1 + ... + c13) + bias + x) and in k
+// order there -- two fp32 evaluations of the same real number; the tests hold this path to the reference's goldens, not to the other plan.
+// fp32 engines, frames of exactly TH x TW pixels.
+// ------------------------------------------------------------------------------------------------
+struct EsplitArgs {
+    const float* in;      // chain input [N, TH*TW, CIN]
+    const float* wp;      // block streams, wstride apart
+    long wstride;
+    float* out;           // chain result (no trailing conv) or nullptr
+    const float* post_w;  // trailing conv: pw fragments + bias (or nullptr)
+    float* post_out;      // [N, TH*TW, POSTN]
+    float* xbuf;          // [2][N][TH*TW][CIN]
+    float* slab;          // [2][N][NCH][TH*TW][CIN]
+    int nblk, k, n_frames;
+};
+
+template <int CIN, int CEXP, int TH, int TW, int POSTN>
+__global__ void __launch_bounds__(((TH * TW) / 16) * 64) mres_esplit_kernel(EsplitArgs a)
+{
+    constexpr int COUT = CIN, NPX = TH * TW, MT = NPX / 16, NWAVE = MT, RH = TH + 2, RW = TW + 2, XP = CIN + 4;
+    constexpr int KS1 = mres_ksteps(CIN), NB1 = CIN / 16, NT2 = COUT / 16, NCH = (CEXP + 15) / 16;
+    constexpr int OFF_B1 = KS1 * 64, OFF_WD = OFF_B1 + 16, OFF_BD = OFF_WD + 144, OFF_W2 = OFF_BD + 16, CHUNK = OFF_W2 + 4 * NT2 * 64;
+    constexpr int EPL = ((RH * RW + 15) / 16) * 16 + YF_MRES_EPL_PAD;
+    static_assert(NPX % 16 == 0 && CIN % 16 == 0 && CHUNK == mres_chunk_floats(CIN, COUT, WM_F32), "shape / pack layout");
+    __shared__ __attribute__((aligned(16))) float X[NPX * XP];
+    __shared__ __attribute__((aligned(16))) float E[4 * EPL * 4];
+    const int n = blockIdx.x / NCH, g = blockIdx.x - n * NCH;
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int k = a.k;
+    constexpr int C4 = CIN / 4, NX4 = NPX * C4, NTHR = NWAVE * 64;
+    const long fr = (long)NPX * CIN;                       // floats per frame
+    // ---- X_k: the chain's input (k = 0) or x + (sum of the partial sums of block k - 1, chunk order) + bias ----
+    if (k == 0) {
+        for (int i = threadIdx.x; i < NX4; i += NTHR) {
+            const int px = i / C4, c4 = i - px * C4;
+            *reinterpret_cast<float4*>(&X[px * XP + c4 * 4]) = *reinterpret_cast<const float4*>(a.in + n * fr + (long)px * CIN + c4 * 4);
+        }
+    } else {
+        const float* xprev = (k == 1 ? a.in : a.xbuf + ((long)((k - 1) & 1) * a.n_frames) * fr) + n * fr;
+        const float* sl = a.slab + (((long)((k - 1) & 1) * a.n_frames + n) * NCH) * fr;
+        const float* b2 = a.wp + (long)(k - 1) * a.wstride + NCH * CHUNK;
+        float* xnext = a.xbuf + ((long)(k & 1) * a.n_frames + n) * fr;
+        for (int i = threadIdx.x; i < NX4; i += NTHR) {
+            const int px = i / C4, c4 = i - px * C4;
+            const long o = (long)px * CIN + c4 * 4;
+            float4 v = *reinterpret_cast<const float4*>(sl + o);
+#pragma unroll
+            for (int c = 1; c < NCH; ++c) {
+                const float4 t = *reinterpret_cast<const float4*>(sl + c * fr + o);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            const float4 bb = *reinterpret_cast<const float4*>(b2 + c4 * 4);
+            const float4 xx = *reinterpret_cast<const float4*>(xprev + o);
+            v.x = (v.x + bb.x) + xx.x; v.y = (v.y + bb.y) + xx.y; v.z = (v.z + bb.z) + xx.z; v.w = (v.w + bb.w) + xx.w;
+            *reinterpret_cast<float4*>(&X[px * XP + c4 * 4]) = v;
+            if (g == 0 && k < a.nblk) *reinterpret_cast<float4*>(xnext + o) = v;                    // the next launch's x
+            if (g == 0 && k == a.nblk && a.out) *reinterpret_cast<float4*>(a.out + n * fr + o) = v;   // the chain's result
+        }
+    }
+    for (int i = threadIdx.x; i < 4 * EPL; i += NTHR) reinterpret_cast<float4*>(E)[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // the halo ring stays zero
+    __syncthreads();
+    const int p = wave * 16 + r, py = p / TW, pxx = p - py * TW;          // this lane's pixel of the wave's M-tile (row-major)
+    const int rp = (py + 1) * RW + pxx + 1;                              // its record in E
+    if (k == a.nblk) {
+        // ---- the trailing 1x1 conv + ReLU on the chain's result: n-tile g, M-tile = wave; mres_post_conv's arithmetic and order ----
+        if constexpr (POSTN > 0) {
+            constexpr int NTP = POSTN / 16;
+            if (!a.post_w || g >= NTP) return;
+            const float* pw = a.post_w;
+            float4 av[NB1];
+#pragma unroll
+            for (int kb = 0; kb < NB1; ++kb) av[kb] = *reinterpret_cast<const float4*>(&X[p * XP + kb * 16 + 4 * q]);
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < NB1; ++kb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[((kb * 4 + j) * NTP + g) * 64 + lane], ((const float*)&av[kb])[j], acc, 0, 0, 0);
+            const float4 bias = *reinterpret_cast<const float4*>(pw + KS1 * NTP * 64 + g * 16 + 4 * q);
+            *reinterpret_cast<float4*>(a.post_out + ((long)n * NPX + p) * POSTN + g * 16 + 4 * q) =
+                make_float4(fmaxf(acc[0] + bias.x, 0.f), fmaxf(acc[1] + bias.y, 0.f), fmaxf(acc[2] + bias.z, 0.f), fmaxf(acc[3] + bias.w, 0.f));
+        }
+        return;
+    }
+    // ---- chunk g of block k: expansion of the wave's M-tile -> E -> depthwise -> partial projection ----
+    const float* wc = a.wp + (long)k * a.wstride + g * CHUNK;
+    float a1[KS1], w1f[KS1];
+#pragma unroll
+    for (int kb = 0; kb < NB1; ++kb) {
+        const float4 t = *reinterpret_cast<const float4*>(&X[p * XP + kb * 16 + 4 * q]);
+        a1[kb * 4 + 0] = t.x; a1[kb * 4 + 1] = t.y; a1[kb * 4 + 2] = t.z; a1[kb * 4 + 3] = t.w;
+    }
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) w1f[s] = wc[s * 64 + lane];
+    const float4 b1 = *reinterpret_cast<const float4*>(wc + OFF_B1 + 4 * q);
+    float4 wd[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wd[t] = *reinterpret_cast<const float4*>(wc + OFF_WD + t * 16 + 4 * q);
+    const float4 bd = *reinterpret_cast<const float4*>(wc + OFF_BD + 4 * q);
+    float w2f[4][NT2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) w2f[j][nt] = wc[OFF_W2 + (j * NT2 + nt) * 64 + lane];
+    f32x4 cf = f32x4{b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) cf = __builtin_amdgcn_mfma_f32_16x16x4f32(w1f[s], a1[s], cf, 0, 0, 0);
+    *reinterpret_cast<float4*>(E + (q * EPL + rp) * 4) = make_float4(fmaxf(cf[0], 0.f), fmaxf(cf[1], 0.f), fmaxf(cf[2], 0.f), fmaxf(cf[3], 0.f));
+    __syncthreads();
+    const float4* e = reinterpret_cast<const float4*>(E) + q * EPL + rp;
+    float d[4] = {bd.x, bd.y, bd.z, bd.w};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float4 v = e[(t / 3 - 1) * RW + (t % 3 - 1)];
+        d[0] = fmaf(v.x, wd[t].x, d[0]); d[1] = fmaf(v.y, wd[t].y, d[1]); d[2] = fmaf(v.z, wd[t].z, d[2]); d[3] = fmaf(v.w, wd[t].w, d[3]);
+    }
+    f32x4 acc[NT2];
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float dj = relu_bits(d[j]);
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[j][nt], dj, acc[nt], 0, 0, 0);
+    }
+    float* so = a.slab + ((((long)(k & 1) * a.n_frames + n) * NCH + g) * NPX + p) * CIN + 4 * q;
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) *reinterpret_cast<float4*>(so + nt * 16) = make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
+}
+
+enum { ESPLIT_MAX_FRAMES = 9 };   // N x 14 workgroups stay a small share of the chip; larger batches keep the chained launch
+size_t mres_esplit_scratch_floats() { return (size_t)ESPLIT_MAX_FRAMES * (2 + 2 * 14) * 80 * 48; }
+static bool mres_esplit_ok(const MresArgs& a, int N, int dtype)
+{
+    static const bool off = getenv("YF_MRES_SMALL_OFF") != nullptr || getenv("YF_MRES_ESPLIT_OFF") != nullptr;
+    return !off && dtype == DT_F32 && a.esplit && a.nblk > 1 && a.H == 8 && a.W == 10 && N <= ESPLIT_MAX_FRAMES;
+}
+static int launch_res5_esplit(const MresArgs& a, int N, hipStream_t s)
+{
+    EsplitArgs e{a.in, a.wp, a.wstride, a.post_w ? nullptr : a.out, a.post_w, a.post_out, a.esplit, a.esplit + (size_t)2 * N * 80 * 48, a.nblk, 0, N};
+    for (int k = 0; k <= a.nblk; ++k) {
+        e.k = k;
+        hipLaunchKernelGGL((mres_esplit_kernel<48, 224, 8, 10, 96>), dim3((unsigned)(N * 14)), dim3(5 * 64), 0, s, e);
+    }
+    return 0;
+}
+
 // Small batches (round 5): when the whole-frame / 16x20 tiling of a launch would leave more than half of the CUs idle, the same arithmetic
 // runs on 8x10 tiles -- four times the workgroups.  A residual CHAIN (tile == frame, one workgroup per frame for all its blocks) is then
 // issued block by block on those tiles: each block reads the previous one's result WITH its halo, so consecutive blocks go through HBM and
@@ -977,6 +1134,9 @@ int mres_dispatches(int cin, int cexp, int cout, bool res, int stride, int nblk,
 {
     if (dtype != DT_F16 && cin == 24 && cexp == 136 && cout == 24 && res && stride == 1 && nblk > 1 && has_scratch && !has_post && mres_small_batch(N, H, W, 16, 20))
         return nblk;
+    if (cin == 48 && cexp == 224 && cout == 48 && res && stride == 1 && nblk > 1 && has_scratch && dtype == DT_F32 && H == 8 && W == 10 && N <= ESPLIT_MAX_FRAMES &&
+        !getenv("YF_MRES_SMALL_OFF") && !getenv("YF_MRES_ESPLIT_OFF"))
+        return nblk + 1;
     return 1;
 }
 
@@ -985,6 +1145,7 @@ int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArg
     if (dtype != DT_F16 && cin == 24 && cexp == 136 && cout == 24 && res && stride == 1 && a.nblk > 1 && a.out_exp && !a.post_w &&
         mres_small_batch(N, a.H, a.W, 16, 20))
         return dtype == DT_F16X3 ? launch_chain_unchained<24, 136, 8, 10, 3, 5, x3_t>(a, N, s) : launch_chain_unchained<24, 136, 8, 10, 3, 5, float>(a, N, s);
+    if (cin == 48 && cexp == 224 && cout == 48 && res && stride == 1 && mres_esplit_ok(a, N, dtype)) return launch_res5_esplit(a, N, s);
     // (the stride-32 chain the same way -- 8x4 tiles, three workgroups per 8x10 frame, conv5_2 as a launch of its own behind it -- measures 64 -> 58 us
     //  at batch 1 for six launches instead of one and no gain end to end: every workgroup stages the block's 94 KB weight stream; not kept)
     if (cin == 24 && cexp == 136 && cout == 48 && !res && stride == 2 && mres_small_batch(N, a.H / 2, a.W / 2, 8, 10))   // conv4_2 triple: 8x4 output tiles
