@@ -803,48 +803,65 @@ def main():
         #     (single lane, small head in line: a graph without parallel branches)
         mb, pb = make(args.dtype, 1, 0)
         x1 = saved["x"][:1].contiguous()
-        tm, tp = [], []
-        with torch.no_grad():
-            for i in range(220):
-                torch.cuda.synchronize(dev)
-                t0 = time.perf_counter()
-                pred = mb(x1)
-                torch.cuda.synchronize(dev)
-                t1 = time.perf_counter()
-                pb.detect_raw(pred, kmax=args.kmax)
-                torch.cuda.synchronize(dev)
-                t2 = time.perf_counter()
-                if i >= 20:
-                    tm.append(1e3 * (t1 - t0)); tp.append(1e3 * (t2 - t1))
         med = lambda v: sorted(v)[len(v) // 2]
-        b1 = {"workload": "one 320x256 frame per call, model then post-process, host-synchronised after each (detect.py:146-171), 200 frames",
-              "eager": {"model_ms": round(med(tm), 4), "post_ms": round(med(tp), 4), "total_ms": round(med([a + b for a, b in zip(tm, tp)]), 4)}}
-        try:
+
+        def batch1_record():
+            tm, tp = [], []
             with torch.no_grad():
-                sg = torch.cuda.Stream()
-                sg.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(sg):
-                    pb.detect_raw_from_input(x1, kmax=args.kmax)
-                torch.cuda.current_stream().wait_stream(sg)
-                gph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gph):
-                    gout = pb.detect_raw_from_input(x1, kmax=args.kmax)
-                tg = []
                 for i in range(220):
                     torch.cuda.synchronize(dev)
                     t0 = time.perf_counter()
+                    pred = mb(x1)
+                    torch.cuda.synchronize(dev)
+                    t1 = time.perf_counter()
+                    pb.detect_raw(pred, kmax=args.kmax)
+                    torch.cuda.synchronize(dev)
+                    t2 = time.perf_counter()
+                    if i >= 20:
+                        tm.append(1e3 * (t1 - t0)); tp.append(1e3 * (t2 - t1))
+            rec = {"eager": {"model_ms": round(med(tm), 4), "post_ms": round(med(tp), 4), "total_ms": round(med([a + b for a, b in zip(tm, tp)]), 4)}}
+            try:
+                with torch.no_grad():
+                    sg = torch.cuda.Stream()
+                    sg.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(sg):
+                        pb.detect_raw_from_input(x1, kmax=args.kmax)
+                    torch.cuda.current_stream().wait_stream(sg)
+                    gph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gph):
+                        gout = pb.detect_raw_from_input(x1, kmax=args.kmax)
+                    tg = []
+                    for i in range(220):
+                        torch.cuda.synchronize(dev)
+                        t0 = time.perf_counter()
+                        gph.replay()
+                        torch.cuda.synchronize(dev)
+                        if i >= 20:
+                            tg.append(1e3 * (time.perf_counter() - t0))
+                    ref1 = pb.detect_raw_from_input(x1, kmax=args.kmax)
                     gph.replay()
                     torch.cuda.synchronize(dev)
-                    if i >= 20:
-                        tg.append(1e3 * (time.perf_counter() - t0))
-                ref1 = pb.detect_raw_from_input(x1, kmax=args.kmax)
-                gph.replay()
-                torch.cuda.synchronize(dev)
-                b1["graph_replay"] = {"total_ms": round(med(tg), 4), "what": "yf_detect (model + decode + NMS) captured once, one hipGraphLaunch per frame",
-                                      "identical_to_eager": bool(torch.equal(gout["counts"], ref1["counts"]) and torch.equal(gout["head_large"], ref1["head_large"]))}
-                del gph
-        except Exception as ex:     # evidence, not product
-            b1["graph_replay"] = {"error": repr(ex)[:200]}
+                    rec["graph_replay"] = {"total_ms": round(med(tg), 4), "what": "yf_detect (model + decode + NMS) captured once, one hipGraphLaunch per frame",
+                                           "identical_to_eager": bool(torch.equal(gout["counts"], ref1["counts"]) and torch.equal(gout["head_large"], ref1["head_large"]))}
+                    del gph
+            except Exception as ex:     # evidence, not product
+                rec["graph_replay"] = {"error": repr(ex)[:200]}
+            return rec
+
+        # default mode (yf_set_split_sums 1: at <= 9 frames the stride-32 chain and the small head split their channel sums over several
+        # workgroups -- DESIGN.md section 4 "Small batches"), then the mode in which a frame's bits never depend on the batch size
+        b1 = {"workload": "one 320x256 frame per call, model then post-process, host-synchronised after each (detect.py:146-171), 200 frames"}
+        b1.update(batch1_record())
+        with torch.no_grad():
+            h_split = [t.clone() for t in mb(x1)]
+            mb.split_sums = False
+            h_stable = [t.clone() for t in mb(x1)]
+            h_big = model(saved["x"])
+        b1["bit_stable_mode"] = batch1_record()
+        b1["bit_stable_mode"]["what"] = "yf_set_split_sums(0): the same frame's logits are the bits of the batch-256 pass"
+        b1["bit_stable_mode"]["bits_of_the_batch_256_pass"] = bool(torch.equal(h_stable[0], h_big[0][:1]) and torch.equal(h_stable[1], h_big[1][:1]))
+        b1["max_abs_logit_diff_default_vs_bit_stable"] = round(max(float((h_split[0] - h_stable[0]).abs().max()), float((h_split[1] - h_stable[1]).abs().max())), 7)
+        mb.split_sums = True
         extras["batch1"] = b1
         del mb, pb
         # (d) the N > 1 code path at one rank: a 1-rank RCCL group and the all-gather of every step's packed records -- its frames/s

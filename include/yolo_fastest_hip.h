@@ -335,6 +335,11 @@ int yf_profile_head_offsets(yf_handle h, int N, size_t *large_off, size_t *small
                                                       profiled (repeated-launch) pass itself to yf_forward's bits */
 int yf_num_launches(yf_handle h, int *out);       /* kernel launches one yf_forward issues            */
 int yf_set_chunk(yf_handle h, int frames);        /* frames per pass of the layer chain (0 = whole batch) */
+int yf_set_split_sums(yf_handle h, int on);       /* 1 (default): at a handful of frames (<= 9, fp32 engines, 320x256 nets) the stride-32 residual chain and the
+                                                      small head split their channel sums over several workgroups and add the partial sums in a fixed
+                                                      chunk order (batch-1 latency: DESIGN.md section 4 "Small batches") -- the same numbers in another
+                                                      association than the large-batch launches, so a frame's last bits then depend on how many frames
+                                                      travel with it.  0: never; every launch keeps one association at every batch size. */
 int yf_set_lanes(yf_handle h, int lanes);          /* 1..4: chunks of the batch (yf_set_chunk) run on this many concurrent
                                                      streams, forked from / joined to the caller's stream by events    */
 int yf_set_branches(yf_handle h, int on);         /* 1 (default): the small head's launches (conv5_3 .. head_5) run on a side stream of

@@ -105,11 +105,15 @@ def test_fusion_levels_agree_bitwise_for_other_io_params(yf, dev, golden, tag):
     m, _, _ = _model(yf, dev, golden, tag)
     x = _x(tag, dev)
     out = {}
-    for f in (1, 2):
-        m.fusion = f
-        with torch.no_grad():
-            out[f] = [t.clone() for t in m(x)]
-    m.fusion = yf.model.DEFAULT_FUSION
+    m.split_sums = False     # the mode that promises one association at every batch size and fusion level (yf_set_split_sums; two frames here)
+    try:
+        for f in (1, 2):
+            m.fusion = f
+            with torch.no_grad():
+                out[f] = [t.clone() for t in m(x)]
+    finally:
+        m.fusion = yf.model.DEFAULT_FUSION
+        m.split_sums = True
     assert torch.equal(out[1][0], out[2][0]) and torch.equal(out[1][1], out[2][1])
 
 

@@ -113,7 +113,9 @@ struct yf_engine {
     size_t esz() const { return dtype == yf::DT_F16 ? 2 : 4; }
     float* d_weights = nullptr;
     float* d_wmfma = nullptr;         // MFMA B fragments of the GEMM-worthy pointwise layers (fused plan)
-    float* d_esplit = nullptr;        // scratch of the stride-32 chain's few-frames form (yf_mres_kernels.hip mres_esplit_kernel): partial sums + block inputs
+    int split_sums = 1;               // yf_set_split_sums: 0 = never re-associate a sum by batch size (a frame's bits do not depend on how many frames travel with it)
+    float* d_esplit = nullptr;        // scratch of the few-frames forms of the stride-32 chain and the small head (mres_esplit_kernel, mdw2_esplit_kernel): partial sums
+    static size_t esplit_lane_floats() { return yf::mres_esplit_scratch_floats() + yf::mdw2_esplit_scratch_floats(); }
     size_t n_floats = 0;
     // io_params of the blob (yolo_fastest.py:72-78): the graph is kBaseLayers with conv0's Cin and the two heads' Cout set from them
     int input_channel = 1, num_anchors = 3, num_cls = 3, num_out = 24;
@@ -636,7 +638,8 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
             if (o.type == OP_DCAT) {
                 rc = yf::launch_dcat(ptr(o.in1), ptr(o.in2), e->d_wmfma + o.mfma_off, e->d_wmfma + o.mfma_off2, ptr(o.out), ti.H, ti.W, n, s, o.kdt);
             } else if (o.type == OP_MDW2) {
-                rc = yf::launch_mdw2(ptr(o.in1), e->d_wmfma + o.mfma_off, e->d_wmfma + o.mfma_off2, ptr(o.out), ti.H, ti.W, e->num_out, n, s, o.kdt);
+                rc = yf::launch_mdw2(ptr(o.in1), e->d_wmfma + o.mfma_off, e->d_wmfma + o.mfma_off2, ptr(o.out), ti.H, ti.W, e->num_out, n, s, o.kdt,
+                                     (e->d_esplit && e->split_sums) ? e->d_esplit + (size_t)lane_id * e->esplit_lane_floats() + yf::mres_esplit_scratch_floats() : nullptr);
             } else if (o.type == OP_MDW) {
                 yf::MdwArgs a{ptr(o.in1), e->d_wmfma + o.mfma_off, ptr(o.out), ti.H, ti.W, 0, 0};
                 rc = yf::launch_mdw(ti.C, kLayers[o.l_proj].cout, o.l_head >= 0 ? e->num_out : 0, a, n, s, o.kdt);
@@ -645,7 +648,7 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                 yf::MresArgs a{ptr(o.in1), e->d_wmfma + o.mfma_off, ptr(o.out), ti.H, ti.W, 0, 0, o.out2 >= 0 ? ptr(o.out2) : nullptr,
                                o.nblk, o.wstride, nullptr, nullptr};
                 if (o.l_post >= 0) { a.post_w = e->d_wmfma + o.post_off; a.post_out = ptr(o.out); a.out = nullptr; }
-                a.esplit = e->d_esplit ? e->d_esplit + (size_t)lane_id * yf::mres_esplit_scratch_floats() : nullptr;   // one region per lane: lanes run concurrently
+                a.esplit = (e->d_esplit && e->split_sums) ? e->d_esplit + (size_t)lane_id * e->esplit_lane_floats() : nullptr;   // one region per lane: lanes run concurrently
                 rc = yf::launch_mres(LE.cin, LE.cout, LP.cout, o.res >= 0, kLayers[o.l_dw].stride, a, n, s, o.kdt);
             } else if (o.type == OP_FUSED_BLOCK) {
                 const bool pre = o.l_pre >= 0;
@@ -956,8 +959,8 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
             }
         }
     }
-    if (dtype == yf::DT_F32 && H / 32 == 8 && W / 32 == 10) {   // the stride-32 chain's few-frames form keeps its partial sums here (4 MB per lane)
-        if (hipMalloc(&e->d_esplit, 4 * yf::mres_esplit_scratch_floats() * sizeof(float)) != hipSuccess) {   // x 4 lanes (yf_set_lanes' maximum)
+    if (dtype == yf::DT_F32 && H / 32 == 8 && W / 32 == 10) {   // the stride-32 chain's few-frames form and the small head's keep their partial sums here (9 MB per lane)
+        if (hipMalloc(&e->d_esplit, 4 * e->esplit_lane_floats() * sizeof(float)) != hipSuccess) {   // x 4 lanes (yf_set_lanes' maximum)
             (void)yf_destroy(e);
             return fail(YF_E_HIP, "hipMalloc(esplit scratch) failed");
         }
@@ -1462,7 +1465,11 @@ int yf_op_dispatches(yf_handle h, int op, int N, int* dispatches)
     if (o.type == OP_MRES) {
         const LayerSpec &LE = h->layers[o.l_exp], &LP = h->layers[o.l_proj];
         const Tensor& ti = h->plan().tensors[o.in1];
-        *dispatches = yf::mres_dispatches(LE.cin, LE.cout, LP.cout, o.res >= 0, h->layers[o.l_dw].stride, o.nblk, o.out2 >= 0, o.l_post >= 0, ti.H, ti.W, N, o.kdt);
+        *dispatches = yf::mres_dispatches(LE.cin, LE.cout, LP.cout, o.res >= 0, h->layers[o.l_dw].stride, o.nblk, o.out2 >= 0, o.l_post >= 0, ti.H, ti.W, N, o.kdt,
+                                          h->d_esplit && h->split_sums);
+    } else if (o.type == OP_MDW2) {
+        const Tensor& ti = h->plan().tensors[o.in1];
+        if (yf::mdw2_esplit_ok(ti.H, ti.W, h->num_out, N, o.kdt, h->split_sums ? h->d_esplit : nullptr)) *dispatches = 3;
     }
     return YF_OK;
 }
@@ -1542,6 +1549,13 @@ int yf_set_branches(yf_handle h, int on)
 {
     if (!h || on < 0 || on > 1) return fail(YF_E_INVALID, "branches must be 0 or 1");
     h->branches = on;
+    return YF_OK;
+}
+
+int yf_set_split_sums(yf_handle h, int on)
+{
+    if (!h || on < 0 || on > 1) return fail(YF_E_INVALID, "split_sums must be 0 or 1");
+    h->split_sums = on;
     return YF_OK;
 }
 

@@ -834,6 +834,9 @@ int launch_k19m(K19Args a, int N, hipStream_t s, int dtype)
         }();
         if (nw < 0) return -1;
         const long items = (long)N * a.Ho * ((a.Wo + 15) / 16);
+        // small batches: the 8-wave form (conv1_9's fragments in registers, a third of the LDS prologue) -- 11.6 -> 8.3 us at batch 1, 12.4 -> 9.0 at
+        // 4, 20.8 -> 18.4 at 16 (tools/small_batch_ops.py); unless the developer switch asks for a form
+        if (!getenv("YF_K19R_NW") && items <= 64L * n_cu) return launch_k19r_t<8, false>(a, items, n_cu, dev, s);
         return nw == 8 ? launch_k19r_t<8, false>(a, items, n_cu, dev, s) : nw == 16 ? launch_k19r_t<16, true>(a, items, n_cu, dev, s)
                        : nw == 1012 ? launch_k19r_t<12, true>(a, items, n_cu, dev, s) : launch_k19r_t<12, false>(a, items, n_cu, dev, s);
     }

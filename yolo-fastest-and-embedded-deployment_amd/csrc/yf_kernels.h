@@ -243,7 +243,7 @@ struct MresArgs {
 };
 size_t mres_esplit_scratch_floats();
 int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArgs& a, int N, hipStream_t s, int dtype = DT_F32);
-int mres_dispatches(int cin, int cexp, int cout, bool res, int stride, int nblk, bool has_scratch, bool has_post, int H, int W, int N, int dtype);
+int mres_dispatches(int cin, int cexp, int cout, bool res, int stride, int nblk, bool has_scratch, bool has_post, int H, int W, int N, int dtype, bool esplit);
 bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride = 1, bool relu_out = false, int dtype = DT_F32);
 bool mres_can_chain(int cin, int cexp, int cout, int H, int W);  // relu_out: ReLU after the projection
 bool mres_has_post(int cin, int cexp, int cout, int postn);      // a trailing 1x1 conv (+ReLU) of postn channels can ride in the launch
@@ -264,7 +264,10 @@ int launch_mdw(int c, int n, int headn, const MdwArgs& a, int Nf, hipStream_t s,
 bool mdw_has_kernel(int c, int n, int headn);
 // the small head's two pairs as ONE launch (frames that fit one tile): stage 1 (c1 -> n1, no head) feeds stage 2 (n1 -> n2 -> head) in LDS
 bool mdw2_can_chain(int c1, int n1, int n2, int headn, int H, int W);
-int launch_mdw2(const float* in, const float* wp1, const float* wp2, float* out_nchw, int H, int W, int headn, int Nf, hipStream_t s, int dtype = DT_F32);
+int launch_mdw2(const float* in, const float* wp1, const float* wp2, float* out_nchw, int H, int W, int headn, int Nf, hipStream_t s, int dtype = DT_F32,
+                float* esplit_scratch = nullptr);   // scratch: mdw2_esplit_scratch_floats() floats (a handful of frames: three launches over 6 / 8 / 1 workgroups per frame)
+size_t mdw2_esplit_scratch_floats();
+bool mdw2_esplit_ok(int H, int W, int headn, int Nf, int dtype, const float* scratch);
 size_t mdw_packed_floats(int c, int n, int headn, int wmode = WM_F32);
 void mdw_pack_weights(const float* wd, const float* bd, const float* w, const float* b, const float* hw, const float* hb, int c,
                       int n, int headn, float* out, int wmode = WM_F32);

@@ -727,8 +727,139 @@ bool mdw2_can_chain(int c1, int n1, int n2, int headn, int H, int W)
     return c1 == 96 && n1 == 128 && n2 == 128 && headn >= 1 && headn <= 32 && H <= 8 && W <= 10;
 }
 
-int launch_mdw2(const float* in, const float* wp1, const float* wp2, float* out, int H, int W, int headn, int Nf, hipStream_t s, int dtype)
+// ------------------------------------------------------------------------------------------------
+// mdw2_esplit_kernel (round 5, batch-1 latency): the small head -- conv5_3 (dw5x5) -> conv5_4 (1x1) -> conv5_5 (dw5x5) -> conv5_6 (1x1) ->
+// head_5 (yolo_fastest.py:127-138) -- when only a few 8x10 frames are in flight.  One workgroup per frame takes 33 us on ONE CU.  Both
+// dw -> 1x1 stages are sums over 16-channel chunks of their input (6 and 8 of them), so each chunk goes to its own workgroup, the
+// PARTIAL 1x1 results go to HBM and the launch boundary is the exchange (yf_mres_kernels.hip mres_esplit_kernel, same scheme):
+//   phase 0: chunk c of stage 1 (dw5x5 of 16 of conv5_2's channels + ReLU, partial conv5_4)                 N x 6 workgroups
+//   phase 1: channels 16c .. 16c+15 of conv5_4 = sum of the six partials + bias (zero outside the frame: conv5_5's padding), dw5x5 + ReLU,
+//            partial conv5_6                                                                               N x 8 workgroups
+//   phase 2: conv5_6 = sum of the eight partials + bias, head conv chained through the accumulator layout, logits NCHW         N x 5 workgroups of one wave
+// Not the bits of mdw2_kernel (its 1x1 sums run chunk after chunk in one accumulator): the same numbers in another association.
+// fp32 engines, heads of up to 32 channels, frames of exactly 8x10.
+// ------------------------------------------------------------------------------------------------
+struct Mdw2EsplitArgs {
+    const float* in;    // conv5_2, NHWC [N, 80, 96]
+    const float* wp1;   // stage 1 stream (mdw_pack_weights: 6 chunks, then conv5_4's bias)
+    const float* wp2;   // stage 2 stream (8 chunks, conv5_6's bias, head fragments, head bias)
+    float* out;         // logits NCHW [N, headn, 8, 10]
+    float* slab1;       // [N][6][80][128]
+    float* slab2;       // [N][8][80][128]
+    int headn, phase;
+};
+
+__global__ void __launch_bounds__(320) mdw2_esplit_kernel(Mdw2EsplitArgs a)
 {
+    constexpr int TH = 8, TW = 10, NPX = 80, C1 = 96, N1 = 128, N2 = 128, NCH1 = C1 / 16, NCH2 = N1 / 16, NT = 8;
+    constexpr int RW = TW + 4, EPL = (((TH + 4) * RW + 15) / 16) * 16, CH = mdw_chunk_floats(128, WM_F32);
+    static_assert(CH == 400 + 16 + 4 * NT * 64, "chunk layout");
+    __shared__ __attribute__((aligned(16))) float E[4 * EPL * 4];
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    // phase 2 runs one wave per workgroup (a frame's five M-tiles on five CUs: each wave pulls 64 KB of partial sums through its CU's L2 port)
+    const int wave = a.phase == 2 ? (int)(blockIdx.x % 5) : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int p = wave * 16 + r, py = p / TW, px = p - py * TW, rp = (py + 2) * RW + px + 2;
+    if (a.phase == 2) {
+        // ---- conv5_6 (+ bias) of this lane's pixel, 16 channels at a time, straight into the head conv's k-steps ----
+        const int n = blockIdx.x / 5;
+        const float* sl = a.slab2 + (long)n * NCH2 * NPX * N2 + (long)p * N2 + 4 * q;
+        const float* bp = a.wp2 + NCH2 * CH;
+        const float* hf = bp + N2;                                   // head fragments [(s)(2 tiles)(lane)]
+        f32x4 hacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 2
+        for (int kb = 0; kb < N2 / 16; ++kb) {
+            float4 y = *reinterpret_cast<const float4*>(sl + kb * 16);
+#pragma unroll
+            for (int c = 1; c < NCH2; ++c) {
+                const float4 t = *reinterpret_cast<const float4*>(sl + (long)c * NPX * N2 + kb * 16);
+                y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+            }
+            const float4 b = *reinterpret_cast<const float4*>(bp + kb * 16 + 4 * q);
+            const float yv[4] = {y.x + b.x, y.y + b.y, y.z + b.z, y.w + b.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ht = 0; ht < 2; ++ht)
+                    hacc[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(hf[((kb * 4 + j) * 2 + ht) * 64 + lane], yv[j], hacc[ht], 0, 0, 0);
+        }
+        const float* hb = hf + (N2 / 4) * 2 * 64;
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ch = ht * 16 + 4 * q + i;
+                if (ch < a.headn) a.out[(((long)n * a.headn + ch) * TH + py) * TW + px] = hacc[ht][i] + hb[ch];
+            }
+        return;
+    }
+    const int nch = a.phase == 0 ? NCH1 : NCH2;
+    const int n = blockIdx.x / nch, c = blockIdx.x - n * nch;
+    for (int i = threadIdx.x; i < 4 * EPL; i += 320) reinterpret_cast<float4*>(E)[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // the 2-pixel ring: padding
+    __syncthreads();
+    // ---- this workgroup's 16 input channels of the frame -> E (one record per lane: pixel p, channels 16c + 4q .. +3) ----
+    float4 v;
+    if (a.phase == 0) {
+        v = *reinterpret_cast<const float4*>(a.in + ((long)n * NPX + p) * C1 + 16 * c + 4 * q);
+    } else {
+        const float* sl = a.slab1 + (long)n * NCH1 * NPX * N1 + (long)p * N1 + 16 * c + 4 * q;
+        v = *reinterpret_cast<const float4*>(sl);
+#pragma unroll
+        for (int s = 1; s < NCH1; ++s) {
+            const float4 t = *reinterpret_cast<const float4*>(sl + (long)s * NPX * N1);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        const float4 b = *reinterpret_cast<const float4*>(a.wp1 + NCH1 * CH + 16 * c + 4 * q);   // conv5_4's bias (no ReLU: yolo_fastest.py:131)
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    *reinterpret_cast<float4*>(E + (q * EPL + rp) * 4) = v;
+    const float* wc = (a.phase == 0 ? a.wp1 : a.wp2) + c * CH;
+    float wf[4][NT];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wf[j][nt] = wc[416 + (j * NT + nt) * 64 + lane];
+    const float4 bd = *reinterpret_cast<const float4*>(wc + 400 + 4 * q);
+    __syncthreads();
+    const float4* e = reinterpret_cast<const float4*>(E) + q * EPL + rp;
+    float d[4] = {bd.x, bd.y, bd.z, bd.w};
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+        const float4 x = e[(t / 5 - 2) * RW + (t % 5 - 2)];
+        const float4 w = *reinterpret_cast<const float4*>(wc + t * 16 + 4 * q);
+        d[0] = fmaf(x.x, w.x, d[0]); d[1] = fmaf(x.y, w.y, d[1]); d[2] = fmaf(x.z, w.z, d[2]); d[3] = fmaf(x.w, w.w, d[3]);
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float dj = fmaxf(d[j], 0.f);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][nt], dj, acc[nt], 0, 0, 0);
+    }
+    float* so = (a.phase == 0 ? a.slab1 + ((long)n * NCH1 + c) * NPX * N1 : a.slab2 + ((long)n * NCH2 + c) * NPX * N2) + (long)p * 128 + 4 * q;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<float4*>(so + nt * 16) = make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
+}
+
+enum { MDW2_ESPLIT_MAX_FRAMES = 9 };
+size_t mdw2_esplit_scratch_floats() { return (size_t)MDW2_ESPLIT_MAX_FRAMES * (6 + 8) * 80 * 128; }
+bool mdw2_esplit_ok(int H, int W, int headn, int Nf, int dtype, const float* scratch)
+{
+    static const bool off = getenv("YF_MRES_SMALL_OFF") != nullptr || getenv("YF_MDW2_ESPLIT_OFF") != nullptr;
+    return !off && scratch && dtype == DT_F32 && H == 8 && W == 10 && headn >= 1 && headn <= 32 && Nf <= MDW2_ESPLIT_MAX_FRAMES;
+}
+
+int launch_mdw2(const float* in, const float* wp1, const float* wp2, float* out, int H, int W, int headn, int Nf, hipStream_t s, int dtype, float* scratch)
+{
+    if (mdw2_esplit_ok(H, W, headn, Nf, dtype, scratch)) {
+        Mdw2EsplitArgs e{in, wp1, wp2, out, scratch, scratch + (size_t)Nf * 6 * 80 * 128, headn, 0};
+        for (int ph = 0; ph < 3; ++ph) {
+            e.phase = ph;
+            hipLaunchKernelGGL(mdw2_esplit_kernel, dim3((unsigned)(Nf * (ph == 0 ? 6 : ph == 1 ? 8 : 5))), dim3(ph == 2 ? 64 : 320), 0, s, e);
+        }
+        return 0;
+    }
     const Mdw2Args a{in, wp1, wp2, out, H, W, headn};
     return dtype == DT_F16 ? launch_mdw2_t<96, 128, 128, 8, 10, 5, half_t>(a, Nf, s)
          : dtype == DT_F16X3 ? launch_mdw2_t<96, 128, 128, 8, 10, 5, x3_t>(a, Nf, s) : launch_mdw2_t<96, 128, 128, 8, 10, 5, float>(a, Nf, s);

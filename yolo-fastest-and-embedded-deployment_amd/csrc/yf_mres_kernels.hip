@@ -1130,11 +1130,11 @@ static int launch_chain_unchained(const MresArgs& a, int N, hipStream_t s)
 }
 
 // kernel dispatches launch_mres() issues for this op at batch N (counter tools match dispatches to launches by order)
-int mres_dispatches(int cin, int cexp, int cout, bool res, int stride, int nblk, bool has_scratch, bool has_post, int H, int W, int N, int dtype)
+int mres_dispatches(int cin, int cexp, int cout, bool res, int stride, int nblk, bool has_scratch, bool has_post, int H, int W, int N, int dtype, bool esplit)
 {
     if (dtype != DT_F16 && cin == 24 && cexp == 136 && cout == 24 && res && stride == 1 && nblk > 1 && has_scratch && !has_post && mres_small_batch(N, H, W, 16, 20))
         return nblk;
-    if (cin == 48 && cexp == 224 && cout == 48 && res && stride == 1 && nblk > 1 && has_scratch && dtype == DT_F32 && H == 8 && W == 10 && N <= ESPLIT_MAX_FRAMES &&
+    if (esplit && cin == 48 && cexp == 224 && cout == 48 && res && stride == 1 && nblk > 1 && has_scratch && dtype == DT_F32 && H == 8 && W == 10 && N <= ESPLIT_MAX_FRAMES &&
         !getenv("YF_MRES_SMALL_OFF") && !getenv("YF_MRES_ESPLIT_OFF"))
         return nblk + 1;
     return 1;
@@ -1151,6 +1151,9 @@ int launch_mres(int cin, int cexp, int cout, bool res, int stride, const MresArg
     if (cin == 24 && cexp == 136 && cout == 48 && !res && stride == 2 && mres_small_batch(N, a.H / 2, a.W / 2, 8, 10))   // conv4_2 triple: 8x4 output tiles
         return dtype == DT_F16 ? launch_mres_t<24, 136, 48, false, 2, 8, 4, 8, half_t>(a, N, s)
              : dtype == DT_F16X3 ? launch_mres_t<24, 136, 48, false, 2, 8, 4, 8, x3_t>(a, N, s) : launch_mres_t<24, 136, 48, false, 2, 8, 4, 8, float>(a, N, s);
+    if (cin == 16 && cexp == 96 && cout == 24 && !res && stride == 2 && mres_small_batch(N, a.H / 2, a.W / 2, 8, 10))   // conv3_5 triple: 8x4 output tiles
+        return dtype == DT_F16 ? launch_mres_t<16, 96, 24, false, 2, 8, 4, 8, half_t>(a, N, s)
+             : dtype == DT_F16X3 ? launch_mres_t<16, 96, 24, false, 2, 8, 4, 8, x3_t>(a, N, s) : launch_mres_t<16, 96, 24, false, 2, 8, 4, 8, float>(a, N, s);
     if (cin == 16 && cexp == 96 && cout == 16 && res && stride == 1 && a.nblk <= 1 && mres_small_batch(N, a.H, a.W, 16, 20))
         return dtype == DT_F16 ? launch_mres_t<16, 96, 16, true, 1, 8, 10, 8, half_t>(a, N, s)
              : dtype == DT_F16X3 ? launch_mres_t<16, 96, 16, true, 1, 8, 10, 8, x3_t>(a, N, s) : launch_mres_t<16, 96, 16, true, 1, 8, 10, 8, float>(a, N, s);

@@ -52,6 +52,7 @@ class _Engine:
         self.H, self.W, self.max_batch, self.device_index = H, W, max_batch, device_index
         self._ws = None
         self.chunk, self.lanes, self.branches = 0, 2, 1     # the C side's defaults (yf_engine: chunk 0, lanes 2, branches on)
+        self.split_sums = 1
 
     def workspace(self, N, device):
         need = ctypes.c_size_t()
@@ -76,6 +77,10 @@ class _Engine:
     def set_branches(self, on):
         _lib.check(self.lib.yf_set_branches(self.handle, int(on)))
         self.branches = int(on)
+
+    def set_split_sums(self, on):
+        _lib.check(self.lib.yf_set_split_sums(self.handle, int(on)))
+        self.split_sums = int(on)
 
     def close(self):
         if self.handle:
@@ -120,6 +125,10 @@ class YoloFastest(nn.Module):
         self.fusion = DEFAULT_FUSION
         self.lanes = 2   # concurrent streams over chunks of the batch (chunk 0 = one chunk per lane); see yf_set_lanes
         self.branches = 1  # 1: the small head's launches run on a side stream beside the large head's; see yf_set_branches
+        # True (default): at <= 9 frames the stride-32 chain and the small head split their channel sums over several workgroups (batch-1 latency
+        # 0.34 -> 0.29 ms) -- the same numbers in another association than at larger batches.  False: a frame's bits never depend on the batch size
+        # (yf_set_split_sums; DESIGN.md section 4 "Small batches").
+        self.split_sums = True
         # activation storage / pointwise-GEMM operand type: torch.float32, or torch.float16 (BASELINE configs[2]: fp16 in HBM,
         # fp16 MFMA, fp32 accumulate).  `model.half()` selects fp16 like it would for the reference module; setting
         # `model.storage_dtype = torch.float16` keeps the fp32 master weights for the BN fold (more accurate).
@@ -211,6 +220,8 @@ class YoloFastest(nn.Module):
         e.set_fusion(self.fusion)
         if e.branches != self.branches:
             e.set_branches(self.branches)
+        if e.split_sums != int(bool(self.split_sums)):
+            e.set_split_sums(int(bool(self.split_sums)))
         return e
 
     def engine_on(self, device):
