@@ -728,6 +728,43 @@ def test_fp16_storage_variant_is_nonconforming_but_detects_identically(yf, golde
     assert np.abs(hh[0].float().cpu().numpy() - g["head_large"][:2]).max() < 1.5
 
 
+def test_fp16_storage_both_forms_of_the_stride2_block(yf, golden, dev, tmp_path):
+    """The fp16-storage plan runs conv1_8 + conv1_9 + conv2_1 as k19h_kernel (no region buffers, conv1_8 per tap on 4x4x4 fp16 MFMAs with its
+    weights rounded to fp16); YF_K19R=0 selects k19m_kernel<half_t> (rounds 2-4: conv1_8 on exact fp32 MFMAs, once per input pixel).
+    Both in child processes (the switch is read once per process) on the bundled frames and on a 192 x 224 noise batch: each stays inside the
+    fp16-storage bounds, and on the frames they differ from each other by less than half of what fp16 storage costs against fp32."""
+    import subprocess
+    import sys
+    code = ("import sys, torch, numpy as np; sys.path.insert(0, %r)\n"
+            "import yolo_fastest_amd as yf\n"
+            "dev = torch.device('cuda:0'); io = yf.io_params_for(256)\n"
+            "m = yf.YoloFastest(io).to(dev).eval(); m.load_state_dict(torch.load(%r, map_location=dev)); m.storage_dtype = torch.float16\n"
+            "g = np.load(%r); x = torch.from_numpy(((g['input_u8'].astype(np.float32) - 128.0) / 255.0)[:, None]).to(dev)\n"
+            "torch.manual_seed(11); y = torch.rand(3, 1, 192, 224, device=dev) - 0.5\n"
+            "with torch.no_grad(): a = m(x); b = m(y)\n"
+            "np.savez(sys.argv[1], hl=a[0].cpu().numpy(), hs=a[1].cpu().numpy(), nl=b[0].cpu().numpy(), ns=b[1].cpu().numpy())\n"
+            "print('RESULT ok')\n") % (ROOT, WEIGHTS[256], os.path.join(ROOT, "tests", "golden", "golden_256.npz"))
+    out = {}
+    for old in (False, True):
+        env = dict(os.environ)
+        env.pop("YF_K19R", None)
+        env.pop("YF_K19H_FORM", None)
+        if old:
+            env["YF_K19R"] = "0"
+        f = str(tmp_path / ("old.npz" if old else "new.npz"))
+        r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "RESULT ok" in r.stdout, r.stderr[-2000:]
+        out[old] = np.load(f)
+    g = golden("golden_256")
+    for k, ref in (("hl", g["head_large"]), ("hs", g["head_small"])):
+        for old in (False, True):
+            assert np.abs(out[old][k] - ref).max() <= FP16_STORAGE_MAX[256], (k, old)
+        assert np.abs(out[False][k] - out[True][k]).max() <= 0.5 * FP16_STORAGE_MAX[256], k
+    assert any(not np.array_equal(out[False][k], out[True][k]) for k in ("hl", "hs"))      # two different kernels did run
+    for k in ("nl", "ns"):      # noise drives the logits far beyond the frames' (one fp16 ulp at 40 is 3e-2): relative to the largest logit
+        assert np.isfinite(out[False][k]).all() and np.abs(out[False][k] - out[True][k]).max() <= 6e-3 * np.abs(out[True][k]).max(), k
+
+
 def test_validation_get_map_end_to_end(yf, models, golden, dev):
     """`Validation.get_mAP` (validate.py:27-122) with the model, the decode and the NMS on the GPU against the
     reference's own run on the same frames and synthetic targets (tests/golden/make_golden.py main_map).  The TP / FP

@@ -17,9 +17,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-enum { K_IDLE = 0, K_M16 = 1, K_M4 = 2, K_M32 = 3, K_H16 = 4, K_FMA = 5, K_PK = 6, K_MOV = 7, K_LDS = 8 };
+enum { K_IDLE = 0, K_M16 = 1, K_M4 = 2, K_M32 = 3, K_H16 = 4, K_FMA = 5, K_PK = 6, K_MOV = 7, K_LDS = 8,
+       K_H32 = 9, K_H4 = 10, K_PKMAX = 11, K_CVT = 12, K_MAXI = 13, K_CND = 14 };   // --f16: what an fp16 block kernel (k19h_kernel) issues
 static const char* kname[] = {"idle", "mfma_f32_16x16x4_f32", "mfma_f32_4x4x1_16B_f32", "mfma_f32_32x32x2_f32", "mfma_f32_16x16x16_f16",
-                              "v_fma_f32", "v_pk_fma_f32", "v_mov_b32", "ds_read_b128"};
+                              "v_fma_f32", "v_pk_fma_f32", "v_mov_b32", "ds_read_b128",
+                              "mfma_f32_16x16x32_f16", "mfma_f32_4x4x4_16B_f16", "v_pk_max_f16", "v_cvt_pk_f16_f32", "v_max_i32", "v_cndmask_b32"};
 
 #define FMA1(c) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
 #define PK1(c) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a2), "v"(b2))
@@ -125,6 +127,48 @@ template <> struct Stream<K_LDS> {
     __device__ float fini() { float s = 0.f; for (int i = 0; i < 8; ++i) s += c[i][0]; return s; }
 };
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <> struct Stream<K_H32> {
+    static constexpr int UNITS = 256;
+    f32x4 c[8]; f16x8 a, b;
+    __device__ void init(int l) { for (int j = 0; j < 8; ++j) { a[j] = (_Float16)(l * 0.001f + j); b[j] = (_Float16)(1.f + l * 0.002f); } for (int i = 0; i < 8; ++i) c[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ void block() {
+#pragma unroll
+        for (int r = 0; r < UNITS / 8; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c[i], 0, 0, 0);
+    }
+    __device__ float fini() { float s = 0.f; for (int i = 0; i < 8; ++i) s += c[i][0] + c[i][3]; return s; }
+};
+template <> struct Stream<K_H4> {
+    static constexpr int UNITS = 256;
+    f32x4 c[8]; f16x4 a, b;
+    __device__ void init(int l) { for (int j = 0; j < 4; ++j) { a[j] = (_Float16)(l * 0.001f + j); b[j] = (_Float16)(1.f + l * 0.002f); } for (int i = 0; i < 8; ++i) c[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ void block() {
+#pragma unroll
+        for (int r = 0; r < UNITS / 8; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_mfma_f32_4x4x4f16(a, b, c[i], 0, 0, 0);
+    }
+    __device__ float fini() { float s = 0.f; for (int i = 0; i < 8; ++i) s += c[i][0] + c[i][3]; return s; }
+};
+// the three VALU instructions of k19h_kernel's tap: independent destinations, one asm statement each
+#define VALU_STREAM(KIND, ASM)                                                                                                   \
+    template <> struct Stream<KIND> {                                                                                            \
+        static constexpr int UNITS = 512;                                                                                        \
+        unsigned c[16]; unsigned a, b;                                                                                           \
+        __device__ void init(int l) { a = 0x3c003c00u + l; b = 0x38003800u; for (int i = 0; i < 16; ++i) c[i] = i; }             \
+        __device__ void block() {                                                                                                \
+            _Pragma("unroll") for (int r = 0; r < UNITS / 16; ++r)                                                               \
+                _Pragma("unroll") for (int i = 0; i < 16; ++i) asm volatile(ASM : "=v"(c[i]) : "v"(a), "v"(b));                   \
+        }                                                                                                                        \
+        __device__ float fini() { unsigned s = 0; for (int i = 0; i < 16; ++i) s += c[i]; return (float)s; }                     \
+    };
+VALU_STREAM(K_PKMAX, "v_pk_max_f16 %0, %1, %2")
+VALU_STREAM(K_CVT, "v_cvt_pk_f16_f32 %0, %1, %2")
+VALU_STREAM(K_MAXI, "v_max_i32 %0, %1, %2")
+VALU_STREAM(K_CND, "v_cndmask_b32 %0, %1, %2, vcc")
+
 template <int KIND>
 __device__ unsigned long long run_window(unsigned long long t0, unsigned dur, int lane, float* sink, unsigned long long* t_end)
 {
@@ -174,6 +218,12 @@ __global__ void __launch_bounds__(1024) pair_kernel(int kindA, int nA, int kindB
         case K_PK:  units = run_window<K_PK>(t0, dur, lane, &s, &t1); break;
         case K_MOV: units = run_window<K_MOV>(t0, dur, lane, &s, &t1); break;
         case K_LDS: units = run_window<K_LDS>(t0, dur, lane, &s, &t1); break;
+        case K_H32: units = run_window<K_H32>(t0, dur, lane, &s, &t1); break;
+        case K_H4:  units = run_window<K_H4>(t0, dur, lane, &s, &t1); break;
+        case K_PKMAX: units = run_window<K_PKMAX>(t0, dur, lane, &s, &t1); break;
+        case K_CVT: units = run_window<K_CVT>(t0, dur, lane, &s, &t1); break;
+        case K_MAXI: units = run_window<K_MAXI>(t0, dur, lane, &s, &t1); break;
+        case K_CND: units = run_window<K_CND>(t0, dur, lane, &s, &t1); break;
         default: break;
     }
     sink[blockIdx.x * blockDim.x + threadIdx.x] = s;
@@ -289,8 +339,8 @@ static void mix_row(int blocks, int per_simd)
 
 int main(int argc, char** argv)
 {
-    int blocks = 1;
-    for (int i = 1; i < argc; ++i) { if (!strcmp(argv[i], "--all-cus")) blocks = 256; if (!strcmp(argv[i], "-v")) g_verbose = 1; }
+    int blocks = 1, f16 = 0;
+    for (int i = 1; i < argc; ++i) { if (!strcmp(argv[i], "--all-cus")) blocks = 256; if (!strcmp(argv[i], "-v")) g_verbose = 1; if (!strcmp(argv[i], "--f16")) f16 = 1; }
     const unsigned dur = 2000000;   // window, shader cycles (~1 ms)
     CK(hipMalloc(&d_rec, sizeof(h_rec))); CK(hipMalloc(&d_sink, 256 * 1024 * 4));
     CK(hipFuncSetAttribute((const void*)pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
@@ -298,6 +348,23 @@ int main(int argc, char** argv)
     printf("# coissue_probe on %s, %d workgroup(s), one per CU, window %u shader cycles (s_memtime ticks)\n", p.gcnArchName, blocks, dur);
     printf("# rate = instructions per 1000 cycles issued by ALL waves of a set on one SIMD (average over the SIMDs); 'together' = both sets resident on the same SIMDs.\n");
     printf("# overlap = rateA_together/rateA_alone + rateB_together/rateB_alone: 2.0 = neither set slows the other (separate issue), 1.0 = ONE shared issue rate.\n");
+    if (f16) {   // the fp16 matrix instructions against the VALU instructions an fp16 block kernel issues between them
+        const int hm[] = {K_H16, K_H32, K_H4}, hv[] = {K_FMA, K_PKMAX, K_CVT, K_MAXI, K_CND, K_LDS};
+        for (int per = 1; per <= 2; ++per) {
+            printf("\n## %d + %d waves per SIMD\n", per, per);
+            double aM[3], aV[6];
+            for (int i = 0; i < 3; ++i) { PairOut o = run_pair(hm[i], 4 * per, K_IDLE, 0, blocks, dur); aM[i] = o.rateA; printf("  alone  %-24s %7.1f /kcycle = %6.2f cycles each\n", kname[hm[i]], o.rateA, 1000.0 / o.rateA); }
+            for (int j = 0; j < 6; ++j) { PairOut o = run_pair(hv[j], 4 * per, K_IDLE, 0, blocks, dur); aV[j] = o.rateA; printf("  alone  %-24s %7.1f /kcycle = %6.2f cycles each\n", kname[hv[j]], o.rateA, 1000.0 / o.rateA); }
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 6; ++j) {
+                    PairOut o = run_pair(hm[i], 4 * per, hv[j], 4 * per, blocks, dur);
+                    printf("  together %-24s %7.1f (x%.2f)   %-18s %7.1f (x%.2f)   overlap %.2f\n", kname[hm[i]], o.rateA, o.rateA / aM[i], kname[hv[j]], o.rateB, o.rateB / aV[j],
+                           o.rateA / aM[i] + o.rateB / aV[j]);
+                }
+            { PairOut o = run_pair(K_H32, 4 * per, K_H4, 4 * per, blocks, dur); printf("  together %-24s %7.1f (x%.2f)   %-18s %7.1f (x%.2f)\n", kname[K_H32], o.rateA, o.rateA / aM[1], kname[K_H4], o.rateB, o.rateB / aM[2]); }
+        }
+        return 0;
+    }
     const int mk[] = {K_M16, K_M4, K_M32, K_H16};
     const int vk[] = {K_FMA, K_PK, K_MOV, K_LDS};
     for (int per = 1; per <= 2; ++per) {

@@ -686,9 +686,196 @@ __global__ void __launch_bounds__(R_NW * 64) k19r_kernel(K19Args a)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k19h_kernel (fp16 storage): k19r_kernel's scheme on the fp16 matrix pipe.  Per tap and 16 output pixels
+//   * conv1_8 (K = 4) is two v_mfma_f32_4x4x4_16B_f16 -- 16 independent 4x4 blocks with K = 4 EXACTLY: block (j, p >> 2) = lanes
+//     4b .. 4b+3 multiplies channels 4j .. 4j+3 (second instruction: 16 + 4j ..) by the 4 pixels of its lanes, so lane (p, j) ends up
+//     with channels 4j + i (and 16 + 4j + i) of pixel p in its 2 x 4 result registers; A = the lane's own weight row, B = the pixel's
+//     four input halves (ONE ds_read_b64 per tap), C = the bias;
+//   * ReLU + RNE to fp16 (4 v_cvt_pk_f16_f32 + 4 v_pk_max_f16) makes those 8 values the lane's f16x8 B operand of ONE K = 32 k-step per
+//     M-tile of conv1_9: k = 8j + e <-> channel 4j + e (e < 4), 16 + 4j + e - 4 (e >= 4, j < 2; k-values 20..23 and 28..31 of lane groups
+//     2, 3 are zero padding) -- the channel permutation lives in the host-side packing of A (k19_pack_weights);
+//   * the epilogue (bias + ReLU -> the same k <-> channel map -> ONE K = 32 k-step of conv2_1) stays in registers.
+// Against k19m_kernel<half_t> (138 us at 640x512 batch 128): no region buffers, no workgroup barrier per tile, no phase-1 LDS store traffic;
+// per 16 output pixels 18 v_mfma_f32_16x16x32_f16 + 18 v_mfma_f32_4x4x4_16B_f16 instead of 14 + 9 v_mfma_f32_16x16x4_f32, and the VALU
+// work of a wave (ReLU, conversions, padding selects) runs under the fp16 MFMAs of the SIMD's other waves (tools/coissue_probe.hip:
+// the fp16 matrix pipe co-issues with VALU, the fp32 one does not).  conv1_8's weights are rounded to fp16 here (k19m keeps them fp32).
+// Items, staging, padding and the unchecked loads: k19r_kernel's, in 8-byte pixels.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int H_PS = 72, H_RS = 2 * H_PS, H_SLICE = 3 * H_RS;   // halves: plane (17 records of 4 + pad), row and slice of a wave
+constexpr int H_BT = 48;                                        // floats: the wave's bias table behind its slice ([j][bias9 x 8 | bias21 x 4])
+constexpr int H_WAVE_BYTES = H_SLICE * 2 + H_BT * 4 + 64 * 16; // + conv2_1's fragment, 16 bytes per lane
+constexpr int H_W9 = 9 * 2 * 64 * 4, H_W21 = 64 * 4;            // floats (an f16x8 fragment = 4 floats per lane)
+constexpr int H_OFF = W9_F16 + W21_F16;                         // the k19h stream follows k19m's in the fp16 blob
+}  // namespace
+#ifndef YF_K19H_DBG
+#define YF_K19H_DBG 0   // timing builds only: 1 = no K = 32 k-steps, 2 = no 4x4x4 MFMAs, 4 = no ReLU / conversion, 8 = no global loads in the loop
+#endif
+#ifndef YF_K19H_C8
+#define YF_K19H_C8 1   // conv1_8 on 1: v_mfma_f32_4x4x4_16B_f16 | 0: v_mfma_f32_16x16x16_f16 with K padded from 4 (A/B builds)
+#endif
+
+// WPS: waves per SIMD the register budget is set for (HIP's second launch bound): 3 -> 128 VGPRs without spills; 4 -> two weight fragments
+// are reloaded from scratch per item.  Measured at 640x512 batch 128 (tools/scratch/k19h_forms.sh): 4 waves per workgroup x 3 per SIMD
+// 74 us | 4 x 4 80 | 8 x 4 80 | 4 x 2 87 | conv1_8 on K-padded 16x16x16 MFMAs (YF_K19H_C8=0) 80 | k19m_kernel<half_t> 138.
+// Where the 74 us go (timing builds, YF_K19H_DBG): the 18 K = 32 k-steps of an item are 288 of its ~1100 SIMD cycles; the 4x4x4 MFMAs, the
+// conversions and the global loads are worth 4 / 10 / 4 us.  The fp16 matrix pipe co-issues with another wave's VALU instruction only
+// every 8 cycles while it is saturated (tools/coissue_probe.hip --f16: v_cvt_pk_f16_f32 / v_pk_max_f16 at 124 per 1000 cycles beside
+// back-to-back 16x16x32 or 4x4x4 MFMAs, against 245 alone), and a tap has 8 such instructions per 48 MFMA cycles.
+template <int R_NW, int WPS>
+__global__ void __launch_bounds__(R_NW * 64, WPS) k19h_kernel(K19Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char k19_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = lane & 15, j = lane >> 4;
+    half_t* const SL = reinterpret_cast<half_t*>(k19_smem + wave * H_WAVE_BYTES);
+    float* const BT = reinterpret_cast<float*>(k19_smem + wave * H_WAVE_BYTES + H_SLICE * 2);
+    const half_t* const in = reinterpret_cast<const half_t*>(a.in);
+    half_t* const out = reinterpret_cast<half_t*>(a.out);
+
+    // ---- weights in registers for the lifetime of the wave: 18 x 4 + 4 + 4 VGPRs ----
+    f16x8 wA[9][2];
+    {
+        const f16x8* w = reinterpret_cast<const f16x8*>(a.wp + H_OFF);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) wA[t][mt] = w[(t * 2 + mt) * 64 + lane];
+    }
+    f32x4* const W21L = reinterpret_cast<f32x4*>(k19_smem + wave * H_WAVE_BYTES + H_SLICE * 2 + H_BT * 4) + lane;   // used once per item: LDS, not 4 VGPRs
+    *W21L = reinterpret_cast<const f32x4*>(a.wp + H_OFF + H_W9)[lane];
+    f16x4 w8A[2];
+    f32x4 bias8[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#if YF_K19H_C8
+        const int cout = 16 * mt + 4 * j + (p & 3);   // the row this lane supplies to its 4x4 block
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w8A[mt][k] = cout < 24 && (mt == 0 || j < 2) ? (half_t)a.w8[k * 24 + cout] : (half_t)0.f;
+#else
+        const int cout = 16 * mt + p;                  // row = cout, k = 4j + i: only lane group 0 holds real k-values
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w8A[mt][k] = cout < 24 && j == 0 ? (half_t)a.w8[k * 24 + cout] : (half_t)0.f;
+#endif
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias8[mt][r] = mt == 0 || j < 2 ? a.b8[16 * mt + 4 * j + r] : 0.f;   // rows without a channel: weights and bias zero -> k-values 0 after the ReLU
+    }
+    // conv1_9's and conv2_1's biases are needed once per item: a per-wave LDS table (12 floats per lane group) instead of 12 VGPRs
+    if (lane < 48) {
+        const int jj = lane / 12, e = lane - 12 * jj;
+        BT[lane] = e < 4 ? a.b9[4 * jj + e] : e < 8 ? (jj < 2 ? a.b9[16 + 4 * jj + e - 4] : 0.f) : (jj < 2 ? a.b21[4 * jj + e - 8] : 0.f);
+    }
+    const float* const bt = BT + 12 * j;
+
+    // ---- the lane's two staging records (region pixel idx = lane, lane + 64 < 99), in halves ----
+    const int row0 = lane / 33, c0 = lane - 33 * row0;
+    const int idx1 = lane + 64 < 99 ? lane + 64 : 0, row1 = idx1 / 33, c1 = idx1 - 33 * row1;
+    const unsigned vo0 = (unsigned)((row0 * a.W + c0) * 4), vo1 = (unsigned)((row1 * a.W + c1) * 4);
+    const int so0 = row0 * H_RS + (c0 & 1) * H_PS + (c0 >> 1) * 4, so1 = row1 * H_RS + (c1 & 1) * H_PS + (c1 >> 1) * 4;
+    const int segs = (a.Wo + 15) >> 4;
+    const int nwaves = gridDim.x * R_NW;
+    const int per_frame = a.Ho * segs;
+    const int d_n = nwaves / per_frame, d_r = nwaves - d_n * per_frame, d_oy = d_r / segs, d_sx = d_r - d_oy * segs;
+    const int w0 = blockIdx.x * R_NW + wave;
+    int n = w0 / per_frame, oy = (w0 - n * per_frame) / segs, sx = w0 - n * per_frame - oy * segs;
+    auto advance = [&](int& n_, int& oy_, int& sx_) {
+        sx_ += d_sx; oy_ += d_oy; n_ += d_n;
+        if (sx_ >= segs) { sx_ -= segs; ++oy_; }
+        if (oy_ >= a.Ho) { oy_ -= a.Ho; ++n_; }
+    };
+    auto origin = [&](int n_, int oy_, int sx_) {   // region pixel (0, 0) = input (2 oy - 1, 32 sx - 1); beyond the last frame: frame 0 (unused)
+        const int nn = n_ < a.n_frames ? n_ : 0;
+        return in + (((long)nn * a.H + (2 * oy_ - 1)) * a.W + (32 * sx_ - 1)) * 4;
+    };
+    f16x4 xin0, xin1;
+    {
+        const half_t* o0 = origin(n, oy, sx);
+        xin0 = *reinterpret_cast<const f16x4*>(o0 + vo0);
+        xin1 = *reinterpret_cast<const f16x4*>(o0 + vo1);
+    }
+    int n2 = n, oy2 = oy, sx2 = sx;
+    advance(n2, oy2, sx2);
+    const half_t* const xb = SL + p * 4;   // the 8-byte record of pixel p: the tap reads are immediates on top of it
+    const f16x4 zero4 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+
+    for (; n < a.n_frames;) {
+        *reinterpret_cast<f16x4*>(SL + so0) = xin0;
+        if (lane < 35) *reinterpret_cast<f16x4*>(SL + so1) = xin1;
+        if (!(YF_K19H_DBG & 8)) {
+            const half_t* o2 = origin(n2, oy2, sx2);
+            xin0 = *reinterpret_cast<const f16x4*>(o2 + vo0);
+            xin1 = *reinterpret_cast<const f16x4*>(o2 + vo1);
+        }
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto taps = [&](auto border) {
+            constexpr bool BORDER = decltype(border)::value;
+            const bool top = oy == 0, left = sx == 0;
+            auto c8 = [&](int t, f32x4& d0, f32x4& d1) {
+                const int ky = t / 3, kx = t - 3 * ky;
+                const f16x4 x = *reinterpret_cast<const f16x4*>(xb + ky * H_RS + (kx == 1 ? H_PS : 0) + (kx == 2 ? 4 : 0));
+                const f32x4 c0 = bias8[0], c1 = bias8[1];
+#if YF_K19H_DBG & 2
+                d0 = c0 + __builtin_convertvector(x, f32x4); d1 = c1;
+#elif YF_K19H_C8
+                d0 = __builtin_amdgcn_mfma_f32_4x4x4f16(w8A[0], x, c0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_4x4x4f16(w8A[1], x, c1, 0, 0, 0);
+#else
+                d0 = __builtin_amdgcn_mfma_f32_16x16x16f16(w8A[0], x, c0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(w8A[1], x, c1, 0, 0, 0);
+#endif
+            };
+            f32x4 d0, d1;
+            c8(0, d0, d1);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ky = t / 3, kx = t - 3 * ky;
+#if YF_K19H_DBG & 4
+                f16x4 b0 = *reinterpret_cast<const f16x4*>(&d0), b1 = *reinterpret_cast<const f16x4*>(&d1);
+#else
+                f16x4 b0 = __builtin_elementwise_max(__builtin_convertvector(d0, f16x4), zero4);
+                f16x4 b1 = __builtin_elementwise_max(__builtin_convertvector(d1, f16x4), zero4);
+#endif
+                if constexpr (BORDER) {
+                    if (ky == 0 || kx == 0) {   // input row -1 / column -1: conv1_9's zero padding of conv1_8's output
+                        const bool z = (ky == 0 && top) || (kx == 0 && left && p == 0);
+                        b0 = z ? zero4 : b0;
+                        b1 = z ? zero4 : b1;
+                    }
+                }
+                if (t + 1 < 9) c8(t + 1, d0, d1);   // the next tap's conv1_8 goes out in front of this tap's k-steps
+                const f16x8 b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+#if YF_K19H_DBG & 1
+                acc0 += __builtin_convertvector(b0, f32x4) * wA[t][0][0]; acc1 += __builtin_convertvector(b1, f32x4) * wA[t][1][0];
+#else
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wA[t][0], b, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wA[t][1], b, acc1, 0, 0, 0);
+#endif
+            }
+        };
+        if (oy == 0 || sx == 0) taps(std::true_type{});
+        else taps(std::false_type{});
+        {
+            const f32x4 bias9a = *reinterpret_cast<const f32x4*>(bt), bias9b = *reinterpret_cast<const f32x4*>(bt + 4), bias21 = *reinterpret_cast<const f32x4*>(bt + 8);
+            const f16x4 h0 = __builtin_elementwise_max(__builtin_convertvector(acc0 + bias9a, f16x4), zero4);
+            const f16x4 h1 = __builtin_elementwise_max(__builtin_convertvector(acc1 + bias9b, f16x4), zero4);
+            const f16x8 h = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            const f32x4 w21v = *W21L;
+            const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&w21v), h, bias21, 0, 0, 0);
+            const int ox = 16 * sx + p;
+            if (j < 2 && ox < a.Wo)
+                *reinterpret_cast<f16x4*>(out + (((long)n * a.Ho + oy) * a.Wo + ox) * 8 + 4 * j) = __builtin_convertvector(o, f16x4);
+        }
+        n = n2; oy = oy2; sx = sx2;
+        advance(n2, oy2, sx2);
+    }
+}
+
 size_t k19_packed_floats(int wmode)
 {
-    return wmode == WM_F16X3 ? (size_t)2 * WX3_HALF : wmode == WM_F16 ? (size_t)(W9_F16 + W21_F16) : (size_t)(R_OFF + 2 * (R_WA + R_WB) + R_WQ);
+    return wmode == WM_F16X3 ? (size_t)2 * WX3_HALF : wmode == WM_F16 ? (size_t)(H_OFF + H_W9 + H_W21) : (size_t)(R_OFF + 2 * (R_WA + R_WB) + R_WQ);
 }
 
 // w9: [tap][cin][cout] (blob layout of the dense 3x3), w21: [cin][cout]
@@ -708,6 +895,20 @@ void k19_pack_weights(const float* w9, const float* w21, float* out, int wmode)
                         oh[((size_t)(g * 2 + mt) * 64 + l) * 8 + e] = f32_to_f16_bits(v);
                         if (x3) ol[((size_t)(g * 2 + mt) * 64 + l) * 8 + e] = f16_lo_bits(v);
                     }
+    }
+    if (h16 && !x3) {   // k19h_kernel: per tap ONE K = 32 fragment per M-tile; lane group jj, element e <-> channel 4 jj + e (e < 4), 16 + 4 jj + e - 4 (jj < 2)
+        uint16_t* o9 = reinterpret_cast<uint16_t*>(out + H_OFF);
+        uint16_t* o21 = reinterpret_cast<uint16_t*>(out + H_OFF + H_W9);
+        for (int l = 0; l < 64; ++l)
+            for (int e = 0; e < 8; ++e) {
+                const int m = l & 15, jj = l >> 4, ch = e < 4 ? 4 * jj + e : jj < 2 ? 16 + 4 * jj + e - 4 : -1;
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const int cout = 16 * mt + m;
+                        o9[((size_t)(tap * 2 + mt) * 64 + l) * 8 + e] = f32_to_f16_bits(ch >= 0 && cout < 24 ? w9[((size_t)tap * 24 + ch) * 24 + cout] : 0.f);
+                    }
+                o21[(size_t)l * 8 + e] = f32_to_f16_bits(ch >= 0 && m < 8 ? w21[ch * 8 + m] : 0.f);
+            }
     }
     for (int g = 0; g < (h16 ? 0 : NG); ++g)
         for (int s = 0; s < 4; ++s)
@@ -799,6 +1000,15 @@ static int launch_k19r_t(const K19Args& a, long items, int n_cu, int dev, hipStr
     return 0;
 }
 
+template <int R_NW, int WPS>
+static int launch_k19h_t(const K19Args& a, long items, int n_cu, hipStream_t s)
+{
+    constexpr size_t lds = (size_t)R_NW * H_WAVE_BYTES;
+    const long wgs = (items + R_NW - 1) / R_NW, cap = (long)n_cu * (4 * WPS / R_NW);
+    hipLaunchKernelGGL((k19h_kernel<R_NW, WPS>), dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(R_NW * 64), lds, s, a);
+    return 0;
+}
+
 // fp32: k19r_kernel unless YF_K19R=0 (A/B: the region-buffer kernel of rounds 1-3)
 static bool k19r_enabled()
 {
@@ -839,6 +1049,18 @@ int launch_k19m(K19Args a, int N, hipStream_t s, int dtype)
         if (!getenv("YF_K19R_NW") && items <= 64L * n_cu) return launch_k19r_t<8, false>(a, items, n_cu, dev, s);
         return nw == 8 ? launch_k19r_t<8, false>(a, items, n_cu, dev, s) : nw == 16 ? launch_k19r_t<16, true>(a, items, n_cu, dev, s)
                        : nw == 1012 ? launch_k19r_t<12, true>(a, items, n_cu, dev, s) : launch_k19r_t<12, false>(a, items, n_cu, dev, s);
+    }
+    if (dtype == DT_F16 && k19r_enabled() && a.H % 2 == 0 && a.W % 2 == 0) {   // fp16 storage: k19h_kernel (YF_K19R=0: the region-buffer kernel)
+        // developer switch YF_K19H_FORM = waves per workgroup * 10 + waves per SIMD (A/B; default 43)
+        static const int form = [] { const char* v = getenv("YF_K19H_FORM"); return v && *v ? atoi(v) : 43; }();
+        const long items = (long)N * a.Ho * ((a.Wo + 15) / 16);
+        switch (form) {
+        case 43: return launch_k19h_t<4, 3>(a, items, n_cu, s);
+        case 44: return launch_k19h_t<4, 4>(a, items, n_cu, s);
+        case 42: return launch_k19h_t<4, 2>(a, items, n_cu, s);
+        case 84: return launch_k19h_t<8, 4>(a, items, n_cu, s);
+        default: fprintf(stderr, "yolo_fastest_hip: YF_K19H_FORM=%d is not one of 42, 43, 44, 84\n", form); return -1;
+        }
     }
     a.tiles_y = (a.Ho + TH - 1) / TH;
     a.tiles_x = (a.Wo + TW - 1) / TW;
