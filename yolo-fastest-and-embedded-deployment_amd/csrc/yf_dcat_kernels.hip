@@ -18,7 +18,7 @@
 //     the grid is persistent over the items.  Operand fragments of the next M-tile are requested while the current one is computed
 //     (the "A ring" of pw_ws_kernel).  No barrier after the weight staging.
 // Arithmetic and its order are those of the two launches this replaces (pw_ws_kernel, OMODE 2 and the two-source GEMM): acc = 0,
-// k-steps in order, + bias, ReLU -- bitwise the same conv4_1_1 tensor.  fp32 storage only (DT_F32; DT_F16X3: dcat_x3_kernel below).
+// k-steps in order, + bias, ReLU -- bitwise the same conv4_1_1 tensor.  DT_F32 here; DT_F16X3: dcat_x3_kernel, DT_F16: dcat_h_kernel below.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -334,6 +334,146 @@ __global__ void __launch_bounds__(256) dcat_x3_kernel(DcatArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// dcat_h_kernel: the same launch for DT_F16 engines (fp16 storage, single fp16 MFMA operands): the two launches it replaces (pw_ws_kernel
+// <half_t>, OMODE 2, and the two-source GEMM) round deconv5_1 to fp16 on its way through HBM; here the ReLU'd deconv result is rounded to
+// fp16 once, in registers, as conv4_1_1's operand -- the same values, so the conv4_1_1 tensor is bitwise the one of the two launches
+// (k-steps in the same order).  A wave holds its quadrant's 36 deconv fragments (72 VGPRs), the conv4_1_1 stream in LDS is one 8-byte
+// record per (16-channel block, n-tile, lane) (47 KB), operands are the 8-byte fragments as they lie in HBM: no conversions on the way in.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int DH_OFF_BD = DX_NG * DC_NT * 64 * 2;            // floats: [block][nt][lane] f16x4 = 2 floats per lane
+constexpr int DH_OFF_BC = DH_OFF_BD + DC_N;
+constexpr int DH_WFLOATS = DH_OFF_BC + DC_N;                 // 11712 floats = 46848 B
+}  // namespace
+
+template <int MT>
+__global__ void __launch_bounds__(256) dcat_h_kernel(DcatArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float dc_smem[];
+    float* WL = dc_smem;
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int qd = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), dy = qd >> 1, dx = qd & 1;
+    const half_t* const xh = reinterpret_cast<const half_t*>(a.x);
+    const half_t* const skh = reinterpret_cast<const half_t*>(a.skip);
+    half_t* const outh = reinterpret_cast<half_t*>(a.out);
+
+    LdsStage<DH_WFLOATS, 256> stage;
+    stage.issue(a.wc);
+    f16x4 dw[DC_NT][DC_KB_D];   // this wave's deconv weights (mfma_pack_weights_f16 per quadrant: [k-block][n-tile][lane] f16x4)
+    {
+        const f16x4* w = reinterpret_cast<const f16x4*>(a.wd) + (size_t)qd * DC_KB_D * DC_NT * 64 + lane;
+#pragma unroll
+        for (int kb = 0; kb < DC_KB_D; ++kb)
+#pragma unroll
+            for (int nt = 0; nt < DC_NT; ++nt) dw[nt][kb] = w[(kb * DC_NT + nt) * 64];
+    }
+    stage.commit(WL);
+    __syncthreads();
+    const f16x4* WL2 = reinterpret_cast<const f16x4*>(WL);
+
+    const int npx = a.h * a.w, ow = 2 * a.w;
+    const long ntile = (long)((a.nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * MT;
+    struct Tile { const half_t* sp; const half_t* cp; long o; bool ok; };
+    auto tile = [&](long t) {
+        const long it = (long)blockIdx.x + (t / MT) * gridDim.x;
+        const int n = (int)(it / a.items_per_frame), chunk = (int)(it - (long)n * a.items_per_frame);
+        const int p = chunk * (MT * 16) + (int)(t % MT) * 16 + r;
+        Tile T;
+        T.ok = p < npx;
+        const int pc = T.ok ? p : npx - 1;
+        const int y = pc / a.w, x = pc - y * a.w;
+        const long opix = (long)n * 4 * npx + (long)(2 * y + dy) * ow + 2 * x + dx;
+        T.sp = xh + ((long)n * npx + pc) * DC_CIN + 4 * q;
+        T.cp = skh + opix * DC_SKIP;
+        T.o = opix * DC_N + 4 * q;
+        return T;
+    };
+    if (ntile <= 0) return;
+    f16x4 sf[DC_KB_D], cf[DC_KB_S];
+    f16x2 ct;
+    Tile cur = tile(0);
+#pragma unroll
+    for (int kb = 0; kb < DC_KB_D; ++kb) sf[kb] = *reinterpret_cast<const f16x4*>(cur.sp + kb * 16);
+#pragma unroll
+    for (int kb = 0; kb < DC_KB_S; ++kb) cf[kb] = *reinterpret_cast<const f16x4*>(cur.cp + kb * 16 + 4 * q);
+    ct = *reinterpret_cast<const f16x2*>(cur.cp + DC_KB_S * 16 + 2 * q);
+    const f16x4 zero4 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+
+#pragma unroll 1
+    for (long t = 0; t < ntile; ++t) {
+        const Tile nxt = tile(t + 1 < ntile ? t + 1 : t);
+        f32x4 dacc[DC_NT];
+#pragma unroll
+        for (int nt = 0; nt < DC_NT; ++nt) dacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < DC_KB_D; ++kb) {
+#pragma unroll
+            for (int nt = 0; nt < DC_NT; ++nt) dacc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(dw[nt][kb], sf[kb], dacc[nt], 0, 0, 0);
+            sf[kb] = *reinterpret_cast<const f16x4*>(nxt.sp + kb * 16);
+        }
+        f16x4 dv[DC_NT];   // relu(deconv + bias), rounded to fp16 as the two-launch plan stores it
+#pragma unroll
+        for (int nt = 0; nt < DC_NT; ++nt) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(WL + DH_OFF_BD + nt * 16 + 4 * q);
+            dv[nt] = __builtin_elementwise_max(__builtin_convertvector(dacc[nt] + b, f16x4), zero4);
+        }
+        f32x4 cacc[DC_NT];
+#pragma unroll
+        for (int nt = 0; nt < DC_NT; ++nt) cacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f16x4 wbuf[2][DC_NT];
+#pragma unroll
+        for (int nt = 0; nt < DC_NT; ++nt) wbuf[0][nt] = WL2[nt * 64 + lane];
+#pragma unroll
+        for (int g = 0; g < DX_NG; ++g) {
+            if (g + 1 < DX_NG) {
+#pragma unroll
+                for (int nt = 0; nt < DC_NT; ++nt) wbuf[(g + 1) & 1][nt] = WL2[((g + 1) * DC_NT + nt) * 64 + lane];
+            }
+            f16x4 op;
+            if (g < DC_KB_S) {
+                op = cf[g];
+                cf[g] = *reinterpret_cast<const f16x4*>(nxt.cp + g * 16 + 4 * q);
+            } else if (g == DC_KB_S) {
+                op = f16x4{ct[0], ct[1], (half_t)0.f, (half_t)0.f};
+                ct = *reinterpret_cast<const f16x2*>(nxt.cp + DC_KB_S * 16 + 2 * q);
+            } else {
+                op = dv[g - DC_KB_S - 1];
+            }
+#pragma unroll
+            for (int nt = 0; nt < DC_NT; ++nt) cacc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(wbuf[g & 1][nt], op, cacc[nt], 0, 0, 0);
+        }
+        if (cur.ok) {
+#pragma unroll
+            for (int nt = 0; nt < DC_NT; ++nt) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(WL + DH_OFF_BC + nt * 16 + 4 * q);
+                *reinterpret_cast<f16x4*>(outh + cur.o + nt * 16) = __builtin_elementwise_max(__builtin_convertvector(cacc[nt] + b, f16x4), zero4);
+            }
+        }
+        cur = nxt;
+    }
+}
+
+size_t dcat_packed_floats_f16() { return (size_t)DH_WFLOATS; }
+
+void dcat_pack_weights_f16(const float* w, const float* bd, const float* bc, float* out)
+{
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(out);
+    for (int g = 0; g < DX_NG; ++g)
+        for (int nt = 0; nt < DC_NT; ++nt)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int q = lane >> 4, c = nt * 16 + (lane & 15);
+                for (int j = 0; j < 4; ++j) {
+                    int k = -1;   // row of w, or none (a zero k-slot)
+                    if (g < DC_KB_S) k = g * 16 + 4 * q + j;
+                    else if (g == DC_KB_S) k = j < 2 ? DC_KB_S * 16 + 2 * q + j : -1;
+                    else k = DC_SKIP + (g - DC_KB_S - 1) * 16 + 4 * q + j;
+                    o16[((size_t)(g * DC_NT + nt) * 64 + lane) * 4 + j] = f32_to_f16_bits(k >= 0 ? w[(size_t)k * DC_N + c] : 0.f);
+                }
+            }
+    for (int i = 0; i < DC_N; ++i) { out[DH_OFF_BD + i] = bd[i]; out[DH_OFF_BC + i] = bc[i]; }
+}
+
 size_t dcat_packed_floats_x3() { return (size_t)DX_WFLOATS; }
 
 void dcat_pack_weights_x3(const float* w, const float* bd, const float* bc, float* out)
@@ -381,13 +521,13 @@ bool dcat_has_kernel(int cin, int cskip, int cout) { return cin == DC_CIN && csk
 
 int launch_dcat(const float* x, const float* skip, const float* wd, const float* wc, float* out, int h, int w, int Nf, hipStream_t s, int dtype)
 {
-    static bool attr_done[2][2][YF_MAX_DEVICES] = {};
+    static bool attr_done[3][2][YF_MAX_DEVICES] = {};
     const int dev = current_device();
     const int n_cu = device_cu_count(dev);
     if (dev < 0 || n_cu <= 0) return -2;
-    if (dtype != DT_F32 && dtype != DT_F16X3) return -1;   // fp32 storage only
-    const bool x3 = dtype == DT_F16X3;
-    const size_t lds = (size_t)(x3 ? DX_WFLOATS : DC_WFLOATS) * sizeof(float);
+    if (dtype != DT_F32 && dtype != DT_F16X3 && dtype != DT_F16) return -1;
+    const bool x3 = dtype == DT_F16X3, h16 = dtype == DT_F16;
+    const size_t lds = (size_t)(x3 ? DX_WFLOATS : h16 ? DH_WFLOATS : DC_WFLOATS) * sizeof(float);
     static_assert((size_t)DX_WFLOATS * sizeof(float) <= 160 * 1024 && (size_t)DC_WFLOATS * sizeof(float) <= 160 * 1024, "LDS");
     // Small batches: an item of five M-tiles is 33 us of MFMA time on ONE CU; when the five-tile items would leave more
     // than half of the CUs idle, an item is ONE M-tile -- a frame of the 320x256 net then runs on five workgroups.  Same tiles, same
@@ -395,10 +535,11 @@ int launch_dcat(const float* x, const float* skip, const float* wd, const float*
     const int items5 = Nf * ((h * w + DC_MT * 16 - 1) / (DC_MT * 16));
     const bool small = 2 * items5 <= n_cu;
     const void* fn = x3 ? (small ? reinterpret_cast<const void*>(dcat_x3_kernel<1>) : reinterpret_cast<const void*>(dcat_x3_kernel<DC_MT>))
+                   : h16 ? (small ? reinterpret_cast<const void*>(dcat_h_kernel<1>) : reinterpret_cast<const void*>(dcat_h_kernel<DC_MT>))
                         : (small ? reinterpret_cast<const void*>(dcat_kernel<1>) : reinterpret_cast<const void*>(dcat_kernel<DC_MT>));
-    if (!attr_done[x3][small][dev]) {
+    if (!attr_done[x3 ? 1 : h16 ? 2 : 0][small][dev]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
-        attr_done[x3][small][dev] = true;
+        attr_done[x3 ? 1 : h16 ? 2 : 0][small][dev] = true;
     }
     DcatArgs a{x, skip, wd, wc, out, h, w, 0, 0};
     const int mt = small ? 1 : DC_MT;
@@ -406,7 +547,8 @@ int launch_dcat(const float* x, const float* skip, const float* wd, const float*
     a.nitems = Nf * a.items_per_frame;
     // persistent grid, every workgroup the same number of items
     const int rounds = (a.nitems + n_cu - 1) / n_cu, grid = (a.nitems + rounds - 1) / rounds;
-    if (x3) { if (small) hipLaunchKernelGGL(dcat_x3_kernel<1>, dim3((unsigned)grid), dim3(256), lds, s, a); else hipLaunchKernelGGL(dcat_x3_kernel<DC_MT>, dim3((unsigned)grid), dim3(256), lds, s, a); }
+    if (h16) { if (small) hipLaunchKernelGGL(dcat_h_kernel<1>, dim3((unsigned)grid), dim3(256), lds, s, a); else hipLaunchKernelGGL(dcat_h_kernel<DC_MT>, dim3((unsigned)grid), dim3(256), lds, s, a); }
+    else if (x3) { if (small) hipLaunchKernelGGL(dcat_x3_kernel<1>, dim3((unsigned)grid), dim3(256), lds, s, a); else hipLaunchKernelGGL(dcat_x3_kernel<DC_MT>, dim3((unsigned)grid), dim3(256), lds, s, a); }
     else { if (small) hipLaunchKernelGGL(dcat_kernel<1>, dim3((unsigned)grid), dim3(256), lds, s, a); else hipLaunchKernelGGL(dcat_kernel<DC_MT>, dim3((unsigned)grid), dim3(256), lds, s, a); }
     return 0;
 }

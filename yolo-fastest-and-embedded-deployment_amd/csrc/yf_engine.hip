@@ -349,8 +349,8 @@ void build_plan(Plan* e, int level, int dtype, const LayerSpec* kLayers)
     if (fused)
         for (size_t i = br0; i < e->ops.size(); ++i) e->ops[i].branch = 1;
     b.fused = false;
-    if (deep && (dmask & 4) && dtype != yf::DT_F16 && yf::dcat_has_kernel(e->tensors[conv5_2].C, e->tensors[conv4_2].C, kLayers[find_layer("conv4_1_1")].cout)) {
-        // level 2, fp32 storage: deconv5_1 + conv4_1_1 in one launch, the deconv result stays in registers (yf_dcat_kernels.hip)
+    if (deep && (dmask & 4) && yf::dcat_has_kernel(e->tensors[conv5_2].C, e->tensors[conv4_2].C, kLayers[find_layer("conv4_1_1")].cout)) {
+        // level 2: deconv5_1 + conv4_1_1 in one launch, the deconv result stays in registers (yf_dcat_kernels.hip)
         Op o{};
         o.type = OP_DCAT;
         o.layer = find_layer("deconv5_1"); o.l_proj = find_layer("conv4_1_1");
@@ -900,18 +900,21 @@ int yf_create_ex(const void* blob, size_t nbytes, int H, int W, int max_batch, i
             }
             if (o.type == OP_DCAT) {   // deconv: the pw GEMM's fragments per quadrant; conv4_1_1: the LDS stream + both biases
                 const LayerSpec& LD = kLayers[o.layer];
-                o.kdt = x3 ? yf::DT_F16X3 : yf::DT_F32;
-                const size_t per = x3 ? yf::mfma_packed_floats_x3(LD.cin, 0, LD.cout) : yf::mfma_packed_floats(LD.cin, 0, LD.cout);
+                o.kdt = x3 ? yf::DT_F16X3 : h16 ? yf::DT_F16 : yf::DT_F32;
+                const size_t per = x3 ? yf::mfma_packed_floats_x3(LD.cin, 0, LD.cout) : h16 ? yf::mfma_packed_floats_f16(LD.cin, 0, LD.cout)
+                                      : yf::mfma_packed_floats(LD.cin, 0, LD.cout);
                 o.mfma_off = (long)packed.size();
                 packed.resize(packed.size() + ((4 * per + 63) & ~(size_t)63));
                 for (int qd = 0; qd < 4; ++qd) {
                     const float* wq = hw + e->w_off[o.layer] + (size_t)qd * LD.cin * LD.cout;
                     if (x3) yf::mfma_pack_weights_x3(wq, LD.cin, 0, LD.cout, packed.data() + o.mfma_off + per * qd);
+                    else if (h16) yf::mfma_pack_weights_f16(wq, LD.cin, 0, LD.cout, packed.data() + o.mfma_off + per * qd);
                     else yf::mfma_pack_weights(wq, LD.cin, 0, LD.cout, packed.data() + o.mfma_off + per * qd);
                 }
                 o.mfma_off2 = (long)packed.size();
-                packed.resize(packed.size() + (((x3 ? yf::dcat_packed_floats_x3() : yf::dcat_packed_floats()) + 63) & ~(size_t)63));
+                packed.resize(packed.size() + (((x3 ? yf::dcat_packed_floats_x3() : h16 ? yf::dcat_packed_floats_f16() : yf::dcat_packed_floats()) + 63) & ~(size_t)63));
                 if (x3) yf::dcat_pack_weights_x3(hw + e->w_off[o.l_proj], hw + e->b_off[o.layer], hw + e->b_off[o.l_proj], packed.data() + o.mfma_off2);
+                else if (h16) yf::dcat_pack_weights_f16(hw + e->w_off[o.l_proj], hw + e->b_off[o.layer], hw + e->b_off[o.l_proj], packed.data() + o.mfma_off2);
                 else yf::dcat_pack_weights(hw + e->w_off[o.l_proj], hw + e->b_off[o.layer], hw + e->b_off[o.l_proj], packed.data() + o.mfma_off2);
                 continue;
             }

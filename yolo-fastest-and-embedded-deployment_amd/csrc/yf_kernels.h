@@ -272,12 +272,14 @@ size_t mdw_packed_floats(int c, int n, int headn, int wmode = WM_F32);
 void mdw_pack_weights(const float* wd, const float* bd, const float* w, const float* b, const float* hw, const float* hb, int c,
                       int n, int headn, float* out, int wmode = WM_F32);
 
-// deconv5_1 + conv4_1_1 over cat(conv4_2, deconv5_1) as one launch (yf_dcat_kernels.hip); fp32 storage
+// deconv5_1 + conv4_1_1 over cat(conv4_2, deconv5_1) as one launch (yf_dcat_kernels.hip)
 bool dcat_has_kernel(int cin, int cskip, int cout);
 size_t dcat_packed_floats();
 void dcat_pack_weights(const float* w_cat /*[136 + 96][96]*/, const float* b_deconv, const float* b_conv, float* out);
 int launch_dcat(const float* x /*conv5_2*/, const float* skip /*conv4_2*/, const float* w_deconv /*4 x mfma_pack_weights[_x3]*/, const float* w_conv,
                 float* out, int h, int w, int Nf, hipStream_t s, int dtype = DT_F32);
+size_t dcat_packed_floats_f16();  // DT_F16: fp16 fragments (the deconv fragments: 4 x mfma_pack_weights_f16)
+void dcat_pack_weights_f16(const float* w_cat, const float* b_deconv, const float* b_conv, float* out);
 size_t dcat_packed_floats_x3();   // DT_F16X3: the split-operand stream
 void dcat_pack_weights_x3(const float* w_cat, const float* b_deconv, const float* b_conv, float* out);
 
