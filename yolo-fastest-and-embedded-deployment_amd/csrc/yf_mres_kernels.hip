@@ -1194,8 +1194,8 @@ bool mres_has_kernel(int cin, int cexp, int cout, bool res, int stride, bool rel
         // 92.1 -> 92.7 k frames/s (one batch at a time 90.5 -> 92.2 k), 320x256 batch 256 363.9 -> 366.9 k (352.8 -> 359.6 k).
         // YF_RES2_X3=1 (developer switch) restores round 3's choice.
         static const bool res2_x3 = getenv("YF_RES2_X3") != nullptr;
-        static const bool res2_h16 = getenv("YF_RES2_H16") != nullptr;   // (A/B) fp16 storage: single fp16 MFMAs, no operand splits
-        return !relu_out && ((dtype == DT_F16X3 && res2_x3) || (dtype == DT_F16 && res2_h16));
+        // (fp16 storage, single fp16 MFMAs, no operand splits: 72 us against the VALU kernel's 61 at 640x512 batch 128 -- round 5)
+        return dtype == DT_F16X3 && !relu_out && res2_x3;
     }
 #define MR(ci, ce, co, rs, st, th, tw, np, nw) \
     if (cin == ci && cexp == ce && cout == co && res == rs && stride == st) return relu_out == mres_relu_out(ci, ce, co, st);
