@@ -690,12 +690,13 @@ __global__ void __launch_bounds__(R_NW * 64) k19r_kernel(K19Args a)
 // ------------------------------------------------------------------------------------------------
 // k19h_kernel (fp16 storage): k19r_kernel's scheme on the fp16 matrix pipe.  Per tap and 16 output pixels
 //   * conv1_8 (K = 4) is two v_mfma_f32_4x4x4_16B_f16 -- 16 independent 4x4 blocks with K = 4 EXACTLY: block (j, p >> 2) = lanes
-//     4b .. 4b+3 multiplies channels 4j .. 4j+3 (second instruction: 16 + 4j ..) by the 4 pixels of its lanes, so lane (p, j) ends up
-//     with channels 4j + i (and 16 + 4j + i) of pixel p in its 2 x 4 result registers; A = the lane's own weight row, B = the pixel's
+//     4b .. 4b+3 multiplies channels 4j .. 4j+3 (second instruction: 16 + 2j, 17 + 2j) by the 4 pixels of its lanes, so lane (p, j) ends up
+//     with channels 4j + i (and 16 + 2j + i, i < 2) of pixel p in its result registers; A = the lane's own weight row, B = the pixel's
 //     four input halves (ONE ds_read_b64 per tap), C = the bias;
-//   * ReLU + RNE to fp16 (4 v_cvt_pk_f16_f32 + 4 v_pk_max_f16) makes those 8 values the lane's f16x8 B operand of ONE K = 32 k-step per
-//     M-tile of conv1_9: k = 8j + e <-> channel 4j + e (e < 4), 16 + 4j + e - 4 (e >= 4, j < 2; k-values 20..23 and 28..31 of lane groups
-//     2, 3 are zero padding) -- the channel permutation lives in the host-side packing of A (k19_pack_weights);
+//   * ReLU + RNE to fp16 (3 v_cvt_pk_f16_f32 + 3 v_pk_max_f16) makes those values the lane's f16x8 B operand of ONE K = 32 k-step per
+//     M-tile of conv1_9: k = 8j + e <-> channel 4j + e (e < 4), 16 + 2j + e - 4 (e = 4, 5; e = 6, 7 are the K padding) -- six live channels in
+//     every lane group, so the second result block costs one conversion and one ReLU, not two; the channel permutation lives in the
+//     host-side packing of A (k19_pack_weights), for conv1_9's own channels 16..23 (rows of its second M-tile) and conv2_1's k order likewise;
 //   * the epilogue (bias + ReLU -> the same k <-> channel map -> ONE K = 32 k-step of conv2_1) stays in registers.
 // Against k19m_kernel<half_t> (138 us at 640x512 batch 128): no region buffers, no workgroup barrier per tile, no phase-1 LDS store traffic;
 // per 16 output pixels 18 v_mfma_f32_16x16x32_f16 + 18 v_mfma_f32_4x4x4_16B_f16 instead of 14 + 9 v_mfma_f32_16x16x4_f32, and the VALU
@@ -719,11 +720,12 @@ constexpr int H_OFF = W9_F16 + W21_F16;                         // the k19h stre
 
 // WPS: waves per SIMD the register budget is set for (HIP's second launch bound): 3 -> 128 VGPRs without spills; 4 -> two weight fragments
 // are reloaded from scratch per item.  Measured at 640x512 batch 128 (tools/scratch/k19h_forms.sh): 4 waves per workgroup x 3 per SIMD
-// 74 us | 4 x 4 80 | 8 x 4 80 | 4 x 2 87 | conv1_8 on K-padded 16x16x16 MFMAs (YF_K19H_C8=0) 80 | k19m_kernel<half_t> 138.
-// Where the 74 us go (timing builds, YF_K19H_DBG): the 18 K = 32 k-steps of an item are 288 of its ~1100 SIMD cycles; the 4x4x4 MFMAs, the
+// 69.6 us | 4 x 4 70.5 | 8 x 4 70.5 | 4 x 2 78.6 | k19m_kernel<half_t> 138 (with four + four conversions per tap: 74 | 80 | 80 | 87, and conv1_8
+// on K-padded 16x16x16 MFMAs, YF_K19H_C8=0, 80).
+// Where the time goes (timing builds, YF_K19H_DBG, at 74 us): the 18 K = 32 k-steps of an item are 288 of its ~1100 SIMD cycles; the 4x4x4 MFMAs, the
 // conversions and the global loads are worth 4 / 10 / 4 us.  The fp16 matrix pipe co-issues with another wave's VALU instruction only
 // every 8 cycles while it is saturated (tools/coissue_probe.hip --f16: v_cvt_pk_f16_f32 / v_pk_max_f16 at 124 per 1000 cycles beside
-// back-to-back 16x16x32 or 4x4x4 MFMAs, against 245 alone), and a tap has 8 such instructions per 48 MFMA cycles.
+// back-to-back 16x16x32 or 4x4x4 MFMAs, against 245 alone), and a tap has 6 such instructions per 48 MFMA cycles.
 template <int R_NW, int WPS>
 __global__ void __launch_bounds__(R_NW * 64, WPS) k19h_kernel(K19Args a)
 {
@@ -751,22 +753,25 @@ __global__ void __launch_bounds__(R_NW * 64, WPS) k19h_kernel(K19Args a)
     f32x4 bias8[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
+        // result row i of lane group jj: channel 4 jj + i (first instruction) / 16 + 2 jj + i, i < 2 (second: rows 2, 3 carry no channel, their
+        // weights and bias are zero and their results are not even converted) -- all four lane groups hold six live channels
+        auto chan = [&](int jj, int i) { return mt == 0 ? 4 * jj + i : i < 2 ? 16 + 2 * jj + i : -1; };
 #if YF_K19H_C8
-        const int cout = 16 * mt + 4 * j + (p & 3);   // the row this lane supplies to its 4x4 block
+        const int cout = chan(j, p & 3);               // the row this lane supplies to its 4x4 block
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w8A[mt][k] = cout < 24 && (mt == 0 || j < 2) ? (half_t)a.w8[k * 24 + cout] : (half_t)0.f;
+        for (int k = 0; k < 4; ++k) w8A[mt][k] = cout >= 0 ? (half_t)a.w8[k * 24 + cout] : (half_t)0.f;
 #else
-        const int cout = 16 * mt + p;                  // row = cout, k = 4j + i: only lane group 0 holds real k-values
+        const int cout = chan(p >> 2, p & 3);          // row p of the 16-row tile; k = 4j + i: only lane group 0 holds real k-values
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w8A[mt][k] = cout < 24 && j == 0 ? (half_t)a.w8[k * 24 + cout] : (half_t)0.f;
+        for (int k = 0; k < 4; ++k) w8A[mt][k] = cout >= 0 && j == 0 ? (half_t)a.w8[k * 24 + cout] : (half_t)0.f;
 #endif
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bias8[mt][r] = mt == 0 || j < 2 ? a.b8[16 * mt + 4 * j + r] : 0.f;   // rows without a channel: weights and bias zero -> k-values 0 after the ReLU
+        for (int r = 0; r < 4; ++r) bias8[mt][r] = chan(j, r) >= 0 ? a.b8[chan(j, r)] : 0.f;
     }
     // conv1_9's and conv2_1's biases are needed once per item: a per-wave LDS table (12 floats per lane group) instead of 12 VGPRs
     if (lane < 48) {
         const int jj = lane / 12, e = lane - 12 * jj;
-        BT[lane] = e < 4 ? a.b9[4 * jj + e] : e < 8 ? (jj < 2 ? a.b9[16 + 4 * jj + e - 4] : 0.f) : (jj < 2 ? a.b21[4 * jj + e - 8] : 0.f);
+        BT[lane] = e < 4 ? a.b9[4 * jj + e] : e < 6 ? a.b9[16 + 2 * jj + e - 4] : e < 8 ? 0.f : (jj < 2 ? a.b21[4 * jj + e - 8] : 0.f);
     }
     const float* const bt = BT + 12 * j;
 
@@ -800,6 +805,7 @@ __global__ void __launch_bounds__(R_NW * 64, WPS) k19h_kernel(K19Args a)
     advance(n2, oy2, sx2);
     const half_t* const xb = SL + p * 4;   // the 8-byte record of pixel p: the tap reads are immediates on top of it
     const f16x4 zero4 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+    const f16x2 zero2 = {(half_t)0.f, (half_t)0.f};
 
     for (; n < a.n_frames;) {
         *reinterpret_cast<f16x4*>(SL + so0) = xin0;
@@ -833,22 +839,23 @@ __global__ void __launch_bounds__(R_NW * 64, WPS) k19h_kernel(K19Args a)
             for (int t = 0; t < 9; ++t) {
                 const int ky = t / 3, kx = t - 3 * ky;
 #if YF_K19H_DBG & 4
-                f16x4 b0 = *reinterpret_cast<const f16x4*>(&d0), b1 = *reinterpret_cast<const f16x4*>(&d1);
+                f16x4 b0 = *reinterpret_cast<const f16x4*>(&d0);
+                f16x2 b1 = *reinterpret_cast<const f16x2*>(&d1);
 #else
                 f16x4 b0 = __builtin_elementwise_max(__builtin_convertvector(d0, f16x4), zero4);
-                f16x4 b1 = __builtin_elementwise_max(__builtin_convertvector(d1, f16x4), zero4);
+                f16x2 b1 = __builtin_elementwise_max(__builtin_convertvector(f32x2{d1[0], d1[1]}, f16x2), zero2);
 #endif
                 if constexpr (BORDER) {
                     if (ky == 0 || kx == 0) {   // input row -1 / column -1: conv1_9's zero padding of conv1_8's output
                         const bool z = (ky == 0 && top) || (kx == 0 && left && p == 0);
                         b0 = z ? zero4 : b0;
-                        b1 = z ? zero4 : b1;
+                        b1 = z ? zero2 : b1;
                     }
                 }
                 if (t + 1 < 9) c8(t + 1, d0, d1);   // the next tap's conv1_8 goes out in front of this tap's k-steps
-                const f16x8 b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const f16x8 b = f16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], (half_t)0.f, (half_t)0.f};
 #if YF_K19H_DBG & 1
-                acc0 += __builtin_convertvector(b0, f32x4) * wA[t][0][0]; acc1 += __builtin_convertvector(b1, f32x4) * wA[t][1][0];
+                acc0 += __builtin_convertvector(b0, f32x4) * wA[t][0][0]; acc1[0] += (float)b1[0] * wA[t][1][0]; acc1[1] += (float)b1[1] * wA[t][1][1];
 #else
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wA[t][0], b, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wA[t][1], b, acc1, 0, 0, 0);
@@ -860,8 +867,8 @@ __global__ void __launch_bounds__(R_NW * 64, WPS) k19h_kernel(K19Args a)
         {
             const f32x4 bias9a = *reinterpret_cast<const f32x4*>(bt), bias9b = *reinterpret_cast<const f32x4*>(bt + 4), bias21 = *reinterpret_cast<const f32x4*>(bt + 8);
             const f16x4 h0 = __builtin_elementwise_max(__builtin_convertvector(acc0 + bias9a, f16x4), zero4);
-            const f16x4 h1 = __builtin_elementwise_max(__builtin_convertvector(acc1 + bias9b, f16x4), zero4);
-            const f16x8 h = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            const f16x2 h1 = __builtin_elementwise_max(__builtin_convertvector(f32x2{acc1[0] + bias9b[0], acc1[1] + bias9b[1]}, f16x2), zero2);
+            const f16x8 h = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], (half_t)0.f, (half_t)0.f};
             const f32x4 w21v = *W21L;
             const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&w21v), h, bias21, 0, 0, 0);
             const int ox = 16 * sx + p;
@@ -896,16 +903,18 @@ void k19_pack_weights(const float* w9, const float* w21, float* out, int wmode)
                         if (x3) ol[((size_t)(g * 2 + mt) * 64 + l) * 8 + e] = f16_lo_bits(v);
                     }
     }
-    if (h16 && !x3) {   // k19h_kernel: per tap ONE K = 32 fragment per M-tile; lane group jj, element e <-> channel 4 jj + e (e < 4), 16 + 4 jj + e - 4 (jj < 2)
+    if (h16 && !x3) {   // k19h_kernel: per tap ONE K = 32 fragment per M-tile
         uint16_t* o9 = reinterpret_cast<uint16_t*>(out + H_OFF);
         uint16_t* o21 = reinterpret_cast<uint16_t*>(out + H_OFF + H_W9);
         for (int l = 0; l < 64; ++l)
             for (int e = 0; e < 8; ++e) {
-                const int m = l & 15, jj = l >> 4, ch = e < 4 ? 4 * jj + e : jj < 2 ? 16 + 4 * jj + e - 4 : -1;
+                // k-value e of lane group jj = row i of conv1_8's two result blocks: channels 4 jj + e (e < 4), 16 + 2 jj + e - 4 (e = 4, 5), none (6, 7);
+                // the second M-tile's rows carry conv1_9's channels 16..23 the same way (row 4 g + i: channel 16 + 2 g + i, i < 2)
+                const int m = l & 15, jj = l >> 4, ch = e < 4 ? 4 * jj + e : e < 6 ? 16 + 2 * jj + e - 4 : -1;
                 for (int tap = 0; tap < 9; ++tap)
                     for (int mt = 0; mt < 2; ++mt) {
-                        const int cout = 16 * mt + m;
-                        o9[((size_t)(tap * 2 + mt) * 64 + l) * 8 + e] = f32_to_f16_bits(ch >= 0 && cout < 24 ? w9[((size_t)tap * 24 + ch) * 24 + cout] : 0.f);
+                        const int cout = mt == 0 ? m : (m & 3) < 2 ? 16 + 2 * (m >> 2) + (m & 3) : -1;
+                        o9[((size_t)(tap * 2 + mt) * 64 + l) * 8 + e] = f32_to_f16_bits(ch >= 0 && cout >= 0 ? w9[((size_t)tap * 24 + ch) * 24 + cout] : 0.f);
                     }
                 o21[(size_t)l * 8 + e] = f32_to_f16_bits(ch >= 0 && m < 8 ? w21[ch * 8 + m] : 0.f);
             }
