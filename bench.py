@@ -49,7 +49,6 @@ FLOPS_PER_FRAME = {256: 236_442_880, 512: 945_771_520}
 # MI355X_MICROARCH.md, chip-level parameters
 HBM_PEAK_GBS = 8000.0          # HBM3E spec
 HBM_STREAM_GBS = 6290.0        # measured float4 copy
-SETTLE_STEPS = 30              # untimed steps of the headline loop in front of its W warm-up steps (clocks, caches); reported as `settle_steps`
 FP32_PEAK_TF = 157.3           # vector fp32 == fp32-input MFMA (64 FLOP/clk/SIMD each; they share the issue rate)
 F16_MFMA_PEAK_TF = 2500.0      # dense fp16/bf16 MFMA
 
@@ -305,57 +304,75 @@ def self_launch(n_gpus):
     return subprocess.call(cmd, env=env)
 
 
-def pin_rank_to_cpus(local_rank, local_world):
-    """One rank = one GPU = one slice of the host's CPUs (VERDICT r4 item 6b): at 8 ranks every host thread issues ~26 k launches/s and
-    must neither migrate nor share a core with another rank's.  Called BEFORE the first GPU call, so the HIP runtime's and RCCL's helper
-    threads inherit the mask.  Which CPUs: those of the NUMA node the rank's GPU hangs off, read from sysfs without touching the GPU
-    (KFD topology node -> PCI address -> numa_node -> cpulist), divided among the ranks whose GPUs share that node; where sysfs does not
-    say, contiguous equal slices of the allowed set.  Returns a small dict for the JSON line (or None: nothing pinned)."""
-    try:
-        allowed = sorted(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        return None
-    if local_world < 2 or len(allowed) < 2 * local_world:
-        return None
+def plan_rank_cpus(local_world, allowed, sysfs="/sys", visible=None):
+    """The CPU slice of EVERY local rank, decided by ONE scheme for all of them: if sysfs resolves the NUMA node of every
+    rank's GPU (KFD topology node -> PCI address -> numa_node -> cpulist; no GPU call) and every node has at least two allowed CPUs per
+    rank hanging off it, each rank gets a share of its GPU's node; if ANY rank cannot be resolved, every rank gets a contiguous equal slice
+    of the allowed set.  (Mixing the two per rank could hand a fallback rank CPUs inside another rank's NUMA share.)  Assumes KFD topology
+    order == HIP device order, narrowed by the first of HIP/ROCR/CUDA_VISIBLE_DEVICES when `visible` is given.  Returns (slices, how)."""
+    allowed = sorted(allowed)
 
     def gpu_numa_nodes():
-        out, base = [], "/sys/class/kfd/kfd/topology/nodes"
+        out, base = [], f"{sysfs}/class/kfd/kfd/topology/nodes"
         for n in sorted(os.listdir(base), key=int):
             props = dict(l.split()[:2] for l in open(f"{base}/{n}/properties") if len(l.split()) >= 2)
             if int(props.get("simd_count", "0")) == 0:
                 continue        # a CPU node
             loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
             bdf = "%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 7)
-            with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            with open(f"{sysfs}/bus/pci/devices/{bdf}/numa_node") as f:
                 out.append(int(f.read()))
         return out
 
     def cpulist(node):
         cpus = []
-        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+        for part in open(f"{sysfs}/devices/system/node/node{node}/cpulist").read().strip().split(","):
             a, _, b = part.partition("-")
             cpus += list(range(int(a), int(b or a) + 1))
         return cpus
 
-    mine, how = None, "contiguous slice of the allowed CPUs"
+    slices, how = None, "contiguous equal slices of the allowed CPUs (all ranks)"
     try:
         nodes = gpu_numa_nodes()
-        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
-        if vis:
-            nodes = [nodes[int(v)] for v in vis.split(",") if v.strip().isdigit() and int(v) < len(nodes)]
-        if local_rank < len(nodes) and nodes[local_rank] >= 0:
-            node = nodes[local_rank]
-            peers = [r for r in range(min(local_world, len(nodes))) if nodes[r] == node]
-            cpus = [c for c in cpulist(node) if c in set(allowed)]
-            per = len(cpus) // len(peers)
-            if per >= 2:
-                k = peers.index(local_rank)
-                mine, how = cpus[k * per:(k + 1) * per], f"NUMA node {node} of the rank's GPU (sysfs), shared by {len(peers)} rank(s)"
+        if visible:
+            nodes = [nodes[int(v)] for v in visible.split(",") if v.strip().isdigit() and int(v) < len(nodes)]
+        if len(nodes) >= local_world and all(n >= 0 for n in nodes[:local_world]):
+            numa = []
+            for r in range(local_world):
+                peers = [q for q in range(local_world) if nodes[q] == nodes[r]]
+                cpus = [c for c in cpulist(nodes[r]) if c in set(allowed)]
+                per = len(cpus) // len(peers)
+                if per < 2:
+                    numa = None
+                    break
+                k = peers.index(r)
+                numa.append(cpus[k * per:(k + 1) * per])
+            if numa is not None:
+                slices, how = numa, "share of the NUMA node of each rank's GPU (sysfs; all ranks)"
     except (OSError, ValueError, IndexError, KeyError):
-        mine = None
-    if not mine:
+        slices = None
+    if slices is None:
         per = len(allowed) // local_world
-        mine = allowed[local_rank * per:(local_rank + 1) * per]
+        slices = [allowed[r * per:(r + 1) * per] for r in range(local_world)]
+    flat = [c for sl in slices for c in sl]
+    assert len(flat) == len(set(flat)) and all(sl for sl in slices), "rank CPU slices must be disjoint and non-empty"
+    return slices, how
+
+
+def pin_rank_to_cpus(local_rank, local_world, sysfs="/sys"):
+    """One rank = one GPU = one slice of the host's CPUs (VERDICT r4 item 6b): at 8 ranks every host thread issues ~26 k launches/s and
+    must neither migrate nor share a core with another rank's.  Called BEFORE the first GPU call, so the HIP runtime's and RCCL's helper
+    threads inherit the mask.  Every process computes ALL ranks' slices (plan_rank_cpus: one scheme for all, disjoint by assertion) and
+    takes its own.  Returns a small dict for the JSON line (or None: nothing pinned)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return None
+    if local_world < 2 or len(allowed) < 2 * local_world:
+        return None
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+    slices, how = plan_rank_cpus(local_world, allowed, sysfs, vis)
+    mine = slices[local_rank]
     try:
         os.sched_setaffinity(0, mine)
     except OSError:
@@ -375,18 +392,27 @@ def launch_roofline(o, dtype, traffic, issue=None):
     pipe names the bound if it holds at least half of the time or more than the parked share, else the launch is latency-bound."""
     t = o["ms"] * 1e-3
     dtype = o.get("kernel_dtype", dtype)   # a f16x3 engine runs the launches without a split-operand kernel in exact fp32
+    issued_frac = None
     if dtype != "f32":
-        issued = o["mfma_flops"] * (3 if dtype == "f16x3" else 1)    # split operands: three MFMAs per k-group are ISSUED
-        floor = max(issued / (F16_MFMA_PEAK_TF * 1e12), o["valu_flops"] / (FP32_PEAK_TF * 1e12))
-        on_mfma = issued / (F16_MFMA_PEAK_TF * 1e12) >= o["valu_flops"] / (FP32_PEAK_TF * 1e12)
+        # split operands (f16x3): three fp16 MFMAs per k-group are ISSUED for one fp32-class product.  `achieved` / `frac` count the USEFUL
+        # flops (one product per k-group) over the peak of the pipe they run on; the issued work decides which pipe is the busier one and is
+        # reported beside it as `issued_frac` (round 5 printed the issued figure as `frac`: 3x too high for every f16x3 launch)
+        mult = 3 if dtype == "f16x3" else 1
+        t_mfma_issued = o["mfma_flops"] * mult / (F16_MFMA_PEAK_TF * 1e12)
+        t_valu = o["valu_flops"] / (FP32_PEAK_TF * 1e12)
+        on_mfma = t_mfma_issued >= t_valu
         peak_tf = F16_MFMA_PEAK_TF if on_mfma else FP32_PEAK_TF
-        flops = issued if on_mfma else o["valu_flops"]
+        flops = o["mfma_flops"] if on_mfma else o["valu_flops"]
+        floor = flops / (peak_tf * 1e12)
+        issued_frac = max(t_mfma_issued, t_valu) / t
     else:
         floor = o["flops"] / (FP32_PEAK_TF * 1e12)
         on_mfma = o["mfma_flops"] >= o["valu_flops"]
         peak_tf, flops = FP32_PEAK_TF, o["flops"]
     r = {"compute_frac": floor / t, "on_mfma": on_mfma, "peak_tf": peak_tf, "achieved_tf": flops / t / 1e12, "hbm_frac": None,
          "hbm_gbs": None}
+    if issued_frac is not None:
+        r["issued_frac"] = issued_frac
     if traffic is not None:
         r["hbm_gbs"] = traffic / t / 1e9
         r["hbm_frac"] = r["hbm_gbs"] / HBM_PEAK_GBS
@@ -417,6 +443,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--settle", type=int, default=0, help="extra untimed steps of the headline loop in front of the W warm-up steps (off by default: "
+                    "the contract's W is the only untimed work; the line reports warmup_effective = W + settle)")
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--res", type=int, default=256, choices=[256, 512])
     ap.add_argument("--chunk", type=int, default=0, help="frames per pass of the layer chain (0 = whole batch)")
@@ -676,7 +704,7 @@ def main():
 
     model, post = make(args.dtype, lanes, branches)
     region_s = []
-    elapsed, raw = timed(model, post, in_flight, args.steps, args.warmup, multi, regions=args.regions, region_times=region_s, settle=SETTLE_STEPS)
+    elapsed, raw = timed(model, post, in_flight, args.steps, args.warmup, multi, regions=args.regions, region_times=region_s, settle=args.settle)
     if args.headline_only:
         if rank == 0:
             print(json.dumps({"metric": "frames/sec end-to-end (headline loop only)", "value": round(n_total * args.steps / elapsed, 1), "unit": "frames/s",
@@ -922,6 +950,8 @@ def main():
                     "peak": HBM_PEAK_GBS if r["bound"] == "hbm" else r["peak_tf"], "unit": unit, "frac": round(r["frac"], 4),
                     "traffic": tr.get(d["name"]), "hbm_frac": None if r["hbm_frac"] is None else round(r["hbm_frac"], 4),
                     "launches": len(ops_), "sum_of_launch_ms": round(sum(o["ms"] for o in ops_), 4)}
+            if "issued_frac" in r:     # fp16 engines: `frac` counts useful flops; the split-operand form issues three MFMAs per product
+                out_["issued_frac"] = round(r["issued_frac"], 4)
             if "counters" in r:
                 out_["counters"] = r["counters"]
                 tot = sum(o["ms"] for o in ops_)
@@ -1046,6 +1076,21 @@ def main():
             roofline.update(achieved=roofline["hbm"]["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=roofline["hbm"]["frac"])
         else:
             roofline.update(achieved=roofline["compute"]["achieved"], peak=dr["peak_tf"], unit="TFLOP/s", frac=roofline["compute"]["frac"])
+        if "issued_frac" in dr:
+            roofline["issued_frac"] = round(dr["issued_frac"], 4)
+        # The three pass-level figures SURVEY.md 8(d) asks a block-fused plan to publish next to the dominant launch's roofline, over the
+        # HEADLINE's own step time (whole job, all launches + post-process, two batches in flight): useful flops over the fp32 issue peak
+        # (fp16 engines: over the peak of the pipe each launch's flops run on, summed as launch floors), counter-measured HBM bytes over
+        # 8 TB/s, and the layer-granular figure (what an unfused network would move; > 1 by construction, NOT a roofline fraction).
+        step_s = elapsed / args.steps
+        per_rank_frames = n_total / world
+        pass_flops = FLOPS_PER_FRAME[args.res] * per_rank_frames
+        roofline["pass_compute_frac"] = round((pass_flops / (FP32_PEAK_TF * 1e12) if args.dtype == "f32" else chain_floor) / step_s, 4)
+        roofline["pass_hbm_frac"] = None if not total_traffic else round(total_traffic * (per_rank_frames / args.batch) / step_s / 1e9 / HBM_PEAK_GBS, 4)
+        roofline["pass_hbm_bytes_per_frame"] = None if not total_traffic else int(total_traffic / args.batch)
+        roofline["layer_granular_equiv_pass"] = round(per_rank_frames * bpf / step_s / 1e9 / HBM_PEAK_GBS, 4)
+        roofline["pass_note"] = ("pass_* = whole pass over the headline's step time: useful flops / fp32 issue peak, PMC bytes / 8 TB/s; "
+                                 "layer_granular_equiv_pass = SURVEY.md 8(d) bytes per frame x frames / step / 8 TB/s (exceeds 1 for a fused plan)")
         if "counters" in dr:      # what the bound was decided on: the launch's issue-side counters of this run (launch_roofline)
             roofline["counters"] = dr["counters"]
             roofline["bound_source"] = ("counters measured in this run (rocprofv3 --pmc child passes: FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU, "
@@ -1061,7 +1106,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "ms_per_frame": round(1e3 * elapsed / args.steps / n_total, 6),
             # `value` is region 0; the same K-step region repeated in the same loop (no re-warm-up, same streams): the spread of the headline
             "repeat_values": [round(n_total * args.steps / t, 1) for t in region_s],
-            "settle_steps": SETTLE_STEPS,
+            "settle_steps": args.settle, "warmup_effective": args.warmup + args.settle,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic" if args.frames == "noise" else "the reference's 20 bundled frames tiled to the batch",
             "config": {"workload": f"YOLO-Fastest {W}x{H} batch={args.batch} fp32 per GPU, synthetic uniform-u8 frames "

@@ -282,6 +282,15 @@ def test_bench_roofline_arithmetic():
     r = b.launch_roofline(o, "f16", 0.1e-3 * 1.0e12)
     assert r["bound"] in ("mfma", "valu") and r["compute_frac"] <= 1.0
     assert abs(r["compute_frac"] - max(12e9 / 2.5e15, 3.73e9 / 157.3e12) / 1e-4) < 1e-9
+    assert abs(r["issued_frac"] - r["compute_frac"]) < 1e-12            # single fp16 operands: issued == useful
+    # split operands (f16x3): three MFMAs per product are ISSUED; `frac` / `achieved` count the useful third, `issued_frac` the rest
+    o3 = dict(ms=0.1, flops=101e9, mfma_flops=100e9, valu_flops=1e9)
+    r1, r3 = b.launch_roofline(o3, "f16", None), b.launch_roofline(o3, "f16x3", None)
+    assert r3["on_mfma"] and abs(r3["compute_frac"] - 100e9 / 2.5e15 / 1e-4) < 1e-9 and abs(r3["frac"] - r1["frac"]) < 1e-12
+    assert abs(r3["issued_frac"] - 3 * r3["compute_frac"]) < 1e-9 and abs(r3["achieved_tf"] - 100e9 / 1e-4 / 1e12) < 1e-6
+    # the issued work (not the useful third) decides which pipe is the busier one
+    o4 = dict(ms=0.1, flops=30e9, mfma_flops=20e9, valu_flops=2e9)       # mfma 8 us useful / 24 us issued, valu 12.7 us
+    assert not b.launch_roofline(o4, "f16", None)["on_mfma"] and b.launch_roofline(o4, "f16x3", None)["on_mfma"]
     assert len(b.source_hash()) == 16
 
 
@@ -329,6 +338,53 @@ def test_plot_one_box_geometry():
     img2 = np.zeros((120, 200, 3), np.uint8)
     plot_one_box([10, 10, 30, 30], img2, color=[0, 0, 255])
     assert tuple(img2[10, 20]) == (255, 0, 0) and tuple(img2[11, 20]) == (0, 0, 0)
+
+
+def _fake_sysfs(root, gpu_numa, node_cpus):
+    """A sysfs tree with one KFD CPU node, len(gpu_numa) GPU nodes (numa_node as given; None: the PCI file is missing) and the NUMA cpulists."""
+    nodes = os.path.join(root, "class/kfd/kfd/topology/nodes")
+    os.makedirs(os.path.join(nodes, "0"))
+    open(os.path.join(nodes, "0", "properties"), "w").write("cpu_cores_count 64\nsimd_count 0\n")
+    for i, numa in enumerate(gpu_numa):
+        os.makedirs(os.path.join(nodes, str(i + 1)))
+        loc = ((0x10 + i) << 8)          # bus 0x10 + i, device 0, function 0
+        open(os.path.join(nodes, str(i + 1), "properties"), "w").write(f"simd_count 1024\nlocation_id {loc}\ndomain 0\n")
+        if numa is not None:
+            d = os.path.join(root, "bus/pci/devices/0000:%02x:00.0" % (0x10 + i))
+            os.makedirs(d)
+            open(os.path.join(d, "numa_node"), "w").write(f"{numa}\n")
+    for node, cl in node_cpus.items():
+        d = os.path.join(root, f"devices/system/node/node{node}")
+        os.makedirs(d)
+        open(os.path.join(d, "cpulist"), "w").write(cl + "\n")
+
+
+def test_rank_cpu_plan_uses_one_scheme_for_all_ranks(tmp_path):
+    """bench.plan_rank_cpus decides the slicing scheme ONCE for all local ranks -- NUMA shares only if every rank's GPU resolves,
+    else contiguous slices for everyone -- and the slices are disjoint either way (a faked sysfs tree; no GPU, no real topology)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    allowed = list(range(64))
+    # all four GPUs resolve: two per NUMA node, each rank half of its node
+    t1 = str(tmp_path / "a"); _fake_sysfs(t1, [0, 0, 1, 1], {0: "0-15,32-47", 1: "16-31,48-63"})
+    sl, how = b.plan_rank_cpus(4, allowed, t1)
+    assert "NUMA" in how and sl[0] == list(range(0, 16)) and sl[1] == list(range(32, 48)) and sl[2] == list(range(16, 32)) and sl[3] == list(range(48, 64))
+    # one GPU reports numa_node -1: EVERY rank falls back to contiguous slices (no mixing of the two schemes)
+    t2 = str(tmp_path / "b"); _fake_sysfs(t2, [0, 0, -1, 1], {0: "0-15,32-47", 1: "16-31,48-63"})
+    sl, how = b.plan_rank_cpus(4, allowed, t2)
+    assert "contiguous" in how and sl == [list(range(16 * r, 16 * r + 16)) for r in range(4)]
+    # a missing PCI entry (OSError) and a node with fewer than two CPUs per rank: the same fallback
+    t3 = str(tmp_path / "c"); _fake_sysfs(t3, [0, None, 1, 1], {0: "0-31", 1: "32-63"})
+    assert "contiguous" in b.plan_rank_cpus(4, allowed, t3)[1]
+    t4 = str(tmp_path / "d"); _fake_sysfs(t4, [0, 0, 0, 0], {0: "0-5", 1: "6-63"})
+    assert "contiguous" in b.plan_rank_cpus(4, allowed, t4)[1]
+    # HIP_VISIBLE_DEVICES narrows and reorders the GPU list before ranks are mapped
+    sl, how = b.plan_rank_cpus(2, allowed, t1, visible="3,0")
+    assert "NUMA" in how and sl[0] == list(range(16, 32)) + list(range(48, 64)) and sl[1] == list(range(0, 16)) + list(range(32, 48))
+    # no sysfs at all
+    sl, how = b.plan_rank_cpus(8, allowed, str(tmp_path / "none"))
+    assert "contiguous" in how and sum(len(x) for x in sl) == 64 and len({c for x in sl for c in x}) == 64
 
 
 def test_bench_pins_each_rank_to_its_own_cpu_slice():
