@@ -276,8 +276,9 @@ int yf_preprocess_u8(yf_handle h, const uint8_t *d_u8, int N, int src_h, int src
  *   src == net size, or exactly 2x (cv::resize turns INTER_LINEAR into INTER_AREA there: the 2x2 box mean (a+b+c+d+2)>>2): fused into the
  *     first kernel's loads -- bit-identical to yf_preprocess_u8 followed by yf_forward, one pass and 3-15 bytes per pixel less HBM traffic;
  *   any other size: one extra pass (yf_cv_preprocess_u8: cv::resize's 8-bit INTER_LINEAR) into net-sized u8 frames at the end of the
- *     workspace, then the fused entry.  The first call for a new source size builds and uploads cv::resize's coefficient tables
- *     (host-synchronous: not inside a stream capture). */
+ *     workspace, then the fused entry.  The first call for a new source size builds cv::resize's coefficient tables with one small
+ *     kernel on `stream` (round 6: no allocation or host synchronisation on this path -- the first resize of an engine allocates the table
+ *     pool once; 32 distinct source sizes are kept, a 33rd evicts behind a device synchronisation). */
 int yf_forward_u8(yf_handle h, const uint8_t *d_u8, int N, int src_h, int src_w, float *d_head_large, float *d_head_small,
                   void *d_workspace, size_t workspace_bytes, void *stream);
 
@@ -285,8 +286,8 @@ int yf_forward_u8(yf_handle h, const uint8_t *d_u8, int N, int src_h, int src_w,
  *     img = cv2.cvtColor(ori_img, cv2.COLOR_BGR2GRAY)        1-channel net, src_c == 3 (cv2.imread's BGR frames)
  *     img = cv2.resize(img, (W, H))                           INTER_LINEAR; exactly 1/2 -> the 2x2 mean; same size -> copy
  * d_src uint8 [N,src_h,src_w(,3)] -> d_dst uint8 [N,H,W(,C_in)] (a 3-channel net keeps BGR order: detect.py:119's reversal is the next step).
- * OpenCV's published 8-bit arithmetic is restated: gray = (B*BY + G*GY + R*RY + half) >> shift with gray_bits 14 (4899/9617/1868; 0 means
- * 14) or 15 (9798/19235/3735: newer 4.x builds); resize with 11-bit coefficients, dst = (((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2) >> 2.
+ * OpenCV's published 8-bit arithmetic is restated: gray = (B*BY + G*GY + R*RY + half) >> shift with gray_bits 15 (9798/19235/3735: OpenCV 4.x;
+ * 0 means 15) or 14 (4899/9617/1868: OpenCV 2.x / 3.x); resize with 11-bit coefficients, dst = (((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2) >> 2.
  * Bit-exact against oracle/cv_oracle.py; parity with an actual OpenCV build is UNPINNED (cv2 is not available where this was built, and an
  * IPP / vendor-HAL build may round differently). */
 int yf_cv_preprocess_u8(yf_handle h, const uint8_t *d_src, int N, int src_h, int src_w, int src_c, int gray_bits, uint8_t *d_dst, void *stream);
@@ -335,11 +336,12 @@ int yf_profile_head_offsets(yf_handle h, int N, size_t *large_off, size_t *small
                                                       profiled (repeated-launch) pass itself to yf_forward's bits */
 int yf_num_launches(yf_handle h, int *out);       /* kernel launches one yf_forward issues            */
 int yf_set_chunk(yf_handle h, int frames);        /* frames per pass of the layer chain (0 = whole batch) */
-int yf_set_split_sums(yf_handle h, int on);       /* 1 (default): at a handful of frames (<= 9, fp32 engines, 320x256 nets) the stride-32 residual chain and the
+int yf_set_split_sums(yf_handle h, int on);       /* 1 (opt in; the default is 0 since round 6): at a handful of frames (<= 9, fp32 engines, 320x256 nets) the stride-32 residual chain and the
                                                       small head split their channel sums over several workgroups and add the partial sums in a fixed
                                                       chunk order (batch-1 latency: DESIGN.md section 4 "Small batches") -- the same numbers in another
                                                       association than the large-batch launches, so a frame's last bits then depend on how many frames
-                                                      travel with it.  0: never; every launch keeps one association at every batch size. */
+                                                      travel with it (held to 2e-4 on the logits and to identical detections on the goldens).  0 (default): never; every
+                                                      launch keeps one association at every batch size. */
 int yf_set_lanes(yf_handle h, int lanes);          /* 1..4: chunks of the batch (yf_set_chunk) run on this many concurrent
                                                      streams, forked from / joined to the caller's stream by events    */
 int yf_set_branches(yf_handle h, int on);         /* 1 (default): the small head's launches (conv5_3 .. head_5) run on a side stream of

@@ -32,7 +32,7 @@ INTER_RESIZE_COEF_SCALE = 1 << INTER_RESIZE_COEF_BITS
 GRAY_COEFFS = {14: (4899, 9617, 1868), 15: (9798, 19235, 3735)}      # (R, G, B)
 
 
-def cvt_bgr2gray(bgr, bits=14):
+def cvt_bgr2gray(bgr, bits=15):
     """cv2.cvtColor(img, cv2.COLOR_BGR2GRAY) for uint8 [..., 3] (B, G, R) -> uint8 [...]."""
     ry, gy, by = GRAY_COEFFS[bits]
     a = np.asarray(bgr).astype(np.int64)
@@ -87,7 +87,7 @@ def resize_linear_u8(img, dsize_wh, _force_linear=False):
     return out[:, :, 0] if img.ndim == 2 else out
 
 
-def cv_pre_process_u8(ori_bgr, input_shape, origin_img_shape, gray_bits=14):
+def cv_pre_process_u8(ori_bgr, input_shape, origin_img_shape, gray_bits=15):
     """detect.py:107-118 up to (not including) the float arithmetic: cv2.imread's frame -> the uint8 image `img` that is normalised next.
     ori_bgr uint8 [h, w, 3]; returns uint8 [H, W] for a 1-channel net on 3-channel originals, else [H, W, 3] (still BGR: the channel
     reversal of :119 belongs to backbone_oracle.preprocess)."""

@@ -113,7 +113,7 @@ def test_fusion_levels_agree_bitwise_for_other_io_params(yf, dev, golden, tag):
                 out[f] = [t.clone() for t in m(x)]
     finally:
         m.fusion = yf.model.DEFAULT_FUSION
-        m.split_sums = True
+        m.split_sums = False
     assert torch.equal(out[1][0], out[2][0]) and torch.equal(out[1][1], out[2][1])
 
 

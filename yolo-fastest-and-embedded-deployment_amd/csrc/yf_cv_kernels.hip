@@ -238,6 +238,34 @@ void launch_mode(const CvArgs& a, unsigned grid, hipStream_t s)
 
 }  // namespace
 
+// cv::resize(INTER_LINEAR, 8-bit): the tables OpenCV's resize() builds on the host -- xofs / ialpha with the edge resets of its horizontal
+// pass, yofs / ibeta with clamped row indices -- from ITS float arithmetic (modules/imgproc/src/resize.cpp; restated in oracle/cv_oracle.py):
+// `scale = 1. / inv_scale` in double, `fx = (float)((dx + 0.5) * scale - 0.5)`, cvFloor, `cvRound(f * 2048)` (half to even).  IEEE double /
+// float operations, built with -ffp-contract=off: the device evaluates exactly what the host expression does.
+__global__ void cv_tables_kernel(int src_h, int src_w, int dst_h, int dst_w, int4* __restrict__ xtab, int4* __restrict__ ytab)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= dst_w + dst_h) return;
+    const bool isx = i < dst_w;
+    const int d = isx ? i : i - dst_w, src = isx ? src_w : src_h, dst = isx ? dst_w : dst_h;
+    const double inv_scale = (double)dst / (double)src, scale = 1.0 / inv_scale;
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int sidx = (int)floorf(f);
+    f -= (float)sidx;
+    if (isx) {   // the horizontal pass resets at the edges (xofs), the vertical pass clamps its row indices
+        if (sidx < 0) { f = 0.f; sidx = 0; }
+        if (sidx >= src - 1) { f = 0.f; sidx = src - 1; }
+    }
+    const int c1 = (int)nearbyintf(f * 2048.f), c0 = (int)nearbyintf((1.f - f) * 2048.f);
+    const int i0 = sidx < 0 ? 0 : (sidx > src - 1 ? src - 1 : sidx), i1 = sidx + 1 < 0 ? 0 : (sidx + 1 > src - 1 ? src - 1 : sidx + 1);
+    (isx ? xtab : ytab)[d] = make_int4(i0, i1, c0, c1);
+}
+
+void launch_cv_tables(int src_h, int src_w, int dst_h, int dst_w, int4* xtab, int4* ytab, hipStream_t s)
+{
+    hipLaunchKernelGGL(cv_tables_kernel, dim3((unsigned)((dst_w + dst_h + 255) / 256)), dim3(256), 0, s, src_h, src_w, dst_h, dst_w, xtab, ytab);
+}
+
 int launch_cv_pre(const CvArgs& a, hipStream_t s)
 {
     if (a.n <= 0 || a.sh <= 0 || a.sw <= 0 || a.dh <= 0 || a.dw <= 0 || (a.dc != 1 && a.dc != 3) || (a.sc != 1 && a.sc != 3)) return -1;

@@ -113,7 +113,7 @@ struct yf_engine {
     size_t esz() const { return dtype == yf::DT_F16 ? 2 : 4; }
     float* d_weights = nullptr;
     float* d_wmfma = nullptr;         // MFMA B fragments of the GEMM-worthy pointwise layers (fused plan)
-    int split_sums = 1;               // yf_set_split_sums: 0 = never re-associate a sum by batch size (a frame's bits do not depend on how many frames travel with it)
+    int split_sums = 0;               // yf_set_split_sums: 0 (default since round 6) = never re-associate a sum by batch size (a frame's bits do not depend on how many frames travel with it)
     float* d_esplit = nullptr;        // scratch of the few-frames forms of the stride-32 chain and the small head (mres_esplit_kernel, mdw2_esplit_kernel): partial sums
     static size_t esplit_lane_floats() { return yf::mres_esplit_scratch_floats() + yf::mdw2_esplit_scratch_floats(); }
     size_t n_floats = 0;
@@ -146,7 +146,11 @@ struct yf_engine {
     hipEvent_t ev_probe[3] = {nullptr, nullptr, nullptr};
     size_t head_l_elems = 0, head_s_elems = 0;
     // cv::resize's per-column / per-row tables of the source sizes seen so far (cv_tables; a handful per engine, LRU)
-    struct CvTab { int sh = 0, sw = 0; int4* d_x = nullptr; int4* d_y = nullptr; long used = 0; } cvtab[4];
+    // one pool of CV_SLOTS x (W + H) entries, allocated at the first resize; a slot is built by a kernel on the caller's stream (no host
+    // synchronisation, capturable) and guarded by an event for callers on another stream
+    enum { CV_SLOTS = 32 };
+    struct CvTab { int sh = 0, sw = 0; bool built = false; hipStream_t stream = nullptr; hipEvent_t ready = nullptr; long used = 0; } cvtab[CV_SLOTS];
+    int4* d_cvpool = nullptr;
     long cv_tick = 0;
     size_t cv_scratch_bytes(int N) const { return (((size_t)N * H * W * input_channel) + 255) & ~(size_t)255; }
     const Plan& plan() const { return plans[fusion]; }
@@ -1014,7 +1018,8 @@ int yf_destroy(yf_handle h)
         if (h->ev_bjoin[l]) (void)hipEventDestroy(h->ev_bjoin[l]);
         if (h->ev_l2b[l]) (void)hipEventDestroy(h->ev_l2b[l]);
     }
-    for (auto& t : h->cvtab) { if (t.d_x) (void)hipFree(t.d_x); if (t.d_y) (void)hipFree(t.d_y); }
+    for (auto& t : h->cvtab) if (t.ready) (void)hipEventDestroy(t.ready);
+    if (h->d_cvpool) (void)hipFree(h->d_cvpool);
     if (h->d_esplit) (void)hipFree(h->d_esplit);
     (void)hipFree(h->d_weights);
     (void)hipFree(h->d_wmfma);
@@ -1111,41 +1116,37 @@ static int u8_mode(yf_handle h, int src_h, int src_w, int* down2)
     return YF_OK;
 }
 
-// cv::resize(INTER_LINEAR, 8-bit): the tables OpenCV's resize() builds on the host -- xofs / ialpha with the edge resets of its horizontal
-// pass, yofs / ibeta with clamped row indices -- from ITS float arithmetic (modules/imgproc/src/resize.cpp; restated in oracle/cv_oracle.py).
-static int cv_tables(yf_engine* e, int sh, int sw, const int4** dx, const int4** dy)
+// cv::resize(INTER_LINEAR, 8-bit) reads per-column / per-row tables (yf_cv_kernels.hip: cv_tables_kernel).  A source size seen before costs
+// nothing; a new one costs ONE small kernel on the caller's stream into a free slot of the engine's pool -- no hipMalloc / hipFree / synchronous
+// copy on the hot path (the 4-slot host-built version paid a device-wide hipFree + 2 hipMalloc + 2 blocking hipMemcpy per evicted
+// size and could not run under stream capture).  Only the 33rd distinct size evicts, behind a device synchronisation (the evicted tables may
+// still be read by earlier launches on other streams).
+static int cv_tables(yf_engine* e, int sh, int sw, const int4** dx, const int4** dy, hipStream_t s)
 {
-    yf_engine::CvTab* slot = &e->cvtab[0];
-    for (auto& t : e->cvtab) {
-        if (t.d_x && t.sh == sh && t.sw == sw) { t.used = ++e->cv_tick; *dx = t.d_x; *dy = t.d_y; return YF_OK; }
-        if (t.used < slot->used) slot = &t;
+    const size_t per = (size_t)e->W + e->H;
+    if (!e->d_cvpool) HIP_OK(hipMalloc(&e->d_cvpool, (size_t)yf_engine::CV_SLOTS * per * sizeof(int4)));
+    int hit = -1, free_slot = -1, lru = 0;
+    for (int i = 0; i < yf_engine::CV_SLOTS; ++i) {
+        auto& t = e->cvtab[i];
+        if (t.built && t.sh == sh && t.sw == sw) { hit = i; break; }
+        if (!t.built && free_slot < 0) free_slot = i;
+        if (t.used < e->cvtab[lru].used) lru = i;
     }
-    auto build = [](int src, int dst, bool reset, std::vector<int4>& out) {
-        const double inv_scale = (double)dst / (double)src, scale = 1.0 / inv_scale;   // `scale_x = 1./inv_scale_x`
-        out.resize(dst);
-        for (int d = 0; d < dst; ++d) {
-            float f = (float)((d + 0.5) * scale - 0.5);
-            int s = (int)floorf(f);
-            f -= (float)s;
-            if (reset) {
-                if (s < 0) { f = 0.f; s = 0; }
-                if (s >= src - 1) { f = 0.f; s = src - 1; }
-            }
-            const int c1 = (int)nearbyintf(f * 2048.f), c0 = (int)nearbyintf((1.f - f) * 2048.f);   // cvRound: half to even
-            const int i0 = s < 0 ? 0 : (s > src - 1 ? src - 1 : s), i1 = s + 1 < 0 ? 0 : (s + 1 > src - 1 ? src - 1 : s + 1);
-            out[d] = make_int4(i0, i1, c0, c1);
-        }
-    };
-    std::vector<int4> hx, hy;
-    build(sw, e->W, true, hx);
-    build(sh, e->H, false, hy);
-    if (slot->d_x) { (void)hipFree(slot->d_x); (void)hipFree(slot->d_y); slot->d_x = slot->d_y = nullptr; }
-    HIP_OK(hipMalloc(&slot->d_x, hx.size() * sizeof(int4)));
-    HIP_OK(hipMalloc(&slot->d_y, hy.size() * sizeof(int4)));
-    HIP_OK(hipMemcpy(slot->d_x, hx.data(), hx.size() * sizeof(int4), hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(slot->d_y, hy.data(), hy.size() * sizeof(int4), hipMemcpyHostToDevice));
-    slot->sh = sh; slot->sw = sw; slot->used = ++e->cv_tick;
-    *dx = slot->d_x; *dy = slot->d_y;
+    int k = hit;
+    if (hit < 0) {
+        k = free_slot >= 0 ? free_slot : lru;
+        auto& t = e->cvtab[k];
+        if (free_slot < 0) HIP_OK(hipDeviceSynchronize());
+        if (!t.ready) HIP_OK(hipEventCreateWithFlags(&t.ready, hipEventDisableTiming));
+        yf::launch_cv_tables(sh, sw, e->H, e->W, e->d_cvpool + k * per, e->d_cvpool + k * per + e->W, s);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipEventRecord(t.ready, s));
+        t.sh = sh; t.sw = sw; t.built = true; t.stream = s;
+    } else if (e->cvtab[k].stream != s) {
+        HIP_OK(hipStreamWaitEvent(s, e->cvtab[k].ready, 0));
+    }
+    e->cvtab[k].used = ++e->cv_tick;
+    *dx = e->d_cvpool + k * per; *dy = e->d_cvpool + k * per + e->W;
     return YF_OK;
 }
 
@@ -1157,8 +1158,8 @@ static int cv_pre(yf_engine* e, const uint8_t* d_src, int N, int src_h, int src_
     yf::CvArgs a{};
     a.src = d_src; a.dst = d_dst; a.n = N; a.sh = src_h; a.sw = src_w; a.sc = src_c; a.dh = e->H; a.dw = e->W; a.dc = e->input_channel;
     if (e->input_channel == 1 && src_c == 3) {
-        if (gray_bits != 0 && gray_bits != 14 && gray_bits != 15) return fail(YF_E_INVALID, "gray_bits must be 14, 15 or 0 (= 14)");
-        a.gray = gray_bits == 15 ? 15 : 14;
+        if (gray_bits != 0 && gray_bits != 14 && gray_bits != 15) return fail(YF_E_INVALID, "gray_bits must be 14, 15 or 0 (= 15)");
+        a.gray = gray_bits == 14 ? 14 : 15;
     } else if (e->input_channel == src_c) {
         a.gray = 0;
     } else {
@@ -1167,7 +1168,7 @@ static int cv_pre(yf_engine* e, const uint8_t* d_src, int N, int src_h, int src_
     }
     a.mode = (src_h == e->H && src_w == e->W) ? 0 : (src_h == 2 * e->H && src_w == 2 * e->W) ? 1 : 2;
     if (a.mode == 2)
-        if (int rc = cv_tables(e, src_h, src_w, &a.xtab, &a.ytab)) return rc;
+        if (int rc = cv_tables(e, src_h, src_w, &a.xtab, &a.ytab, s)) return rc;
     if (yf::launch_cv_pre(a, s)) return fail(YF_E_INVALID, "no pre-process kernel for this combination");
     HIP_OK(hipGetLastError());
     return YF_OK;

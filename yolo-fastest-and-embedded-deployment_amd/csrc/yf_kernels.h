@@ -205,6 +205,8 @@ struct CvArgs {
     const int4* ytab;           // [dh] {y0, y1, b0, b1}
 };
 int launch_cv_pre(const CvArgs& a, hipStream_t s);
+// cv::resize's xofs / ialpha and yofs / ibeta tables for one source size, built ON THE DEVICE (stream-ordered, no allocation, capturable)
+void launch_cv_tables(int src_h, int src_w, int dst_h, int dst_w, int4* xtab, int4* ytab, hipStream_t s);
 void launch_preprocess(const uint8_t* in, float* out, long N, int H, int W, int down2, hipStream_t s, int channels = 1);   // channels 3: HWC BGR in, NCHW RGB planes out
 
 struct FbArgs {

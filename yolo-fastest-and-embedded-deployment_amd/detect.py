@@ -78,7 +78,7 @@ class Detect_YOLO():
         u8 = self.model.cv_preprocess_u8(bgr, self.input_shape)
         return preprocess_u8(self.model, u8, self.input_shape)
 
-    def detect_bgr_u8(self, bgr, kmax=64, gray_bits=14):
+    def detect_bgr_u8(self, bgr, kmax=64, gray_bits=None):
         """bgr: uint8 GPU tensor [N,h,w,3] as cv2.imread returns frames, any size.  The whole of detect.py:108-182 on the device; per-frame
         lists in the coordinates of `origin_img_shape` (after __adjust_coord, :131-139)."""
         pred = self.model.forward_bgr_u8(bgr, self.input_shape, gray_bits=gray_bits)

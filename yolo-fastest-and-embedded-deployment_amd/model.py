@@ -52,7 +52,7 @@ class _Engine:
         self.H, self.W, self.max_batch, self.device_index = H, W, max_batch, device_index
         self._ws = None
         self.chunk, self.lanes, self.branches = 0, 2, 1     # the C side's defaults (yf_engine: chunk 0, lanes 2, branches on)
-        self.split_sums = 1
+        self.split_sums = 0
 
     def workspace(self, N, device):
         need = ctypes.c_size_t()
@@ -125,10 +125,15 @@ class YoloFastest(nn.Module):
         self.fusion = DEFAULT_FUSION
         self.lanes = 2   # concurrent streams over chunks of the batch (chunk 0 = one chunk per lane); see yf_set_lanes
         self.branches = 1  # 1: the small head's launches run on a side stream beside the large head's; see yf_set_branches
-        # True (default): at <= 9 frames the stride-32 chain and the small head split their channel sums over several workgroups (batch-1 latency
-        # 0.34 -> 0.29 ms) -- the same numbers in another association than at larger batches.  False: a frame's bits never depend on the batch size
+        # False (default since round 6): a frame's bits never depend on the batch it travels in.  True (opt in, batch-1 latency 0.33 -> 0.29 ms):
+        # at <= 9 frames the stride-32 chain and the small head split their channel sums over several workgroups -- the same numbers in another
+        # association than at larger batches (<= 2e-4 on the logits; a score sitting exactly at conf_thres could then flip with the batch size)
         # (yf_set_split_sums; DESIGN.md section 4 "Small batches").
-        self.split_sums = True
+        self.split_sums = False
+        # cv2.cvtColor(BGR2GRAY)'s fixed-point coefficient set on the device (yf_cv_preprocess_u8): 15 = OpenCV 4.x's RGB2Gray<uchar> (9798 / 19235 /
+        # 3735, shift 15: what a current `pip install opencv-python` gives the reference), 14 = OpenCV 2.x / 3.x (4899 / 9617 / 1868, shift 14).  They
+        # differ by at most 1 LSB on colour frames; gray frames (the bundled test_data) come out identical.  io_params["gray_bits"] overrides.
+        self.gray_bits = int(io_params.get("gray_bits", 15)) if isinstance(io_params, dict) else 15
         # activation storage / pointwise-GEMM operand type: torch.float32, or torch.float16 (BASELINE configs[2]: fp16 in HBM,
         # fp16 MFMA, fp32 accumulate).  `model.half()` selects fp16 like it would for the reference module; setting
         # `model.storage_dtype = torch.float16` keeps the fp32 master weights for the BN fold (more accurate).
@@ -258,7 +263,7 @@ class YoloFastest(nn.Module):
             return hl.half(), hs.half()
         return hl, hs
 
-    def forward_bgr_u8(self, bgr, input_shape, gray_bits=14, slot=0):
+    def forward_bgr_u8(self, bgr, input_shape, gray_bits=None, slot=0):
         """model(__pre_process(frame)) for cv2.imread's frames (detect.py:108-127): uint8 GPU tensor [N,h,w,3] in BGR order and of ANY size
         -> cvtColor(BGR2GRAY) for a 1-channel net + cv2.resize to the net's input (yf_cv_preprocess_u8, OpenCV's 8-bit arithmetic) +
         (v - 128) / 255 fused into the first kernel -> (head_large, head_small).  gray_bits: OpenCV's 14- or 15-bit gray coefficients."""
@@ -274,11 +279,11 @@ class YoloFastest(nn.Module):
         hs = torch.empty((N, self.num_out, H // 32, W // 32), dtype=torch.float32, device=bgr.device)
         ws = e.workspace(N, bgr.device)
         stream = torch.cuda.current_stream(bgr.device).cuda_stream
-        _lib.check(e.lib.yf_forward_bgr_u8(e.handle, bgr.data_ptr(), N, bgr.shape[1], bgr.shape[2], int(gray_bits), hl.data_ptr(), hs.data_ptr(),
+        _lib.check(e.lib.yf_forward_bgr_u8(e.handle, bgr.data_ptr(), N, bgr.shape[1], bgr.shape[2], int(self.gray_bits if gray_bits is None else gray_bits), hl.data_ptr(), hs.data_ptr(),
                                            ws.data_ptr(), ws.numel(), ctypes.c_void_p(stream)))
         return hl, hs
 
-    def cv_preprocess_u8(self, src, input_shape, gray_bits=14):
+    def cv_preprocess_u8(self, src, input_shape, gray_bits=None):
         """detect.py:110-116 alone (yf_cv_preprocess_u8): uint8 GPU frames [N,h,w] or [N,h,w,3] of any size -> the uint8 frames
         [N,H,W] ([N,H,W,3] for a 3-channel net) that `(img - 128.0) / 255.0` is applied to next."""
         if not src.is_cuda or src.dtype != torch.uint8 or src.dim() not in (3, 4):
@@ -290,7 +295,7 @@ class YoloFastest(nn.Module):
         shape = (N, H, W) if self.input_channel == 1 else (N, H, W, self.input_channel)
         dst = torch.empty(shape, dtype=torch.uint8, device=src.device)
         stream = torch.cuda.current_stream(src.device).cuda_stream
-        _lib.check(e.lib.yf_cv_preprocess_u8(e.handle, src.data_ptr(), N, src.shape[1], src.shape[2], sc, int(gray_bits), dst.data_ptr(),
+        _lib.check(e.lib.yf_cv_preprocess_u8(e.handle, src.data_ptr(), N, src.shape[1], src.shape[2], sc, int(self.gray_bits if gray_bits is None else gray_bits), dst.data_ptr(),
                                              ctypes.c_void_p(stream)))
         return dst
 
