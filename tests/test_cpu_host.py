@@ -158,12 +158,18 @@ def test_config_mirror():
     assert abs(training.cosine_factor(15, 30) - 0.6) < 1e-12
 
 
-def test_ncnn_model_files_give_the_same_blob(sd):
-    """the reference's shipped ncnn .param/.bin (BN already folded by its converter) packs to the same
-    blob as the .pth folded here -- to fp32 rounding of two different fold orders."""
+W512 = os.path.join(ROOT, "yolo-fastest-and-embedded-deployment_amd", "assets", "weights", "yolo_fastest_512x640_epoch27.pth")
+SHIPPED = {"256x320": W256, "512x640": W512}     # models/{ncnn,onnx}/<size>/ of the reference, copied (data) to tests/golden/{ncnn,onnx}/
+
+
+@pytest.mark.parametrize("size", ["256x320", "512x640"])
+def test_ncnn_model_files_give_the_same_blob(size):
+    """the reference's shipped ncnn .param/.bin (BN already folded by its converter; both sizes, models/ncnn/256x320 and
+    /512x640) packs to the same blob as the .pth of that size folded here -- to fp32 rounding of two different fold orders."""
+    sd = bo.load_state_dict(SHIPPED[size])
     pth = packer.unpack(packer.pack_state_dict(sd))
-    ncnn = packer.unpack(packer.pack_ncnn(os.path.join(ROOT, "tests", "golden", "ncnn", "yolo_fastest_256x320.param"),
-                                          os.path.join(ROOT, "tests", "golden", "ncnn", "yolo_fastest_256x320.bin")))
+    ncnn = packer.unpack(packer.pack_ncnn(os.path.join(ROOT, "tests", "golden", "ncnn", f"yolo_fastest_{size}.param"),
+                                          os.path.join(ROOT, "tests", "golden", "ncnn", f"yolo_fastest_{size}.bin")))
     assert list(pth) == list(ncnn)
     for k in pth:
         for f in ("kind", "cin", "cout", "k", "stride", "relu"):
@@ -230,11 +236,13 @@ def test_validation_bookkeeping_matches_the_oracle(golden):
         assert got == float(want) or (got != got and float(want) != float(want)), (trial, n)   # 0 targets and 0 TP: nan in both
 
 
-def test_onnx_export_gives_the_same_state_dict(sd):
-    """the reference's shipped ONNX export (models/onnx/256x320, copied to tests/golden/onnx) read with the
-    built-in protobuf reader is the shipped .pth, key for key and bit for bit, hence the same blob."""
+@pytest.mark.parametrize("size", ["256x320", "512x640"])
+def test_onnx_export_gives_the_same_state_dict(size):
+    """the reference's shipped ONNX exports (models/onnx/256x320 and /512x640, copied to tests/golden/onnx) read with the
+    built-in protobuf reader are the shipped .pth of that size, key for key and bit for bit, hence the same blob."""
     from yolo_fastest_amd import packer
-    got = packer.read_onnx(os.path.join(ROOT, "tests", "golden", "onnx", "yolo_fastest_256x320.onnx"))
+    sd = bo.load_state_dict(SHIPPED[size])
+    got = packer.read_onnx(os.path.join(ROOT, "tests", "golden", "onnx", f"yolo_fastest_{size}.onnx"))
     assert set(got) == set(sd)
     for k, v in sd.items():
         if v.is_floating_point():

@@ -468,15 +468,30 @@ def test_int32_saturation_of_box_corners(models, dev):
     assert len(differ) == 2 and all(want[i][6] in (1, 2) for i in differ)
 
 
-def test_weights_from_ncnn_files(yf, golden, dev):
-    """The engine fed from the reference's ncnn .param/.bin instead of the .pth: same heads as the reference."""
-    io = yf.io_params_for(256)
-    m = yf.YoloFastest(io).eval().load_ncnn(os.path.join(ROOT, "tests", "golden", "ncnn", "yolo_fastest_256x320.param"),
-                                            os.path.join(ROOT, "tests", "golden", "ncnn", "yolo_fastest_256x320.bin")).to(dev)
-    g = golden("golden_256")
+@pytest.mark.parametrize("res", [256, 512])
+def test_weights_from_ncnn_files(yf, golden, dev, res):
+    """The engine fed from the reference's ncnn .param/.bin (both shipped sizes) instead of the .pth: same heads as the reference."""
+    io = yf.io_params_for(res)
+    size = "256x320" if res == 256 else "512x640"
+    m = yf.YoloFastest(io).eval().load_ncnn(os.path.join(ROOT, "tests", "golden", "ncnn", f"yolo_fastest_{size}.param"),
+                                            os.path.join(ROOT, "tests", "golden", "ncnn", f"yolo_fastest_{size}.bin")).to(dev)
+    g = golden(f"golden_{res}")
     with torch.no_grad():
         hl, hs = m(_x(g["input_u8"], dev))
-    _check_heads(hl, hs, g["head_large"], g["head_small"], g["head_large_f64"], g["head_small_f64"])
+    _check_heads(hl, hs, g["head_large"], g["head_small"], g["head_large_f64"], g["head_small_f64"], res == 256)
+
+
+@pytest.mark.parametrize("res", [256, 512])
+def test_weights_from_onnx_files(yf, models, golden, dev, res):
+    """... and from the shipped ONNX exports: the state-dict they hold is the .pth's, so the heads are the .pth engine's bit for bit."""
+    io = yf.io_params_for(res)
+    size = "256x320" if res == 256 else "512x640"
+    m = yf.YoloFastest(io).eval().load_onnx(os.path.join(ROOT, "tests", "golden", "onnx", f"yolo_fastest_{size}.onnx")).to(dev)
+    g = golden(f"golden_{res}")
+    x = _x(g["input_u8"][:6], dev)
+    with torch.no_grad():
+        a, b = m(x), models[res][0](x)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
 def test_validation_path_decode_and_nms(yf, models, golden, dev):
@@ -1085,6 +1100,20 @@ def test_batch_detect_writes_the_references_results(yf, golden, dev, res, tmp_pa
                 assert np.abs(ours - c).max() <= 40, (name, j, i, ours)
                 # and it is what the reference's own result image shows at that pixel (JPEG tolerance on both sides)
                 assert np.abs(ours - r[f"edge_rgb_{res}"][k, j, i].astype(np.int32)).max() <= 60, (name, j, i)
+    # with more than one batch the driver goes through BatchPipeline (two batches in flight); one batch at a time
+    # (in_flight=1, and a single batch of all 20) writes the same flags, labels and images
+    piped_labels, piped_flags = dict(det.last_labels), [pat.match(l).group(2) for l in lines[:20]]
+    assert det.model.lanes == 2 and det.model.branches == 1        # the pipeline's engine settings were restored
+    for kw in (dict(batch_size=8, in_flight=1), dict(batch_size=32)):
+        del lines[:]
+        out2 = tmp_path / ("serial_%d" % kw["batch_size"])
+        out2.mkdir()
+        det.batch_detect(data, str(out2), **kw)
+        assert det.last_labels == piped_labels and [pat.match(l).group(2) for l in lines[:20]] == piped_flags and len(lines) == 21
+        for name in names[:4]:
+            a = np.asarray(Image.open(os.path.join(str(tmp_path), "result_" + name)))
+            b = np.asarray(Image.open(os.path.join(str(out2), "result_" + name)))
+            assert np.array_equal(a, b), name
 
 
 def test_two_models_of_different_sizes_in_one_process(yf, models, golden, dev):

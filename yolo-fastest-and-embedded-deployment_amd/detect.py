@@ -96,32 +96,24 @@ class Detect_YOLO():
             origin = self.origin_img_shape
         return self.post_process.detect(pred, kmax=kmax, origin_shape=origin)
 
-    def batch_detect(self, data_path, result_path, batch_size=256):
+    def batch_detect(self, data_path, result_path, batch_size=256, in_flight=2):
+        """detect.py:141-192 over a directory, `batch_size` images per pass.  More than one batch: the batches go through `BatchPipeline`
+        (`in_flight` of them on the GPU at a time, each on its own stream and engine -- the throughput mode bench.py measures) while the host
+        decodes the next batch's files and writes the previous batch's result images; the per-image times in the log lines are then the
+        batch's DEVICE times (HIP events around model and post-process, divided by the frames of the batch).  Same results, same log format
+        and order as one batch at a time (`in_flight=1`)."""
         img_list = sorted(os.listdir(data_path))   # the reference iterates os.listdir order; its logs show it sorted
         num = len(img_list)
-        avg_time = 0.0
         self.last_labels = {}
-        for b0 in range(0, num, batch_size):
-            names = img_list[b0:b0 + batch_size]
-            bgrs, oris = zip(*[self._read_bgr(os.path.join(data_path, n)) for n in names])
-            if len({b.shape for b in bgrs}) == 1:
-                x = self._pre_process(torch.from_numpy(np.stack(bgrs)).to(self.device))
-            else:                      # frames of different sizes: the resize brings them to one
-                x = torch.cat([self._pre_process(torch.from_numpy(b[None]).to(self.device)) for b in bgrs])
-            torch.cuda.synchronize(self.device)
-            start_time = time.time()
-            with torch.no_grad():
-                pred = self.model(x)
-            torch.cuda.synchronize(self.device)
-            time_mark = time.time()
-            infer_time = (time_mark - start_time) * 1000 / len(names)
-            origin = None
-            if list(self.input_shape[0:2]) != list(self.origin_img_shape[0:2]):
-                origin = self.origin_img_shape
-            results = self.post_process.detect(pred, origin_shape=origin)
-            post_process_time = (time.time() - time_mark) * 1000 / len(names)
+        origin = None
+        if list(self.input_shape[0:2]) != list(self.origin_img_shape[0:2]):
+            origin = self.origin_img_shape
+        batches = [img_list[b0:b0 + batch_size] for b0 in range(0, num, batch_size)]
+        state = {"avg": 0.0}
+
+        def report(names, oris, results, infer_time, post_process_time):
             total_time = infer_time + post_process_time
-            avg_time += total_time * len(names)
+            state["avg"] += total_time * len(names)
             for filename, ori, boxes in zip(names, oris, results):
                 if len(boxes) == 0:
                     self.last_labels[filename] = self._save(os.path.join(result_path, "result_" + filename), ori, [])
@@ -131,7 +123,66 @@ class Detect_YOLO():
                 self.last_labels[filename] = self._save(os.path.join(result_path, "result_" + filename), ori, boxes)
                 self.logger.info("image_name:%s -> detect finished, infer time:%.2fms, post_process time:%.2fms, "
                                  "total time:%.2fms" % (filename, infer_time, post_process_time, total_time))
-        self.logger.info("detect avg_time: %.2fms" % (avg_time / max(num, 1)))
+
+        def load(names):
+            bgrs, oris = zip(*[self._read_bgr(os.path.join(data_path, n)) for n in names])
+            return bgrs, oris, len({b.shape for b in bgrs}) == 1
+
+        if len(batches) > 1 and in_flight > 1:
+            from .pipeline import BatchPipeline
+            saved = (self.model.lanes, self.model.branches)
+            pipe = BatchPipeline(self.model, self.post_process, depth=in_flight, kmax=64, origin_shape=origin, lanes=1, branches=0)
+            pending = []
+
+            def finish(item):
+                names, oris, ticket, ev = item
+                raw = ticket.synchronize()
+                most = int(raw["counts"].max().item()) if raw["counts"].numel() else 0
+                if most > raw["boxes"].shape[1]:      # more survivors than the first attempt reserved: once more with room for all (post.detect does the same)
+                    raw = self.post_process.detect_raw((raw["head_large"], raw["head_small"]), kmax=most, origin_shape=origin)
+                results = self.post_process.to_lists(raw)
+                report(names, oris, results, ev[0].elapsed_time(ev[1]) / len(names), ev[1].elapsed_time(ev[2]) / len(names))
+
+            try:
+                for names in batches:
+                    bgrs, oris, same = load(names)
+                    if same:       # cv2.imread-shaped frames of one size: cvtColor + resize + (v - 128) / 255 inside the batch's own stream
+                        x = torch.from_numpy(np.stack(bgrs)).to(self.device)
+                    else:          # frames of different sizes: the resize brings them to one
+                        x = torch.cat([self._pre_process(torch.from_numpy(b[None]).to(self.device)) for b in bgrs])
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                    ev[0].record()
+
+                    def mid(pred, ev=ev):
+                        ev[1].record()
+                        return pred
+                    ticket = pipe.submit(x, mid=mid, then=lambda out, ev=ev: ev[2].record())
+                    pending.append((names, oris, ticket, ev))
+                    if len(pending) >= in_flight:
+                        finish(pending.pop(0))
+                while pending:
+                    finish(pending.pop(0))
+            finally:
+                pipe.drain()
+                self.model.lanes, self.model.branches = saved
+        else:
+            for names in batches:
+                bgrs, oris, same = load(names)
+                if same:
+                    x = self._pre_process(torch.from_numpy(np.stack(bgrs)).to(self.device))
+                else:
+                    x = torch.cat([self._pre_process(torch.from_numpy(b[None]).to(self.device)) for b in bgrs])
+                torch.cuda.synchronize(self.device)
+                start_time = time.time()
+                with torch.no_grad():
+                    pred = self.model(x)
+                torch.cuda.synchronize(self.device)
+                time_mark = time.time()
+                infer_time = (time_mark - start_time) * 1000 / len(names)
+                results = self.post_process.detect(pred, origin_shape=origin)
+                post_process_time = (time.time() - time_mark) * 1000 / len(names)
+                report(names, oris, results, infer_time, post_process_time)
+        self.logger.info("detect avg_time: %.2fms" % (state["avg"] / max(num, 1)))
 
     def _save(self, path, ori, boxes):
         """detect.py:184-190: one box + label per detection (plot.plot_one_box), then the image file.  Returns the label
