@@ -221,8 +221,19 @@ def test_deep_stage_fusion_is_bitwise_neutral(yf, dev, res, batch, prec, monkeyp
     assert launches[2] < launches[1], launches
 
 
+@pytest.fixture(params=[2, 1], ids=["one-wg-per-frame", "one-wg-per-frame-and-class"])
+def post_split(request, models):
+    """Both forms of the post-process launch (yf_set_post_split): 2 = one workgroup per frame (post_kernel), 1 = one per frame and class with the
+    frame's last workgroup assembling the classes (post_split_kernel, round 6: dense frames).  0 = auto (by kmax) is the default and is restored."""
+    for m, _, _ in models.values():
+        m.post_split = request.param
+    yield request.param
+    for m, _, _ in models.values():
+        m.post_split = 0
+
+
 @pytest.mark.parametrize("name", ["golden_256", "golden_512", "golden_dense_256", "golden_dense_512"])
-def test_post_process_bit_exact_on_reference_logits(models, golden, dev, name):
+def test_post_process_bit_exact_on_reference_logits(models, golden, dev, name, post_split):
     res = 256 if name.endswith("256") else 512
     _, post, _ = models[res]
     g = golden(name)
@@ -881,8 +892,8 @@ def test_fp16_other_input_sizes_and_u8(yf, dev):
 
 
 @pytest.mark.parametrize("res", [256, 512])
-def test_post_process_randomised_against_c_oracle(yf, models, dev, res):
-    """Windowed NMS / 16-wave post kernel against oracle/post_oracle.c (the reference's loop, restated) on random logit fields:
+def test_post_process_randomised_against_c_oracle(yf, models, dev, res, post_split):
+    """Windowed NMS / 16-wave post kernel (both launch forms: post_split) against oracle/post_oracle.c (the reference's loop, restated) on random logit fields:
     sparse to very dense, thresholds at the extremes (nms_thres 0 and 1, a NEGATIVE one -- where even disjoint boxes suppress each
     other --, conf_thres low), quantised confidences (many exact ties), tiny boxes (zero-area -> the reference's ZeroDivisionError
     path must agree too).  Bit-exact boxes, classes and survivor order."""
@@ -921,6 +932,63 @@ def test_post_process_randomised_against_c_oracle(yf, models, dev, res):
                 assert np.array_equal(raw["src"][f, :n].cpu().numpy(), r["src"]), (res, ci, f)
                 assert np.array_equal(raw["boxes"][f, :n].cpu().numpy(), r["box"]), (res, ci, f)
                 assert np.array_equal(raw["cls"][f, :n].cpu().numpy(), r["cls"]), (res, ci, f)
+
+
+def test_dense_post_process_per_class_workgroups_give_the_same_records(yf, models, dev):
+    """the per-(frame, class) form of the post-process (post_split_kernel; chosen automatically at kmax >= 256) against the
+    one-workgroup-per-frame form on the same logits: identical counts, boxes, classes, sources, scores -- on dense synthetic fields (SURVEY.md
+    8(d).5's recipe), with a capacity overflow (the count stays the true number, the first kmax records are stored), with the packed record
+    block, inside yf_detect on two lanes (each lane's frames use their own scratch rows), and launched repeatedly (the ticket is reset)."""
+    m, post, io = models[512]
+    H, W = io["input_shape"][:2]
+    N = 10
+    hl, hs = [], []
+    for f in range(N):
+        g = np.random.default_rng(500 + f)
+        for (h, w), dst in (((H // 16, W // 16), hl), ((H // 32, W // 32), hs)):
+            t = np.empty((3, 8, h, w), np.float32)
+            t[:, 0:2] = g.normal(0.0, 1.0, (3, 2, h, w)); t[:, 2:4] = g.normal(0.0, 0.5, (3, 2, h, w))
+            t[:, 4] = g.normal(-1.0, 1.5, (3, h, w)); t[:, 5:8] = g.normal(0.0, 2.0, (3, 3, h, w))
+            if f == 3:
+                t[:, 5] += 50.0        # one frame whose candidates all fall into class 0 (two workgroups of the frame find nothing)
+            if f == 4:
+                t[:, 4] = -30.0        # one frame without candidates
+            dst.append(t.reshape(24, h, w))
+    pred = (torch.from_numpy(np.stack(hl)).to(dev), torch.from_numpy(np.stack(hs)).to(dev))
+    m(_x(np.zeros((1, H, W), np.uint8), dev))
+    keys = ("counts", "boxes", "scores", "cls", "src")
+
+    def same(a, b, kmax):
+        assert torch.equal(a["counts"], b["counts"])
+        valid = torch.arange(kmax, device=dev)[None, :] < a["counts"].clamp(max=kmax)[:, None]
+        for k in keys[1:]:
+            assert torch.equal(a[k][valid], b[k][valid]), k
+    refs = {}
+    try:
+        for kmax in (1024, 100):             # 100: fewer records than survivors (capacity overflow)
+            m.post_split = 2
+            ref = refs[kmax] = {k: v.clone() for k, v in post.detect_raw(pred, kmax=kmax).items() if k in keys}
+            assert int(ref["counts"].max()) > 200 and int(ref["counts"][4]) == 0
+            m.post_split = 1
+            for rep in range(3):
+                got = post.detect_raw(pred, kmax=kmax)
+                same(ref, got, kmax)
+            same(ref, post.detect_raw(pred, kmax=kmax, packed=True), kmax)
+        m.post_split = 0                     # auto: kmax 1024 takes the per-class form, kmax 100 the per-frame form
+        for kmax in (1024, 100):
+            same(refs[kmax], post.detect_raw(pred, kmax=kmax), kmax)
+        # inside yf_detect, two lanes: low thresholds make the shipped model's own logits dense enough to matter
+        rng = np.random.default_rng(9)
+        x = _x(rng.integers(0, 256, (6, H, W), dtype=np.uint8), dev)
+        lowpost = yf.YOLO_post_process(0.001, 0.9, 3, 3, io["anchors"], io["input_shape"]).bind(m)
+        m.post_split = 2
+        a = {k: v.clone() for k, v in lowpost.detect_raw_from_input(x, kmax=2048).items() if k in keys}
+        assert int(a["counts"].min()) > 20
+        m.post_split = 1
+        for rep in range(2):
+            same(a, lowpost.detect_raw_from_input(x, kmax=2048), 2048)
+    finally:
+        m.post_split = 0
 
 
 @pytest.mark.parametrize("seed", [0, 1])

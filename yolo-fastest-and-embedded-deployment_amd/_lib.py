@@ -108,6 +108,7 @@ _SIGS = {
     "yf_set_branches": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "yf_set_lanes": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "yf_set_split_sums": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "yf_set_post_split": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "yf_set_profile_repeats": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "yf_cv_preprocess_u8": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "yf_forward_bgr_u8": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p,

@@ -151,6 +151,10 @@ struct yf_engine {
     enum { CV_SLOTS = 32 };
     struct CvTab { int sh = 0, sw = 0; bool built = false; hipStream_t stream = nullptr; hipEvent_t ready = nullptr; long used = 0; } cvtab[CV_SLOTS];
     int4* d_cvpool = nullptr;
+    // post_split_kernel (dense frames: one workgroup per frame AND class): scratch rows + per-frame tickets, grown on demand
+    int post_split = 0;               // yf_set_post_split: 0 = auto (K_max >= 256 and <= 8 classes), 1 = always, 2 = never
+    int32_t* d_post_tmp = nullptr; size_t post_tmp_ints = 0;
+    int32_t* d_post_done = nullptr; int post_done_n = 0;
     long cv_tick = 0;
     size_t cv_scratch_bytes(int N) const { return (((size_t)N * H * W * input_channel) + 255) & ~(size_t)255; }
     const Plan& plan() const { return plans[fusion]; }
@@ -735,6 +739,7 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                 a.boxes += (size_t)f0 * a.kmax * 4; a.scores += (size_t)f0 * a.kmax * 2;
                 a.cls += (size_t)f0 * a.kmax; a.src += (size_t)f0 * a.kmax; a.counts += f0;
             }
+            if (a.split_tmp) { a.split_tmp += yf::post_split_tmp_ints(f0, a.nc, a.kmax); a.split_done += f0; }
             const int rc = yf::launch_post(a, n, sl);
             if (rc == -1) return fail(YF_E_INVALID, "frame of %dx%d has too many cells for the on-chip NMS (limit 8191 cells / 160 KiB LDS)", e->H, e->W);
             if (rc) return fail(YF_E_HIP, "hipFuncSetAttribute(post_kernel) failed");
@@ -1020,6 +1025,8 @@ int yf_destroy(yf_handle h)
     }
     for (auto& t : h->cvtab) if (t.ready) (void)hipEventDestroy(t.ready);
     if (h->d_cvpool) (void)hipFree(h->d_cvpool);
+    if (h->d_post_tmp) (void)hipFree(h->d_post_tmp);
+    if (h->d_post_done) (void)hipFree(h->d_post_done);
     if (h->d_esplit) (void)hipFree(h->d_esplit);
     (void)hipFree(h->d_weights);
     (void)hipFree(h->d_wmfma);
@@ -1074,7 +1081,31 @@ static yf::PostArgs make_post_args(yf_handle h, const float* d_hl, const float* 
     a.kmax = K_max;
     a.boxes = d_boxes; a.scores = d_scores; a.cls = d_cls; a.src = d_src; a.counts = d_counts;
     a.records = nullptr;
+    a.split_tmp = nullptr; a.split_done = nullptr;
     return a;
+}
+
+// Dense frames (a caller that reserves K_max >= 256 survivors per frame expects them): the post-process of N frames as N x num_cls workgroups
+// (yf_post_kernels.hip post_split_kernel) -- same records, bit for bit.  The scratch is the engine's, grown on demand (the first dense call
+// of a size allocates: not inside a stream capture); lanes of one batch use disjoint frame ranges of it.
+static int post_setup(yf_handle h, yf::PostArgs& a, int N)
+{
+    const bool on = h->post_split == 1 || (h->post_split == 0 && a.kmax >= 256 && a.nc <= 8);
+    if (!on || a.nc > 64) return YF_OK;
+    const size_t need = yf::post_split_tmp_ints(N, a.nc, a.kmax);
+    if (need > h->post_tmp_ints) {
+        if (h->d_post_tmp) { HIP_OK(hipDeviceSynchronize()); (void)hipFree(h->d_post_tmp); h->d_post_tmp = nullptr; h->post_tmp_ints = 0; }
+        HIP_OK(hipMalloc(&h->d_post_tmp, need * sizeof(int32_t)));
+        h->post_tmp_ints = need;
+    }
+    if (N > h->post_done_n) {
+        if (h->d_post_done) { HIP_OK(hipDeviceSynchronize()); (void)hipFree(h->d_post_done); h->d_post_done = nullptr; h->post_done_n = 0; }
+        HIP_OK(hipMalloc(&h->d_post_done, (size_t)N * sizeof(int32_t)));
+        HIP_OK(hipMemset(h->d_post_done, 0, (size_t)N * sizeof(int32_t)));
+        h->post_done_n = N;
+    }
+    a.split_tmp = h->d_post_tmp; a.split_done = h->d_post_done;
+    return YF_OK;
 }
 
 int yf_decode_nms(yf_handle h, const float* d_hl, const float* d_hs, int N, double conf_thres, double nms_thres,
@@ -1084,8 +1115,9 @@ int yf_decode_nms(yf_handle h, const float* d_hl, const float* d_hs, int N, doub
     if (!h || !d_hl || !d_hs || !anchors || !d_boxes || !d_scores || !d_cls || !d_src || !d_counts || N <= 0 || K_max <= 0)
         return fail(YF_E_INVALID, "yf_decode_nms: null pointer or non-positive size");
     HIP_OK(hipSetDevice(h->device));
-    const yf::PostArgs a = make_post_args(h, d_hl, d_hs, conf_thres, nms_thres, anchors, origin_h, origin_w, K_max, d_boxes, d_scores,
-                                          d_cls, d_src, d_counts);
+    yf::PostArgs a = make_post_args(h, d_hl, d_hs, conf_thres, nms_thres, anchors, origin_h, origin_w, K_max, d_boxes, d_scores,
+                                    d_cls, d_src, d_counts);
+    if (int rs = post_setup(h, a, N)) return rs;
     int rc = yf::launch_post(a, N, (hipStream_t)stream);
     if (rc == -1) return fail(YF_E_INVALID, "frame of %dx%d has too many cells for the on-chip NMS (limit 8191 cells / 160 KiB LDS)", h->H, h->W);
     if (rc) return fail(YF_E_HIP, "hipFuncSetAttribute(post_kernel) failed");
@@ -1101,6 +1133,7 @@ int yf_decode_nms_packed(yf_handle h, const float* d_hl, const float* d_hs, int 
     HIP_OK(hipSetDevice(h->device));
     yf::PostArgs a = make_post_args(h, d_hl, d_hs, conf_thres, nms_thres, anchors, origin_h, origin_w, K_max, nullptr, nullptr, nullptr, nullptr, nullptr);
     a.records = d_records;
+    if (int rs = post_setup(h, a, N)) return rs;
     int rc = yf::launch_post(a, N, (hipStream_t)stream);
     if (rc == -1) return fail(YF_E_INVALID, "frame of %dx%d has too many cells for the on-chip NMS (limit 8191 cells / 160 KiB LDS)", h->H, h->W);
     if (rc) return fail(YF_E_HIP, "hipFuncSetAttribute(post_kernel) failed");
@@ -1327,8 +1360,9 @@ int yf_detect(yf_handle h, const float* d_x, int N, double conf_thres, double nm
     float* hs = d_hs ? d_hs : reinterpret_cast<float*>(static_cast<char*>(ws) + chain) + h->head_l_elems * (size_t)N;
     if (!anchors || !d_boxes || !d_scores || !d_cls || !d_src || !d_counts || N <= 0 || K_max <= 0)
         return fail(YF_E_INVALID, "yf_detect: null pointer or non-positive size");
-    const yf::PostArgs pa = make_post_args(h, hl, hs, conf_thres, nms_thres, anchors, origin_h, origin_w, K_max, d_boxes, d_scores,
-                                           d_cls, d_src, d_counts);
+    yf::PostArgs pa = make_post_args(h, hl, hs, conf_thres, nms_thres, anchors, origin_h, origin_w, K_max, d_boxes, d_scores,
+                                     d_cls, d_src, d_counts);
+    if (int rs = post_setup(h, pa, N)) return rs;
     int rc = run_forward(h, d_x, N, hl, hs, ws, chain, (hipStream_t)stream, nullptr, nullptr, 0, nullptr, nullptr, 0, &pa);
     if (rc) return rc;
     HIP_OK(hipGetLastError());
@@ -1347,6 +1381,7 @@ int yf_detect_packed(yf_handle h, const float* d_x, int N, double conf_thres, do
     if (!anchors || !d_records || N <= 0 || K_max <= 0) return fail(YF_E_INVALID, "yf_detect_packed: null pointer or non-positive size");
     yf::PostArgs pa = make_post_args(h, hl, hs, conf_thres, nms_thres, anchors, origin_h, origin_w, K_max, nullptr, nullptr, nullptr, nullptr, nullptr);
     pa.records = d_records;
+    if (int rs = post_setup(h, pa, N)) return rs;
     int rc = run_forward(h, d_x, N, hl, hs, ws, chain, (hipStream_t)stream, nullptr, nullptr, 0, nullptr, nullptr, 0, &pa);
     if (rc) return rc;
     HIP_OK(hipGetLastError());
@@ -1560,6 +1595,13 @@ int yf_set_split_sums(yf_handle h, int on)
 {
     if (!h || on < 0 || on > 1) return fail(YF_E_INVALID, "split_sums must be 0 or 1");
     h->split_sums = on;
+    return YF_OK;
+}
+
+int yf_set_post_split(yf_handle h, int mode)
+{
+    if (!h || mode < 0 || mode > 2) return fail(YF_E_INVALID, "post_split must be 0 (auto), 1 (always) or 2 (never)");
+    h->post_split = mode;
     return YF_OK;
 }
 

@@ -324,8 +324,13 @@ struct PostArgs {
     // count | boxes (4 kmax) | conf, cls_score as float bits (2 kmax) | cls (kmax) | src (kmax) -- the layout of the multi-GPU exchange
     // (dist.pack_records), so that the all-gather sends the kernel's own buffer
     int32_t* records;
+    // optional (both or neither): scratch of post_split_kernel -- one workgroup per (frame, class) instead of one per frame: dense frames.
+    // split_tmp int32 [N, nc, 2 + 5 kmax] (post_split_tmp_ints), split_done int32 [N], zero before the first launch (the kernel re-zeroes it)
+    int32_t* split_tmp;
+    int32_t* split_done;
 };
 int launch_post(const PostArgs& a, int N, hipStream_t s);
+size_t post_split_tmp_ints(int N, int nc, int kmax);
 size_t post_lds_bytes(int ncell);
 // anc: na (w, h) pairs in feature-map units; rows of `out` / `pred` are 5 + nc floats
 void launch_val_decode(const float* in, float* out, int N, int h, int w, int M_total, int m_off, const float* anc, int na, int nc, float stride_w,

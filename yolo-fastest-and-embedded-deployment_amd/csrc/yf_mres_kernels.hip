@@ -918,10 +918,19 @@ static int launch_mres_t(MresArgs a, int N, hipStream_t s)
 //      (cin, cexp, cout, residual, stride, TH, TW, producer waves (0 = two-barrier kernel), waves / consumer waves)
 // Producer/consumer pays where one workgroup owns the CU anyway (strides 16, 32); at stride 8 its second E buffer
 // halves the workgroups per CU and it is slower (tools/kbench.hip mrespc).
+// A/B builds (round 6): the stride-8 blocks on the producer/consumer kernel, e.g. -DYF_S8A_NWP=3 -DYF_S8A_NW=5
+#ifndef YF_S8A_NWP
+#define YF_S8A_NWP 0   // res3_1, res3_2, conv3_2 triple (8 -> 48 -> 8 / 16)
+#define YF_S8A_NW 8
+#endif
+#ifndef YF_S8B_NWP
+#define YF_S8B_NWP 0   // res3_3 .. res3_6 (16 -> 96 -> 16)
+#define YF_S8B_NW 8
+#endif
 #define YF_MRES_SHAPES(MR)                                                            \
-    MR(8, 48, 8, true, 1, 16, 20, 0, 8)     /* res3_1, res3_2           @ H/8  */         \
-    MR(8, 48, 16, false, 1, 16, 20, 0, 8)   /* conv3_2/3_3/3_4          @ H/8  */         \
-    MR(16, 96, 16, true, 1, 16, 20, 0, 8)   /* res3_3 .. res3_6         @ H/8  */         \
+    MR(8, 48, 8, true, 1, 16, 20, YF_S8A_NWP, YF_S8A_NW)     /* res3_1, res3_2           @ H/8  */         \
+    MR(8, 48, 16, false, 1, 16, 20, YF_S8A_NWP, YF_S8A_NW)   /* conv3_2/3_3/3_4          @ H/8  */         \
+    MR(16, 96, 16, true, 1, 16, 20, YF_S8B_NWP, YF_S8B_NW)   /* res3_3 .. res3_6         @ H/8  */         \
     MR(16, 96, 24, false, 2, 8, 10, 0, 8)   /* conv3_5/3_6/4_1          H/8 -> H/16 */    \
     MR(8, 32, 8, false, 2, 8, 10, 0, 8)     /* conv2_2/2_3/3_1          H/4 -> H/8  */    \
     MR(8, 32, 8, true, 1, 16, 20, 0, 8)     /* res2_1, res2_2 @ H/4: planned for DT_F16X3 only (fp32: the VALU block is as fast) */ \

@@ -79,33 +79,33 @@ __device__ inline CellRef locate(const PostArgs& a, long frame, int cell)
 __device__ inline long s_area(const int4& b) { return ((long)b.z - b.x) * ((long)b.w - b.y); }
 __device__ inline float logit_at(const CellRef& r, int k) { return r.p[((r.pp * r.attrs + k) * r.h + r.i) * r.w + r.j]; }
 
-// LDS carve: keys u64[mpad] | boxes int4[ncell] | kept u16[ncell] | alive u8[ncell] | small scalars
-// (worst case 512x640: 8192*8 + 4800*19 = 156.7 KB of the CU's 160 KB)
-__global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncell, int mpad_max)
+// Shared scalars of one workgroup's post-process
+struct PostShared {
+    int wave_cnt[POST_THREADS / 64];
+    int total, nkept, err, zero_area, wlen, wk, ticket;
+    uint16_t pm[64][POST_PARTS], pz[64][POST_PARTS];
+    int4 wb[64];   // the current window's survivors: boxes and areas
+    long wa[64];
+};
+
+// ---- phase 1: threshold + order-preserving compaction of candidate keys (decode order).  only_cls >= 0: the candidates of that class only
+// (post_split_kernel: one workgroup per frame and class).  A thread owns CPT CONSECUTIVE cells, so one block-wide prefix sum (wave scan +
+// 16 wave totals: two barriers) orders everything -- rounds of 1024 cells with three barriers each before round 6.
+constexpr int POST_MAX_CPT = 8;   // ncell <= 8191 = 8 x 1024 - 1
+__device__ __forceinline__ int compact_keys(const PostArgs& a, long frame, int ncell, uint64_t* keys, int only_cls, PostShared& sh)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
-    int4* boxes = reinterpret_cast<int4*>(smem + (size_t)mpad_max * 8);
-    uint16_t* kept = reinterpret_cast<uint16_t*>(smem + (size_t)mpad_max * 8 + (size_t)ncell * 16);
-    unsigned char* alive = smem + (size_t)mpad_max * 8 + (size_t)ncell * 18;
-    __shared__ int s_wave_cnt[POST_THREADS / 64];
-    __shared__ int s_total, s_nkept, s_err, s_zero_area;
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long frame = blockIdx.x;
-    if (tid == 0) { s_total = 0; s_nkept = 0; s_err = 0; s_zero_area = 0; }
-    __syncthreads();
-
-    // ---- phase 1: threshold + order-preserving compaction of candidate keys (decode order) ----
-    for (int base = 0; base < ncell; base += POST_THREADS) {
-        int cell = base + tid;
-        bool pass = false;
-        uint64_t key = 0;
-        if (cell < ncell) {
+    const int cpt = (ncell + POST_THREADS - 1) / POST_THREADS;
+    uint64_t mine[POST_MAX_CPT];
+    unsigned mask = 0;
+#pragma unroll
+    for (int u = 0; u < POST_MAX_CPT; ++u) {
+        mine[u] = 0;
+        const int cell = tid * cpt + u;
+        if (u < cpt && cell < ncell) {
             CellRef r = locate(a, frame, cell);
             float t4 = logit_at(r, 4);
-            pass = t4 >= a.logit_min;  // NaN fails, like `nan > thres`
-            if (pass) {
+            if (t4 >= a.logit_min) {  // NaN fails, like `nan > thres`
                 if (t4 == 0.f) t4 = 0.f;  // -0.0 and +0.0 have the same conf
                 float best = logit_at(r, 5);
                 int cls = 0;
@@ -113,36 +113,44 @@ __global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncel
                     float v = logit_at(r, 5 + k);
                     if (v > best) { best = v; cls = k; }  // np.argmax: first maximum wins (detect.py:59)
                 }
-                key = ((uint64_t)cls << 45) | ((uint64_t)conf_order(t4) << 13) | (uint64_t)cell;
+                if (only_cls < 0 || cls == only_cls) {
+                    mine[u] = ((uint64_t)cls << 45) | ((uint64_t)conf_order(t4) << 13) | (uint64_t)cell;
+                    mask |= 1u << u;
+                }
             }
         }
-        unsigned long long m = __ballot(pass);
-        int before = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wave_cnt[wave] = __popcll(m);
-        __syncthreads();
-        int off = s_total;
-        for (int wv = 0; wv < wave; ++wv) off += s_wave_cnt[wv];
-        if (pass) keys[off + before] = key;
-        __syncthreads();
-        if (tid == 0) {
-            int t = s_total;
-            for (int wv = 0; wv < POST_THREADS / 64; ++wv) t += s_wave_cnt[wv];
-            s_total = t;
-        }
-        __syncthreads();
     }
-    const int M = s_total;
-    int32_t* const rec = a.records ? a.records + frame * (1 + 8L * a.kmax) : nullptr;   // packed record row of this frame
-    if (M == 0) {
-        if (tid == 0) { if (rec) rec[0] = 0; else a.counts[frame] = 0; }
-        return;
+    const int c = __popc(mask);
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
     }
+    if (lane == 63) sh.wave_cnt[wave] = incl;
+    __syncthreads();
+    int off = incl - c, total = 0;
+#pragma unroll
+    for (int wv = 0; wv < POST_THREADS / 64; ++wv) {
+        const int n = sh.wave_cnt[wv];
+        if (wv < wave) off += n;
+        total += n;
+    }
+#pragma unroll
+    for (int u = 0; u < POST_MAX_CPT; ++u)
+        if ((mask >> u) & 1u) keys[off + __popc(mask & ((1u << u) - 1u))] = mine[u];
+    __syncthreads();
+    return total;
+}
+
+// ---- phase 2: bitonic sort of the unique keys (ascending); keys[M .. mpad) are padded with ~0 ----
+__device__ __forceinline__ void sort_keys(uint64_t* keys, int M)
+{
+    const int tid = threadIdx.x;
     int mpad = 64;
     while (mpad < M) mpad <<= 1;
     for (int i = M + tid; i < mpad; i += POST_THREADS) keys[i] = ~0ull;
     __syncthreads();
-
-    // ---- phase 2: bitonic sort of the unique keys (ascending) ----
     for (int k = 2; k <= mpad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < mpad; i += POST_THREADS) {
@@ -156,9 +164,12 @@ __global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncel
             __syncthreads();
         }
     }
+}
 
-    // ---- phase 3: decode the boxes of the sorted candidates (fp64, round-half-even) ----
-    for (int k = tid; k < M; k += POST_THREADS) {
+// ---- phase 3: decode the boxes of the sorted candidates (fp64, round-half-even) ----
+__device__ __forceinline__ void decode_boxes(const PostArgs& a, long frame, const uint64_t* keys, int4* boxes, unsigned char* alive, int M, PostShared& sh)
+{
+    for (int k = threadIdx.x; k < M; k += POST_THREADS) {
         int cell = (int)(keys[k] & 0x1fffu);
         CellRef r = locate(a, frame, cell);
         double scale_h = (double)a.in_h / r.h, scale_w = (double)a.in_w / r.w;
@@ -169,34 +180,34 @@ __global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncel
         boxes[k] = make_int4(clamp_i32(rint(x - bw / 2)), clamp_i32(rint(y - bh / 2)), clamp_i32(rint(x + bw / 2)),
                              clamp_i32(rint(y + bh / 2)));
         alive[k] = 1;
-        if (s_area(boxes[k]) == 0) s_zero_area = 1;
+        if (s_area(boxes[k]) == 0) sh.zero_area = 1;
     }
     __syncthreads();
+}
 
-    // ---- phase 4: greedy NMS, class segments are contiguous in the sorted list ----
-    // The reference's loop (detect.py:69-84) keeps the best remaining box of a class and drops every later box it overlaps; one
-    // barrier-separated sweep per kept box costs ~1.3 us each (dense frames: 260 survivors of 1200 candidates = 0.36 ms).  The same
-    // decisions in windows of 64 consecutive candidates of one class:
-    //   (1) all pairs inside the window at once: thread (row i = tid / PARTS, part q = tid % PARTS) tests i against the CPT candidates
-    //       of its part -> a piece of row i's suppression mask (and of its "union == 0" mask, the reference's
-    //       ZeroDivisionError, which must only count if the reference would have evaluated that pair);
-    //   (2) wave 0 resolves the window greedily on 64-bit masks: take the lowest remaining bit, keep it, clear what it suppresses;
-    //   (3) every later candidate of the class tests itself against the window's survivors, in order, until one drops it.
-    // Identical to the sequential procedure: a box is dropped iff an EARLIER KEPT box of its class overlaps it.
-    __shared__ uint16_t s_pm[64][POST_PARTS], s_pz[64][POST_PARTS];
-    __shared__ int4 s_wb[64];   // the window's survivors: boxes and areas
-    __shared__ long s_wa[64];
-    __shared__ int s_wlen, s_wk;
+// ---- phase 4: greedy NMS, class segments are contiguous in the sorted list ----
+// The reference's loop (detect.py:69-84) keeps the best remaining box of a class and drops every later box it overlaps; one
+// barrier-separated sweep per kept box costs ~1.3 us each (dense frames: 260 survivors of 1200 candidates = 0.36 ms).  The same
+// decisions in windows of 64 consecutive candidates of one class:
+//   (1) all pairs inside the window at once: thread (row i = tid / PARTS, part q = tid % PARTS) tests i against the CPT candidates
+//       of its part -> a piece of row i's suppression mask (and of its "union == 0" mask, the reference's
+//       ZeroDivisionError, which must only count if the reference would have evaluated that pair);
+//   (2) wave 0 resolves the window greedily on 64-bit masks: take the lowest remaining bit, keep it, clear what it suppresses;
+//   (3) every later candidate of the class tests itself against the window's survivors, in order, until one drops it.
+// Identical to the sequential procedure: a box is dropped iff an EARLIER KEPT box of its class overlaps it.
+__device__ __forceinline__ void greedy_nms(const PostArgs& a, const uint64_t* keys, const int4* boxes, uint16_t* kept, unsigned char* alive, int M, PostShared& sh)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool skip0 = !(0.0 > a.nms_thres);  // with a non-negative threshold a zero intersection can never suppress
     for (int pos = 0; pos < M;) {
         const int cls = (int)(keys[pos] >> 45);
         if (wave == 0) {  // window = the run of this class starting at pos, at most 64 long (sorted: the class is a contiguous run)
             const bool in = pos + lane < M && (int)(keys[pos + lane] >> 45) == cls;
             const unsigned long long b = __ballot(in);
-            if (lane == 0) s_wlen = __popcll(b);   // the lanes of this class form a prefix
+            if (lane == 0) sh.wlen = __popcll(b);   // the lanes of this class form a prefix
         }
         __syncthreads();
-        const int wlen = s_wlen;
+        const int wlen = sh.wlen;
         {   // (1)
             const int i = tid / POST_PARTS, q = tid % POST_PARTS;
             unsigned pm = 0, pz = 0;
@@ -219,14 +230,14 @@ __global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncel
                     if ((double)inter / (double)uni > a.nms_thres) pm |= 1u << t;
                 }
             }
-            s_pm[i][q] = (uint16_t)pm; s_pz[i][q] = (uint16_t)pz;
+            sh.pm[i][q] = (uint16_t)pm; sh.pz[i][q] = (uint16_t)pz;
         }
         __syncthreads();
         if (wave == 0) {  // (2)
             unsigned long long row = 0, zrow = 0;
 #pragma unroll
             for (int q = 0; q < POST_PARTS; ++q) {
-                row |= (unsigned long long)s_pm[lane][q] << (POST_CPT * q); zrow |= (unsigned long long)s_pz[lane][q] << (POST_CPT * q);
+                row |= (unsigned long long)sh.pm[lane][q] << (POST_CPT * q); zrow |= (unsigned long long)sh.pz[lane][q] << (POST_CPT * q);
             }
             const bool al = lane < wlen && alive[pos + lane];
             unsigned long long rem = __ballot(al);   // candidates not yet decided
@@ -245,20 +256,20 @@ __global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncel
                 keptbits |= 1ull << i;
             }
             // every lane publishes its own decision: alive := kept; the window's survivors (in order) with boxes and areas
-            const int nk0 = s_nkept, wk = __popcll(keptbits);
+            const int nk0 = sh.nkept, wk = __popcll(keptbits);
             if (lane < wlen) alive[pos + lane] = (keptbits >> lane) & 1;
             if ((keptbits >> lane) & 1) {
                 const int rank = __popcll(keptbits & ((1ull << lane) - 1));
                 const int4 b = boxes[pos + lane];
                 kept[nk0 + rank] = (uint16_t)(pos + lane);
-                s_wb[rank] = b; s_wa[rank] = s_area(b);
+                sh.wb[rank] = b; sh.wa[rank] = s_area(b);
             }
-            if (lane == 0) { s_nkept = nk0 + wk; s_wk = wk; if (err) s_err = 1; }
+            if (lane == 0) { sh.nkept = nk0 + wk; sh.wk = wk; if (err) sh.err = 1; }
         }
         __syncthreads();
         {   // (3)
-            const int wk = s_wk;
-            if (!s_zero_area && skip0) {
+            const int wk = sh.wk;
+            if (!sh.zero_area && skip0) {
                 // no zero-area box in the frame: a union can never be 0, so "dropped by the FIRST survivor that overlaps it" is just
                 // "dropped if ANY survivor overlaps it" -- order-free: SPLIT threads share a candidate and take every SPLIT-th survivor
                 constexpr int SPLIT = 4;
@@ -269,12 +280,12 @@ __global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncel
                     const int4 bj = boxes[j];
                     const long area_j = s_area(bj);
                     for (int k = sub; k < wk; k += SPLIT) {
-                        const int4 bi = s_wb[k];
+                        const int4 bi = sh.wb[k];
                         const long iw = (long)min(bj.z, bi.z) - (long)max(bj.x, bi.x);
                         const long ih = (long)min(bj.w, bi.w) - (long)max(bj.y, bi.y);
                         if (iw <= 0 || ih <= 0) continue;
                         const long inter = iw * ih;
-                        if ((double)inter / (double)(area_j + s_wa[k] - inter) > a.nms_thres) { alive[j] = 0; break; }
+                        if ((double)inter / (double)(area_j + sh.wa[k] - inter) > a.nms_thres) { alive[j] = 0; break; }
                     }
                 }
             } else {
@@ -284,16 +295,16 @@ __global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncel
                     const int4 bj = boxes[j];
                     const long area_j = s_area(bj);
                     for (int k = 0; k < wk; ++k) {
-                        const int4 bi = s_wb[k];           // the same address for every lane: an LDS broadcast
+                        const int4 bi = sh.wb[k];           // the same address for every lane: an LDS broadcast
                         const long iw = (long)min(bj.z, bi.z) - (long)max(bj.x, bi.x);
                         const long ih = (long)min(bj.w, bi.w) - (long)max(bj.y, bi.y);
                         if ((iw <= 0 || ih <= 0) && skip0) {
-                            if ((area_j | s_wa[k]) == 0) s_err = 1;
+                            if ((area_j | sh.wa[k]) == 0) sh.err = 1;
                             continue;
                         }
                         const long inter = (iw > 0 && ih > 0) ? iw * ih : 0;
-                        const long uni = area_j + s_wa[k] - inter;
-                        if (uni == 0) { s_err = 1; continue; }  // the reference raises ZeroDivisionError here
+                        const long uni = area_j + sh.wa[k] - inter;
+                        if (uni == 0) { sh.err = 1; continue; }  // the reference raises ZeroDivisionError here
                         if ((double)inter / (double)uni > a.nms_thres) { alive[j] = 0; break; }
                     }
                 }
@@ -302,37 +313,130 @@ __global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncel
         __syncthreads();
         pos += wlen;
     }
+}
 
-    // ---- phase 5: write survivors ----
-    const int nk = s_nkept;
-    if (tid == 0) { if (rec) rec[0] = s_err ? -2 : nk; else a.counts[frame] = s_err ? -2 : nk; }
+// ---- phase 5: one survivor into the caller's arrays / packed record row ----
+__device__ __forceinline__ void emit_survivor(const PostArgs& a, int32_t* rec, long frame, int k, int4 b, int cls, int cell)
+{
+    CellRef r = locate(a, frame, cell);
+    if (a.adj_w != 0.0) {  // __adjust_coord: int * float scale, round-half-even
+        b.x = clamp_i32(rint((double)b.x * a.adj_w)); b.z = clamp_i32(rint((double)b.z * a.adj_w));
+        b.y = clamp_i32(rint((double)b.y * a.adj_h)); b.w = clamp_i32(rint((double)b.w * a.adj_h));
+    }
+    const float conf = (float)sigmoid_d((double)logit_at(r, 4)), score = (float)sigmoid_d((double)logit_at(r, 5 + cls));
+    if (rec) {   // (rows start at an odd int32 offset: no 16-byte stores here)
+        int32_t* bx = rec + 1 + 4 * k;
+        bx[0] = b.x; bx[1] = b.y; bx[2] = b.z; bx[3] = b.w;
+        rec[1 + 4 * a.kmax + 2 * k] = __float_as_int(conf);
+        rec[1 + 4 * a.kmax + 2 * k + 1] = __float_as_int(score);
+        rec[1 + 6 * a.kmax + k] = cls;
+        rec[1 + 7 * a.kmax + k] = cell;
+        return;
+    }
+    long o = frame * a.kmax + k;
+    reinterpret_cast<int4*>(a.boxes)[o] = b;
+    a.scores[o * 2 + 0] = conf;
+    a.scores[o * 2 + 1] = score;
+    a.cls[o] = cls;
+    a.src[o] = cell;
+}
+
+// LDS carve: keys u64[mpad] | boxes int4[ncell] | kept u16[ncell] | alive u8[ncell] | small scalars
+// (worst case 512x640: 8192*8 + 4800*19 = 156.7 KB of the CU's 160 KB)
+__global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncell, int mpad_max)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+    int4* boxes = reinterpret_cast<int4*>(smem + (size_t)mpad_max * 8);
+    uint16_t* kept = reinterpret_cast<uint16_t*>(smem + (size_t)mpad_max * 8 + (size_t)ncell * 16);
+    unsigned char* alive = smem + (size_t)mpad_max * 8 + (size_t)ncell * 18;
+    __shared__ PostShared sh;
+
+    const int tid = threadIdx.x;
+    const long frame = blockIdx.x;
+    if (tid == 0) { sh.nkept = 0; sh.err = 0; sh.zero_area = 0; }
+    const int M = compact_keys(a, frame, ncell, keys, -1, sh);    // (its barriers also publish the three scalars)
+    int32_t* const rec = a.records ? a.records + frame * (1 + 8L * a.kmax) : nullptr;   // packed record row of this frame
+    if (M == 0) {
+        if (tid == 0) { if (rec) rec[0] = 0; else a.counts[frame] = 0; }
+        return;
+    }
+    sort_keys(keys, M);
+    decode_boxes(a, frame, keys, boxes, alive, M, sh);
+    greedy_nms(a, keys, boxes, kept, alive, M, sh);
+
+    const int nk = sh.nkept;
+    if (tid == 0) { if (rec) rec[0] = sh.err ? -2 : nk; else a.counts[frame] = sh.err ? -2 : nk; }
     const int nw = nk < a.kmax ? nk : a.kmax;
     for (int k = tid; k < nw; k += POST_THREADS) {
-        int i = kept[k];
-        uint64_t key = keys[i];
-        int cell = (int)(key & 0x1fffu), cls = (int)(key >> 45);
-        CellRef r = locate(a, frame, cell);
-        int4 b = boxes[i];
-        if (a.adj_w != 0.0) {  // __adjust_coord: int * float scale, round-half-even
-            b.x = clamp_i32(rint((double)b.x * a.adj_w)); b.z = clamp_i32(rint((double)b.z * a.adj_w));
-            b.y = clamp_i32(rint((double)b.y * a.adj_h)); b.w = clamp_i32(rint((double)b.w * a.adj_h));
+        const int i = kept[k];
+        const uint64_t key = keys[i];
+        emit_survivor(a, rec, frame, k, boxes[i], (int)(key >> 45), (int)(key & 0x1fffu));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// post_split_kernel (round 6): dense frames.  The reference runs NMS per class (detect.py:158-169: bucket, sort, NMS,
+// concatenate in class order): the classes of a frame are independent work.  One workgroup per (frame, class): it compacts the
+// candidates whose argmax class is its own (decode order), sorts them by conf, decodes them and runs the same windowed greedy NMS on
+// them -- the arithmetic, and therefore the survivors and their order inside the class, of post_kernel -- and leaves its survivors
+// (box, cell) with their count and error flag in a scratch row.  The LAST workgroup of a frame to finish (a device-scope ticket:
+// release fence -> atomic increment -> acquire fence; nothing spins) concatenates the classes in class order into the caller's arrays
+// and resets the ticket.  BASELINE configs[4]'s per-GPU share (64 dense 640x512 frames) then uses 192 of the 256 CUs instead of 64.
+// scratch row of (frame, class): int32 [2 + 5 kmax] = count | err | kmax x (x1, y1, x2, y2, cell)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(POST_THREADS) post_split_kernel(PostArgs a, int ncell, int mpad_max)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+    int4* boxes = reinterpret_cast<int4*>(smem + (size_t)mpad_max * 8);
+    uint16_t* kept = reinterpret_cast<uint16_t*>(smem + (size_t)mpad_max * 8 + (size_t)ncell * 16);
+    unsigned char* alive = smem + (size_t)mpad_max * 8 + (size_t)ncell * 18;
+    __shared__ PostShared sh;
+
+    const int tid = threadIdx.x;
+    const long frame = blockIdx.x / a.nc;
+    const int mycls = blockIdx.x - (int)frame * a.nc;
+    const long row_ints = 2 + 5L * a.kmax;
+    int32_t* const row = a.split_tmp + (frame * a.nc + mycls) * row_ints;
+    if (tid == 0) { sh.nkept = 0; sh.err = 0; sh.zero_area = 0; }
+    const int M = compact_keys(a, frame, ncell, keys, mycls, sh);
+    if (M > 0) {
+        sort_keys(keys, M);
+        decode_boxes(a, frame, keys, boxes, alive, M, sh);
+        greedy_nms(a, keys, boxes, kept, alive, M, sh);
+    }
+    const int nk = M > 0 ? sh.nkept : 0;
+    if (tid == 0) { row[0] = nk; row[1] = M > 0 ? sh.err : 0; }
+    for (int k = tid; k < (nk < a.kmax ? nk : a.kmax); k += POST_THREADS) {
+        const int i = kept[k];
+        const int4 b = boxes[i];
+        int32_t* e = row + 2 + 5 * k;
+        e[0] = b.x; e[1] = b.y; e[2] = b.z; e[3] = b.w; e[4] = (int)(keys[i] & 0x1fffu);
+    }
+    // ---- the frame's last workgroup assembles the result ----
+    __threadfence();                         // release: this workgroup's scratch row is visible device-wide before its ticket
+    __syncthreads();
+    if (tid == 0) sh.ticket = atomicAdd(&a.split_done[frame], 1);
+    __syncthreads();
+    if (sh.ticket != a.nc - 1) return;
+    __threadfence();                         // acquire: the other classes' rows
+    if (tid == 0) a.split_done[frame] = 0;   // ready for the next launch on this stream
+    const int32_t* rows = a.split_tmp + frame * a.nc * row_ints;
+    int total = 0, err = 0;
+    for (int c = 0; c < a.nc; ++c) { total += rows[c * row_ints]; err |= rows[c * row_ints + 1]; }
+    int32_t* const rec = a.records ? a.records + frame * (1 + 8L * a.kmax) : nullptr;
+    if (tid == 0) { if (rec) rec[0] = err ? -2 : total; else a.counts[frame] = err ? -2 : total; }
+    const int nw = total < a.kmax ? total : a.kmax;
+    for (int k = tid; k < nw; k += POST_THREADS) {
+        int c = 0, kk = k;
+        for (;; ++c) {                        // class of output slot k (class-major concatenation, detect.py:169)
+            const int n = rows[c * row_ints];
+            if (kk < n) break;
+            kk -= n;
         }
-        const float conf = (float)sigmoid_d((double)logit_at(r, 4)), score = (float)sigmoid_d((double)logit_at(r, 5 + cls));
-        if (rec) {   // (rows start at an odd int32 offset: no 16-byte stores here)
-            int32_t* bx = rec + 1 + 4 * k;
-            bx[0] = b.x; bx[1] = b.y; bx[2] = b.z; bx[3] = b.w;
-            rec[1 + 4 * a.kmax + 2 * k] = __float_as_int(conf);
-            rec[1 + 4 * a.kmax + 2 * k + 1] = __float_as_int(score);
-            rec[1 + 6 * a.kmax + k] = cls;
-            rec[1 + 7 * a.kmax + k] = cell;
-            continue;
-        }
-        long o = frame * a.kmax + k;
-        reinterpret_cast<int4*>(a.boxes)[o] = b;
-        a.scores[o * 2 + 0] = conf;
-        a.scores[o * 2 + 1] = score;
-        a.cls[o] = cls;
-        a.src[o] = cell;
+        const int32_t* e = rows + c * row_ints + 2 + 5 * kk;   // kk < kmax: k < kmax and kk <= k
+        emit_survivor(a, rec, frame, k, make_int4(e[0], e[1], e[2], e[3]), c, e[4]);
     }
 }
 
@@ -541,23 +645,27 @@ size_t post_lds_bytes(int ncell)
     return (b + 15) & ~(size_t)15;
 }
 
+size_t post_split_tmp_ints(int N, int nc, int kmax) { return (size_t)N * nc * (2 + 5 * (size_t)kmax); }
+
 int launch_post(const PostArgs& a, int N, hipStream_t s)
 {
     if (a.na < 1 || a.na > POST_MAX_ANCHORS || a.nc < 1 || a.nc >= (1 << 18)) return -1;   // (the class sits above bit 45 of the sort key)
     int ncell = a.na * (a.hl * a.wl + a.hs * a.ws);
     if (ncell > 8191) return -1;  // 13-bit cell field of the sort key
     size_t lds = post_lds_bytes(ncell);
-    if (lds > 160 * 1024 - 64) return -1;  // + 28 B of static LDS
-    static size_t attr_set[YF_MAX_DEVICES] = {};
+    if (lds + sizeof(PostShared) + 64 > 160 * 1024) return -1;  // dynamic + static LDS of one CU
+    static size_t attr_set[YF_MAX_DEVICES][2] = {};
     const int dev = current_device();
     if (dev < 0) return -2;
-    if (lds > attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(post_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
+    const bool split = a.split_tmp != nullptr && a.split_done != nullptr;
+    if (lds > attr_set[dev][split]) {
+        if (hipFuncSetAttribute(split ? reinterpret_cast<const void*>(post_split_kernel) : reinterpret_cast<const void*>(post_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
-        attr_set[dev] = lds;
+        attr_set[dev][split] = lds;
     }
-    hipLaunchKernelGGL(post_kernel, dim3(N), dim3(POST_THREADS), lds, s, a, ncell, pow2_at_least(ncell));
+    if (split) hipLaunchKernelGGL(post_split_kernel, dim3((unsigned)(N * a.nc)), dim3(POST_THREADS), lds, s, a, ncell, pow2_at_least(ncell));
+    else hipLaunchKernelGGL(post_kernel, dim3(N), dim3(POST_THREADS), lds, s, a, ncell, pow2_at_least(ncell));
     return 0;
 }
 

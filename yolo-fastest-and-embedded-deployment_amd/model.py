@@ -53,6 +53,7 @@ class _Engine:
         self._ws = None
         self.chunk, self.lanes, self.branches = 0, 2, 1     # the C side's defaults (yf_engine: chunk 0, lanes 2, branches on)
         self.split_sums = 0
+        self.post_split = 0
 
     def workspace(self, N, device):
         need = ctypes.c_size_t()
@@ -81,6 +82,10 @@ class _Engine:
     def set_split_sums(self, on):
         _lib.check(self.lib.yf_set_split_sums(self.handle, int(on)))
         self.split_sums = int(on)
+
+    def set_post_split(self, mode):
+        _lib.check(self.lib.yf_set_post_split(self.handle, int(mode)))
+        self.post_split = int(mode)
 
     def close(self):
         if self.handle:
@@ -134,6 +139,9 @@ class YoloFastest(nn.Module):
         # 3735, shift 15: what a current `pip install opencv-python` gives the reference), 14 = OpenCV 2.x / 3.x (4899 / 9617 / 1868, shift 14).  They
         # differ by at most 1 LSB on colour frames; gray frames (the bundled test_data) come out identical.  io_params["gray_bits"] overrides.
         self.gray_bits = int(io_params.get("gray_bits", 15)) if isinstance(io_params, dict) else 15
+        # decode + NMS as one workgroup per frame and class (dense frames) instead of one per frame: 0 = automatically when the caller reserves
+        # kmax >= 256 survivors per frame, 1 = always, 2 = never (yf_set_post_split); the records are the same bit for bit
+        self.post_split = 0
         # activation storage / pointwise-GEMM operand type: torch.float32, or torch.float16 (BASELINE configs[2]: fp16 in HBM,
         # fp16 MFMA, fp32 accumulate).  `model.half()` selects fp16 like it would for the reference module; setting
         # `model.storage_dtype = torch.float16` keeps the fp32 master weights for the BN fold (more accurate).
@@ -227,6 +235,8 @@ class YoloFastest(nn.Module):
             e.set_branches(self.branches)
         if e.split_sums != int(bool(self.split_sums)):
             e.set_split_sums(int(bool(self.split_sums)))
+        if e.post_split != int(self.post_split):
+            e.set_post_split(int(self.post_split))
         return e
 
     def engine_on(self, device):
