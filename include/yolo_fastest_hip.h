@@ -343,11 +343,11 @@ int yf_set_split_sums(yf_handle h, int on);       /* 1 (opt in; the default is 0
                                                       travel with it (held to 2e-4 on the logits and to identical detections on the goldens).  0 (default): never; every
                                                       launch keeps one association at every batch size. */
 int yf_set_post_split(yf_handle h, int mode);      /* decode + NMS as one workgroup per frame AND class instead of one per frame (the reference runs NMS per class,
-                                                      detect.py:158-169: independent work; the frame's last workgroup concatenates the classes in class order) --
-                                                      the same records bit for bit, for DENSE frames: 64 frames of 1200 candidates use 192 CUs instead of 64.
-                                                      0 (default): automatically when the caller reserves K_max >= 256 survivors per frame and the model has
-                                                      <= 8 classes; 1: always (<= 64 classes); 2: never.  The first dense call of a size allocates the engine's
-                                                      scratch (not inside a stream capture). */
+                                                      detect.py:158-169: independent work; a second small launch concatenates the classes in class order) --
+                                                      the same records bit for bit, for DENSE frames: 64 frames of 1200 candidates use 192 CUs instead of 64
+                                                      (0.127 -> 0.058 ms).  0 (default): automatically when the caller reserves K_max >= 256 survivors per frame,
+                                                      the model has <= 8 classes and 2 N <= #CU; 1: always (<= 64 classes); 2: never.  The first dense call of a
+                                                      size allocates the engine's scratch (not inside a stream capture). */
 int yf_set_lanes(yf_handle h, int lanes);          /* 1..4: chunks of the batch (yf_set_chunk) run on this many concurrent
                                                      streams, forked from / joined to the caller's stream by events    */
 int yf_set_branches(yf_handle h, int on);         /* 1 (default): the small head's launches (conv5_3 .. head_5) run on a side stream of

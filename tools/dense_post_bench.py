@@ -27,18 +27,36 @@ for res, batch in ((512, 64), (256, 256)):
             dst.append(t.reshape(24, h, w))
     pred = (torch.from_numpy(np.stack(hl)).to(dev), torch.from_numpy(np.stack(hs)).to(dev))
     kmax = 1024
-    raw = post.detect_raw(pred, kmax=kmax)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
-        raw = post.detect_raw(pred, kmax=kmax)
-    e1.record(); torch.cuda.synchronize()
-    counts = raw["counts"].cpu().numpy()
-    ok = True
-    for f in range(3):
-        r = poc.post_process(hl[f], hs[f], io["anchors"], io["input_shape"][:2])
-        n = r["count"]
-        ok &= n == counts[f] and np.array_equal(raw["src"][f, :n].cpu().numpy(), r["src"]) and np.array_equal(raw["boxes"][f, :n].cpu().numpy(), r["box"])
-    print(f"{W}x{H} batch {batch}: post kernel {e0.elapsed_time(e1) / 10:.3f} ms/batch, survivors/frame mean {counts.mean():.1f}, "
-          f"candidates ~{(np.stack(hl)[:, 4::8] > 0).sum() / batch + (np.stack(hs)[:, 4::8] > 0).sum() / batch:.0f}, oracle match: {ok}")
+    for mode, what in ((2, "one workgroup per frame"), (1, "one workgroup per frame and class")):
+        m.post_split = mode
+        for _ in range(3):
+            raw = post.detect_raw(pred, kmax=kmax)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            raw = post.detect_raw(pred, kmax=kmax)
+        e1.record(); torch.cuda.synchronize()
+        counts = raw["counts"].cpu().numpy()
+        ok = True
+        for f in range(3):
+            r = poc.post_process(hl[f], hs[f], io["anchors"], io["input_shape"][:2])
+            n = r["count"]
+            ok &= n == counts[f] and np.array_equal(raw["src"][f, :n].cpu().numpy(), r["src"]) and np.array_equal(raw["boxes"][f, :n].cpu().numpy(), r["box"])
+        print(f"{W}x{H} batch {batch}, {what}: post kernel {e0.elapsed_time(e1) / 20:.4f} ms/batch, survivors/frame mean {counts.mean():.1f}, "
+              f"candidates ~{(np.stack(hl)[:, 4::8] > 0).sum() / batch + (np.stack(hs)[:, 4::8] > 0).sum() / batch:.0f}, oracle match: {ok}", flush=True)
+    # the sparse case beside it (the headline's frames give ~0-2 survivors): the model's own logits on noise, kmax 64
+    x = torch.rand(batch, 1, H, W, device=dev) - 0.5
+    with torch.no_grad():
+        p2 = m(x)
+    for mode, what in ((2, "one workgroup per frame"), (1, "one workgroup per frame and class")):
+        m.post_split = mode
+        for _ in range(3):
+            post.detect_raw(p2, kmax=64)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            post.detect_raw(p2, kmax=64)
+        e1.record(); torch.cuda.synchronize()
+        print(f"{W}x{H} batch {batch}, sparse (net on noise), {what}: {e0.elapsed_time(e1) / 20:.4f} ms/batch", flush=True)

@@ -154,7 +154,6 @@ struct yf_engine {
     // post_split_kernel (dense frames: one workgroup per frame AND class): scratch rows + per-frame tickets, grown on demand
     int post_split = 0;               // yf_set_post_split: 0 = auto (K_max >= 256 and <= 8 classes), 1 = always, 2 = never
     int32_t* d_post_tmp = nullptr; size_t post_tmp_ints = 0;
-    int32_t* d_post_done = nullptr; int post_done_n = 0;
     long cv_tick = 0;
     size_t cv_scratch_bytes(int N) const { return (((size_t)N * H * W * input_channel) + 255) & ~(size_t)255; }
     const Plan& plan() const { return plans[fusion]; }
@@ -739,7 +738,7 @@ int run_forward(yf_engine* e, const float* d_x, int N, float* d_hl, float* d_hs,
                 a.boxes += (size_t)f0 * a.kmax * 4; a.scores += (size_t)f0 * a.kmax * 2;
                 a.cls += (size_t)f0 * a.kmax; a.src += (size_t)f0 * a.kmax; a.counts += f0;
             }
-            if (a.split_tmp) { a.split_tmp += yf::post_split_tmp_ints(f0, a.nc, a.kmax); a.split_done += f0; }
+            if (a.split_tmp) a.split_tmp += yf::post_split_tmp_ints(f0, a.nc, a.kmax);
             const int rc = yf::launch_post(a, n, sl);
             if (rc == -1) return fail(YF_E_INVALID, "frame of %dx%d has too many cells for the on-chip NMS (limit 8191 cells / 160 KiB LDS)", e->H, e->W);
             if (rc) return fail(YF_E_HIP, "hipFuncSetAttribute(post_kernel) failed");
@@ -1026,7 +1025,6 @@ int yf_destroy(yf_handle h)
     for (auto& t : h->cvtab) if (t.ready) (void)hipEventDestroy(t.ready);
     if (h->d_cvpool) (void)hipFree(h->d_cvpool);
     if (h->d_post_tmp) (void)hipFree(h->d_post_tmp);
-    if (h->d_post_done) (void)hipFree(h->d_post_done);
     if (h->d_esplit) (void)hipFree(h->d_esplit);
     (void)hipFree(h->d_weights);
     (void)hipFree(h->d_wmfma);
@@ -1081,16 +1079,19 @@ static yf::PostArgs make_post_args(yf_handle h, const float* d_hl, const float* 
     a.kmax = K_max;
     a.boxes = d_boxes; a.scores = d_scores; a.cls = d_cls; a.src = d_src; a.counts = d_counts;
     a.records = nullptr;
-    a.split_tmp = nullptr; a.split_done = nullptr;
+    a.split_tmp = nullptr;
     return a;
 }
 
-// Dense frames (a caller that reserves K_max >= 256 survivors per frame expects them): the post-process of N frames as N x num_cls workgroups
-// (yf_post_kernels.hip post_split_kernel) -- same records, bit for bit.  The scratch is the engine's, grown on demand (the first dense call
-// of a size allocates: not inside a stream capture); lanes of one batch use disjoint frame ranges of it.
+// Dense frames: the post-process of N frames as N x num_cls workgroups + a small assembly launch (yf_post_kernels.hip post_split_kernel) -- the
+// same records, bit for bit.  Automatic (yf_set_post_split 0) when the caller reserves K_max >= 256 survivors per frame (it expects dense
+// frames), the model has <= 8 classes and one workgroup per frame would leave at least half of the CUs idle (2 N <= #CU: with 256 dense
+// 320x256 frames the per-frame form is the faster one, 0.057 against 0.075 ms).  The scratch is the engine's, grown on demand (the first dense
+// call of a size allocates: not inside a stream capture); lanes of one batch use disjoint frame ranges of it.
 static int post_setup(yf_handle h, yf::PostArgs& a, int N)
 {
-    const bool on = h->post_split == 1 || (h->post_split == 0 && a.kmax >= 256 && a.nc <= 8);
+    const int n_cu = yf::device_cu_count(h->device);
+    const bool on = h->post_split == 1 || (h->post_split == 0 && a.kmax >= 256 && a.nc <= 8 && n_cu > 0 && 2 * N <= n_cu);
     if (!on || a.nc > 64) return YF_OK;
     const size_t need = yf::post_split_tmp_ints(N, a.nc, a.kmax);
     if (need > h->post_tmp_ints) {
@@ -1098,13 +1099,7 @@ static int post_setup(yf_handle h, yf::PostArgs& a, int N)
         HIP_OK(hipMalloc(&h->d_post_tmp, need * sizeof(int32_t)));
         h->post_tmp_ints = need;
     }
-    if (N > h->post_done_n) {
-        if (h->d_post_done) { HIP_OK(hipDeviceSynchronize()); (void)hipFree(h->d_post_done); h->d_post_done = nullptr; h->post_done_n = 0; }
-        HIP_OK(hipMalloc(&h->d_post_done, (size_t)N * sizeof(int32_t)));
-        HIP_OK(hipMemset(h->d_post_done, 0, (size_t)N * sizeof(int32_t)));
-        h->post_done_n = N;
-    }
-    a.split_tmp = h->d_post_tmp; a.split_done = h->d_post_done;
+    a.split_tmp = h->d_post_tmp;
     return YF_OK;
 }
 

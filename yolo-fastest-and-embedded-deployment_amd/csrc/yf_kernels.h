@@ -324,10 +324,9 @@ struct PostArgs {
     // count | boxes (4 kmax) | conf, cls_score as float bits (2 kmax) | cls (kmax) | src (kmax) -- the layout of the multi-GPU exchange
     // (dist.pack_records), so that the all-gather sends the kernel's own buffer
     int32_t* records;
-    // optional (both or neither): scratch of post_split_kernel -- one workgroup per (frame, class) instead of one per frame: dense frames.
-    // split_tmp int32 [N, nc, 2 + 5 kmax] (post_split_tmp_ints), split_done int32 [N], zero before the first launch (the kernel re-zeroes it)
+    // optional: scratch of post_split_kernel + post_assemble_kernel -- one workgroup per (frame, class) instead of one per frame: dense frames.
+    // split_tmp int32 [N, nc, 2 + 5 kmax] (post_split_tmp_ints)
     int32_t* split_tmp;
-    int32_t* split_done;
 };
 int launch_post(const PostArgs& a, int N, hipStream_t s);
 size_t post_split_tmp_ints(int N, int nc, int kmax);

@@ -82,7 +82,7 @@ __device__ inline float logit_at(const CellRef& r, int k) { return r.p[((r.pp * 
 // Shared scalars of one workgroup's post-process
 struct PostShared {
     int wave_cnt[POST_THREADS / 64];
-    int total, nkept, err, zero_area, wlen, wk, ticket;
+    int total, nkept, err, zero_area, wlen, wk;
     uint16_t pm[64][POST_PARTS], pz[64][POST_PARTS];
     int4 wb[64];   // the current window's survivors: boxes and areas
     long wa[64];
@@ -144,6 +144,20 @@ __device__ __forceinline__ int compact_keys(const PostArgs& a, long frame, int n
 }
 
 // ---- phase 2: bitonic sort of the unique keys (ascending); keys[M .. mpad) are padded with ~0 ----
+// The compare-exchange stages whose partner distance j is below 64 stay inside one wave's 64 consecutive keys: they run in REGISTERS
+// (one key per lane, partner by __shfl_xor) without a workgroup barrier between them -- all of levels k = 2 .. 64 in one pass, and the
+// tail j = 32 .. 1 of every later level; only the stages with j >= 64 go through LDS with a barrier each.  2048 keys: 21 barriers
+// instead of 66; 512 keys (one class of a dense frame): 10 instead of 45.  Unique keys: the result is THE sorted order either way.
+__device__ __forceinline__ uint64_t bitonic_in_wave(uint64_t x, int i, int k, int jmax)
+{
+    const bool up = (i & k) == 0;
+    for (int j = jmax; j > 0; j >>= 1) {
+        const uint64_t y = __shfl_xor(x, j);
+        const bool take_min = ((i & j) == 0) == up;
+        x = take_min ? (x < y ? x : y) : (x < y ? y : x);
+    }
+    return x;
+}
 __device__ __forceinline__ void sort_keys(uint64_t* keys, int M)
 {
     const int tid = threadIdx.x;
@@ -151,8 +165,14 @@ __device__ __forceinline__ void sort_keys(uint64_t* keys, int M)
     while (mpad < M) mpad <<= 1;
     for (int i = M + tid; i < mpad; i += POST_THREADS) keys[i] = ~0ull;
     __syncthreads();
-    for (int k = 2; k <= mpad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
+    for (int i = tid; i < mpad; i += POST_THREADS) {      // levels 2 .. 64 (a wave's iteration covers 64 consecutive keys: mpad and 1024 are multiples of 64)
+        uint64_t x = keys[i];
+        for (int k = 2; k <= 64; k <<= 1) x = bitonic_in_wave(x, i, k, k >> 1);
+        keys[i] = x;
+    }
+    __syncthreads();
+    for (int k = 128; k <= mpad; k <<= 1) {
+        for (int j = k >> 1; j >= 64; j >>= 1) {
             for (int i = tid; i < mpad; i += POST_THREADS) {
                 int l = i ^ j;
                 if (l > i) {
@@ -163,6 +183,8 @@ __device__ __forceinline__ void sort_keys(uint64_t* keys, int M)
             }
             __syncthreads();
         }
+        for (int i = tid; i < mpad; i += POST_THREADS) keys[i] = bitonic_in_wave(keys[i], i, k, 32);
+        __syncthreads();
     }
 }
 
@@ -375,14 +397,39 @@ __global__ void __launch_bounds__(POST_THREADS) post_kernel(PostArgs a, int ncel
     }
 }
 
+// class-major concatenation of a frame's per-class scratch rows into the caller's arrays (detect.py:169); any number of threads
+__device__ __forceinline__ void assemble_frame(const PostArgs& a, long frame)
+{
+    const long row_ints = 2 + 5L * a.kmax;
+    const int32_t* rows = a.split_tmp + frame * a.nc * row_ints;
+    int total = 0, err = 0;
+    for (int c = 0; c < a.nc; ++c) { total += rows[c * row_ints]; err |= rows[c * row_ints + 1]; }
+    int32_t* const rec = a.records ? a.records + frame * (1 + 8L * a.kmax) : nullptr;
+    if (threadIdx.x == 0) { if (rec) rec[0] = err ? -2 : total; else a.counts[frame] = err ? -2 : total; }
+    const int nw = total < a.kmax ? total : a.kmax;
+    for (int k = threadIdx.x; k < nw; k += blockDim.x) {
+        int c = 0, kk = k;
+        for (;; ++c) {                        // class of output slot k
+            const int n = rows[c * row_ints];
+            if (kk < n) break;
+            kk -= n;
+        }
+        const int32_t* e = rows + c * row_ints + 2 + 5 * kk;   // kk < kmax: k < kmax and kk <= k
+        emit_survivor(a, rec, frame, k, make_int4(e[0], e[1], e[2], e[3]), c, e[4]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // post_split_kernel (round 6): dense frames.  The reference runs NMS per class (detect.py:158-169: bucket, sort, NMS,
 // concatenate in class order): the classes of a frame are independent work.  One workgroup per (frame, class): it compacts the
 // candidates whose argmax class is its own (decode order), sorts them by conf, decodes them and runs the same windowed greedy NMS on
 // them -- the arithmetic, and therefore the survivors and their order inside the class, of post_kernel -- and leaves its survivors
-// (box, cell) with their count and error flag in a scratch row.  The LAST workgroup of a frame to finish (a device-scope ticket:
-// release fence -> atomic increment -> acquire fence; nothing spins) concatenates the classes in class order into the caller's arrays
-// and resets the ticket.  BASELINE configs[4]'s per-GPU share (64 dense 640x512 frames) then uses 192 of the 256 CUs instead of 64.
+// (box, cell) with their count and error flag in a scratch row; post_assemble_kernel, a second small launch, concatenates the classes in
+// class order into the caller's arrays.  BASELINE configs[4]'s per-GPU share (64 dense 640x512 frames: 1210 candidates, 260 survivors per
+// frame) then uses 192 of the 256 CUs instead of 64: 0.127 -> 0.058 ms per 64 frames (tools/dense_post_bench.py).  Measured and dropped: the
+// assembly inside this launch by the frame's LAST workgroup to finish (device-scope ticket: release fence -> atomic increment -> acquire
+// fence) -- a device-scope release is an L2 write-back on this part (the class workgroups sit on different XCDs): 0.076 ms with one fence
+// per workgroup, 0.136 ms with one per thread, and 0.23 ms against 0.075 ms for 768 workgroups; the kernel boundary is the cheaper fence.
 // scratch row of (frame, class): int32 [2 + 5 kmax] = count | err | kmax x (x1, y1, x2, y2, cell)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(POST_THREADS) post_split_kernel(PostArgs a, int ncell, int mpad_max)
@@ -414,30 +461,13 @@ __global__ void __launch_bounds__(POST_THREADS) post_split_kernel(PostArgs a, in
         int32_t* e = row + 2 + 5 * k;
         e[0] = b.x; e[1] = b.y; e[2] = b.z; e[3] = b.w; e[4] = (int)(keys[i] & 0x1fffu);
     }
-    // ---- the frame's last workgroup assembles the result ----
-    __threadfence();                         // release: this workgroup's scratch row is visible device-wide before its ticket
-    __syncthreads();
-    if (tid == 0) sh.ticket = atomicAdd(&a.split_done[frame], 1);
-    __syncthreads();
-    if (sh.ticket != a.nc - 1) return;
-    __threadfence();                         // acquire: the other classes' rows
-    if (tid == 0) a.split_done[frame] = 0;   // ready for the next launch on this stream
-    const int32_t* rows = a.split_tmp + frame * a.nc * row_ints;
-    int total = 0, err = 0;
-    for (int c = 0; c < a.nc; ++c) { total += rows[c * row_ints]; err |= rows[c * row_ints + 1]; }
-    int32_t* const rec = a.records ? a.records + frame * (1 + 8L * a.kmax) : nullptr;
-    if (tid == 0) { if (rec) rec[0] = err ? -2 : total; else a.counts[frame] = err ? -2 : total; }
-    const int nw = total < a.kmax ? total : a.kmax;
-    for (int k = tid; k < nw; k += POST_THREADS) {
-        int c = 0, kk = k;
-        for (;; ++c) {                        // class of output slot k (class-major concatenation, detect.py:169)
-            const int n = rows[c * row_ints];
-            if (kk < n) break;
-            kk -= n;
-        }
-        const int32_t* e = rows + c * row_ints + 2 + 5 * kk;   // kk < kmax: k < kmax and kk <= k
-        emit_survivor(a, rec, frame, k, make_int4(e[0], e[1], e[2], e[3]), c, e[4]);
-    }
+}
+
+// ... and the second launch: one small workgroup per frame concatenates the frame's class rows in class order.  The kernel boundary is the
+// release / acquire between the class workgroups (which run on different XCDs, each behind its own L2) and this one.
+__global__ void __launch_bounds__(256) post_assemble_kernel(PostArgs a)
+{
+    assemble_frame(a, blockIdx.x);
 }
 
 // Stand-alone greedy NMS over one class's conf-sorted list (detect.py:69-84); one workgroup.
@@ -657,14 +687,17 @@ int launch_post(const PostArgs& a, int N, hipStream_t s)
     static size_t attr_set[YF_MAX_DEVICES][2] = {};
     const int dev = current_device();
     if (dev < 0) return -2;
-    const bool split = a.split_tmp != nullptr && a.split_done != nullptr;
+    const bool split = a.split_tmp != nullptr;
     if (lds > attr_set[dev][split]) {
         if (hipFuncSetAttribute(split ? reinterpret_cast<const void*>(post_split_kernel) : reinterpret_cast<const void*>(post_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
         attr_set[dev][split] = lds;
     }
-    if (split) hipLaunchKernelGGL(post_split_kernel, dim3((unsigned)(N * a.nc)), dim3(POST_THREADS), lds, s, a, ncell, pow2_at_least(ncell));
+    if (split) {
+        hipLaunchKernelGGL(post_split_kernel, dim3((unsigned)(N * a.nc)), dim3(POST_THREADS), lds, s, a, ncell, pow2_at_least(ncell));
+        hipLaunchKernelGGL(post_assemble_kernel, dim3((unsigned)N), dim3(256), 0, s, a);
+    }
     else hipLaunchKernelGGL(post_kernel, dim3(N), dim3(POST_THREADS), lds, s, a, ncell, pow2_at_least(ncell));
     return 0;
 }
