@@ -799,6 +799,43 @@ def test_fp16_storage_both_forms_of_the_stride2_block(yf, golden, dev, tmp_path)
         assert np.isfinite(out[False][k]).all() and np.abs(out[False][k] - out[True][k]).max() <= 6e-3 * np.abs(out[True][k]).max(), k
 
 
+def test_f16x3_both_forms_of_the_stride2_block(yf, golden, dev, tmp_path):
+    """Round 6: the split-operand (f16x3) plan runs conv1_8 + conv1_9 + conv2_1 as k19m_kernel<x3_t> (region buffers, split once per region pixel);
+    YF_K19X=43 selects k19x_kernel (no region buffers: conv1_8 exact fp32 per tap, ONE hi/lo split per tap in registers, six K = 32 fp16 MFMAs per
+    tap -- built for VERDICT r5 item 3, measured a tie, kept as the A/B form).  Both in child processes (the switch is read once per process) on the bundled frames, at 640x512 and on a 192 x 224 noise batch: each
+    stays inside the fp32 golden bounds (_check_heads: the bounds of the fp32 path, SURVEY's 2e-2 by a factor of 100), and they agree with each other
+    like two fp32 evaluations do."""
+    import subprocess
+    import sys
+    code = ("import sys, torch, numpy as np; sys.path.insert(0, %r)\n"
+            "import yolo_fastest_amd as yf\n"
+            "dev = torch.device('cuda:0'); res = int(sys.argv[2]); io = yf.io_params_for(res)\n"
+            "m = yf.YoloFastest(io).to(dev).eval(); m.load_state_dict(torch.load(sys.argv[3], map_location=dev)); m.precision = 'f16x3'\n"
+            "g = np.load(sys.argv[4]); x = torch.from_numpy(((g['input_u8'].astype(np.float32) - 128.0) / 255.0)[:, None]).to(dev)\n"
+            "torch.manual_seed(11); y = torch.rand(3, 1, 192, 224, device=dev) - 0.5\n"
+            "with torch.no_grad(): a = m(x); b = m(y)\n"
+            "np.savez(sys.argv[1], hl=a[0].cpu().numpy(), hs=a[1].cpu().numpy(), nl=b[0].cpu().numpy(), ns=b[1].cpu().numpy())\n"
+            "print('RESULT ok')\n") % ROOT
+    for res in (256, 512):
+        out = {}
+        for old in (False, True):
+            env = dict(os.environ)
+            for k in ("YF_K19R", "YF_K19X"):
+                env.pop(k, None)
+            env["YF_K19X"] = "0" if old else "43"
+            f = str(tmp_path / ("old_%d.npz" % res if old else "new_%d.npz" % res))
+            r = subprocess.run([sys.executable, "-c", code, f, str(res), WEIGHTS[res], os.path.join(ROOT, "tests", "golden", f"golden_{res}.npz")],
+                               env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0 and "RESULT ok" in r.stdout, r.stderr[-2000:]
+            out[old] = np.load(f)
+        g = golden(f"golden_{res}")
+        for old in (False, True):
+            _check_heads(out[old]["hl"], out[old]["hs"], g["head_large"], g["head_small"], g["head_large_f64"], g["head_small_f64"], res == 256)
+        assert any(not np.array_equal(out[False][k], out[True][k]) for k in ("hl", "hs"))      # two different kernels did run
+        for k in ("hl", "hs", "nl", "ns"):
+            assert np.isfinite(out[False][k]).all() and np.abs(out[False][k] - out[True][k]).max() <= 2e-5 * max(1.0, np.abs(out[True][k]).max()), (res, k)
+
+
 def test_validation_get_map_end_to_end(yf, models, golden, dev):
     """`Validation.get_mAP` (validate.py:27-122) with the model, the decode and the NMS on the GPU against the
     reference's own run on the same frames and synthetic targets (tests/golden/make_golden.py main_map).  The TP / FP

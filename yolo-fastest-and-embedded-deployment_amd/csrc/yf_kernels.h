@@ -52,13 +52,60 @@ template <typename T> __device__ __forceinline__ float ld1(const T* p) { return 
 template <> __device__ __forceinline__ float ld1<x3_t>(const x3_t* p) { return p->v; }
 template <typename T> __device__ __forceinline__ void st1(T* p, float v) { *p = (T)v; }
 template <> __device__ __forceinline__ void st1<x3_t>(x3_t* p, float v) { p->v = v; }
-// split four fp32 values into fp16 hi and lo halves: hi = rne(a), lo = rne(a - hi); a - hi is exact in fp32
+// split fp32 values into fp16 hi and lo halves: hi = rne(a), lo = rne(a - hi); a - hi is exact in fp32.
+// YF_X3_MIX (round 6): lo through v_fma_mixlo_f16 / v_fma_mixhi_f16 -- fma(hi as f16, -1.0, a) rounded once to f16 and written straight into a
+// half of the packed register: one instruction per value where the C form costs 2.5 (v_cvt_f32_f16, a packed subtraction per pair, a
+// v_cvt_pk_f16_f32 per pair).  The same bits: a - hi is exact, both forms round the same real number once (tools/mix_probe.hip: 2 M pairs,
+// normal and denormal results, bit-identical).  No builtin exists, so this is inline asm -- and the compiler's hazard recogniser does not see
+// inside it: an MFMA that reads the result in the next cycle got the STALE register (VALU write -> MFMA read needs wait states the compiler
+// inserts only for instructions it knows to be VALU; test_deep_stage_fusion_is_bitwise_neutral caught it as two fusion levels disagreeing).
+// Hence the trailing s_nop in the asm block: YF_X3_MIX_NOP wait states (2 = what the compiler places for its own VALU writes).
+// Measured with the s_nop in place (tools/x3_ab.sh, 640x512 batch 128 f16x3, two interleaved rounds): conv1_8+conv1_9+conv2_1 198-201 -> 190-192 us,
+// deconv5_1+conv4_1_1 46.0 -> 48.4 (its compiler-scheduled form was the tighter one), every other launch +-1 %: launch sum 1410 -> 1411-1415 us.
+// No gain for the pass: OFF.
+#ifndef YF_X3_MIX
+#define YF_X3_MIX 0
+#endif
+#ifndef YF_X3_MIX_NOP
+#define YF_X3_MIX_NOP 1    // s_nop operand: N + 1 wait states
+#endif
+#define YF_STR2(x) #x
+#define YF_STR(x) YF_STR2(x)
+__device__ __forceinline__ void split_f16x2(float a0, float a1, f16x2& hi, f16x2& lo)
+{
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    const f32x2v a = {a0, a1};
+    hi = __builtin_convertvector(a, f16x2);
+#if YF_X3_MIX
+    unsigned r, h = __builtin_bit_cast(unsigned, hi);
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "s_nop " YF_STR(YF_X3_MIX_NOP)
+        : "=&v"(r) : "v"(h), "v"(a0), "v"(a1));
+    lo = __builtin_bit_cast(f16x2, r);
+#else
+    lo = __builtin_convertvector(a - __builtin_convertvector(hi, f32x2v), f16x2);
+#endif
+}
 __device__ __forceinline__ void split_f16x4(float a0, float a1, float a2, float a3, f16x4& hi, f16x4& lo)
 {
     typedef float f32x4v __attribute__((ext_vector_type(4)));
     const f32x4v a = {a0, a1, a2, a3};
     hi = __builtin_convertvector(a, f16x4);
+#if YF_X3_MIX
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+    const u32x2v h = __builtin_bit_cast(u32x2v, hi);
+    unsigned r0, r1;
+    asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %3, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %2, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %3, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "s_nop " YF_STR(YF_X3_MIX_NOP)
+        : "=&v"(r0), "=&v"(r1) : "v"(h[0]), "v"(h[1]), "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+    lo = __builtin_bit_cast(f16x4, u32x2v{r0, r1});
+#else
     lo = __builtin_convertvector(a - __builtin_convertvector(hi, f32x4v), f16x4);
+#endif
 }
 #endif
 
