@@ -4,7 +4,7 @@
 # instructions, MFMA busy cycles, LDS), and the HBM byte counters (FETCH_SIZE, WRITE_SIZE in separate passes, as the guide prescribes).
 # tools/c2_report.py turns them into profiles/<tag>_configs2_binding_<dtype>.txt (tools/profiles_collect.sh).
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 COMMON="--steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-configs --no-train --no-extras --no-live-traffic --in-flight 1 --lanes 1 --res 512 --batch 128"
 for DT in f16x3 f16 f32; do

@@ -3,7 +3,7 @@
 # summaries under profiles/ (kernel stats per run, PMC rows of the yf:: kernels, pmc_traffic.json stamped with the source hash).
 set -e
 cd "$(dirname "$0")/.."
-TAG=${1:-r05}
+TAG=${1:-r06}
 python tools/pmc_traffic.py gpurun_out/ops.json gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv profiles/pmc_traffic.json gpurun_out/${TAG}_source_hash.txt 256 256 f32 | head -1
 for t in default lanes1 f16 f16x3 f16x3_512; do
   f=$(ls gpurun_out/prof_$t/*_kernel_stats.csv)

@@ -4,7 +4,7 @@
 #   guide prescribes) with the per-launch op list.  Copy the summaries into profiles/ afterwards (tools/pmc_traffic.py).
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r05}
+TAG=${1:-r06}
 python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.source_hash())" > $R/gpurun_out/${TAG}_source_hash.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_default -o d --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-configs --no-train --no-extras --no-live-traffic > $R/gpurun_out/prof_default.log 2>&1
