@@ -65,6 +65,62 @@ def test_bgr_frames_to_net_sized_gray_frames_bit_exact(gray_model, dev, size):
     assert np.array_equal(got, np.stack([cv.resize_linear_u8(f, (320, 256)) for f in gray]))
 
 
+def test_resize_tables_for_many_source_sizes_and_streams(gray_model, dev):
+    """ADVICE r5: cv::resize's coefficient tables are built by a kernel on the caller's stream into a pool of 32 slots per engine (no allocation
+    or host synchronisation per new size).  40 distinct source sizes -- more than the pool holds, so the oldest are evicted and rebuilt -- each
+    bit-exact against the oracle, interleaved with a size seen before; then one size used from two streams (the second waits for the first's build)."""
+    from oracle import cv_oracle as cv
+    m, io = gray_model
+    rng = np.random.default_rng(5)
+    first = None
+    for k in range(40):
+        h, w = 40 + 3 * k, 50 + 5 * k
+        g = rng.integers(0, 256, (1, h, w), dtype=np.uint8)
+        got = m.cv_preprocess_u8(torch.from_numpy(g).to(dev), io["input_shape"]).cpu().numpy()
+        assert np.array_equal(got[0], cv.resize_linear_u8(g[0], (320, 256))), (h, w)
+        if first is None:
+            first = (g, got)
+        elif k % 7 == 0:      # a size whose slot may have been evicted in between
+            assert np.array_equal(m.cv_preprocess_u8(torch.from_numpy(first[0]).to(dev), io["input_shape"]).cpu().numpy(), first[1])
+    g = rng.integers(0, 256, (2, 333, 217), dtype=np.uint8)
+    want = np.stack([cv.resize_linear_u8(f, (320, 256)) for f in g])
+    x = torch.from_numpy(g).to(dev)
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(s1):
+        a = m.cv_preprocess_u8(x, io["input_shape"])
+    with torch.cuda.stream(s2):
+        b = m.cv_preprocess_u8(x, io["input_shape"])
+    torch.cuda.synchronize(dev)
+    assert np.array_equal(a.cpu().numpy(), want) and np.array_equal(b.cpu().numpy(), want)
+
+
+def test_gray_coefficient_set_default_and_override(yf, gray_model, dev):
+    """the default BGR2GRAY coefficients are OpenCV 4.x's 15-bit set (what a current opencv-python gives the reference); `model.gray_bits`
+    / io_params["gray_bits"] select the 14-bit set of OpenCV 2.x / 3.x, and the choice reaches forward_bgr_u8, Detect_YOLO and BatchPipeline through the
+    model.  A frame on which the two sets differ (they do by at most 1 LSB) tells them apart."""
+    import copy
+    from oracle import cv_oracle as cv
+    m, io = gray_model
+    rng = np.random.default_rng(77)
+    bgr = rng.integers(0, 256, (2, 256, 320, 3), dtype=np.uint8)
+    g14, g15 = cv.cvt_bgr2gray(bgr, 14), cv.cvt_bgr2gray(bgr, 15)
+    assert (g14 != g15).any() and np.abs(g14.astype(np.int32) - g15.astype(np.int32)).max() == 1
+    x = torch.from_numpy(bgr).to(dev)
+    assert m.gray_bits == 15 and np.array_equal(m.cv_preprocess_u8(x, io["input_shape"]).cpu().numpy(), g15)
+    assert np.array_equal(cv.cv_pre_process_u8(bgr[0], io["input_shape"], [256, 320, 3]), g15[0])     # the oracle's default is the same set
+    try:
+        m.gray_bits = 14
+        assert np.array_equal(m.cv_preprocess_u8(x, io["input_shape"]).cpu().numpy(), g14)
+        a = m.forward_bgr_u8(x, io["input_shape"])
+        b = m.forward_u8(torch.from_numpy(g14).to(dev), io["input_shape"])
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    finally:
+        m.gray_bits = 15
+    io14 = copy.deepcopy(io); io14["gray_bits"] = 14
+    assert yf.YoloFastest(io14).gray_bits == 14 and yf.YoloFastest(io).gray_bits == 15
+
+
 @pytest.mark.parametrize("size", [(512, 640), (480, 640), (64, 96), (200, 333), (128, 192)])
 def test_three_channel_net_keeps_bgr_and_resizes_per_channel(yf, dev, golden, size):
     from oracle import cv_oracle as cv
