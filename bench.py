@@ -371,11 +371,11 @@ def pin_rank_to_cpus(local_rank, local_world, sysfs="/sys"):
     if local_world < 2 or len(allowed) < 2 * local_world:
         return None
     vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
-    slices, how = plan_rank_cpus(local_world, allowed, sysfs, vis)
-    mine = slices[local_rank]
-    try:
+    try:      # pinning is an optimisation: whatever goes wrong on a topology this was never run on, the benchmark runs unpinned
+        slices, how = plan_rank_cpus(local_world, allowed, sysfs, vis)
+        mine = slices[local_rank]
         os.sched_setaffinity(0, mine)
-    except OSError:
+    except Exception:
         return None
     return {"cpus": len(mine), "first": mine[0], "last": mine[-1], "how": how}
 

@@ -971,14 +971,14 @@ def test_post_process_randomised_against_c_oracle(yf, models, dev, res, post_spl
                 assert np.array_equal(raw["cls"][f, :n].cpu().numpy(), r["cls"]), (res, ci, f)
 
 
-def test_dense_post_process_per_class_workgroups_give_the_same_records(yf, models, dev):
+@pytest.mark.parametrize("N", [10, 64])      # 64 = BASELINE configs[4]'s per-GPU share (512 dense 640x512 frames over 8 GPUs)
+def test_dense_post_process_per_class_workgroups_give_the_same_records(yf, models, dev, N):
     """the per-(frame, class) form of the post-process (post_split_kernel; chosen automatically at kmax >= 256) against the
     one-workgroup-per-frame form on the same logits: identical counts, boxes, classes, sources, scores -- on dense synthetic fields (SURVEY.md
     8(d).5's recipe), with a capacity overflow (the count stays the true number, the first kmax records are stored), with the packed record
     block, inside yf_detect on two lanes (each lane's frames use their own scratch rows), and launched repeatedly (the ticket is reset)."""
     m, post, io = models[512]
     H, W = io["input_shape"][:2]
-    N = 10
     hl, hs = [], []
     for f in range(N):
         g = np.random.default_rng(500 + f)
@@ -1014,6 +1014,14 @@ def test_dense_post_process_per_class_workgroups_give_the_same_records(yf, model
         m.post_split = 0                     # auto: kmax 1024 takes the per-class form, kmax 100 the per-frame form
         for kmax in (1024, 100):
             same(refs[kmax], post.detect_raw(pred, kmax=kmax), kmax)
+        if N == 64:     # ... and a few frames of the full-size share against the reference's loop restated in C (oracle/post_oracle.c)
+            from oracle import post_oracle_c as poc
+            got = post.detect_raw(pred, kmax=1024)
+            for f in (0, 3, 31, 63):
+                r = poc.post_process(hl[f], hs[f], io["anchors"], io["input_shape"][:2])
+                n = r["count"]
+                assert int(got["counts"][f]) == n and np.array_equal(got["src"][f, :n].cpu().numpy(), r["src"])
+                assert np.array_equal(got["boxes"][f, :n].cpu().numpy(), r["box"]) and np.array_equal(got["cls"][f, :n].cpu().numpy(), r["cls"])
         # inside yf_detect, two lanes: low thresholds make the shipped model's own logits dense enough to matter
         rng = np.random.default_rng(9)
         x = _x(rng.integers(0, 256, (6, H, W), dtype=np.uint8), dev)
