@@ -879,20 +879,20 @@ def main():
                 rec["graph_replay"] = {"error": repr(ex)[:200]}
             return rec
 
-        # default mode (yf_set_split_sums 0, since round 6: a frame's bits never depend on the batch size), then the opt-in mode in which, at <= 9
-        # frames, the stride-32 chain and the small head split their channel sums over several workgroups (DESIGN.md section 4 "Small batches")
+        # default: at <= 9 frames the stride-32 chain and the small head run as split-sum launches (DESIGN.md section 4 "Small batches"); since round 6
+        # they carry the bits of the large-batch kernels, so a frame's logits never depend on the batch size.  Beside it: the one-workgroup launches.
         b1 = {"workload": "one 320x256 frame per call, model then post-process, host-synchronised after each (detect.py:146-171), 200 frames"}
         b1.update(batch1_record())
         with torch.no_grad():
-            h_stable = [t.clone() for t in mb(x1)]
-            h_big = model(saved["x"])
-            mb.split_sums = True
             h_split = [t.clone() for t in mb(x1)]
-        b1["bits_of_the_batch_256_pass"] = bool(torch.equal(h_stable[0], h_big[0][:1]) and torch.equal(h_stable[1], h_big[1][:1]))
-        b1["split_sums_mode"] = batch1_record()
-        b1["split_sums_mode"]["what"] = "yf_set_split_sums(1), opt in: two channel sums re-associated over several workgroups at <= 9 frames"
-        b1["max_abs_logit_diff_split_sums_vs_default"] = round(max(float((h_split[0] - h_stable[0]).abs().max()), float((h_split[1] - h_stable[1]).abs().max())), 7)
-        mb.split_sums = False
+            h_big = model(saved["x"])
+            mb.split_sums = False
+            h_one = [t.clone() for t in mb(x1)]
+        b1["bits_of_the_batch_256_pass"] = bool(torch.equal(h_split[0], h_big[0][:1]) and torch.equal(h_split[1], h_big[1][:1]))
+        b1["split_sums_off"] = batch1_record()
+        b1["split_sums_off"]["what"] = "yf_set_split_sums(0): the stride-32 chain and the small head as one workgroup per frame (the same bits)"
+        b1["split_sums_off"]["bits_of_the_default"] = bool(torch.equal(h_one[0], h_split[0]) and torch.equal(h_one[1], h_split[1]))
+        mb.split_sums = True
         extras["batch1"] = b1
         del mb, pb
         # (d) the N > 1 code path at one rank: a 1-rank RCCL group and the all-gather of every step's packed records -- its frames/s

@@ -336,12 +336,11 @@ int yf_profile_head_offsets(yf_handle h, int N, size_t *large_off, size_t *small
                                                       profiled (repeated-launch) pass itself to yf_forward's bits */
 int yf_num_launches(yf_handle h, int *out);       /* kernel launches one yf_forward issues            */
 int yf_set_chunk(yf_handle h, int frames);        /* frames per pass of the layer chain (0 = whole batch) */
-int yf_set_split_sums(yf_handle h, int on);       /* 1 (opt in; the default is 0 since round 6): at a handful of frames (<= 9, fp32 engines, 320x256 nets) the stride-32 residual chain and the
-                                                      small head split their channel sums over several workgroups and add the partial sums in a fixed
-                                                      chunk order (batch-1 latency: DESIGN.md section 4 "Small batches") -- the same numbers in another
-                                                      association than the large-batch launches, so a frame's last bits then depend on how many frames
-                                                      travel with it (held to 2e-4 on the logits and to identical detections on the goldens).  0 (default): never; every
-                                                      launch keeps one association at every batch size. */
+int yf_set_split_sums(yf_handle h, int on);       /* 1 (default): at a handful of frames (<= 9, fp32 engines, 320x256 nets) the stride-32 residual chain and the
+                                                      small head split their channel sums over several workgroups and add the partial sums in chunk order at
+                                                      launch boundaries (batch-1 latency: DESIGN.md section 4 "Small batches").  Since round 6 the large-batch
+                                                      kernels form the same per-chunk partial sums in the same order: THE SAME BITS either way, a frame's logits
+                                                      never depend on how many frames travel with it.  0: the one-workgroup launches at every batch size. */
 int yf_set_post_split(yf_handle h, int mode);      /* decode + NMS as one workgroup per frame AND class instead of one per frame (the reference runs NMS per class,
                                                       detect.py:158-169: independent work; a second small launch concatenates the classes in class order) --
                                                       the same records bit for bit, for DENSE frames: 64 frames of 1200 candidates use 192 CUs instead of 64

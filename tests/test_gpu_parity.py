@@ -77,15 +77,14 @@ def _x(u8, dev):
 @pytest.fixture
 def bit_stable(models):
     """The tests that assert BITWISE independence of a frame's result from the batch it travels in (chunking, position, fusion level, one
-    call or two) run the models in the mode that promises it: yf_set_split_sums(0) -- the DEFAULT since round 6 (this fixture only guards against a
-    test that left the opt-in mode on).  yf_set_split_sums(1) re-associates two channel sums at <= 9 frames (batch-1 latency) and is held to the goldens,
-    to 2e-4 of the default and to the default's detections in test_small_batch_plan_against_the_large_batch_plan_and_the_goldens /
-    test_split_sums_mode_detects_like_the_default_mode."""
+    call or two) once switched the few-frames split-sum launches off (round 5: they were another association of two channel sums).  Since round 6 those
+    launches carry the bits of the large-batch kernels (test_split_sum_launches_carry_the_bits_of_the_large_batch_plan), so the tests that use this fixture
+    run in the DEFAULT mode, split-sum launches on; the fixture only restores that default should a test have changed it."""
     for m, _, _ in models.values():
-        m.split_sums = False
+        m.split_sums = True
     yield
     for m, _, _ in models.values():
-        m.split_sums = False
+        m.split_sums = True
 
 
 _SD64 = {}
@@ -1516,8 +1515,7 @@ def test_profile_with_repeated_launches_changes_nothing(yf, golden, dev):
 @pytest.mark.parametrize("split", [False, True])
 def test_batch_1_against_the_reference_goldens_in_both_sum_modes(models, golden, dev, split):
     """VERDICT r5 item 7 / ADVICE r5: the reference's real calling pattern is ONE frame per call (detect.py:146-171).  Every golden frame goes
-    through alone -- the small-batch plan -- in the default mode (yf_set_split_sums(0): bits independent of the batch) and in the opt-in
-    split-sum mode: heads within the golden bounds of test_heads_match_reference_goldens, boxes / classes / survivor order those of
+    through alone -- the small-batch plan -- with the split-sum launches off and on (default; the same bits since round 6): heads within the golden bounds of test_heads_match_reference_goldens, boxes / classes / survivor order those of
     test_end_to_end_boxes_on_test_data."""
     for res in (256, 512):
         m, post, io = models[res]
@@ -1538,41 +1536,56 @@ def test_batch_1_against_the_reference_goldens_in_both_sum_modes(models, golden,
                 assert np.allclose([e[4] for e in L], g["adj_conf"][f, :n], atol=1e-4, rtol=0)
                 assert np.allclose([e[5] for e in L], g["adj_score"][f, :n], atol=1e-4, rtol=0)
         finally:
-            m.split_sums = False
+            m.split_sums = True
 
 
-def test_split_sums_mode_detects_like_the_default_mode(models, golden, dev):
-    """yf_set_split_sums(1) re-associates two channel sums at <= 9 frames (fp32, 320x256).  Its logits stay within 2e-4 of the default
-    mode's and -- what a caller sees -- its detections (boxes, classes, survivor order) are the default mode's at every batch size 1 .. 9, on
-    the golden frames and on the golden frames mixed with noise frames; above 9 frames the two modes are the same launches (same bits)."""
+def test_split_sum_launches_carry_the_bits_of_the_large_batch_plan(models, golden, dev):
+    """at <= 9 frames (fp32, 320x256) the stride-32 chain and the small head run as split-sum launches (chunk c of a channel sum on
+    its own workgroup, partial sums added in chunk order at the launch boundary).  The large-batch kernels form the same per-chunk partial sums in the
+    same order, so a frame's logits are THE SAME BITS at every batch size 1 .. 10, with the split-sum launches on (default) or off, alone or inside a
+    large batch -- and so are its detections.  Golden frames mixed with noise frames, every grouping."""
     m, post, io = models[256]
     g = golden("golden_256")
     rng = np.random.default_rng(23)
     u8 = np.concatenate([g["input_u8"], rng.integers(0, 256, (7,) + g["input_u8"].shape[1:], dtype=np.uint8)])
     order = rng.permutation(len(u8))
     x = _x(u8[order], dev)
-    worst = 0.0
+    with torch.no_grad():
+        big = [t.clone() for t in m(torch.cat([x] * 6)[:160].contiguous())]     # 160 frames: the whole-frame (chained) launches
     try:
         for n in range(1, 11):
             for f0 in range(0, len(u8) - n + 1, n):
                 xb = x[f0:f0 + n].contiguous()
                 with torch.no_grad():
-                    m.split_sums = False
-                    a = [t.clone() for t in m(xb)]
                     m.split_sums = True
+                    a = [t.clone() for t in m(xb)]
+                    m.split_sums = False
                     b = [t.clone() for t in m(xb)]
-                d = max(float((a[0] - b[0]).abs().max()), float((a[1] - b[1]).abs().max()))
-                worst = max(worst, d)
-                if n > 9:
-                    assert d == 0.0, (n, f0, d)
-                assert d <= 2e-4, (n, f0, d)
-                da, db = post.detect(a, with_src=True), post.detect(b, with_src=True)
-                for La, Lb in zip(da, db):
-                    assert [e[:4] + [e[6], e[7]] for e in La] == [e[:4] + [e[6], e[7]] for e in Lb], (n, f0)
-                    assert np.allclose([e[4:6] for e in La], [e[4:6] for e in Lb], atol=1e-4, rtol=0) if La else True
+                assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (n, f0)
+                assert torch.equal(a[0], big[0][f0:f0 + n]) and torch.equal(a[1], big[1][f0:f0 + n]), (n, f0)
     finally:
-        m.split_sums = False
-    assert 0.0 < worst <= 2e-4, worst     # the opt-in mode really is another association (else this test tests nothing)
+        m.split_sums = yf_default_split_sums(m)
+    # the launches really differ: fewer dispatches with the split sums off at one frame
+    import ctypes
+    counts = {}
+    for on in (True, False):
+        m.split_sums = on
+        e = m.engine(256, 320, 1, dev)
+        tot = 0
+        nl = ctypes.c_int()
+        e.lib.yf_num_launches(e.handle, ctypes.byref(nl))
+        for op in range(nl.value):
+            d = ctypes.c_int()
+            assert e.lib.yf_op_dispatches(e.handle, op, 1, ctypes.byref(d)) == 0
+            tot += d.value
+        counts[on] = tot
+    m.split_sums = yf_default_split_sums(m)
+    assert counts[True] > counts[False], counts
+
+
+def yf_default_split_sums(m):
+    import yolo_fastest_amd as yf
+    return yf.YoloFastest(yf.io_params_for(256)).split_sums
 
 
 @pytest.mark.parametrize("prec", ["f32", "f16x3", "f16"])
@@ -1581,8 +1594,8 @@ def test_small_batch_plan_against_the_large_batch_plan_and_the_goldens(yf, golde
     """at N x tiles < #CU every per-frame launch spreads a frame over several workgroups (DESIGN.md section 4 "Small
     batches").  Where that only regroups pixels -- everything but the two split-sum launches -- frames pushed through alone (N = 1), in twos
     and in eights carry the SAME BITS as the same frames inside a batch large enough for the whole-frame launches; the split-sum launches
-    (yf_set_split_sums(1), fp32, 320x256) stay within 2e-4 of them, and in the default mode (yf_set_split_sums(0)) the bits are the same there too.  Both modes are
-    held to the reference's goldens, and the one-frame detections are the reference's."""
+    (yf_set_split_sums(1), fp32, 320x256) carry the same bits as well since round 6 (the large-batch kernels sum per chunk like they do), with and without them.  Both
+    settings are held to the reference's goldens, and the one-frame detections are the reference's."""
     io = yf.io_params_for(res)
     m = yf.YoloFastest(io).to(dev).eval()
     m.load_state_dict(torch.load(WEIGHTS[res], map_location=dev))
@@ -1601,15 +1614,11 @@ def test_small_batch_plan_against_the_large_batch_plan_and_the_goldens(yf, golde
                 for split in (True, False):
                     m.split_sums = split
                     small = m(x[f0:f0 + n].contiguous())
-                    if split and res == 256 and prec == "f32":
-                        # opt-in mode: the stride-32 chain and the small head of an fp32 engine on 320x256 frames split their channel sums over
-                        # several workgroups at <= 9 frames (mres_esplit_kernel, mdw2_esplit_kernel): the same real numbers in another
-                        # association -- two fp32 evaluations, within the noise floor of this graph (the goldens below hold the path itself)
-                        for a_, b_ in zip(small, (big[0][f0:f0 + n], big[1][f0:f0 + n])):
-                            assert float((a_ - b_).abs().max()) <= 2e-4, (res, prec, n, f0, float((a_ - b_).abs().max()))
-                    else:      # every other regrouping keeps the bits; so does everything with yf_set_split_sums(0)
-                        assert torch.equal(small[0], big[0][f0:f0 + n]) and torch.equal(small[1], big[1][f0:f0 + n]), (res, prec, n, f0, split)
-        m.split_sums = False
+                    # every regrouping keeps the bits -- since round 6 also the split-sum launches (fp32, 320x256, <= 9 frames: the stride-32 chain
+                    # and the small head spread their channel sums over several workgroups, mres_esplit_kernel / mdw2_esplit_kernel): the
+                    # large-batch kernels form the same per-chunk partial sums in the same order (PSUM in yf_mres_kernels.hip / yf_mdw_kernels.hip)
+                    assert torch.equal(small[0], big[0][f0:f0 + n]) and torch.equal(small[1], big[1][f0:f0 + n]), (res, prec, n, f0, split)
+        m.split_sums = True
     if prec != "f16":
         _check_heads(big[0][:20], big[1][:20], g["head_large"], g["head_small"], g["head_large_f64"], g["head_small_f64"], res == 256)
         # ... and the small-batch launches themselves against the reference: the 20 golden frames four at a time, and one by one for the detections

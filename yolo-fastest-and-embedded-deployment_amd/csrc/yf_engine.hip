@@ -113,7 +113,7 @@ struct yf_engine {
     size_t esz() const { return dtype == yf::DT_F16 ? 2 : 4; }
     float* d_weights = nullptr;
     float* d_wmfma = nullptr;         // MFMA B fragments of the GEMM-worthy pointwise layers (fused plan)
-    int split_sums = 0;               // yf_set_split_sums: 0 (default since round 6) = never re-associate a sum by batch size (a frame's bits do not depend on how many frames travel with it)
+    int split_sums = 1;               // yf_set_split_sums: 1 (default) = the few-frames split-sum launches (same bits as the large-batch kernels since round 6); 0 = never re-associate a sum by batch size (a frame's bits do not depend on how many frames travel with it)
     float* d_esplit = nullptr;        // scratch of the few-frames forms of the stride-32 chain and the small head (mres_esplit_kernel, mdw2_esplit_kernel): partial sums
     static size_t esplit_lane_floats() { return yf::mres_esplit_scratch_floats() + yf::mdw2_esplit_scratch_floats(); }
     size_t n_floats = 0;

@@ -66,6 +66,8 @@ typedef float mdw_f32x2 __attribute__((ext_vector_type(2)));
 #ifndef YF_MDW_EPL_ADD
 #define YF_MDW_EPL_ADD 0
 #endif
+// the small head's 1x1 convs (128 output channels) in fp32: per-chunk partial sums (see mdw_kernel, PSUM)
+__host__ __device__ constexpr bool mdw_psum(int n, int wmode) { return n == 128 && wmode == WM_F32; }
 __host__ __device__ constexpr int mdw_epl(int th, int tw, int nwave)
 {
     const int nrp = (th + 4) * (tw + 4), mto = th * tw / 16, mtow = (mto + nwave - 1) / nwave;
@@ -241,6 +243,32 @@ __global__ void __launch_bounds__(NWAVE * 64) mdw_kernel(MdwArgs a)
                     for (int nt = 0; nt < NT; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(w2h[nt], dh, acc[i][nt], 0, 0, 0);
                 }
             }
+        } else if constexpr (mdw_psum(N, wmode_of<TT>())) {
+            // PSUM (round 6, the small head's two 1x1 convs in fp32): one partial sum per 16-channel chunk, added to the running total -- the
+            // association of mdw2_esplit_kernel (chunk c on its own workgroup), so both forms give the same bits (yf_mres_kernels.hip, PSUM)
+            f32x4 part[MTOW][NT];
+#pragma unroll
+            for (int i = 0; i < MTOW; ++i)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) part[i][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float w2f[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) w2f[nt] = wc[OFF_W + (j * NT + nt) * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < MTOW; ++i) {
+                    if (EVEN || wave + i * NWAVE < MTO) {
+                        const float dj = __int_as_float(max(__float_as_int(d2[i][j >> 1][j & 1]), 0));
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) part[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[nt], dj, part[i][nt], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MTOW; ++i)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[i][nt] += part[i][nt];
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -514,6 +542,10 @@ __device__ __forceinline__ void mdw_chunk_1tile(const float* E, int epl, const f
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(reinterpret_cast<const f16x4*>(wc + OFF_W)[nt * 64 + lane], dh, acc[nt], 0, 0, 0);
     } else {
+        constexpr bool PSUM = mdw_psum(N, WM_F32);      // per-chunk partial sums: mdw_kernel, PSUM
+        f32x4 part[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) part[nt] = PSUM ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[nt];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float w2f[NT];
@@ -521,8 +553,10 @@ __device__ __forceinline__ void mdw_chunk_1tile(const float* E, int epl, const f
             for (int nt = 0; nt < NT; ++nt) w2f[nt] = wc[OFF_W + (j * NT + nt) * 64 + lane];
             const float dj = __int_as_float(max(__float_as_int(d2[j >> 1][j & 1]), 0));   // ReLU of a non-NaN as one v_max_i32
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[nt], dj, acc[nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) part[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[nt], dj, part[nt], 0, 0, 0);
         }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = PSUM ? acc[nt] + part[nt] : part[nt];
     }
 }
 
@@ -736,7 +770,7 @@ bool mdw2_can_chain(int c1, int n1, int n2, int headn, int H, int W)
 //   phase 1: channels 16c .. 16c+15 of conv5_4 = sum of the six partials + bias (zero outside the frame: conv5_5's padding), dw5x5 + ReLU,
 //            partial conv5_6                                                                               N x 8 workgroups
 //   phase 2: conv5_6 = sum of the eight partials + bias, head conv chained through the accumulator layout, logits NCHW         N x 5 workgroups of one wave
-// Not the bits of mdw2_kernel (its 1x1 sums run chunk after chunk in one accumulator): the same numbers in another association.
+// The bits of mdw2_kernel / mdw_kernel since round 6: their 1x1 sums are formed per chunk and added in chunk order as well (PSUM).
 // fp32 engines, heads of up to 32 channels, frames of exactly 8x10.
 // ------------------------------------------------------------------------------------------------
 struct Mdw2EsplitArgs {

@@ -565,6 +565,12 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
     constexpr int NPH = ((CEXP + 15) / 16) / CPP;   // barrier phases per block
     static_assert(((CEXP + 15) / 16) % CPP == 0, "chunks per phase must divide the chunk count");
     constexpr int WFLOATS = (NCH * CHUNK + COUT + 3) & ~3;
+    // PSUM (round 6; fp32 stride-32 blocks): the projection's sum over the expanded channels is formed as (p0 + p1 + ... ) with one partial sum
+    // p_c per 16-channel chunk -- each chunk's k-steps start from a zero accumulator and its result is ADDED to the running total -- instead of
+    // one accumulator running through all chunks.  That is the association of mres_esplit_kernel (the few-frames form: chunk c on its own
+    // workgroup, the partial sums added in chunk order at the launch boundary), so that form and this one give the SAME BITS and a frame's
+    // logits do not depend on which of them its batch size selects.  Costs 12 v_add_f32 per chunk and consumer wave.
+    constexpr bool PSUM = !H16 && CIN == 48 && CEXP == 224 && COUT == 48;
 
     const int b = xcd_tile(blockIdx.x, gridDim.x);
     const int tx = b % a.tiles_x, ty = (b / a.tiles_x) % a.tiles_y, n = b / (a.tiles_x * a.tiles_y);
@@ -790,6 +796,18 @@ __global__ void __launch_bounds__((NWP + NWC) * 64) mres_pc_kernel(MresArgs a)
 #pragma unroll
                             for (int nt = 0; nt < NT2; ++nt)
                                 acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(w2h[nt], dh, acc[i][nt], 0, 0, 0);
+                        } else if constexpr (PSUM) {
+                            f32x4 part[NT2];
+#pragma unroll
+                            for (int nt = 0; nt < NT2; ++nt) part[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float dj = relu_bits(d[j]);
+#pragma unroll
+                                for (int nt = 0; nt < NT2; ++nt) part[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[j][nt], dj, part[nt], 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int nt = 0; nt < NT2; ++nt) acc[i][nt] += part[nt];
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
@@ -958,8 +976,8 @@ size_t mres_post_packed_floats(int cout, int postn) { return (size_t)mres_ksteps
 // its input X_k is), then computes its own chunk of block k.  nblk + 1 launches of ~5 us instead of one of 64; no grid barrier, nothing
 // spins, every launch only reads what earlier launches wrote and writes the other half of two alternating buffers (repeatable).
 // The last launch forms the chain's result and applies the trailing 1x1 conv (conv5_2: n-tile g on workgroup g) or stores the result.
-// NOT the bits of the chained launch: a block's 224-term sums are associated per chunk here ((c0 + c1 + ... + c13) + bias + x) and in k
-// order there -- two fp32 evaluations of the same real number; the tests hold this path to the reference's goldens, not to the other plan.
+// THE BITS of the chained launch since round 6: a block's 224-term sums are associated per chunk here ((c0 + c1 + ... + c13) + bias + x), and
+// mres_pc_kernel forms the same per-chunk partial sums and adds them in the same order (PSUM); tests/test_gpu_parity.py holds the two forms bitwise.
 // fp32 engines, frames of exactly TH x TW pixels.
 // ------------------------------------------------------------------------------------------------
 struct EsplitArgs {

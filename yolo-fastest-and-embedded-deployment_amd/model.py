@@ -52,7 +52,7 @@ class _Engine:
         self.H, self.W, self.max_batch, self.device_index = H, W, max_batch, device_index
         self._ws = None
         self.chunk, self.lanes, self.branches = 0, 2, 1     # the C side's defaults (yf_engine: chunk 0, lanes 2, branches on)
-        self.split_sums = 0
+        self.split_sums = 1
         self.post_split = 0
 
     def workspace(self, N, device):
@@ -130,11 +130,11 @@ class YoloFastest(nn.Module):
         self.fusion = DEFAULT_FUSION
         self.lanes = 2   # concurrent streams over chunks of the batch (chunk 0 = one chunk per lane); see yf_set_lanes
         self.branches = 1  # 1: the small head's launches run on a side stream beside the large head's; see yf_set_branches
-        # False (default since round 6): a frame's bits never depend on the batch it travels in.  True (opt in, batch-1 latency 0.33 -> 0.29 ms):
-        # at <= 9 frames the stride-32 chain and the small head split their channel sums over several workgroups -- the same numbers in another
-        # association than at larger batches (<= 2e-4 on the logits; a score sitting exactly at conf_thres could then flip with the batch size)
+        # True (default): at <= 9 frames the stride-32 chain and the small head split their channel sums over several workgroups (batch-1 latency
+        # 0.33 -> 0.29 ms).  Since round 6 the large-batch kernels form the same per-chunk partial sums in the same order, so a frame's bits never
+        # depend on the batch it travels in EITHER WAY; False only selects the one-workgroup launches (A/B, profiling)
         # (yf_set_split_sums; DESIGN.md section 4 "Small batches").
-        self.split_sums = False
+        self.split_sums = True
         # cv2.cvtColor(BGR2GRAY)'s fixed-point coefficient set on the device (yf_cv_preprocess_u8): 15 = OpenCV 4.x's RGB2Gray<uchar> (9798 / 19235 /
         # 3735, shift 15: what a current `pip install opencv-python` gives the reference), 14 = OpenCV 2.x / 3.x (4899 / 9617 / 1868, shift 14).  They
         # differ by at most 1 LSB on colour frames; gray frames (the bundled test_data) come out identical.  io_params["gray_bits"] overrides.
