@@ -93,7 +93,16 @@ __global__ void __launch_bounds__(256) cv_pre_kernel(CvArgs a)
 // rows they read are fetched ONCE with coalesced 4-byte loads -- BGR pixels converted to gray on the way, so that LDS holds the image the
 // resize works on (detect.py:110-116: cvtColor first, then resize) -- and the taps come from LDS.  Needs 4-byte aligned source rows
 // ((sw * sc) % 4 == 0) and rows that fit the staging buffer; the launcher falls back to the direct kernel otherwise.
-constexpr int CV_TR = 4;                 // destination rows per workgroup
+// A/B builds (tools/cv_ab.sh, round 6, us per 256 BGR frames of 480x640 / 128 of 720x1280): TR 4 (default) 73-76 / 70; TR 8 71 / 82; TR 2 90 / 75; loads in
+// flight 3 / 12: 71.5 / 85.  A persistent, software-pipelined form (the next row group's loads requested before the current one is interpolated): 88 / 95 --
+// slower (more live registers, a second barrier per group); the one-group-per-workgroup form with seven resident workgroups per CU stays.
+#ifndef YF_CV_TR
+#define YF_CV_TR 4
+#endif
+#ifndef YF_CV_UNR
+#define YF_CV_UNR 6
+#endif
+constexpr int CV_TR = YF_CV_TR;          // destination rows per workgroup
 
 template <int GRAY, int MODE, int DC>
 __global__ void __launch_bounds__(256) cv_pre_lds_kernel(CvArgs a, int pitch)
@@ -111,7 +120,7 @@ __global__ void __launch_bounds__(256) cv_pre_lds_kernel(CvArgs a, int pitch)
     int4* const xl = reinterpret_cast<int4*>(cv_smem + 2 * CV_TR * pitch);   // the column table, staged for the CV_TR rows that share it
     if constexpr (MODE == 2)
         for (int i = threadIdx.x; i < a.dw; i += 256) xl[i] = a.xtab[i];
-    constexpr int CV_UNR = 6, NW = GRAY != 0 ? 3 : DC;
+    constexpr int CV_UNR = YF_CV_UNR, NW = GRAY != 0 ? 3 : DC;
 #pragma unroll 1
     for (int base = threadIdx.x; base < total; base += 256 * CV_UNR) {
         uint32_t w[CV_UNR][NW];
