@@ -285,12 +285,12 @@ def train_records(dev, pmc):
     return out
 
 
-def self_launch(n_gpus):
+def self_launch(n_gpus, share_gpu=False):
     """--gpus N > 1 without a launcher: start the N ranks as a CHILD process tree (never exec: this process must not have
     touched the GPU, and it has not -- device_count() does not initialise it) and relay its output."""
     import torch
     have = torch.cuda.device_count()
-    if have < n_gpus:
+    if have < n_gpus and not (share_gpu and have >= 1):
         sys.stderr.write(f"bench.py: --gpus {n_gpus} but only {have} GPU(s) are visible on this host; refusing to run a smaller "
                          f"job under that label\n")
         return 2
@@ -467,6 +467,10 @@ def main():
     ap.add_argument("--kmax", type=int, default=64)
     ap.add_argument("--exchange-at-1", action="store_true",
                     help="rehearsal of the N > 1 code path on one GPU: a 1-rank RCCL group and the all-gather of every step's records")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="REHEARSAL of the N > 1 code path where only one GPU exists: the N ranks all use GPU 0 and exchange their records over gloo "
+                         "(launcher, rank / world checks, per-rank seeds, CPU pinning, barriers, max-over-ranks timing, gather, rank 0's line) -- "
+                         "never a performance figure: the line says so (`rehearsal`)")
     ap.add_argument("--pin-cpus", type=int, nargs=2, default=None, metavar=("RANK", "OF"),
                     help="rehearse the multi-GPU CPU pinning on one GPU: pin this process like local rank RANK of OF ranks")
     ap.add_argument("--regions", type=int, default=5,
@@ -497,7 +501,7 @@ def main():
 
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
-        sys.exit(self_launch(args.gpus))
+        sys.exit(self_launch(args.gpus, args.share_gpu))
     world = int(env_world) if env_world is not None else 1
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; "
@@ -540,11 +544,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if torch.cuda.device_count() < (world if world > 1 else 1):
+    if torch.cuda.device_count() < (world if world > 1 and not args.share_gpu else 1):
         raise SystemExit(f"bench.py: {world} rank(s) but only {torch.cuda.device_count()} GPU(s) visible")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP extension is the only implementation (no CPU fallback)")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if args.share_gpu else local_rank)
     torch.cuda.set_device(dev)
     multi = world > 1 or args.exchange_at_1
     if multi:
@@ -553,7 +557,10 @@ def main():
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.share_gpu:
+            dist.init_process_group("gloo")       # (RCCL refuses two ranks on one GPU; gloo carries GPU tensors through the host)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: RCCL world size {dist.get_world_size()} != --gpus {args.gpus}")
 
@@ -1115,7 +1122,8 @@ def main():
                                    + (", dense synthetic head logits (SURVEY.md 8(d) config 5)" if args.dense else ""),
                        "global_batch": n_total, "weights": wname, "kmax": args.kmax, "chunk": args.chunk, "in_flight": in_flight, "lanes": lanes, "branches": branches,
                        "world_size": world, "cpu_affinity": affinity,
-                       "parallelism": f"dp{world} (frames sharded, one RCCL all-gather of box records)" if world > 1 else "single GPU",
+                       "parallelism": (f"dp{world} REHEARSAL: {world} ranks share ONE GPU, records exchanged over gloo -- not a performance figure" if args.share_gpu and world > 1
+                                       else f"dp{world} (frames sharded, one RCCL all-gather of box records)" if world > 1 else "single GPU"),
                        "survivors_per_frame_mean": round(float(np.clip(counts, 0, None).mean()), 3)},
             "roofline": roofline,
             # the whole forward pass (all launches)

@@ -1435,6 +1435,37 @@ def test_two_gpu_bench_gathers_the_single_gpu_records(tmp_path):
         assert np.array_equal(a[k][valid], b[k][valid]), k
 
 
+def test_two_rank_bench_rehearsal_on_one_gpu(tmp_path):
+    """Round 6: the N > 1 path of bench.py has never met a multi-GPU node (SCALE_r01..r05: skipped).  `--share-gpu` runs it with two REAL ranks on the one
+    GPU there is -- bench.py's own launcher (torch.distributed.run, 127.0.0.1), WORLD_SIZE / rank checks, per-rank CPU slices, per-rank frames, barriers and
+    max-over-ranks timing, the asynchronous exchange of every step's packed records (gloo here, RCCL refuses two ranks on one GPU), rank 0's line: the
+    gathered records of the 40 frames are exactly what one process computes for them, in frame order."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    common = ["--steps", "3", "--warmup", "1", "--frames", "fixtures", "--no-cpu-baseline", "--no-variants", "--no-configs", "--no-train", "--no-live-traffic"]
+    two, one = str(tmp_path / "two.npz"), str(tmp_path / "one.npz")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--batch", "20", "--dump-records", two] + common,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    j = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["config"]["world_size"] == 2 and j["config"]["global_batch"] == 40 and "REHEARSAL" in j["config"]["parallelism"]
+    assert j["scaling"] == "weak" and j["value"] > 0 and j["config"]["cpu_affinity"] is not None
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "40", "--dump-records", one] + common,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = np.load(two), np.load(one)
+    assert int(a["world_size"]) == 2 and int(b["world_size"]) == 1
+    assert np.array_equal(a["counts"], b["counts"]) and a["counts"].shape == (40,) and a["counts"].sum() > 40
+    valid = np.arange(a["cls"].shape[1])[None, :] < a["counts"][:, None]
+    for k in ("boxes", "scores", "cls", "src"):
+        assert np.array_equal(a[k][valid], b[k][valid]), k
+
+
 def test_training_loss_matches_the_reference(yf, models, golden, dev):
     """SURVEY.md 8(f).4, first slice: `YOLOLossV3(...)(input, targets)` (loss/yolo_loss.py:48-97, get_target :144-196) and the
     gradient `loss.backward()` leaves in the head tensor (train.py:131), on the GPU, against the reference's own run
